@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- m6A calls/sec of the hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (strand resolve + window scan + record ordering + MLP classifier, then the
+D2H copy of the flush records) over one batch of synthetic eventalign rows that is already resident in HBM.
+Workload at N=1: BASELINE.json configs[2] -- synthetic 10^8 events, -m GATC, NN classifier (r95 two-base MLP),
+skip_thresh 0.  N>1: every rank scans its own 10^8-row shard of reads (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the window-scan kernel
+(algorithmic bytes = 17 B/event row + 64 B/emitted call) and `cpu_baseline` (the C oracle,
+single host core, same workload sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod      # plumbing only: rendezvous, barrier, max-over-ranks
+        dist_mod.init_process_group(backend='gloo', init_method='env://')
+        dist = dist_mod
+    return rank, world, local, dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--events', type=float, default=1e8, help='event rows per GPU')
+    ap.add_argument('--motif', default='GATC')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
+    args = ap.parse_args()
+
+    rank, world, local, dist = dist_setup(args.gpus)
+    from mcaller_amd import synth, _lib
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    from tests import helpers as H
+
+    n_rows = int(args.events)
+    t_gen = time.time()
+    codes = synth.genome()
+    ref = synth.SynthRef(codes, motif=args.motif)
+    table, qual = synth.make_table(n_rows, seed=1000 + rank, codes=codes)
+    t_gen = time.time() - t_gen
+    modelset = H.load_modelset('r95')
+    _, weights, _, soc = submodel_setup(modelset, 'A')
+
+    dev = Device(local)
+    dev.set_reference(ref.device_arrays())
+    t_up = time.time()
+    dev.upload_table(table)
+    t_up = time.time() - t_up
+    dev.set_read_quality(qual)
+    dev.set_mlp(weights, soc)
+
+    def step():
+        dev.run(6, 0, 0.0, tail_contig=-1, score=True)
+        return dev.fetch()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rec = step()
+    k1_ms, tot_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+        tm = dev.times_ms()
+        k1_ms.append(tm['window_scan'])
+        tot_ms.append(tm)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    info = rec.info[:rec.n]
+    n_calls = int(((info & _lib.I_TOO_MANY) == 0).sum())
+
+    calls_total, elapsed_max = n_calls, elapsed
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([n_calls], dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        elapsed_max, calls_total = float(t[0]), int(c[0])
+
+    if rank == 0:
+        k1 = float(np.mean(k1_ms))
+        alg_bytes = 17.0 * n_rows + 64.0 * n_calls
+        achieved = alg_bytes / (k1 * 1e-3) / 1e9
+        out = {
+            'metric': 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)',
+            'value': calls_total * args.steps / elapsed_max,
+            'unit': 'calls/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed_max / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
+                                   'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
+                       'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
+                       'events_per_s': n_rows * world * args.steps / elapsed_max,
+                       'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
+                       'h2d_table_s': t_up, 'generate_s': t_gen},
+            'roofline': {'bound': 'hbm', 'kernel': 'k1_scan', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes': alg_bytes, 'kernel_ms': k1},
+        }
+        if not args.no_cpu_baseline:
+            n_cpu = min(n_rows, int(args.cpu_events))
+            sub = table if n_cpu == n_rows else table.slice_segments(
+                0, int(np.searchsorted(table.seg_row_begin, n_cpu, side='left')))
+            arrays = ref.device_arrays()
+            t1 = time.perf_counter()
+            orc = H.oracle_records(sub, arrays, qual, 6, 0, 0.0)
+            H.oracle_score(orc, sub, qual, weights, soc, 6)
+            dt = time.perf_counter() - t1
+            oc = int(((orc.info[:orc.n] & _lib.I_TOO_MANY) == 0).sum())
+            out['cpu_baseline'] = {'value': oc / dt, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
+                                   'sample': '%d event rows of the same workload (C oracle: literal window machine + '
+                                             'MLP, one host core, %.2f s)' % (sub.n_rows, dt),
+                                   'events_per_s': sub.n_rows / dt}
+        print(json.dumps(out))
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

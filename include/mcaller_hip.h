@@ -1,0 +1,143 @@
+/*
+ * mcaller_hip.h -- C ABI of libmcaller_hip.so, the MI355X-native replacement for the hot path of
+ * al-mcintyre/mCaller:
+ *
+ *   extract_contexts.py::extract_features   (reference extract_contexts.py:110-303)
+ *     - the per-row 6-slot window machine over nanopolish eventalign rows   (:147-291)
+ *     - model[key].predict_proba([diffs]) per observation                    (:199)
+ *
+ * The reference has no FFI: the path sits behind the Python call boundary
+ * `extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile,
+ * classifier, startline, endline, train, pos_label, base, motif, positions_list)`
+ * (extract_contexts.py:110, called at mCaller.py:53,58,60).  A maintainer of the reference binds the
+ * entry points below with ctypes; mcaller_amd/extract_contexts.py is that
+ * binding, with the reference's signature.
+ *
+ * Conventions: every function returns 0 on success, <0 on error (text via mc_last_error(), thread
+ * local).  Plain pointers and sizes only; no exceptions or callbacks cross the ABI.  Host buffers are
+ * caller-allocated and never retained after the call returns.  One mc_ctx per GPU; calls on a ctx
+ * are serialised by the caller (one process per GPU).
+ */
+#ifndef MCALLER_HIP_H
+#define MCALLER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_MAX_K 8            /* -n/--num_variables supported: 1..8 (reference default 6, mCaller.py:131) */
+
+/* ---- columnar event table (one entry per eventalign row the reference's loop would process) ---- */
+/* flags column bits */
+#define MC_F_KMER_EQ    0x01  /* reference_kmer (col 3) == model_kmer (col 10)      extract_contexts.py:169 */
+#define MC_F_MODEL_N    0x02  /* model_kmer == "NNNNNN"                            extract_contexts.py:167 */
+#define MC_F_SEG_START  0x04  /* first row of a (read name, contig) segment                          */
+#define MC_F_NAME_START 0x08  /* first row of a name block (maximal run of rows with one read name)  */
+
+typedef struct mc_table_view {
+    int64_t n_rows;
+    const int32_t *pos;        /* col 2: 0-based k-mer start                                  :175 */
+    const int32_t *event_e4;   /* col 7: event_level_mean in units of 1e-4 pA                 :286 */
+    const int32_t *model_e4;   /* col 11: model_mean in units of 1e-4 pA                      :286 */
+    const int32_t *event_idx;  /* col 6                                                   :162,169 */
+    const uint8_t *flags;      /* MC_F_*                                                           */
+    int32_t n_seg;
+    const int64_t *seg_row_begin; /* [n_seg+1] */
+    const int32_t *seg_read;      /* [n_seg] read id: equal names <=> equal ids               :161 */
+    const int32_t *seg_contig;    /* [n_seg] contig id (index into the reference set)         :154 */
+    int32_t n_reads;
+} mc_table_view;
+
+/* ---- marked reference: what find_and_methylate builds (extract_contexts.py:60-81), as bitmasks ---- */
+typedef struct mc_ref_view {
+    int32_t n_contigs;
+    const int64_t *contig_len;    /* [n_contigs] */
+    const int64_t *seq_off;       /* [n_contigs] byte offset of the contig in seq                    */
+    const uint8_t *seq;           /* upper-cased bases, ASCII                                    :80 */
+    const int64_t *word_off;      /* [n_contigs] u32-word offset of the contig in mbits_*            */
+    const uint32_t *mbits_fwd;    /* bit p set <=> meth_fwd[p]=='M'; >= 2 zero words of padding  :62 */
+    const uint32_t *mbits_rev;    /* bit p set <=> meth_rev[p]=='M'                              :63 */
+    int64_t n_seq_bytes, n_words;
+} mc_ref_view;
+
+/* ---- flush records: one per window the machine closes (extract_contexts.py:179-239) ---- */
+/* info bits */
+#define MC_I_EMPTY_MASK   0x000000FFu /* bit i: feature i (final order) came from an empty slot -> literal 0 :186 */
+#define MC_I_REV          0x00000100u /* strand '-'                                               :216 */
+#define MC_I_TOO_MANY     0x00000200u /* num_skips > skip_thresh: counted, not emitted            :239 */
+#define MC_I_MULTI        0x00000400u /* the closing row shifted the window with kmer[0]!='M'     :247 */
+#define MC_I_EDGE         0x00000800u /* context slice leaves the contig: host decides (Python slicing) */
+#define MC_I_NEXT_SHIFT   16          /* bits 16..23: context[k] (ASCII) -> sub-model key   :197 */
+
+typedef struct mc_calls_view {
+    int64_t capacity;
+    double  *feats;      /* [capacity*k] slot means in the order the reference prints them   :186-188 */
+    int32_t *site_pos;   /* mpos                                                                 :216 */
+    int32_t *site_seg;   /* segment of the window's last site row -> read name, site contig      :216 */
+    int64_t *close_row;  /* row that closed the window (its contig is the chrom column, R8); n_rows if
+                            the closing row lies beyond this table (see tail_contig)             :216 */
+    uint32_t *info;      /* MC_I_* */
+    double  *prob;       /* p(m6A) from the MLP/forest; NaN where not scored                     :199 */
+} mc_calls_view;
+
+const char *mc_last_error(void);
+const char *mc_version(void);
+
+/* ===== native eventalign parser (host), replaces the line.split() ingest extract_contexts.py:140-152 ===== */
+typedef struct mc_parsed mc_parsed;
+/* Parses the byte range the reference's loop would consume for (startline, endline):
+ * seek(max(startline-500,0)), readlines(8000000) batches while linepos <= endline-500 (:141-146).
+ * Rows with < 12 tokens are dropped (:149-152); rows whose contig is not in contig_names are dropped
+ * and recorded (the "could not find sequence" path :156-160).  n_threads <= 0: all cores. */
+int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
+                        const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
+                        mc_parsed **out);
+int mc_parsed_view(const mc_parsed *p, mc_table_view *out);
+const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id);
+int64_t mc_parsed_n_unknown(const mc_parsed *p);                 /* rows dropped for an unknown contig */
+const char *mc_parsed_unknown_name(const mc_parsed *p, int64_t i); /* contig text of the i-th such row */
+void mc_parsed_free(mc_parsed *p);
+
+/* ===== device context ===== */
+typedef struct mc_ctx mc_ctx;
+int mc_ctx_create(int device, mc_ctx **out);
+void mc_ctx_destroy(mc_ctx *ctx);
+int mc_ctx_set_reference(mc_ctx *ctx, const mc_ref_view *host_ref);          /* H2D, replaces :154-160 */
+int mc_ctx_upload_table(mc_ctx *ctx, const mc_table_view *host_table);        /* H2D of the columns     */
+int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/* read2qual, :163-166   */
+/* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model;
+ * submodel_of_char[256]: context[k] (ASCII) -> sub-model index, 255 = KeyError path (:197,:218). */
+int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden,
+                   const double *W1, const double *b1, const double *W2, const double *b2,
+                   const uint8_t *submodel_of_char);
+
+typedef struct mc_params {
+    int32_t k;             /* -n   (:110 `k`)            */
+    int32_t skip_thresh;   /* -s   (:183,242)            */
+    double  qual_thresh;   /* -q   (:167)                */
+    int32_t tail_contig;   /* contig id of the first unfiltered row AFTER this table (next shard), or -1
+                              if none: the last window is then lost, as at EOF (R6)                  */
+    int32_t score;         /* 1: run the classifier (predict mode); 0: features only (--train)     */
+    int32_t entry_read;    /* read id `last_read` holds when the table starts (-1: none), and      */
+    int32_t entry_first_idx; /* the matching first_read_ind (:161-162); shards > 0 of one file      */
+} mc_params;
+
+/* The hot path on the GPU: strand resolve + window scan + classifier.  Leaves the flush records on the
+ * device, in file order; *n_records = how many. */
+int mc_extract_features(mc_ctx *ctx, const mc_params *prm, int64_t *n_records);
+/* D2H of the records of the last mc_extract_features (host buffers, capacity >= n_records). */
+int mc_fetch_records(mc_ctx *ctx, const mc_calls_view *host_out);
+/* Kernel times of the last mc_extract_features, from hipEvents on the ctx stream, in ms:
+ * [0] strand resolve, [1] window scan (K1), [2] record ordering, [3] classifier (K2), [4] total. */
+int mc_last_times_ms(mc_ctx *ctx, float *out5);
+int mc_ctx_sync(mc_ctx *ctx);
+
+/* Batched classifier alone (B2, extract_contexts.py:199): X[n*n_in] -> p[n]; host buffers. */
+int mc_mlp_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""ctypes binding of libmcaller_hip.so (C ABI: include/mcaller_hip.h).
+
+The library holds the native eventalign parser and the HIP kernels.  There is no fallback: if the
+shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmcaller_hip.so')
+
+MC_MAX_K = 8
+F_KMER_EQ, F_MODEL_N, F_SEG_START, F_NAME_START = 1, 2, 4, 8
+I_EMPTY_MASK, I_REV, I_TOO_MANY, I_MULTI, I_EDGE, I_NEXT_SHIFT = 0xFF, 0x100, 0x200, 0x400, 0x800, 16
+
+
+class McError(RuntimeError):
+    pass
+
+
+class TableView(C.Structure):
+    _fields_ = [('n_rows', C.c_int64),
+                ('pos', C.c_void_p), ('event_e4', C.c_void_p), ('model_e4', C.c_void_p),
+                ('event_idx', C.c_void_p), ('flags', C.c_void_p),
+                ('n_seg', C.c_int32),
+                ('seg_row_begin', C.c_void_p), ('seg_read', C.c_void_p), ('seg_contig', C.c_void_p),
+                ('n_reads', C.c_int32)]
+
+
+class RefView(C.Structure):
+    _fields_ = [('n_contigs', C.c_int32),
+                ('contig_len', C.c_void_p), ('seq_off', C.c_void_p), ('seq', C.c_void_p),
+                ('word_off', C.c_void_p), ('mbits_fwd', C.c_void_p), ('mbits_rev', C.c_void_p),
+                ('n_seq_bytes', C.c_int64), ('n_words', C.c_int64)]
+
+
+class CallsView(C.Structure):
+    _fields_ = [('capacity', C.c_int64),
+                ('feats', C.c_void_p), ('site_pos', C.c_void_p), ('site_seg', C.c_void_p),
+                ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [('k', C.c_int32), ('skip_thresh', C.c_int32), ('qual_thresh', C.c_double),
+                ('tail_contig', C.c_int32), ('score', C.c_int32),
+                ('entry_read', C.c_int32), ('entry_first_idx', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmcaller_hip.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mc_last_error.restype = C.c_char_p
+        L.mc_version.restype = C.c_char_p
+        L.mc_parse_eventalign.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.c_int32,
+                                          C.c_int32, C.POINTER(C.c_void_p)]
+        L.mc_parsed_view.argtypes = [C.c_void_p, C.POINTER(TableView)]
+        L.mc_parsed_read_name.argtypes = [C.c_void_p, C.c_int32]
+        L.mc_parsed_read_name.restype = C.c_char_p
+        L.mc_parsed_n_unknown.argtypes = [C.c_void_p]
+        L.mc_parsed_n_unknown.restype = C.c_int64
+        L.mc_parsed_unknown_name.argtypes = [C.c_void_p, C.c_int64]
+        L.mc_parsed_unknown_name.restype = C.c_char_p
+        L.mc_parsed_free.argtypes = [C.c_void_p]
+        L.mc_parsed_free.restype = None
+        L.mc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mc_ctx_destroy.argtypes = [C.c_void_p]
+        L.mc_ctx_destroy.restype = None
+        L.mc_ctx_set_reference.argtypes = [C.c_void_p, C.POINTER(RefView)]
+        L.mc_ctx_upload_table.argtypes = [C.c_void_p, C.POINTER(TableView)]
+        L.mc_ctx_set_read_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.mc_ctx_set_mlp.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mc_extract_features.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
+        L.mc_fetch_records.argtypes = [C.c_void_p, C.POINTER(CallsView)]
+        L.mc_last_times_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.mc_ctx_sync.argtypes = [C.c_void_p]
+        L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise McError(lib().mc_last_error().decode('utf-8', 'replace') or 'libmcaller_hip error %d' % rc)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _from_ptr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Table(object):
+    """Columnar event table on the host: numpy arrays + a TableView over them."""
+
+    def __init__(self, pos, event_e4, model_e4, event_idx, flags, seg_row_begin, seg_read, seg_contig, n_reads,
+                 read_names=None, unknown=(), owner=None):
+        self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self.event_e4 = np.ascontiguousarray(event_e4, dtype=np.int32)
+        self.model_e4 = np.ascontiguousarray(model_e4, dtype=np.int32)
+        self.event_idx = np.ascontiguousarray(event_idx, dtype=np.int32)
+        self.flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self.seg_row_begin = np.ascontiguousarray(seg_row_begin, dtype=np.int64)
+        self.seg_read = np.ascontiguousarray(seg_read, dtype=np.int32)
+        self.seg_contig = np.ascontiguousarray(seg_contig, dtype=np.int32)
+        self.n_reads = int(n_reads)
+        self.read_names = read_names
+        self.unknown = list(unknown)
+        self._owner = owner
+        self.n_rows = len(self.pos)
+        self.n_seg = len(self.seg_read)
+
+    def view(self):
+        v = TableView()
+        v.n_rows = self.n_rows
+        v.pos, v.event_e4, v.model_e4 = _ptr(self.pos), _ptr(self.event_e4), _ptr(self.model_e4)
+        v.event_idx, v.flags = _ptr(self.event_idx), _ptr(self.flags)
+        v.n_seg = self.n_seg
+        v.seg_row_begin, v.seg_read, v.seg_contig = _ptr(self.seg_row_begin), _ptr(self.seg_read), _ptr(self.seg_contig)
+        v.n_reads = self.n_reads
+        return v
+
+    def slice_segments(self, s0, s1):
+        """Sub-table of segments [s0, s1) (a shard); row indices restart at 0, read ids are kept."""
+        r0, r1 = int(self.seg_row_begin[s0]), int(self.seg_row_begin[s1])
+        return Table(self.pos[r0:r1], self.event_e4[r0:r1], self.model_e4[r0:r1], self.event_idx[r0:r1],
+                     self.flags[r0:r1], self.seg_row_begin[s0:s1 + 1] - r0, self.seg_read[s0:s1],
+                     self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names)
+
+
+def parse_eventalign(path, startline, endline, contig_names, n_threads=0):
+    """Native parser -> Table (copies out of the library's buffers)."""
+    L = lib()
+    arr = (C.c_char_p * max(1, len(contig_names)))()
+    for i, n in enumerate(contig_names):
+        arr[i] = n.encode('utf-8')
+    handle = C.c_void_p()
+    check(L.mc_parse_eventalign(path.encode('utf-8'), int(startline), int(endline), arr, len(contig_names),
+                                int(n_threads), C.byref(handle)))
+    try:
+        v = TableView()
+        check(L.mc_parsed_view(handle, C.byref(v)))
+        n, ns = v.n_rows, v.n_seg
+        names = [L.mc_parsed_read_name(handle, i).decode('utf-8', 'surrogateescape') for i in range(v.n_reads)]
+        unknown = [L.mc_parsed_unknown_name(handle, i).decode('utf-8', 'surrogateescape')
+                   for i in range(L.mc_parsed_n_unknown(handle))]
+        t = Table(_from_ptr(v.pos, n, np.int32).copy(), _from_ptr(v.event_e4, n, np.int32).copy(),
+                  _from_ptr(v.model_e4, n, np.int32).copy(), _from_ptr(v.event_idx, n, np.int32).copy(),
+                  _from_ptr(v.flags, n, np.uint8).copy(), _from_ptr(v.seg_row_begin, ns + 1, np.int64).copy(),
+                  _from_ptr(v.seg_read, ns, np.int32).copy(), _from_ptr(v.seg_contig, ns, np.int32).copy(),
+                  v.n_reads, read_names=names, unknown=unknown)
+    finally:
+        L.mc_parsed_free(handle)
+    return t
+
+
+def make_ref_view(arrays):
+    """arrays: dict from MarkedReference.device_arrays() -> (RefView, keepalive)."""
+    v = RefView()
+    v.n_contigs = len(arrays['contig_len'])
+    v.contig_len, v.seq_off, v.seq = _ptr(arrays['contig_len']), _ptr(arrays['seq_off']), _ptr(arrays['seq'])
+    v.word_off, v.mbits_fwd, v.mbits_rev = _ptr(arrays['word_off']), _ptr(arrays['mbits_fwd']), _ptr(arrays['mbits_rev'])
+    v.n_seq_bytes = len(arrays['seq'])
+    v.n_words = len(arrays['mbits_fwd'])
+    return v
+
+
+class Records(object):
+    """Host buffers for flush records (mc_calls_view)."""
+
+    def __init__(self, capacity, k):
+        self.k = k
+        self.capacity = int(capacity)
+        c = max(1, self.capacity)
+        self.feats = np.zeros(c * k, dtype=np.float64)
+        self.site_pos = np.zeros(c, dtype=np.int32)
+        self.site_seg = np.zeros(c, dtype=np.int32)
+        self.close_row = np.zeros(c, dtype=np.int64)
+        self.info = np.zeros(c, dtype=np.uint32)
+        self.prob = np.full(c, np.nan, dtype=np.float64)
+        self.n = 0
+
+    def view(self):
+        v = CallsView()
+        v.capacity = self.capacity
+        v.feats, v.site_pos, v.site_seg = _ptr(self.feats), _ptr(self.site_pos), _ptr(self.site_seg)
+        v.close_row, v.info, v.prob = _ptr(self.close_row), _ptr(self.info), _ptr(self.prob)
+        return v

@@ -1,0 +1,26 @@
+"""Build libmcaller_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ['csrc/mc_device.hip', 'csrc/mc_parse.cpp', 'csrc/mc_common.cpp']
+OUT = os.path.join(HERE, 'libmcaller_hip.so')
+
+
+def build_lib(force=False, verbose=True):
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    deps = srcs + [os.path.join(os.path.dirname(HERE), 'include', 'mcaller_hip.h')]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+           '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build_lib(force='--force' in sys.argv)

@@ -1,0 +1,1168 @@
+// libmcaller_hip.so -- device side (gfx950 / MI355X).  C ABI: include/mcaller_hip.h.
+//
+// The reference's hot path (extract_contexts.py:147-291 + :199) as HIP kernels over a columnar event
+// table resident in HBM:
+//
+//   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone
+//                k_tile_nb       name block of the first row of every tile
+//   per call     k0_first_site   first site row of every name block under the "new read" strand rule
+//                                (:161-174) -> strand of the block
+//                k0_classify     regular / no-sites / irregular per name block
+//                k1_scan         THE SCAN: one workgroup per tile of rows; columns are read once with
+//                                16-byte loads, (pos, event-model, site offset) are staged in LDS, and the
+//                                rows that end a window (last row whose first 'M' is the site) walk back
+//                                over the <= k positions of their window in LDS to build the slot means
+//                                (NumPy pairwise order, fp64) -> one flush record per closed window
+//                k_order_*       tile-local record runs -> file order
+//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64 (one lane per record)
+//
+// Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
+// index monotone in the direction the first site row implies, no site at contig position 0, read name not
+// seen before) is argued in DESIGN.md; every other block is classified irregular and handled by the
+// literal per-run kernel (k_literal) so results never depend on a CPU path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mcaller_hip.h"
+
+void mc_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -10;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+namespace {
+
+constexpr int TILE = 4096;          // rows per workgroup tile
+constexpr int NTHREADS = 256;       // 4 waves
+constexpr int RPT = TILE / NTHREADS;  // rows per thread in the detection pass
+constexpr int NBMAX = 32;           // name-block descriptors staged in LDS per tile
+constexpr int O_NONE = 15;
+
+// meta byte per staged row: bit0 valid (passes :167-168), bit1 first row of a name block, bits 2..5 offset of
+// the first 'M' in the row's k-mer (O_NONE: not a site row)
+constexpr uint32_t M_VALID = 1, M_NS = 2;
+
+enum : uint8_t { MODE_NONE = 0, MODE_REGULAR = 1, MODE_IRREGULAR = 2 };
+
+// validation flags per name block (k_validate)
+constexpr uint32_t V_POS_DEC = 1, V_IDX_INC = 2, V_IDX_DEC = 4, V_IDX_EQ = 8, V_POS0 = 16, V_MULTI_SEG = 32;
+
+struct __attribute__((aligned(16))) NbDesc {
+    int64_t row_begin;
+    int64_t f0;        // first site row of the block (regular blocks); INT64_MAX: none
+    int32_t contig;
+    int32_t read;
+    uint8_t mode, rev, filtered, pad0;
+    int32_t pad1;
+};
+static_assert(sizeof(NbDesc) == 32, "NbDesc layout");
+
+struct DevTable {
+    int64_t n_rows = 0;
+    int32_t *pos = nullptr, *ev = nullptr, *mu = nullptr, *idx = nullptr;
+    uint8_t *flags = nullptr;
+    int32_t n_seg = 0;
+    int64_t *seg_begin = nullptr;
+    int32_t *seg_read = nullptr, *seg_contig = nullptr;
+    int32_t n_reads = 0;
+    int32_t n_nb = 0;
+    int64_t *nb_row_begin = nullptr;  // [n_nb+1]
+    int32_t *nb_seg_begin = nullptr;  // [n_nb+1]
+    int32_t *nb_read = nullptr;       // [n_nb]
+    uint8_t *nb_repeat = nullptr;     // [n_nb] read id seen in an earlier name block
+    uint32_t *nb_vflags = nullptr;    // [n_nb]
+    int64_t n_tiles = 0;
+    int32_t *tile_nb = nullptr;       // [n_tiles]
+    int has_repeats = 0;
+};
+
+struct DevRef {
+    int32_t n_contigs = 0;
+    int64_t *contig_len = nullptr, *seq_off = nullptr, *word_off = nullptr;
+    uint8_t *seq = nullptr;
+    uint32_t *mf = nullptr, *mr = nullptr;
+};
+
+struct DevRecords {
+    int64_t capacity = 0;
+    double *feats = nullptr;
+    int32_t *site_pos = nullptr, *site_seg = nullptr;
+    int64_t *close_row = nullptr;
+    uint32_t *info = nullptr;
+    double *prob = nullptr;
+};
+
+struct DevMlp {
+    int32_t n_models = 0, n_in = 0, n_hidden = 0;
+    double *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    uint8_t *sub_of_char = nullptr;
+};
+
+struct Counters {          // device-side status block
+    unsigned long long n_records;
+    unsigned int overflow;
+    unsigned int n_irregular;
+    unsigned int n_big;
+    unsigned int pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int first_m(const uint32_t *__restrict__ bits, int64_t L, int64_t pos, int k) {
+    if (pos >= L) return -1;
+    const int64_t w0 = pos >> 5;
+    const uint64_t lo = bits[w0], hi = bits[w0 + 1];
+    uint64_t w = ((hi << 32) | lo) >> (pos & 31);
+    w &= (1ull << k) - 1ull;
+    return w ? __builtin_ctzll(w) : -1;
+}
+
+__device__ __forceinline__ int bit_at(const uint32_t *__restrict__ bits, int64_t p) {
+    return (int)((bits[p >> 5] >> (p & 31)) & 1u);
+}
+
+__device__ __forceinline__ unsigned char comp_char(unsigned char c) {
+    switch (c) {
+        case 'A': return 'T';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        case 'T': return 'A';
+        case 'N': return 'N';
+        case 'M': return 'M';
+        default: return 0xFF;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// upload-time kernels
+// ---------------------------------------------------------------------------------------------------
+// one wave per name block: monotonicity of positions / event indices over ALL rows of the block
+__global__ void k_validate(DevTable T) {
+    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= T.n_nb) return;
+    const int64_t rb = T.nb_row_begin[b], re = T.nb_row_begin[b + 1];
+    uint32_t f = 0;
+    for (int64_t r = rb + lane; r < re; r += 64) {
+        const int32_t p = T.pos[r];
+        if (p == 0) f |= V_POS0;
+        if (r > rb) {
+            const int32_t pp = T.pos[r - 1];
+            if (p < pp) f |= V_POS_DEC;
+            const int32_t i0 = T.idx[r - 1], i1 = T.idx[r];
+            f |= (i1 > i0) ? V_IDX_INC : (i1 < i0 ? V_IDX_DEC : V_IDX_EQ);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    if (lane == 0) {
+        if (T.nb_seg_begin[b + 1] - T.nb_seg_begin[b] > 1) f |= V_MULTI_SEG;
+        T.nb_vflags[b] = f;
+    }
+}
+
+__global__ void k_tile_nb(DevTable T) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= T.n_tiles) return;
+    const int64_t row = t * TILE;
+    int lo = 0, hi = T.n_nb - 1;  // last block with row_begin <= row
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (T.nb_row_begin[mid] <= row) lo = mid; else hi = mid - 1;
+    }
+    T.tile_nb[t] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K0: strand resolve
+// ---------------------------------------------------------------------------------------------------
+// One wave per name block.  Under the reference's rule for a read it has not seen a site row of yet
+// (`read_name != last_read`, :161-174) each unfiltered row is tested on the strand `rev = (col3 != col10)`;
+// the first row that holds an 'M' in its k-mer becomes the block's first site row f0.
+__global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
+                              NbDesc *__restrict__ desc, int32_t *__restrict__ nb_f0idx,
+                              int32_t *__restrict__ nb_lastidx) {
+    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= T.n_nb) return;
+    const int read = T.nb_read[b];
+    const bool filtered = qual[read] < qual_thresh;
+    int64_t f0 = -1;
+    int f0rev = 0;
+    if (!filtered) {
+        for (int seg = T.nb_seg_begin[b]; seg < T.nb_seg_begin[b + 1] && f0 < 0; ++seg) {
+            const int contig = T.seg_contig[seg];
+            const int64_t L = R.contig_len[contig];
+            const uint32_t *mf = R.mf + R.word_off[contig], *mr = R.mr + R.word_off[contig];
+            const int64_t se = T.seg_begin[seg + 1];
+            for (int64_t base = T.seg_begin[seg]; base < se; base += 64) {
+                const int64_t r = base + lane;
+                bool c = false;
+                int rev = 0;
+                if (r < se) {
+                    const uint32_t fl = T.flags[r];
+                    if (!(fl & MC_F_MODEL_N)) {
+                        rev = (fl & MC_F_KMER_EQ) ? 0 : 1;
+                        c = first_m(rev ? mr : mf, L, T.pos[r], k) >= 0;
+                    }
+                }
+                const unsigned long long mask = __ballot(c);
+                if (mask) {
+                    const int first = __builtin_ctzll(mask);
+                    f0 = base + first;
+                    f0rev = __shfl(rev, first);
+                    break;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        NbDesc d;
+        d.row_begin = T.nb_row_begin[b];
+        d.f0 = f0;
+        d.contig = T.seg_contig[T.nb_seg_begin[b]];
+        d.read = read;
+        d.mode = MODE_NONE;
+        d.rev = (uint8_t)f0rev;
+        d.filtered = filtered ? 1 : 0;
+        d.pad0 = 0;
+        d.pad1 = 0;
+        desc[b] = d;
+        nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
+        nb_lastidx[b] = T.idx[T.nb_row_begin[b + 1] - 1];
+    }
+}
+
+// One thread per name block: is the block regular?
+__global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, int entry_read, Counters *cnt) {
+    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (b >= T.n_nb) return;
+    NbDesc d = desc[b];
+    // `last_read` when the block starts = name of the latest earlier block that has a site row (:282)
+    bool h1 = false;
+    if (T.nb_repeat[b] || entry_read >= 0) {
+        int j = b - 1;
+        while (j >= 0 && desc[j].f0 < 0) --j;
+        const int last_read = j >= 0 ? desc[j].read : entry_read;
+        h1 = (last_read == d.read);
+    }
+    uint8_t mode = MODE_NONE;
+    if (d.filtered) {
+        mode = MODE_NONE;                                 // every row fails :167, nothing else reads them
+    } else if (h1) {
+        mode = MODE_IRREGULAR;                            // rows see name == last_read: literal machine
+    } else if (d.f0 >= 0) {
+        const uint32_t vf = T.nb_vflags[b];
+        bool regular = !(vf & (V_POS_DEC | V_IDX_EQ | V_MULTI_SEG));
+        const bool inc = vf & V_IDX_INC, dec = vf & V_IDX_DEC;
+        if (inc && dec) regular = false;
+        // rows after f0 take rev = !(idx > idx[f0]) (:169): must equal the strand f0 was tested on
+        if (inc && d.rev) regular = false;
+        if (dec && !d.rev) regular = false;
+        if (vf & V_POS0) {   // a site at contig position 0 has a falsy mpos (:179, :272, :279)
+            const uint32_t *bits = (d.rev ? R.mr : R.mf) + R.word_off[d.contig];
+            if (R.contig_len[d.contig] > 0 && (bits[0] & 1u)) regular = false;
+        }
+        mode = regular ? MODE_REGULAR : MODE_IRREGULAR;
+    }
+    desc[b].mode = mode;
+    if (mode == MODE_IRREGULAR) atomicAdd(&cnt->n_irregular, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: the window scan
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events, finished by k1_bigfix
+
+struct RowSrc {   // where a walker reads rows from: LDS inside the tile, HBM/L2 outside
+    const int32_t *s_pos, *s_d;
+    const uint8_t *s_fl;
+    const int32_t *g_pos, *g_ev, *g_mu;
+    const uint8_t *g_flags;
+    int64_t t0;
+};
+
+// rows are only ever walked inside the name block of a row that passed the quality filter, so "valid"
+// (:167-168) reduces to model_kmer != NNNNNN
+__device__ __forceinline__ void row_get(const RowSrc &S, int64_t r, bool &valid, int32_t &pos, int32_t &d) {
+    if (r >= S.t0) {
+        const int i = (int)(r - S.t0);
+        valid = !(S.s_fl[i] & MC_F_MODEL_N);
+        pos = S.s_pos[i];
+        d = S.s_d[i];
+    } else {
+        valid = !(S.g_flags[r] & MC_F_MODEL_N);
+        pos = S.g_pos[r];
+        d = S.g_ev[r] - S.g_mu[r];
+    }
+}
+
+__device__ __forceinline__ double next_val(const RowSrc &S, int64_t &cur) {
+    for (;;) {
+        bool v;
+        int32_t p, d;
+        row_get(S, cur, v, p, d);
+        ++cur;
+        if (v) return (double)d / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+    }
+}
+
+// NumPy pairwise_sum over the next n values, n <= 128 (np.mean, :186): n < 8 sequential from -0.0;
+// else eight strided accumulators over the first n - n%8 values, combined pairwise, tail added in order.
+// (Values are never -0.0 -- they are integer/1e4 -- so starting the accumulators at +0.0 is exact.)
+__device__ __forceinline__ double leaf_sum(const RowSrc &S, int64_t &cur, int n) {
+    const int n8 = n < 8 ? 0 : n - (n % 8);
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
+    for (int i = 0; i < n8; ++i) {
+        const double v = next_val(S, cur);
+        switch (i & 7) {
+            case 0: r0 += v; break;
+            case 1: r1 += v; break;
+            case 2: r2 += v; break;
+            case 3: r3 += v; break;
+            case 4: r4 += v; break;
+            case 5: r5 += v; break;
+            case 6: r6 += v; break;
+            default: r7 += v; break;
+        }
+    }
+    double res = n8 ? ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) : -0.0;
+    for (int i = n8; i < n; ++i) res += next_val(S, cur);
+    return res;
+}
+
+struct K1Args {
+    DevTable T;
+    DevRef R;
+    const NbDesc *desc;
+    DevRecords U;            // unordered record runs (one run per tile)
+    int64_t *tile_base;      // [n_tiles]
+    int32_t *tile_cnt;       // [n_tiles]
+    Counters *cnt;
+    int k, skip_thresh, tail_contig;
+};
+
+// Record for the window of site m whose last row is r (global), in name block `d`.
+__device__ __forceinline__ void emit_record(const K1Args &A, const RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
+                                            int m, int64_t t1, int64_t slot) {
+    const DevTable &T = A.T;
+    const int k = A.k;
+    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+    const int64_t L = A.R.contig_len[d.contig];
+
+    // ---- the closing row: next unfiltered row in the file (:179) ----
+    int64_t close_row = -1;
+    int close_pos = 0;
+    bool close_ns = false;
+    {
+        int64_t rr = r + 1;
+        int bb = nb_abs;
+        const int64_t my_end = T.nb_row_begin[nb_abs + 1];
+        while (rr < T.n_rows) {
+            if (rr < my_end) {                          // still my name block: valid <=> not an N row
+                bool v; int32_t p, dd;
+                row_get(S, rr, v, p, dd);
+                if (v) { close_row = rr; close_pos = p; break; }
+                ++rr;
+                continue;
+            }
+            close_ns = true;                            // another read begins: closes whatever its position
+            while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
+            if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }   // skip the read whole
+            if (!(T.flags[rr] & MC_F_MODEL_N)) { close_row = rr; close_pos = T.pos[rr]; break; }
+            ++rr;
+        }
+        if (close_row < 0 && A.tail_contig >= 0) { close_row = T.n_rows; close_ns = true; }
+    }
+    (void)t1;
+    const bool closes = close_row >= 0 && (close_ns || close_pos > m);
+    if (!closes) {                   // not the last row of its window after all, or lost at EOF (R6)
+        A.U.site_seg[slot] = -1;     // tombstone, dropped by the ordering pass
+        A.U.info[slot] = 0;
+        A.U.close_row[slot] = -1;
+        A.U.site_pos[slot] = m;
+        return;
+    }
+    uint32_t info = d.rev ? MC_I_REV : 0u;
+
+    // ---- window rows: back to the first row at position >= m-k+1 (never before f0 / the block start) ----
+    // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
+    const int64_t lb = max(d.row_begin, d.f0);
+    unsigned long long cnt8 = 0;
+    bool big = false;
+    int64_t ws = r;
+    for (int64_t rr = r; rr >= lb; --rr) {
+        bool v; int32_t p, dd;
+        row_get(S, rr, v, p, dd);
+        if (!v) continue;
+        if (p < m - k + 1) break;
+        const int sh = 8 * (m - p);
+        if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
+        else cnt8 += 1ull << sh;
+        ws = rr;
+    }
+    int nskip = 0;
+    for (int s = 0; s < k; ++s) nskip += (((cnt8 >> (8 * s)) & 0xFFull) == 0ull);
+
+    if (nskip > A.skip_thresh) {
+        info |= MC_I_TOO_MANY;
+        for (int s = 0; s < k; ++s) A.U.feats[slot * k + s] = 0.0;
+    } else {
+        int64_t cur = ws;
+        for (int s = k - 1; s >= 0; --s) {             // positions ascend => slots descend
+            const int dst = d.rev ? s : k - 1 - s;      // :187-188
+            const int n = (int)((cnt8 >> (8 * s)) & 0xFFull);
+            double f = 0.0;
+            if (n == 0) info |= 1u << dst;
+            else if (!big) f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
+            A.U.feats[slot * k + dst] = f;
+        }
+        if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
+        if (m - k + 1 < 0 || (int64_t)m + k > L) {
+            info |= MC_I_EDGE;
+        } else {
+            unsigned char ch;
+            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
+            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
+            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
+            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+        }
+    }
+    // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
+    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {
+        const int fm = first_m(bits, L, close_pos, k);
+        if (fm > 0) info |= MC_I_MULTI;
+    }
+    A.U.site_pos[slot] = m;
+    A.U.site_seg[slot] = T.nb_seg_begin[nb_abs];        // regular blocks have one segment
+    A.U.close_row[slot] = close_row;
+    A.U.info[slot] = info;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
+    __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
+    __shared__ __attribute__((aligned(16))) int32_t s_d[TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
+    __shared__ uint16_t s_emit[TILE];
+    __shared__ NbDesc s_nb[NBMAX];
+    __shared__ int s_nnb;
+    __shared__ int s_wsum[NTHREADS / 64];
+    __shared__ long long s_base;
+
+    const DevTable &T = A.T;
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t t0 = tile * TILE;
+    const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
+    const int nrows = (int)(t1 - t0);
+    const int k = A.k;
+
+    // ---- pass 1: stream the tile's columns into LDS, 16-byte loads, nothing else ----
+#pragma unroll
+    for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
+        const int i0 = (j * NTHREADS + tid) * 4;
+        const int64_t q = t0 + i0;
+        if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
+            const int4 p4 = *reinterpret_cast<const int4 *>(T.pos + q);
+            const int4 e4 = *reinterpret_cast<const int4 *>(T.ev + q);
+            const int4 m4 = *reinterpret_cast<const int4 *>(T.mu + q);
+            const uint32_t f4 = *reinterpret_cast<const uint32_t *>(T.flags + q);
+            int4 d4;
+            d4.x = e4.x - m4.x; d4.y = e4.y - m4.y; d4.z = e4.z - m4.z; d4.w = e4.w - m4.w;
+            *reinterpret_cast<int4 *>(&s_pos[i0]) = p4;
+            *reinterpret_cast<int4 *>(&s_d[i0]) = d4;
+            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = f4;
+        }
+    }
+    // name blocks that overlap the tile
+    const int nb0 = T.tile_nb[tile];
+    if (tid == 0) s_nnb = 0;
+    __syncthreads();
+    if (tid < NBMAX) {
+        const int b = nb0 + tid;
+        if (b < T.n_nb && T.nb_row_begin[b] < t1) {
+            s_nb[tid] = A.desc[b];
+            atomicAdd(&s_nnb, 1);
+        }
+    }
+    __syncthreads();
+    const int nnb = s_nnb;   // descriptors staged; a tile that overlaps more reads them from global memory
+    auto desc_of = [&](int bi) -> NbDesc { return (bi < nnb) ? s_nb[bi] : A.desc[nb0 + bi]; };
+    auto begin_of = [&](int bi) -> int64_t { return (bi < nnb) ? s_nb[bi].row_begin : T.nb_row_begin[nb0 + bi]; };
+    const int nb_last = T.n_nb - 1 - nb0;   // largest relative block index
+
+    // ---- pass 2: detection.  Thread owns RPT consecutive rows; a site row (k-mer holds an 'M', :269) is the
+    // last row of its window iff the next unfiltered row starts another read or lies beyond the site (:179).
+    const int i_begin = tid * RPT;
+    uint32_t emit_mask = 0;
+    if (i_begin < nrows) {
+        int bi = 0;
+        while (bi < nb_last && begin_of(bi + 1) <= t0 + i_begin) ++bi;
+        NbDesc d = desc_of(bi);
+        const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+        int64_t L = A.R.contig_len[d.contig];
+        for (int u = 0; u < RPT; ++u) {
+            const int i = i_begin + u;
+            if (i >= nrows) break;
+            const uint32_t fl = s_fl[i];
+            if ((fl & MC_F_NAME_START) && t0 + i != d.row_begin) {
+                ++bi;
+                d = desc_of(bi);
+                bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+                L = A.R.contig_len[d.contig];
+            }
+            if ((fl & MC_F_MODEL_N) || d.mode != MODE_REGULAR || t0 + i < d.f0) continue;
+            const int o = first_m(bits, L, s_pos[i], k);
+            if (o < 0) continue;
+            const int m = s_pos[i] + o;
+            bool last = true;                       // undecided inside the tile => decided at emission
+            for (int j = i + 1; j < nrows; ++j) {
+                const uint32_t fj = s_fl[j];
+                if (fj & MC_F_NAME_START) break;    // another read follows
+                if (!(fj & MC_F_MODEL_N)) { last = s_pos[j] > m; break; }
+            }
+            if (last) emit_mask |= 1u << u;
+        }
+    }
+
+    // ---- allocate record slots: exclusive scan over the workgroup, one atomic per tile ----
+    const int my_cnt = __popc(emit_mask);
+    int incl = my_cnt;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int w = 0; w < NTHREADS / 64; ++w) {
+        if (w < wave) wave_off += s_wsum[w];
+        total += s_wsum[w];
+    }
+    if (tid == 0) {
+        long long base = 0;
+        if (total > 0) base = (long long)atomicAdd(&A.cnt->n_records, (unsigned long long)total);
+        s_base = base;
+        A.tile_base[tile] = base;
+        A.tile_cnt[tile] = total;
+    }
+    {
+        int q = wave_off + incl - my_cnt;
+        uint32_t mk = emit_mask;
+        while (mk) {
+            const int u = __builtin_ctz(mk);
+            mk &= mk - 1;
+            s_emit[q++] = (uint16_t)(i_begin + u);
+        }
+    }
+    __syncthreads();
+    if (total == 0) return;
+
+    // ---- pass 3: emission, one thread per closed window, rows read back from LDS ----
+    const int64_t base = s_base;
+    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0};
+    for (int q = tid; q < total; q += NTHREADS) {
+        const int64_t slot = base + q;
+        if (slot >= A.U.capacity) { atomicOr(&A.cnt->overflow, 1u); continue; }
+        const int i = s_emit[q];
+        const int64_t r = t0 + i;
+        int bi = 0;
+        while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
+        const NbDesc d = desc_of(bi);
+        const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+        const int m = s_pos[i] + first_m(bits, A.R.contig_len[d.contig], s_pos[i], k);
+        emit_record(A, S, d, nb0 + bi, r, m, t1, slot);
+    }
+}
+
+// Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
+// thread per such record, so that the scan kernel carries neither the stack nor the registers for it.
+__device__ double big_pairwise(const RowSrc &S, int64_t &cur, int64_t n) {
+    // emulate  f(n) = n <= 128 ? leaf(n) : f(n2) + f(n - n2),  n2 = n/2 rounded down to a multiple of 8
+    int64_t fsize[40];
+    int fstage[40];      // 0 = not started, 1 = left half pending, 2 = right half pending
+    double fleft[40];
+    int fp = 1;
+    fsize[0] = n;
+    fstage[0] = 0;
+    double ret = 0.0;
+    while (fp > 0) {
+        const int top = fp - 1;
+        int64_t n2 = fsize[top] / 2;
+        n2 -= n2 % 8;
+        if (fstage[top] == 0) {
+            if (fsize[top] <= 128) {
+                ret = leaf_sum(S, cur, (int)fsize[top]);
+                --fp;
+            } else {
+                fstage[top] = 1;
+                fsize[fp] = n2; fstage[fp] = 0; ++fp;
+            }
+        } else if (fstage[top] == 1) {
+            fleft[top] = ret;
+            fstage[top] = 2;
+            fsize[fp] = fsize[top] - n2; fstage[fp] = 0; ++fp;
+        } else {
+            ret = fleft[top] + ret;
+            --fp;
+        }
+    }
+    return ret;
+}
+
+__global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t info = O.info[j];
+    if (!(info & MC_I_BIG)) return;
+    const DevTable &T = A.T;
+    const int k = A.k;
+    const int m = O.site_pos[j];
+    const bool rev = info & MC_I_REV;
+    // name block of the record = the one its (single) segment starts
+    const int seg = O.site_seg[j];
+    int lo = 0, hi = T.n_nb - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
+    }
+    const NbDesc d = A.desc[lo];
+    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, (int64_t)1 << 62};
+    // last row of the window: the last unfiltered row of the block before the closing row
+    int64_t r = min(O.close_row[j], T.nb_row_begin[lo + 1]) - 1;
+    const int64_t lb = max(d.row_begin, d.f0);
+    while (r >= lb && (T.flags[r] & MC_F_MODEL_N)) --r;
+    int64_t cnt[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t ws = r;
+    for (int64_t rr = r; rr >= lb; --rr) {
+        if (T.flags[rr] & MC_F_MODEL_N) continue;
+        const int p = T.pos[rr];
+        if (p < m - k + 1) break;
+        cnt[m - p] += 1;
+        ws = rr;
+    }
+    int64_t cur = ws;
+    for (int s = k - 1; s >= 0; --s) {
+        const int dst = rev ? s : k - 1 - s;
+        double f = 0.0;
+        if (cnt[s] > 0) f = (0.0 + big_pairwise(S, cur, cnt[s])) / (double)cnt[s];
+        O.feats[j * k + dst] = f;
+    }
+    O.info[j] = info & ~MC_I_BIG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// record ordering: per-tile runs (tile_base, tile_cnt) in arrival order -> file order, tombstones dropped
+// ---------------------------------------------------------------------------------------------------
+// pass 1: one wave per tile counts live records
+__global__ void k_order_count(DevRecords U, const int64_t *tile_base, const int32_t *tile_cnt, int64_t n_tiles,
+                              int32_t *tile_live) {
+    const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int64_t base = tile_base[t];
+    const int n = tile_cnt[t];
+    int live = 0;
+    for (int i = lane; i < n; i += 64) live += (U.site_seg[base + i] >= 0);
+    for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
+    if (lane == 0) tile_live[t] = live;
+}
+
+// pass 2: single workgroup exclusive scan of tile_live -> tile_out, total
+__global__ void k_order_scan(const int32_t *tile_live, int64_t n_tiles, int64_t *tile_out, Counters *cnt) {
+    __shared__ long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n_tiles + 1023) / 1024;
+    const int64_t lo = tid * per, hi = min(lo + per, n_tiles);
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += tile_live[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        long long v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long long run = s_part[tid] - sum;
+    for (int64_t i = lo; i < hi; ++i) {
+        tile_out[i] = run;
+        run += tile_live[i];
+    }
+    if (tid == 1023) cnt->n_records = (unsigned long long)s_part[1023];
+}
+
+// pass 3: one wave per tile moves its live records to their final slots
+__global__ void k_order_gather(DevRecords U, DevRecords O, const int64_t *tile_base, const int32_t *tile_cnt,
+                               const int64_t *tile_out, int64_t n_tiles, int k) {
+    const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int64_t base = tile_base[t];
+    const int n = tile_cnt[t];
+    int64_t dst = tile_out[t];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < n && U.site_seg[base + i] >= 0;
+        const unsigned long long mask = __ballot(live);
+        if (live) {
+            const int64_t s = base + i;
+            const int64_t d = dst + __popcll(mask & ((1ull << lane) - 1ull));
+            for (int f = 0; f < k; ++f) O.feats[d * k + f] = U.feats[s * k + f];
+            O.site_pos[d] = U.site_pos[s];
+            O.site_seg[d] = U.site_seg[s];
+            O.close_row[d] = U.close_row[s];
+            O.info[d] = U.info[s];
+            O.prob[d] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        dst += __popcll(mask);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; weights staged in LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+                                              const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                              const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                              const uint8_t *__restrict__ submodel_in, int64_t n,
+                                              double *__restrict__ prob) {
+    extern __shared__ double s_w[];   // per model: W1[n_in*H] b1[H] W2[H] b2[1]
+    const int H = M.n_hidden, NI = M.n_in;
+    const int per = NI * H + 2 * H + 1;
+    for (int i = threadIdx.x; i < M.n_models * per; i += blockDim.x) {
+        const int mi = i / per, j = i % per;
+        double v;
+        if (j < NI * H) v = M.W1[(size_t)mi * NI * H + j];
+        else if (j < NI * H + H) v = M.b1[(size_t)mi * H + (j - NI * H)];
+        else if (j < NI * H + 2 * H) v = M.W2[(size_t)mi * H + (j - NI * H - H)];
+        else v = M.b2[mi];
+        s_w[i] = v;
+    }
+    __syncthreads();
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int mi;
+    double x[MC_MAX_K + 1];
+    if (submodel_in) {                       // plain batched call: X rows of n_in values
+        mi = submodel_in[r];
+#pragma unroll
+        for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+    } else {                                 // flush records: k slot means + read quality (:189-193)
+        const uint32_t inf = info[r];
+        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
+        mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+        const double q = qual[seg_read[site_seg[r]]];
+#pragma unroll
+        for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+    }
+    if (mi >= M.n_models) return;            // KeyError path (:218): the host decides
+    const double *w = s_w + (size_t)mi * per;
+    const double *b1 = w + NI * H, *w2 = b1 + H;
+    double z = 0.0;
+    for (int j = 0; j < H; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i <= MC_MAX_K; ++i)
+            if (i < NI) a += x[i] * w[i * H + j];
+        z += tanh(a + b1[j]) * w2[j];
+    }
+    z += w2[H];
+    prob[r] = 1.0 / (1.0 + exp(-z));
+}
+
+}  // namespace
+
+// ===================================================================================================
+// host side
+// ===================================================================================================
+struct mc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    DevTable T;
+    DevRef R;
+    DevMlp M;
+    double *qual = nullptr;
+    int32_t n_qual = 0;
+    NbDesc *desc = nullptr;
+    int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
+    DevRecords U, O;
+    int64_t *tile_base = nullptr, *tile_out = nullptr;
+    int32_t *tile_cnt = nullptr, *tile_live = nullptr;
+    Counters *cnt = nullptr;
+    int last_k = 0;
+    int64_t last_n = 0;
+    float times[5] = {0, 0, 0, 0, 0};
+    std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
+};
+
+template <typename Tp>
+static int dev_alloc(std::vector<void *> &pool, Tp **p, size_t n) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n * sizeof(Tp), 256));
+    if (e != hipSuccess) {
+        mc_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(Tp), hipGetErrorString(e));
+        return -10;
+    }
+    pool.push_back(q);
+    *p = (Tp *)q;
+    return 0;
+}
+
+static void free_pool(std::vector<void *> &pool) {
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+extern "C" int mc_ctx_create(int device, mc_ctx **out) {
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        mc_set_error("no HIP device available (%s): libmcaller_hip has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return -11;
+    }
+    if (device < 0 || device >= n) {
+        mc_set_error("device %d out of range (%d visible)", device, n);
+        return -11;
+    }
+    HIP_TRY(hipSetDevice(device));
+    mc_ctx *c = new mc_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipMalloc((void **)&c->cnt, sizeof(Counters)));
+    HIP_TRY(hipMemset(c->cnt, 0, sizeof(Counters)));
+    *out = c;
+    return 0;
+}
+
+extern "C" void mc_ctx_destroy(mc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_pool(c->table_allocs);
+    free_pool(c->ref_allocs);
+    free_pool(c->mlp_allocs);
+    free_pool(c->rec_allocs);
+    if (c->qual) (void)hipFree(c->qual);
+    if (c->cnt) (void)hipFree(c->cnt);
+    for (auto &ev : c->ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mc_ctx_sync(mc_ctx *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+#define UP(dst, src, n, pool)                                                                          \
+    do {                                                                                               \
+        if (dev_alloc(pool, &(dst), (size_t)(n)) != 0) return -10;                                     \
+        if ((n) > 0) HIP_TRY(hipMemcpyAsync((void *)(dst), (src), (size_t)(n) * sizeof(*(dst)), hipMemcpyHostToDevice, c->stream)); \
+    } while (0)
+
+extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_pool(c->ref_allocs);
+    DevRef &R = c->R;
+    R.n_contigs = h->n_contigs;
+    UP(R.contig_len, h->contig_len, h->n_contigs, c->ref_allocs);
+    UP(R.seq_off, h->seq_off, h->n_contigs, c->ref_allocs);
+    UP(R.word_off, h->word_off, h->n_contigs, c->ref_allocs);
+    UP(R.seq, h->seq, h->n_seq_bytes, c->ref_allocs);
+    UP(R.mf, h->mbits_fwd, h->n_words, c->ref_allocs);
+    UP(R.mr, h->mbits_rev, h->n_words, c->ref_allocs);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_pool(c->table_allocs);
+    DevTable &T = c->T;
+    T = DevTable();
+    T.n_rows = h->n_rows;
+    T.n_seg = h->n_seg;
+    T.n_reads = h->n_reads;
+    const int64_t n = h->n_rows;
+    const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
+    if (dev_alloc(c->table_allocs, &T.pos, (size_t)padded) || dev_alloc(c->table_allocs, &T.ev, (size_t)padded) ||
+        dev_alloc(c->table_allocs, &T.mu, (size_t)padded) || dev_alloc(c->table_allocs, &T.idx, (size_t)padded) ||
+        dev_alloc(c->table_allocs, &T.flags, (size_t)padded))
+        return -10;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(T.ev, h->event_e4, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(T.mu, h->model_e4, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(T.idx, h->event_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(T.flags, h->flags, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    UP(T.seg_begin, h->seg_row_begin, h->n_seg + 1, c->table_allocs);
+    UP(T.seg_read, h->seg_read, h->n_seg, c->table_allocs);
+    UP(T.seg_contig, h->seg_contig, h->n_seg, c->table_allocs);
+
+    // name blocks: maximal runs of segments with one read name (MC_F_NAME_START on the first row)
+    std::vector<int64_t> nb_row;
+    std::vector<int32_t> nb_seg, nb_read;
+    std::vector<uint8_t> nb_rep;
+    std::vector<uint8_t> seen((size_t)std::max(h->n_reads, 1), 0);
+    int has_rep = 0;
+    for (int32_t s = 0; s < h->n_seg; ++s) {
+        const int64_t rb = h->seg_row_begin[s];
+        if (s == 0 || (h->flags[rb] & MC_F_NAME_START)) {
+            nb_row.push_back(rb);
+            nb_seg.push_back(s);
+            const int32_t rd = h->seg_read[s];
+            if (rd < 0 || rd >= h->n_reads) {
+                mc_set_error("segment %d: read id %d out of range", s, rd);
+                return -12;
+            }
+            nb_read.push_back(rd);
+            nb_rep.push_back(seen[(size_t)rd]);
+            has_rep |= seen[(size_t)rd];
+            seen[(size_t)rd] = 1;
+        }
+    }
+    T.n_nb = (int32_t)nb_read.size();
+    nb_row.push_back(n);
+    nb_seg.push_back(h->n_seg);
+    T.has_repeats = has_rep;
+    UP(T.nb_row_begin, nb_row.data(), nb_row.size(), c->table_allocs);
+    UP(T.nb_seg_begin, nb_seg.data(), nb_seg.size(), c->table_allocs);
+    UP(T.nb_read, nb_read.data(), nb_read.size(), c->table_allocs);
+    UP(T.nb_repeat, nb_rep.data(), nb_rep.size(), c->table_allocs);
+    if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1)) return -10;
+    T.n_tiles = (n + TILE - 1) / TILE;
+    if (dev_alloc(c->table_allocs, &T.tile_nb, (size_t)T.n_tiles + 1)) return -10;
+    if (dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) ||
+        dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
+        dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
+        dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
+        dev_alloc(c->table_allocs, &c->tile_out, (size_t)T.n_tiles + 1) ||
+        dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1) ||
+        dev_alloc(c->table_allocs, &c->tile_live, (size_t)T.n_tiles + 1))
+        return -10;
+    if (T.n_nb > 0) {
+        const int64_t threads = (int64_t)T.n_nb * 64;
+        hipLaunchKernelGGL(k_validate, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T);
+        hipLaunchKernelGGL(k_tile_nb, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mc_ctx_set_read_quality(mc_ctx *c, const double *qual, int32_t n_reads) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->qual) (void)hipFree(c->qual);
+    c->qual = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->qual, std::max<size_t>((size_t)n_reads * 8, 256)));
+    if (n_reads > 0) HIP_TRY(hipMemcpy(c->qual, qual, (size_t)n_reads * 8, hipMemcpyHostToDevice));
+    c->n_qual = n_reads;
+    return 0;
+}
+
+extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t n_hidden, const double *W1,
+                              const double *b1, const double *W2, const double *b2, const uint8_t *sub_of_char) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_in < 1 || n_in > MC_MAX_K + 1 || n_models < 1 || n_hidden < 1) {
+        mc_set_error("unsupported MLP shape: %d models, %d inputs, %d hidden", n_models, n_in, n_hidden);
+        return -12;
+    }
+    const size_t lds = (size_t)n_models * ((size_t)n_in * n_hidden + 2 * (size_t)n_hidden + 1) * 8;
+    if (lds > 64 * 1024) {
+        mc_set_error("MLP weights (%zu bytes) do not fit the LDS budget of k2_mlp", lds);
+        return -12;
+    }
+    free_pool(c->mlp_allocs);
+    DevMlp &M = c->M;
+    M.n_models = n_models;
+    M.n_in = n_in;
+    M.n_hidden = n_hidden;
+    UP(M.W1, W1, (size_t)n_models * n_in * n_hidden, c->mlp_allocs);
+    UP(M.b1, b1, (size_t)n_models * n_hidden, c->mlp_allocs);
+    UP(M.W2, W2, (size_t)n_models * n_hidden, c->mlp_allocs);
+    UP(M.b2, b2, (size_t)n_models, c->mlp_allocs);
+    UP(M.sub_of_char, sub_of_char, 256, c->mlp_allocs);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int ensure_records(mc_ctx *c, int64_t cap, int k) {
+    if (c->U.capacity >= cap && c->last_k == k) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_pool(c->rec_allocs);
+    for (DevRecords *D : {&c->U, &c->O}) {
+        D->capacity = cap;
+        if (dev_alloc(c->rec_allocs, &D->feats, (size_t)cap * k) || dev_alloc(c->rec_allocs, &D->site_pos, (size_t)cap) ||
+            dev_alloc(c->rec_allocs, &D->site_seg, (size_t)cap) || dev_alloc(c->rec_allocs, &D->close_row, (size_t)cap) ||
+            dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
+            return -10;
+    }
+    c->last_k = k;
+    return 0;
+}
+
+static size_t mlp_lds_bytes(const DevMlp &M) {
+    return (size_t)M.n_models * ((size_t)M.n_in * M.n_hidden + 2 * (size_t)M.n_hidden + 1) * 8;
+}
+
+extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_records) {
+    HIP_TRY(hipSetDevice(c->device));
+    *n_records = 0;
+    const DevTable &T = c->T;
+    const int k = prm->k;
+    if (k < 1 || k > MC_MAX_K) {
+        mc_set_error("num_variables %d not supported (1..%d)", k, MC_MAX_K);
+        return -12;
+    }
+    if (!T.pos || !c->R.mf || !c->qual) {
+        mc_set_error("mc_extract_features: table, reference and read qualities must be set first");
+        return -12;
+    }
+    if (c->n_qual < T.n_reads) {
+        mc_set_error("read quality table has %d entries, table names %d reads", c->n_qual, T.n_reads);
+        return -12;
+    }
+    if (prm->score && (!c->M.W1 || c->M.n_in != k + 1)) {
+        mc_set_error("classifier expects %d inputs but num_variables+1 = %d", c->M.W1 ? c->M.n_in : 0, k + 1);
+        return -12;
+    }
+    c->last_n = 0;
+    if (T.n_rows == 0 || T.n_nb == 0) return 0;
+
+    int64_t cap = std::max<int64_t>(1 << 16, T.n_rows / 4 + 1024);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (int rc = ensure_records(c, cap, k)) return rc;
+        HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        {
+            const int64_t threads = (int64_t)T.n_nb * 64;
+            hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0idx, c->nb_lastidx);
+            hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                               c->desc, prm->entry_read, c->cnt);
+        }
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        K1Args A;
+        A.T = T; A.R = c->R; A.desc = c->desc; A.U = c->U; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
+        A.cnt = c->cnt; A.k = k; A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
+        hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        {
+            const int64_t threads = T.n_tiles * 64;
+            const unsigned g = (unsigned)((threads + 255) / 256);
+            hipLaunchKernelGGL(k_order_count, dim3(g), dim3(256), 0, c->stream, c->U, c->tile_base, c->tile_cnt, T.n_tiles,
+                               c->tile_live);
+            hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, c->stream, c->tile_live, T.n_tiles, c->tile_out, c->cnt);
+            hipLaunchKernelGGL(k_order_gather, dim3(g), dim3(256), 0, c->stream, c->U, c->O, c->tile_base, c->tile_cnt,
+                               c->tile_out, T.n_tiles, k);
+        }
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        Counters h;
+        HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        if (h.overflow) {
+            cap *= 4;
+            continue;
+        }
+        if (h.n_irregular) {
+            mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
+                         "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
+                         "contigs): not available in this build of the HIP path", h.n_irregular);
+            return -20;
+        }
+        const int64_t n = (int64_t)h.n_records;
+        if (h.n_big && n > 0)
+            hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, c->O, n);
+        if (prm->score && n > 0) {
+            hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M,
+                               c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
+                               c->O.prob);
+        }
+        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
+        c->last_n = n;
+        *n_records = n;
+        return 0;
+    }
+    mc_set_error("record buffer overflow after 3 attempts");
+    return -13;
+}
+
+extern "C" int mc_fetch_records(mc_ctx *c, const mc_calls_view *out) {
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = c->last_n;
+    const int k = c->last_k;
+    if (out->capacity < n) {
+        mc_set_error("mc_fetch_records: capacity %lld < %lld records", (long long)out->capacity, (long long)n);
+        return -12;
+    }
+    if (n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(out->feats, c->O.feats, (size_t)n * k * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->site_pos, c->O.site_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->site_seg, c->O.site_seg, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->close_row, c->O.close_row, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->info, c->O.info, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->prob, c->O.prob, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mc_last_times_ms(mc_ctx *c, float *out5) {
+    for (int i = 0; i < 5; ++i) out5[i] = c->times[i];
+    return 0;
+}
+
+extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->M.W1) {
+        mc_set_error("mc_mlp_forward: no classifier set");
+        return -12;
+    }
+    if (n <= 0) return 0;
+    double *dX = nullptr, *dp = nullptr;
+    uint8_t *ds = nullptr;
+    const int ni = c->M.n_in;
+    HIP_TRY(hipMalloc((void **)&dX, (size_t)n * ni * 8));
+    HIP_TRY(hipMalloc((void **)&dp, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void **)&ds, (size_t)n));
+    HIP_TRY(hipMemcpyAsync(dX, X, (size_t)n * ni * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(ds, submodel, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(dp, 0xFF, (size_t)n * 8, c->stream));   // NaN
+    hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                       (const uint32_t *)nullptr, ds, n, dp);
+    HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    (void)hipFree(dX);
+    (void)hipFree(dp);
+    (void)hipFree(ds);
+    return 0;
+}

@@ -1,0 +1,328 @@
+// Native eventalign parser (host side of libmcaller_hip.so).
+//
+// Replaces the text ingest of the reference's hot loop -- extract_contexts.py:140-152 (seek, readlines
+// batches, line.split()[:12]) plus the per-row conversions it feeds (int(read_pos) :175, int(read_ind)
+// :162/:169, float(event_current)-float(model_current) :286, the k-mer comparisons :167/:169) -- by one
+// pass that turns ~128 B of text per row into the 17 B/row columnar table of include/mcaller_hip.h.
+//
+// Currents are stored as integers in units of 1e-4 pA.  np.round(float(e)-float(m), 4) (:286) always
+// equals fl(R/1e4) for the integer R = rint((e-m)*1e4); for the plain decimals nanopolish prints
+// (<= 4 fractional digits) R is exactly E4-M4, so the table keeps E4 and M4 and the subtraction stays on
+// the GPU.  For any other spelling strtod is used and the row stores (R, 0).
+#include "../../include/mcaller_hip.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+void mc_set_error(const char *fmt, ...);
+
+namespace {
+
+inline bool is_ws(unsigned char c) {
+    // ASCII subset of what str.split() treats as whitespace
+    return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31);
+}
+
+struct Tok {
+    const char *p;
+    size_t n;
+};
+
+// first 12 whitespace-separated tokens of [s, e); returns the number found (<= 12)
+inline int split12(const char *s, const char *e, Tok *t) {
+    int n = 0;
+    while (s < e && n < 12) {
+        while (s < e && is_ws((unsigned char)*s)) ++s;
+        if (s >= e) break;
+        const char *b = s;
+        while (s < e && !is_ws((unsigned char)*s)) ++s;
+        t[n].p = b;
+        t[n].n = (size_t)(s - b);
+        ++n;
+    }
+    return n;
+}
+
+inline bool parse_int(const Tok &t, int64_t *out) {
+    const char *p = t.p, *e = t.p + t.n;
+    bool neg = false;
+    if (p < e && (*p == '+' || *p == '-')) {
+        neg = (*p == '-');
+        ++p;
+    }
+    if (p >= e) return false;
+    int64_t v = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (*p - '0');
+        if (v > (int64_t)1 << 40) return false;
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// plain decimal with <= 4 fractional digits -> value * 1e4 as an integer
+inline bool parse_e4_fast(const Tok &t, int64_t *out) {
+    const char *p = t.p, *e = t.p + t.n;
+    bool neg = false;
+    if (p < e && (*p == '+' || *p == '-')) {
+        neg = (*p == '-');
+        ++p;
+    }
+    int64_t v = 0;
+    int nd = 0;
+    for (; p < e && *p >= '0' && *p <= '9'; ++p) {
+        v = v * 10 + (*p - '0');
+        if (++nd > 9) return false;
+    }
+    int nf = 0;
+    if (p < e && *p == '.') {
+        ++p;
+        for (; p < e && *p >= '0' && *p <= '9'; ++p) {
+            if (++nf > 4) return false;
+            v = v * 10 + (*p - '0');
+        }
+    }
+    if (p != e || (nd == 0 && nf == 0)) return false;
+    for (int i = nf; i < 4; ++i) v *= 10;
+    *out = neg ? -v : v;
+    return true;
+}
+
+inline bool parse_double_slow(const Tok &t, double *out) {
+    if (t.n == 0 || t.n > 64) return false;
+    char buf[72];
+    memcpy(buf, t.p, t.n);
+    buf[t.n] = 0;
+    for (size_t i = 0; i < t.n; ++i)
+        if (buf[i] == 'x' || buf[i] == 'X') return false;  // float() has no hex form
+    char *end = nullptr;
+    errno = 0;
+    double v = strtod(buf, &end);
+    if (end != buf + t.n) return false;
+    *out = v;
+    return true;
+}
+
+struct SvHash {
+    size_t operator()(std::string_view s) const { return std::hash<std::string_view>()(s); }
+};
+
+}  // namespace
+
+struct mc_parsed {
+    std::vector<int32_t> pos, ev, mu, idx;
+    std::vector<uint8_t> flags;
+    std::vector<int64_t> seg_begin;
+    std::vector<int32_t> seg_read, seg_contig;
+    std::vector<std::string> read_names;
+    std::vector<std::string> unknown;
+};
+
+// The byte range [lo, hi) the reference's batch loop consumes (:141-148).
+static void consumed_range(const char *base, int64_t fsize, int64_t startline, int64_t endline,
+                           int64_t *lo, int64_t *hi) {
+    int64_t linepos = startline - 500 > 0 ? startline - 500 : 0;
+    if (linepos > fsize) linepos = fsize;
+    *lo = linepos;
+    while (linepos <= endline - 500) {
+        if (linepos >= fsize) break;  // the reference would spin here; we stop
+        // one readlines(8000000) batch: lines are taken until their total size exceeds the hint
+        int64_t probe = linepos + 8000000;
+        if (probe >= fsize) {
+            linepos = fsize;
+        } else {
+            const void *nl = memchr(base + probe, '\n', (size_t)(fsize - probe));
+            linepos = nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
+        }
+    }
+    *hi = linepos;
+}
+
+extern "C" int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
+                                   const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
+                                   mc_parsed **out) {
+    (void)n_threads;
+    *out = nullptr;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        mc_set_error("cannot open %s: %s", path, strerror(errno));
+        return -1;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        mc_set_error("cannot stat %s", path);
+        close(fd);
+        return -1;
+    }
+    int64_t fsize = (int64_t)st.st_size;
+    const char *base = nullptr;
+    if (fsize > 0) {
+        base = (const char *)mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (base == MAP_FAILED) {
+            mc_set_error("cannot mmap %s: %s", path, strerror(errno));
+            close(fd);
+            return -1;
+        }
+        madvise((void *)base, (size_t)fsize, MADV_SEQUENTIAL);
+    }
+    close(fd);
+
+    int64_t lo = 0, hi = 0;
+    if (fsize > 0) consumed_range(base, fsize, startline, endline, &lo, &hi);
+
+    std::unordered_map<std::string_view, int32_t, SvHash> contig_map;
+    std::vector<std::string> contig_store(contig_names, contig_names + n_contigs);
+    for (int32_t i = 0; i < n_contigs; ++i)
+        contig_map.emplace(std::string_view(contig_store[i]), i);  // first id wins, like the FASTA scan :77-81
+
+    mc_parsed *P = new mc_parsed();
+    std::unordered_map<std::string, int32_t> read_map;
+    size_t guess = (size_t)((hi - lo) / 100 + 16);
+    P->pos.reserve(guess);
+    P->ev.reserve(guess);
+    P->mu.reserve(guess);
+    P->idx.reserve(guess);
+    P->flags.reserve(guess);
+
+    std::string last_name, last_contig_txt;
+    int32_t last_contig = -2, last_read = -1;
+    bool have_prev = false;
+    int rc = 0;
+
+    const char *p = base + lo, *end = base + hi;
+    Tok t[12];
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        int nt = split12(p, le, t);
+        p = nl ? nl + 1 : end;
+        if (nt < 12) continue;  // :149-152
+
+        // contig (:154-160)
+        int32_t contig;
+        if (last_contig != -2 && t[0].n == last_contig_txt.size() &&
+            memcmp(t[0].p, last_contig_txt.data(), t[0].n) == 0) {
+            contig = last_contig;
+        } else {
+            auto it = contig_map.find(std::string_view(t[0].p, t[0].n));
+            contig = it == contig_map.end() ? -1 : it->second;
+            last_contig_txt.assign(t[0].p, t[0].n);
+            last_contig = contig;
+        }
+        if (contig < 0) {
+            P->unknown.emplace_back(t[0].p, t[0].n);
+            continue;
+        }
+
+        int64_t pos, idx;
+        if (!parse_int(t[1], &pos) || !parse_int(t[5], &idx)) {
+            mc_set_error("invalid literal for int() in eventalign row %lld: '%.*s' / '%.*s'",
+                         (long long)P->pos.size(), (int)t[1].n, t[1].p, (int)t[5].n, t[5].p);
+            rc = -2;
+            break;
+        }
+        if (pos < 0 || pos > 0x7fffffff || idx < -0x7fffffff || idx > 0x7fffffff) {
+            mc_set_error("position/event index out of range in eventalign row %lld", (long long)P->pos.size());
+            rc = -2;
+            break;
+        }
+        int64_t e4, m4;
+        if (!(parse_e4_fast(t[6], &e4) && parse_e4_fast(t[10], &m4) && e4 > -2000000000LL && e4 < 2000000000LL &&
+              m4 > -2000000000LL && m4 < 2000000000LL)) {
+            double e, m;
+            if (!parse_double_slow(t[6], &e) || !parse_double_slow(t[10], &m)) {
+                mc_set_error("could not convert string to float in eventalign row %lld: '%.*s' / '%.*s'",
+                             (long long)P->pos.size(), (int)t[6].n, t[6].p, (int)t[10].n, t[10].p);
+                rc = -2;
+                break;
+            }
+            double r = std::nearbyint((e - m) * 10000.0);  // np.round(x,4) numerator (:286)
+            if (!(std::fabs(r) < 2000000000.0)) {
+                mc_set_error("current difference not representable in eventalign row %lld", (long long)P->pos.size());
+                rc = -2;
+                break;
+            }
+            e4 = (int64_t)r;
+            m4 = 0;
+        }
+
+        uint8_t fl = 0;
+        if (t[2].n == t[9].n && memcmp(t[2].p, t[9].p, t[2].n) == 0) fl |= MC_F_KMER_EQ;
+        if (t[9].n == 6 && memcmp(t[9].p, "NNNNNN", 6) == 0) fl |= MC_F_MODEL_N;
+
+        bool new_name = !have_prev || t[3].n != last_name.size() || memcmp(t[3].p, last_name.data(), t[3].n) != 0;
+        if (new_name) {
+            last_name.assign(t[3].p, t[3].n);
+            auto it = read_map.find(last_name);
+            if (it == read_map.end()) {
+                last_read = (int32_t)P->read_names.size();
+                read_map.emplace(last_name, last_read);
+                P->read_names.push_back(last_name);
+            } else {
+                last_read = it->second;
+            }
+            fl |= MC_F_NAME_START;
+        }
+        if (new_name || P->seg_contig.empty() || P->seg_contig.back() != contig) {
+            fl |= MC_F_SEG_START;
+            P->seg_begin.push_back((int64_t)P->pos.size());
+            P->seg_read.push_back(last_read);
+            P->seg_contig.push_back(contig);
+        }
+        have_prev = true;
+        P->pos.push_back((int32_t)pos);
+        P->idx.push_back((int32_t)idx);
+        P->ev.push_back((int32_t)e4);
+        P->mu.push_back((int32_t)m4);
+        P->flags.push_back(fl);
+    }
+    P->seg_begin.push_back((int64_t)P->pos.size());
+    if (base) munmap((void *)base, (size_t)fsize);
+    if (rc != 0) {
+        delete P;
+        return rc;
+    }
+    *out = P;
+    return 0;
+}
+
+extern "C" int mc_parsed_view(const mc_parsed *p, mc_table_view *out) {
+    out->n_rows = (int64_t)p->pos.size();
+    out->pos = p->pos.data();
+    out->event_e4 = p->ev.data();
+    out->model_e4 = p->mu.data();
+    out->event_idx = p->idx.data();
+    out->flags = p->flags.data();
+    out->n_seg = (int32_t)p->seg_read.size();
+    out->seg_row_begin = p->seg_begin.data();
+    out->seg_read = p->seg_read.data();
+    out->seg_contig = p->seg_contig.data();
+    out->n_reads = (int32_t)p->read_names.size();
+    return 0;
+}
+
+extern "C" const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id) {
+    if (read_id < 0 || (size_t)read_id >= p->read_names.size()) return nullptr;
+    return p->read_names[(size_t)read_id].c_str();
+}
+
+extern "C" int64_t mc_parsed_n_unknown(const mc_parsed *p) { return (int64_t)p->unknown.size(); }
+
+extern "C" const char *mc_parsed_unknown_name(const mc_parsed *p, int64_t i) {
+    if (i < 0 || (size_t)i >= p->unknown.size()) return nullptr;
+    return p->unknown[(size_t)i].c_str();
+}
+
+extern "C" void mc_parsed_free(mc_parsed *p) { delete p; }

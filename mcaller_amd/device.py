@@ -1,0 +1,108 @@
+"""One MI355X: the resident event table, marked reference, read qualities, classifier, and the hot path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, Records, check, lib, make_ref_view, _ptr
+
+
+def default_device_index():
+    for var in ('MCALLER_DEVICE', 'LOCAL_RANK'):
+        if os.environ.get(var, '') != '':
+            return int(os.environ[var])
+    return 0
+
+
+class Device(object):
+    def __init__(self, index=None):
+        self.index = default_device_index() if index is None else int(index)
+        self._ctx = C.c_void_p()
+        check(lib().mc_ctx_create(self.index, C.byref(self._ctx)))
+        self._keep = {}
+
+    def close(self):
+        if self._ctx:
+            lib().mc_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- resident inputs ----
+    def set_reference(self, arrays):
+        v = make_ref_view(arrays)
+        check(lib().mc_ctx_set_reference(self._ctx, C.byref(v)))
+
+    def upload_table(self, table):
+        v = table.view()
+        check(lib().mc_ctx_upload_table(self._ctx, C.byref(v)))
+        self.n_rows = table.n_rows
+
+    def set_read_quality(self, qual):
+        q = np.ascontiguousarray(qual, dtype=np.float64)
+        check(lib().mc_ctx_set_read_quality(self._ctx, _ptr(q), len(q)))
+
+    def set_mlp(self, weights, submodel_of_char):
+        """weights: list of MLPWeights (same shapes); submodel_of_char: uint8[256]."""
+        n_in, n_hidden = weights[0].n_in, weights[0].n_hidden
+        for w in weights:
+            if (w.n_in, w.n_hidden) != (n_in, n_hidden):
+                raise NotImplementedError('sub-models with different shapes')
+        W1 = np.ascontiguousarray(np.stack([w.W1 for w in weights]), dtype=np.float64)
+        b1 = np.ascontiguousarray(np.stack([w.b1 for w in weights]), dtype=np.float64)
+        W2 = np.ascontiguousarray(np.stack([w.W2 for w in weights]), dtype=np.float64)
+        b2 = np.ascontiguousarray(np.concatenate([w.b2 for w in weights]), dtype=np.float64)
+        soc = np.ascontiguousarray(submodel_of_char, dtype=np.uint8)
+        assert soc.shape == (256,)
+        check(lib().mc_ctx_set_mlp(self._ctx, len(weights), n_in, n_hidden, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                   _ptr(soc)))
+
+    # ---- the hot path ----
+    def run(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
+        """K0+K1+K2 on the resident table; records stay on the device.  Returns their number."""
+        p = Params(int(k), int(skip_thresh), float(qual_thresh), int(tail_contig), 1 if score else 0,
+                   int(entry_read), int(entry_first_idx))
+        n = C.c_int64(0)
+        check(lib().mc_extract_features(self._ctx, C.byref(p), C.byref(n)))
+        self._last = (n.value, int(k))
+        return n.value
+
+    def fetch(self):
+        n, k = self._last
+        rec = Records(n, k)
+        v = rec.view()
+        check(lib().mc_fetch_records(self._ctx, C.byref(v)))
+        rec.n = n
+        return rec
+
+    def extract(self, k, skip_thresh, qual_thresh, **kw):
+        self.run(k, skip_thresh, qual_thresh, **kw)
+        return self.fetch()
+
+    def times_ms(self):
+        t = np.zeros(5, dtype=np.float32)
+        check(lib().mc_last_times_ms(self._ctx, _ptr(t)))
+        return dict(strand_resolve=float(t[0]), window_scan=float(t[1]), order=float(t[2]), classifier=float(t[3]),
+                    total=float(t[4]))
+
+    def mlp_forward(self, X, submodel):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        sm = np.ascontiguousarray(submodel, dtype=np.uint8)
+        p = np.empty(len(X), dtype=np.float64)
+        check(lib().mc_mlp_forward(self._ctx, _ptr(X), _ptr(sm), len(X), _ptr(p)))
+        return p
+
+
+_devices = {}
+
+
+def get_device(index=None):
+    index = default_device_index() if index is None else int(index)
+    if index not in _devices:
+        _devices[index] = Device(index)
+    return _devices[index]

@@ -1,0 +1,241 @@
+"""`extract_features` on MI355X: the drop-in for the reference's extract_contexts.py:110-303.
+
+Same signature, same side effects (appends `<tsv minus ext>.diffs.<k>[.train].tmp<startline>`, prints the
+five counter lines, returns `(signals, contexts)` in train mode), same error behaviour (messages +
+`sys.exit(0)`), but the per-row window machine and the per-observation `predict_proba` run as HIP kernels
+behind the C ABI of include/mcaller_hip.h.  The host keeps what is text: FASTA/positions marking
+(refmark.py), the model file (model_io.py), context strings and number formatting.
+
+There is no CPU path here: without libmcaller_hip.so or without a GPU every call raises.
+"""
+import sys
+
+import numpy as np
+
+from . import _lib
+from .device import get_device
+from .model_io import load_model_file
+from .refmark import MarkedReference, revcomp, strand, base_comps, comp  # noqa: F401  (reference names)
+
+_I = _lib
+
+
+def base_models(base, twobase=False):
+    """Sub-model key for a context's two centre characters (extract_contexts.py:99-106)."""
+    if base == 'A' and twobase:
+        return {'MG': 'MG', 'MC': 'MH', 'MA': 'MH', 'MT': 'MH', 'MM': 'MH', 'MH': 'MH', 'AT': 'MH', 'AC': 'MH',
+                'AG': 'MG', 'AA': 'MH', 'AM': 'MH'}
+    base_model = {'M' + nextb: 'general' for nextb in ['A', 'C', 'G', 'T', 'M']}
+    base_model.update({'A' + nextb: 'general' for nextb in ['A', 'C', 'G', 'T', 'M']})
+    base_model.update({'T' + nextb: 'general' for nextb in ['A', 'C', 'G', 'T', 'M']})
+    return base_model
+
+
+def writefi(data, fi):
+    """Append rows to the tmp file (extract_contexts.py:83-86)."""
+    with open(fi, 'a') as outfi:
+        for entry in data:
+            outfi.write('\t'.join(entry) + '\n')
+
+
+def fmt_float(x):
+    """str(np.float64): shortest round-trip repr (what the reference's str(diff) prints)."""
+    return repr(float(x))
+
+
+def round2(p):
+    """np.round(p, 2) (extract_contexts.py:207)."""
+    return float(np.round(np.float64(p), 2))
+
+
+class Prepared(object):
+    """Everything the kernels and the formatter need for one (tsv byte range, reference, marking)."""
+    pass
+
+
+def _lookup_quality(read2qual, name):
+    try:
+        return read2qual[name]                                     # extract_contexts.py:163-166
+    except KeyError:
+        return read2qual[name.split(':')[0].split('_')[0]]
+
+
+def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list, n_threads=0):
+    """Parse + mark: the host-side pre-pass.  Returns a Prepared; `fatal` holds the exception the
+    reference would hit at table row `len(table)` (the table is cut there)."""
+    P = Prepared()
+    ref = MarkedReference(fasta_input, base, motif, positions_list)
+    table = _lib.parse_eventalign(tsv_input, startline, endline, ref.names, n_threads)
+    for name in table.unknown:
+        print('Error: could not find sequence for reference contig', name)       # :159
+    P.fatal = None
+    qual_obj = [None] * table.n_reads
+    cut_seg = None
+    for seg in range(table.n_seg):
+        cid, rid = int(table.seg_contig[seg]), int(table.seg_read[seg])
+        try:
+            if cid not in ref.meth:
+                ref.mark(cid)                                                    # :154-157 (may print + exit)
+            if qual_obj[rid] is None:
+                qual_obj[rid] = _lookup_quality(read2qual, table.read_names[rid])
+        except (SystemExit, Exception) as e:                                     # noqa
+            P.fatal = e
+            cut_seg = seg
+            break
+    if cut_seg is not None:
+        table = table.slice_segments(0, cut_seg)
+    P.ref, P.table, P.qual_obj = ref, table, qual_obj
+    P.qual = np.array([float(q) if q is not None else np.nan for q in qual_obj], dtype=np.float64)
+    return P
+
+
+def submodel_setup(modelset, base):
+    """-> (base_model table, [weights...], key -> index, uint8[256] context[k] char -> index or 255)."""
+    table = base_models(base, modelset.twobase)
+    keys = modelset.keys()
+    index = {key: i for i, key in enumerate(keys)}
+    soc = np.full(256, 255, dtype=np.uint8)
+    for c in range(256):
+        two = 'M' + chr(c)
+        if two in table and table[two] in index:
+            soc[c] = index[table[two]]
+    return table, [modelset.models[key] for key in keys], index, soc
+
+
+def compute(P, k, skip_thresh, qual_thresh, modelset, base, train, device=None, tail_contig=-1):
+    """Upload + run the HIP path.  Returns (records, info dict)."""
+    dev = device if device is not None else get_device()
+    dev.set_reference(P.ref.device_arrays())
+    dev.upload_table(P.table)
+    dev.set_read_quality(P.qual)
+    if not train:
+        _, weights, _, soc = submodel_setup(modelset, base)
+        dev.set_mlp(weights, soc)
+    rec = dev.extract(k, skip_thresh, qual_thresh, tail_contig=tail_contig, score=not train)
+    return rec
+
+
+class Finisher(object):
+    """Flush records -> the reference's rows, counters and train dicts, in record (= file) order."""
+
+    def __init__(self, P, k, base, train, modelset=None, pos_label=None, device=None, tail_chrom=None):
+        self.P, self.k, self.base, self.train = P, k, base, train
+        self.pos_label = pos_label
+        self.device = device
+        self.tail_chrom = tail_chrom
+        if not train:
+            self.table, _, self.model_index, _ = submodel_setup(modelset, base)
+            self.model_keys = modelset.keys()
+        else:
+            self.table = base_models(base, False)                                 # :133
+            self.model_keys = None
+        self.signals = {bm: {} for bm in self.table.values()} if train else None
+        self.contexts = {bm: {} for bm in self.table.values()} if train else None
+        self.rows = []          # every emitted row, in order
+        self.num_observations = 0
+        self.pos_set, self.multi, self.w_skips, self.skipped = set(), set(), set(), set()
+
+    def counters(self):
+        return ['thread finished processing...:', '%d observations' % self.num_observations,
+                '%d positions' % len(self.pos_set), '%d regions with multiple methylated bases' % len(self.multi),
+                '%d observations with skips included' % len(self.w_skips),
+                '%d observations with too many skips' % len(self.skipped)]
+
+    def run(self, rec):
+        """Returns None, or the exception (SystemExit / error) the reference would raise at that record."""
+        P, k, t = self.P, self.k, self.P.table
+        n = rec.n
+        feats = rec.feats[:n * k].reshape(n, k)
+        info = rec.info[:n]
+        site_pos = rec.site_pos[:n]
+        seg_of = rec.site_seg[:n]
+        close_seg = np.searchsorted(t.seg_row_begin, rec.close_row[:n], side='right') - 1
+        names = t.read_names
+        half = int((2 * k - 1) / 2)
+        for j in range(n):
+            inf = int(info[j])
+            seg = int(seg_of[j])
+            rid = int(t.seg_read[seg])
+            read, mpos = names[rid], int(site_pos[j])
+            rev = bool(inf & _I.I_REV)
+            if inf & _I.I_TOO_MANY:
+                self.skipped.add((read, mpos))                                    # :239
+            else:
+                empty = inf & _I.I_EMPTY_MASK
+                if empty:
+                    self.w_skips.add((read, mpos))                                # :184-185
+                diffs = [0 if (empty >> i) & 1 else float(feats[j, i]) for i in range(k)]
+                qual = P.qual_obj[rid]
+                diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[j, i]) for i in range(k)]
+                                     + [str(qual)])
+                cseg = int(close_seg[j])
+                chrom = self.tail_chrom if cseg >= t.n_seg else P.ref.names[int(t.seg_contig[cseg])]
+                last_ref = P.ref.meth[int(t.seg_contig[seg])][1 if rev else 0]
+                context = revcomp(last_ref[mpos - k + 1:mpos + k], rev)           # :194 (Python slicing rules)
+                line = read + '\t' + str(mpos) + '\t' + context + '\t' + diffs_txt + '\t' + strand(rev)
+                centre = int(len(context) / 2)
+                if context[centre] == 'M':                                        # IndexError propagates, as there
+                    try:
+                        twobase_model = self.table[context[centre:centre + 2]]
+                        if not self.train:
+                            mi = self.model_index[twobase_model]                  # KeyError: model[...] :199
+                            p1 = rec.prob[j]
+                            want = (inf >> _I.I_NEXT_SHIFT) & 0xFF
+                            if (inf & _I.I_EDGE) or np.isnan(p1):
+                                dev = self.device if self.device is not None else get_device()
+                                p1 = dev.mlp_forward(np.array([diffs + [float(qual)]], dtype=np.float64),
+                                                     np.array([mi], dtype=np.uint8))[0]
+                            elif len(context) > half + 1 and ord(context[half + 1]) != want:
+                                raise AssertionError('device and host disagree on the sub-model of %s' % line)
+                            if p1 >= 0.5:
+                                label = 'm6A' if self.base == 'A' else 'm' + self.base
+                            else:
+                                label = self.base
+                            label = label + '\t' + fmt_float(round2(p1))          # :207
+                        else:
+                            label = self.pos_label[(chrom, mpos, strand(rev))]    # :210
+                            self.signals[twobase_model].setdefault(label, []).append(diffs + [qual])
+                            self.contexts[twobase_model].setdefault(label, []).append(context)
+                        self.rows.append([chrom, read, str(mpos), context, diffs_txt, strand(rev), label])
+                    except (IndexError, KeyError) as e:                           # :218-223
+                        print(line, '- Index or Key Error')
+                        print(list(self.model_keys or []), list(self.table.keys()), context[centre:centre + 2])
+                        print(e)
+                        return SystemExit(0)
+                else:                                                             # :224-228
+                    print(line)
+                    return SystemExit(0)
+                self.num_observations += 1
+                self.pos_set.add(mpos)
+            if inf & _I.I_MULTI:
+                self.multi.add((read, mpos))                                      # :247-248
+        return None
+
+
+def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, classifier,
+                     startline, endline=None, train=False, pos_label=None, base=None, motif=None,
+                     positions_list=None):
+    """Drop-in for extract_contexts.py:110 (see module docstring)."""
+    suffix = '.diffs.' + str(k) + ('.train' if train else '') + '.tmp' + str(startline)
+    tsv_output = '.'.join(tsv_input.split('.')[:-1]) + suffix                     # :122 / :134
+    modelset = None
+    if not train:
+        modelset = load_model_file(modelfile)                                     # :123-130
+
+    P = prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list)
+    rec = compute(P, k, skip_thresh, qual_thresh, modelset, base, train)
+    fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label)
+    stop = fin.run(rec)
+    if stop is None and P.fatal is not None:
+        stop = P.fatal
+    if stop is not None:
+        # the reference dies mid-file: only the 5000-row batches already flushed are on disk (:230-232)
+        n_written = (fin.num_observations // 5000) * 5000
+        writefi(fin.rows[:n_written], tsv_output)
+        raise stop
+    writefi(fin.rows, tsv_output)                                                 # :293
+
+    for line in fin.counters():                                                   # :295-301
+        print(line)
+    if train:
+        return fin.signals, fin.contexts

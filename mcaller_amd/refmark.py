@@ -1,0 +1,154 @@
+"""Reference marking on the host: the pre-pass that builds what the kernels read.
+
+Mirrors extract_contexts.py:33-81 (methylate_motifs / methylate_positions / methylate_references /
+find_and_methylate): per contig, two copies of the upper-cased sequence in which the target bases are
+replaced by 'M' -- `meth_fwd` (motif, base) and `meth_rev` (revcomp(motif), complement base), or the
+positions listed for '+' / '-' in the positions file.  The strings are kept (the 2k-1 context of every
+call is sliced from them, :194) and turned into the per-strand bitmasks of `mc_ref_view`.
+"""
+import sys
+
+import numpy as np
+
+base_comps = {'A': 'T', 'C': 'G', 'T': 'A', 'G': 'C', 'N': 'N', 'M': 'M'}     # extract_contexts.py:11
+
+
+def comp(seq):
+    return ''.join([base_comps[nt] for nt in seq])
+
+
+def revcomp(seq, rev=True):
+    if not rev:
+        return seq
+    return comp(seq)[::-1]
+
+
+def strand(rev):
+    return '-' if rev else '+'
+
+
+def read_fasta(path):
+    """[(id, sequence)] in file order; id = first token of the title line (what Bio.SeqIO yields)."""
+    records, name, chunks = [], None, []
+    with open(path, 'r') as fh:
+        for line in fh:
+            if line.startswith('>'):
+                if name is not None:
+                    records.append((name, ''.join(chunks)))
+                title = line[1:].rstrip()
+                parts = title.split(None, 1)
+                name = parts[0] if parts else ''
+                chunks = []
+            elif name is not None:
+                chunks.append(line.strip().replace(' ', '').replace('\r', ''))
+    if name is not None:
+        records.append((name, ''.join(chunks)))
+    return records
+
+
+def methylate_motifs(ref_seq, motif, meth_base):
+    """extract_contexts.py:33-41 (meth_position=None): left-to-right, non-overlapping."""
+    return ref_seq.replace(motif, 'M'.join(motif.split(meth_base)))
+
+
+def methylate_positions(ref_seq, positions, meth_base):
+    """extract_contexts.py:45-56; prints and exits like the reference on a wrong base."""
+    buf = bytearray(ref_seq, 'latin1')
+    b, m = ord(meth_base), ord('M')
+    for pos in positions:
+        if pos < 0:
+            raise NotImplementedError('negative position %d in the positions file' % pos)
+        if buf[pos] == b or buf[pos] == m:          # IndexError past the contig end, like the reference
+            buf[pos] = m
+        else:
+            print('Base {} does not correspond to methylated base - check reference positions are 0-based'
+                  ' - quitting thread now'.format(pos))
+            sys.exit(0)
+    return buf.decode('latin1')
+
+
+def _positions_for(positions, contig, strand_char):
+    out = []
+    for line in open(positions, 'r').read().split('\n'):
+        t = line.split()
+        if len(t) > 1 and t[2] == strand_char and t[0] == contig:
+            out.append(int(t[1]))
+    return out
+
+
+def methylate_references(ref_seq, base, motif=None, positions=None, train=False, contig=None):
+    """extract_contexts.py:60-73 -> (meth_fwd, meth_rev)."""
+    if not positions and motif:
+        meth_fwd = methylate_motifs(ref_seq, motif, base)
+        meth_rev = methylate_motifs(ref_seq, revcomp(motif), base_comps[base])
+    elif positions:
+        meth_fwd = methylate_positions(ref_seq, _positions_for(positions, contig, '+'), base)
+        meth_rev = methylate_positions(ref_seq, _positions_for(positions, contig, '-'), base_comps[base])
+    else:
+        print('no motifs or positions specified')
+        sys.exit(0)
+    return meth_fwd, meth_rev
+
+
+def m_bitmask(meth, pad_words=2):
+    """bit p of the little-endian u32 array is set <=> meth[p] == 'M'; zero padding at the end."""
+    raw = np.frombuffer(meth.encode('latin1'), dtype=np.uint8)
+    packed = np.packbits(raw == ord('M'), bitorder='little')
+    n_words = (len(meth) + 31) // 32 + pad_words
+    out = np.zeros(n_words * 4, dtype=np.uint8)
+    out[:len(packed)] = packed
+    return out.view('<u4')
+
+
+class MarkedReference(object):
+    """Contig table + marked strings for the contigs a table touches (marked on first use, in the
+    order the reference would load them: extract_contexts.py:154-157)."""
+
+    def __init__(self, fasta_path, base, motif, positions_list):
+        self.records = read_fasta(fasta_path)
+        self.names = [r[0] for r in self.records]
+        self.base, self.motif, self.positions_list = base, motif, positions_list
+        self.meth = {}                                  # contig id -> (meth_fwd, meth_rev)
+
+    def first_index(self):
+        idx = {}
+        for i, n in enumerate(self.names):
+            idx.setdefault(n, i)                        # first record with that id wins (:77-81)
+        return idx
+
+    def mark(self, contig_id):
+        if contig_id not in self.meth:
+            name, seq = self.records[contig_id]
+            self.meth[contig_id] = methylate_references(seq.upper(), self.base, motif=self.motif,
+                                                        positions=self.positions_list, contig=name)
+        return self.meth[contig_id]
+
+    def device_arrays(self):
+        """Concatenated arrays for mc_ref_view (unmarked contigs: empty sequence, all-zero masks)."""
+        n = len(self.records)
+        contig_len = np.zeros(n, dtype=np.int64)
+        seq_off = np.zeros(n, dtype=np.int64)
+        word_off = np.zeros(n, dtype=np.int64)
+        seqs, fw, rv = [], [], []
+        so = wo = 0
+        for cid in range(n):
+            seq_off[cid], word_off[cid] = so, wo
+            if cid in self.meth:
+                mf, mr = self.meth[cid]
+                s = np.frombuffer(self.records[cid][1].upper().encode('latin1'), dtype=np.uint8)
+                contig_len[cid] = len(s)
+                bf, br = m_bitmask(mf), m_bitmask(mr)
+                if len(bf) != len(br):                  # cannot happen: both come from one sequence
+                    raise AssertionError('marked strands differ in length')
+            else:
+                s = np.zeros(0, dtype=np.uint8)
+                bf = br = np.zeros(2, dtype='<u4')
+            seqs.append(s)
+            fw.append(bf)
+            rv.append(br)
+            so += len(s)
+            wo += len(bf)
+        cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0, dt), dtype=dt)
+        return dict(contig_len=contig_len, seq_off=seq_off, word_off=word_off,
+                    seq=cat(seqs + [np.zeros(8, np.uint8)], np.uint8),
+                    mbits_fwd=cat(fw, np.uint32), mbits_rev=cat(rv, np.uint32))

@@ -1,0 +1,132 @@
+"""Host pipeline (native parser -> marking -> [records] -> formatter) against the golden fixtures, with the C
+oracle standing in for the GPU as the producer of flush records.  This pins (a) the C oracle to the reference's
+outputs and (b) every host-side piece the HIP path shares: parser, bitmasks, context slicing, number formatting,
+counters, exit paths.  No GPU needed."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def run_with_oracle(paths, args, out_dir):
+    """What mcaller_amd.extract_contexts.extract_features does, with oracle records instead of device records."""
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    read2qual = extract_read_quality(paths['fastq'])
+    k, train, base = args['k'], args['train'], args['base']
+    modelset = None if train else H.load_modelset(args['model'])
+    buf = io.StringIO()
+    outcome, fin = 'ok', None
+    with contextlib.redirect_stdout(buf):
+        try:
+            P = ec.prepare(paths['tsv'], paths['fasta'], read2qual, 0, os.path.getsize(paths['tsv']), base,
+                           args['motif'], paths['positions'])
+            rec = H.oracle_records(P.table, P.ref.device_arrays(), P.qual, k, args['skip_thresh'], args['qual_thresh'])
+            if not train:
+                _, weights, _, soc = ec.submodel_setup(modelset, base)
+                H.oracle_score(rec, P.table, P.qual, weights, soc, k)
+
+            class _NoDev(object):
+                def mlp_forward(self, X, sub):
+                    raise AssertionError('edge records need the device classifier')
+            fin = ec.Finisher(P, k, base, train, modelset=modelset,
+                              pos_label=H.pos2label(paths['positions']) if (train and paths['positions']) else None,
+                              device=_NoDev())
+            stop = fin.run(rec)
+            if stop is None and P.fatal is not None:
+                stop = P.fatal
+            if stop is not None:
+                outcome = 'exit' if isinstance(stop, SystemExit) else 'crash:' + type(stop).__name__
+                rows = fin.rows[:(fin.num_observations // 5000) * 5000]
+            else:
+                rows = fin.rows
+                for line in fin.counters():
+                    print(line)
+        except Exception as e:                         # noqa
+            outcome = 'crash:' + type(e).__name__
+            rows = []
+    text = ''.join('\t'.join(r) + '\n' for r in rows)
+    return outcome, text, [l for l in buf.getvalue().split('\n') if l.strip()], fin
+
+
+@pytest.fixture(scope='module')
+def td(tmp_path_factory):
+    return H.testdata_paths(str(tmp_path_factory.mktemp('testdata')))
+
+
+@pytest.mark.parametrize('tag,kw,model,skip', [
+    ('config1_positions_m6A', dict(positions='test_positions_m6A.txt'), 'r95', 0),
+    ('motif_GATC', dict(motif='GATC'), 'r95', 0),
+    ('motif_A', dict(motif='A'), 'r95', 0),
+    ('positions_all', dict(positions='test_positions.txt'), 'r95', 0),
+    ('motif_GATC_s1', dict(motif='GATC'), 'r95', 1),
+    ('motif_A_r94', dict(motif='A'), 'r94', 0),
+])
+def test_testdata_against_reference_outputs(td, tag, kw, model, skip, tmp_path):
+    paths = dict(tsv=td['tsv'], fasta=td['fasta'], fastq=td['fastq'],
+                 positions=td[kw['positions']] if 'positions' in kw else None)
+    args = dict(k=6, skip_thresh=skip, qual_thresh=0, base='A', motif=kw.get('motif'), train=False, model=model)
+    outcome, text, stdout, _ = run_with_oracle(paths, args, str(tmp_path))
+    assert outcome == 'ok'
+    ref = open(os.path.join(H.GOLDEN, 'ref_outputs', tag + '.diffs.6')).read()
+    assert text == ref
+    ref_stdout = open(os.path.join(H.GOLDEN, 'ref_outputs', tag + '.stdout')).read().split('\n')
+    for line in stdout:
+        assert line in ref_stdout
+
+
+def test_reference_own_golden_columns(td, tmp_path):
+    """The reference's own golden diffs.6 (README.md:132): columns 1-6 byte-for-byte (7-8 are stale there)."""
+    paths = dict(tsv=td['tsv'], fasta=td['fasta'], fastq=td['fastq'], positions=td['test_positions_m6A.txt'])
+    args = dict(k=6, skip_thresh=0, qual_thresh=0, base='A', motif=None, train=False, model='r95')
+    _, text, _, _ = run_with_oracle(paths, args, str(tmp_path))
+    gold = open(os.path.join(H.GOLDEN, 'testdata', 'masonread1.eventalign.diffs.6')).read()
+    mine = ['\t'.join(l.split('\t')[:6]) for l in text.strip().split('\n')]
+    theirs = ['\t'.join(l.split('\t')[:6]) for l in gold.strip().split('\n')]
+    assert mine == theirs
+
+
+def test_train_dicts(td, tmp_path):
+    import json
+    paths = dict(tsv=td['tsv'], fasta=td['fasta'], fastq=td['fastq'], positions=td['test_positions.txt'])
+    args = dict(k=6, skip_thresh=0, qual_thresh=0, base='A', motif=None, train=True, model='r95')
+    outcome, text, stdout, fin = run_with_oracle(paths, args, str(tmp_path))
+    assert outcome == 'ok'
+    assert text == open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.diffs.6.train')).read()
+    gold = json.load(open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.dicts.json')))
+    assert H.plain_signals(fin.signals) == gold['signals']
+    assert fin.contexts == gold['contexts']
+    ref_stdout = open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.stdout')).read().split('\n')
+    for line in stdout:
+        assert line in ref_stdout
+
+
+def test_micro_cases(tmp_path):
+    bad = []
+    cases = H.micro_cases()
+    for case in cases:
+        d = tmp_path / ('c%d' % case['seed'])
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        outcome, text, stdout, fin = run_with_oracle(paths, case['args'], str(d))
+        exp = case['expected']
+        exp_bad, got_bad = exp['outcome'] != 'ok', outcome != 'ok'
+        if exp_bad != got_bad:
+            bad.append((case['seed'], case['flavour'], 'outcome', exp['outcome'], outcome))
+            continue
+        if exp_bad:
+            if not outcome.startswith('crash') and (exp['text'] or '') != text:
+                bad.append((case['seed'], case['flavour'], 'partial text'))
+            continue
+        if (exp['text'] or '') != text:
+            bad.append((case['seed'], case['flavour'], 'text'))
+        elif exp['stdout'] != stdout:
+            bad.append((case['seed'], case['flavour'], 'stdout', exp['stdout'], stdout))
+        elif exp['train'] is not None:
+            if H.plain_signals(fin.signals) != exp['train']['signals'] or fin.contexts != exp['train']['contexts']:
+                bad.append((case['seed'], case['flavour'], 'train dicts'))
+    assert not bad, '%d of %d micro-cases differ: %s' % (len(bad), len(cases), bad[:10])
