@@ -290,13 +290,13 @@ struct RowSrc {   // where a walker reads rows from: LDS inside the tile, HBM/L2
     const uint8_t *s_fl;
     const int32_t *g_pos, *g_ev, *g_mu;
     const uint8_t *g_flags;
-    int64_t t0;
+    int64_t t0, t1;      // rows [t0, t1) are in LDS
 };
 
 // rows are only ever walked inside the name block of a row that passed the quality filter, so "valid"
 // (:167-168) reduces to model_kmer != NNNNNN
 __device__ __forceinline__ void row_get(const RowSrc &S, int64_t r, bool &valid, int32_t &pos, int32_t &d) {
-    if (r >= S.t0) {
+    if (r >= S.t0 && r < S.t1) {
         const int i = (int)(r - S.t0);
         valid = !(S.s_fl[i] & MC_F_MODEL_N);
         pos = S.s_pos[i];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
 
     // ---- pass 3: emission, one thread per closed window, rows read back from LDS ----
     const int64_t base = s_base;
-    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0};
+    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0, t1};
     for (int q = tid; q < total; q += NTHREADS) {
         const int64_t slot = base + q;
         if (slot >= A.U.capacity) { atomicOr(&A.cnt->overflow, 1u); continue; }
@@ -639,7 +639,7 @@ __global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
         if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
     }
     const NbDesc d = A.desc[lo];
-    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, (int64_t)1 << 62};
+    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, 0, 0};
     // last row of the window: the last unfiltered row of the block before the closing row
     int64_t r = min(O.close_row[j], T.nb_row_begin[lo + 1]) - 1;
     const int64_t lb = max(d.row_begin, d.f0);
