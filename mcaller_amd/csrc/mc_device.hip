@@ -58,15 +58,20 @@ enum : uint8_t { MODE_NONE = 0, MODE_REGULAR = 1, MODE_IRREGULAR = 2 };
 // validation flags per name block (k_validate)
 constexpr uint32_t V_POS_DEC = 1, V_IDX_INC = 2, V_IDX_DEC = 4, V_IDX_EQ = 8, V_POS0 = 16, V_MULTI_SEG = 32;
 
+constexpr int32_t NO_STRAY = INT32_MIN;
+
 struct __attribute__((aligned(16))) NbDesc {
     int64_t row_begin;
-    int64_t f0;        // first site row of the block (regular blocks); INT64_MAX: none
+    int64_t first;      // rows >= first are tested on the block's strand (regular blocks); window walks stop here
+    int64_t extra_row;  // row of the one-event '+' window a reverse read opens on a palindromic k-mer (R5), or -1
     int32_t contig;
     int32_t read;
-    uint8_t mode, rev, filtered, pad0;
-    int32_t pad1;
+    int32_t stray_q;    // pseudo-position of that event once the strand flips (:276-277), NO_STRAY if none
+    int32_t stray_d;    // its value, (event - model) in 1e-4 pA
+    int32_t extra_mpos; // site of the '+' window
+    uint8_t mode, rev, filtered, extra_multi;
 };
-static_assert(sizeof(NbDesc) == 32, "NbDesc layout");
+static_assert(sizeof(NbDesc) == 48, "NbDesc layout");
 
 struct DevTable {
     int64_t n_rows = 0;
@@ -191,7 +196,7 @@ __global__ void k_tile_nb(DevTable T) {
 // (`read_name != last_read`, :161-174) each unfiltered row is tested on the strand `rev = (col3 != col10)`;
 // the first row that holds an 'M' in its k-mer becomes the block's first site row f0.
 __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
-                              NbDesc *__restrict__ desc, int32_t *__restrict__ nb_f0idx,
+                              NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
                               int32_t *__restrict__ nb_lastidx) {
     const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -230,31 +235,52 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
     if (lane == 0) {
         NbDesc d;
         d.row_begin = T.nb_row_begin[b];
-        d.f0 = f0;
+        d.first = f0;
+        d.extra_row = -1;
         d.contig = T.seg_contig[T.nb_seg_begin[b]];
         d.read = read;
+        d.stray_q = NO_STRAY;
+        d.stray_d = 0;
+        d.extra_mpos = 0;
         d.mode = MODE_NONE;
         d.rev = (uint8_t)f0rev;
         d.filtered = filtered ? 1 : 0;
-        d.pad0 = 0;
-        d.pad1 = 0;
+        d.extra_multi = 0;
         desc[b] = d;
+        nb_f0[b] = f0;
         nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
         nb_lastidx[b] = T.idx[T.nb_row_begin[b + 1] - 1];
     }
 }
 
 // One thread per name block: is the block regular?
-__global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, int entry_read, Counters *cnt) {
+//
+// Regular = the sequential machine reduces to the local window rule: the read name is new
+// (`last_read` differs when the block starts), one contig, positions non-decreasing, event indices strictly
+// monotone, and every row after the first site row f0 takes the strand f0 was tested on.  One irregularity is
+// common enough (~1 % of reads) to be folded into the fast path exactly: a reverse read whose f0 is a
+// reverse-complement-palindromic k-mer (R5).  f0 is then scored on '+', opening a one-event '+' window; the
+// rows after it are all '-' (event index decreasing, :169).  What the machine does with that event depends only
+// on the next unfiltered row r1 (:179, :242-256, :272-279):
+//   pos(r1) >  site of the '+' window: the window is flushed with k-1 empty slots (a too-many-skips record);
+//              if r1 continues the chain (a '-' site row within skip_thresh+1) the event shifts with the slots
+//              and stays at its own position p, else it is dropped;
+//   pos(r1) <= site: if r1 is a '-' site row the strand flips, mpos is re-set to r1's site but the slots are
+//              kept: the event now sits at pseudo-position pos(r1)+o_r-o_f; else everything is cleared.
+// From then on the block behaves as a regular '-' block starting at f0+1 with one extra event, first in its
+// slot, at that (pseudo-)position.
+__global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, const int64_t *__restrict__ nb_f0,
+                            int entry_read, int k, int skip_thresh, Counters *cnt) {
     const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
     if (b >= T.n_nb) return;
     NbDesc d = desc[b];
+    const int64_t f0 = nb_f0[b];
     // `last_read` when the block starts = name of the latest earlier block that has a site row (:282)
     bool h1 = false;
     if (T.nb_repeat[b] || entry_read >= 0) {
         int j = b - 1;
-        while (j >= 0 && desc[j].f0 < 0) --j;
-        const int last_read = j >= 0 ? desc[j].read : entry_read;
+        while (j >= 0 && nb_f0[j] < 0) --j;
+        const int last_read = j >= 0 ? T.nb_read[j] : entry_read;
         h1 = (last_read == d.read);
     }
     uint8_t mode = MODE_NONE;
@@ -262,21 +288,52 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, int
         mode = MODE_NONE;                                 // every row fails :167, nothing else reads them
     } else if (h1) {
         mode = MODE_IRREGULAR;                            // rows see name == last_read: literal machine
-    } else if (d.f0 >= 0) {
+    } else if (f0 >= 0) {
         const uint32_t vf = T.nb_vflags[b];
         bool regular = !(vf & (V_POS_DEC | V_IDX_EQ | V_MULTI_SEG));
         const bool inc = vf & V_IDX_INC, dec = vf & V_IDX_DEC;
         if (inc && dec) regular = false;
-        // rows after f0 take rev = !(idx > idx[f0]) (:169): must equal the strand f0 was tested on
+        // rows after f0 take rev = !(idx > idx[f0]) (:169)
         if (inc && d.rev) regular = false;
-        if (dec && !d.rev) regular = false;
-        if (vf & V_POS0) {   // a site at contig position 0 has a falsy mpos (:179, :272, :279)
-            const uint32_t *bits = (d.rev ? R.mr : R.mf) + R.word_off[d.contig];
-            if (R.contig_len[d.contig] > 0 && (bits[0] & 1u)) regular = false;
+        const uint32_t *mf = R.mf + R.word_off[d.contig], *mr = R.mr + R.word_off[d.contig];
+        const int64_t L = R.contig_len[d.contig];
+        if ((vf & V_POS0) && L > 0 && ((mf[0] | mr[0]) & 1u)) regular = false;   // falsy mpos (:179,:272,:279)
+        if (regular && dec && !d.rev) {
+            if (k < 2) {
+                regular = false;
+            } else {
+                // palindromic first site row of a reverse read
+                const int p = T.pos[f0];
+                const int o_f = first_m(mf, L, p, k);
+                const int mpos_f = p + o_f;
+                int64_t r1 = f0 + 1;
+                const int64_t re = T.nb_row_begin[b + 1];
+                while (r1 < re && (T.flags[r1] & MC_F_MODEL_N)) ++r1;
+                d.first = f0 + 1;
+                d.rev = 1;
+                d.stray_d = T.ev[f0] - T.mu[f0];
+                d.extra_mpos = mpos_f;
+                if (r1 >= re) {
+                    d.extra_row = f0;                       // closed by the next read (or lost at EOF)
+                } else {
+                    const int p1 = T.pos[r1];
+                    const int o_r = first_m(mr, L, p1, k);
+                    if (p1 >= mpos_f + 1) {
+                        d.extra_row = f0;
+                        if (o_r >= 0 && p1 <= mpos_f + skip_thresh + 1) {
+                            d.extra_multi = o_r != 0;
+                            if (p1 + o_r - p < k) d.stray_q = p;
+                        }
+                    } else if (o_r >= 0) {
+                        d.stray_q = p1 + o_r - o_f;
+                    }
+                }
+            }
         }
         mode = regular ? MODE_REGULAR : MODE_IRREGULAR;
     }
-    desc[b].mode = mode;
+    d.mode = mode;
+    desc[b] = d;
     if (mode == MODE_IRREGULAR) atomicAdd(&cnt->n_irregular, 1u);
 }
 
@@ -291,6 +348,8 @@ struct RowSrc {   // where a walker reads rows from: LDS inside the tile, HBM/L2
     const int32_t *g_pos, *g_ev, *g_mu;
     const uint8_t *g_flags;
     int64_t t0, t1;      // rows [t0, t1) are in LDS
+    bool stray_pending;  // the next value handed out is the block's stray event (R5), not a row
+    double stray_val;
 };
 
 // rows are only ever walked inside the name block of a row that passed the quality filter, so "valid"
@@ -308,7 +367,11 @@ __device__ __forceinline__ void row_get(const RowSrc &S, int64_t r, bool &valid,
     }
 }
 
-__device__ __forceinline__ double next_val(const RowSrc &S, int64_t &cur) {
+__device__ __forceinline__ double next_val(RowSrc &S, int64_t &cur) {
+    if (S.stray_pending) {
+        S.stray_pending = false;
+        return S.stray_val;
+    }
     for (;;) {
         bool v;
         int32_t p, d;
@@ -321,7 +384,7 @@ __device__ __forceinline__ double next_val(const RowSrc &S, int64_t &cur) {
 // NumPy pairwise_sum over the next n values, n <= 128 (np.mean, :186): n < 8 sequential from -0.0;
 // else eight strided accumulators over the first n - n%8 values, combined pairwise, tail added in order.
 // (Values are never -0.0 -- they are integer/1e4 -- so starting the accumulators at +0.0 is exact.)
-__device__ __forceinline__ double leaf_sum(const RowSrc &S, int64_t &cur, int n) {
+__device__ __forceinline__ double leaf_sum(RowSrc &S, int64_t &cur, int n) {
     const int n8 = n < 8 ? 0 : n - (n % 8);
     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
     for (int i = 0; i < n8; ++i) {
@@ -353,52 +416,75 @@ struct K1Args {
     int k, skip_thresh, tail_contig;
 };
 
+// The row that closes a window whose last row is r: the next unfiltered row in the file (:179).  Returns its
+// index (T.n_rows when it lies in the next shard, -1 when there is none: lost at EOF, R6).
+__device__ __forceinline__ int64_t find_close(const K1Args &A, const RowSrc &S, int nb_abs, int64_t r, int &close_pos,
+                                              bool &close_ns) {
+    const DevTable &T = A.T;
+    int64_t rr = r + 1;
+    int bb = nb_abs;
+    const int64_t my_end = T.nb_row_begin[nb_abs + 1];
+    close_ns = false;
+    close_pos = 0;
+    while (rr < T.n_rows) {
+        if (rr < my_end) {                          // still my name block: valid <=> not an N row
+            bool v; int32_t p, dd;
+            row_get(S, rr, v, p, dd);
+            if (v) { close_pos = p; return rr; }
+            ++rr;
+            continue;
+        }
+        close_ns = true;                            // another read begins: closes whatever its position
+        while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
+        if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }   // skip the read whole
+        if (!(T.flags[rr] & MC_F_MODEL_N)) { close_pos = T.pos[rr]; return rr; }
+        ++rr;
+    }
+    close_ns = true;
+    return A.tail_contig >= 0 ? T.n_rows : -1;
+}
+
+__device__ __forceinline__ void write_tombstone(const K1Args &A, int64_t slot, int m) {
+    A.U.site_seg[slot] = -1;         // dropped by the ordering pass
+    A.U.info[slot] = 0;
+    A.U.close_row[slot] = -1;
+    A.U.site_pos[slot] = m;
+}
+
+// The one-event '+' window a reverse read opens on a palindromic first site row (R5): flushed with k-1 empty slots.
+__device__ __forceinline__ void emit_extra(const K1Args &A, const RowSrc &S, const NbDesc &d, int nb_abs, int64_t slot) {
+    int close_pos;
+    bool close_ns;
+    const int64_t close_row = find_close(A, S, nb_abs, d.extra_row, close_pos, close_ns);
+    if (close_row < 0) { write_tombstone(A, slot, d.extra_mpos); return; }
+    for (int s = 0; s < A.k; ++s) A.U.feats[slot * A.k + s] = 0.0;
+    A.U.site_pos[slot] = d.extra_mpos;
+    A.U.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
+    A.U.close_row[slot] = close_row;
+    A.U.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi) ? MC_I_MULTI : 0u);
+}
+
 // Record for the window of site m whose last row is r (global), in name block `d`.
-__device__ __forceinline__ void emit_record(const K1Args &A, const RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
-                                            int m, int64_t t1, int64_t slot) {
+__device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
+                                            int m, int64_t slot) {
     const DevTable &T = A.T;
     const int k = A.k;
     const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
     const int64_t L = A.R.contig_len[d.contig];
 
-    // ---- the closing row: next unfiltered row in the file (:179) ----
-    int64_t close_row = -1;
-    int close_pos = 0;
-    bool close_ns = false;
-    {
-        int64_t rr = r + 1;
-        int bb = nb_abs;
-        const int64_t my_end = T.nb_row_begin[nb_abs + 1];
-        while (rr < T.n_rows) {
-            if (rr < my_end) {                          // still my name block: valid <=> not an N row
-                bool v; int32_t p, dd;
-                row_get(S, rr, v, p, dd);
-                if (v) { close_row = rr; close_pos = p; break; }
-                ++rr;
-                continue;
-            }
-            close_ns = true;                            // another read begins: closes whatever its position
-            while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
-            if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }   // skip the read whole
-            if (!(T.flags[rr] & MC_F_MODEL_N)) { close_row = rr; close_pos = T.pos[rr]; break; }
-            ++rr;
-        }
-        if (close_row < 0 && A.tail_contig >= 0) { close_row = T.n_rows; close_ns = true; }
-    }
-    (void)t1;
+    int close_pos;
+    bool close_ns;
+    const int64_t close_row = find_close(A, S, nb_abs, r, close_pos, close_ns);
     const bool closes = close_row >= 0 && (close_ns || close_pos > m);
     if (!closes) {                   // not the last row of its window after all, or lost at EOF (R6)
-        A.U.site_seg[slot] = -1;     // tombstone, dropped by the ordering pass
-        A.U.info[slot] = 0;
-        A.U.close_row[slot] = -1;
-        A.U.site_pos[slot] = m;
+        write_tombstone(A, slot, m);
         return;
     }
     uint32_t info = d.rev ? MC_I_REV : 0u;
 
-    // ---- window rows: back to the first row at position >= m-k+1 (never before f0 / the block start) ----
+    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first / the block start) ----
     // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
-    const int64_t lb = max(d.row_begin, d.f0);
+    const int64_t lb = max(d.row_begin, d.first);
     unsigned long long cnt8 = 0;
     bool big = false;
     int64_t ws = r;
@@ -411,6 +497,16 @@ __device__ __forceinline__ void emit_record(const K1Args &A, const RowSrc &S, co
         if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
         else cnt8 += 1ull << sh;
         ws = rr;
+    }
+    // the stray event of a palindromic first site row: first in the slot of its pseudo-position
+    int stray_slot = -1;
+    if (d.stray_q != NO_STRAY) {
+        const int sq = m - d.stray_q;
+        if (sq >= 0 && sq < k) {
+            stray_slot = sq;
+            if (((cnt8 >> (8 * sq)) & 0xFFull) >= 128ull) big = true;
+            else cnt8 += 1ull << (8 * sq);
+        }
     }
     int nskip = 0;
     for (int s = 0; s < k; ++s) nskip += (((cnt8 >> (8 * s)) & 0xFFull) == 0ull);
@@ -425,7 +521,10 @@ __device__ __forceinline__ void emit_record(const K1Args &A, const RowSrc &S, co
             const int n = (int)((cnt8 >> (8 * s)) & 0xFFull);
             double f = 0.0;
             if (n == 0) info |= 1u << dst;
-            else if (!big) f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
+            else if (!big) {
+                if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
+                f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
+            }
             A.U.feats[slot * k + dst] = f;
         }
         if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
@@ -522,7 +621,9 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                 bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
                 L = A.R.contig_len[d.contig];
             }
-            if ((fl & MC_F_MODEL_N) || d.mode != MODE_REGULAR || t0 + i < d.f0) continue;
+            if ((fl & MC_F_MODEL_N) || d.mode != MODE_REGULAR) continue;
+            if (t0 + i == d.extra_row) { emit_mask |= 1u << u; continue; }   // the '+' window of a palindromic f0
+            if (t0 + i < d.first) continue;
             const int o = first_m(bits, L, s_pos[i], k);
             if (o < 0) continue;
             const int m = s_pos[i] + o;
@@ -572,7 +673,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
 
     // ---- pass 3: emission, one thread per closed window, rows read back from LDS ----
     const int64_t base = s_base;
-    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0, t1};
+    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0, t1, false, 0.0};
     for (int q = tid; q < total; q += NTHREADS) {
         const int64_t slot = base + q;
         if (slot >= A.U.capacity) { atomicOr(&A.cnt->overflow, 1u); continue; }
@@ -581,15 +682,16 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         int bi = 0;
         while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
         const NbDesc d = desc_of(bi);
+        if (r == d.extra_row) { emit_extra(A, S, d, nb0 + bi, slot); continue; }
         const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
         const int m = s_pos[i] + first_m(bits, A.R.contig_len[d.contig], s_pos[i], k);
-        emit_record(A, S, d, nb0 + bi, r, m, t1, slot);
+        emit_record(A, S, d, nb0 + bi, r, m, slot);
     }
 }
 
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
 // thread per such record, so that the scan kernel carries neither the stack nor the registers for it.
-__device__ double big_pairwise(const RowSrc &S, int64_t &cur, int64_t n) {
+__device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
     // emulate  f(n) = n <= 128 ? leaf(n) : f(n2) + f(n - n2),  n2 = n/2 rounded down to a multiple of 8
     int64_t fsize[40];
     int fstage[40];      // 0 = not started, 1 = left half pending, 2 = right half pending
@@ -639,10 +741,10 @@ __global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
         if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
     }
     const NbDesc d = A.desc[lo];
-    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, 0, 0};
+    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, 0, 0, false, 0.0};
     // last row of the window: the last unfiltered row of the block before the closing row
     int64_t r = min(O.close_row[j], T.nb_row_begin[lo + 1]) - 1;
-    const int64_t lb = max(d.row_begin, d.f0);
+    const int64_t lb = max(d.row_begin, d.first);
     while (r >= lb && (T.flags[r] & MC_F_MODEL_N)) --r;
     int64_t cnt[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t ws = r;
@@ -653,10 +755,16 @@ __global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
         cnt[m - p] += 1;
         ws = rr;
     }
+    int stray_slot = -1;
+    if (d.stray_q != NO_STRAY && m - d.stray_q >= 0 && m - d.stray_q < k) {
+        stray_slot = m - d.stray_q;
+        cnt[stray_slot] += 1;
+    }
     int64_t cur = ws;
     for (int s = k - 1; s >= 0; --s) {
         const int dst = rev ? s : k - 1 - s;
         double f = 0.0;
+        if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
         if (cnt[s] > 0) f = (0.0 + big_pairwise(S, cur, cnt[s])) / (double)cnt[s];
         O.feats[j * k + dst] = f;
     }
@@ -798,6 +906,7 @@ struct mc_ctx {
     double *qual = nullptr;
     int32_t n_qual = 0;
     NbDesc *desc = nullptr;
+    int64_t *nb_f0 = nullptr;
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
     DevRecords U, O;
     int64_t *tile_base = nullptr, *tile_out = nullptr;
@@ -953,7 +1062,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1)) return -10;
     T.n_tiles = (n + TILE - 1) / TILE;
     if (dev_alloc(c->table_allocs, &T.tile_nb, (size_t)T.n_tiles + 1)) return -10;
-    if (dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) ||
+    if (dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
@@ -1060,9 +1169,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         {
             const int64_t threads = (int64_t)T.n_nb * 64;
             hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0idx, c->nb_lastidx);
+                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
             hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->desc, prm->entry_read, c->cnt);
+                               c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
         }
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         K1Args A;

@@ -158,3 +158,36 @@ def test_mlp_known_answers(dev):
             p = dev.mlp_forward(X, np.full(len(X), i, dtype=np.uint8))
             want = np.array(meta[stem]['known_answers'][key])
             assert np.abs(p - want).max() < 1e-12, (tag, key, np.abs(p - want).max())
+
+
+@pytest.mark.parametrize('flavour,n', [('quirk_pal', 150), ('plain', 60), ('dense', 60), ('skips', 60), ('heavy', 40),
+                                       ('multi_contig', 40), ('qual', 40)])
+def test_fresh_random_cases(dev, tmp_path, flavour, n):
+    """Random cases that are NOT in the committed fixtures (seeds >= 10^6): HIP records == C-oracle records."""
+    from oracle import casegen
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    from mcaller_amd._lib import McError
+    n_ok = n_lit = 0
+    for i in range(n):
+        case = casegen.gen_case(1000000 + 1000 * (sum(map(ord, flavour)) % 97) + i, flavour=flavour)
+        d = tmp_path / ('f%d' % i)
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        a = case['args']
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                r2q = extract_read_quality(paths['fastq'])
+                P = ec.prepare(paths['tsv'], paths['fasta'], r2q, 0, os.path.getsize(paths['tsv']), a['base'],
+                               a['motif'], paths['positions'])
+        except BaseException:
+            continue
+        try:
+            device_vs_oracle(dev, P, a['k'], a['skip_thresh'], a['qual_thresh'],
+                             None if a['train'] else H.load_modelset(a['model']), a['base'], a['train'])
+            n_ok += 1
+        except McError as e:
+            assert 'literal path' in str(e)
+            n_lit += 1
+    print('%s: %d identical, %d literal' % (flavour, n_ok, n_lit))
+    assert n_ok >= n // 2
