@@ -16,6 +16,8 @@ def build_lib(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
            '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs
+    if os.environ.get('MC_TILE'):
+        cmd.insert(1, '-DMC_TILE=' + os.environ['MC_TILE'])
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

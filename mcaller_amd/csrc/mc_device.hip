@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,10 +44,15 @@ void mc_set_error(const char *fmt, ...);
 
 namespace {
 
-constexpr int TILE = 4096;          // rows per workgroup tile
+#ifndef MC_TILE
+#define MC_TILE 4096
+#endif
+constexpr int TILE = MC_TILE;       // rows per workgroup tile
 constexpr int NTHREADS = 256;       // 4 waves
 constexpr int RPT = TILE / NTHREADS;  // rows per thread in the detection pass
-constexpr int NBMAX = 32;           // name-block descriptors staged in LDS per tile
+constexpr int NBMAX = 16;           // name-block descriptors staged in LDS per tile
+constexpr int NBST = 2;             // ... of which this many get their strand-mask window staged in LDS
+constexpr int BW = 192;             // words per staged mask window (6144 positions)
 constexpr int O_NONE = 15;
 
 // meta byte per staged row: bit0 valid (passes :167-168), bit1 first row of a name block, bits 2..5 offset of
@@ -64,6 +70,8 @@ struct __attribute__((aligned(16))) NbDesc {
     int64_t row_begin;
     int64_t first;      // rows >= first are tested on the block's strand (regular blocks); window walks stop here
     int64_t extra_row;  // row of the one-event '+' window a reverse read opens on a palindromic k-mer (R5), or -1
+    int64_t row_end;    // one past the block's last row
+    int64_t contig_len;
     int32_t contig;
     int32_t read;
     int32_t stray_q;    // pseudo-position of that event once the strand flips (:276-277), NO_STRAY if none
@@ -71,7 +79,7 @@ struct __attribute__((aligned(16))) NbDesc {
     int32_t extra_mpos; // site of the '+' window
     uint8_t mode, rev, filtered, extra_multi;
 };
-static_assert(sizeof(NbDesc) == 48, "NbDesc layout");
+static_assert(sizeof(NbDesc) == 64, "NbDesc layout");
 
 struct DevTable {
     int64_t n_rows = 0;
@@ -114,8 +122,11 @@ struct DevMlp {
     uint8_t *sub_of_char = nullptr;
 };
 
+constexpr int NSHARD = 8;  // record-slot counters, one per blockIdx & 7 (= XCD): no single hot atomic
+
 struct Counters {          // device-side status block
     unsigned long long n_records;
+    unsigned long long shard[NSHARD];
     unsigned int overflow;
     unsigned int n_irregular;
     unsigned int n_big;
@@ -237,7 +248,9 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
         d.row_begin = T.nb_row_begin[b];
         d.first = f0;
         d.extra_row = -1;
+        d.row_end = T.nb_row_begin[b + 1];
         d.contig = T.seg_contig[T.nb_seg_begin[b]];
+        d.contig_len = R.contig_len[d.contig];
         d.read = read;
         d.stray_q = NO_STRAY;
         d.stray_d = 0;
@@ -405,25 +418,46 @@ __device__ __forceinline__ double leaf_sum(RowSrc &S, int64_t &cur, int n) {
     return res;
 }
 
+struct TileDesc {      // per tile, written by k0_tiles after classification
+    int32_t nb0;       // name block of the tile's first row
+    int32_t nnb;       // name blocks that overlap the tile
+    int32_t w0[NBST];  // first word of the strand-mask window staged for block nb0+i (relative to the contig's mask)
+    int32_t nw[NBST];  // words staged (0: none)
+    int64_t boff[NBST];// word offset of that window in the concatenated mask arrays
+    uint8_t rev[NBST]; // which strand's mask
+    uint8_t pad[8 - NBST];
+};
+
 struct K1Args {
     DevTable T;
     DevRef R;
     const NbDesc *desc;
+    const TileDesc *tiles;
     DevRecords U;            // unordered record runs (one run per tile)
     int64_t *tile_base;      // [n_tiles]
     int32_t *tile_cnt;       // [n_tiles]
     Counters *cnt;
     int k, skip_thresh, tail_contig;
+    int debug;               // MCALLER_K1_DEBUG: cut the kernel after a stage (timing experiments only)
 };
+
+// first 'M' offset from a window of the strand bitmask staged in LDS (words [w0, w0+nw) of the contig's mask)
+__device__ __forceinline__ int first_m_lds(const uint32_t *s_bits, int w0, int64_t L, int pos, int k) {
+    if (pos >= L) return -1;
+    const int wi = (pos >> 5) - w0;
+    const uint64_t lo = s_bits[wi], hi = s_bits[wi + 1];
+    uint64_t w = ((hi << 32) | lo) >> (pos & 31);
+    w &= (1ull << k) - 1ull;
+    return w ? __builtin_ctzll(w) : -1;
+}
 
 // The row that closes a window whose last row is r: the next unfiltered row in the file (:179).  Returns its
 // index (T.n_rows when it lies in the next shard, -1 when there is none: lost at EOF, R6).
-__device__ __forceinline__ int64_t find_close(const K1Args &A, const RowSrc &S, int nb_abs, int64_t r, int &close_pos,
-                                              bool &close_ns) {
+__device__ __forceinline__ int64_t find_close(const K1Args &A, const RowSrc &S, int nb_abs, int64_t my_end, int64_t r,
+                                              int &close_pos, bool &close_ns) {
     const DevTable &T = A.T;
     int64_t rr = r + 1;
     int bb = nb_abs;
-    const int64_t my_end = T.nb_row_begin[nb_abs + 1];
     close_ns = false;
     close_pos = 0;
     while (rr < T.n_rows) {
@@ -455,7 +489,7 @@ __device__ __forceinline__ void write_tombstone(const K1Args &A, int64_t slot, i
 __device__ __forceinline__ void emit_extra(const K1Args &A, const RowSrc &S, const NbDesc &d, int nb_abs, int64_t slot) {
     int close_pos;
     bool close_ns;
-    const int64_t close_row = find_close(A, S, nb_abs, d.extra_row, close_pos, close_ns);
+    const int64_t close_row = find_close(A, S, nb_abs, d.row_end, d.extra_row, close_pos, close_ns);
     if (close_row < 0) { write_tombstone(A, slot, d.extra_mpos); return; }
     for (int s = 0; s < A.k; ++s) A.U.feats[slot * A.k + s] = 0.0;
     A.U.site_pos[slot] = d.extra_mpos;
@@ -466,15 +500,14 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const RowSrc &S, con
 
 // Record for the window of site m whose last row is r (global), in name block `d`.
 __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
-                                            int m, int64_t slot) {
+                                            int m, int64_t slot, const uint32_t *sbits, int sw0, int snw) {
     const DevTable &T = A.T;
     const int k = A.k;
-    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
-    const int64_t L = A.R.contig_len[d.contig];
+    const int64_t L = d.contig_len;
 
     int close_pos;
     bool close_ns;
-    const int64_t close_row = find_close(A, S, nb_abs, r, close_pos, close_ns);
+    const int64_t close_row = find_close(A, S, nb_abs, d.row_end, r, close_pos, close_ns);
     const bool closes = close_row >= 0 && (close_ns || close_pos > m);
     if (!closes) {                   // not the last row of its window after all, or lost at EOF (R6)
         write_tombstone(A, slot, m);
@@ -528,19 +561,14 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
             A.U.feats[slot * k + dst] = f;
         }
         if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
-        if (m - k + 1 < 0 || (int64_t)m + k > L) {
-            info |= MC_I_EDGE;
-        } else {
-            unsigned char ch;
-            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
-            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-        }
     }
     // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
     if (!close_ns && close_pos <= m + A.skip_thresh + 1) {
-        const int fm = first_m(bits, L, close_pos, k);
+        int fm;
+        if (snw > 0 && (close_pos >> 5) >= sw0 && (close_pos >> 5) + 1 < sw0 + snw)
+            fm = first_m_lds(sbits, sw0, L, close_pos, k);
+        else
+            fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], L, close_pos, k);
         if (fm > 0) info |= MC_I_MULTI;
     }
     A.U.site_pos[slot] = m;
@@ -549,143 +577,332 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
     A.U.info[slot] = info;
 }
 
+// One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
+__global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= T.n_tiles) return;
+    const int64_t t0 = t * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
+    TileDesc td;
+    td.nb0 = T.tile_nb[t];
+    int nnb = 1;
+    while (td.nb0 + nnb < T.n_nb && T.nb_row_begin[td.nb0 + nnb] < t1) ++nnb;
+    td.nnb = nnb;
+    for (int sb = 0; sb < NBST; ++sb) {
+        td.w0[sb] = 0; td.nw[sb] = 0; td.boff[sb] = 0; td.rev[sb] = 0;
+        if (sb >= nnb) continue;
+        const NbDesc d = desc[td.nb0 + sb];
+        if (d.mode != MODE_REGULAR) continue;
+        const int64_t lo = max(d.row_begin, t0), hi = min(d.row_end, t1);
+        const int64_t wmax = ((d.contig_len + 31) >> 5) + 1;       // the mask has 2 zero words of padding
+        if (hi <= lo) continue;
+        const int64_t w0 = T.pos[lo] >> 5;
+        const int64_t w1 = min<int64_t>(((int64_t)T.pos[hi - 1] + k) >> 5, wmax - 1) + 1;
+        const int64_t nw = w1 - w0 + 1;
+        if (nw > 0 && nw <= BW) {
+            td.w0[sb] = (int32_t)w0;
+            td.nw[sb] = (int32_t)nw;
+            td.boff[sb] = R.word_off[d.contig] + w0;
+            td.rev[sb] = d.rev;
+        }
+    }
+    for (int i = 0; i < 8 - NBST; ++i) td.pad[i] = 0;
+    tiles[t] = td;
+}
+
+// ---- wave-cooperative emission: one wave per closed window (few windows per tile: the GATC regime) ----
+// Lane j looks at row r-j; the window is the run of rows back to the first one at a position < m-k+1.  Windows of
+// more than 64 rows, windows closed by another read, and slots of >= 8 events fall back to the serial path on
+// lane 0.  All control flow below is wave-uniform.
+__device__ __forceinline__ void emit_record_coop(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
+                                                 int m, int64_t slot, const uint32_t *sbits, int sw0, int snw,
+                                                 int lane) {
+    const int k = A.k;
+    // closing row: first non-N row among r+1 .. r+64 of my block
+    int close_pos = 0;
+    int64_t close_row = -1;
+    {
+        const int64_t rr = r + 1 + lane;
+        bool v = false;
+        int32_t p = 0, dd;
+        if (rr < d.row_end) row_get(S, rr, v, p, dd);
+        const unsigned long long mk = __ballot(v);
+        if (mk) {
+            const int f = __builtin_ctzll(mk);
+            close_row = r + 1 + f;
+            close_pos = __shfl(p, f);
+        }
+    }
+    // window rows r, r-1, ...
+    const int64_t lb = max(d.row_begin, d.first);
+    const int64_t rr = r - lane;
+    bool v = false;
+    int32_t p = 0, dd = 0;
+    const bool inb = rr >= lb;
+    if (inb) row_get(S, rr, v, p, dd);
+    const unsigned long long stop = __ballot(!inb || (v && p < m - k + 1));
+    bool serial = (close_row < 0) || (stop == 0ull);
+    unsigned long long ms[MC_MAX_K];
+    int nskip = 0;
+    int stray_slot = -1;
+    if (d.stray_q != NO_STRAY && m - d.stray_q >= 0 && m - d.stray_q < k) stray_slot = m - d.stray_q;
+    if (!serial) {
+        const int n_in = __builtin_ctzll(stop);
+        const bool mine = lane < n_in && v;
+        const int sl = m - p;
+#pragma unroll
+        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
+            ms[s2] = (s2 < k) ? __ballot(mine && sl == s2) : 0ull;
+            const int n = __popcll(ms[s2]) + (s2 == stray_slot ? 1 : 0);
+            if (s2 < k && n == 0) ++nskip;
+            if (n >= 8) serial = true;
+        }
+    }
+    if (serial) {
+        if (lane == 0) emit_record(A, S, d, nb_abs, r, m, slot, sbits, sw0, snw);
+        return;
+    }
+    if (!(close_pos > m)) {               // the next row still belongs to this window: not its last row
+        if (lane == 0) write_tombstone(A, slot, m);
+        return;
+    }
+    uint32_t info = d.rev ? MC_I_REV : 0u;
+    double myfeat = 0.0;
+    if (nskip > A.skip_thresh) {
+        info |= MC_I_TOO_MANY;
+    } else {
+        const double val = (double)dd / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+#pragma unroll
+        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
+            if (s2 >= k) continue;
+            const int dst = d.rev ? s2 : k - 1 - s2;  // :187-188
+            unsigned long long mk = ms[s2];
+            int n = __popcll(mk);
+            double res = -0.0;                        // n < 8: sequential from -0.0 (np.mean, :186)
+            if (s2 == stray_slot) { res += (double)d.stray_d / 10000.0; ++n; }
+            while (mk) {                              // file order = farthest row first = highest lane first
+                const int hi = 63 - __builtin_clzll(mk);
+                mk &= ~(1ull << hi);
+                res += __shfl(val, hi);
+            }
+            if (n == 0) info |= 1u << dst;
+            else if (lane == dst) myfeat = (0.0 + res) / (double)n;
+        }
+    }
+    if (lane < k) A.U.feats[slot * k + lane] = myfeat;
+    if (lane == 0) {
+        if (close_pos <= m + A.skip_thresh + 1) {    // the closing row shifts the window (:242-248)
+            int fm;
+            if (snw > 0 && (close_pos >> 5) >= sw0 && (close_pos >> 5) + 1 < sw0 + snw)
+                fm = first_m_lds(sbits, sw0, d.contig_len, close_pos, k);
+            else
+                fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, close_pos, k);
+            if (fm > 0) info |= MC_I_MULTI;
+        }
+        A.U.site_pos[slot] = m;
+        A.U.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
+        A.U.close_row[slot] = close_row;
+        A.U.info[slot] = info;
+    }
+}
+
+constexpr int COOP_MAX = 24;        // up to this many windows per tile: one wave per window; above: one thread each
+
 __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
     __shared__ __attribute__((aligned(16))) int32_t s_d[TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];   // flags (N, name start) | first-'M' offset << 4
     __shared__ uint16_t s_emit[TILE];
+    __shared__ unsigned long long s_emask[TILE / 64];
+    __shared__ int s_eprefix[TILE / 64 + 1];
+    __shared__ uint32_t s_bits[NBST][BW];
     __shared__ NbDesc s_nb[NBMAX];
-    __shared__ int s_nnb;
-    __shared__ int s_wsum[NTHREADS / 64];
     __shared__ long long s_base;
 
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t t0 = tile * TILE;
     const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
     const int nrows = (int)(t1 - t0);
     const int k = A.k;
+    constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
-    // ---- pass 1: stream the tile's columns into LDS, 16-byte loads, nothing else ----
+    // ---- issue the tile's column loads (16 bytes per lane per column) ----
+    int4 p4[NQ], d4[NQ];
+    uint32_t f4[NQ];
 #pragma unroll
-    for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
+    for (int j = 0; j < NQ; ++j) {
         const int i0 = (j * NTHREADS + tid) * 4;
         const int64_t q = t0 + i0;
+        p4[j] = make_int4(0, 0, 0, 0);
+        d4[j] = p4[j];
+        f4[j] = 0;
         if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
-            const int4 p4 = *reinterpret_cast<const int4 *>(T.pos + q);
+            p4[j] = *reinterpret_cast<const int4 *>(T.pos + q);
             const int4 e4 = *reinterpret_cast<const int4 *>(T.ev + q);
             const int4 m4 = *reinterpret_cast<const int4 *>(T.mu + q);
-            const uint32_t f4 = *reinterpret_cast<const uint32_t *>(T.flags + q);
-            int4 d4;
-            d4.x = e4.x - m4.x; d4.y = e4.y - m4.y; d4.z = e4.z - m4.z; d4.w = e4.w - m4.w;
-            *reinterpret_cast<int4 *>(&s_pos[i0]) = p4;
-            *reinterpret_cast<int4 *>(&s_d[i0]) = d4;
-            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = f4;
+            f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + q);
+            d4[j].x = e4.x - m4.x; d4[j].y = e4.y - m4.y; d4[j].z = e4.z - m4.z; d4[j].w = e4.w - m4.w;
         }
     }
-    // name blocks that overlap the tile
-    const int nb0 = T.tile_nb[tile];
-    if (tid == 0) s_nnb = 0;
-    __syncthreads();
-    if (tid < NBMAX) {
-        const int b = nb0 + tid;
-        if (b < T.n_nb && T.nb_row_begin[b] < t1) {
-            s_nb[tid] = A.desc[b];
-            atomicAdd(&s_nnb, 1);
+    if (A.debug == 1) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * NTHREADS + tid) * 4;
+            *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
+            *reinterpret_cast<int4 *>(&s_d[i0]) = d4[j];
+            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = f4[j];
         }
+        return;
     }
+
+    // ---- tile metadata: name blocks that overlap the tile, strand-mask windows of the first NBST of them ----
+    const TileDesc td = A.tiles[tile];
+    const int nb0 = td.nb0;
+    const int nnb = min(td.nnb, NBMAX);            // descriptors staged; beyond: global memory
+    if (tid < nnb) s_nb[tid] = A.desc[nb0 + tid];
+#pragma unroll
+    for (int sb = 0; sb < NBST; ++sb) {
+        const uint32_t *bits = (td.rev[sb] ? A.R.mr : A.R.mf) + td.boff[sb];
+        for (int w = tid; w < td.nw[sb]; w += NTHREADS) s_bits[sb][w] = bits[w];
+    }
+    if (tid < TILE / 64) s_emask[tid] = 0ull;
     __syncthreads();
-    const int nnb = s_nnb;   // descriptors staged; a tile that overlaps more reads them from global memory
     auto desc_of = [&](int bi) -> NbDesc { return (bi < nnb) ? s_nb[bi] : A.desc[nb0 + bi]; };
     auto begin_of = [&](int bi) -> int64_t { return (bi < nnb) ? s_nb[bi].row_begin : T.nb_row_begin[nb0 + bi]; };
-    const int nb_last = T.n_nb - 1 - nb0;   // largest relative block index
+    const int nb_last = td.nnb - 1;                // largest relative block index in this tile
+    const bool single = nb_last == 0;
+    const NbDesc d0 = s_nb[0];
+    if (A.debug == 2) return;
 
-    // ---- pass 2: detection.  Thread owns RPT consecutive rows; a site row (k-mer holds an 'M', :269) is the
-    // last row of its window iff the next unfiltered row starts another read or lies beyond the site (:179).
-    const int i_begin = tid * RPT;
-    uint32_t emit_mask = 0;
-    if (i_begin < nrows) {
+    // ---- pass 1: per row, is its k-mer a site (first 'M' offset, :269-270)?  stage (pos, event-model, meta) ----
+    uint32_t meta[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int i0 = (j * NTHREADS + tid) * 4;
+        const int pp[4] = {p4[j].x, p4[j].y, p4[j].z, p4[j].w};
+        uint32_t m4 = 0;
         int bi = 0;
-        while (bi < nb_last && begin_of(bi + 1) <= t0 + i_begin) ++bi;
-        NbDesc d = desc_of(bi);
-        const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
-        int64_t L = A.R.contig_len[d.contig];
-        for (int u = 0; u < RPT; ++u) {
-            const int i = i_begin + u;
-            if (i >= nrows) break;
-            const uint32_t fl = s_fl[i];
-            if ((fl & MC_F_NAME_START) && t0 + i != d.row_begin) {
-                ++bi;
-                d = desc_of(bi);
-                bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
-                L = A.R.contig_len[d.contig];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = t0 + i0 + u;
+            const uint32_t fl = (f4[j] >> (8 * u)) & 0xFFu;
+            int o = O_NONE;
+            if (r < t1 && !(fl & MC_F_MODEL_N)) {
+                if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
+                const NbDesc d = single ? d0 : desc_of(bi);
+                if (d.mode == MODE_REGULAR && r >= d.first) {
+                    const int p = pp[u];
+                    int fm;
+                    if (bi < NBST && td.nw[bi < NBST ? bi : 0] > 0 && (p >> 5) >= td.w0[bi < NBST ? bi : 0] &&
+                        (p >> 5) + 1 < td.w0[bi < NBST ? bi : 0] + td.nw[bi < NBST ? bi : 0])
+                        fm = first_m_lds(s_bits[bi < NBST ? bi : 0], td.w0[bi < NBST ? bi : 0], d.contig_len, p, k);
+                    else
+                        fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
+                    if (fm >= 0) o = fm;
+                }
+                if (d.mode == MODE_REGULAR && r == d.extra_row) o = 14;     // the '+' window of a palindromic f0 (R5)
             }
-            if ((fl & MC_F_MODEL_N) || d.mode != MODE_REGULAR) continue;
-            if (t0 + i == d.extra_row) { emit_mask |= 1u << u; continue; }   // the '+' window of a palindromic f0
-            if (t0 + i < d.first) continue;
-            const int o = first_m(bits, L, s_pos[i], k);
-            if (o < 0) continue;
-            const int m = s_pos[i] + o;
-            bool last = true;                       // undecided inside the tile => decided at emission
-            for (int j = i + 1; j < nrows; ++j) {
-                const uint32_t fj = s_fl[j];
-                if (fj & MC_F_NAME_START) break;    // another read follows
-                if (!(fj & MC_F_MODEL_N)) { last = s_pos[j] > m; break; }
+            m4 |= ((fl & (MC_F_MODEL_N | MC_F_NAME_START)) | ((uint32_t)o << 4)) << (8 * u);
+        }
+        meta[j] = m4;
+        *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
+        *reinterpret_cast<int4 *>(&s_d[i0]) = d4[j];
+        *reinterpret_cast<uint32_t *>(&s_fl[i0]) = m4;
+    }
+    __syncthreads();
+
+    // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
+    // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
+    uint32_t emit_bits = 0;                        // bit j*4+u
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int i0 = (j * NTHREADS + tid) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = (meta[j] >> (8 * u + 4)) & 15;
+            if (o == O_NONE) continue;
+            const int i = i0 + u;
+            bool emit = true;                      // undecided inside the tile => decided at emission
+            if (o != 14) {
+                const int pi = u == 0 ? p4[j].x : (u == 1 ? p4[j].y : (u == 2 ? p4[j].z : p4[j].w));
+                const int m = pi + o;
+                for (int jj = i + 1; jj < nrows; ++jj) {
+                    const uint32_t fj = s_fl[jj];
+                    if (fj & MC_F_NAME_START) break;               // another read follows
+                    if (!(fj & MC_F_MODEL_N)) { emit = s_pos[jj] > m; break; }
+                }
             }
-            if (last) emit_mask |= 1u << u;
+            if (emit) {
+                emit_bits |= 1u << (j * 4 + u);
+                atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
+            }
         }
     }
-
-    // ---- allocate record slots: exclusive scan over the workgroup, one atomic per tile ----
-    const int my_cnt = __popc(emit_mask);
-    int incl = my_cnt;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    int wave_off = 0, total = 0;
-    for (int w = 0; w < NTHREADS / 64; ++w) {
-        if (w < wave) wave_off += s_wsum[w];
-        total += s_wsum[w];
+
+    // ---- record slots: prefix over the tile's emit bitmap (row order), one atomic per tile ----
+    if (wave == 0) {
+        const int c = lane < TILE / 64 ? __popcll(s_emask[lane]) : 0;
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane < TILE / 64) s_eprefix[lane] = incl - c;
+        if (lane == 63) {
+            s_eprefix[TILE / 64] = incl;
+            long long base = 0;
+            if (incl > 0) {     // slots come from the counter of this tile's shard; shard s owns [s*cap/8, (s+1)*cap/8)
+                const int sh = (int)(tile & (NSHARD - 1));
+                const long long per = A.U.capacity / NSHARD;
+                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)incl);
+                base = sh * per + off;
+                if (off + incl > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+            }
+            s_base = base;
+            A.tile_base[tile] = base;
+            A.tile_cnt[tile] = incl;
+        }
     }
-    if (tid == 0) {
-        long long base = 0;
-        if (total > 0) base = (long long)atomicAdd(&A.cnt->n_records, (unsigned long long)total);
-        s_base = base;
-        A.tile_base[tile] = base;
-        A.tile_cnt[tile] = total;
-    }
+    __syncthreads();
+    const int total = s_eprefix[TILE / 64];
+    if (total == 0 || A.debug == 3) return;
     {
-        int q = wave_off + incl - my_cnt;
-        uint32_t mk = emit_mask;
+        uint32_t mk = emit_bits;
         while (mk) {
-            const int u = __builtin_ctz(mk);
+            const int b = __builtin_ctz(mk);
             mk &= mk - 1;
-            s_emit[q++] = (uint16_t)(i_begin + u);
+            const int i = ((b >> 2) * NTHREADS + tid) * 4 + (b & 3);
+            const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
+            s_emit[q] = (uint16_t)i;
         }
     }
     __syncthreads();
-    if (total == 0) return;
 
-    // ---- pass 3: emission, one thread per closed window, rows read back from LDS ----
+    // ---- pass 3: emission; window rows are read back from LDS ----
     const int64_t base = s_base;
+    if (base < 0) return;                                    // record buffer too small: the host retries
     RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0, t1, false, 0.0};
-    for (int q = tid; q < total; q += NTHREADS) {
+    const bool coop = total <= COOP_MAX;
+    for (int q = coop ? wave : tid; q < total; q += coop ? NTHREADS / 64 : NTHREADS) {
         const int64_t slot = base + q;
-        if (slot >= A.U.capacity) { atomicOr(&A.cnt->overflow, 1u); continue; }
         const int i = s_emit[q];
         const int64_t r = t0 + i;
         int bi = 0;
-        while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
-        const NbDesc d = desc_of(bi);
-        if (r == d.extra_row) { emit_extra(A, S, d, nb0 + bi, slot); continue; }
-        const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
-        const int m = s_pos[i] + first_m(bits, A.R.contig_len[d.contig], s_pos[i], k);
-        emit_record(A, S, d, nb0 + bi, r, m, slot);
+        if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
+        const NbDesc d = single ? d0 : desc_of(bi);
+        const int o = (s_fl[i] >> 4) & 15;
+        const int sb = bi < NBST ? bi : 0;
+        const int snw = bi < NBST ? td.nw[sb] : 0;
+        if (o == 14) {
+            if (!coop || lane == 0) emit_extra(A, S, d, nb0 + bi, slot);
+        } else if (coop) {
+            emit_record_coop(A, S, d, nb0 + bi, r, s_pos[i] + o, slot, s_bits[sb], td.w0[sb], snw, lane);
+        } else {
+            emit_record(A, S, d, nb0 + bi, r, s_pos[i] + o, slot, s_bits[sb], td.w0[sb], snw);
+        }
     }
 }
 
@@ -781,7 +998,7 @@ __global__ void k_order_count(DevRecords U, const int64_t *tile_base, const int3
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
     const int64_t base = tile_base[t];
-    const int n = tile_cnt[t];
+    const int n = base < 0 ? 0 : tile_cnt[t];
     int live = 0;
     for (int i = lane; i < n; i += 64) live += (U.site_seg[base + i] >= 0);
     for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
@@ -813,13 +1030,15 @@ __global__ void k_order_scan(const int32_t *tile_live, int64_t n_tiles, int64_t 
 }
 
 // pass 3: one wave per tile moves its live records to their final slots
+// ... and fills in what the host needs to pick the sub-model: context[k], the character after the 'M' (:197)
 __global__ void k_order_gather(DevRecords U, DevRecords O, const int64_t *tile_base, const int32_t *tile_cnt,
-                               const int64_t *tile_out, int64_t n_tiles, int k) {
+                               const int64_t *tile_out, int64_t n_tiles, int k, DevRef R,
+                               const int32_t *__restrict__ seg_contig) {
     const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
     const int64_t base = tile_base[t];
-    const int n = tile_cnt[t];
+    const int n = base < 0 ? 0 : tile_cnt[t];
     int64_t dst = tile_out[t];
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -832,7 +1051,22 @@ __global__ void k_order_gather(DevRecords U, DevRecords O, const int64_t *tile_b
             O.site_pos[d] = U.site_pos[s];
             O.site_seg[d] = U.site_seg[s];
             O.close_row[d] = U.close_row[s];
-            O.info[d] = U.info[s];
+            uint32_t info = U.info[s];
+            if (!(info & MC_I_TOO_MANY)) {
+                const int contig = seg_contig[U.site_seg[s]];
+                const int64_t L = R.contig_len[contig];
+                const int m = U.site_pos[s];
+                if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
+                    info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
+                } else {
+                    unsigned char ch;
+                    const uint8_t *seq = R.seq + R.seq_off[contig];
+                    if (!(info & MC_I_REV)) ch = bit_at(R.mf + R.word_off[contig], m + 1) ? 'M' : seq[m + 1];
+                    else ch = bit_at(R.mr + R.word_off[contig], m - 1) ? 'M' : comp_char(seq[m - 1]);
+                    info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+                }
+            }
+            O.info[d] = info;
             O.prob[d] = __longlong_as_double(0x7ff8000000000000LL);
         }
         dst += __popcll(mask);
@@ -906,6 +1140,7 @@ struct mc_ctx {
     double *qual = nullptr;
     int32_t n_qual = 0;
     NbDesc *desc = nullptr;
+    TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
     DevRecords U, O;
@@ -1062,7 +1297,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1)) return -10;
     T.n_tiles = (n + TILE - 1) / TILE;
     if (dev_alloc(c->table_allocs, &T.tile_nb, (size_t)T.n_tiles + 1)) return -10;
-    if (dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
+    if (dev_alloc(c->table_allocs, &c->tiles, (size_t)T.n_tiles + 1) || dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
@@ -1172,11 +1407,14 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
                                c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
             hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
                                c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
+            hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R, c->desc,
+                               k, c->tiles);
         }
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         K1Args A;
-        A.T = T; A.R = c->R; A.desc = c->desc; A.U = c->U; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
+        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.U = c->U; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
         A.cnt = c->cnt; A.k = k; A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
+        { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
         hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         {
@@ -1186,7 +1424,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
                                c->tile_live);
             hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, c->stream, c->tile_live, T.n_tiles, c->tile_out, c->cnt);
             hipLaunchKernelGGL(k_order_gather, dim3(g), dim3(256), 0, c->stream, c->U, c->O, c->tile_base, c->tile_cnt,
-                               c->tile_out, T.n_tiles, k);
+                               c->tile_out, T.n_tiles, k, c->R, T.seg_contig);
         }
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         Counters h;

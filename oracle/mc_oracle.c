@@ -115,7 +115,7 @@ static int emit_record(const mc_table_view *T, const mc_ref_view *R, machine_t *
             else
                 out->feats[j * k + dst] = np_mean(&m->slots[i]);
         }
-        if (m->mpos - k + 1 < 0 || m->mpos + k > L) {
+        if (m->mpos - k + 1 < 0 || m->mpos + k > L || m->mpos < 1 || m->mpos + 1 >= L) {
             info |= MC_I_EDGE;
         } else {
             unsigned char c;
