@@ -13,7 +13,7 @@
 //                                rows that end a window (last row whose first 'M' is the site) walk back
 //                                over the <= k positions of their window in LDS to build the slot means
 //                                (NumPy pairwise order, fp64) -> one flush record per closed window
-//                k_order_*       tile-local record runs -> file order
+//                k1_offsets/k1_emit  per closed window: gather its rows, build the record, in file order
 //                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64 (one lane per record)
 //
 // Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
@@ -351,46 +351,37 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1: the window scan
+// K1: the window scan, as two launches
+//
+//   k1_scan  streams the position and flag columns (5 B/row), stages them in LDS with the per-row site offset
+//            (first 'M' in the row's k-mer, looked up in a window of the strand bitmask staged in LDS), and decides
+//            for every site row whether it is the LAST row of its window: the next unfiltered row starts another
+//            read or lies beyond the site (:179).  Output: one bit per row (the tile's emit bitmap) + a count.
+//   k1_emit  one lane per closed window: walks back over the <= k positions of the window, reading the event and
+//            model columns only for these rows, and builds the flush record (slot means in NumPy pairwise order).
+//            Records land in file order (slot = exclusive scan of the tile counts + rank in the bitmap).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events, finished by k1_bigfix
+constexpr int O_EXTRA = 14;              // meta nibble: the one-event '+' window of a palindromic f0 (R5)
 
-struct RowSrc {   // where a walker reads rows from: LDS inside the tile, HBM/L2 outside
-    const int32_t *s_pos, *s_d;
-    const uint8_t *s_fl;
+struct RowSrc {   // the columns, for window walks
     const int32_t *g_pos, *g_ev, *g_mu;
     const uint8_t *g_flags;
-    int64_t t0, t1;      // rows [t0, t1) are in LDS
     bool stray_pending;  // the next value handed out is the block's stray event (R5), not a row
     double stray_val;
 };
 
 // rows are only ever walked inside the name block of a row that passed the quality filter, so "valid"
 // (:167-168) reduces to model_kmer != NNNNNN
-__device__ __forceinline__ void row_get(const RowSrc &S, int64_t r, bool &valid, int32_t &pos, int32_t &d) {
-    if (r >= S.t0 && r < S.t1) {
-        const int i = (int)(r - S.t0);
-        valid = !(S.s_fl[i] & MC_F_MODEL_N);
-        pos = S.s_pos[i];
-        d = S.s_d[i];
-    } else {
-        valid = !(S.g_flags[r] & MC_F_MODEL_N);
-        pos = S.g_pos[r];
-        d = S.g_ev[r] - S.g_mu[r];
-    }
-}
-
 __device__ __forceinline__ double next_val(RowSrc &S, int64_t &cur) {
     if (S.stray_pending) {
         S.stray_pending = false;
         return S.stray_val;
     }
     for (;;) {
-        bool v;
-        int32_t p, d;
-        row_get(S, cur, v, p, d);
-        ++cur;
-        if (v) return (double)d / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+        const int64_t r = cur++;
+        if (!(S.g_flags[r] & MC_F_MODEL_N))
+            return (double)(S.g_ev[r] - S.g_mu[r]) / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
     }
 }
 
@@ -433,149 +424,15 @@ struct K1Args {
     DevRef R;
     const NbDesc *desc;
     const TileDesc *tiles;
-    DevRecords U;            // unordered record runs (one run per tile)
-    int64_t *tile_base;      // [n_tiles]
-    int32_t *tile_cnt;       // [n_tiles]
+    unsigned long long *bitmap;   // [n_tiles * TILE/64] emit bits, row order
+    int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
+    const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
+    const int64_t *group_sum;     // [n_groups] windows per group
+    DevRecords O;                 // records, file order
     Counters *cnt;
     int k, skip_thresh, tail_contig;
-    int debug;               // MCALLER_K1_DEBUG: cut the kernel after a stage (timing experiments only)
+    int debug;                    // MCALLER_K1_DEBUG: cut k1_scan after a stage (timing experiments only)
 };
-
-// first 'M' offset from a window of the strand bitmask staged in LDS (words [w0, w0+nw) of the contig's mask)
-__device__ __forceinline__ int first_m_lds(const uint32_t *s_bits, int w0, int64_t L, int pos, int k) {
-    if (pos >= L) return -1;
-    const int wi = (pos >> 5) - w0;
-    const uint64_t lo = s_bits[wi], hi = s_bits[wi + 1];
-    uint64_t w = ((hi << 32) | lo) >> (pos & 31);
-    w &= (1ull << k) - 1ull;
-    return w ? __builtin_ctzll(w) : -1;
-}
-
-// The row that closes a window whose last row is r: the next unfiltered row in the file (:179).  Returns its
-// index (T.n_rows when it lies in the next shard, -1 when there is none: lost at EOF, R6).
-__device__ __forceinline__ int64_t find_close(const K1Args &A, const RowSrc &S, int nb_abs, int64_t my_end, int64_t r,
-                                              int &close_pos, bool &close_ns) {
-    const DevTable &T = A.T;
-    int64_t rr = r + 1;
-    int bb = nb_abs;
-    close_ns = false;
-    close_pos = 0;
-    while (rr < T.n_rows) {
-        if (rr < my_end) {                          // still my name block: valid <=> not an N row
-            bool v; int32_t p, dd;
-            row_get(S, rr, v, p, dd);
-            if (v) { close_pos = p; return rr; }
-            ++rr;
-            continue;
-        }
-        close_ns = true;                            // another read begins: closes whatever its position
-        while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
-        if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }   // skip the read whole
-        if (!(T.flags[rr] & MC_F_MODEL_N)) { close_pos = T.pos[rr]; return rr; }
-        ++rr;
-    }
-    close_ns = true;
-    return A.tail_contig >= 0 ? T.n_rows : -1;
-}
-
-__device__ __forceinline__ void write_tombstone(const K1Args &A, int64_t slot, int m) {
-    A.U.site_seg[slot] = -1;         // dropped by the ordering pass
-    A.U.info[slot] = 0;
-    A.U.close_row[slot] = -1;
-    A.U.site_pos[slot] = m;
-}
-
-// The one-event '+' window a reverse read opens on a palindromic first site row (R5): flushed with k-1 empty slots.
-__device__ __forceinline__ void emit_extra(const K1Args &A, const RowSrc &S, const NbDesc &d, int nb_abs, int64_t slot) {
-    int close_pos;
-    bool close_ns;
-    const int64_t close_row = find_close(A, S, nb_abs, d.row_end, d.extra_row, close_pos, close_ns);
-    if (close_row < 0) { write_tombstone(A, slot, d.extra_mpos); return; }
-    for (int s = 0; s < A.k; ++s) A.U.feats[slot * A.k + s] = 0.0;
-    A.U.site_pos[slot] = d.extra_mpos;
-    A.U.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
-    A.U.close_row[slot] = close_row;
-    A.U.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi) ? MC_I_MULTI : 0u);
-}
-
-// Record for the window of site m whose last row is r (global), in name block `d`.
-__device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
-                                            int m, int64_t slot, const uint32_t *sbits, int sw0, int snw) {
-    const DevTable &T = A.T;
-    const int k = A.k;
-    const int64_t L = d.contig_len;
-
-    int close_pos;
-    bool close_ns;
-    const int64_t close_row = find_close(A, S, nb_abs, d.row_end, r, close_pos, close_ns);
-    const bool closes = close_row >= 0 && (close_ns || close_pos > m);
-    if (!closes) {                   // not the last row of its window after all, or lost at EOF (R6)
-        write_tombstone(A, slot, m);
-        return;
-    }
-    uint32_t info = d.rev ? MC_I_REV : 0u;
-
-    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first / the block start) ----
-    // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
-    const int64_t lb = max(d.row_begin, d.first);
-    unsigned long long cnt8 = 0;
-    bool big = false;
-    int64_t ws = r;
-    for (int64_t rr = r; rr >= lb; --rr) {
-        bool v; int32_t p, dd;
-        row_get(S, rr, v, p, dd);
-        if (!v) continue;
-        if (p < m - k + 1) break;
-        const int sh = 8 * (m - p);
-        if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
-        else cnt8 += 1ull << sh;
-        ws = rr;
-    }
-    // the stray event of a palindromic first site row: first in the slot of its pseudo-position
-    int stray_slot = -1;
-    if (d.stray_q != NO_STRAY) {
-        const int sq = m - d.stray_q;
-        if (sq >= 0 && sq < k) {
-            stray_slot = sq;
-            if (((cnt8 >> (8 * sq)) & 0xFFull) >= 128ull) big = true;
-            else cnt8 += 1ull << (8 * sq);
-        }
-    }
-    int nskip = 0;
-    for (int s = 0; s < k; ++s) nskip += (((cnt8 >> (8 * s)) & 0xFFull) == 0ull);
-
-    if (nskip > A.skip_thresh) {
-        info |= MC_I_TOO_MANY;
-        for (int s = 0; s < k; ++s) A.U.feats[slot * k + s] = 0.0;
-    } else {
-        int64_t cur = ws;
-        for (int s = k - 1; s >= 0; --s) {             // positions ascend => slots descend
-            const int dst = d.rev ? s : k - 1 - s;      // :187-188
-            const int n = (int)((cnt8 >> (8 * s)) & 0xFFull);
-            double f = 0.0;
-            if (n == 0) info |= 1u << dst;
-            else if (!big) {
-                if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
-                f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
-            }
-            A.U.feats[slot * k + dst] = f;
-        }
-        if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
-    }
-    // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
-    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {
-        int fm;
-        if (snw > 0 && (close_pos >> 5) >= sw0 && (close_pos >> 5) + 1 < sw0 + snw)
-            fm = first_m_lds(sbits, sw0, L, close_pos, k);
-        else
-            fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], L, close_pos, k);
-        if (fm > 0) info |= MC_I_MULTI;
-    }
-    A.U.site_pos[slot] = m;
-    A.U.site_seg[slot] = T.nb_seg_begin[nb_abs];        // regular blocks have one segment
-    A.U.close_row[slot] = close_row;
-    A.U.info[slot] = info;
-}
 
 // One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
 __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
@@ -609,114 +466,47 @@ __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, 
     tiles[t] = td;
 }
 
-// ---- wave-cooperative emission: one wave per closed window (few windows per tile: the GATC regime) ----
-// Lane j looks at row r-j; the window is the run of rows back to the first one at a position < m-k+1.  Windows of
-// more than 64 rows, windows closed by another read, and slots of >= 8 events fall back to the serial path on
-// lane 0.  All control flow below is wave-uniform.
-__device__ __forceinline__ void emit_record_coop(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r,
-                                                 int m, int64_t slot, const uint32_t *sbits, int sw0, int snw,
-                                                 int lane) {
-    const int k = A.k;
-    // closing row: first non-N row among r+1 .. r+64 of my block
-    int close_pos = 0;
-    int64_t close_row = -1;
-    {
-        const int64_t rr = r + 1 + lane;
-        bool v = false;
-        int32_t p = 0, dd;
-        if (rr < d.row_end) row_get(S, rr, v, p, dd);
-        const unsigned long long mk = __ballot(v);
-        if (mk) {
-            const int f = __builtin_ctzll(mk);
-            close_row = r + 1 + f;
-            close_pos = __shfl(p, f);
-        }
-    }
-    // window rows r, r-1, ...
-    const int64_t lb = max(d.row_begin, d.first);
-    const int64_t rr = r - lane;
-    bool v = false;
-    int32_t p = 0, dd = 0;
-    const bool inb = rr >= lb;
-    if (inb) row_get(S, rr, v, p, dd);
-    const unsigned long long stop = __ballot(!inb || (v && p < m - k + 1));
-    bool serial = (close_row < 0) || (stop == 0ull);
-    unsigned long long ms[MC_MAX_K];
-    int nskip = 0;
-    int stray_slot = -1;
-    if (d.stray_q != NO_STRAY && m - d.stray_q >= 0 && m - d.stray_q < k) stray_slot = m - d.stray_q;
-    if (!serial) {
-        const int n_in = __builtin_ctzll(stop);
-        const bool mine = lane < n_in && v;
-        const int sl = m - p;
-#pragma unroll
-        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
-            ms[s2] = (s2 < k) ? __ballot(mine && sl == s2) : 0ull;
-            const int n = __popcll(ms[s2]) + (s2 == stray_slot ? 1 : 0);
-            if (s2 < k && n == 0) ++nskip;
-            if (n >= 8) serial = true;
-        }
-    }
-    if (serial) {
-        if (lane == 0) emit_record(A, S, d, nb_abs, r, m, slot, sbits, sw0, snw);
-        return;
-    }
-    if (!(close_pos > m)) {               // the next row still belongs to this window: not its last row
-        if (lane == 0) write_tombstone(A, slot, m);
-        return;
-    }
-    uint32_t info = d.rev ? MC_I_REV : 0u;
-    double myfeat = 0.0;
-    if (nskip > A.skip_thresh) {
-        info |= MC_I_TOO_MANY;
-    } else {
-        const double val = (double)dd / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
-#pragma unroll
-        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
-            if (s2 >= k) continue;
-            const int dst = d.rev ? s2 : k - 1 - s2;  // :187-188
-            unsigned long long mk = ms[s2];
-            int n = __popcll(mk);
-            double res = -0.0;                        // n < 8: sequential from -0.0 (np.mean, :186)
-            if (s2 == stray_slot) { res += (double)d.stray_d / 10000.0; ++n; }
-            while (mk) {                              // file order = farthest row first = highest lane first
-                const int hi = 63 - __builtin_clzll(mk);
-                mk &= ~(1ull << hi);
-                res += __shfl(val, hi);
-            }
-            if (n == 0) info |= 1u << dst;
-            else if (lane == dst) myfeat = (0.0 + res) / (double)n;
-        }
-    }
-    if (lane < k) A.U.feats[slot * k + lane] = myfeat;
-    if (lane == 0) {
-        if (close_pos <= m + A.skip_thresh + 1) {    // the closing row shifts the window (:242-248)
-            int fm;
-            if (snw > 0 && (close_pos >> 5) >= sw0 && (close_pos >> 5) + 1 < sw0 + snw)
-                fm = first_m_lds(sbits, sw0, d.contig_len, close_pos, k);
-            else
-                fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, close_pos, k);
-            if (fm > 0) info |= MC_I_MULTI;
-        }
-        A.U.site_pos[slot] = m;
-        A.U.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
-        A.U.close_row[slot] = close_row;
-        A.U.info[slot] = info;
-    }
+// first 'M' offset from a window of the strand bitmask staged in LDS (words [w0, w0+nw) of the contig's mask)
+__device__ __forceinline__ int first_m_lds(const uint32_t *s_bits, int w0, int64_t L, int pos, int k) {
+    if (pos >= L) return -1;
+    const int wi = (pos >> 5) - w0;
+    const uint64_t lo = s_bits[wi], hi = s_bits[wi + 1];
+    uint64_t w = ((hi << 32) | lo) >> (pos & 31);
+    w &= (1ull << k) - 1ull;
+    return w ? __builtin_ctzll(w) : -1;
 }
 
-constexpr int COOP_MAX = 24;        // up to this many windows per tile: one wave per window; above: one thread each
+// The row that closes a window whose last row is r (in name block nb_abs, which ends at my_end): the next
+// unfiltered row in the file (:179).  Returns its index (T.n_rows when it lies in the next shard, -1 when there is
+// none: the window is lost at EOF, R6).
+__device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *__restrict__ desc, int tail_contig,
+                                              int nb_abs, int64_t my_end, int64_t r, int &close_pos, bool &close_ns) {
+    int64_t rr = r + 1;
+    int bb = nb_abs;
+    close_ns = false;
+    close_pos = 0;
+    while (rr < T.n_rows) {
+        if (rr < my_end) {                          // still my name block: valid <=> not an N row
+            if (!(T.flags[rr] & MC_F_MODEL_N)) { close_pos = T.pos[rr]; return rr; }
+            ++rr;
+            continue;
+        }
+        close_ns = true;                            // another read begins: closes whatever its position
+        while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
+        if (desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }   // skip the read whole
+        if (!(T.flags[rr] & MC_F_MODEL_N)) { close_pos = T.pos[rr]; return rr; }
+        ++rr;
+    }
+    close_ns = true;
+    return tail_contig >= 0 ? T.n_rows : -1;
+}
 
 __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
-    __shared__ __attribute__((aligned(16))) int32_t s_d[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];   // flags (N, name start) | first-'M' offset << 4
-    __shared__ uint16_t s_emit[TILE];
     __shared__ unsigned long long s_emask[TILE / 64];
-    __shared__ int s_eprefix[TILE / 64 + 1];
     __shared__ uint32_t s_bits[NBST][BW];
     __shared__ NbDesc s_nb[NBMAX];
-    __shared__ long long s_base;
 
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
@@ -728,22 +518,17 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     const int k = A.k;
     constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
-    // ---- issue the tile's column loads (16 bytes per lane per column) ----
-    int4 p4[NQ], d4[NQ];
+    // ---- issue the tile's column loads: 16 bytes of positions + 4 flag bytes per lane and quad ----
+    int4 p4[NQ];
     uint32_t f4[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int i0 = (j * NTHREADS + tid) * 4;
-        const int64_t q = t0 + i0;
         p4[j] = make_int4(0, 0, 0, 0);
-        d4[j] = p4[j];
         f4[j] = 0;
         if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
-            p4[j] = *reinterpret_cast<const int4 *>(T.pos + q);
-            const int4 e4 = *reinterpret_cast<const int4 *>(T.ev + q);
-            const int4 m4 = *reinterpret_cast<const int4 *>(T.mu + q);
-            f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + q);
-            d4[j].x = e4.x - m4.x; d4[j].y = e4.y - m4.y; d4[j].z = e4.z - m4.z; d4[j].w = e4.w - m4.w;
+            p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+            f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
         }
     }
     if (A.debug == 1) {
@@ -751,7 +536,6 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * NTHREADS + tid) * 4;
             *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
-            *reinterpret_cast<int4 *>(&s_d[i0]) = d4[j];
             *reinterpret_cast<uint32_t *>(&s_fl[i0]) = f4[j];
         }
         return;
@@ -776,7 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     const NbDesc d0 = s_nb[0];
     if (A.debug == 2) return;
 
-    // ---- pass 1: per row, is its k-mer a site (first 'M' offset, :269-270)?  stage (pos, event-model, meta) ----
+    // ---- pass 1: per row, is its k-mer a site (first 'M' offset, :269-270)?  stage (pos, meta) ----
     uint32_t meta[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -794,28 +578,29 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                 const NbDesc d = single ? d0 : desc_of(bi);
                 if (d.mode == MODE_REGULAR && r >= d.first) {
                     const int p = pp[u];
+                    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
+                    const int sw0 = bi == 0 ? td.w0[0] : td.w0[1];
+                    const int snw = bi == 0 ? td.nw[0] : (bi == 1 ? td.nw[1] : 0);
                     int fm;
-                    if (bi < NBST && td.nw[bi < NBST ? bi : 0] > 0 && (p >> 5) >= td.w0[bi < NBST ? bi : 0] &&
-                        (p >> 5) + 1 < td.w0[bi < NBST ? bi : 0] + td.nw[bi < NBST ? bi : 0])
-                        fm = first_m_lds(s_bits[bi < NBST ? bi : 0], td.w0[bi < NBST ? bi : 0], d.contig_len, p, k);
+                    if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
+                        fm = first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
                     else
                         fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
                     if (fm >= 0) o = fm;
                 }
-                if (d.mode == MODE_REGULAR && r == d.extra_row) o = 14;     // the '+' window of a palindromic f0 (R5)
+                if (d.mode == MODE_REGULAR && r == d.extra_row) o = O_EXTRA;
             }
             m4 |= ((fl & (MC_F_MODEL_N | MC_F_NAME_START)) | ((uint32_t)o << 4)) << (8 * u);
         }
         meta[j] = m4;
         *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
-        *reinterpret_cast<int4 *>(&s_d[i0]) = d4[j];
         *reinterpret_cast<uint32_t *>(&s_fl[i0]) = m4;
     }
     __syncthreads();
+    if (A.debug == 3) return;
 
     // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
     // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
-    uint32_t emit_bits = 0;                        // bit j*4+u
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int i0 = (j * NTHREADS + tid) * 4;
@@ -824,90 +609,373 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
             const int o = (meta[j] >> (8 * u + 4)) & 15;
             if (o == O_NONE) continue;
             const int i = i0 + u;
-            bool emit = true;                      // undecided inside the tile => decided at emission
-            if (o != 14) {
-                const int pi = u == 0 ? p4[j].x : (u == 1 ? p4[j].y : (u == 2 ? p4[j].z : p4[j].w));
-                const int m = pi + o;
+            const int pi = u == 0 ? p4[j].x : (u == 1 ? p4[j].y : (u == 2 ? p4[j].z : p4[j].w));
+            const int m = pi + o;                                    // unused for O_EXTRA
+            int state = 0;                                           // 0 undecided, 1 last row, 2 not last
+            if (o != O_EXTRA) {
                 for (int jj = i + 1; jj < nrows; ++jj) {
                     const uint32_t fj = s_fl[jj];
-                    if (fj & MC_F_NAME_START) break;               // another read follows
-                    if (!(fj & MC_F_MODEL_N)) { emit = s_pos[jj] > m; break; }
+                    if (fj & MC_F_NAME_START) break;                 // another read follows: decided below
+                    if (!(fj & MC_F_MODEL_N)) { state = s_pos[jj] > m ? 1 : 2; break; }
                 }
             }
-            if (emit) {
-                emit_bits |= 1u << (j * 4 + u);
-                atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
+            if (state == 0) {    // rare: the closing row is another read's, or lies in a later tile, or does not exist
+                int bi = 0;
+                if (!single) while (bi < nb_last && begin_of(bi + 1) <= t0 + i) ++bi;
+                const NbDesc d = single ? d0 : desc_of(bi);
+                int cp;
+                bool cns;
+                const int64_t cr = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, t0 + i, cp, cns);
+                state = (cr >= 0 && (cns || o == O_EXTRA || cp > m)) ? 1 : 2;
             }
+            if (state == 1) atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
         }
     }
     __syncthreads();
 
-    // ---- record slots: prefix over the tile's emit bitmap (row order), one atomic per tile ----
+    // ---- the tile's emit bitmap and count ----
     if (wave == 0) {
-        const int c = lane < TILE / 64 ? __popcll(s_emask[lane]) : 0;
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane < TILE / 64) s_eprefix[lane] = incl - c;
-        if (lane == 63) {
-            s_eprefix[TILE / 64] = incl;
-            long long base = 0;
-            if (incl > 0) {     // slots come from the counter of this tile's shard; shard s owns [s*cap/8, (s+1)*cap/8)
-                const int sh = (int)(tile & (NSHARD - 1));
-                const long long per = A.U.capacity / NSHARD;
-                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)incl);
-                base = sh * per + off;
-                if (off + incl > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
-            }
-            s_base = base;
-            A.tile_base[tile] = base;
-            A.tile_cnt[tile] = incl;
-        }
-    }
-    __syncthreads();
-    const int total = s_eprefix[TILE / 64];
-    if (total == 0 || A.debug == 3) return;
-    {
-        uint32_t mk = emit_bits;
-        while (mk) {
-            const int b = __builtin_ctz(mk);
-            mk &= mk - 1;
-            const int i = ((b >> 2) * NTHREADS + tid) * 4 + (b & 3);
-            const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
-            s_emit[q] = (uint16_t)i;
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 3: emission; window rows are read back from LDS ----
-    const int64_t base = s_base;
-    if (base < 0) return;                                    // record buffer too small: the host retries
-    RowSrc S{s_pos, s_d, s_fl, T.pos, T.ev, T.mu, T.flags, t0, t1, false, 0.0};
-    const bool coop = total <= COOP_MAX;
-    for (int q = coop ? wave : tid; q < total; q += coop ? NTHREADS / 64 : NTHREADS) {
-        const int64_t slot = base + q;
-        const int i = s_emit[q];
-        const int64_t r = t0 + i;
-        int bi = 0;
-        if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
-        const NbDesc d = single ? d0 : desc_of(bi);
-        const int o = (s_fl[i] >> 4) & 15;
-        const int sb = bi < NBST ? bi : 0;
-        const int snw = bi < NBST ? td.nw[sb] : 0;
-        if (o == 14) {
-            if (!coop || lane == 0) emit_extra(A, S, d, nb0 + bi, slot);
-        } else if (coop) {
-            emit_record_coop(A, S, d, nb0 + bi, r, s_pos[i] + o, slot, s_bits[sb], td.w0[sb], snw, lane);
-        } else {
-            emit_record(A, S, d, nb0 + bi, r, s_pos[i] + o, slot, s_bits[sb], td.w0[sb], snw);
-        }
+        const unsigned long long w = lane < TILE / 64 ? s_emask[lane] : 0ull;
+        if (lane < TILE / 64) A.bitmap[tile * (TILE / 64) + lane] = w;
+        int c = __popcll(w);
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) A.tile_cnt[tile] = c;
     }
 }
 
+// Tile counts -> first record slot of every tile, two levels: groups of 1024 tiles are scanned here (coalesced),
+// the prefix over the group totals is added by the consumers (tile_slot()).
+constexpr int GROUP = 1024;
+
+__global__ __launch_bounds__(GROUP) void k1_group_scan(const int32_t *__restrict__ tile_cnt, int64_t n_tiles,
+                                                       int32_t *__restrict__ tile_local, int64_t *__restrict__ group_sum) {
+    __shared__ int s_w[GROUP / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = blockIdx.x * (int64_t)GROUP + tid;
+    const int c = t < n_tiles ? tile_cnt[t] : 0;
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < GROUP / 64; ++w) {
+        if (w < wave) off += s_w[w];
+        total += s_w[w];
+    }
+    if (t < n_tiles) tile_local[t] = off + incl - c;
+    if (tid == 0) group_sum[blockIdx.x] = total;
+}
+
+// first record slot of a tile; wave-uniform call (all 64 lanes), n_groups <= a few hundred
+__device__ __forceinline__ int64_t tile_slot(const int32_t *__restrict__ tile_local, const int64_t *__restrict__ group_sum,
+                                             int64_t tile, int lane) {
+    const int g = (int)(tile / GROUP);
+    long long part = 0;
+    for (int i = lane; i < g; i += 64) part += group_sum[i];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    return part + tile_local[tile];
+}
+
+// Record for the window of site m whose last row is r, in name block nb_abs (descriptor d).
+__device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r, int m,
+                                            int64_t slot) {
+    const DevTable &T = A.T;
+    const int k = A.k;
+    const int64_t L = d.contig_len;
+    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+    int close_pos;
+    bool close_ns;
+    const int64_t close_row = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, r, close_pos, close_ns);
+    uint32_t info = d.rev ? MC_I_REV : 0u;
+
+    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first / the block start) ----
+    // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
+    const int64_t lb = max(d.row_begin, d.first);
+    unsigned long long cnt8 = 0;
+    bool big = false;
+    int64_t ws = r;
+    for (int64_t rr = r; rr >= lb; --rr) {
+        if (T.flags[rr] & MC_F_MODEL_N) continue;
+        const int p = T.pos[rr];
+        if (p < m - k + 1) break;
+        const int sh = 8 * (m - p);
+        if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
+        else cnt8 += 1ull << sh;
+        ws = rr;
+    }
+    // the stray event of a palindromic first site row: first in the slot of its pseudo-position
+    int stray_slot = -1;
+    if (d.stray_q != NO_STRAY) {
+        const int sq = m - d.stray_q;
+        if (sq >= 0 && sq < k) {
+            stray_slot = sq;
+            if (((cnt8 >> (8 * sq)) & 0xFFull) >= 128ull) big = true;
+            else cnt8 += 1ull << (8 * sq);
+        }
+    }
+    int nskip = 0;
+    for (int s = 0; s < k; ++s) nskip += (((cnt8 >> (8 * s)) & 0xFFull) == 0ull);
+
+    if (nskip > A.skip_thresh) {
+        info |= MC_I_TOO_MANY;
+        for (int s = 0; s < k; ++s) A.O.feats[slot * k + s] = 0.0;
+    } else {
+        int64_t cur = ws;
+        for (int s = k - 1; s >= 0; --s) {             // positions ascend => slots descend
+            const int dst = d.rev ? s : k - 1 - s;      // :187-188
+            const int n = (int)((cnt8 >> (8 * s)) & 0xFFull);
+            double f = 0.0;
+            if (n == 0) info |= 1u << dst;
+            else if (!big) {
+                if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
+                f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
+            }
+            A.O.feats[slot * k + dst] = f;
+        }
+        if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
+        // context[k], the character after the 'M', picks the sub-model (:197)
+        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
+            info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
+        } else {
+            unsigned char ch;
+            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
+            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
+            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
+            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+        }
+    }
+    // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
+    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {
+        if (first_m(bits, L, close_pos, k) > 0) info |= MC_I_MULTI;
+    }
+    A.O.site_pos[slot] = m;
+    A.O.site_seg[slot] = T.nb_seg_begin[nb_abs];        // regular blocks have one segment
+    A.O.close_row[slot] = close_row;
+    A.O.info[slot] = info;
+    A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// The one-event '+' window a reverse read opens on a palindromic first site row (R5): flushed with k-1 empty slots.
+__device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int nb_abs, int64_t slot) {
+    int close_pos;
+    bool close_ns;
+    const int64_t close_row = find_close(A.T, A.desc, A.tail_contig, nb_abs, d.row_end, d.extra_row, close_pos, close_ns);
+    for (int s = 0; s < A.k; ++s) A.O.feats[slot * A.k + s] = 0.0;
+    A.O.site_pos[slot] = d.extra_mpos;
+    A.O.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
+    A.O.close_row[slot] = close_row;
+    A.O.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi) ? MC_I_MULTI : 0u);
+    A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// One wave per tile: the rows (global indices) of the tile's closed windows, in record order.
+__global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ rec_row) {
+    const DevTable &T = A.T;
+    const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (tile >= T.n_tiles) return;
+    const int n_groups = (int)((T.n_tiles + GROUP - 1) / GROUP);
+    if (tile == T.n_tiles - 1) {       // the last tile's wave also publishes the total
+        const int64_t tot = tile_slot(A.tile_local, A.group_sum, tile, lane) + A.tile_cnt[tile];
+        if (lane == 0) A.cnt->n_records = (unsigned long long)tot;
+        (void)n_groups;
+    }
+    if (A.tile_cnt[tile] == 0) return;
+    unsigned long long w = lane < TILE / 64 ? A.bitmap[tile * (TILE / 64) + lane] : 0ull;
+    const int c = __popcll(w);
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    int64_t slot = tile_slot(A.tile_local, A.group_sum, tile, lane) + (incl - c);
+    if (slot + c > A.O.capacity) { if (c) atomicOr(&A.cnt->overflow, 1u); return; }
+    while (w) {
+        const int b = __builtin_ctzll(w);
+        w &= w - 1;
+        rec_row[slot++] = tile * TILE + 64 * lane + b;
+    }
+}
+
+constexpr int WROWS = 32;   // rows fetched at once by the emission fast path
+constexpr int WNEXT = 4;    // rows after r examined for the closing row
+
+// One thread per closed window.  Fast path: the window's rows lie among the WROWS rows ending at r: all columns of
+// those rows are fetched with independent loads (one memory round trip) and reduced from registers, in NumPy's
+// pairwise order.  Longer windows and blocks with a stray event (R5) take the row-at-a-time walk (emit_record).
+__global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restrict__ rec_row) {
+    const DevTable &T = A.T;
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= (int64_t)A.cnt->n_records || q >= A.O.capacity) return;
+    const int k = A.k;
+    const int64_t r = rec_row[q];
+    const TileDesc td = A.tiles[r / TILE];
+    int nb = td.nb0;
+    NbDesc d = A.desc[nb];
+    while (r >= d.row_end) { ++nb; d = A.desc[nb]; }
+    if (r == d.extra_row) { emit_extra(A, d, nb, q); return; }
+    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+
+    // ---- fetch rows r-WROWS+1 .. r+WNEXT ----
+    const int64_t lb = max(d.row_begin, d.first);
+    uint32_t nmask = 0, oob = 0;        // bit j: row r-j is an N row / lies before the block's window range
+    int32_t ps[WROWS], dv[WROWS];
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+        const int64_t rr = r - j;
+        const bool inb = rr >= lb;
+        const int64_t ra = inb ? rr : r;                  // clamp: values unused when out of range
+        if (!inb) oob |= 1u << j;
+        if (T.flags[ra] & MC_F_MODEL_N) nmask |= 1u << j;
+        ps[j] = T.pos[ra];
+        dv[j] = T.ev[ra] - T.mu[ra];
+    }
+    int close_pos = 0;
+    int64_t close_row = -1;
+    bool close_ns = false;
+#pragma unroll
+    for (int j = WNEXT; j >= 1; --j) {                    // nearest non-N row of my block after r
+        const int64_t rr = r + j;
+        const bool in = rr < d.row_end;
+        const int64_t ra = in ? rr : r;
+        const bool n = T.flags[ra] & MC_F_MODEL_N;
+        const int pj = T.pos[ra];
+        if (in && !n) { close_row = rr; close_pos = pj; }
+    }
+    if (close_row < 0)                                    // block end, EOF or a run of N rows: general search
+        close_row = find_close(T, A.desc, A.tail_contig, nb, d.row_end, r, close_pos, close_ns);
+    const int m = ps[0] + first_m(bits, d.contig_len, ps[0], k);
+
+    // ---- window extent and per-slot counts (packed 8 bits each) ----
+    unsigned long long cnt8 = 0;
+    bool open = true, terminated = false, big = false;
+    uint32_t inwin = 0;
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+        const bool o = (oob >> j) & 1u;
+        const bool valid = !o && !((nmask >> j) & 1u);
+        if (open && (o || (valid && ps[j] < m - k + 1))) { open = false; terminated = true; }
+        if (open && valid) {
+            inwin |= 1u << j;
+            const int sh = 8 * (m - ps[j]);
+            if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
+            else cnt8 += 1ull << sh;
+        }
+    }
+    if (!terminated || d.stray_q != NO_STRAY || big) {
+        RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
+        emit_record(A, S, d, nb, r, m, q);
+        return;
+    }
+    int nskip = 0;
+    bool any8 = false;
+    for (int s2 = 0; s2 < k; ++s2) {
+        const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
+        nskip += (n == 0);
+        any8 |= (n >= 8);
+    }
+
+    uint32_t info = d.rev ? MC_I_REV : 0u;
+    if (nskip > A.skip_thresh) {
+        info |= MC_I_TOO_MANY;
+        for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+    } else {
+        double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, f5 = 0.0, f6 = 0.0, f7 = 0.0;
+        if (!any8) {
+            // every slot has < 8 events: sequential from -0.0, oldest row first (np.mean, :186)
+            f0 = f1 = f2 = f3 = f4 = f5 = f6 = f7 = -0.0;
+#pragma unroll
+            for (int j = WROWS - 1; j >= 0; --j) {
+                if (!(inwin & (1u << j))) continue;
+                const double v = (double)dv[j] / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+                switch (m - ps[j]) {
+                    case 0: f0 += v; break;
+                    case 1: f1 += v; break;
+                    case 2: f2 += v; break;
+                    case 3: f3 += v; break;
+                    case 4: f4 += v; break;
+                    case 5: f5 += v; break;
+                    case 6: f6 += v; break;
+                    default: f7 += v; break;
+                }
+            }
+        } else {
+            // a slot with 8..128 events: NumPy's eight strided accumulators, slot by slot
+            for (int s2 = 0; s2 < k; ++s2) {
+                const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
+                const int n8 = n < 8 ? 0 : n - (n % 8);
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0, tail = -0.0;
+                int i = 0;
+#pragma unroll
+                for (int j = WROWS - 1; j >= 0; --j) {
+                    if (!(inwin & (1u << j)) || m - ps[j] != s2) continue;
+                    const double v = (double)dv[j] / 10000.0;
+                    if (i < n8) {
+                        switch (i & 7) {
+                            case 0: r0 += v; break;
+                            case 1: r1 += v; break;
+                            case 2: r2 += v; break;
+                            case 3: r3 += v; break;
+                            case 4: r4 += v; break;
+                            case 5: r5 += v; break;
+                            case 6: r6 += v; break;
+                            default: r7 += v; break;
+                        }
+                        if (i == n8 - 1) tail = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                    } else {
+                        tail += v;
+                    }
+                    ++i;
+                }
+                switch (s2) {
+                    case 0: f0 = tail; break;
+                    case 1: f1 = tail; break;
+                    case 2: f2 = tail; break;
+                    case 3: f3 = tail; break;
+                    case 4: f4 = tail; break;
+                    case 5: f5 = tail; break;
+                    case 6: f6 = tail; break;
+                    default: f7 = tail; break;
+                }
+            }
+        }
+        const double acc[MC_MAX_K] = {f0, f1, f2, f3, f4, f5, f6, f7};
+#pragma unroll
+        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
+            if (s2 >= k) continue;
+            const int dst = d.rev ? s2 : k - 1 - s2;      // :187-188
+            const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
+            double f = 0.0;
+            if (n == 0) info |= 1u << dst;
+            else f = (0.0 + acc[s2]) / (double)n;
+            A.O.feats[q * k + dst] = f;
+        }
+        const int64_t L = d.contig_len;
+        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
+            info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
+        } else {
+            unsigned char ch;
+            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
+            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
+            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
+            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+        }
+    }
+    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {         // the closing row shifts the window (:242-248)
+        if (first_m(bits, d.contig_len, close_pos, k) > 0) info |= MC_I_MULTI;
+    }
+    A.O.site_pos[q] = m;
+    A.O.site_seg[q] = T.nb_seg_begin[nb];
+    A.O.close_row[q] = close_row;
+    A.O.info[q] = info;
+    A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
-// thread per such record, so that the scan kernel carries neither the stack nor the registers for it.
+// thread per such record, so that k1_emit carries neither the stack nor the registers for it.
 __device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
     // emulate  f(n) = n <= 128 ? leaf(n) : f(n2) + f(n - n2),  n2 = n/2 rounded down to a multiple of 8
     int64_t fsize[40];
@@ -941,9 +1009,10 @@ __device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
     return ret;
 }
 
-__global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
+__global__ void k1_bigfix(K1Args A, int64_t n) {
     const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= n) return;
+    const DevRecords &O = A.O;
     const uint32_t info = O.info[j];
     if (!(info & MC_I_BIG)) return;
     const DevTable &T = A.T;
@@ -958,9 +1027,9 @@ __global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
         if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
     }
     const NbDesc d = A.desc[lo];
-    RowSrc S{nullptr, nullptr, nullptr, T.pos, T.ev, T.mu, T.flags, 0, 0, false, 0.0};
+    RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
     // last row of the window: the last unfiltered row of the block before the closing row
-    int64_t r = min(O.close_row[j], T.nb_row_begin[lo + 1]) - 1;
+    int64_t r = min(O.close_row[j], d.row_end) - 1;
     const int64_t lb = max(d.row_begin, d.first);
     while (r >= lb && (T.flags[r] & MC_F_MODEL_N)) --r;
     int64_t cnt[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -986,91 +1055,6 @@ __global__ void k1_bigfix(K1Args A, DevRecords O, int64_t n) {
         O.feats[j * k + dst] = f;
     }
     O.info[j] = info & ~MC_I_BIG;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// record ordering: per-tile runs (tile_base, tile_cnt) in arrival order -> file order, tombstones dropped
-// ---------------------------------------------------------------------------------------------------
-// pass 1: one wave per tile counts live records
-__global__ void k_order_count(DevRecords U, const int64_t *tile_base, const int32_t *tile_cnt, int64_t n_tiles,
-                              int32_t *tile_live) {
-    const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (t >= n_tiles) return;
-    const int64_t base = tile_base[t];
-    const int n = base < 0 ? 0 : tile_cnt[t];
-    int live = 0;
-    for (int i = lane; i < n; i += 64) live += (U.site_seg[base + i] >= 0);
-    for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
-    if (lane == 0) tile_live[t] = live;
-}
-
-// pass 2: single workgroup exclusive scan of tile_live -> tile_out, total
-__global__ void k_order_scan(const int32_t *tile_live, int64_t n_tiles, int64_t *tile_out, Counters *cnt) {
-    __shared__ long long s_part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (n_tiles + 1023) / 1024;
-    const int64_t lo = tid * per, hi = min(lo + per, n_tiles);
-    long long sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += tile_live[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        long long v = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    long long run = s_part[tid] - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        tile_out[i] = run;
-        run += tile_live[i];
-    }
-    if (tid == 1023) cnt->n_records = (unsigned long long)s_part[1023];
-}
-
-// pass 3: one wave per tile moves its live records to their final slots
-// ... and fills in what the host needs to pick the sub-model: context[k], the character after the 'M' (:197)
-__global__ void k_order_gather(DevRecords U, DevRecords O, const int64_t *tile_base, const int32_t *tile_cnt,
-                               const int64_t *tile_out, int64_t n_tiles, int k, DevRef R,
-                               const int32_t *__restrict__ seg_contig) {
-    const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (t >= n_tiles) return;
-    const int64_t base = tile_base[t];
-    const int n = base < 0 ? 0 : tile_cnt[t];
-    int64_t dst = tile_out[t];
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const bool live = i < n && U.site_seg[base + i] >= 0;
-        const unsigned long long mask = __ballot(live);
-        if (live) {
-            const int64_t s = base + i;
-            const int64_t d = dst + __popcll(mask & ((1ull << lane) - 1ull));
-            for (int f = 0; f < k; ++f) O.feats[d * k + f] = U.feats[s * k + f];
-            O.site_pos[d] = U.site_pos[s];
-            O.site_seg[d] = U.site_seg[s];
-            O.close_row[d] = U.close_row[s];
-            uint32_t info = U.info[s];
-            if (!(info & MC_I_TOO_MANY)) {
-                const int contig = seg_contig[U.site_seg[s]];
-                const int64_t L = R.contig_len[contig];
-                const int m = U.site_pos[s];
-                if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
-                    info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
-                } else {
-                    unsigned char ch;
-                    const uint8_t *seq = R.seq + R.seq_off[contig];
-                    if (!(info & MC_I_REV)) ch = bit_at(R.mf + R.word_off[contig], m + 1) ? 'M' : seq[m + 1];
-                    else ch = bit_at(R.mr + R.word_off[contig], m - 1) ? 'M' : comp_char(seq[m - 1]);
-                    info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-                }
-            }
-            O.info[d] = info;
-            O.prob[d] = __longlong_as_double(0x7ff8000000000000LL);
-        }
-        dst += __popcll(mask);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1143,9 +1127,12 @@ struct mc_ctx {
     TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
-    DevRecords U, O;
-    int64_t *tile_base = nullptr, *tile_out = nullptr;
-    int32_t *tile_cnt = nullptr, *tile_live = nullptr;
+    DevRecords O;
+    int32_t *tile_local = nullptr;
+    int64_t *group_sum = nullptr;
+    int32_t *tile_cnt = nullptr;
+    unsigned long long *bitmap = nullptr;
+    int64_t *rec_row = nullptr;
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
@@ -1300,10 +1287,10 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     if (dev_alloc(c->table_allocs, &c->tiles, (size_t)T.n_tiles + 1) || dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_out, (size_t)T.n_tiles + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_live, (size_t)T.n_tiles + 1))
+        dev_alloc(c->table_allocs, &c->bitmap, ((size_t)T.n_tiles + 1) * (TILE / 64)) ||
+        dev_alloc(c->table_allocs, &c->tile_local, (size_t)T.n_tiles + 1) ||
+        dev_alloc(c->table_allocs, &c->group_sum, (size_t)(T.n_tiles / GROUP + 2)) ||
+        dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1))
         return -10;
     if (T.n_nb > 0) {
         const int64_t threads = (int64_t)T.n_nb * 64;
@@ -1354,16 +1341,17 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
 }
 
 static int ensure_records(mc_ctx *c, int64_t cap, int k) {
-    if (c->U.capacity >= cap && c->last_k == k) return 0;
+    if (c->O.capacity >= cap && c->last_k == k) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_pool(c->rec_allocs);
-    for (DevRecords *D : {&c->U, &c->O}) {
+    for (DevRecords *D : {&c->O}) {
         D->capacity = cap;
         if (dev_alloc(c->rec_allocs, &D->feats, (size_t)cap * k) || dev_alloc(c->rec_allocs, &D->site_pos, (size_t)cap) ||
             dev_alloc(c->rec_allocs, &D->site_seg, (size_t)cap) || dev_alloc(c->rec_allocs, &D->close_row, (size_t)cap) ||
             dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
             return -10;
     }
+    if (dev_alloc(c->rec_allocs, &c->rec_row, (size_t)cap)) return -10;
     c->last_k = k;
     return 0;
 }
@@ -1396,70 +1384,66 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
 
-    int64_t cap = std::max<int64_t>(1 << 16, T.n_rows / 4 + 1024);
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        if (int rc = ensure_records(c, cap, k)) return rc;
-        HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        {
-            const int64_t threads = (int64_t)T.n_nb * 64;
-            hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
-            hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
-            hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R, c->desc,
-                               k, c->tiles);
-        }
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        K1Args A;
-        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.U = c->U; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
-        A.cnt = c->cnt; A.k = k; A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
-        { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-        hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
-        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        {
-            const int64_t threads = T.n_tiles * 64;
-            const unsigned g = (unsigned)((threads + 255) / 256);
-            hipLaunchKernelGGL(k_order_count, dim3(g), dim3(256), 0, c->stream, c->U, c->tile_base, c->tile_cnt, T.n_tiles,
-                               c->tile_live);
-            hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, c->stream, c->tile_live, T.n_tiles, c->tile_out, c->cnt);
-            hipLaunchKernelGGL(k_order_gather, dim3(g), dim3(256), 0, c->stream, c->U, c->O, c->tile_base, c->tile_cnt,
-                               c->tile_out, T.n_tiles, k, c->R, T.seg_contig);
-        }
-        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-        Counters h;
-        HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipGetLastError());
-        if (h.overflow) {
-            cap *= 4;
-            continue;
-        }
-        if (h.n_irregular) {
-            mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
-                         "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
-                         "contigs): not available in this build of the HIP path", h.n_irregular);
-            return -20;
-        }
-        const int64_t n = (int64_t)h.n_records;
-        if (h.n_big && n > 0)
-            hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, c->O, n);
-        if (prm->score && n > 0) {
-            hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M,
-                               c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
-                               c->O.prob);
-        }
-        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipGetLastError());
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
-        c->last_n = n;
-        *n_records = n;
-        return 0;
+    if (int rc = ensure_records(c, std::max<int64_t>(1 << 16, T.n_rows / 64 + 1024), k)) return rc;
+    HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    {
+        const int64_t threads = (int64_t)T.n_nb * 64;
+        hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                           c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
+        hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                           c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
+        hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R, c->desc,
+                           k, c->tiles);
     }
-    mc_set_error("record buffer overflow after 3 attempts");
-    return -13;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    K1Args A;
+    A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.bitmap = c->bitmap; A.tile_cnt = c->tile_cnt;
+    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k; A.skip_thresh = prm->skip_thresh;
+    A.tail_contig = prm->tail_contig;
+    { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+    hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    const unsigned g_emit = (unsigned)((T.n_tiles * 64 + 255) / 256);
+    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
+                       (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
+    hipLaunchKernelGGL(k1_list, dim3(g_emit), dim3(256), 0, c->stream, A, c->rec_row);
+    hipLaunchKernelGGL(k1_emit, dim3((unsigned)((c->O.capacity + 255) / 256)), dim3(256), 0, c->stream, A,
+                       (const int64_t *)c->rec_row);
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    Counters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (h.n_irregular) {
+        mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
+                     "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
+                     "contigs): not available in this build of the HIP path", h.n_irregular);
+        return -20;
+    }
+    const int64_t n = (int64_t)h.n_records;
+    if (h.overflow) {                       // the record buffer was a guess: now the exact size is known
+        if (int rc = ensure_records(c, n + 1024, k)) return rc;
+        A.O = c->O;
+        hipLaunchKernelGGL(k1_list, dim3(g_emit), dim3(256), 0, c->stream, A, c->rec_row);
+        hipLaunchKernelGGL(k1_emit, dim3((unsigned)((c->O.capacity + 255) / 256)), dim3(256), 0, c->stream, A,
+                           (const int64_t *)c->rec_row);
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    }
+    if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
+    if (prm->score && n > 0) {
+        hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M,
+                           c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
+                           c->O.prob);
+    }
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
+    c->last_n = n;
+    *n_records = n;
+    return 0;
 }
 
 extern "C" int mc_fetch_records(mc_ctx *c, const mc_calls_view *out) {

@@ -87,7 +87,7 @@ class Device(object):
     def times_ms(self):
         t = np.zeros(5, dtype=np.float32)
         check(lib().mc_last_times_ms(self._ctx, _ptr(t)))
-        return dict(strand_resolve=float(t[0]), window_scan=float(t[1]), order=float(t[2]), classifier=float(t[3]),
+        return dict(strand_resolve=float(t[0]), window_scan=float(t[1]), emit=float(t[2]), classifier=float(t[3]),
                     total=float(t[4]))
 
     def mlp_forward(self, X, submodel):
