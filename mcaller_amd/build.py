@@ -16,8 +16,9 @@ def build_lib(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
            '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs
-    if os.environ.get('MC_TILE'):
-        cmd.insert(1, '-DMC_TILE=' + os.environ['MC_TILE'])
+    for macro in ('MC_TILE', 'MC_SCAN_WAVES'):
+        if os.environ.get(macro):
+            cmd.insert(1, '-D%s=%s' % (macro, os.environ[macro]))
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -13,7 +13,7 @@
 //                                rows that end a window (last row whose first 'M' is the site) walk back
 //                                over the <= k positions of their window in LDS to build the slot means
 //                                (NumPy pairwise order, fp64) -> one flush record per closed window
-//                k1_offsets/k1_emit  per closed window: gather its rows, build the record, in file order
+//                k1_group_scan/k1_list/k1_emit  per closed window: build the record, in file order
 //                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64 (one lane per record)
 //
 // Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
@@ -84,6 +84,7 @@ static_assert(sizeof(NbDesc) == 64, "NbDesc layout");
 struct DevTable {
     int64_t n_rows = 0;
     int32_t *pos = nullptr, *ev = nullptr, *mu = nullptr, *idx = nullptr;
+    int2 *evmu = nullptr;     // (event, model) interleaved: one DRAM page per window for k1_emit
     uint8_t *flags = nullptr;
     int32_t n_seg = 0;
     int64_t *seg_begin = nullptr;
@@ -200,6 +201,11 @@ __global__ void k_tile_nb(DevTable T) {
     T.tile_nb[t] = lo;
 }
 
+__global__ void k_interleave(DevTable T) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < T.n_rows) T.evmu[i] = make_int2(T.ev[i], T.mu[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K0: strand resolve
 // ---------------------------------------------------------------------------------------------------
@@ -222,23 +228,37 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
             const int64_t L = R.contig_len[contig];
             const uint32_t *mf = R.mf + R.word_off[contig], *mr = R.mr + R.word_off[contig];
             const int64_t se = T.seg_begin[seg + 1];
-            for (int64_t base = T.seg_begin[seg]; base < se; base += 64) {
-                const int64_t r = base + lane;
-                bool c = false;
-                int rev = 0;
-                if (r < se) {
-                    const uint32_t fl = T.flags[r];
-                    if (!(fl & MC_F_MODEL_N)) {
-                        rev = (fl & MC_F_KMER_EQ) ? 0 : 1;
-                        c = first_m(rev ? mr : mf, L, T.pos[r], k) >= 0;
-                    }
+            for (int64_t base = T.seg_begin[seg]; base < se && f0 < 0; base += 256) {
+                // four stripes of 64 rows; all loads of the iteration are issued before any is used
+                uint32_t fl[4];
+                int ps[4];
+                uint64_t wf[4], wr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t r = base + u * 64 + lane;
+                    const int64_t ra = r < se ? r : se - 1;
+                    fl[u] = r < se ? (uint32_t)T.flags[ra] : (uint32_t)MC_F_MODEL_N;
+                    ps[u] = T.pos[ra];
                 }
-                const unsigned long long mask = __ballot(c);
-                if (mask) {
-                    const int first = __builtin_ctzll(mask);
-                    f0 = base + first;
-                    f0rev = __shfl(rev, first);
-                    break;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t p = ps[u] < L ? ps[u] : 0;
+                    const int64_t w0 = p >> 5;
+                    wf[u] = ((uint64_t)mf[w0 + 1] << 32) | mf[w0];
+                    wr[u] = ((uint64_t)mr[w0 + 1] << 32) | mr[w0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rev = (fl[u] & MC_F_KMER_EQ) ? 0 : 1;
+                    uint64_t w = (rev ? wr[u] : wf[u]) >> (ps[u] & 31);
+                    w &= (1ull << k) - 1ull;
+                    const bool c = !(fl[u] & MC_F_MODEL_N) && ps[u] < L && w != 0ull;
+                    const unsigned long long mask = __ballot(c);
+                    if (mask && f0 < 0) {
+                        const int first = __builtin_ctzll(mask);
+                        f0 = base + u * 64 + first;
+                        f0rev = __shfl(rev, first);
+                    }
                 }
             }
         }
@@ -419,12 +439,29 @@ struct TileDesc {      // per tile, written by k0_tiles after classification
     uint8_t pad[8 - NBST];
 };
 
+// What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
+constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_SLOW = 4, PF_MULTI = 8;
+
+struct __attribute__((aligned(16))) Payload {
+    int64_t r;          // last row of the window
+    int64_t close_row;  // row that closes it (:179); n_rows: in the next shard; -1 cannot occur (not emitted)
+    int32_t m;          // the site
+    int32_t close_pos;
+    uint32_t code[4];   // bit planes: rows r-j, j = 0..31 -> slot (k-mer offset) 0..7, or 15 = not in the window
+    uint32_t flags;     // PF_*
+    int32_t nb;         // name block
+};
+static_assert(sizeof(Payload) == 48, "Payload layout");
+
 struct K1Args {
     DevTable T;
     DevRef R;
     const NbDesc *desc;
     const TileDesc *tiles;
     unsigned long long *bitmap;   // [n_tiles * TILE/64] emit bits, row order
+    Payload *payload;             // [payload_cap]
+    long long payload_cap;
+    int64_t *tile_base;           // [n_tiles] first payload slot of the tile
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -501,12 +538,18 @@ __device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *_
     return tail_contig >= 0 ? T.n_rows : -1;
 }
 
-__global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
+#ifndef MC_SCAN_WAVES
+#define MC_SCAN_WAVES 1
+#endif
+__global__ __launch_bounds__(NTHREADS, MC_SCAN_WAVES) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];   // flags (N, name start) | first-'M' offset << 4
     __shared__ unsigned long long s_emask[TILE / 64];
+    __shared__ int s_eprefix[TILE / 64 + 1];
+    __shared__ uint16_t s_emit[TILE];
     __shared__ uint32_t s_bits[NBST][BW];
     __shared__ NbDesc s_nb[NBMAX];
+    __shared__ long long s_base;
 
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
@@ -558,6 +601,14 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     const int nb_last = td.nnb - 1;                // largest relative block index in this tile
     const bool single = nb_last == 0;
     const NbDesc d0 = s_nb[0];
+    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
+    auto site_offset = [&](const NbDesc &d, int bi, int p) -> int {        // first 'M' in meth_ref[p:p+k] (:176,:270)
+        const int sw0 = bi == 0 ? td.w0[0] : td.w0[1];
+        const int snw = bi == 0 ? td.nw[0] : (bi == 1 ? td.nw[1] : 0);
+        if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
+            return first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
+        return first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
+    };
     if (A.debug == 2) return;
 
     // ---- pass 1: per row, is its k-mer a site (first 'M' offset, :269-270)?  stage (pos, meta) ----
@@ -568,24 +619,31 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         const int pp[4] = {p4[j].x, p4[j].y, p4[j].z, p4[j].w};
         uint32_t m4 = 0;
         int bi = 0;
+        // the four rows of a quad lie in one regular block most of the time: one test of the mask bits between the
+        // quad's first position and its last position + k clears all four (no 'M' there: ~95 % of quads for GATC)
+        bool quad_clear = false;
+        if (single && d0.mode == MODE_REGULAR && t0 + i0 >= d0.first && i0 + 3 < nrows && d0.extra_row < 0 &&
+            td.nw[0] > 0 && pp[3] >= pp[0] && pp[3] + k - pp[0] <= 64 && (pp[0] >> 5) >= td.w0[0] &&
+            ((pp[3] + k) >> 5) + 1 < td.w0[0] + td.nw[0] && pp[3] + k <= d0.contig_len) {
+            const int wi = (pp[0] >> 5) - td.w0[0];
+            const uint64_t lo = s_bits[0][wi], mid = s_bits[0][wi + 1], hi = s_bits[0][wi + 2];
+            const int sh = pp[0] & 31;
+            uint64_t w = ((mid << 32) | lo) >> sh;
+            if (sh) w |= hi << (64 - sh);
+            const int span = pp[3] + k - pp[0];
+            if (span < 64) w &= (1ull << span) - 1ull;
+            quad_clear = (w == 0ull);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t r = t0 + i0 + u;
             const uint32_t fl = (f4[j] >> (8 * u)) & 0xFFu;
             int o = O_NONE;
-            if (r < t1 && !(fl & MC_F_MODEL_N)) {
+            if (!quad_clear && r < t1 && !(fl & MC_F_MODEL_N)) {
                 if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
                 const NbDesc d = single ? d0 : desc_of(bi);
                 if (d.mode == MODE_REGULAR && r >= d.first) {
-                    const int p = pp[u];
-                    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
-                    const int sw0 = bi == 0 ? td.w0[0] : td.w0[1];
-                    const int snw = bi == 0 ? td.nw[0] : (bi == 1 ? td.nw[1] : 0);
-                    int fm;
-                    if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
-                        fm = first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
-                    else
-                        fm = first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
+                    const int fm = site_offset(d, bi, pp[u]);
                     if (fm >= 0) o = fm;
                 }
                 if (d.mode == MODE_REGULAR && r == d.extra_row) o = O_EXTRA;
@@ -601,6 +659,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
 
     // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
     // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
+    uint32_t emit_bits = 0;                        // bit j*4+u
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int i0 = (j * NTHREADS + tid) * 4;
@@ -628,18 +687,122 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                 const int64_t cr = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, t0 + i, cp, cns);
                 state = (cr >= 0 && (cns || o == O_EXTRA || cp > m)) ? 1 : 2;
             }
-            if (state == 1) atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
+            if (state == 1) {
+                emit_bits |= 1u << (j * 4 + u);
+                atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
+            }
         }
     }
     __syncthreads();
 
-    // ---- the tile's emit bitmap and count ----
+    // ---- the tile's emit bitmap, count and window-payload slots (one atomic per tile, sharded by tile & 7) ----
     if (wave == 0) {
         const unsigned long long w = lane < TILE / 64 ? s_emask[lane] : 0ull;
         if (lane < TILE / 64) A.bitmap[tile * (TILE / 64) + lane] = w;
-        int c = __popcll(w);
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) A.tile_cnt[tile] = c;
+        const int c = __popcll(w);
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane < TILE / 64) s_eprefix[lane] = incl - c;
+        if (lane == 63) {
+            s_eprefix[TILE / 64] = incl;
+            long long base = 0;
+            if (incl > 0) {
+                const int sh = (int)(tile & (NSHARD - 1));
+                const long long per = A.payload_cap / NSHARD;
+                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)incl);
+                base = sh * per + off;
+                if (off + incl > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+            }
+            s_base = base;
+            A.tile_base[tile] = base;
+            A.tile_cnt[tile] = incl;
+        }
+    }
+    __syncthreads();
+    const int total = s_eprefix[TILE / 64];
+    const long long base = s_base;
+    if (total == 0 || base < 0) return;
+    {
+        uint32_t mk = emit_bits;
+        while (mk) {
+            const int b = __builtin_ctz(mk);
+            mk &= mk - 1;
+            const int i = ((b >> 2) * NTHREADS + tid) * 4 + (b & 3);
+            const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
+            s_emit[q] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3: the window of every closed site, 32 lanes per window: which of the 32 rows ending at the window's
+    // last row belong to it and to which slot (k-mer offset), read from LDS; the closing row.  -> 48-byte payload.
+    const int half = lane >> 5, hl = lane & 31;
+    for (int q0 = 0; q0 < total; q0 += 2 * (NTHREADS / 64)) {
+        const int q = q0 + wave * 2 + half;
+        const bool active = q < total;
+        const int i = active ? s_emit[q] : 0;
+        const int64_t r = t0 + i;
+        int bi = 0;
+        if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
+        const NbDesc d = single ? d0 : desc_of(bi);
+        const int o = (s_fl[i] >> 4) & 15;
+        const bool extra = o == O_EXTRA;
+        const int m = s_pos[i] + o;
+        // rows r, r-1, ... r-31
+        const int64_t lb = max(d.row_begin, d.first);
+        const int64_t rr = r - hl;
+        const bool inb = rr >= lb;
+        int pj = 0;
+        bool nj = true;
+        if (active && inb) {
+            if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
+            else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
+        }
+        const bool valid = inb && !nj;
+        const bool stopf = !inb || (valid && pj < m - k + 1);
+        const uint32_t stopmask = (uint32_t)(__ballot(active && stopf) >> (32 * half));
+        const int n_in = stopmask ? __builtin_ctz(stopmask) : 32;
+        const bool inw = active && hl < n_in && valid;
+        const int code = inw ? (m - pj) : 15;
+        const uint32_t c0 = (uint32_t)(__ballot(code & 1) >> (32 * half));
+        const uint32_t c1 = (uint32_t)(__ballot(code & 2) >> (32 * half));
+        const uint32_t c2 = (uint32_t)(__ballot(code & 4) >> (32 * half));
+        const uint32_t c3 = (uint32_t)(__ballot(code & 8) >> (32 * half));
+        // closing row among r+1 .. r+4
+        const int64_t rn = r + 1 + hl;
+        int pn = 0;
+        bool vn = false;
+        if (active && hl < 4 && rn < d.row_end) {
+            if (rn < t1) { pn = s_pos[rn - t0]; vn = !(s_fl[rn - t0] & MC_F_MODEL_N); }
+            else { pn = T.pos[rn]; vn = !(T.flags[rn] & MC_F_MODEL_N); }
+        }
+        const uint32_t cm = (uint32_t)(__ballot(vn) >> (32 * half));
+        const int cj = cm ? __builtin_ctz(cm) : 0;
+        const int close_pos_l = __shfl(pn, half * 32 + cj);
+        if (active && hl == 0) {
+            int64_t close_row;
+            int close_pos = close_pos_l;
+            bool close_ns = false;
+            if (cm) close_row = r + 1 + cj;
+            else close_row = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, extra ? d.extra_row : r, close_pos, close_ns);
+            uint32_t pf = 0;
+            if (extra) pf |= PF_EXTRA;
+            if (close_ns) pf |= PF_CLOSE_NS;
+            if (!stopmask || d.stray_q != NO_STRAY) pf |= PF_SLOW;
+            if (!extra && !close_ns && close_pos <= m + A.skip_thresh + 1 && site_offset(d, bi, close_pos) > 0) pf |= PF_MULTI;
+            Payload P;
+            P.r = r;
+            P.close_row = close_row;
+            P.m = extra ? d.extra_mpos : m;
+            P.close_pos = close_pos;
+            P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
+            P.flags = pf;
+            P.nb = nb0 + bi;
+            A.payload[base + q] = P;
+        }
     }
 }
 
@@ -771,113 +934,74 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
     A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
-// One wave per tile: the rows (global indices) of the tile's closed windows, in record order.
-__global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ rec_row) {
+constexpr int WROWS = 32;   // rows of a window payload
+
+// One wave per tile: where each of the tile's records (file order) finds its payload (arrival order).
+__global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ rec_slot) {
     const DevTable &T = A.T;
     const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (tile >= T.n_tiles) return;
-    const int n_groups = (int)((T.n_tiles + GROUP - 1) / GROUP);
+    const int c = A.tile_cnt[tile];
     if (tile == T.n_tiles - 1) {       // the last tile's wave also publishes the total
-        const int64_t tot = tile_slot(A.tile_local, A.group_sum, tile, lane) + A.tile_cnt[tile];
+        const int64_t tot = tile_slot(A.tile_local, A.group_sum, tile, lane) + c;
         if (lane == 0) A.cnt->n_records = (unsigned long long)tot;
-        (void)n_groups;
     }
-    if (A.tile_cnt[tile] == 0) return;
-    unsigned long long w = lane < TILE / 64 ? A.bitmap[tile * (TILE / 64) + lane] : 0ull;
-    const int c = __popcll(w);
-    int incl = c;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    int64_t slot = tile_slot(A.tile_local, A.group_sum, tile, lane) + (incl - c);
-    if (slot + c > A.O.capacity) { if (c) atomicOr(&A.cnt->overflow, 1u); return; }
-    while (w) {
-        const int b = __builtin_ctzll(w);
-        w &= w - 1;
-        rec_row[slot++] = tile * TILE + 64 * lane + b;
-    }
+    if (c == 0) return;
+    const int64_t first = tile_slot(A.tile_local, A.group_sum, tile, lane);
+    const int64_t base = A.tile_base[tile];
+    if (base < 0 || first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    for (int j = lane; j < c; j += 64) rec_slot[first + j] = base + j;
 }
 
-constexpr int WROWS = 32;   // rows fetched at once by the emission fast path
-constexpr int WNEXT = 4;    // rows after r examined for the closing row
-
-// One thread per closed window.  Fast path: the window's rows lie among the WROWS rows ending at r: all columns of
-// those rows are fetched with independent loads (one memory round trip) and reduced from registers, in NumPy's
-// pairwise order.  Longer windows and blocks with a stray event (R5) take the row-at-a-time walk (emit_record).
-__global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restrict__ rec_row) {
+// One thread per closed window: the (event, model) pairs of the 32 rows ending at the window's last row come in with
+// independent 8-byte loads from the interleaved column (one DRAM page per window); slot sums from registers in NumPy's
+// pairwise order.  Windows longer than 32 rows and blocks with a stray event (R5) take the row-at-a-time walk.
+__global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restrict__ rec_slot) {
     const DevTable &T = A.T;
     const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (q >= (int64_t)A.cnt->n_records || q >= A.O.capacity) return;
     const int k = A.k;
-    const int64_t r = rec_row[q];
-    const TileDesc td = A.tiles[r / TILE];
-    int nb = td.nb0;
-    NbDesc d = A.desc[nb];
-    while (r >= d.row_end) { ++nb; d = A.desc[nb]; }
-    if (r == d.extra_row) { emit_extra(A, d, nb, q); return; }
-    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
-
-    // ---- fetch rows r-WROWS+1 .. r+WNEXT ----
-    const int64_t lb = max(d.row_begin, d.first);
-    uint32_t nmask = 0, oob = 0;        // bit j: row r-j is an N row / lies before the block's window range
-    int32_t ps[WROWS], dv[WROWS];
-#pragma unroll
-    for (int j = 0; j < WROWS; ++j) {
-        const int64_t rr = r - j;
-        const bool inb = rr >= lb;
-        const int64_t ra = inb ? rr : r;                  // clamp: values unused when out of range
-        if (!inb) oob |= 1u << j;
-        if (T.flags[ra] & MC_F_MODEL_N) nmask |= 1u << j;
-        ps[j] = T.pos[ra];
-        dv[j] = T.ev[ra] - T.mu[ra];
-    }
-    int close_pos = 0;
-    int64_t close_row = -1;
-    bool close_ns = false;
-#pragma unroll
-    for (int j = WNEXT; j >= 1; --j) {                    // nearest non-N row of my block after r
-        const int64_t rr = r + j;
-        const bool in = rr < d.row_end;
-        const int64_t ra = in ? rr : r;
-        const bool n = T.flags[ra] & MC_F_MODEL_N;
-        const int pj = T.pos[ra];
-        if (in && !n) { close_row = rr; close_pos = pj; }
-    }
-    if (close_row < 0)                                    // block end, EOF or a run of N rows: general search
-        close_row = find_close(T, A.desc, A.tail_contig, nb, d.row_end, r, close_pos, close_ns);
-    const int m = ps[0] + first_m(bits, d.contig_len, ps[0], k);
-
-    // ---- window extent and per-slot counts (packed 8 bits each) ----
-    unsigned long long cnt8 = 0;
-    bool open = true, terminated = false, big = false;
-    uint32_t inwin = 0;
-#pragma unroll
-    for (int j = 0; j < WROWS; ++j) {
-        const bool o = (oob >> j) & 1u;
-        const bool valid = !o && !((nmask >> j) & 1u);
-        if (open && (o || (valid && ps[j] < m - k + 1))) { open = false; terminated = true; }
-        if (open && valid) {
-            inwin |= 1u << j;
-            const int sh = 8 * (m - ps[j]);
-            if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
-            else cnt8 += 1ull << sh;
-        }
-    }
-    if (!terminated || d.stray_q != NO_STRAY || big) {
-        RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
-        emit_record(A, S, d, nb, r, m, q);
+    const Payload P = A.payload[rec_slot[q]];
+    const NbDesc d = A.desc[P.nb];
+    const int64_t r = P.r;
+    const int m = P.m;
+    if (P.flags & PF_EXTRA) {
+        for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+        A.O.site_pos[q] = m;
+        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+        A.O.close_row[q] = P.close_row;
+        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && d.extra_multi) ? MC_I_MULTI : 0u);
+        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
+    if (P.flags & PF_SLOW) {
+        RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
+        emit_record(A, S, d, P.nb, r, m, q);
+        return;
+    }
+    const uint32_t c0 = P.code[0], c1 = P.code[1], c2 = P.code[2], c3 = P.code[3];
+    const uint32_t inwin = ~(c0 & c1 & c2 & c3);          // code 15 = not part of the window
+    // ---- fetch (event, model) of the window's rows ----
+    int32_t dv[WROWS];
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+        const int64_t ra = (inwin >> j) & 1u ? r - j : r;
+        const int2 em = T.evmu[ra];
+        dv[j] = em.x - em.y;
+    }
+    // per-slot counts
     int nskip = 0;
-    bool any8 = false;
+    bool any8 = false, big = false;
+    unsigned long long cnt8 = 0;
     for (int s2 = 0; s2 < k; ++s2) {
-        const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
+        const uint32_t ms = (s2 & 1 ? c0 : ~c0) & (s2 & 2 ? c1 : ~c1) & (s2 & 4 ? c2 : ~c2) & ~c3;
+        const int n = __popc(ms);
         nskip += (n == 0);
         any8 |= (n >= 8);
+        big |= (n > 128);
+        cnt8 |= (unsigned long long)(n & 0xFF) << (8 * s2);
     }
-
     uint32_t info = d.rev ? MC_I_REV : 0u;
     if (nskip > A.skip_thresh) {
         info |= MC_I_TOO_MANY;
@@ -889,9 +1013,10 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
             f0 = f1 = f2 = f3 = f4 = f5 = f6 = f7 = -0.0;
 #pragma unroll
             for (int j = WROWS - 1; j >= 0; --j) {
-                if (!(inwin & (1u << j))) continue;
+                if (!((inwin >> j) & 1u)) continue;
                 const double v = (double)dv[j] / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
-                switch (m - ps[j]) {
+                const int code = ((c0 >> j) & 1u) | (((c1 >> j) & 1u) << 1) | (((c2 >> j) & 1u) << 2);
+                switch (code) {
                     case 0: f0 += v; break;
                     case 1: f1 += v; break;
                     case 2: f2 += v; break;
@@ -903,15 +1028,16 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
                 }
             }
         } else {
-            // a slot with 8..128 events: NumPy's eight strided accumulators, slot by slot
+            // a slot with 8..32 events: NumPy's eight strided accumulators, slot by slot
             for (int s2 = 0; s2 < k; ++s2) {
                 const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
                 const int n8 = n < 8 ? 0 : n - (n % 8);
+                const uint32_t ms = (s2 & 1 ? c0 : ~c0) & (s2 & 2 ? c1 : ~c1) & (s2 & 4 ? c2 : ~c2) & ~c3;
                 double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0, tail = -0.0;
                 int i = 0;
 #pragma unroll
                 for (int j = WROWS - 1; j >= 0; --j) {
-                    if (!(inwin & (1u << j)) || m - ps[j] != s2) continue;
+                    if (!((ms >> j) & 1u)) continue;
                     const double v = (double)dv[j] / 10000.0;
                     if (i < n8) {
                         switch (i & 7) {
@@ -953,23 +1079,24 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
             else f = (0.0 + acc[s2]) / (double)n;
             A.O.feats[q * k + dst] = f;
         }
+        (void)big;    // a window of 32 rows cannot hold a slot of > 128 events
+        // context[k], the character after the 'M', picks the sub-model (:197)
         const int64_t L = d.contig_len;
         if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
             info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
         } else {
-            unsigned char ch;
+            const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
             const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
+            unsigned char ch;
             if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
             else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
             info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
         }
     }
-    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {         // the closing row shifts the window (:242-248)
-        if (first_m(bits, d.contig_len, close_pos, k) > 0) info |= MC_I_MULTI;
-    }
+    if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
     A.O.site_pos[q] = m;
-    A.O.site_seg[q] = T.nb_seg_begin[nb];
-    A.O.close_row[q] = close_row;
+    A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+    A.O.close_row[q] = P.close_row;
     A.O.info[q] = info;
     A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
 }
@@ -1060,7 +1187,14 @@ __global__ void k1_bigfix(K1Args A, int64_t n) {
 // ---------------------------------------------------------------------------------------------------
 // K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; weights staged in LDS.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+// tanh(x) = sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}): one exp and one division; absolute error ~1e-16, far inside the
+// 1e-5 the probabilities are held to (the library tanh costs several times more and dominates this kernel)
+__device__ __forceinline__ double tanh_1exp(double x) {
+    const double t = exp(-2.0 * fabs(x));
+    return copysign((1.0 - t) / (1.0 + t), x);
+}
+
+__global__ __launch_bounds__(64) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                               const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                               const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                               const uint8_t *__restrict__ submodel_in, int64_t n,
@@ -1097,13 +1231,32 @@ __global__ __launch_bounds__(256) void k2_mlp(DevMlp M, const double *__restrict
     if (mi >= M.n_models) return;            // KeyError path (:218): the host decides
     const double *w = s_w + (size_t)mi * per;
     const double *b1 = w + NI * H, *w2 = b1 + H;
+    // hidden units in groups of four independent chains (the fp64 tanh is a long dependent sequence); the sum over
+    // hidden units keeps its order j = 0, 1, 2, ...
     double z = 0.0;
-    for (int j = 0; j < H; ++j) {
+    int j = 0;
+    for (; j + 4 <= H; j += 4) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i <= MC_MAX_K; ++i)
+            if (i < NI) {
+                const double xi = x[i];
+                a0 += xi * w[i * H + j]; a1 += xi * w[i * H + j + 1];
+                a2 += xi * w[i * H + j + 2]; a3 += xi * w[i * H + j + 3];
+            }
+        const double t0 = tanh_1exp(a0 + b1[j]), t1 = tanh_1exp(a1 + b1[j + 1]), t2 = tanh_1exp(a2 + b1[j + 2]),
+                     t3 = tanh_1exp(a3 + b1[j + 3]);
+        z += t0 * w2[j];
+        z += t1 * w2[j + 1];
+        z += t2 * w2[j + 2];
+        z += t3 * w2[j + 3];
+    }
+    for (; j < H; ++j) {
         double a = 0.0;
 #pragma unroll
         for (int i = 0; i <= MC_MAX_K; ++i)
             if (i < NI) a += x[i] * w[i * H + j];
-        z += tanh(a + b1[j]) * w2[j];
+        z += tanh_1exp(a + b1[j]) * w2[j];
     }
     z += w2[H];
     prob[r] = 1.0 / (1.0 + exp(-z));
@@ -1132,7 +1285,9 @@ struct mc_ctx {
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr;
     unsigned long long *bitmap = nullptr;
-    int64_t *rec_row = nullptr;
+    int64_t *rec_slot = nullptr;
+    Payload *payload = nullptr;
+    int64_t *tile_base = nullptr;
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
@@ -1238,7 +1393,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
     if (dev_alloc(c->table_allocs, &T.pos, (size_t)padded) || dev_alloc(c->table_allocs, &T.ev, (size_t)padded) ||
         dev_alloc(c->table_allocs, &T.mu, (size_t)padded) || dev_alloc(c->table_allocs, &T.idx, (size_t)padded) ||
-        dev_alloc(c->table_allocs, &T.flags, (size_t)padded))
+        dev_alloc(c->table_allocs, &T.flags, (size_t)padded) || dev_alloc(c->table_allocs, &T.evmu, (size_t)padded))
         return -10;
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -1289,6 +1444,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
         dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->bitmap, ((size_t)T.n_tiles + 1) * (TILE / 64)) ||
         dev_alloc(c->table_allocs, &c->tile_local, (size_t)T.n_tiles + 1) ||
+        dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
         dev_alloc(c->table_allocs, &c->group_sum, (size_t)(T.n_tiles / GROUP + 2)) ||
         dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1))
         return -10;
@@ -1296,6 +1452,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
         const int64_t threads = (int64_t)T.n_nb * 64;
         hipLaunchKernelGGL(k_validate, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T);
         hipLaunchKernelGGL(k_tile_nb, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T);
+        hipLaunchKernelGGL(k_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, T);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1351,7 +1508,7 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
             dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
             return -10;
     }
-    if (dev_alloc(c->rec_allocs, &c->rec_row, (size_t)cap)) return -10;
+    if (dev_alloc(c->rec_allocs, &c->rec_slot, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)cap)) return -10;
     c->last_k = k;
     return 0;
 }
@@ -1384,66 +1541,67 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
 
-    if (int rc = ensure_records(c, std::max<int64_t>(1 << 16, T.n_rows / 64 + 1024), k)) return rc;
-    HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    {
-        const int64_t threads = (int64_t)T.n_nb * 64;
-        hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                           c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
-        hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                           c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
-        hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R, c->desc,
-                           k, c->tiles);
-    }
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    K1Args A;
-    A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.bitmap = c->bitmap; A.tile_cnt = c->tile_cnt;
-    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k; A.skip_thresh = prm->skip_thresh;
-    A.tail_contig = prm->tail_contig;
-    { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-    hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    const unsigned g_emit = (unsigned)((T.n_tiles * 64 + 255) / 256);
-    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
-                       (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-    hipLaunchKernelGGL(k1_list, dim3(g_emit), dim3(256), 0, c->stream, A, c->rec_row);
-    hipLaunchKernelGGL(k1_emit, dim3((unsigned)((c->O.capacity + 255) / 256)), dim3(256), 0, c->stream, A,
-                       (const int64_t *)c->rec_row);
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    Counters h;
-    HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipGetLastError());
-    if (h.n_irregular) {
-        mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
-                     "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
-                     "contigs): not available in this build of the HIP path", h.n_irregular);
-        return -20;
-    }
-    const int64_t n = (int64_t)h.n_records;
-    if (h.overflow) {                       // the record buffer was a guess: now the exact size is known
-        if (int rc = ensure_records(c, n + 1024, k)) return rc;
-        A.O = c->O;
-        hipLaunchKernelGGL(k1_list, dim3(g_emit), dim3(256), 0, c->stream, A, c->rec_row);
+    int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->O.capacity);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (int rc = ensure_records(c, cap, k)) return rc;
+        HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        {
+            const int64_t threads = (int64_t)T.n_nb * 64;
+            hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
+            hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                               c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
+            hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                               c->desc, k, c->tiles);
+        }
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        K1Args A;
+        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.bitmap = c->bitmap; A.payload = c->payload;
+        A.payload_cap = c->O.capacity; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
+        A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
+        A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
+        { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+        hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
+                           (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
+        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 64 + 255) / 256)), dim3(256), 0, c->stream, A, c->rec_slot);
         hipLaunchKernelGGL(k1_emit, dim3((unsigned)((c->O.capacity + 255) / 256)), dim3(256), 0, c->stream, A,
-                           (const int64_t *)c->rec_row);
+                           (const int64_t *)c->rec_slot);
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        Counters h;
+        HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        if (h.n_irregular) {
+            mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
+                         "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
+                         "contigs): not available in this build of the HIP path", h.n_irregular);
+            return -20;
+        }
+        const int64_t n = (int64_t)h.n_records;
+        if (h.overflow) {                   // the buffers were a guess; the exact need is known now (+ shard skew)
+            cap = std::max<int64_t>(cap * 2, n + n / 4 + 4096);
+            continue;
+        }
+        if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
+        if (prm->score && n > 0) {
+            hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
+                               c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
+                               c->O.prob);
+        }
+        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
+        c->last_n = n;
+        *n_records = n;
+        return 0;
     }
-    if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
-    if (prm->score && n > 0) {
-        hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M,
-                           c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
-                           c->O.prob);
-    }
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipGetLastError());
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
-    c->last_n = n;
-    *n_records = n;
-    return 0;
+    mc_set_error("record buffer overflow after 3 attempts");
+    return -13;
 }
 
 extern "C" int mc_fetch_records(mc_ctx *c, const mc_calls_view *out) {
@@ -1486,7 +1644,7 @@ extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submode
     HIP_TRY(hipMemcpyAsync(dX, X, (size_t)n * ni * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(ds, submodel, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dp, 0xFF, (size_t)n * 8, c->stream));   // NaN
-    hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 255) / 256)), dim3(256), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
+    hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
                        (const uint32_t *)nullptr, ds, n, dp);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
