@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mcaller_hip.h"
@@ -132,6 +133,7 @@ struct Counters {          // device-side status block
     unsigned int n_irregular;
     unsigned int n_big;
     unsigned int pad[3];
+    unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -429,14 +431,13 @@ __device__ __forceinline__ double leaf_sum(RowSrc &S, int64_t &cur, int n) {
     return res;
 }
 
-struct TileDesc {      // per tile, written by k0_tiles after classification
+struct TileDesc {      // per tile, written by k0_tiles after classification (plain scalars: stays in registers)
     int32_t nb0;       // name block of the tile's first row
     int32_t nnb;       // name blocks that overlap the tile
-    int32_t w0[NBST];  // first word of the strand-mask window staged for block nb0+i (relative to the contig's mask)
-    int32_t nw[NBST];  // words staged (0: none)
-    int64_t boff[NBST];// word offset of that window in the concatenated mask arrays
-    uint8_t rev[NBST]; // which strand's mask
-    uint8_t pad[8 - NBST];
+    int32_t w0a, w0b;  // first word of the strand-mask window staged for block nb0 / nb0+1 (relative to the contig's mask)
+    int32_t nwa, nwb;  // words staged (0: none)
+    int64_t boffa, boffb; // word offset of that window in the concatenated mask arrays
+    int32_t reva, revb;   // which strand's mask
 };
 
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
@@ -461,7 +462,7 @@ struct K1Args {
     unsigned long long *bitmap;   // [n_tiles * TILE/64] emit bits, row order
     Payload *payload;             // [payload_cap]
     long long payload_cap;
-    int64_t *tile_base;           // [n_tiles] first payload slot of the tile
+    int64_t *tile_base;           // [n_tiles] first overflow payload slot of the tile (windows beyond the PT reserved)
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -481,8 +482,9 @@ __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, 
     int nnb = 1;
     while (td.nb0 + nnb < T.n_nb && T.nb_row_begin[td.nb0 + nnb] < t1) ++nnb;
     td.nnb = nnb;
+    td.w0a = td.w0b = td.nwa = td.nwb = td.reva = td.revb = 0;
+    td.boffa = td.boffb = 0;
     for (int sb = 0; sb < NBST; ++sb) {
-        td.w0[sb] = 0; td.nw[sb] = 0; td.boff[sb] = 0; td.rev[sb] = 0;
         if (sb >= nnb) continue;
         const NbDesc d = desc[td.nb0 + sb];
         if (d.mode != MODE_REGULAR) continue;
@@ -493,13 +495,10 @@ __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, 
         const int64_t w1 = min<int64_t>(((int64_t)T.pos[hi - 1] + k) >> 5, wmax - 1) + 1;
         const int64_t nw = w1 - w0 + 1;
         if (nw > 0 && nw <= BW) {
-            td.w0[sb] = (int32_t)w0;
-            td.nw[sb] = (int32_t)nw;
-            td.boff[sb] = R.word_off[d.contig] + w0;
-            td.rev[sb] = d.rev;
+            if (sb == 0) { td.w0a = (int32_t)w0; td.nwa = (int32_t)nw; td.boffa = R.word_off[d.contig] + w0; td.reva = d.rev; }
+            else { td.w0b = (int32_t)w0; td.nwb = (int32_t)nw; td.boffb = R.word_off[d.contig] + w0; td.revb = d.rev; }
         }
     }
-    for (int i = 0; i < 8 - NBST; ++i) td.pad[i] = 0;
     tiles[t] = td;
 }
 
@@ -538,272 +537,318 @@ __device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *_
     return tail_contig >= 0 ? T.n_rows : -1;
 }
 
-#ifndef MC_SCAN_WAVES
-#define MC_SCAN_WAVES 1
+constexpr int PT = 32;              // payload slots reserved per tile (more: one atomic into the overflow area)
+
+// columns of one tile in flight: 16 bytes of positions + 4 flag bytes per lane and quad
+struct TileRegs {
+    int4 p4[TILE / (NTHREADS * 4)];
+    uint32_t f4[TILE / (NTHREADS * 4)];
+    uint32_t descw;                 // dword `tid` of the tile's name-block descriptors
+    uint32_t maskw[NBST];           // word `tid` of the staged strand-mask windows
+};
+
+__device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc &td, int64_t tile, int tid, TileRegs &R) {
+    const DevTable &T = A.T;
+    const int64_t t0 = tile * TILE;
+    const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
+#pragma unroll
+    for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
+        const int i0 = (j * NTHREADS + tid) * 4;
+        R.p4[j] = make_int4(0, 0, 0, 0);
+        R.f4[j] = 0;
+        if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
+            R.p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+            R.f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
+        }
+    }
+    const int nnb = min(td.nnb, NBMAX);
+    const uint32_t *dsrc = reinterpret_cast<const uint32_t *>(A.desc + td.nb0);
+    R.descw = tid < nnb * (int)(sizeof(NbDesc) / 4) ? dsrc[tid] : 0u;
+    R.maskw[0] = tid < td.nwa ? ((td.reva ? A.R.mr : A.R.mf) + td.boffa)[tid] : 0u;
+    R.maskw[1] = tid < td.nwb ? ((td.revb ? A.R.mr : A.R.mf) + td.boffb)[tid] : 0u;
+}
+
+#ifdef MC_PROFILE
+#define PH(n) do { if (tid == 0) { const long long _t = clock64(); ph[n] += _t - ph_t; ph_t = _t; } } while (0)
+#else
+#define PH(n) do {} while (0)
 #endif
-__global__ __launch_bounds__(NTHREADS, MC_SCAN_WAVES) void k1_scan(K1Args A) {
+
+#ifndef MC_SCAN_WGS
+#define MC_SCAN_WGS 5               // resident workgroups per CU the persistent grid is sized for
+#endif
+
+// Persistent workgroups, tiles taken grid-stride; the loads of tile i+1 (columns, descriptors, mask words) are issued
+// before tile i is processed, and its TileDesc one tile earlier still, so no memory round trip sits on the per-tile
+// critical path.
+__global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];   // flags (N, name start) | first-'M' offset << 4
     __shared__ unsigned long long s_emask[TILE / 64];
     __shared__ int s_eprefix[TILE / 64 + 1];
     __shared__ uint16_t s_emit[TILE];
-    __shared__ uint32_t s_bits[NBST][BW];
-    __shared__ NbDesc s_nb[NBMAX];
-    __shared__ long long s_base;
+    __shared__ uint32_t s_bits[NBST][256];
+    __shared__ __attribute__((aligned(16))) NbDesc s_nb[NBMAX];
+    __shared__ long long s_ovf;
 
+    static_assert(BW <= 256 && NBMAX * sizeof(NbDesc) / 4 <= NTHREADS, "one dword per thread");
+    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = blockIdx.x;
-    const int64_t t0 = tile * TILE;
-    const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
-    const int nrows = (int)(t1 - t0);
     const int k = A.k;
+    const int64_t G = gridDim.x;
     constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
-    // ---- issue the tile's column loads: 16 bytes of positions + 4 flag bytes per lane and quad ----
-    int4 p4[NQ];
-    uint32_t f4[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int i0 = (j * NTHREADS + tid) * 4;
-        p4[j] = make_int4(0, 0, 0, 0);
-        f4[j] = 0;
-        if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
-            p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-            f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
-        }
-    }
-    if (A.debug == 1) {
+    int64_t tile = blockIdx.x;
+    if (tile >= T.n_tiles) return;
+#ifdef MC_PROFILE
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
+#endif
+    TileDesc td = A.tiles[tile];
+    TileDesc td_next = td;
+    if (tile + G < T.n_tiles) td_next = A.tiles[tile + G];
+    TileRegs R;
+    tile_issue_loads(A, td, tile, tid, R);
+
+    for (; tile < T.n_tiles; tile += G) {
+        const int64_t t0 = tile * TILE;
+        const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
+        const int nrows = (int)(t1 - t0);
+        const int nb0 = td.nb0;
+        const int nnb = min(td.nnb, NBMAX);            // descriptors staged; beyond: global memory
+
+        // ---- this tile's descriptors, mask words and columns: registers -> LDS ----
+        reinterpret_cast<uint32_t *>(s_nb)[tid] = R.descw;
+        s_bits[0][tid] = R.maskw[0];
+        s_bits[1][tid] = R.maskw[1];
+        if (tid < TILE / 64) s_emask[tid] = 0ull;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * NTHREADS + tid) * 4;
-            *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
-            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = f4[j];
+            *reinterpret_cast<int4 *>(&s_pos[i0]) = R.p4[j];
+            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = R.f4[j];
         }
-        return;
-    }
-
-    // ---- tile metadata: name blocks that overlap the tile, strand-mask windows of the first NBST of them ----
-    const TileDesc td = A.tiles[tile];
-    const int nb0 = td.nb0;
-    const int nnb = min(td.nnb, NBMAX);            // descriptors staged; beyond: global memory
-    if (tid < nnb) s_nb[tid] = A.desc[nb0 + tid];
-#pragma unroll
-    for (int sb = 0; sb < NBST; ++sb) {
-        const uint32_t *bits = (td.rev[sb] ? A.R.mr : A.R.mf) + td.boff[sb];
-        for (int w = tid; w < td.nw[sb]; w += NTHREADS) s_bits[sb][w] = bits[w];
-    }
-    if (tid < TILE / 64) s_emask[tid] = 0ull;
-    __syncthreads();
-    auto desc_of = [&](int bi) -> NbDesc { return (bi < nnb) ? s_nb[bi] : A.desc[nb0 + bi]; };
-    auto begin_of = [&](int bi) -> int64_t { return (bi < nnb) ? s_nb[bi].row_begin : T.nb_row_begin[nb0 + bi]; };
-    const int nb_last = td.nnb - 1;                // largest relative block index in this tile
-    const bool single = nb_last == 0;
-    const NbDesc d0 = s_nb[0];
-    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
-    auto site_offset = [&](const NbDesc &d, int bi, int p) -> int {        // first 'M' in meth_ref[p:p+k] (:176,:270)
-        const int sw0 = bi == 0 ? td.w0[0] : td.w0[1];
-        const int snw = bi == 0 ? td.nw[0] : (bi == 1 ? td.nw[1] : 0);
-        if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
-            return first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
-        return first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
-    };
-    if (A.debug == 2) return;
-
-    // ---- pass 1: per row, is its k-mer a site (first 'M' offset, :269-270)?  stage (pos, meta) ----
-    uint32_t meta[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int i0 = (j * NTHREADS + tid) * 4;
-        const int pp[4] = {p4[j].x, p4[j].y, p4[j].z, p4[j].w};
-        uint32_t m4 = 0;
-        int bi = 0;
-        // the four rows of a quad lie in one regular block most of the time: one test of the mask bits between the
-        // quad's first position and its last position + k clears all four (no 'M' there: ~95 % of quads for GATC)
-        bool quad_clear = false;
-        if (single && d0.mode == MODE_REGULAR && t0 + i0 >= d0.first && i0 + 3 < nrows && d0.extra_row < 0 &&
-            td.nw[0] > 0 && pp[3] >= pp[0] && pp[3] + k - pp[0] <= 64 && (pp[0] >> 5) >= td.w0[0] &&
-            ((pp[3] + k) >> 5) + 1 < td.w0[0] + td.nw[0] && pp[3] + k <= d0.contig_len) {
-            const int wi = (pp[0] >> 5) - td.w0[0];
-            const uint64_t lo = s_bits[0][wi], mid = s_bits[0][wi + 1], hi = s_bits[0][wi + 2];
-            const int sh = pp[0] & 31;
-            uint64_t w = ((mid << 32) | lo) >> sh;
-            if (sh) w |= hi << (64 - sh);
-            const int span = pp[3] + k - pp[0];
-            if (span < 64) w &= (1ull << span) - 1ull;
-            quad_clear = (w == 0ull);
+        __syncthreads();
+        PH(0);
+        // ... and the next tile's loads go out now; they land while this tile is processed
+        const int64_t tile_n = tile + G;
+        TileDesc td_nn = td_next;
+        if (tile_n < T.n_tiles) {
+            tile_issue_loads(A, td_next, tile_n, tid, R);
+            if (tile_n + G < T.n_tiles) td_nn = A.tiles[tile_n + G];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t r = t0 + i0 + u;
-            const uint32_t fl = (f4[j] >> (8 * u)) & 0xFFu;
+
+        PH(1);
+        const int nb_last = td.nnb - 1;                // largest relative block index in this tile
+        const bool single = nb_last == 0;
+        // The tile body, compiled twice: with every descriptor of the tile staged in LDS (the normal case), and for a
+        // tile that overlaps more than NBMAX name blocks, reading descriptors from global memory.  Keeping the two
+        // address spaces apart at compile time matters: a pointer that may be either is a FLAT access, and every FLAT
+        // access waits for the next tile's loads in flight.
+        auto run_tile = [&](auto staged_tag) {
+        constexpr bool STAGED = decltype(staged_tag)::value;
+        auto begin_of = [&](int bi) -> int64_t {
+            if constexpr (STAGED) return s_nb[bi].row_begin; else return T.nb_row_begin[nb0 + bi];
+        };
+        auto block_of = [&](int64_t r) -> int {
+            int bi = 0;
+            if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
+            return bi;
+        };
+        auto desc_at = [&](int bi) -> NbDesc {
+            if constexpr (STAGED) return s_nb[bi]; else return A.desc[nb0 + bi];
+        };
+        auto site_offset = [&](const NbDesc &d, int bi, int p) -> int {    // first 'M' in meth_ref[p:p+k] (:176,:270)
+            const int sw0 = bi == 0 ? td.w0a : td.w0b;
+            const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
+            if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
+                return first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
+            return first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
+        };
+
+        // ---- pass 1: per row (lane l of stripe u owns row 256 u + l), is its k-mer a site (first 'M' offset,
+        // :269-270)?  meta byte = flags (N, name start) | offset << 4, written back over the raw flags ----
+#pragma unroll 2
+        for (int u = 0; u < RPT; ++u) {
+            const int i = u * NTHREADS + tid;
+            if (i >= nrows) break;
+            const uint32_t fl = s_fl[i];
             int o = O_NONE;
-            if (!quad_clear && r < t1 && !(fl & MC_F_MODEL_N)) {
-                if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
-                const NbDesc d = single ? d0 : desc_of(bi);
-                if (d.mode == MODE_REGULAR && r >= d.first) {
-                    const int fm = site_offset(d, bi, pp[u]);
-                    if (fm >= 0) o = fm;
+            if (!(fl & MC_F_MODEL_N)) {
+                const int64_t r = t0 + i;
+                const int bi = block_of(r);
+                const NbDesc d = desc_at(bi);
+                if (d.mode == MODE_REGULAR) {
+                    if (r >= d.first) {
+                        const int fm = site_offset(d, bi, s_pos[i]);
+                        if (fm >= 0) o = fm;
+                    } else if (r == d.extra_row) {
+                        o = O_EXTRA;
+                    }
                 }
-                if (d.mode == MODE_REGULAR && r == d.extra_row) o = O_EXTRA;
             }
-            m4 |= ((fl & (MC_F_MODEL_N | MC_F_NAME_START)) | ((uint32_t)o << 4)) << (8 * u);
+            s_fl[i] = (uint8_t)((fl & (MC_F_MODEL_N | MC_F_NAME_START)) | ((uint32_t)o << 4));
         }
-        meta[j] = m4;
-        *reinterpret_cast<int4 *>(&s_pos[i0]) = p4[j];
-        *reinterpret_cast<uint32_t *>(&s_fl[i0]) = m4;
-    }
-    __syncthreads();
-    if (A.debug == 3) return;
+        __syncthreads();
+        PH(2);
 
-    // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
-    // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
-    uint32_t emit_bits = 0;                        // bit j*4+u
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int i0 = (j * NTHREADS + tid) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int o = (meta[j] >> (8 * u + 4)) & 15;
+        // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
+        // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
+        uint32_t emit_bits = 0;                        // bit u: my row of stripe u closes a window
+#pragma unroll 2
+        for (int u = 0; u < RPT; ++u) {
+            const int i = u * NTHREADS + tid;
+            if (i >= nrows) break;
+            const int o = (s_fl[i] >> 4) & 15;
             if (o == O_NONE) continue;
-            const int i = i0 + u;
-            const int pi = u == 0 ? p4[j].x : (u == 1 ? p4[j].y : (u == 2 ? p4[j].z : p4[j].w));
-            const int m = pi + o;                                    // unused for O_EXTRA
-            int state = 0;                                           // 0 undecided, 1 last row, 2 not last
+            const int m = s_pos[i] + o;                                  // unused for O_EXTRA
+            int state = 0;                                               // 0 undecided, 1 last row, 2 not last
             if (o != O_EXTRA) {
                 for (int jj = i + 1; jj < nrows; ++jj) {
                     const uint32_t fj = s_fl[jj];
-                    if (fj & MC_F_NAME_START) break;                 // another read follows: decided below
+                    if (fj & MC_F_NAME_START) break;                     // another read follows: decided below
                     if (!(fj & MC_F_MODEL_N)) { state = s_pos[jj] > m ? 1 : 2; break; }
                 }
             }
-            if (state == 0) {    // rare: the closing row is another read's, or lies in a later tile, or does not exist
-                int bi = 0;
-                if (!single) while (bi < nb_last && begin_of(bi + 1) <= t0 + i) ++bi;
-                const NbDesc d = single ? d0 : desc_of(bi);
+            if (state == 0) {    // rare: the closing row is another read's, lies in a later tile, or does not exist
+                const int bi = block_of(t0 + i);
+                const NbDesc d = desc_at(bi);
                 int cp;
                 bool cns;
                 const int64_t cr = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, t0 + i, cp, cns);
                 state = (cr >= 0 && (cns || o == O_EXTRA || cp > m)) ? 1 : 2;
             }
             if (state == 1) {
-                emit_bits |= 1u << (j * 4 + u);
+                emit_bits |= 1u << u;
                 atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        PH(3);
 
-    // ---- the tile's emit bitmap, count and window-payload slots (one atomic per tile, sharded by tile & 7) ----
-    if (wave == 0) {
-        const unsigned long long w = lane < TILE / 64 ? s_emask[lane] : 0ull;
-        if (lane < TILE / 64) A.bitmap[tile * (TILE / 64) + lane] = w;
-        const int c = __popcll(w);
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane < TILE / 64) s_eprefix[lane] = incl - c;
-        if (lane == 63) {
-            s_eprefix[TILE / 64] = incl;
-            long long base = 0;
-            if (incl > 0) {
-                const int sh = (int)(tile & (NSHARD - 1));
-                const long long per = A.payload_cap / NSHARD;
-                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)incl);
-                base = sh * per + off;
-                if (off + incl > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+        // ---- the tile's emit bitmap and count; payload slots: PT reserved per tile, the rest from one atomic ----
+        if (wave == 0) {
+            const unsigned long long w = lane < TILE / 64 ? s_emask[lane] : 0ull;
+            if (lane < TILE / 64) A.bitmap[tile * (TILE / 64) + lane] = w;
+            const int c = __popcll(w);
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
             }
-            s_base = base;
-            A.tile_base[tile] = base;
-            A.tile_cnt[tile] = incl;
+            if (lane < TILE / 64) s_eprefix[lane] = incl - c;
+            if (lane == 63) {
+                s_eprefix[TILE / 64] = incl;
+                long long ovf = 0;
+                if (incl > PT) {
+                    const long long off = (long long)atomicAdd(&A.cnt->shard[tile & (NSHARD - 1)], (unsigned long long)(incl - PT));
+                    const long long per = (A.payload_cap - T.n_tiles * PT) / NSHARD;
+                    ovf = T.n_tiles * PT + (tile & (NSHARD - 1)) * per + off;
+                    if (off + incl - PT > per) { atomicOr(&A.cnt->overflow, 1u); ovf = -1; }
+                }
+                s_ovf = ovf;
+                A.tile_base[tile] = ovf;
+                A.tile_cnt[tile] = incl;
+            }
         }
-    }
-    __syncthreads();
-    const int total = s_eprefix[TILE / 64];
-    const long long base = s_base;
-    if (total == 0 || base < 0) return;
-    {
-        uint32_t mk = emit_bits;
-        while (mk) {
-            const int b = __builtin_ctz(mk);
-            mk &= mk - 1;
-            const int i = ((b >> 2) * NTHREADS + tid) * 4 + (b & 3);
-            const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
-            s_emit[q] = (uint16_t)i;
+        __syncthreads();
+        PH(4);
+        const int total = s_eprefix[TILE / 64];
+        const long long ovf = s_ovf;
+        if (total > 0 && ovf >= 0) {
+            uint32_t mk = emit_bits;
+            while (mk) {
+                const int u = __builtin_ctz(mk);
+                mk &= mk - 1;
+                const int i = u * NTHREADS + tid;
+                const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
+                s_emit[q] = (uint16_t)i;
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        PH(5);
 
-    // ---- pass 3: the window of every closed site, 32 lanes per window: which of the 32 rows ending at the window's
-    // last row belong to it and to which slot (k-mer offset), read from LDS; the closing row.  -> 48-byte payload.
-    const int half = lane >> 5, hl = lane & 31;
-    for (int q0 = 0; q0 < total; q0 += 2 * (NTHREADS / 64)) {
-        const int q = q0 + wave * 2 + half;
-        const bool active = q < total;
-        const int i = active ? s_emit[q] : 0;
-        const int64_t r = t0 + i;
-        int bi = 0;
-        if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
-        const NbDesc d = single ? d0 : desc_of(bi);
-        const int o = (s_fl[i] >> 4) & 15;
-        const bool extra = o == O_EXTRA;
-        const int m = s_pos[i] + o;
-        // rows r, r-1, ... r-31
-        const int64_t lb = max(d.row_begin, d.first);
-        const int64_t rr = r - hl;
-        const bool inb = rr >= lb;
-        int pj = 0;
-        bool nj = true;
-        if (active && inb) {
-            if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
-            else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
+        // ---- pass 3: the window of every closed site, 32 lanes per window: which of the 32 rows ending at the
+        // window's last row belong to it and to which slot (k-mer offset), read from LDS; the closing row.
+        if (total > 0 && ovf >= 0) {
+            const int half = lane >> 5, hl = lane & 31;
+            for (int q0 = 0; q0 < total; q0 += 2 * (NTHREADS / 64)) {
+                const int q = q0 + wave * 2 + half;
+                const bool active = q < total;
+                const int i = active ? s_emit[q] : 0;
+                const int64_t r = t0 + i;
+                const int bi = block_of(r);
+                const NbDesc d = desc_at(bi);
+                const int o = (s_fl[i] >> 4) & 15;
+                const bool extra = o == O_EXTRA;
+                const int m = s_pos[i] + o;
+                // rows r, r-1, ... r-31
+                const int64_t lb = max(d.row_begin, d.first);
+                const int64_t rr = r - hl;
+                const bool inb = rr >= lb;
+                int pj = 0;
+                bool nj = true;
+                if (active && inb) {
+                    if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
+                    else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
+                }
+                const bool valid = inb && !nj;
+                const bool stopf = !inb || (valid && pj < m - k + 1);
+                const uint32_t stopmask = (uint32_t)(__ballot(active && stopf) >> (32 * half));
+                const int n_in = stopmask ? __builtin_ctz(stopmask) : 32;
+                const bool inw = active && hl < n_in && valid;
+                const int code = inw ? (m - pj) : 15;
+                const uint32_t c0 = (uint32_t)(__ballot(code & 1) >> (32 * half));
+                const uint32_t c1 = (uint32_t)(__ballot(code & 2) >> (32 * half));
+                const uint32_t c2 = (uint32_t)(__ballot(code & 4) >> (32 * half));
+                const uint32_t c3 = (uint32_t)(__ballot(code & 8) >> (32 * half));
+                // closing row among r+1 .. r+4
+                const int64_t rn = r + 1 + hl;
+                int pn = 0;
+                bool vn = false;
+                if (active && hl < 4 && rn < d.row_end) {
+                    if (rn < t1) { pn = s_pos[rn - t0]; vn = !(s_fl[rn - t0] & MC_F_MODEL_N); }
+                    else { pn = T.pos[rn]; vn = !(T.flags[rn] & MC_F_MODEL_N); }
+                }
+                const uint32_t cm = (uint32_t)(__ballot(vn) >> (32 * half));
+                const int cj = cm ? __builtin_ctz(cm) : 0;
+                const int close_pos_l = __shfl(pn, half * 32 + cj);
+                if (active && hl == 0) {
+                    int64_t close_row;
+                    int close_pos = close_pos_l;
+                    bool close_ns = false;
+                    if (cm) close_row = r + 1 + cj;
+                    else close_row = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, extra ? d.extra_row : r,
+                                                close_pos, close_ns);
+                    uint32_t pf = 0;
+                    if (extra) pf |= PF_EXTRA;
+                    if (close_ns) pf |= PF_CLOSE_NS;
+                    if (!stopmask || d.stray_q != NO_STRAY) pf |= PF_SLOW;
+                    if (!extra && !close_ns && close_pos <= m + A.skip_thresh + 1 && site_offset(d, bi, close_pos) > 0)
+                        pf |= PF_MULTI;
+                    Payload P;
+                    P.r = r;
+                    P.close_row = close_row;
+                    P.m = extra ? d.extra_mpos : m;
+                    P.close_pos = close_pos;
+                    P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
+                    P.flags = pf;
+                    P.nb = nb0 + bi;
+                    A.payload[q < PT ? tile * PT + q : ovf + (q - PT)] = P;
+                }
+            }
         }
-        const bool valid = inb && !nj;
-        const bool stopf = !inb || (valid && pj < m - k + 1);
-        const uint32_t stopmask = (uint32_t)(__ballot(active && stopf) >> (32 * half));
-        const int n_in = stopmask ? __builtin_ctz(stopmask) : 32;
-        const bool inw = active && hl < n_in && valid;
-        const int code = inw ? (m - pj) : 15;
-        const uint32_t c0 = (uint32_t)(__ballot(code & 1) >> (32 * half));
-        const uint32_t c1 = (uint32_t)(__ballot(code & 2) >> (32 * half));
-        const uint32_t c2 = (uint32_t)(__ballot(code & 4) >> (32 * half));
-        const uint32_t c3 = (uint32_t)(__ballot(code & 8) >> (32 * half));
-        // closing row among r+1 .. r+4
-        const int64_t rn = r + 1 + hl;
-        int pn = 0;
-        bool vn = false;
-        if (active && hl < 4 && rn < d.row_end) {
-            if (rn < t1) { pn = s_pos[rn - t0]; vn = !(s_fl[rn - t0] & MC_F_MODEL_N); }
-            else { pn = T.pos[rn]; vn = !(T.flags[rn] & MC_F_MODEL_N); }
-        }
-        const uint32_t cm = (uint32_t)(__ballot(vn) >> (32 * half));
-        const int cj = cm ? __builtin_ctz(cm) : 0;
-        const int close_pos_l = __shfl(pn, half * 32 + cj);
-        if (active && hl == 0) {
-            int64_t close_row;
-            int close_pos = close_pos_l;
-            bool close_ns = false;
-            if (cm) close_row = r + 1 + cj;
-            else close_row = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, extra ? d.extra_row : r, close_pos, close_ns);
-            uint32_t pf = 0;
-            if (extra) pf |= PF_EXTRA;
-            if (close_ns) pf |= PF_CLOSE_NS;
-            if (!stopmask || d.stray_q != NO_STRAY) pf |= PF_SLOW;
-            if (!extra && !close_ns && close_pos <= m + A.skip_thresh + 1 && site_offset(d, bi, close_pos) > 0) pf |= PF_MULTI;
-            Payload P;
-            P.r = r;
-            P.close_row = close_row;
-            P.m = extra ? d.extra_mpos : m;
-            P.close_pos = close_pos;
-            P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
-            P.flags = pf;
-            P.nb = nb0 + bi;
-            A.payload[base + q] = P;
-        }
+        };   // run_tile
+        if (td.nnb <= NBMAX) run_tile(std::true_type{}); else run_tile(std::false_type{});
+        __syncthreads();          // LDS is rewritten for the next tile
+        PH(6);
+        td = td_next;
+        td_next = td_nn;
     }
+#ifdef MC_PROFILE
+    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&A.cnt->prof[i], (unsigned long long)ph[i]);
+#endif
 }
 
 // Tile counts -> first record slot of every tile, two levels: groups of 1024 tiles are scanned here (coalesced),
@@ -949,9 +994,9 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ r
     }
     if (c == 0) return;
     const int64_t first = tile_slot(A.tile_local, A.group_sum, tile, lane);
-    const int64_t base = A.tile_base[tile];
-    if (base < 0 || first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
-    for (int j = lane; j < c; j += 64) rec_slot[first + j] = base + j;
+    const int64_t ovf = A.tile_base[tile];
+    if (ovf < 0 || first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    for (int j = lane; j < c; j += 64) rec_slot[first + j] = j < PT ? tile * PT + j : ovf + (j - PT);
 }
 
 // One thread per closed window: the (event, model) pairs of the 32 rows ending at the window's last row come in with
@@ -1287,6 +1332,8 @@ struct mc_ctx {
     unsigned long long *bitmap = nullptr;
     int64_t *rec_slot = nullptr;
     Payload *payload = nullptr;
+    long long payload_cap = 0;
+    int n_cu = 256;
     int64_t *tile_base = nullptr;
     Counters *cnt = nullptr;
     int last_k = 0;
@@ -1330,6 +1377,10 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     mc_ctx *c = new mc_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipMalloc((void **)&c->cnt, sizeof(Counters)));
     HIP_TRY(hipMemset(c->cnt, 0, sizeof(Counters)));
@@ -1508,7 +1559,8 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
             dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
             return -10;
     }
-    if (dev_alloc(c->rec_allocs, &c->rec_slot, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)cap)) return -10;
+    c->payload_cap = cap + (c->T.n_tiles + 1) * PT;
+    if (dev_alloc(c->rec_allocs, &c->rec_slot, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
     c->last_k = k;
     return 0;
 }
@@ -1558,11 +1610,12 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         K1Args A;
         A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.bitmap = c->bitmap; A.payload = c->payload;
-        A.payload_cap = c->O.capacity; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
+        A.payload_cap = c->payload_cap; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
         A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
         A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
         { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-        hipLaunchKernelGGL(k1_scan, dim3((unsigned)T.n_tiles), dim3(NTHREADS), 0, c->stream, A);
+        hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>(T.n_tiles, (int64_t)c->n_cu * MC_SCAN_WGS)), dim3(NTHREADS), 0,
+                           c->stream, A);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
                            (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
@@ -1581,6 +1634,11 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
             return -20;
         }
         const int64_t n = (int64_t)h.n_records;
+#ifdef MC_PROFILE
+        fprintf(stderr, "k1_scan phase cycles:");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", h.prof[i]);
+        fprintf(stderr, "\n");
+#endif
         if (h.overflow) {                   // the buffers were a guess; the exact need is known now (+ shard skew)
             cap = std::max<int64_t>(cap * 2, n + n / 4 + 4096);
             continue;
