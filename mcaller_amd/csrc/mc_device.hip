@@ -46,14 +46,17 @@ void mc_set_error(const char *fmt, ...);
 namespace {
 
 #ifndef MC_TILE
-#define MC_TILE 4096
+#define MC_TILE 2048
+#endif
+#ifndef MC_NTHREADS
+#define MC_NTHREADS 64
 #endif
 constexpr int TILE = MC_TILE;       // rows per workgroup tile
-constexpr int NTHREADS = 256;       // 4 waves
+constexpr int NTHREADS = MC_NTHREADS; // k1_scan workgroup: one wave (the per-tile site walk is a single wave's work)
 constexpr int RPT = TILE / NTHREADS;  // rows per thread in the detection pass
-constexpr int NBMAX = 16;           // name-block descriptors staged in LDS per tile
+constexpr int NBMAX = NTHREADS / 16; // name-block descriptors staged in LDS per tile (one dword per thread)
 constexpr int NBST = 2;             // ... of which this many get their strand-mask window staged in LDS
-constexpr int BW = 192;             // words per staged mask window (6144 positions)
+constexpr int BW = NTHREADS;         // words per staged mask window (one per thread)
 constexpr int O_NONE = 15;
 
 // meta byte per staged row: bit0 valid (passes :167-168), bit1 first row of a name block, bits 2..5 offset of
@@ -69,16 +72,21 @@ constexpr int32_t NO_STRAY = INT32_MIN;
 
 struct __attribute__((aligned(16))) NbDesc {
     int64_t row_begin;
-    int64_t first;      // rows >= first are tested on the block's strand (regular blocks); window walks stop here
-    int64_t extra_row;  // row of the one-event '+' window a reverse read opens on a palindromic k-mer (R5), or -1
     int64_t row_end;    // one past the block's last row
-    int64_t contig_len;
+    int64_t mask_off;   // word offset of the contig's strand masks (both strands share it)
+    int32_t first_delta;// rows >= row_begin + first_delta are tested on the block's strand; window walks stop there
+    int32_t contig_len;
     int32_t contig;
     int32_t read;
-    int32_t stray_q;    // pseudo-position of that event once the strand flips (:276-277), NO_STRAY if none
+    int32_t stray_q;    // pseudo-position of the stray event of a palindromic first site row once the strand flips
+                        // (:276-277), NO_STRAY if none
     int32_t stray_d;    // its value, (event - model) in 1e-4 pA
-    int32_t extra_mpos; // site of the '+' window
-    uint8_t mode, rev, filtered, extra_multi;
+    int32_t extra_mpos; // site of the one-event '+' window such a row opens (R5)
+    uint8_t mode, rev, filtered, xflags;   // xflags: bit0 extra_multi, bit1 has the '+' window (its row = first - 1)
+    int32_t pad;
+    __host__ __device__ int64_t first() const { return first_delta < 0 ? -1 : row_begin + first_delta; }
+    __host__ __device__ int64_t extra_row() const { return (xflags & 2) ? row_begin + first_delta - 1 : -1; }
+    __host__ __device__ bool extra_multi() const { return xflags & 1; }
 };
 static_assert(sizeof(NbDesc) == 64, "NbDesc layout");
 
@@ -268,11 +276,11 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
     if (lane == 0) {
         NbDesc d;
         d.row_begin = T.nb_row_begin[b];
-        d.first = f0;
-        d.extra_row = -1;
         d.row_end = T.nb_row_begin[b + 1];
         d.contig = T.seg_contig[T.nb_seg_begin[b]];
-        d.contig_len = R.contig_len[d.contig];
+        d.mask_off = R.word_off[d.contig];
+        d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
+        d.contig_len = (int32_t)R.contig_len[d.contig];
         d.read = read;
         d.stray_q = NO_STRAY;
         d.stray_d = 0;
@@ -280,7 +288,8 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
         d.mode = MODE_NONE;
         d.rev = (uint8_t)f0rev;
         d.filtered = filtered ? 1 : 0;
-        d.extra_multi = 0;
+        d.xflags = 0;
+        d.pad = 0;
         desc[b] = d;
         nb_f0[b] = f0;
         nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
@@ -330,8 +339,8 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
         if (inc && dec) regular = false;
         // rows after f0 take rev = !(idx > idx[f0]) (:169)
         if (inc && d.rev) regular = false;
-        const uint32_t *mf = R.mf + R.word_off[d.contig], *mr = R.mr + R.word_off[d.contig];
-        const int64_t L = R.contig_len[d.contig];
+        const uint32_t *mf = R.mf + d.mask_off, *mr = R.mr + d.mask_off;
+        const int64_t L = d.contig_len;
         if ((vf & V_POS0) && L > 0 && ((mf[0] | mr[0]) & 1u)) regular = false;   // falsy mpos (:179,:272,:279)
         if (regular && dec && !d.rev) {
             if (k < 2) {
@@ -344,19 +353,19 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
                 int64_t r1 = f0 + 1;
                 const int64_t re = T.nb_row_begin[b + 1];
                 while (r1 < re && (T.flags[r1] & MC_F_MODEL_N)) ++r1;
-                d.first = f0 + 1;
+                d.first_delta = (int32_t)(f0 + 1 - d.row_begin);
                 d.rev = 1;
                 d.stray_d = T.ev[f0] - T.mu[f0];
                 d.extra_mpos = mpos_f;
                 if (r1 >= re) {
-                    d.extra_row = f0;                       // closed by the next read (or lost at EOF)
+                    d.xflags |= 2;                          // closed by the next read (or lost at EOF)
                 } else {
                     const int p1 = T.pos[r1];
                     const int o_r = first_m(mr, L, p1, k);
                     if (p1 >= mpos_f + 1) {
-                        d.extra_row = f0;
+                        d.xflags |= 2;
                         if (o_r >= 0 && p1 <= mpos_f + skip_thresh + 1) {
-                            d.extra_multi = o_r != 0;
+                            if (o_r != 0) d.xflags |= 1;
                             if (p1 + o_r - p < k) d.stray_q = p;
                         }
                     } else if (o_r >= 0) {
@@ -378,10 +387,10 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
 //   k1_scan  streams the position and flag columns (5 B/row), stages them in LDS with the per-row site offset
 //            (first 'M' in the row's k-mer, looked up in a window of the strand bitmask staged in LDS), and decides
 //            for every site row whether it is the LAST row of its window: the next unfiltered row starts another
-//            read or lies beyond the site (:179).  Output: one bit per row (the tile's emit bitmap) + a count.
+//            read or lies beyond the site (:179).  Output: a 48-byte payload per closed window + a count per tile.
 //   k1_emit  one lane per closed window: walks back over the <= k positions of the window, reading the event and
 //            model columns only for these rows, and builds the flush record (slot means in NumPy pairwise order).
-//            Records land in file order (slot = exclusive scan of the tile counts + rank in the bitmap).
+//            Records land in file order (slot = exclusive scan of the tile counts + rank inside the tile).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events, finished by k1_bigfix
 constexpr int O_EXTRA = 14;              // meta nibble: the one-event '+' window of a palindromic f0 (R5)
@@ -459,10 +468,9 @@ struct K1Args {
     DevRef R;
     const NbDesc *desc;
     const TileDesc *tiles;
-    unsigned long long *bitmap;   // [n_tiles * TILE/64] emit bits, row order
     Payload *payload;             // [payload_cap]
     long long payload_cap;
-    int64_t *tile_base;           // [n_tiles] first overflow payload slot of the tile (windows beyond the PT reserved)
+    long long *tile_chunk;        // [n_tiles * TILE/64] first payload slot of the tile's chunk c >= 1 (chunk 0: tile * PT)
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -491,12 +499,12 @@ __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, 
         const int64_t lo = max(d.row_begin, t0), hi = min(d.row_end, t1);
         const int64_t wmax = ((d.contig_len + 31) >> 5) + 1;       // the mask has 2 zero words of padding
         if (hi <= lo) continue;
-        const int64_t w0 = T.pos[lo] >> 5;
+        const int64_t w0 = max<int64_t>((T.pos[lo] >> 5) - 1, 0);        // one word to the left: nearest-left-'M' lookups
         const int64_t w1 = min<int64_t>(((int64_t)T.pos[hi - 1] + k) >> 5, wmax - 1) + 1;
         const int64_t nw = w1 - w0 + 1;
         if (nw > 0 && nw <= BW) {
-            if (sb == 0) { td.w0a = (int32_t)w0; td.nwa = (int32_t)nw; td.boffa = R.word_off[d.contig] + w0; td.reva = d.rev; }
-            else { td.w0b = (int32_t)w0; td.nwb = (int32_t)nw; td.boffb = R.word_off[d.contig] + w0; td.revb = d.rev; }
+            if (sb == 0) { td.w0a = (int32_t)w0; td.nwa = (int32_t)nw; td.boffa = d.mask_off + w0; td.reva = d.rev; }
+            else { td.w0b = (int32_t)w0; td.nwb = (int32_t)nw; td.boffb = d.mask_off + w0; td.revb = d.rev; }
         }
     }
     tiles[t] = td;
@@ -537,7 +545,7 @@ __device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *_
     return tail_contig >= 0 ? T.n_rows : -1;
 }
 
-constexpr int PT = 32;              // payload slots reserved per tile (more: one atomic into the overflow area)
+constexpr int PT = 64;              // payload slots reserved per tile; further chunks of 64 come from an atomic
 
 // columns of one tile in flight: 16 bytes of positions + 4 flag bytes per lane and quad
 struct TileRegs {
@@ -545,11 +553,15 @@ struct TileRegs {
     uint32_t f4[TILE / (NTHREADS * 4)];
     uint32_t descw;                 // dword `tid` of the tile's name-block descriptors
     uint32_t maskw[NBST];           // word `tid` of the staged strand-mask windows
+    uint32_t tdw;                   // dword `tid` of the TileDesc of the tile AFTER this one (same workgroup)
 };
 
-__device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc &td, int64_t tile, int tid, TileRegs &R) {
+__device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc &td, int64_t tile, int64_t tile_after,
+                                                 int tid, TileRegs &R) {
     const DevTable &T = A.T;
     const int64_t t0 = tile * TILE;
+    R.tdw = (tid < (int)(sizeof(TileDesc) / 4) && tile_after < T.n_tiles)
+                ? reinterpret_cast<const uint32_t *>(A.tiles + tile_after)[tid] : 0u;
     const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
 #pragma unroll
     for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
@@ -575,24 +587,30 @@ __device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc
 #endif
 
 #ifndef MC_SCAN_WGS
-#define MC_SCAN_WGS 5               // resident workgroups per CU the persistent grid is sized for
+#define MC_SCAN_WGS 16              // workgroups per CU the persistent grid is sized for (registers allow 16 waves per CU)
 #endif
 
-// Persistent workgroups, tiles taken grid-stride; the loads of tile i+1 (columns, descriptors, mask words) are issued
-// before tile i is processed, and its TileDesc one tile earlier still, so no memory round trip sits on the per-tile
-// critical path.
+// k1_scan: persistent workgroups, tiles taken grid-stride.
+//
+// Per tile: the position and flag columns (5 B/row) are streamed into LDS -- the loads of tile i+1 (columns,
+// descriptors, mask words) are issued before tile i is processed, and its TileDesc one tile earlier still, so no memory
+// round trip sits on the per-tile critical path.  The work on a staged tile is driven by the SITES, not the rows: inside a
+// regular name block positions are non-decreasing, so for every 'M' of the block's strand mask that the tile's positions
+// can reach, one lane binary-searches the last row at a position <= the site (LDS), checks that this row's first 'M' is
+// the site (no nearer 'M' to its left, :269-270) and that the next unfiltered row lies beyond it or starts another read
+// (:179): that is a closed window.  The lane then walks the <= 32 rows before it in LDS and writes which rows belong to
+// which slot, plus the closing row, as a 48-byte payload (k1_emit turns payloads into records).
 __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];   // flags (N, name start) | first-'M' offset << 4
-    __shared__ unsigned long long s_emask[TILE / 64];
-    __shared__ int s_eprefix[TILE / 64 + 1];
-    __shared__ uint16_t s_emit[TILE];
-    __shared__ uint32_t s_bits[NBST][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
+    __shared__ uint32_t s_bits[NBST][NTHREADS];
     __shared__ __attribute__((aligned(16))) NbDesc s_nb[NBMAX];
-    __shared__ long long s_ovf;
+    __shared__ uint16_t s_rv[64 * 32];              // per lane and mask bit: last row of the window (tile-relative)
+    __shared__ long long s_chunk[TILE / 64];        // first payload slot of the tile's 64-record chunks
 
-    static_assert(BW <= 256 && NBMAX * sizeof(NbDesc) / 4 <= NTHREADS, "one dword per thread");
-    static_assert(NBST == 2, "mask window selects are written for two staged blocks");
+    static_assert(BW <= NTHREADS && NBMAX * sizeof(NbDesc) / 4 <= NTHREADS && sizeof(TileDesc) / 4 <= NTHREADS,
+                  "one dword per thread");
+    static_assert(NBST == 2, "two staged mask windows");
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -605,24 +623,24 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
 #ifdef MC_PROFILE
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
-    TileDesc td = A.tiles[tile];
-    TileDesc td_next = td;
-    if (tile + G < T.n_tiles) td_next = A.tiles[tile + G];
+    __shared__ __attribute__((aligned(16))) TileDesc s_td[2];   // [cur]: this tile, [cur ^ 1]: the workgroup's next tile
     TileRegs R;
-    tile_issue_loads(A, td, tile, tid, R);
+    {
+        const TileDesc td0 = A.tiles[tile];
+        if (tid == 0) s_td[0] = td0;
+        tile_issue_loads(A, td0, tile, tile + G, tid, R);
+    }
+    int cur = 0;
 
-    for (; tile < T.n_tiles; tile += G) {
+    for (; tile < T.n_tiles; tile += G, cur ^= 1) {
         const int64_t t0 = tile * TILE;
         const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
-        const int nrows = (int)(t1 - t0);
-        const int nb0 = td.nb0;
-        const int nnb = min(td.nnb, NBMAX);            // descriptors staged; beyond: global memory
 
-        // ---- this tile's descriptors, mask words and columns: registers -> LDS ----
+        // ---- this tile's descriptors, mask words and columns, the next tile's TileDesc: registers -> LDS ----
         reinterpret_cast<uint32_t *>(s_nb)[tid] = R.descw;
         s_bits[0][tid] = R.maskw[0];
         s_bits[1][tid] = R.maskw[1];
-        if (tid < TILE / 64) s_emask[tid] = 0ull;
+        if (tid < (int)(sizeof(TileDesc) / 4)) reinterpret_cast<uint32_t *>(&s_td[cur ^ 1])[tid] = R.tdw;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * NTHREADS + tid) * 4;
@@ -631,220 +649,221 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         }
         __syncthreads();
         PH(0);
+        const TileDesc td = s_td[cur];
+        const int nb0 = td.nb0;
         // ... and the next tile's loads go out now; they land while this tile is processed
         const int64_t tile_n = tile + G;
-        TileDesc td_nn = td_next;
-        if (tile_n < T.n_tiles) {
-            tile_issue_loads(A, td_next, tile_n, tid, R);
-            if (tile_n + G < T.n_tiles) td_nn = A.tiles[tile_n + G];
-        }
-
+        if (tile_n < T.n_tiles) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_n + G, tid, R);
         PH(1);
-        const int nb_last = td.nnb - 1;                // largest relative block index in this tile
-        const bool single = nb_last == 0;
-        // The tile body, compiled twice: with every descriptor of the tile staged in LDS (the normal case), and for a
-        // tile that overlaps more than NBMAX name blocks, reading descriptors from global memory.  Keeping the two
-        // address spaces apart at compile time matters: a pointer that may be either is a FLAT access, and every FLAT
-        // access waits for the next tile's loads in flight.
-        auto run_tile = [&](auto staged_tag) {
-        constexpr bool STAGED = decltype(staged_tag)::value;
-        auto begin_of = [&](int bi) -> int64_t {
-            if constexpr (STAGED) return s_nb[bi].row_begin; else return T.nb_row_begin[nb0 + bi];
-        };
-        auto block_of = [&](int64_t r) -> int {
-            int bi = 0;
-            if (!single) while (bi < nb_last && begin_of(bi + 1) <= r) ++bi;
-            return bi;
-        };
-        auto desc_at = [&](int bi) -> NbDesc {
-            if constexpr (STAGED) return s_nb[bi]; else return A.desc[nb0 + bi];
-        };
-        auto site_offset = [&](const NbDesc &d, int bi, int p) -> int {    // first 'M' in meth_ref[p:p+k] (:176,:270)
-            const int sw0 = bi == 0 ? td.w0a : td.w0b;
-            const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
-            if (snw > 0 && (p >> 5) >= sw0 && (p >> 5) + 1 < sw0 + snw)
-                return first_m_lds(bi == 0 ? s_bits[0] : s_bits[1], sw0, d.contig_len, p, k);
-            return first_m((d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig], d.contig_len, p, k);
-        };
 
-        // ---- pass 1: per row (lane l of stripe u owns row 256 u + l), is its k-mer a site (first 'M' offset,
-        // :269-270)?  meta byte = flags (N, name start) | offset << 4, written back over the raw flags ----
-#pragma unroll 2
-        for (int u = 0; u < RPT; ++u) {
-            const int i = u * NTHREADS + tid;
-            if (i >= nrows) break;
-            const uint32_t fl = s_fl[i];
-            int o = O_NONE;
-            if (!(fl & MC_F_MODEL_N)) {
-                const int64_t r = t0 + i;
-                const int bi = block_of(r);
-                const NbDesc d = desc_at(bi);
-                if (d.mode == MODE_REGULAR) {
-                    if (r >= d.first) {
-                        const int fm = site_offset(d, bi, s_pos[i]);
-                        if (fm >= 0) o = fm;
-                    } else if (r == d.extra_row) {
-                        o = O_EXTRA;
+        if (wave == 0 && A.debug != 3) {
+            // The site walk, compiled twice: with every descriptor of the tile staged in LDS (the normal case), and for a
+            // tile that overlaps more than NBMAX name blocks (descriptors read from global memory).  Keeping the address
+            // spaces apart at compile time matters: a pointer that may be either is a FLAT access, and every FLAT access
+            // waits for the next tile's loads in flight.
+            auto run_tile = [&](auto staged_tag) {
+                constexpr bool STAGED = decltype(staged_tag)::value;
+                int total = 0;                               // windows closed so far in this tile
+                for (int bi = 0; bi < td.nnb; ++bi) {
+                    NbDesc d;
+                    if constexpr (STAGED) d = s_nb[bi]; else d = A.desc[nb0 + bi];
+                    if (d.mode != MODE_REGULAR) continue;
+                    const int nb_abs = nb0 + bi;
+                    const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+                    const int sw0 = bi == 0 ? td.w0a : td.w0b;
+                    const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
+                    const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
+                    const int64_t n_mask_words = ((d.contig_len + 31) >> 5) + 2;
+                    auto mword = [&](int64_t w) -> uint32_t {          // word w of the block's strand mask
+                        if (w < 0 || w >= n_mask_words) return 0u;
+                        if (w >= sw0 && w < sw0 + snw) return sb[w - sw0];
+                        return gbits[w];
+                    };
+                    auto site_off = [&](int p) -> int {                // first 'M' in meth_ref[p:p+k] (:176,:270)
+                        if (p >= d.contig_len) return -1;
+                        const int64_t w = p >> 5;
+                        uint64_t bits = (((uint64_t)mword(w + 1) << 32) | mword(w)) >> (p & 31);
+                        bits &= (1ull << k) - 1ull;
+                        return bits ? __builtin_ctzll(bits) : -1;
+                    };
+                    auto slot_of = [&](int rank) -> long long {
+                        return rank < PT ? tile * PT + rank : s_chunk[rank >> 6] + (rank & 63);
+                    };
+                    auto reserve = [&](int new_total) {                 // chunks for ranks < new_total (wave-uniform call)
+                        const int c0 = (total + 63) >> 6, c1 = (new_total + 63) >> 6;     // chunks [max(c0,1), c1) are new
+                        if (c1 > max(c0, 1)) {
+                            long long base = 0;
+                            if (lane == 0) {
+                                const int cb = max(c0, 1), n = c1 - cb;
+                                const int sh = (int)(tile & (NSHARD - 1));
+                                const long long per = (A.payload_cap - T.n_tiles * PT) / NSHARD;
+                                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n * 64ull);
+                                base = T.n_tiles * PT + sh * per + off;
+                                if (off + n * 64LL > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+                                for (int c = cb; c < c1; ++c) {
+                                    s_chunk[c] = base < 0 ? -1 : base + (long long)(c - cb) * 64;
+                                    A.tile_chunk[tile * (TILE / 64) + c] = s_chunk[c];
+                                }
+                            }
+                            __threadfence_block();        // lane 0's s_chunk entries, before any lane reads them
+                        }
+                    };
+
+                    // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
+                    if (d.extra_row() >= t0 && d.extra_row() < t1) {
+                        int cp;
+                        bool cns;
+                        const int64_t cr = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, d.extra_row(), cp, cns);
+                        if (cr >= 0) {
+                            reserve(total + 1);
+                            if (lane == 0 && slot_of(total) >= 0) {
+                                Payload P;
+                                P.r = d.extra_row(); P.close_row = cr; P.m = d.extra_mpos; P.close_pos = cp;
+                                P.code[0] = P.code[1] = P.code[2] = P.code[3] = 0xFFFFFFFFu;
+                                P.flags = PF_EXTRA | (cns ? PF_CLOSE_NS : 0u);
+                                P.nb = nb_abs;
+                                A.payload[slot_of(total)] = P;
+                            }
+                            total += 1;
+                        }
+                    }
+
+                    const int64_t lb_abs = max(d.row_begin, d.first());
+                    const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t1) - t0);
+                    if (hi <= lo) continue;
+                    const int mlo = s_pos[lo];
+                    const int64_t mhi64 = min<int64_t>((int64_t)s_pos[hi - 1] + k - 1, d.contig_len - 1);
+                    if (mhi64 < mlo) continue;
+                    const int mhi = (int)mhi64;
+                    const bool block_continues = d.row_end > t1;
+
+                    for (int wb = mlo >> 5; wb <= (mhi >> 5); wb += 64) {
+                        // ---- pass A: lane owns mask word wb + lane; which of its sites closes a window here? ----
+                        const int w = wb + lane;
+#ifdef MC_PROFILE
+                        if (lane == 0) ph[4] += 1;
+#endif
+                        uint32_t word = 0;
+                        if (w <= (mhi >> 5)) {
+                            word = mword(w);
+                            if (w == (mlo >> 5)) word &= ~0u << (mlo & 31);
+                            if (w == (mhi >> 5) && (mhi & 31) != 31) word &= (1u << ((mhi & 31) + 1)) - 1u;
+                        }
+                        const uint64_t raw = word ? (((uint64_t)mword(w) << 32) | mword(w - 1)) : 0ull;
+                        uint32_t emit = 0;
+                        for (uint32_t rest = word; rest; rest &= rest - 1) {
+                            const int b = __builtin_ctz(rest);
+                            const int m = w * 32 + b;
+#ifdef MC_PROFILE
+                            atomicAdd(&A.cnt->prof[5], 1ull);
+#endif
+                            // nearest 'M' to the left within k-1 positions: rows at or before it belong to its group
+                            int plo = m - k + 1;
+                            if (k > 1) {
+                                const uint32_t left = (uint32_t)(raw >> (32 + b - (k - 1))) & ((1u << (k - 1)) - 1u);
+                                if (left) plo = m - (k - 1) + (31 - __builtin_clz(left)) + 1;
+                            }
+                            // first row of the range with pos > m
+                            int a = lo, z = hi;
+                            while (a < z) {
+                                const int mid = (a + z) >> 1;
+                                if (s_pos[mid] <= m) a = mid + 1; else z = mid;
+                            }
+                            const int ub = a;
+                            int rv = ub - 1;
+                            while (rv >= lo && (s_fl[rv] & MC_F_MODEL_N)) --rv;
+                            if (rv < lo || s_pos[rv] < plo) continue;          // no row of this tile has first 'M' == m
+                            // the next unfiltered row must lie beyond the site (or belong to another read)
+                            int c = ub;
+                            while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
+                            bool closed = c < hi;                              // a row with pos > m follows in the tile
+                            if (!closed) {                                    // rare: look past the tile / the block
+#ifdef MC_PROFILE
+                                atomicAdd(&A.cnt->prof[6], 1ull);
+#endif
+                                int cp;
+                                bool cns;
+                                const int64_t cr = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, t0 + rv, cp, cns);
+                                closed = cr >= 0 && (cns || cp > m);
+                            }
+                            (void)block_continues;
+                            if (closed) {
+                                emit |= 1u << b;
+                                s_rv[lane * 32 + b] = (uint16_t)rv;
+                            }
+                        }
+                        // ---- ranks: exclusive prefix of the lanes' counts (site order = row order = record order) ----
+                        const int cnt = __popc(emit);
+                        int incl = cnt;
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int v = __shfl_up(incl, o);
+                            if (lane >= o) incl += v;
+                        }
+                        const int round_total = __shfl(incl, 63);
+                        if (round_total == 0) continue;
+                        reserve(total + round_total);
+                        int rank = total + incl - cnt;
+                        total += round_total;
+                        // ---- pass B: the payload of every closed window ----
+                        for (uint32_t rest = emit; rest; rest &= rest - 1, ++rank) {
+                            const int b = __builtin_ctz(rest);
+                            const int m = w * 32 + b;
+                            const int rv = s_rv[lane * 32 + b];
+                            const int64_t r = t0 + rv;
+                            // closing row
+                            int64_t close_row;
+                            int close_pos;
+                            bool close_ns = false;
+                            {
+                                int c = rv + 1;
+                                while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
+                                if (c < hi) { close_row = t0 + c; close_pos = s_pos[c]; }
+                                else close_row = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, r, close_pos, close_ns);
+                            }
+                            // rows r, r-1, ... r-31 -> slot codes
+                            uint32_t c0 = ~0u, c1 = ~0u, c2 = ~0u, c3 = ~0u;
+                            bool stopped = false;
+                            for (int j = 0; j < 32; ++j) {
+#ifdef MC_PROFILE
+                                atomicAdd(&A.cnt->prof[7], 1ull);
+#endif
+                                const int64_t rr = r - j;
+                                if (rr < lb_abs) { stopped = true; break; }
+                                int pj;
+                                bool nj;
+                                if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
+                                else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
+                                if (nj) continue;
+                                if (pj < m - k + 1) { stopped = true; break; }
+                                const uint32_t code = (uint32_t)(m - pj), bit = 1u << j;
+                                if (!(code & 1u)) c0 &= ~bit;
+                                if (!(code & 2u)) c1 &= ~bit;
+                                if (!(code & 4u)) c2 &= ~bit;
+                                c3 &= ~bit;
+                            }
+                            uint32_t pf = 0;
+                            if (close_ns) pf |= PF_CLOSE_NS;
+                            if (!stopped || d.stray_q != NO_STRAY) pf |= PF_SLOW;
+                            if (!close_ns && close_pos <= m + A.skip_thresh + 1 && site_off(close_pos) > 0) pf |= PF_MULTI;
+                            const long long slot = slot_of(rank);
+                            if (slot >= 0) {
+                                Payload P;
+                                P.r = r; P.close_row = close_row; P.m = m; P.close_pos = close_pos;
+                                P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
+                                P.flags = pf;
+                                P.nb = nb_abs;
+                                A.payload[slot] = P;
+                            }
+                        }
                     }
                 }
-            }
-            s_fl[i] = (uint8_t)((fl & (MC_F_MODEL_N | MC_F_NAME_START)) | ((uint32_t)o << 4));
+                if (lane == 0) A.tile_cnt[tile] = total;
+            };
+            if (td.nnb <= NBMAX) run_tile(std::true_type{}); else run_tile(std::false_type{});
         }
-        __syncthreads();
         PH(2);
-
-        // ---- pass 2: a site row is the last row of its window iff the next unfiltered row starts another read or
-        // lies beyond the site (:179).  Only site rows do any work here (2-3 % of rows for GATC).
-        uint32_t emit_bits = 0;                        // bit u: my row of stripe u closes a window
-#pragma unroll 2
-        for (int u = 0; u < RPT; ++u) {
-            const int i = u * NTHREADS + tid;
-            if (i >= nrows) break;
-            const int o = (s_fl[i] >> 4) & 15;
-            if (o == O_NONE) continue;
-            const int m = s_pos[i] + o;                                  // unused for O_EXTRA
-            int state = 0;                                               // 0 undecided, 1 last row, 2 not last
-            if (o != O_EXTRA) {
-                for (int jj = i + 1; jj < nrows; ++jj) {
-                    const uint32_t fj = s_fl[jj];
-                    if (fj & MC_F_NAME_START) break;                     // another read follows: decided below
-                    if (!(fj & MC_F_MODEL_N)) { state = s_pos[jj] > m ? 1 : 2; break; }
-                }
-            }
-            if (state == 0) {    // rare: the closing row is another read's, lies in a later tile, or does not exist
-                const int bi = block_of(t0 + i);
-                const NbDesc d = desc_at(bi);
-                int cp;
-                bool cns;
-                const int64_t cr = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, t0 + i, cp, cns);
-                state = (cr >= 0 && (cns || o == O_EXTRA || cp > m)) ? 1 : 2;
-            }
-            if (state == 1) {
-                emit_bits |= 1u << u;
-                atomicOr(&s_emask[i >> 6], 1ull << (i & 63));
-            }
-        }
-        __syncthreads();
-        PH(3);
-
-        // ---- the tile's emit bitmap and count; payload slots: PT reserved per tile, the rest from one atomic ----
-        if (wave == 0) {
-            const unsigned long long w = lane < TILE / 64 ? s_emask[lane] : 0ull;
-            if (lane < TILE / 64) A.bitmap[tile * (TILE / 64) + lane] = w;
-            const int c = __popcll(w);
-            int incl = c;
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            if (lane < TILE / 64) s_eprefix[lane] = incl - c;
-            if (lane == 63) {
-                s_eprefix[TILE / 64] = incl;
-                long long ovf = 0;
-                if (incl > PT) {
-                    const long long off = (long long)atomicAdd(&A.cnt->shard[tile & (NSHARD - 1)], (unsigned long long)(incl - PT));
-                    const long long per = (A.payload_cap - T.n_tiles * PT) / NSHARD;
-                    ovf = T.n_tiles * PT + (tile & (NSHARD - 1)) * per + off;
-                    if (off + incl - PT > per) { atomicOr(&A.cnt->overflow, 1u); ovf = -1; }
-                }
-                s_ovf = ovf;
-                A.tile_base[tile] = ovf;
-                A.tile_cnt[tile] = incl;
-            }
-        }
-        __syncthreads();
-        PH(4);
-        const int total = s_eprefix[TILE / 64];
-        const long long ovf = s_ovf;
-        if (total > 0 && ovf >= 0) {
-            uint32_t mk = emit_bits;
-            while (mk) {
-                const int u = __builtin_ctz(mk);
-                mk &= mk - 1;
-                const int i = u * NTHREADS + tid;
-                const int q = s_eprefix[i >> 6] + __popcll(s_emask[i >> 6] & ((1ull << (i & 63)) - 1ull));
-                s_emit[q] = (uint16_t)i;
-            }
-        }
-        __syncthreads();
-        PH(5);
-
-        // ---- pass 3: the window of every closed site, 32 lanes per window: which of the 32 rows ending at the
-        // window's last row belong to it and to which slot (k-mer offset), read from LDS; the closing row.
-        if (total > 0 && ovf >= 0) {
-            const int half = lane >> 5, hl = lane & 31;
-            for (int q0 = 0; q0 < total; q0 += 2 * (NTHREADS / 64)) {
-                const int q = q0 + wave * 2 + half;
-                const bool active = q < total;
-                const int i = active ? s_emit[q] : 0;
-                const int64_t r = t0 + i;
-                const int bi = block_of(r);
-                const NbDesc d = desc_at(bi);
-                const int o = (s_fl[i] >> 4) & 15;
-                const bool extra = o == O_EXTRA;
-                const int m = s_pos[i] + o;
-                // rows r, r-1, ... r-31
-                const int64_t lb = max(d.row_begin, d.first);
-                const int64_t rr = r - hl;
-                const bool inb = rr >= lb;
-                int pj = 0;
-                bool nj = true;
-                if (active && inb) {
-                    if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
-                    else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
-                }
-                const bool valid = inb && !nj;
-                const bool stopf = !inb || (valid && pj < m - k + 1);
-                const uint32_t stopmask = (uint32_t)(__ballot(active && stopf) >> (32 * half));
-                const int n_in = stopmask ? __builtin_ctz(stopmask) : 32;
-                const bool inw = active && hl < n_in && valid;
-                const int code = inw ? (m - pj) : 15;
-                const uint32_t c0 = (uint32_t)(__ballot(code & 1) >> (32 * half));
-                const uint32_t c1 = (uint32_t)(__ballot(code & 2) >> (32 * half));
-                const uint32_t c2 = (uint32_t)(__ballot(code & 4) >> (32 * half));
-                const uint32_t c3 = (uint32_t)(__ballot(code & 8) >> (32 * half));
-                // closing row among r+1 .. r+4
-                const int64_t rn = r + 1 + hl;
-                int pn = 0;
-                bool vn = false;
-                if (active && hl < 4 && rn < d.row_end) {
-                    if (rn < t1) { pn = s_pos[rn - t0]; vn = !(s_fl[rn - t0] & MC_F_MODEL_N); }
-                    else { pn = T.pos[rn]; vn = !(T.flags[rn] & MC_F_MODEL_N); }
-                }
-                const uint32_t cm = (uint32_t)(__ballot(vn) >> (32 * half));
-                const int cj = cm ? __builtin_ctz(cm) : 0;
-                const int close_pos_l = __shfl(pn, half * 32 + cj);
-                if (active && hl == 0) {
-                    int64_t close_row;
-                    int close_pos = close_pos_l;
-                    bool close_ns = false;
-                    if (cm) close_row = r + 1 + cj;
-                    else close_row = find_close(T, A.desc, A.tail_contig, nb0 + bi, d.row_end, extra ? d.extra_row : r,
-                                                close_pos, close_ns);
-                    uint32_t pf = 0;
-                    if (extra) pf |= PF_EXTRA;
-                    if (close_ns) pf |= PF_CLOSE_NS;
-                    if (!stopmask || d.stray_q != NO_STRAY) pf |= PF_SLOW;
-                    if (!extra && !close_ns && close_pos <= m + A.skip_thresh + 1 && site_offset(d, bi, close_pos) > 0)
-                        pf |= PF_MULTI;
-                    Payload P;
-                    P.r = r;
-                    P.close_row = close_row;
-                    P.m = extra ? d.extra_mpos : m;
-                    P.close_pos = close_pos;
-                    P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
-                    P.flags = pf;
-                    P.nb = nb0 + bi;
-                    A.payload[q < PT ? tile * PT + q : ovf + (q - PT)] = P;
-                }
-            }
-        }
-        };   // run_tile
-        if (td.nnb <= NBMAX) run_tile(std::true_type{}); else run_tile(std::false_type{});
         __syncthreads();          // LDS is rewritten for the next tile
-        PH(6);
-        td = td_next;
-        td_next = td_nn;
+        PH(3);
     }
 #ifdef MC_PROFILE
     if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&A.cnt->prof[i], (unsigned long long)ph[i]);
@@ -893,15 +912,15 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
     const DevTable &T = A.T;
     const int k = A.k;
     const int64_t L = d.contig_len;
-    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
     int close_pos;
     bool close_ns;
     const int64_t close_row = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, r, close_pos, close_ns);
     uint32_t info = d.rev ? MC_I_REV : 0u;
 
-    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first / the block start) ----
+    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first() / the block start) ----
     // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
-    const int64_t lb = max(d.row_begin, d.first);
+    const int64_t lb = max(d.row_begin, d.first());
     unsigned long long cnt8 = 0;
     bool big = false;
     int64_t ws = r;
@@ -970,12 +989,12 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
 __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int nb_abs, int64_t slot) {
     int close_pos;
     bool close_ns;
-    const int64_t close_row = find_close(A.T, A.desc, A.tail_contig, nb_abs, d.row_end, d.extra_row, close_pos, close_ns);
+    const int64_t close_row = find_close(A.T, A.desc, A.tail_contig, nb_abs, d.row_end, d.extra_row(), close_pos, close_ns);
     for (int s = 0; s < A.k; ++s) A.O.feats[slot * A.k + s] = 0.0;
     A.O.site_pos[slot] = d.extra_mpos;
     A.O.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
     A.O.close_row[slot] = close_row;
-    A.O.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi) ? MC_I_MULTI : 0u);
+    A.O.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi()) ? MC_I_MULTI : 0u);
     A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
@@ -994,9 +1013,16 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ r
     }
     if (c == 0) return;
     const int64_t first = tile_slot(A.tile_local, A.group_sum, tile, lane);
-    const int64_t ovf = A.tile_base[tile];
-    if (ovf < 0 || first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
-    for (int j = lane; j < c; j += 64) rec_slot[first + j] = j < PT ? tile * PT + j : ovf + (j - PT);
+    if (first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    for (int j = lane; j < c; j += 64) {
+        long long slot = tile * PT + j;
+        if (j >= PT) {
+            const long long cb = A.tile_chunk[tile * (TILE / 64) + (j >> 6)];
+            if (cb < 0) { atomicOr(&A.cnt->overflow, 1u); continue; }
+            slot = cb + (j & 63);
+        }
+        rec_slot[first + j] = slot;
+    }
 }
 
 // One thread per closed window: the (event, model) pairs of the 32 rows ending at the window's last row come in with
@@ -1016,7 +1042,7 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
         A.O.site_pos[q] = m;
         A.O.site_seg[q] = T.nb_seg_begin[P.nb];
         A.O.close_row[q] = P.close_row;
-        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && d.extra_multi) ? MC_I_MULTI : 0u);
+        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && d.extra_multi()) ? MC_I_MULTI : 0u);
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
@@ -1130,7 +1156,7 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
         if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
             info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
         } else {
-            const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + A.R.word_off[d.contig];
+            const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
             const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
             unsigned char ch;
             if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
@@ -1202,7 +1228,7 @@ __global__ void k1_bigfix(K1Args A, int64_t n) {
     RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
     // last row of the window: the last unfiltered row of the block before the closing row
     int64_t r = min(O.close_row[j], d.row_end) - 1;
-    const int64_t lb = max(d.row_begin, d.first);
+    const int64_t lb = max(d.row_begin, d.first());
     while (r >= lb && (T.flags[r] & MC_F_MODEL_N)) --r;
     int64_t cnt[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t ws = r;
@@ -1329,12 +1355,11 @@ struct mc_ctx {
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr;
-    unsigned long long *bitmap = nullptr;
+    long long *tile_chunk = nullptr;
     int64_t *rec_slot = nullptr;
     Payload *payload = nullptr;
     long long payload_cap = 0;
     int n_cu = 256;
-    int64_t *tile_base = nullptr;
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
@@ -1493,9 +1518,8 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     if (dev_alloc(c->table_allocs, &c->tiles, (size_t)T.n_tiles + 1) || dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
         dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
-        dev_alloc(c->table_allocs, &c->bitmap, ((size_t)T.n_tiles + 1) * (TILE / 64)) ||
+        dev_alloc(c->table_allocs, &c->tile_chunk, ((size_t)T.n_tiles + 1) * (TILE / 64)) ||
         dev_alloc(c->table_allocs, &c->tile_local, (size_t)T.n_tiles + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_base, (size_t)T.n_tiles + 1) ||
         dev_alloc(c->table_allocs, &c->group_sum, (size_t)(T.n_tiles / GROUP + 2)) ||
         dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1))
         return -10;
@@ -1609,8 +1633,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         }
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         K1Args A;
-        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.bitmap = c->bitmap; A.payload = c->payload;
-        A.payload_cap = c->payload_cap; A.tile_base = c->tile_base; A.tile_cnt = c->tile_cnt;
+        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
+        A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
         A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
         A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
         { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
