@@ -341,7 +341,7 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
         if (inc && d.rev) regular = false;
         const uint32_t *mf = R.mf + d.mask_off, *mr = R.mr + d.mask_off;
         const int64_t L = d.contig_len;
-        if ((vf & V_POS0) && L > 0 && ((mf[0] | mr[0]) & 1u)) regular = false;   // falsy mpos (:179,:272,:279)
+        if ((vf & V_POS0) && L > 0 && ((mf[0] | mr[0]) & 1u)) { regular = false; d.xflags |= 4; }   // falsy mpos (:179,:272,:279)
         if (regular && dec && !d.rev) {
             if (k < 2) {
                 regular = false;
@@ -1256,6 +1256,279 @@ __global__ void k1_bigfix(K1Args A, int64_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The literal path: name blocks the window rule does not cover (same read name in several blocks, positions going
+// backwards, strand changes inside a read, a site at contig position 0, reads spanning contigs).  Runs of such blocks
+// are executed row by row exactly as the reference's loop does (extract_contexts.py:147-291), one GPU thread per run;
+// they are rare, so this path is written for exactness, not speed.  Its records are merged with the fast path's by
+// closing row (= flush order).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t XR_POS0 = 4;      // NbDesc.xflags: irregular because of a site at contig position 0 (falsy mpos)
+
+// After k0_classify: widen the irregular set so that every run starts and ends in a state the fast path knows.
+__global__ void k0_extend(DevTable T, NbDesc *__restrict__ desc, const int64_t *__restrict__ nb_f0, int entry_read,
+                          Counters *cnt) {
+    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (b >= T.n_nb || cnt->n_irregular == 0) return;
+    const NbDesc d = desc[b];
+    if (d.mode != MODE_IRREGULAR) return;
+    // (a) a block that sees name == last_read continues the state of the block that set last_read: take everything
+    //     from that block on (the blocks in between have no site row but may hold rows that flush and reset)
+    if (T.nb_repeat[b] || entry_read >= 0) {
+        int j = b - 1;
+        while (j >= 0 && nb_f0[j] < 0) --j;
+        const int last_read = j >= 0 ? T.nb_read[j] : entry_read;
+        if (last_read == d.read && j >= 0)
+            for (int i = j; i < b; ++i) desc[i].mode = MODE_IRREGULAR;
+    }
+    // (b) a falsy mpos (site at position 0) can leave events in the slots while no window is open: they survive until
+    //     the next window is flushed, i.e. through the next block that has a site row
+    if (d.xflags & XR_POS0) {
+        for (int i = b + 1; i < T.n_nb; ++i) {
+            const bool site_block = nb_f0[i] >= 0 && !desc[i].filtered;
+            desc[i].mode = MODE_IRREGULAR;
+            if (site_block) break;
+        }
+    }
+}
+
+struct LitArgs {
+    DevTable T;
+    DevRef R;
+    const NbDesc *desc;
+    const int64_t *nb_f0;
+    const double *qual;
+    double qual_thresh;
+    int k, skip_thresh, tail_contig, entry_read, entry_first_idx;
+    int32_t *run_cnt;          // [n_nb] flush records of the run that starts at this block (0 elsewhere)
+    int32_t *run_rows;         // [n_nb] rows of that run
+    const int32_t *cnt_local;  // exclusive scans of the two (inside groups of 1024 blocks) + group sums
+    const int64_t *cnt_group;
+    const int32_t *rows_local;
+    const int64_t *rows_group;
+    double *scratch;           // MC_MAX_K slot arrays per run, each as long as the run
+    DevRecords L;
+    int write;                 // 0: count records and rows per run; 1: produce the records
+};
+
+// NumPy pairwise_sum over an array (np.mean of a slot list, :186)
+__device__ double pairwise_arr(const double *a, int64_t n) {
+    int64_t fbeg[40], fsize[40];
+    int fstage[40];
+    double fleft[40];
+    int fp = 1;
+    fbeg[0] = 0; fsize[0] = n; fstage[0] = 0;
+    double ret = 0.0;
+    while (fp > 0) {
+        const int top = fp - 1;
+        int64_t n2 = fsize[top] / 2;
+        n2 -= n2 % 8;
+        if (fstage[top] == 0) {
+            const int64_t m = fsize[top];
+            const double *p = a + fbeg[top];
+            if (m < 8) {
+                double res = -0.0;
+                for (int64_t i = 0; i < m; ++i) res += p[i];
+                ret = res;
+                --fp;
+            } else if (m <= 128) {
+                double r[8];
+                int64_t i;
+                for (i = 0; i < 8; ++i) r[i] = p[i];
+                for (i = 8; i < m - (m % 8); i += 8)
+                    for (int j = 0; j < 8; ++j) r[j] += p[i + j];
+                double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < m; ++i) res += p[i];
+                ret = res;
+                --fp;
+            } else {
+                fstage[top] = 1;
+                fbeg[fp] = fbeg[top]; fsize[fp] = n2; fstage[fp] = 0; ++fp;
+            }
+        } else if (fstage[top] == 1) {
+            fleft[top] = ret;
+            fstage[top] = 2;
+            fbeg[fp] = fbeg[top] + n2; fsize[fp] = fsize[top] - n2; fstage[fp] = 0; ++fp;
+        } else {
+            ret = fleft[top] + ret;
+            --fp;
+        }
+    }
+    return ret;
+}
+
+__global__ void k_literal(LitArgs A) {
+    const DevTable &T = A.T;
+    const int b0 = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (b0 >= T.n_nb) return;
+    if (A.desc[b0].mode != MODE_IRREGULAR || (b0 > 0 && A.desc[b0 - 1].mode == MODE_IRREGULAR)) {
+        if (!A.write) { A.run_cnt[b0] = 0; A.run_rows[b0] = 0; }
+        return;
+    }
+    const int k = A.k;
+    // ---- machine state (:113-119) ----
+    int last_read;
+    {
+        int j = b0 - 1;
+        while (j >= 0 && A.nb_f0[j] < 0) --j;
+        last_read = j >= 0 ? T.nb_read[j] : A.entry_read;
+    }
+    int64_t first_idx = A.entry_first_idx;
+    bool has_mpos = false;
+    int64_t mpos = 0;
+    int last_rev = 0, last_seg = -1;
+    int64_t nslot[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int sid[MC_MAX_K] = {0, 1, 2, 3, 4, 5, 6, 7};        // logical slot -> physical array
+    int64_t run_rows = 0, out = 0, cap = 0;
+    double *slots = nullptr;
+    if (A.write) {
+        const int g = b0 / GROUP;
+        long long ro = A.rows_local[b0], co = A.cnt_local[b0];
+        for (int i = 0; i < g; ++i) { ro += A.rows_group[i]; co += A.cnt_group[i]; }
+        cap = A.run_rows[b0];
+        slots = A.scratch + (size_t)ro * MC_MAX_K;
+        out = co;
+    }
+    auto truthy = [&]() { return has_mpos && mpos != 0; };
+    auto flush = [&](int64_t close_row, bool multi) {                                   // :179-239
+        if (A.write) {
+            const int64_t j = out;
+            int nskip = 0;
+            for (int i = 0; i < k; ++i) nskip += (nslot[i] == 0);
+            uint32_t info = last_rev ? MC_I_REV : 0u;
+            const int contig = T.seg_contig[last_seg];
+            const int64_t L = A.R.contig_len[contig];
+            for (int i = 0; i < k; ++i) A.L.feats[j * k + i] = 0.0;
+            if (nskip <= A.skip_thresh) {
+                for (int i = 0; i < k; ++i) {
+                    const int dst = last_rev ? i : k - 1 - i;
+                    if (nslot[i] == 0) info |= 1u << dst;
+                    else A.L.feats[j * k + dst] = (0.0 + pairwise_arr(slots + (size_t)sid[i] * cap, nslot[i])) / (double)nslot[i];
+                }
+                if (mpos - k + 1 < 0 || mpos + k > L || mpos < 1 || mpos + 1 >= L) {
+                    info |= MC_I_EDGE;
+                } else {
+                    const uint8_t *seq = A.R.seq + A.R.seq_off[contig];
+                    unsigned char ch;
+                    if (!last_rev) ch = bit_at(A.R.mf + A.R.word_off[contig], mpos + 1) ? 'M' : seq[mpos + 1];
+                    else ch = bit_at(A.R.mr + A.R.word_off[contig], mpos - 1) ? 'M' : comp_char(seq[mpos - 1]);
+                    info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+                }
+            } else {
+                info |= MC_I_TOO_MANY;
+            }
+            if (multi) info |= MC_I_MULTI;
+            A.L.site_pos[j] = (int32_t)mpos;
+            A.L.site_seg[j] = last_seg;
+            A.L.close_row[j] = close_row;
+            A.L.info[j] = info;
+            A.L.prob[j] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        ++out;
+    };
+    auto clear_slots = [&]() { for (int i = 0; i < k; ++i) nslot[i] = 0; };
+
+    int b = b0;
+    for (; b < T.n_nb && A.desc[b].mode == MODE_IRREGULAR; ++b) {
+        for (int seg = T.nb_seg_begin[b]; seg < T.nb_seg_begin[b + 1]; ++seg) {
+            const int name = T.seg_read[seg], contig = T.seg_contig[seg];
+            const bool filtered = A.qual[name] < A.qual_thresh;
+            const int64_t L = A.R.contig_len[contig];
+            const uint32_t *mf = A.R.mf + A.R.word_off[contig], *mr = A.R.mr + A.R.word_off[contig];
+            for (int64_t r = T.seg_begin[seg]; r < T.seg_begin[seg + 1]; ++r) {
+                ++run_rows;
+                const int64_t idx = T.idx[r];
+                const uint32_t fl = T.flags[r];
+                if (name != last_read) first_idx = idx;                                  // :161-162
+                if (filtered || (fl & MC_F_MODEL_N)) continue;                           // :167-168
+                int rev;
+                if ((name != last_read && (fl & MC_F_KMER_EQ)) || (name == last_read && idx > first_idx)) rev = 0;
+                else rev = 1;                                                            // :169-174
+                const int64_t pos = T.pos[r];
+                const int off = first_m(rev ? mr : mf, L, pos, k);                       // :176
+                if (truthy() && ((pos >= mpos + 1 && name == last_read) || name != last_read)) {   // :179
+                    const bool reset = off < 0 || name != last_read || pos > mpos + A.skip_thresh + 1;
+                    flush(r, !reset && off != 0);
+                    if (reset) {                                                         // :242-245
+                        clear_slots();
+                        has_mpos = false;
+                    } else {                                                             // :246-256
+                        const int64_t old = mpos;
+                        mpos = pos + off;
+                        const int s = (int)(mpos - old < k ? mpos - old : k);
+                        int psid[MC_MAX_K];
+                        int64_t pn[MC_MAX_K];
+                        for (int i = 0; i < k; ++i) { psid[i] = sid[i]; pn[i] = nslot[i]; }
+                        for (int i = 0; i < k; ++i) {
+                            const int src = (i - s + k) % k;
+                            sid[i] = psid[src];
+                            nslot[i] = i < s ? 0 : pn[src];
+                        }
+                    }
+                }
+                if (off >= 0) {                                                          // :269-287
+                    if (truthy()) {
+                        if (name != last_read) { has_mpos = false; clear_slots(); }
+                        else if (rev != last_rev) has_mpos = false;                      // slots kept (:276-277)
+                    }
+                    if (!truthy()) { has_mpos = true; mpos = pos + off; }
+                    last_read = name;
+                    last_rev = rev;
+                    last_seg = seg;
+                    if (A.write) slots[(size_t)sid[off] * cap + nslot[off]] = (double)(T.ev[r] - T.mu[r]) / 10000.0;
+                    nslot[off] += 1;
+                } else if (truthy()) {                                                   // :289-291
+                    has_mpos = false;
+                    clear_slots();
+                }
+            }
+        }
+    }
+    // the run is over: its open window is closed by the next unfiltered row of the file (another read's)
+    if (truthy()) {
+        int64_t close_row = -1;
+        int64_t rr = T.nb_row_begin[b];
+        int bb = b;
+        while (rr < T.n_rows) {
+            while (bb + 1 < T.n_nb && T.nb_row_begin[bb + 1] <= rr) ++bb;
+            if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb + 1]; continue; }
+            if (!(T.flags[rr] & MC_F_MODEL_N)) { close_row = rr; break; }
+            ++rr;
+        }
+        if (close_row < 0 && A.tail_contig >= 0) close_row = T.n_rows;
+        if (close_row >= 0) flush(close_row, false);
+    }
+    if (!A.write) {
+        A.run_cnt[b0] = (int32_t)out;
+        A.run_rows[b0] = (int32_t)run_rows;
+    }
+}
+
+// fast records O (sorted by closing row) + literal records L (sorted) -> M (sorted); closing rows are distinct
+__global__ void k_merge(DevRecords O, int64_t n_o, DevRecords L, int64_t n_l, DevRecords M, int k) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_o + n_l) return;
+    const bool from_l = i >= n_o;
+    const int64_t j = from_l ? i - n_o : i;
+    const DevRecords &S = from_l ? L : O;
+    const DevRecords &X = from_l ? O : L;
+    const int64_t nx = from_l ? n_o : n_l;
+    const int64_t key = S.close_row[j];
+    int64_t lo = 0, hi = nx;
+    while (lo < hi) {                                       // records of the other list that come first
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t xk = X.close_row[mid];
+        if (xk < key || (xk == key && from_l)) lo = mid + 1; else hi = mid;
+    }
+    const int64_t d = j + lo;
+    for (int f = 0; f < k; ++f) M.feats[d * k + f] = S.feats[j * k + f];
+    M.site_pos[d] = S.site_pos[j];
+    M.site_seg[d] = S.site_seg[j];
+    M.close_row[d] = S.close_row[j];
+    M.info[d] = S.info[j];
+    M.prob[d] = S.prob[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; weights staged in LDS.
 // ---------------------------------------------------------------------------------------------------
 // tanh(x) = sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}): one exp and one division; absolute error ~1e-16, far inside the
@@ -1351,7 +1624,9 @@ struct mc_ctx {
     TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
-    DevRecords O;
+    DevRecords O;            // records of the last call (view: the fast path's buffers, or the merged ones)
+    DevRecords Omain;        // the fast path's buffers
+    std::vector<void *> lit_allocs;
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr;
@@ -1421,6 +1696,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     free_pool(c->ref_allocs);
     free_pool(c->mlp_allocs);
     free_pool(c->rec_allocs);
+    free_pool(c->lit_allocs);
     if (c->qual) (void)hipFree(c->qual);
     if (c->cnt) (void)hipFree(c->cnt);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
@@ -1573,10 +1849,10 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
 }
 
 static int ensure_records(mc_ctx *c, int64_t cap, int k) {
-    if (c->O.capacity >= cap && c->last_k == k) return 0;
+    if (c->Omain.capacity >= cap && c->last_k == k) { c->O = c->Omain; return 0; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_pool(c->rec_allocs);
-    for (DevRecords *D : {&c->O}) {
+    for (DevRecords *D : {&c->Omain}) {
         D->capacity = cap;
         if (dev_alloc(c->rec_allocs, &D->feats, (size_t)cap * k) || dev_alloc(c->rec_allocs, &D->site_pos, (size_t)cap) ||
             dev_alloc(c->rec_allocs, &D->site_seg, (size_t)cap) || dev_alloc(c->rec_allocs, &D->close_row, (size_t)cap) ||
@@ -1586,11 +1862,68 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
     c->payload_cap = cap + (c->T.n_tiles + 1) * PT;
     if (dev_alloc(c->rec_allocs, &c->rec_slot, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
     c->last_k = k;
+    c->O = c->Omain;
     return 0;
 }
 
 static size_t mlp_lds_bytes(const DevMlp &M) {
     return (size_t)M.n_models * ((size_t)M.n_in * M.n_hidden + 2 * (size_t)M.n_hidden + 1) * 8;
+}
+
+static int alloc_records(std::vector<void *> &pool, DevRecords &D, int64_t cap, int k) {
+    D.capacity = cap;
+    if (dev_alloc(pool, &D.feats, (size_t)cap * k) || dev_alloc(pool, &D.site_pos, (size_t)cap) ||
+        dev_alloc(pool, &D.site_seg, (size_t)cap) || dev_alloc(pool, &D.close_row, (size_t)cap) ||
+        dev_alloc(pool, &D.info, (size_t)cap) || dev_alloc(pool, &D.prob, (size_t)cap))
+        return -10;
+    return 0;
+}
+
+// Irregular name blocks: literal row-by-row machine on the GPU, then merge with the fast path's records.
+static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
+    const DevTable &T = c->T;
+    const int k = prm->k;
+    const int n_groups = (T.n_nb + GROUP - 1) / GROUP;
+    LitArgs LA;
+    LA.T = T; LA.R = c->R; LA.desc = c->desc; LA.nb_f0 = c->nb_f0; LA.qual = c->qual; LA.qual_thresh = prm->qual_thresh;
+    LA.k = k; LA.skip_thresh = prm->skip_thresh; LA.tail_contig = prm->tail_contig; LA.entry_read = prm->entry_read;
+    LA.entry_first_idx = prm->entry_first_idx;
+    int32_t *run_cnt, *run_rows, *cnt_local, *rows_local;
+    int64_t *cnt_group, *rows_group;
+    std::vector<void *> &P = c->lit_allocs;
+    if (dev_alloc(P, &run_cnt, (size_t)T.n_nb + 1) || dev_alloc(P, &run_rows, (size_t)T.n_nb + 1) ||
+        dev_alloc(P, &cnt_local, (size_t)T.n_nb + 1) || dev_alloc(P, &rows_local, (size_t)T.n_nb + 1) ||
+        dev_alloc(P, &cnt_group, (size_t)n_groups + 1) || dev_alloc(P, &rows_group, (size_t)n_groups + 1))
+        return -10;
+    LA.run_cnt = run_cnt; LA.run_rows = run_rows; LA.cnt_local = cnt_local; LA.cnt_group = cnt_group;
+    LA.rows_local = rows_local; LA.rows_group = rows_group; LA.scratch = nullptr; LA.L = DevRecords(); LA.write = 0;
+    const unsigned g = (unsigned)((T.n_nb + 63) / 64);
+    hipLaunchKernelGGL(k_literal, dim3(g), dim3(64), 0, c->stream, LA);
+    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)n_groups), dim3(GROUP), 0, c->stream, (const int32_t *)run_cnt,
+                       (int64_t)T.n_nb, cnt_local, cnt_group);
+    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)n_groups), dim3(GROUP), 0, c->stream, (const int32_t *)run_rows,
+                       (int64_t)T.n_nb, rows_local, rows_group);
+    std::vector<int64_t> hc((size_t)n_groups), hr((size_t)n_groups);
+    HIP_TRY(hipMemcpyAsync(hc.data(), cnt_group, (size_t)n_groups * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hr.data(), rows_group, (size_t)n_groups * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    int64_t n_lit = 0, n_rows_lit = 0;
+    for (int i = 0; i < n_groups; ++i) { n_lit += hc[(size_t)i]; n_rows_lit += hr[(size_t)i]; }
+    if (n_lit == 0) return 0;
+    DevRecords L, M;
+    double *scratch;
+    const int64_t n_fast = *n_io;
+    if (alloc_records(P, L, n_lit, k) || alloc_records(P, M, n_fast + n_lit, k) ||
+        dev_alloc(P, &scratch, (size_t)std::max<int64_t>(n_rows_lit, 1) * MC_MAX_K))
+        return -10;
+    LA.scratch = scratch; LA.L = L; LA.write = 1;
+    hipLaunchKernelGGL(k_literal, dim3(g), dim3(64), 0, c->stream, LA);
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((n_fast + n_lit + 255) / 256)), dim3(256), 0, c->stream, c->O, n_fast, L, n_lit, M, k);
+    HIP_TRY(hipGetLastError());
+    c->O = M;
+    *n_io = n_fast + n_lit;
+    return 0;
 }
 
 extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_records) {
@@ -1617,7 +1950,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
 
-    int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->O.capacity);
+    free_pool(c->lit_allocs);
+    int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
         HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
@@ -1628,6 +1962,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
                                c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
             hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
                                c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
+            hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->desc,
+                               (const int64_t *)c->nb_f0, prm->entry_read, c->cnt);
             hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
                                c->desc, k, c->tiles);
         }
@@ -1651,13 +1987,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
-        if (h.n_irregular) {
-            mc_set_error("%u read block(s) need the literal path (same read name in several blocks, positions going "
-                         "backwards, strand change inside a read, a site at contig position 0, or a read spanning "
-                         "contigs): not available in this build of the HIP path", h.n_irregular);
-            return -20;
-        }
-        const int64_t n = (int64_t)h.n_records;
+        int64_t n = (int64_t)h.n_records;
 #ifdef MC_PROFILE
         fprintf(stderr, "k1_scan phase cycles:");
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", h.prof[i]);
@@ -1668,6 +1998,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
             continue;
         }
         if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
+        if (h.n_irregular) {
+            if (int rc = run_literal_path(c, prm, &n)) return rc;
+        }
         if (prm->score && n > 0) {
             hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
                                c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,

@@ -111,15 +111,12 @@ def test_micro_cases_records(dev, tmp_path):
             device_vs_oracle(dev, P, a['k'], a['skip_thresh'], a['qual_thresh'], modelset, a['base'], a['train'])
             n_ok += 1
         except McError as e:
-            if 'literal path' in str(e):
-                n_irregular += 1
-            else:
-                bad.append((case['seed'], case['flavour'], str(e)))
+            bad.append((case['seed'], case['flavour'], str(e)))
         except AssertionError as e:
             bad.append((case['seed'], case['flavour'], str(e)[:200]))
-    print('micro-cases: %d identical, %d need the literal path' % (n_ok, n_irregular))
+    print('micro-cases: %d identical' % n_ok)
     assert not bad, bad[:10]
-    assert n_ok > 100
+    assert n_ok > 250
 
 
 @pytest.mark.parametrize('n_rows,seed,motif,skip,qthresh', [
@@ -161,7 +158,8 @@ def test_mlp_known_answers(dev):
 
 
 @pytest.mark.parametrize('flavour,n', [('quirk_pal', 150), ('plain', 60), ('dense', 60), ('skips', 60), ('heavy', 40),
-                                       ('multi_contig', 40), ('qual', 40)])
+                                       ('multi_contig', 40), ('qual', 40), ('quirk_names', 80), ('quirk_flip', 80),
+                                       ('quirk_backwards', 80), ('quirk_pos0', 80), ('header', 30), ('n_context', 40)])
 def test_fresh_random_cases(dev, tmp_path, flavour, n):
     """Random cases that are NOT in the committed fixtures (seeds >= 10^6): HIP records == C-oracle records."""
     from oracle import casegen
@@ -187,7 +185,8 @@ def test_fresh_random_cases(dev, tmp_path, flavour, n):
                              None if a['train'] else H.load_modelset(a['model']), a['base'], a['train'])
             n_ok += 1
         except McError as e:
-            assert 'literal path' in str(e)
-            n_lit += 1
-    print('%s: %d identical, %d literal' % (flavour, n_ok, n_lit))
+            raise AssertionError('seed %d: %s' % (case['seed'], e))
+        except AssertionError as e:
+            raise AssertionError('seed %d (%s): %s' % (case['seed'], flavour, str(e)[:300]))
+    print('%s: %d identical' % (flavour, n_ok))
     assert n_ok >= n // 2
