@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""mCaller command line on MI355X -- same flags, output naming and messages as the reference's mCaller.py:118-184.
+
+`-t/--threads` is accepted for compatibility: the GPU path is one process per GPU and always produces the reference's
+single-process (`-t 1`) row order; with `-t N>1` the rows are passed through the same `sort | uniq` the reference applies
+after its workers (mCaller.py:106), in the C locale.
+"""
+import glob
+import os
+import sys
+
+assert sys.version_info >= (3, 0), 'please use python3'
+
+from .extract_contexts import extract_features
+from .read_qual import extract_read_quality
+from .refmark import read_fasta
+
+
+def pos2label(positions):
+    """{(chrom, pos, strand): label} from a positions file (train_model.py:18-20)."""
+    return {(pos.split()[0], int(pos.split()[1]), pos.split()[2]): pos.split()[3]
+            for pos in open(positions, 'r').read().split('\n') if len(pos.split()) > 1}
+
+
+def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_refs, base, mod, nprocs, nvariables, train,
+                       modelfile, skip_thresh, qual_thresh, classifier, training_tsv, plot_training):
+    """mCaller.py:25-115 without the process fan-out: one GPU pass, then the same file naming."""
+    outdir = '/'.join(tsvname.split('/')[:-1])
+    if len(outdir) > 1:
+        outdir = outdir + '/'
+    print(outdir)
+    if not train:
+        tsv_output = '.'.join(tsvname.split('.')[:-1]) + '.diffs.' + str(nvariables)
+        training_pos_dict = None
+    else:
+        tsv_output = '.'.join(tsvname.split('.')[:-1]) + '.diffs.' + str(nvariables) + '.train'
+        if training_tsv:
+            raise NotImplementedError('--training_tsv (re-loading a labelled diffs file) is outside the GPU path')
+        training_pos_dict = pos2label(positions_list)
+
+    print('%d contigs' % num_refs)
+    print('%d threads' % nprocs)
+    bytesize = os.path.getsize(tsvname)
+    ret = extract_features(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile, classifier, 0,
+                           endline=bytesize, train=train, pos_label=training_pos_dict, base=base, motif=motif,
+                           positions_list=positions_list)
+    print('Finished extracting signals')
+    tmpfis = glob.glob('.'.join(tsvname.split('.')[:-1]) + '*.tmp[0-9]*')
+    if nprocs > 1:
+        print('Merging files...')
+        lines = set()
+        for tmpfi in tmpfis:
+            with open(tmpfi, 'rb') as fh:
+                lines.update(fh.read().splitlines(True))
+            os.remove(tmpfi)
+        with open(tsv_output, 'wb') as out:                 # `sort -n -k2 | uniq`: field 2 is not numeric, so the
+            out.writelines(sorted(lines))                   # order is the last-resort whole-line comparison
+    else:
+        os.rename(tmpfis[0], tsv_output)
+
+    if train:
+        print('Training...')
+        from .train_model import train_classifier
+        signal_mat, context_array = ret
+        train_classifier(signal_mat, context_array, modelfile, classifier, plot_training)
+        print('Finished training')
+
+
+def main(argv=None):
+    from argparse import ArgumentParser
+    parser = ArgumentParser(description='Classify bases as methylated or unmethylated', prog='mCaller')
+    all_or_some = parser.add_mutually_exclusive_group(required=True)
+    all_or_some.add_argument('-p', '--positions', type=str, required=False, help='file with a list of positions at which to classify bases (must be formatted as space- or tab-separated file with chromosome, position, strand, and label if training)')
+    all_or_some.add_argument('-m', '--motif', type=str, required=False, help='classify every base of type --base in the motif specified instead (can be single one-mer)')
+    parser.add_argument('-r', '--reference', type=str, required=True, help='fasta file with reference aligned to')
+    parser.add_argument('-e', '--tsv', type=str, required=True, help='tsv file with nanopolish event alignment')
+    parser.add_argument('-f', '--fastq', type=str, required=True, help='fastq file with nanopore reads')
+    parser.add_argument('-t', '--threads', type=int, required=False, help='specify number of processes (default = 1)', default=1)
+    parser.add_argument('-b', '--base', type=str, required=False, help='bases to classify as methylated or unmethylated (A or C, default A)', default='A')
+    parser.add_argument('-n', '--num_variables', type=int, required=False, help='change the length of the context used to classify (default of 6 variables corresponds to 11-mer context (6*2-1))', default=6)
+    parser.add_argument('--train', action='store_true', required=False, help='train a new model (requires labels in positions file)', default=False)
+    parser.add_argument('--training_tsv', type=str, required=False, help='mCaller output file for training')
+    parser.add_argument('-d', '--modelfile', type=str, required=False, help='model file name')
+    parser.add_argument('-s', '--skip_thresh', type=int, required=False, help='number of skips to allow within an observation (default 0)', default=0)
+    parser.add_argument('-q', '--qual_thresh', type=float, required=False, help='quality threshold for reads (default none)', default=0)
+    parser.add_argument('-c', '--classifier', type=str, required=False, help='use alternative classifier: options = NN (default), RF, LR, or NBC (non-default may significantly increase runtime)', default='NN')
+    parser.add_argument('--plot_training', action='store_true', required=False, help='plot probabilities distributions for training positions (requires labels in positions file and --train)', default=False)
+    parser.add_argument('-v', '--version', action='version', help='print version', version='%(prog)s v1.0')
+    args = parser.parse_args(argv)
+
+    if args.base == 'A':
+        mod = 'm6A'
+    elif args.base == 'C':
+        mod = 'm5C'
+    else:
+        print('classification only available for A or C bases so far')
+        sys.exit(0)
+
+    if not args.modelfile:
+        modelfile = (os.path.dirname(os.path.realpath(sys.argv[0])) + '/model_' + args.classifier + '_' +
+                     str(args.num_variables) + '_' + mod + '.pkl')
+    else:
+        modelfile = args.modelfile
+    if not args.train:
+        assert os.path.isfile(modelfile), 'model file not found at ' + modelfile
+
+    if args.motif and len(args.motif) == 1:
+        base = args.motif
+    else:
+        base = args.base
+
+    assert (args.skip_thresh < args.num_variables / 2), ('too many skips with only ' + str(args.num_variables) +
+                                                         ' variables - try < half')
+    assert os.path.isfile(args.fastq), 'fastq file not found at ' + args.fastq
+    read2qual = extract_read_quality(args.fastq)
+
+    try:
+        num_refs = len(read_fasta(args.reference))
+    except IOError:
+        print('reference file missing')
+        sys.exit(0)
+
+    distribute_threads(args.positions, args.motif, args.tsv, read2qual, args.reference, num_refs, base, mod, args.threads,
+                       args.num_variables, args.train, modelfile, args.skip_thresh, args.qual_thresh, args.classifier,
+                       args.training_tsv if args.training_tsv else None, args.plot_training)
+
+
+if __name__ == '__main__':
+    main()

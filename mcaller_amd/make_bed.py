@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Per-position summary of an mCaller `.diffs.<n>` file: the BED writer of the reference's make_bed.py:67-164, plus the
+same reduction computed from flush records with an all-reduce over ranks (the one exchange step of the multi-GPU path).
+
+Supported: -f, -d, -t, -p (positions mode without the t-test columns is NOT offered: use the reference for those),
+--control, --vo, --gff (without --vo statistics), --ref.  Plotting options are out of scope.
+"""
+import os
+import sys
+
+import numpy as np
+
+from .refmark import read_fasta, revcomp
+
+
+def check_thresh(locus_list, mod_thresh, depth_thresh, control):
+    """make_bed.py:21-28 (returns None below the depth threshold, like the reference)."""
+    if len(locus_list) >= depth_thresh:
+        if not control and np.mean(locus_list) >= mod_thresh:
+            return True
+        elif control and np.mean(locus_list) < mod_thresh:
+            return True
+        else:
+            return False
+
+
+def ref2context(ref, pos_dict):
+    """make_bed.py:36-48: +-20 bp context around each locus."""
+    ref_dict = {name: seq for name, seq in read_fasta(ref)}
+    out = {}
+    for pos in pos_dict:
+        if pos[0] in ref_dict:
+            cx = ref_dict[pos[0]][int(pos[1]) - 20:int(pos[1]) + 21].upper()
+            if pos[4] == '-':
+                cx = revcomp(cx)
+            out[pos] = cx
+    return out
+
+
+def aggregate_by_pos(meth_fi, aggfi, depth_thresh, mod_thresh, pos_list, control, verbose_results, gff, ref,
+                     plot=False, plotdir=None, plotsummary=False):
+    """make_bed.py:67-164 for the non-plotting, non-positions modes."""
+    if pos_list:
+        raise NotImplementedError('make_bed -p (per-position t-tests) is outside the accelerated path')
+    if plot or plotsummary:
+        raise NotImplementedError('plotting is out of scope')
+    pos_dict, pos_dict_verbose = {}, {}
+    for line in open(meth_fi, 'r'):
+        try:
+            csome, read, pos, context, values, strand, label, prob = tuple(line.split('\t'))
+        except ValueError:
+            csome, read, pos, context, values, strand, label = tuple(line.split('\t'))
+            prob = ''
+        nextpos = str(int(pos) + 1)
+        if context[int(len(context) / 2)] != 'M':
+            continue
+        key = (csome, pos, nextpos, context, strand)
+        if key not in pos_dict:
+            pos_dict[key] = []
+            pos_dict_verbose[key] = []
+        pos_dict[key].append(1 if label[0] == 'm' else 0)
+        if verbose_results:
+            pos_dict_verbose[key].append(prob.strip())
+    print({key: [] for key in pos_dict})                               # make_bed.py:101 prints values_dict
+    context_dict = ref2context(ref, pos_dict) if ref else None
+    count = 0
+    with open(aggfi, 'w') as outfi:
+        for locus in pos_dict.keys():
+            if not check_thresh(pos_dict[locus], mod_thresh, depth_thresh, control):
+                continue
+            cx = context_dict[locus] if ref else locus[3]
+            count += 1
+            frac = np.mean(pos_dict[locus])
+            if gff:
+                deets = 'coverage=' + str(len(pos_dict[locus])) + ';context=' + cx + ';IPDRatio=5;frac=' + str(frac)
+                if verbose_results:
+                    raise NotImplementedError('--gff --vo (scipy.stats.sem columns) is not offered')
+                outfi.write('\t'.join([locus[0], 'kinModCall', 'm6A', locus[2], locus[2], '10', locus[4], '.', deets]) + '\n')
+            else:
+                print(aggfi)
+                out_line = '\t'.join(list(locus)[:-1] + [str(np.mean(pos_dict[locus]))] + [locus[-1]] +
+                                     [str(len(pos_dict[locus]))])
+                if verbose_results:
+                    out_line = out_line + '\t' + ','.join(pos_dict_verbose[locus])
+                outfi.write(out_line + '\n')
+    if not control:
+        print(count, 'methylated loci found with min depth', depth_thresh, 'reads')
+    else:
+        print(count, 'unmethylated loci found with min depth', depth_thresh, 'reads')
+
+
+# ---- the same reduction from flush records, summed over ranks -----------------------------------------------------
+def site_counts(rec, k, table, n_contigs, contig_len, row_offset=0):
+    """Per (contig, strand, site) arrays from this rank's records: n_meth, n_total (int64) and the global row of the first
+    occurrence (int64, big = none).  Keys are flattened as (contig_off[c] + pos) * 2 + strand."""
+    from . import _lib
+    off = np.concatenate([[0], np.cumsum(contig_len)]).astype(np.int64)
+    size = int(off[-1]) * 2
+    n_meth = np.zeros(size, dtype=np.int64)
+    n_total = np.zeros(size, dtype=np.int64)
+    first = np.full(size, np.iinfo(np.int64).max, dtype=np.int64)
+    n = rec.n
+    info = rec.info[:n]
+    ok = (info & _lib.I_TOO_MANY) == 0
+    if ok.any():
+        contig = table.seg_contig[rec.site_seg[:n][ok]].astype(np.int64)
+        key = (off[contig] + rec.site_pos[:n][ok].astype(np.int64)) * 2 + ((info[ok] & _lib.I_REV) != 0)
+        np.add.at(n_total, key, 1)
+        np.add.at(n_meth, key, (rec.prob[:n][ok] >= 0.5).astype(np.int64))
+        np.minimum.at(first, key, rec.close_row[:n][ok] + row_offset)
+    return n_meth, n_total, first
+
+
+def allreduce_site_counts(n_meth, n_total, first, dist=None):
+    """Sum / min over ranks (torch.distributed: gloo on CPU tensors, nccl = RCCL over xGMI on GPU tensors)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return n_meth, n_total, first
+    import torch
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    packed = torch.from_numpy(np.stack([n_meth, n_total])).to(dev)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    fmin = torch.from_numpy(first).to(dev)
+    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
+    packed = packed.cpu().numpy()
+    return packed[0], packed[1], fmin.cpu().numpy()
+
+
+def write_bed_from_counts(aggfi, n_meth, n_total, first, contig_names, contig_len, meth_strings, k, depth_thresh,
+                          mod_thresh, control=False):
+    """BED rows in first-occurrence order (make_bed.py:134,154-159) from reduced counts."""
+    off = np.concatenate([[0], np.cumsum(contig_len)]).astype(np.int64)
+    keys = np.nonzero(n_total > 0)[0]
+    keys = keys[np.argsort(first[keys], kind='stable')]
+    count = 0
+    with open(aggfi, 'w') as outfi:
+        for key in keys:
+            depth, meth = int(n_total[key]), int(n_meth[key])
+            frac = np.float64(meth) / np.float64(depth)
+            if depth < depth_thresh or ((frac >= mod_thresh) == bool(control)):
+                continue
+            rev = int(key & 1)
+            gp = int(key >> 1)
+            c = int(np.searchsorted(off, gp, side='right') - 1)
+            pos = gp - int(off[c])
+            context = revcomp(meth_strings[c][rev][pos - k + 1:pos + k], bool(rev))
+            outfi.write('\t'.join([contig_names[c], str(pos), str(pos + 1), context, str(frac), '-' if rev else '+',
+                                   str(depth)]) + '\n')
+            count += 1
+    return count
+
+
+def main(argv=None):
+    from argparse import ArgumentParser
+    parser = ArgumentParser(description='Produce bed file of methylated positions based on mCaller output')
+    parser.add_argument('-d', '--min_read_depth', type=int, required=False, default=15)
+    parser.add_argument('-t', '--mod_threshold', type=float, required=False, default=0.5)
+    parser.add_argument('-f', '--mCaller_file', type=str, required=True)
+    parser.add_argument('-p', '--positions', type=str, required=False)
+    parser.add_argument('--control', action='store_true', required=False)
+    parser.add_argument('--gff', action='store_true', required=False)
+    parser.add_argument('--ref', type=str, required=False)
+    parser.add_argument('--plot', action='store_true', required=False)
+    parser.add_argument('--plotsummary', action='store_true', required=False)
+    parser.add_argument('--plotdir', type=str, required=False, default='mCaller_position_plots')
+    parser.add_argument('--vo', action='store_true', required=False)
+    parser.add_argument('-v', '--version', action='version', version='%(prog)s v1.0')
+    args = parser.parse_args(argv)
+    assert os.path.isfile(args.mCaller_file), 'file not found at ' + args.mCaller_file
+    if args.positions:
+        output_file = args.mCaller_file.split('.')[0] + '.methylation.positions.summary'
+    elif not args.control:
+        output_file = args.mCaller_file.split('.')[0] + '.methylation.summary'
+    else:
+        output_file = args.mCaller_file.split('.')[0] + '.methylation.control.summary'
+    output_file = output_file + ('.gff' if args.gff else '.bed')
+    print(args.mCaller_file)
+    aggregate_by_pos(args.mCaller_file, output_file, args.min_read_depth, args.mod_threshold, args.positions, args.control,
+                     args.vo, args.gff, args.ref, args.plot, args.plotdir, args.plotsummary)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,42 @@
+"""NumPy semantics the path depends on, restated in the oracle and in the host formatter."""
+import random
+
+import numpy as np
+
+from oracle import py_oracle as po
+from mcaller_amd.extract_contexts import fmt_float, round2
+
+
+def test_pairwise_mean_matches_numpy():
+    rng = random.Random(3)
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 130, 136, 137, 255, 256, 257, 300, 1000, 1031]:
+        for _ in range(20):
+            vals = [round(rng.gauss(-0.17, 2.44), 2) for _ in range(n)]
+            assert po.np_mean(vals) == float(np.mean([np.float64(v) for v in vals])), n
+
+
+def test_round4_is_integer_division():
+    """np.round(float(e) - float(m), 4) == fl((E4 - M4) / 1e4) for 2- to 4-decimal prints."""
+    rng = random.Random(5)
+    for dec in (2, 3, 4):
+        for _ in range(20000):
+            e = round(rng.uniform(40, 140), dec)
+            m = round(rng.uniform(40, 140), dec)
+            es, ms = ('%.' + str(dec) + 'f') % e, ('%.' + str(dec) + 'f') % m
+            want = float(np.round(float(es) - float(ms), 4))
+            e4 = int(round(float(es) * 10000)); m4 = int(round(float(ms) * 10000))
+            assert want == (e4 - m4) / 10000.0
+            assert po.round_dec(float(es) - float(ms), 4) == want
+
+
+def test_float_formatting_matches_numpy_str():
+    rng = random.Random(7)
+    vals = [0.0, -0.0, 1.0, -2.5, 1e-5, 1e-4, 123456789.125, 1e16, 0.1 + 0.2, 7.055265349382997]
+    vals += [rng.uniform(-10, 10) for _ in range(5000)] + [rng.uniform(-1e-3, 1e-3) for _ in range(2000)]
+    for v in vals:
+        assert fmt_float(v) == str(np.float64(v)), v
+        assert po.fmt_float(v) == str(np.float64(v))
+    for _ in range(5000):
+        p = rng.random()
+        assert fmt_float(round2(p)) == str(np.round(np.float64(p), 2))
+        assert po.round_dec(p, 2) == float(np.round(np.float64(p), 2))

@@ -1,0 +1,80 @@
+"""The native eventalign parser against a line.split() parse (what the reference does, extract_contexts.py:140-152)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import py_oracle as po
+
+
+def split_parse(path, startline, endline, contigs):
+    rows, unknown = [], []
+    for line in po.consumed_lines(path, startline, endline):
+        t = line.split()[:12]
+        if len(t) < 12:
+            continue
+        if t[0] not in contigs:
+            unknown.append(t[0])
+            continue
+        d = int(round((float(t[6]) - float(t[10])) * 10000))
+        rows.append((contigs.index(t[0]), int(t[1]), t[3], int(t[5]), d, t[2] == t[9], t[9] == 'NNNNNN'))
+    return rows, unknown
+
+
+def check(path, startline, endline, contigs):
+    from mcaller_amd import _lib
+    t = _lib.parse_eventalign(path, startline, endline, contigs)
+    rows, unknown = split_parse(path, startline, endline, contigs)
+    assert t.n_rows == len(rows)
+    assert t.unknown == unknown
+    seg_of_row = np.repeat(np.arange(t.n_seg), np.diff(t.seg_row_begin))
+    for i, (c, p, name, idx, d, eq, isn) in enumerate(rows):
+        s = seg_of_row[i]
+        assert t.seg_contig[s] == c and t.pos[i] == p and t.event_idx[i] == idx
+        assert t.read_names[t.seg_read[s]] == name
+        assert int(t.event_e4[i]) - int(t.model_e4[i]) == d
+        assert bool(t.flags[i] & _lib.F_KMER_EQ) == eq and bool(t.flags[i] & _lib.F_MODEL_N) == isn
+    # segment / name-block flags
+    for i in range(t.n_rows):
+        new_name = i == 0 or rows[i][2] != rows[i - 1][2]
+        new_seg = new_name or rows[i][0] != rows[i - 1][0]
+        assert bool(t.flags[i] & _lib.F_NAME_START) == new_name
+        assert bool(t.flags[i] & _lib.F_SEG_START) == new_seg
+    return t
+
+
+def test_micro_cases(tmp_path):
+    for case in H.micro_cases()[::3]:
+        d = tmp_path / ('c%d' % case['seed'])
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        contigs = [r[0] for r in po.read_fasta(paths['fasta'])]
+        check(paths['tsv'], 0, os.path.getsize(paths['tsv']), contigs)
+
+
+def test_byte_ranges_follow_the_reference_window(tmp_path):
+    """seek(max(start-500,0)); readlines(8000000) batches while linepos <= endline-500 (:141-146)."""
+    from oracle import casegen
+    case = casegen.gen_case(424242, flavour='plain')
+    p = str(tmp_path / 'big.eventalign.tsv')
+    body = case['tsv'] * 40
+    open(p, 'w').write(body)
+    size = os.path.getsize(p)
+    contigs = ['ctg0', 'ecoli0', 'ctg1', 'ecoli1']
+    for start, end in [(0, size), (0, size // 3), (size // 3, 2 * size // 3), (1234, 5678), (0, 400), (size - 100, size)]:
+        check(p, start, end, contigs)
+
+
+def test_testdata_columns(tmp_path):
+    td = H.testdata_paths(str(tmp_path))
+    t = check(td['tsv'], 0, os.path.getsize(td['tsv']), ['ecoli'])
+    assert t.n_rows == 25344 and t.n_seg == 1 and int((t.flags & 2 != 0).sum()) == 1005
+
+
+def test_malformed_numbers_are_rejected(tmp_path):
+    from mcaller_amd import _lib
+    p = str(tmp_path / 'bad.tsv')
+    open(p, 'w').write(('c\t12\tACGTAC\tr\tt\t5\t80.1x\t1\t1\tACGTAC\t80.00\t1\t0\n') * 20)
+    with pytest.raises(_lib.McError):
+        _lib.parse_eventalign(p, 0, os.path.getsize(p), ['c'])

@@ -1,0 +1,81 @@
+"""Sharding by read and the per-site reduction, on CPU: the C oracle produces the records of every
+shard; concatenated they must equal the records of the whole table.  The N>1 reduction runs under torch.distributed with
+the gloo backend, world size 2."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from tests import helpers as H
+
+
+def make_workload(n_rows=150000, seed=21, motif='GATC', genome_len=300000):
+    from mcaller_amd import synth
+    codes = synth.genome(length=genome_len, seed=9)
+    ref = synth.SynthRef(codes, motif=motif)
+    table, qual = synth.make_table(n_rows, seed=seed, codes=codes, read_len=(800, 3000))
+    return codes, ref, table, qual
+
+
+def sharded_records(table, ref, qual, n_shards, k=6, skip=0, qthresh=0.0):
+    from mcaller_amd import shard
+    bounds = shard.shard_bounds(table, n_shards)
+    parts, ro, so, nr, tr = [], [], [], [], []
+    for lo, hi in bounds:
+        sub = table.slice_segments(lo, hi)
+        trow, tail = shard.tail_close(table, qual, qthresh, hi)
+        parts.append(H.oracle_records(sub, ref.device_arrays(), qual, k, skip, qthresh, tail_contig=tail))
+        ro.append(int(table.seg_row_begin[lo]))
+        so.append(lo)
+        nr.append(sub.n_rows)
+        tr.append(trow)
+    return shard.concat_records(parts, k, ro, so, nr, tr), bounds
+
+
+def test_shards_concatenate_to_the_whole():
+    codes, ref, table, qual = make_workload()
+    whole = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+    for n in (2, 3, 8):
+        rec, bounds = sharded_records(table, ref, qual, n)
+        assert len(bounds) == n and bounds[0][0] == 0 and bounds[-1][1] == table.n_seg
+        rows = [table.seg_row_begin[hi] - table.seg_row_begin[lo] for lo, hi in bounds]
+        assert max(rows) < 2.5 * table.n_rows / n                 # balanced by rows
+        H.assert_records_equal(rec, whole, 6)
+
+
+def test_shards_with_quality_filter_and_skips():
+    codes, ref, table, qual = make_workload(seed=22, motif='A')
+    whole = H.oracle_records(table, ref.device_arrays(), qual, 6, 1, 9.0)
+    rec, _ = sharded_records(table, ref, qual, 4, skip=1, qthresh=9.0)
+    H.assert_records_equal(rec, whole, 6)
+
+
+def test_repeated_read_names_are_not_cut():
+    from mcaller_amd import shard, _lib
+    codes, ref, table, qual = make_workload(n_rows=30000)
+    table.seg_read[-1] = table.seg_read[0]                        # the last read reuses the first read's name
+    assert shard.has_repeated_names(table)
+    bounds = shard.shard_bounds(table, 4)
+    assert bounds[0] == (0, table.n_seg) and all(lo == hi for lo, hi in bounds[1:])
+
+
+def test_site_reduction_gloo_world2(tmp_path):
+    """Two ranks (gloo): each reduces its shard's records per site; all-reduce; rank 0 writes the BED.  Must equal the BED
+    of the single-process run."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = [str(tmp_path / ('bed%d' % w)) for w in (1, 2)]
+    for world, path in zip((1, 2), out):
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port + world),
+                       PYTHONPATH=H.REPO)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(H.REPO, 'tests', '_reduce_worker.py'), path], env=env))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    a, b = open(out[0]).read(), open(out[1]).read()
+    assert a == b and a.count('\n') > 50
