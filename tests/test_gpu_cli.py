@@ -1,0 +1,96 @@
+"""The command line end to end on the GPU: same files as the reference's README commands (README.md:126-148)."""
+import contextlib
+import io
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def td(tmp_path_factory):
+    return H.testdata_paths(str(tmp_path_factory.mktemp('testdata')))
+
+
+def run_cli(td, tmp_path, extra):
+    from mcaller_amd import mCaller
+    tsv = str(tmp_path / 'masonread1.eventalign.tsv')
+    shutil.copy(td['tsv'], tsv)
+    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mCaller.main(extra + ['-r', td['fasta'], '-e', tsv, '-f', td['fastq'], '-d', model])
+    return str(tmp_path / 'masonread1.eventalign.diffs.6'), buf.getvalue()
+
+
+def test_readme_command_positions(td, tmp_path):
+    out, stdout = run_cli(td, tmp_path, ['-p', td['test_positions_m6A.txt']])
+    assert open(out).read() == open(os.path.join(H.GOLDEN, 'ref_outputs', 'config1_positions_m6A.diffs.6')).read()
+    want = open(os.path.join(H.GOLDEN, 'ref_outputs', 'config1_positions_m6A.stdout')).read().replace('<DIR>/', str(tmp_path) + '/')
+    assert [l for l in stdout.split('\n') if l.strip()] == [l for l in want.split('\n') if l.strip()]
+
+
+def test_readme_command_motif_then_make_bed(td, tmp_path):
+    from mcaller_amd import make_bed
+    out, _ = run_cli(td, tmp_path, ['-m', 'GATC'])
+    assert open(out).read() == open(os.path.join(H.GOLDEN, 'ref_outputs', 'motif_GATC.diffs.6')).read()
+    with contextlib.redirect_stdout(io.StringIO()):
+        make_bed.main(['-f', out, '-d', '1', '-t', '0.5'])
+    bed = str(tmp_path / 'masonread1.methylation.summary.bed')
+    assert open(bed).read() == open(os.path.join(H.GOLDEN, 'ref_outputs', 'motif_GATC.bed')).read()
+
+
+def test_threads_flag_sorts_like_the_reference(td, tmp_path):
+    out, _ = run_cli(td, tmp_path, ['-m', 'GATC', '-t', '4'])
+    want = sorted(set(open(os.path.join(H.GOLDEN, 'ref_outputs', 'motif_GATC.diffs.6'), 'rb').read().splitlines(True)))
+    assert open(out, 'rb').read() == b''.join(want)
+
+
+def test_train_mode_feature_matrix(td, tmp_path):
+    """--train: the labelled rows and the returned dicts (the fit itself is scikit-learn's and stochastic)."""
+    import json
+    from mcaller_amd.extract_contexts import extract_features
+    from mcaller_amd.read_qual import extract_read_quality
+    tsv = str(tmp_path / 'masonread1.eventalign.tsv')
+    shutil.copy(td['tsv'], tsv)
+    posf = td['test_positions.txt']
+    with contextlib.redirect_stdout(io.StringIO()):
+        sig, ctx = extract_features(tsv, td['fasta'], extract_read_quality(td['fastq']), 6, 0, 0, None, 'NN', 0,
+                                    endline=os.path.getsize(tsv), train=True, pos_label=H.pos2label(posf), base='A',
+                                    motif=None, positions_list=posf)
+    out = open(str(tmp_path / 'masonread1.eventalign.diffs.6.train.tmp0')).read()
+    assert out == open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.diffs.6.train')).read()
+    gold = json.load(open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.dicts.json')))
+    assert H.plain_signals(sig) == gold['signals'] and ctx == gold['contexts']
+
+
+def test_sharded_run_on_one_gpu_equals_the_whole():
+    """Shards scanned one after the other on the same GPU (tail_contig path of the kernels) == the whole table."""
+    from mcaller_amd import shard, synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    codes = synth.genome(length=500000, seed=9)
+    ref = synth.SynthRef(codes)
+    table, qual = synth.make_table(600000, seed=77, codes=codes, read_len=(2000, 9000))
+    _, weights, _, soc = submodel_setup(H.load_modelset('r95'), 'A')
+    dev = Device(0)
+    dev.set_reference(ref.device_arrays())
+    dev.set_read_quality(qual)
+    dev.set_mlp(weights, soc)
+    dev.upload_table(table)
+    whole = dev.extract(6, 0, 0.0)
+    parts, ro, so, nr, tr = [], [], [], [], []
+    for lo, hi in shard.shard_bounds(table, 4):
+        sub = table.slice_segments(lo, hi)
+        trow, tail = shard.tail_close(table, qual, 0.0, hi)
+        dev.upload_table(sub)
+        parts.append(dev.extract(6, 0, 0.0, tail_contig=tail))
+        ro.append(int(table.seg_row_begin[lo])); so.append(lo); nr.append(sub.n_rows); tr.append(trow)
+    rec = shard.concat_records(parts, 6, ro, so, nr, tr)
+    H.assert_records_equal(rec, whole, 6, prob_tol=0.0)
+    dev.close()
