@@ -72,7 +72,7 @@ def main():
 
     def step():
         dev.run(6, 0, 0.0, tail_contig=-1, score=True)
-        return dev.fetch()
+        return dev.fetch(copy=False)      # records land in pinned host memory inside the step
 
     def barrier():
         if dist is not None:

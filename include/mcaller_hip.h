@@ -127,10 +127,14 @@ typedef struct mc_params {
 /* The hot path on the GPU: strand resolve + window scan + classifier.  Leaves the flush records on the
  * device, in file order; *n_records = how many. */
 int mc_extract_features(mc_ctx *ctx, const mc_params *prm, int64_t *n_records);
-/* D2H of the records of the last mc_extract_features (host buffers, capacity >= n_records). */
+/* The records of the last mc_extract_features, copied into caller buffers (capacity >= n_records) ... */
 int mc_fetch_records(mc_ctx *ctx, const mc_calls_view *host_out);
+/* ... or as a view of the context's own pinned host buffers (no copy; valid until the next call on this ctx;
+ * capacity is set to the record count).  mc_extract_features already moved them there, overlapped with the classifier. */
+int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
 /* Kernel times of the last mc_extract_features, from hipEvents on the ctx stream, in ms:
- * [0] strand resolve, [1] window scan (K1), [2] record ordering, [3] classifier (K2), [4] total. */
+ * [0] strand resolve (K0), [1] window scan (k1_scan), [2] window emit (k1_group_scan + k1_list + k1_emit),
+ * [3] classifier (K2), [4] total. */
 int mc_last_times_ms(mc_ctx *ctx, float *out5);
 int mc_ctx_sync(mc_ctx *ctx);
 

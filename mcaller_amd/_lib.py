@@ -82,6 +82,7 @@ def lib():
                                      C.c_void_p, C.c_void_p, C.c_void_p]
         L.mc_extract_features.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.mc_fetch_records.argtypes = [C.c_void_p, C.POINTER(CallsView)]
+        L.mc_fetch_records_view.argtypes = [C.c_void_p, C.POINTER(CallsView)]
         L.mc_last_times_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_ctx_sync.argtypes = [C.c_void_p]
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -201,3 +202,16 @@ class Records(object):
         v.feats, v.site_pos, v.site_seg = _ptr(self.feats), _ptr(self.site_pos), _ptr(self.site_seg)
         v.close_row, v.info, v.prob = _ptr(self.close_row), _ptr(self.info), _ptr(self.prob)
         return v
+
+    @classmethod
+    def from_view(cls, v, n, k, owner):
+        """Zero-copy wrap of library-owned buffers (valid until the next call on the owning context)."""
+        r = cls.__new__(cls)
+        r.k, r.capacity, r.n, r._owner = k, n, n, owner
+        r.feats = _from_ptr(v.feats, n * k, np.float64)
+        r.site_pos = _from_ptr(v.site_pos, n, np.int32)
+        r.site_seg = _from_ptr(v.site_seg, n, np.int32)
+        r.close_row = _from_ptr(v.close_row, n, np.int64)
+        r.info = _from_ptr(v.info, n, np.uint32)
+        r.prob = _from_ptr(v.prob, n, np.float64)
+        return r

@@ -141,6 +141,7 @@ struct Counters {          // device-side status block
     unsigned int n_irregular;
     unsigned int n_big;
     unsigned int pad[3];
+    unsigned long long next_chunk; // k1_scan's tile-chunk ticket counter
     unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
 };
 
@@ -615,11 +616,30 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int k = A.k;
-    const int64_t G = gridDim.x;
     constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
-    int64_t tile = blockIdx.x;
-    if (tile >= T.n_tiles) return;
+    // Tiles are handed out in chunks of CHUNK consecutive tiles from a ticket counter, so the grid need not match the
+    // residency the hardware grants (a static grid-stride split runs a second, unbalanced round when it does not).
+    // The ticket for the chunk after the current one is drawn when a chunk starts and first used CHUNK-2 tiles later.
+    constexpr int CHUNK = 4;
+    const int64_t n_chunks = (T.n_tiles + CHUNK - 1) / CHUNK;
+    auto draw = [&]() -> unsigned long long {       // tickets start after the chunks the grid takes by block index
+        unsigned long long t = 0;
+        if (lane == 0) t = gridDim.x + atomicAdd(&A.cnt->next_chunk, 1ull);
+        return t;
+    };
+    int64_t chunk = blockIdx.x;                     // the first chunk needs no ticket (no start-up storm on the counter)
+    if (chunk >= n_chunks) return;
+    unsigned long long pending = draw();            // ticket of the next chunk, in lane 0 until needed
+    int64_t chunk_next = -1;                        // ... resolved lazily
+    int pin = 0;                                    // position inside the current chunk
+    // tile j steps after the current one (j <= 2): stays in the chunk or continues in the next chunk
+    auto tile_ahead = [&](int j) -> int64_t {
+        if (pin + j < CHUNK) return chunk * CHUNK + pin + j;
+        if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
+        return chunk_next >= n_chunks ? T.n_tiles : chunk_next * CHUNK + (pin + j - CHUNK);
+    };
+    int64_t tile = chunk * CHUNK;
 #ifdef MC_PROFILE
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
@@ -628,11 +648,11 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     {
         const TileDesc td0 = A.tiles[tile];
         if (tid == 0) s_td[0] = td0;
-        tile_issue_loads(A, td0, tile, tile + G, tid, R);
+        tile_issue_loads(A, td0, tile, tile_ahead(1), tid, R);
     }
     int cur = 0;
 
-    for (; tile < T.n_tiles; tile += G, cur ^= 1) {
+    for (; tile < T.n_tiles; cur ^= 1) {
         const int64_t t0 = tile * TILE;
         const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
 
@@ -652,8 +672,8 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         const TileDesc td = s_td[cur];
         const int nb0 = td.nb0;
         // ... and the next tile's loads go out now; they land while this tile is processed
-        const int64_t tile_n = tile + G;
-        if (tile_n < T.n_tiles) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_n + G, tid, R);
+        const int64_t tile_n = tile_ahead(1);
+        if (tile_n < T.n_tiles) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);
         PH(1);
 
         if (wave == 0 && A.debug != 3) {
@@ -740,9 +760,6 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                     for (int wb = mlo >> 5; wb <= (mhi >> 5); wb += 64) {
                         // ---- pass A: lane owns mask word wb + lane; which of its sites closes a window here? ----
                         const int w = wb + lane;
-#ifdef MC_PROFILE
-                        if (lane == 0) ph[4] += 1;
-#endif
                         uint32_t word = 0;
                         if (w <= (mhi >> 5)) {
                             word = mword(w);
@@ -754,20 +771,32 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                         for (uint32_t rest = word; rest; rest &= rest - 1) {
                             const int b = __builtin_ctz(rest);
                             const int m = w * 32 + b;
-#ifdef MC_PROFILE
-                            atomicAdd(&A.cnt->prof[5], 1ull);
-#endif
                             // nearest 'M' to the left within k-1 positions: rows at or before it belong to its group
                             int plo = m - k + 1;
                             if (k > 1) {
                                 const uint32_t left = (uint32_t)(raw >> (32 + b - (k - 1))) & ((1u << (k - 1)) - 1u);
                                 if (left) plo = m - (k - 1) + (31 - __builtin_clz(left)) + 1;
                             }
-                            // first row of the range with pos > m
+                            // first row of the range with pos > m: 8-ary search, the 7 probes of a level are independent
+                            // LDS reads (4 round trips for 2048 rows instead of 11 dependent ones)
                             int a = lo, z = hi;
-                            while (a < z) {
-                                const int mid = (a + z) >> 1;
-                                if (s_pos[mid] <= m) a = mid + 1; else z = mid;
+                            while (z - a > 8) {
+                                const int step = (z - a + 7) >> 3;
+                                int c = 0;
+#pragma unroll
+                                for (int t = 1; t < 8; ++t) {
+                                    const int ix = a + t * step;
+                                    c += (ix < z && s_pos[ix < z ? ix : a] <= m) ? 1 : 0;
+                                }
+                                const int nxt = a + (c + 1) * step;
+                                if (c > 0) a = a + c * step + 1;
+                                if (nxt < z) z = nxt;
+                            }
+                            {
+                                int c = 0;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) c += (a + t < z && s_pos[a + t < z ? a + t : a] <= m) ? 1 : 0;
+                                a += c;
                             }
                             const int ub = a;
                             int rv = ub - 1;
@@ -778,9 +807,6 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                             while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
                             bool closed = c < hi;                              // a row with pos > m follows in the tile
                             if (!closed) {                                    // rare: look past the tile / the block
-#ifdef MC_PROFILE
-                                atomicAdd(&A.cnt->prof[6], 1ull);
-#endif
                                 int cp;
                                 bool cns;
                                 const int64_t cr = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, t0 + rv, cp, cns);
@@ -823,10 +849,30 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                             // rows r, r-1, ... r-31 -> slot codes
                             uint32_t c0 = ~0u, c1 = ~0u, c2 = ~0u, c3 = ~0u;
                             bool stopped = false;
-                            for (int j = 0; j < 32; ++j) {
-#ifdef MC_PROFILE
-                                atomicAdd(&A.cnt->prof[7], 1ull);
-#endif
+                            int j0 = 0;
+                            if (rv - 15 >= lo) {
+                                // the common case: the 16 rows ending at r are in LDS and in the block: read them with
+                                // independent loads (one round trip), then decide from registers
+                                int pj[16];
+                                uint32_t nmask = 0;
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) {
+                                    pj[j] = s_pos[rv - j];
+                                    nmask |= (uint32_t)((s_fl[rv - j] >> 1) & 1u) << j;      // MC_F_MODEL_N is bit 1
+                                }
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) {
+                                    if (stopped || ((nmask >> j) & 1u)) continue;
+                                    if (pj[j] < m - k + 1) { stopped = true; continue; }
+                                    const uint32_t code = (uint32_t)(m - pj[j]), bit = 1u << j;
+                                    if (!(code & 1u)) c0 &= ~bit;
+                                    if (!(code & 2u)) c1 &= ~bit;
+                                    if (!(code & 4u)) c2 &= ~bit;
+                                    c3 &= ~bit;
+                                }
+                                j0 = 16;
+                            }
+                            for (int j = j0; j < 32 && !stopped; ++j) {
                                 const int64_t rr = r - j;
                                 if (rr < lb_abs) { stopped = true; break; }
                                 int pj;
@@ -864,6 +910,15 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         PH(2);
         __syncthreads();          // LDS is rewritten for the next tile
         PH(3);
+        // advance to the next tile of the ticket stream
+        tile = tile_n;
+        if (++pin == CHUNK) {
+            if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
+            chunk = chunk_next;
+            chunk_next = -1;
+            pin = 0;
+            if (chunk < n_chunks) pending = draw();
+        }
     }
 #ifdef MC_PROFILE
     if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&A.cnt->prof[i], (unsigned long long)ph[i]);
@@ -1626,6 +1681,9 @@ struct mc_ctx {
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
     DevRecords O;            // records of the last call (view: the fast path's buffers, or the merged ones)
     DevRecords Omain;        // the fast path's buffers
+    DevRecords H;            // pinned host copy of the last call's records (mc_fetch_records_view)
+    int h_k = 0;
+    hipStream_t copy_stream = nullptr;
     std::vector<void *> lit_allocs;
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
@@ -1635,6 +1693,7 @@ struct mc_ctx {
     Payload *payload = nullptr;
     long long payload_cap = 0;
     int n_cu = 256;
+    int scan_wgs = MC_SCAN_WGS;    // resident k1_scan workgroups per CU (occupancy query; MCALLER_SCAN_WGS overrides)
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
@@ -1660,6 +1719,41 @@ static void free_pool(std::vector<void *> &pool) {
     pool.clear();
 }
 
+static void free_pinned(DevRecords &H) {
+    if (H.feats) (void)hipHostFree(H.feats);
+    if (H.site_pos) (void)hipHostFree(H.site_pos);
+    if (H.site_seg) (void)hipHostFree(H.site_seg);
+    if (H.close_row) (void)hipHostFree(H.close_row);
+    if (H.info) (void)hipHostFree(H.info);
+    if (H.prob) (void)hipHostFree(H.prob);
+    H = DevRecords();
+}
+
+static int ensure_pinned(mc_ctx *c, int64_t n, int k) {
+    if (c->H.capacity >= n && c->h_k == k) return 0;
+    free_pinned(c->H);
+    const int64_t cap = std::max<int64_t>(n + n / 4, 1 << 16);
+    HIP_TRY(hipHostMalloc((void **)&c->H.feats, (size_t)cap * k * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->H.site_pos, (size_t)cap * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->H.site_seg, (size_t)cap * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->H.close_row, (size_t)cap * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->H.info, (size_t)cap * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->H.prob, (size_t)cap * 8, hipHostMallocDefault));
+    c->H.capacity = cap;
+    c->h_k = k;
+    return 0;
+}
+
+// D2H of everything but the probabilities (they follow when the classifier is done)
+static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
+    HIP_TRY(hipMemcpyAsync(c->H.feats, c->O.feats, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->H.site_pos, c->O.site_pos, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->H.site_seg, c->O.site_seg, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->H.close_row, c->O.close_row, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->H.info, c->O.info, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
 extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     *out = nullptr;
     int n = 0;
@@ -1677,9 +1771,14 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     mc_ctx *c = new mc_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+        int occ = 0;       // resident k1_scan workgroups per CU: the grid is sized to it (tickets balance the rest)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1_scan, NTHREADS, 0) == hipSuccess && occ > 0) c->scan_wgs = occ;
+        if (const char *e = getenv("MCALLER_SCAN_WGS")) { if (atoi(e) > 0) c->scan_wgs = atoi(e); }
+        if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: %d CUs, k1_scan occupancy %d workgroups/CU\n", c->n_cu, c->scan_wgs);
     }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipMalloc((void **)&c->cnt, sizeof(Counters)));
@@ -1700,6 +1799,8 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->qual) (void)hipFree(c->qual);
     if (c->cnt) (void)hipFree(c->cnt);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
+    free_pinned(c->H);
+    (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1974,7 +2075,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
         A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
         { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-        hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>(T.n_tiles, (int64_t)c->n_cu * MC_SCAN_WGS)), dim3(NTHREADS), 0,
+        hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
                            c->stream, A);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
@@ -2001,13 +2102,22 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         if (h.n_irregular) {
             if (int rc = run_literal_path(c, prm, &n)) return rc;
         }
+        // records -> pinned host memory; the slot means and indices travel while the classifier runs
+        if (int rc = ensure_pinned(c, n, k)) return rc;
+        const bool early = n > 0 && !h.n_big && !h.n_irregular;
+        if (early) { if (int rc = copy_out_features(c, n, k, c->copy_stream)) return rc; }
         if (prm->score && n > 0) {
             hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
                                c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
                                c->O.prob);
         }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        if (n > 0) {
+            if (!early) { if (int rc = copy_out_features(c, n, k, c->stream)) return rc; }
+            HIP_TRY(hipMemcpyAsync(c->H.prob, c->O.prob, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
         HIP_TRY(hipGetLastError());
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
         HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
@@ -2028,13 +2138,23 @@ extern "C" int mc_fetch_records(mc_ctx *c, const mc_calls_view *out) {
         return -12;
     }
     if (n == 0) return 0;
-    HIP_TRY(hipMemcpyAsync(out->feats, c->O.feats, (size_t)n * k * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->site_pos, c->O.site_pos, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->site_seg, c->O.site_seg, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->close_row, c->O.close_row, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->info, c->O.info, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->prob, c->O.prob, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out->feats, c->H.feats, (size_t)n * k * 8);
+    memcpy(out->site_pos, c->H.site_pos, (size_t)n * 4);
+    memcpy(out->site_seg, c->H.site_seg, (size_t)n * 4);
+    memcpy(out->close_row, c->H.close_row, (size_t)n * 8);
+    memcpy(out->info, c->H.info, (size_t)n * 4);
+    memcpy(out->prob, c->H.prob, (size_t)n * 8);
+    return 0;
+}
+
+extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
+    out->capacity = c->last_n;
+    out->feats = c->H.feats;
+    out->site_pos = c->H.site_pos;
+    out->site_seg = c->H.site_seg;
+    out->close_row = c->H.close_row;
+    out->info = c->H.info;
+    out->prob = c->H.prob;
     return 0;
 }
 

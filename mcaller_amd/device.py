@@ -72,8 +72,13 @@ class Device(object):
         self._last = (n.value, int(k))
         return n.value
 
-    def fetch(self):
+    def fetch(self, copy=True):
+        """Records of the last run.  copy=False: views of the context's pinned buffers (overwritten by the next run)."""
         n, k = self._last
+        if not copy:
+            v = _lib.CallsView()
+            check(lib().mc_fetch_records_view(self._ctx, C.byref(v)))
+            return Records.from_view(v, n, k, self)
         rec = Records(n, k)
         v = rec.view()
         check(lib().mc_fetch_records(self._ctx, C.byref(v)))
