@@ -113,6 +113,14 @@ int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden
                    const double *W1, const double *b1, const double *W2, const double *b2,
                    const uint8_t *submodel_of_char);
 
+/* Random forest (classifier RF, train_model.py:39-45; same call site :199): trees flattened, node arrays concatenated.
+ * model_tree_off[n_models+1]: first tree of each sub-model; tree_node_off[n_trees+1]: root of each tree; left/right: child
+ * node (absolute index) or -1 at a leaf; value[2*node .. 2*node+1]: the node's two class values.  Inputs are cast to
+ * float32 before the comparisons `x[feature] <= threshold`, as scikit-learn does; p = mean over trees of v1/(v0+v1). */
+int mc_ctx_set_forest(mc_ctx *ctx, int32_t n_models, int32_t n_in, const int32_t *model_tree_off,
+                      const int32_t *tree_node_off, const int32_t *left, const int32_t *right, const int32_t *feature,
+                      const double *threshold, const double *value, const uint8_t *submodel_of_char);
+
 typedef struct mc_params {
     int32_t k;             /* -n   (:110 `k`)            */
     int32_t skip_thresh;   /* -s   (:183,242)            */
@@ -140,6 +148,7 @@ int mc_ctx_sync(mc_ctx *ctx);
 
 /* Batched classifier alone (B2, extract_contexts.py:199): X[n*n_in] -> p[n]; host buffers. */
 int mc_mlp_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
+int mc_forest_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,13 @@ struct DevMlp {
     uint8_t *sub_of_char = nullptr;
 };
 
+struct DevForest {
+    int32_t n_models = 0, n_in = 0;
+    int32_t *model_tree_off = nullptr, *tree_node_off = nullptr, *left = nullptr, *right = nullptr, *feature = nullptr;
+    double *threshold = nullptr, *value = nullptr;
+    uint8_t *sub_of_char = nullptr;
+};
+
 constexpr int NSHARD = 8;  // record-slot counters, one per blockIdx & 7 (= XCD): no single hot atomic
 
 struct Counters {          // device-side status block
@@ -1661,6 +1668,47 @@ __global__ __launch_bounds__(64) void k2_mlp(DevMlp M, const double *__restrict_
     prob[r] = 1.0 / (1.0 + exp(-z));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K3: random-forest predict_proba (classifier RF, train_model.py:39-45; call site :199).  One lane per record: inputs cast
+// to float32 (scikit-learn's DTYPE), each tree walked with `x[feature] <= threshold` to a leaf, p1 = v1/(v0+v1) per tree
+// (predict_proba normalises the leaf values), summed over the trees in order and divided by their number.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__restrict__ feats, int k,
+                                                const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                double *__restrict__ prob) {
+    __shared__ double s_x[64][MC_MAX_K + 2];
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double *x = s_x[threadIdx.x];
+    const int NI = F.n_in;
+    int mi;
+    if (submodel_in) {
+        mi = submodel_in[r];
+        for (int i = 0; i < NI; ++i) x[i] = (double)(float)feats[r * NI + i];
+    } else {
+        const uint32_t inf = info[r];
+        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
+        mi = F.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+        for (int i = 0; i < k; ++i) x[i] = (double)(float)feats[r * k + i];
+        x[k] = (double)(float)qual[seg_read[site_seg[r]]];
+    }
+    if (mi >= F.n_models) return;
+    const int t0 = F.model_tree_off[mi], t1 = F.model_tree_off[mi + 1];
+    double sum = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        int node = F.tree_node_off[t];
+        int l;
+        while ((l = F.left[node]) >= 0) node = (x[F.feature[node]] <= F.threshold[node]) ? l : F.right[node];
+        const double v0 = F.value[2 * (size_t)node], v1 = F.value[2 * (size_t)node + 1];
+        double norm = (-0.0 + v0) + v1;
+        if (norm == 0.0) norm = 1.0;
+        sum += v1 / norm;
+    }
+    prob[r] = sum / (double)(t1 - t0);
+}
+
 }  // namespace
 
 // ===================================================================================================
@@ -1673,6 +1721,8 @@ struct mc_ctx {
     DevTable T;
     DevRef R;
     DevMlp M;
+    DevForest F;
+    std::vector<void *> forest_allocs;
     double *qual = nullptr;
     int32_t n_qual = 0;
     NbDesc *desc = nullptr;
@@ -1794,6 +1844,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     free_pool(c->table_allocs);
     free_pool(c->ref_allocs);
     free_pool(c->mlp_allocs);
+    free_pool(c->forest_allocs);
     free_pool(c->rec_allocs);
     free_pool(c->lit_allocs);
     if (c->qual) (void)hipFree(c->qual);
@@ -1936,6 +1987,8 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
         return -12;
     }
     free_pool(c->mlp_allocs);
+    free_pool(c->forest_allocs);
+    c->F = DevForest();
     DevMlp &M = c->M;
     M.n_models = n_models;
     M.n_in = n_in;
@@ -1945,6 +1998,41 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
     UP(M.W2, W2, (size_t)n_models * n_hidden, c->mlp_allocs);
     UP(M.b2, b2, (size_t)n_models, c->mlp_allocs);
     UP(M.sub_of_char, sub_of_char, 256, c->mlp_allocs);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, const int32_t *model_tree_off,
+                                 const int32_t *tree_node_off, const int32_t *left, const int32_t *right,
+                                 const int32_t *feature, const double *threshold, const double *value,
+                                 const uint8_t *sub_of_char) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_models < 1 || n_in < 1 || n_in > MC_MAX_K + 1) {
+        mc_set_error("unsupported forest shape: %d models, %d inputs", n_models, n_in);
+        return -12;
+    }
+    const int n_trees = model_tree_off[n_models];
+    const int n_nodes = tree_node_off[n_trees];
+    for (int i = 0; i < n_nodes; ++i)
+        if (left[i] >= 0 && (feature[i] < 0 || feature[i] >= n_in || left[i] >= n_nodes || right[i] < 0 || right[i] >= n_nodes)) {
+            mc_set_error("forest node %d is malformed", i);
+            return -12;
+        }
+    free_pool(c->forest_allocs);
+    free_pool(c->mlp_allocs);
+    c->M = DevMlp();
+    DevForest &F = c->F;
+    F.n_models = n_models;
+    F.n_in = n_in;
+    UP(F.model_tree_off, model_tree_off, (size_t)n_models + 1, c->forest_allocs);
+    UP(F.tree_node_off, tree_node_off, (size_t)n_trees + 1, c->forest_allocs);
+    UP(F.left, left, (size_t)n_nodes, c->forest_allocs);
+    UP(F.right, right, (size_t)n_nodes, c->forest_allocs);
+    UP(F.feature, feature, (size_t)n_nodes, c->forest_allocs);
+    UP(F.threshold, threshold, (size_t)n_nodes, c->forest_allocs);
+    UP(F.value, value, (size_t)n_nodes * 2, c->forest_allocs);
+    UP(F.sub_of_char, sub_of_char, 256, c->forest_allocs);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -2044,8 +2132,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         mc_set_error("read quality table has %d entries, table names %d reads", c->n_qual, T.n_reads);
         return -12;
     }
-    if (prm->score && (!c->M.W1 || c->M.n_in != k + 1)) {
-        mc_set_error("classifier expects %d inputs but num_variables+1 = %d", c->M.W1 ? c->M.n_in : 0, k + 1);
+    const int clf_in = c->F.left ? c->F.n_in : (c->M.W1 ? c->M.n_in : 0);
+    if (prm->score && clf_in != k + 1) {
+        mc_set_error("classifier expects %d inputs but num_variables+1 = %d", clf_in, k + 1);
         return -12;
     }
     c->last_n = 0;
@@ -2107,9 +2196,13 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         const bool early = n > 0 && !h.n_big && !h.n_irregular;
         if (early) { if (int rc = copy_out_features(c, n, k, c->copy_stream)) return rc; }
         if (prm->score && n > 0) {
-            hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
-                               c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
-                               c->O.prob);
+            if (c->F.left)
+                hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, c->O.feats, k,
+                                   c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob);
+            else
+                hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
+                                   c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
+                                   c->O.prob);
         }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         if (n > 0) {
@@ -2163,25 +2256,30 @@ extern "C" int mc_last_times_ms(mc_ctx *c, float *out5) {
     return 0;
 }
 
-extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uint8_t *submodel, int64_t n, double *p) {
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->M.W1) {
-        mc_set_error("mc_mlp_forward: no classifier set");
+    if (forest ? !c->F.left : !c->M.W1) {
+        mc_set_error("classifier forward: no %s set", forest ? "forest" : "MLP");
         return -12;
     }
     if (n <= 0) return 0;
     double *dX = nullptr, *dp = nullptr;
     uint8_t *ds = nullptr;
-    const int ni = c->M.n_in;
+    const int ni = forest ? c->F.n_in : c->M.n_in;
     HIP_TRY(hipMalloc((void **)&dX, (size_t)n * ni * 8));
     HIP_TRY(hipMalloc((void **)&dp, (size_t)n * 8));
     HIP_TRY(hipMalloc((void **)&ds, (size_t)n));
     HIP_TRY(hipMemcpyAsync(dX, X, (size_t)n * ni * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(ds, submodel, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dp, 0xFF, (size_t)n * 8, c->stream));   // NaN
-    hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                       (const uint32_t *)nullptr, ds, n, dp);
+    if (forest)
+        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, dX, ni - 1,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                           (const uint32_t *)nullptr, ds, n, dp);
+    else
+        hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                           (const uint32_t *)nullptr, ds, n, dp);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
@@ -2189,4 +2287,12 @@ extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submode
     (void)hipFree(dp);
     (void)hipFree(ds);
     return 0;
+}
+
+extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+    return classifier_forward(c, false, X, submodel, n, p);
+}
+
+extern "C" int mc_forest_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+    return classifier_forward(c, true, X, submodel, n, p);
 }

@@ -62,6 +62,31 @@ class Device(object):
         check(lib().mc_ctx_set_mlp(self._ctx, len(weights), n_in, n_hidden, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
                                    _ptr(soc)))
 
+    def set_forest(self, forests, submodel_of_char):
+        """forests: list of ForestWeights (one per sub-model)."""
+        arr = forest_arrays(forests)
+        soc = np.ascontiguousarray(submodel_of_char, dtype=np.uint8)
+        check(lib().mc_ctx_set_forest(self._ctx, len(forests), forests[0].n_in, _ptr(arr['model_tree_off']),
+                                      _ptr(arr['tree_node_off']), _ptr(arr['left']), _ptr(arr['right']),
+                                      _ptr(arr['feature']), _ptr(arr['threshold']), _ptr(arr['value']), _ptr(soc)))
+        self._clf = 'forest'
+
+    def set_classifier(self, weights, submodel_of_char):
+        """MLP or forest, whatever the model file held (extract_contexts.py:199 calls either the same way)."""
+        if weights[0].kind == 'forest':
+            self.set_forest(weights, submodel_of_char)
+        else:
+            self.set_mlp(weights, submodel_of_char)
+            self._clf = 'mlp'
+
+    def classifier_forward(self, X, submodel):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        sm = np.ascontiguousarray(submodel, dtype=np.uint8)
+        p = np.empty(len(X), dtype=np.float64)
+        fn = lib().mc_forest_forward if getattr(self, '_clf', 'mlp') == 'forest' else lib().mc_mlp_forward
+        check(fn(self._ctx, _ptr(X), _ptr(sm), len(X), _ptr(p)))
+        return p
+
     # ---- the hot path ----
     def run(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
         """K0+K1+K2 on the resident table; records stay on the device.  Returns their number."""
@@ -96,11 +121,32 @@ class Device(object):
                     total=float(t[4]))
 
     def mlp_forward(self, X, submodel):
+        if getattr(self, '_clf', 'mlp') == 'forest':
+            return self.classifier_forward(X, submodel)
         X = np.ascontiguousarray(X, dtype=np.float64)
         sm = np.ascontiguousarray(submodel, dtype=np.uint8)
         p = np.empty(len(X), dtype=np.float64)
         check(lib().mc_mlp_forward(self._ctx, _ptr(X), _ptr(sm), len(X), _ptr(p)))
         return p
+
+
+def forest_arrays(forests):
+    """Concatenate the sub-models' trees into the flat arrays of mc_ctx_set_forest."""
+    model_tree_off, tree_node_off = [0], [0]
+    left, right, feature, threshold, value = [], [], [], [], []
+    for f in forests:
+        base = tree_node_off[-1]
+        left.append(np.where(f.left >= 0, f.left + base, -1))
+        right.append(np.where(f.right >= 0, f.right + base, -1))
+        feature.append(f.feature)
+        threshold.append(f.threshold)
+        value.append(f.value)
+        tree_node_off.extend((f.tree_off[1:] + base).tolist())
+        model_tree_off.append(model_tree_off[-1] + f.n_trees)
+    cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs), dtype=dt)
+    return dict(model_tree_off=np.asarray(model_tree_off, dtype=np.int32), tree_node_off=np.asarray(tree_node_off, dtype=np.int32),
+                left=cat(left, np.int32), right=cat(right, np.int32), feature=cat(feature, np.int32),
+                threshold=cat(threshold, np.float64), value=cat([v.reshape(-1) for v in value], np.float64))
 
 
 _devices = {}

@@ -110,7 +110,7 @@ def compute(P, k, skip_thresh, qual_thresh, modelset, base, train, device=None, 
     dev.set_read_quality(P.qual)
     if not train:
         _, weights, _, soc = submodel_setup(modelset, base)
-        dev.set_mlp(weights, soc)
+        dev.set_classifier(weights, soc)
     rec = dev.extract(k, skip_thresh, qual_thresh, tail_contig=tail_contig, score=not train)
     return rec
 

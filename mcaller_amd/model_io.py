@@ -39,6 +39,7 @@ _ALLOWED = {
     ('copy_reg', '_reconstructor'), ('copyreg', '_reconstructor'),
     ('__builtin__', 'object'), ('builtins', 'object'),
     ('collections', 'OrderedDict'), ('collections', 'defaultdict'),
+    ('_codecs', 'encode'),
 }
 
 
@@ -70,15 +71,51 @@ class MLPWeights(object):
         self.n_in, self.n_hidden = self.W1.shape
 
 
+class ForestWeights(object):
+    """scikit-learn RandomForestClassifier (binary): flattened trees.  Node arrays are concatenated over trees; leaves have
+    left == -1; `value` holds the two class values of every node as the tree stores them (predict_proba normalises)."""
+    kind = 'forest'
+
+    def __init__(self, trees, n_features, classes=None):
+        off, left, right, feat, thr, val = [0], [], [], [], [], []
+        for nodes, values in trees:
+            base = off[-1]
+            n = len(nodes)
+            l = nodes['left_child'].astype(np.int64)
+            r = nodes['right_child'].astype(np.int64)
+            left.append(np.where(l >= 0, l + base, -1))
+            right.append(np.where(r >= 0, r + base, -1))
+            feat.append(nodes['feature'].astype(np.int64))
+            thr.append(nodes['threshold'].astype(np.float64))
+            v = np.asarray(values, dtype=np.float64).reshape(n, -1)
+            if v.shape[1] != 2:
+                raise NotImplementedError('forests with %d classes' % v.shape[1])
+            val.append(v)
+            off.append(base + n)
+        self.tree_off = np.asarray(off, dtype=np.int32)
+        self.left = np.concatenate(left).astype(np.int32)
+        self.right = np.concatenate(right).astype(np.int32)
+        self.feature = np.concatenate(feat).astype(np.int32)
+        self.threshold = np.ascontiguousarray(np.concatenate(thr), dtype=np.float64)
+        self.value = np.ascontiguousarray(np.concatenate(val), dtype=np.float64)
+        self.n_in = int(n_features)
+        self.n_trees = len(trees)
+        self.classes = classes
+
+
 def _as_text(x):
     return x.decode('latin1') if isinstance(x, bytes) else str(x)
 
 
 def _estimator_weights(est, where):
     cls = type(est).__name__
+    if cls == 'RandomForestClassifier':
+        trees = [(t.tree_.nodes, t.tree_.values) for t in est.estimators_]
+        n_feat = int(getattr(est, 'n_features_in_', getattr(est, 'n_features_', 0)) or 0)
+        return ForestWeights(trees, n_feat, [_as_text(c) for c in getattr(est, 'classes_', [])])
     if cls != 'MLPClassifier':
-        raise NotImplementedError('%s: classifier %s is not supported by the HIP path yet '
-                                  '(MLPClassifier only)' % (where, cls))
+        raise NotImplementedError('%s: classifier %s is not supported by the HIP path '
+                                  '(MLPClassifier and RandomForestClassifier are)' % (where, cls))
     coefs, inter = est.coefs_, est.intercepts_
     act = _as_text(getattr(est, 'activation', 'tanh'))
     out_act = _as_text(getattr(est, 'out_activation_', 'logistic'))

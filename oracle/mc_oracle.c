@@ -242,3 +242,30 @@ int mco_mlp_forward(int32_t n_models, int32_t n_in, int32_t n_hidden, const doub
     }
     return 0;
 }
+
+/* Random-forest predict_proba (scikit-learn RandomForestClassifier, binary; call site extract_contexts.py:199 with
+ * classifier RF): float32 inputs, x[feature] <= threshold, mean over trees of v1/(v0+v1). */
+int mco_forest_forward(int32_t n_models, int32_t n_in, const int32_t *model_tree_off, const int32_t *tree_node_off,
+                       const int32_t *left, const int32_t *right, const int32_t *feature, const double *threshold,
+                       const double *value, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+    for (int64_t r = 0; r < n; ++r) {
+        int mi = submodel[r];
+        if (mi >= n_models) {
+            p[r] = NAN;
+            continue;
+        }
+        double x[MC_MAX_K + 2];
+        for (int i = 0; i < n_in; ++i) x[i] = (double)(float)X[r * n_in + i];
+        double sum = 0.0;
+        for (int t = model_tree_off[mi]; t < model_tree_off[mi + 1]; ++t) {
+            int node = tree_node_off[t];
+            while (left[node] >= 0) node = (x[feature[node]] <= threshold[node]) ? left[node] : right[node];
+            double v0 = value[2 * (size_t)node], v1 = value[2 * (size_t)node + 1];
+            double norm = (-0.0 + v0) + v1;
+            if (norm == 0.0) norm = 1.0;
+            sum += v1 / norm;
+        }
+        p[r] = sum / (double)(model_tree_off[mi + 1] - model_tree_off[mi]);
+    }
+    return 0;
+}

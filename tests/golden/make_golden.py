@@ -173,6 +173,35 @@ def export_models(outdir):
     return meta
 
 
+def export_rf_fixture(outdir):
+    """BASELINE config 5's alternative classifier: a scikit-learn RandomForestClassifier with the reference's
+    hyper-parameters (train_model.py:40-45; `min_impurity_split` dropped, scikit-learn >= 1.0 rejects it) and a fixed
+    random_state, fitted HERE on seeded synthetic vectors labelled by the shipped r95 MLP.  The pickle (data, written by
+    this script) and predict_proba on probe vectors are the fixture for the forest kernel."""
+    import pickle
+    import numpy as np
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(11)
+    ref = pickle.loads(open(os.path.join(REF, 'r95_twobase_model_NN_6_m6A.pkl'), 'rb').read(), encoding='latin')
+    models, ka = {}, {}
+    probes = np.concatenate([rng.normal(0, 2.5, size=(256, 6)), rng.uniform(6, 12, size=(256, 1))], axis=1)
+    probes = np.round(probes, 4)
+    for key in ('MG', 'MH'):
+        X = np.concatenate([rng.normal(0, 2.5, size=(300, 6)), rng.uniform(6, 12, size=(300, 1))], axis=1)
+        y = np.where(ref[key].predict_proba(X)[:, 1] + rng.normal(0, 0.15, size=300) >= 0.5, 'm6A', 'A')
+        rf = RandomForestClassifier(bootstrap=True, criterion='entropy', max_depth=10, max_features=4,
+                                    min_samples_leaf=2, min_samples_split=3, n_estimators=50, random_state=3)
+        rf.fit(X, y)
+        models[key] = rf
+        ka[key] = [float(v) for v in rf.predict_proba(probes)[:, 1]]
+    with open(os.path.join(outdir, 'rf_twobase_model_RF_6_m6A.pkl'), 'wb') as fh:
+        pickle.dump(models, fh, protocol=4)
+    import sklearn
+    json.dump(dict(sklearn=sklearn.__version__, probes=[[float(v) for v in r] for r in probes], known_answers=ka,
+                   classes=[str(c) for c in models['MG'].classes_]),
+              open(os.path.join(outdir, 'rf_meta.json'), 'w'))
+
+
 def load_weights(models_dir, stem):
     import numpy as np
     z = np.load(os.path.join(models_dir, stem + '.npz'))
@@ -294,7 +323,7 @@ def _plain(sig):
 
 
 def main():
-    n_micro = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    n_micro = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000
     scratch = tempfile.mkdtemp(prefix='mcaller_golden_')
     install_shims(scratch)
     import extract_contexts as ec
@@ -303,7 +332,11 @@ def main():
     from oracle import casegen
 
     models_dir = os.path.join(HERE, 'models')
+    if '--rf-only' in sys.argv:
+        export_rf_fixture(models_dir)
+        return
     meta = export_models(models_dir)
+    export_rf_fixture(models_dir)
     report = {'models': {k: v['sha256'] for k, v in meta.items()}}
 
     # ------------------------------------------------------------------ testdata ------------

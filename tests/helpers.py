@@ -29,6 +29,7 @@ def oracle_lib():
                                            C.POINTER(_lib.Params), C.POINTER(_lib.CallsView), C.POINTER(C.c_int64)]
         L.mco_mlp_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mco_forest_forward.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 9 + [C.c_int64, C.c_void_p]
         _oracle = L
     return _oracle
 
@@ -63,8 +64,26 @@ def oracle_records(table, ref_arrays, qual, k, skip_thresh, qual_thresh, tail_co
     return rec
 
 
+def oracle_forest_forward(forests, X, submodel):
+    from mcaller_amd.device import forest_arrays
+    L = oracle_lib()
+    a = forest_arrays(forests)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    sm = np.ascontiguousarray(submodel, dtype=np.uint8)
+    p = np.full(len(X), np.nan)
+    P_ = lambda z: z.ctypes.data_as(C.c_void_p)
+    L.mco_forest_forward(len(forests), forests[0].n_in, P_(a['model_tree_off']), P_(a['tree_node_off']), P_(a['left']),
+                         P_(a['right']), P_(a['feature']), P_(a['threshold']), P_(a['value']), P_(X), P_(sm), len(X), P_(p))
+    return p
+
+
+def load_rf_modelset():
+    from mcaller_amd.model_io import load_model_file
+    return load_model_file(os.path.join(GOLDEN, 'models', 'rf_twobase_model_RF_6_m6A.pkl'))
+
+
 def oracle_score(rec, table, qual, weights, soc, k):
-    """Fill rec.prob with the C oracle's MLP for records that are scored on the device too."""
+    """Fill rec.prob with the C oracle's classifier for records that are scored on the device too."""
     from mcaller_amd import _lib
     L = oracle_lib()
     n = rec.n
@@ -77,6 +96,9 @@ def oracle_score(rec, table, qual, weights, soc, k):
     X = np.zeros((n, k + 1), dtype=np.float64)
     X[:, :k] = rec.feats[:n * k].reshape(n, k)
     X[:, k] = np.asarray(qual, dtype=np.float64)[table.seg_read[rec.site_seg[:n]]]
+    if weights[0].kind == 'forest':
+        rec.prob[:n] = oracle_forest_forward(weights, X, sub)
+        return
     W1 = np.ascontiguousarray(np.stack([w.W1 for w in weights]))
     b1 = np.ascontiguousarray(np.stack([w.b1 for w in weights]))
     W2 = np.ascontiguousarray(np.stack([w.W2 for w in weights]))
