@@ -90,7 +90,8 @@ typedef struct mc_parsed mc_parsed;
 /* Parses the byte range the reference's loop would consume for (startline, endline):
  * seek(max(startline-500,0)), readlines(8000000) batches while linepos <= endline-500 (:141-146).
  * Rows with < 12 tokens are dropped (:149-152); rows whose contig is not in contig_names are dropped
- * and recorded (the "could not find sequence" path :156-160).  n_threads <= 0: all cores. */
+ * and recorded (the "could not find sequence" path :156-160).  The range is cut at line starts into one piece per
+ * thread (n_threads > 0: exactly that many pieces; <= 0: one per core, pieces of at least 4 MB) and stitched in file order. */
 int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
                         const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
                         mc_parsed **out);

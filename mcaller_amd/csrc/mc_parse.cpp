@@ -20,8 +20,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -150,10 +152,115 @@ static void consumed_range(const char *base, int64_t fsize, int64_t startline, i
     *hi = linepos;
 }
 
+namespace {
+
+// What one thread makes of its byte range.  Read names stay text here (one entry per change of name); ids are assigned
+// when the chunks are stitched together, in file order, so equal names get equal ids across the whole file.
+struct Chunk {
+    std::vector<int32_t> pos, ev, mu, idx;
+    std::vector<uint8_t> flags;
+    std::vector<int64_t> seg_begin;        // local row index
+    std::vector<int32_t> seg_name;         // index into names
+    std::vector<int32_t> seg_contig;
+    std::vector<std::string> names;        // one per name change inside the chunk
+    std::vector<std::string> unknown;
+    int rc = 0;
+    std::string err;
+    int64_t err_row = 0;
+};
+
+using ContigMap = std::unordered_map<std::string_view, int32_t, SvHash>;
+
+void parse_chunk(const char *base, int64_t lo, int64_t hi, const ContigMap &contig_map, Chunk &C) {
+    size_t guess = (size_t)((hi - lo) / 100 + 16);
+    C.pos.reserve(guess);
+    C.ev.reserve(guess);
+    C.mu.reserve(guess);
+    C.idx.reserve(guess);
+    C.flags.reserve(guess);
+    std::string last_contig_txt;
+    int32_t last_contig = -2;
+    const char *p = base + lo, *end = base + hi;
+    Tok t[12];
+    char msg[256];
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        int nt = split12(p, le, t);
+        p = nl ? nl + 1 : end;
+        if (nt < 12) continue;  // :149-152
+
+        // contig (:154-160)
+        int32_t contig;
+        if (last_contig != -2 && t[0].n == last_contig_txt.size() && memcmp(t[0].p, last_contig_txt.data(), t[0].n) == 0) {
+            contig = last_contig;
+        } else {
+            auto it = contig_map.find(std::string_view(t[0].p, t[0].n));
+            contig = it == contig_map.end() ? -1 : it->second;
+            last_contig_txt.assign(t[0].p, t[0].n);
+            last_contig = contig;
+        }
+        if (contig < 0) {
+            C.unknown.emplace_back(t[0].p, t[0].n);
+            continue;
+        }
+        int64_t pos, idx;
+        if (!parse_int(t[1], &pos) || !parse_int(t[5], &idx)) {
+            snprintf(msg, sizeof(msg), "invalid literal for int(): '%.*s' / '%.*s'", (int)t[1].n, t[1].p, (int)t[5].n, t[5].p);
+            C.rc = -2; C.err = msg; C.err_row = (int64_t)C.pos.size();
+            return;
+        }
+        if (pos < 0 || pos > 0x7fffffff || idx < -0x7fffffff || idx > 0x7fffffff) {
+            C.rc = -2; C.err = "position/event index out of range"; C.err_row = (int64_t)C.pos.size();
+            return;
+        }
+        int64_t e4, m4;
+        if (!(parse_e4_fast(t[6], &e4) && parse_e4_fast(t[10], &m4) && e4 > -1000000000LL && e4 < 1000000000LL &&
+              m4 > -1000000000LL && m4 < 1000000000LL)) {
+            double e, m;
+            if (!parse_double_slow(t[6], &e) || !parse_double_slow(t[10], &m)) {
+                snprintf(msg, sizeof(msg), "could not convert string to float: '%.*s' / '%.*s'", (int)t[6].n, t[6].p,
+                         (int)t[10].n, t[10].p);
+                C.rc = -2; C.err = msg; C.err_row = (int64_t)C.pos.size();
+                return;
+            }
+            double r = std::nearbyint((e - m) * 10000.0);  // np.round(x,4) numerator (:286)
+            if (!(std::fabs(r) < 2000000000.0)) {
+                C.rc = -2; C.err = "current difference not representable"; C.err_row = (int64_t)C.pos.size();
+                return;
+            }
+            e4 = (int64_t)r;
+            m4 = 0;
+        }
+        uint8_t fl = 0;
+        if (t[2].n == t[9].n && memcmp(t[2].p, t[9].p, t[2].n) == 0) fl |= MC_F_KMER_EQ;
+        if (t[9].n == 6 && memcmp(t[9].p, "NNNNNN", 6) == 0) fl |= MC_F_MODEL_N;
+
+        const bool new_name = C.names.empty() || t[3].n != C.names.back().size() ||
+                              memcmp(t[3].p, C.names.back().data(), t[3].n) != 0;
+        if (new_name) {
+            C.names.emplace_back(t[3].p, t[3].n);
+            fl |= MC_F_NAME_START;
+        }
+        if (new_name || C.seg_contig.empty() || C.seg_contig.back() != contig) {
+            fl |= MC_F_SEG_START;
+            C.seg_begin.push_back((int64_t)C.pos.size());
+            C.seg_name.push_back((int32_t)C.names.size() - 1);
+            C.seg_contig.push_back(contig);
+        }
+        C.pos.push_back((int32_t)pos);
+        C.idx.push_back((int32_t)idx);
+        C.ev.push_back((int32_t)e4);
+        C.mu.push_back((int32_t)m4);
+        C.flags.push_back(fl);
+    }
+}
+
+}  // namespace
+
 extern "C" int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
                                    const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
                                    mc_parsed **out) {
-    (void)n_threads;
     *out = nullptr;
     int fd = open(path, O_RDONLY);
     if (fd < 0) {
@@ -175,125 +282,114 @@ extern "C" int mc_parse_eventalign(const char *path, int64_t startline, int64_t 
             close(fd);
             return -1;
         }
-        madvise((void *)base, (size_t)fsize, MADV_SEQUENTIAL);
     }
     close(fd);
 
     int64_t lo = 0, hi = 0;
     if (fsize > 0) consumed_range(base, fsize, startline, endline, &lo, &hi);
 
-    std::unordered_map<std::string_view, int32_t, SvHash> contig_map;
+    ContigMap contig_map;
     std::vector<std::string> contig_store(contig_names, contig_names + n_contigs);
     for (int32_t i = 0; i < n_contigs; ++i)
         contig_map.emplace(std::string_view(contig_store[i]), i);  // first id wins, like the FASTA scan :77-81
 
+    // ---- cut [lo, hi) at line starts, one piece per thread ----
+    // n_threads > 0: that many pieces; <= 0: one per core, but no piece smaller than 4 MB
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    const int64_t min_piece = 4 << 20;
+    if (n_threads <= 0 && (hi - lo) / nt < min_piece) nt = (int)std::max<int64_t>(1, (hi - lo) / min_piece);
+    std::vector<int64_t> cuts;
+    cuts.push_back(lo);
+    for (int i = 1; i < nt; ++i) {
+        int64_t c = lo + (hi - lo) * i / nt;
+        if (c <= cuts.back()) continue;
+        const void *nl = memchr(base + c, '\n', (size_t)(hi - c));
+        if (!nl) break;
+        c = (int64_t)((const char *)nl - base) + 1;
+        if (c > cuts.back() && c < hi) cuts.push_back(c);
+    }
+    cuts.push_back(hi);
+    const int np = (int)cuts.size() - 1;
+    std::vector<Chunk> chunks((size_t)np);
+    if (np == 1) {
+        parse_chunk(base, cuts[0], cuts[1], contig_map, chunks[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < np; ++i)
+            th.emplace_back([&, i] { parse_chunk(base, cuts[(size_t)i], cuts[(size_t)i + 1], contig_map, chunks[(size_t)i]); });
+        for (auto &x : th) x.join();
+    }
+    if (base) munmap((void *)base, (size_t)fsize);
+
+    // ---- stitch ----
+    int64_t total = 0;
+    for (int i = 0; i < np; ++i) {
+        if (chunks[(size_t)i].rc != 0) {     // the first error in file order (earlier pieces are complete)
+            mc_set_error("%s in eventalign row %lld", chunks[(size_t)i].err.c_str(), (long long)(total + chunks[(size_t)i].err_row));
+            return chunks[(size_t)i].rc;
+        }
+        total += (int64_t)chunks[(size_t)i].pos.size();
+    }
     mc_parsed *P = new mc_parsed();
+    P->pos.resize((size_t)total);
+    P->ev.resize((size_t)total);
+    P->mu.resize((size_t)total);
+    P->idx.resize((size_t)total);
+    P->flags.resize((size_t)total);
     std::unordered_map<std::string, int32_t> read_map;
-    size_t guess = (size_t)((hi - lo) / 100 + 16);
-    P->pos.reserve(guess);
-    P->ev.reserve(guess);
-    P->mu.reserve(guess);
-    P->idx.reserve(guess);
-    P->flags.reserve(guess);
-
-    std::string last_name, last_contig_txt;
-    int32_t last_contig = -2, last_read = -1;
+    int64_t off = 0;
+    std::string prev_name;
     bool have_prev = false;
-    int rc = 0;
-
-    const char *p = base + lo, *end = base + hi;
-    Tok t[12];
-    while (p < end) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *le = nl ? nl : end;
-        int nt = split12(p, le, t);
-        p = nl ? nl + 1 : end;
-        if (nt < 12) continue;  // :149-152
-
-        // contig (:154-160)
-        int32_t contig;
-        if (last_contig != -2 && t[0].n == last_contig_txt.size() &&
-            memcmp(t[0].p, last_contig_txt.data(), t[0].n) == 0) {
-            contig = last_contig;
-        } else {
-            auto it = contig_map.find(std::string_view(t[0].p, t[0].n));
-            contig = it == contig_map.end() ? -1 : it->second;
-            last_contig_txt.assign(t[0].p, t[0].n);
-            last_contig = contig;
+    for (int i = 0; i < np; ++i) {
+        Chunk &C = chunks[(size_t)i];
+        const size_t n = C.pos.size();
+        if (n) {
+            memcpy(P->pos.data() + off, C.pos.data(), n * 4);
+            memcpy(P->ev.data() + off, C.ev.data(), n * 4);
+            memcpy(P->mu.data() + off, C.mu.data(), n * 4);
+            memcpy(P->idx.data() + off, C.idx.data(), n * 4);
+            memcpy(P->flags.data() + off, C.flags.data(), n);
         }
-        if (contig < 0) {
-            P->unknown.emplace_back(t[0].p, t[0].n);
-            continue;
-        }
-
-        int64_t pos, idx;
-        if (!parse_int(t[1], &pos) || !parse_int(t[5], &idx)) {
-            mc_set_error("invalid literal for int() in eventalign row %lld: '%.*s' / '%.*s'",
-                         (long long)P->pos.size(), (int)t[1].n, t[1].p, (int)t[5].n, t[5].p);
-            rc = -2;
-            break;
-        }
-        if (pos < 0 || pos > 0x7fffffff || idx < -0x7fffffff || idx > 0x7fffffff) {
-            mc_set_error("position/event index out of range in eventalign row %lld", (long long)P->pos.size());
-            rc = -2;
-            break;
-        }
-        int64_t e4, m4;
-        if (!(parse_e4_fast(t[6], &e4) && parse_e4_fast(t[10], &m4) && e4 > -2000000000LL && e4 < 2000000000LL &&
-              m4 > -2000000000LL && m4 < 2000000000LL)) {
-            double e, m;
-            if (!parse_double_slow(t[6], &e) || !parse_double_slow(t[10], &m)) {
-                mc_set_error("could not convert string to float in eventalign row %lld: '%.*s' / '%.*s'",
-                             (long long)P->pos.size(), (int)t[6].n, t[6].p, (int)t[10].n, t[10].p);
-                rc = -2;
-                break;
-            }
-            double r = std::nearbyint((e - m) * 10000.0);  // np.round(x,4) numerator (:286)
-            if (!(std::fabs(r) < 2000000000.0)) {
-                mc_set_error("current difference not representable in eventalign row %lld", (long long)P->pos.size());
-                rc = -2;
-                break;
-            }
-            e4 = (int64_t)r;
-            m4 = 0;
-        }
-
-        uint8_t fl = 0;
-        if (t[2].n == t[9].n && memcmp(t[2].p, t[9].p, t[2].n) == 0) fl |= MC_F_KMER_EQ;
-        if (t[9].n == 6 && memcmp(t[9].p, "NNNNNN", 6) == 0) fl |= MC_F_MODEL_N;
-
-        bool new_name = !have_prev || t[3].n != last_name.size() || memcmp(t[3].p, last_name.data(), t[3].n) != 0;
-        if (new_name) {
-            last_name.assign(t[3].p, t[3].n);
-            auto it = read_map.find(last_name);
+        std::vector<int32_t> name_id(C.names.size());
+        for (size_t j = 0; j < C.names.size(); ++j) {
+            auto it = read_map.find(C.names[j]);
             if (it == read_map.end()) {
-                last_read = (int32_t)P->read_names.size();
-                read_map.emplace(last_name, last_read);
-                P->read_names.push_back(last_name);
+                name_id[j] = (int32_t)P->read_names.size();
+                read_map.emplace(C.names[j], name_id[j]);
+                P->read_names.push_back(C.names[j]);
             } else {
-                last_read = it->second;
+                name_id[j] = it->second;
             }
-            fl |= MC_F_NAME_START;
         }
-        if (new_name || P->seg_contig.empty() || P->seg_contig.back() != contig) {
-            fl |= MC_F_SEG_START;
-            P->seg_begin.push_back((int64_t)P->pos.size());
-            P->seg_read.push_back(last_read);
+        for (size_t sgi = 0; sgi < C.seg_begin.size(); ++sgi) {
+            const int32_t rid = name_id[(size_t)C.seg_name[sgi]];
+            const int32_t contig = C.seg_contig[sgi];
+            const int64_t row = off + C.seg_begin[sgi];
+            if (sgi == 0 && have_prev && C.names[0] == prev_name) {
+                // the piece starts inside a name block of the previous piece
+                P->flags[(size_t)row] &= (uint8_t)~MC_F_NAME_START;
+                if (!P->seg_contig.empty() && P->seg_contig.back() == contig) {
+                    P->flags[(size_t)row] &= (uint8_t)~MC_F_SEG_START;
+                    continue;                      // same (name, contig) segment continues
+                }
+            }
+            P->seg_begin.push_back(row);
+            P->seg_read.push_back(rid);
             P->seg_contig.push_back(contig);
         }
-        have_prev = true;
-        P->pos.push_back((int32_t)pos);
-        P->idx.push_back((int32_t)idx);
-        P->ev.push_back((int32_t)e4);
-        P->mu.push_back((int32_t)m4);
-        P->flags.push_back(fl);
+        if (!C.names.empty()) {
+            prev_name = C.names.back();
+            have_prev = true;
+        }
+        for (auto &u : C.unknown) P->unknown.push_back(std::move(u));
+        off += (int64_t)n;
+        Chunk().pos.swap(C.pos);       // release piece memory early
+        Chunk().ev.swap(C.ev);
+        Chunk().mu.swap(C.mu);
+        Chunk().idx.swap(C.idx);
     }
-    P->seg_begin.push_back((int64_t)P->pos.size());
-    if (base) munmap((void *)base, (size_t)fsize);
-    if (rc != 0) {
-        delete P;
-        return rc;
-    }
+    P->seg_begin.push_back(total);
     *out = P;
     return 0;
 }

@@ -216,6 +216,10 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
                      startline, endline=None, train=False, pos_label=None, base=None, motif=None,
                      positions_list=None):
     """Drop-in for extract_contexts.py:110 (see module docstring)."""
+    import os
+    import time
+    timing = os.environ.get('MCALLER_TIMING')
+    t_start = time.perf_counter()
     suffix = '.diffs.' + str(k) + ('.train' if train else '') + '.tmp' + str(startline)
     tsv_output = '.'.join(tsv_input.split('.')[:-1]) + suffix                     # :122 / :134
     modelset = None
@@ -223,7 +227,9 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
         modelset = load_model_file(modelfile)                                     # :123-130
 
     P = prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list)
+    t_prep = time.perf_counter()
     rec = compute(P, k, skip_thresh, qual_thresh, modelset, base, train)
+    t_gpu = time.perf_counter()
     fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label)
     stop = fin.run(rec)
     if stop is None and P.fatal is not None:
@@ -234,6 +240,12 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
         writefi(fin.rows[:n_written], tsv_output)
         raise stop
     writefi(fin.rows, tsv_output)                                                 # :293
+    if timing:
+        t_end = time.perf_counter()
+        print('[mcaller_amd timing] rows=%d records=%d  parse+mark %.3f s | upload+kernels+fetch %.3f s (kernels %s ms) | '
+              'format+write %.3f s | total %.3f s' % (P.table.n_rows, rec.n, t_prep - t_start, t_gpu - t_prep,
+                                                     get_device().times_ms(), t_end - t_gpu, t_end - t_start),
+              file=sys.stderr)
 
     for line in fin.counters():                                                   # :295-301
         print(line)

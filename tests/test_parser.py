@@ -22,9 +22,9 @@ def split_parse(path, startline, endline, contigs):
     return rows, unknown
 
 
-def check(path, startline, endline, contigs):
+def check(path, startline, endline, contigs, n_threads=0):
     from mcaller_amd import _lib
-    t = _lib.parse_eventalign(path, startline, endline, contigs)
+    t = _lib.parse_eventalign(path, startline, endline, contigs, n_threads)
     rows, unknown = split_parse(path, startline, endline, contigs)
     assert t.n_rows == len(rows)
     assert t.unknown == unknown
@@ -64,6 +64,10 @@ def test_byte_ranges_follow_the_reference_window(tmp_path):
     contigs = ['ctg0', 'ecoli0', 'ctg1', 'ecoli1']
     for start, end in [(0, size), (0, size // 3), (size // 3, 2 * size // 3), (1234, 5678), (0, 400), (size - 100, size)]:
         check(p, start, end, contigs)
+    # several threads: pieces cut at line starts and stitched (names, segments and flags across the cuts)
+    for nt in (2, 3, 7, 16, 61):
+        check(p, 0, size, contigs, n_threads=nt)
+        check(p, size // 5, 4 * size // 5, contigs, n_threads=nt)
 
 
 def test_testdata_columns(tmp_path):
