@@ -62,7 +62,7 @@ def main():
     modelset = H.load_modelset('r95')
     _, weights, _, soc = submodel_setup(modelset, 'A')
 
-    dev = Device(local)
+    dev = Device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)   # (one-GPU boxes: test the N>1 plumbing)
     dev.set_reference(ref.device_arrays())
     t_up = time.time()
     dev.upload_table(table)
@@ -102,9 +102,48 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         elapsed_max, calls_total = float(t[0]), int(c[0])
 
+    # the one exchange step of the multi-GPU job: per-site counts summed over ranks (feeds make_bed).  Outside the timed
+    # steps; RCCL when torch's nccl backend comes up, else the gloo group that already carries the barrier.
+    reduction = None
+    if dist is not None:
+        try:
+            from mcaller_amd import make_bed
+            import torch
+            index = make_bed.SiteIndex(ref.meth, 1)
+            counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
+            def reduce_with(backend):
+                group = dist.new_group(backend=backend) if backend == 'nccl' else None
+                packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
+                fmin = torch.from_numpy(counts[2].copy())
+                if backend == 'nccl':
+                    torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
+                    packed, fmin = packed.cuda(), fmin.cuda()
+                t_r = time.perf_counter()
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
+                if backend == 'nccl':
+                    torch.cuda.synchronize()
+                return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
+
+            backend = 'nccl'
+            try:
+                packed, fmin, ms = reduce_with('nccl')
+            except Exception as e_nccl:                        # noqa  (e.g. two ranks sharing one GPU in a plumbing test)
+                backend = 'gloo (nccl failed: %s)' % type(e_nccl).__name__
+                packed, fmin, ms = reduce_with('gloo')
+            total_obs = int(packed[1].sum().item())
+            reduction = {'backend': backend, 'ms': ms, 'observations': total_obs,
+                         'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
+        except Exception as e:                                 # noqa
+            reduction = {'error': '%s: %s' % (type(e).__name__, e)}
+
     if rank == 0:
         k1 = float(np.mean(k1_ms))
         alg_bytes = 17.0 * n_rows + 64.0 * n_calls
+        traffic = None      # HBM bytes per step of the same kernels from the committed rocprofv3 PMC passes (same workload)
+        pmc = os.path.join(REPO, 'profiles', 'r01_pmc.json')
+        if os.path.exists(pmc) and n_rows == 100000000 and args.motif == 'GATC':
+            traffic = json.load(open(pmc)).get('feature_extraction_hbm_bytes_per_step')
         achieved = alg_bytes / (k1 * 1e-3) / 1e9
         out = {
             'metric': 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)',
@@ -124,10 +163,10 @@ def main():
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
-                       'h2d_table_s': t_up, 'generate_s': t_gen},
+                       'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction},
             'roofline': {'bound': 'hbm', 'kernel': 'k1_scan + k1_group_scan + k1_list + k1_emit (feature extraction)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes': alg_bytes, 'kernel_ms': k1},
         }
         if not args.no_cpu_baseline:

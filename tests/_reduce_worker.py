@@ -24,11 +24,11 @@ def main():
     sub = table.slice_segments(lo, hi)
     rec = H.oracle_records(sub, ref.device_arrays(), qual, 6, 0, 0.0, tail_contig=shard.tail_contig(table, qual, 0.0, hi))
     H.oracle_score(rec, sub, qual, weights, soc, 6)
-    clen = np.array([len(ref.records[0][1])], dtype=np.int64)
-    counts = make_bed.site_counts(rec, 6, sub, 1, clen, row_offset=int(table.seg_row_begin[lo]))
+    index = make_bed.SiteIndex(ref.meth, 1)
+    counts = make_bed.site_counts(rec, sub, index, row_offset=int(table.seg_row_begin[lo]))
     n_meth, n_total, first = make_bed.allreduce_site_counts(*counts, dist=dist)
     if rank == 0:
-        make_bed.write_bed_from_counts(out_path, n_meth, n_total, first, ref.names, clen, ref.meth, 6, 1, 0.0)
+        make_bed.write_bed_from_counts(out_path, n_meth, n_total, first, index, ref.names, ref.meth, 6, 1, 0.0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
