@@ -764,6 +764,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                     const int mhi = (int)mhi64;
                     const bool block_continues = d.row_end > t1;
 
+                    PH(4);
                     for (int wb = mlo >> 5; wb <= (mhi >> 5); wb += 64) {
                         // ---- pass A: lane owns mask word wb + lane; which of its sites closes a window here? ----
                         const int w = wb + lane;
@@ -789,20 +790,23 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                             int a = lo, z = hi;
                             while (z - a > 8) {
                                 const int step = (z - a + 7) >> 3;
+                                int pv[7];
+#pragma unroll
+                                for (int t = 1; t < 8; ++t) pv[t - 1] = s_pos[min(a + t * step, z - 1)];   // unconditional: one batch
                                 int c = 0;
 #pragma unroll
-                                for (int t = 1; t < 8; ++t) {
-                                    const int ix = a + t * step;
-                                    c += (ix < z && s_pos[ix < z ? ix : a] <= m) ? 1 : 0;
-                                }
+                                for (int t = 1; t < 8; ++t) c += (int)(a + t * step < z) & (int)(pv[t - 1] <= m);
                                 const int nxt = a + (c + 1) * step;
                                 if (c > 0) a = a + c * step + 1;
                                 if (nxt < z) z = nxt;
                             }
                             {
+                                int pv[8];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) pv[t] = s_pos[min(a + t, z - 1)];
                                 int c = 0;
 #pragma unroll
-                                for (int t = 0; t < 8; ++t) c += (a + t < z && s_pos[a + t < z ? a + t : a] <= m) ? 1 : 0;
+                                for (int t = 0; t < 8; ++t) c += (int)(a + t < z) & (int)(pv[t] <= m);
                                 a += c;
                             }
                             const int ub = a;
@@ -825,6 +829,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                                 s_rv[lane * 32 + b] = (uint16_t)rv;
                             }
                         }
+                        PH(5);
                         // ---- ranks: exclusive prefix of the lanes' counts (site order = row order = record order) ----
                         const int cnt = __popc(emit);
                         int incl = cnt;
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                         reserve(total + round_total);
                         int rank = total + incl - cnt;
                         total += round_total;
+                        PH(6);
                         // ---- pass B: the payload of every closed window ----
                         for (uint32_t rest = emit; rest; rest &= rest - 1, ++rank) {
                             const int b = __builtin_ctz(rest);
@@ -908,6 +914,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                                 A.payload[slot] = P;
                             }
                         }
+                        PH(7);
                     }
                 }
                 if (lane == 0) A.tile_cnt[tile] = total;
