@@ -553,7 +553,76 @@ __device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *_
     return tail_contig >= 0 ? T.n_rows : -1;
 }
 
+// ---- k1_scan's rare paths, kept out of line ----
+// k1_scan keeps the next tile's loads in flight while it works on the staged one.  Any global load inlined into that
+// work -- even on a path that is never taken -- makes the compiler wait for ALL outstanding loads (vmcnt counts in
+// order) where the paths join.  So everything that has to touch global memory from the walk is a call: the waits
+// stay inside the callee.
+struct ScanGlobals {            // what the out-of-line paths need
+    const int32_t *pos;
+    const uint8_t *flags;
+    const int64_t *nb_row_begin;
+    const NbDesc *desc;
+    int64_t n_rows;
+    int n_nb, tail_contig, k, skip_thresh;
+};
+struct CloseRes { int64_t row; int pos; int ns; };
+struct RowRes { int64_t cr; int m, cp, closed; uint32_t pf; };
+
+__device__ __noinline__ CloseRes far_close(const ScanGlobals G, int nb_abs, int64_t my_end, int64_t r) {
+    DevTable T;
+    T.n_rows = G.n_rows; T.flags = const_cast<uint8_t *>(G.flags); T.pos = const_cast<int32_t *>(G.pos);
+    T.nb_row_begin = const_cast<int64_t *>(G.nb_row_begin); T.n_nb = G.n_nb;
+    CloseRes c;
+    bool ns;
+    c.row = find_close(T, G.desc, G.tail_contig, nb_abs, my_end, r, c.pos, ns);
+    c.ns = ns ? 1 : 0;
+    return c;
+}
+
+// word w of a strand mask of n_words words (0 outside)
+__device__ __forceinline__ uint32_t mask_word_global(const uint32_t *__restrict__ gbits, int64_t n_words, int64_t w) {
+    return (w < 0 || w >= n_words) ? 0u : gbits[w];
+}
+__device__ __forceinline__ int site_off_global(const uint32_t *__restrict__ gbits, int contig_len, int k, int p) {
+    if (p >= contig_len) return -1;
+    const int64_t n_words = (((int64_t)contig_len + 31) >> 5) + 2, w = p >> 5;
+    uint64_t bits = (((uint64_t)mask_word_global(gbits, n_words, w + 1) << 32) | mask_word_global(gbits, n_words, w)) >> (p & 31);
+    bits &= (1ull << k) - 1ull;
+    return bits ? __builtin_ctzll(bits) : -1;
+}
+
+// Is `row` (unfiltered, inside its regular name block) the last row of a window?  Everything from global memory.
+__device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbits, int contig_len, int nb_abs, int64_t my_end,
+                                       int64_t row) {
+    RowRes res;
+    res.cr = 0; res.m = 0; res.cp = 0; res.closed = 0; res.pf = 0;
+    const int p = G.pos[row];
+    const int o = site_off_global(gbits, contig_len, G.k, p);
+    if (o < 0) return res;
+    res.m = p + o;
+    const CloseRes c = far_close(G, nb_abs, my_end, row);
+    res.cr = c.row; res.cp = c.pos;
+    res.closed = (c.row >= 0 && (c.ns || c.pos > res.m)) ? 1 : 0;
+    if (c.ns) res.pf |= PF_CLOSE_NS;
+    if (!c.ns && c.pos <= res.m + G.skip_thresh + 1 && site_off_global(gbits, contig_len, G.k, c.pos) > 0) res.pf |= PF_MULTI;
+    return res;
+}
+
+// dword `lane` of the descriptors desc[0 .. n)
+__device__ __noinline__ uint32_t far_desc_word(const NbDesc *desc, int lane, int n) {
+    return lane < n * (int)(sizeof(NbDesc) / 4) ? reinterpret_cast<const uint32_t *>(desc)[lane] : 0u;
+}
+
+__device__ __noinline__ int2 far_pos_flag(const ScanGlobals G, int64_t row) {
+    return make_int2(G.pos[row], (int)G.flags[row]);
+}
+
 constexpr int PT = 64;              // payload slots reserved per tile; further chunks of 64 come from an atomic
+constexpr int UROWS = 8;            // k1_scan: rows per prefilter unit
+constexpr int UPL = TILE / UROWS / 64; // ... units per lane
+constexpr int WCAP = 128;           // ... closed windows buffered in LDS before their payloads are written
+static_assert(TILE % (UROWS * 64) == 0, "whole units per lane");
 
 // columns of one tile in flight: 16 bytes of positions + 4 flag bytes per lane and quad
 struct TileRegs {
@@ -613,16 +682,24 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
     __shared__ uint32_t s_bits[NBST][NTHREADS];
     __shared__ __attribute__((aligned(16))) NbDesc s_nb[NBMAX];
-    __shared__ uint16_t s_rv[64 * 32];              // per lane and mask bit: last row of the window (tile-relative)
+    __shared__ uint16_t s_cand[TILE / UROWS];       // candidate units of the name block in hand, ascending
+    __shared__ int64_t s_w_cr[WCAP];                // closed windows waiting for their payload: closing row,
+    __shared__ int32_t s_w_m[WCAP], s_w_cp[WCAP];   // site, closing position,
+    __shared__ uint16_t s_w_rv[WCAP];               // last row (tile-relative),
+    __shared__ uint8_t s_w_pf[WCAP];                // PF_CLOSE_NS | PF_MULTI
     __shared__ long long s_chunk[TILE / 64];        // first payload slot of the tile's 64-record chunks
 
     static_assert(BW <= NTHREADS && NBMAX * sizeof(NbDesc) / 4 <= NTHREADS && sizeof(TileDesc) / 4 <= NTHREADS,
                   "one dword per thread");
     static_assert(NBST == 2, "two staged mask windows");
+    static_assert(NTHREADS == 64, "the walk is one wave's work, and one wave refills the staged descriptors");
     const DevTable &T = A.T;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int k = A.k;
+    ScanGlobals G;
+    G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
+    G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
     // Tiles are handed out in chunks of CHUNK consecutive tiles from a ticket counter, so the grid need not match the
@@ -684,34 +761,31 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
         PH(1);
 
         if (wave == 0 && A.debug != 3) {
-            // The site walk, compiled twice: with every descriptor of the tile staged in LDS (the normal case), and for a
-            // tile that overlaps more than NBMAX name blocks (descriptors read from global memory).  Keeping the address
-            // spaces apart at compile time matters: a pointer that may be either is a FLAT access, and every FLAT access
-            // waits for the next tile's loads in flight.
-            auto run_tile = [&](auto staged_tag) {
-                constexpr bool STAGED = decltype(staged_tag)::value;
+            // The walk works from LDS alone.  Whatever needs global memory (more name blocks than were staged, a closing
+            // row beyond the tile, a window reaching back before it) is an out-of-line call -- see far_close().
+            {
                 int total = 0;                               // windows closed so far in this tile
                 for (int bi = 0; bi < td.nnb; ++bi) {
-                    NbDesc d;
-                    if constexpr (STAGED) d = s_nb[bi]; else d = A.desc[nb0 + bi];
+                    if (bi >= NBMAX && (bi % NBMAX) == 0)          // rare: the tile overlaps more name blocks than were staged
+                        reinterpret_cast<uint32_t *>(s_nb)[lane] = far_desc_word(A.desc + nb0 + bi, lane, min(td.nnb - bi, NBMAX));
+                    const NbDesc d = s_nb[bi % NBMAX];
                     if (d.mode != MODE_REGULAR) continue;
                     const int nb_abs = nb0 + bi;
                     const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
                     const int sw0 = bi == 0 ? td.w0a : td.w0b;
                     const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
                     const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
-                    const int64_t n_mask_words = ((d.contig_len + 31) >> 5) + 2;
-                    auto mword = [&](int64_t w) -> uint32_t {          // word w of the block's strand mask
-                        if (w < 0 || w >= n_mask_words) return 0u;
-                        if (w >= sw0 && w < sw0 + snw) return sb[w - sw0];
-                        return gbits[w];
-                    };
-                    auto site_off = [&](int p) -> int {                // first 'M' in meth_ref[p:p+k] (:176,:270)
-                        if (p >= d.contig_len) return -1;
-                        const int64_t w = p >> 5;
-                        uint64_t bits = (((uint64_t)mword(w + 1) << 32) | mword(w)) >> (p & 31);
+                    // first 'M' in meth_ref[p:p+k] (:176,:270) from the staged mask window; ok = false when the window
+                    // does not hold both words (the row then takes the out-of-line path)
+                    auto site_off = [&](int p, bool &ok) -> int {
+                        const int wi = (p >> 5) - sw0;
+                        ok = wi >= 0 && wi + 1 < snw;
+                        const int wc = min(max(wi, 0), BW - 2);
+                        uint64_t bits = ((((uint64_t)sb[wc + 1]) << 32) | sb[wc]) >> (p & 31);
                         bits &= (1ull << k) - 1ull;
-                        return bits ? __builtin_ctzll(bits) : -1;
+                        int o = bits ? (int)__builtin_ctzll(bits) : -1;
+                        if (p >= d.contig_len) { o = -1; ok = true; }
+                        return o;
                     };
                     auto slot_of = [&](int rank) -> long long {
                         return rank < PT ? tile * PT + rank : s_chunk[rank >> 6] + (rank & 63);
@@ -738,9 +812,10 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
 
                     // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
                     if (d.extra_row() >= t0 && d.extra_row() < t1) {
-                        int cp;
-                        bool cns;
-                        const int64_t cr = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, d.extra_row(), cp, cns);
+                        const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
+                        const int64_t cr = xc.row;
+                        const int cp = xc.pos;
+                        const bool cns = xc.ns;
                         if (cr >= 0) {
                             reserve(total + 1);
                             if (lane == 0 && slot_of(total) >= 0) {
@@ -758,168 +833,168 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                     const int64_t lb_abs = max(d.row_begin, d.first());
                     const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t1) - t0);
                     if (hi <= lo) continue;
-                    const int mlo = s_pos[lo];
-                    const int64_t mhi64 = min<int64_t>((int64_t)s_pos[hi - 1] + k - 1, d.contig_len - 1);
-                    if (mhi64 < mlo) continue;
-                    const int mhi = (int)mhi64;
-                    const bool block_continues = d.row_end > t1;
-
+                    const int lb_rel = (int)max<int64_t>(lb_abs - t0, -64);      // window walks look back < 32 rows
                     PH(4);
-                    for (int wb = mlo >> 5; wb <= (mhi >> 5); wb += 64) {
-                        // ---- pass A: lane owns mask word wb + lane; which of its sites closes a window here? ----
-                        const int w = wb + lane;
-                        uint32_t word = 0;
-                        if (w <= (mhi >> 5)) {
-                            word = mword(w);
-                            if (w == (mlo >> 5)) word &= ~0u << (mlo & 31);
-                            if (w == (mhi >> 5) && (mhi & 31) != 31) word &= (1u << ((mhi & 31) + 1)) - 1u;
+
+                    // ---- pass 1 (all lanes): which units of UROWS rows can hold a site row at all? ----
+                    // A full unit spans positions [p0, p1]; its rows' k-mers cover mask bits [p0, p1 + k).  One 64-bit
+                    // extract from the staged mask window decides; units cut by the block's ends, units whose span does
+                    // not fit the extract or the staged window go to pass 2 unconditionally.
+                    int ncand = 0;
+                    {
+                        int p0[UPL], p1[UPL];
+                        uint32_t wlo[UPL], whi[UPL];
+#pragma unroll
+                        for (int j = 0; j < UPL; ++j) {
+                            const int i0 = (j * 64 + lane) * UROWS;
+                            p0[j] = s_pos[i0];
+                            p1[j] = s_pos[i0 + UROWS - 1];
                         }
-                        const uint64_t raw = word ? (((uint64_t)mword(w) << 32) | mword(w - 1)) : 0ull;
-                        uint32_t emit = 0;
-                        for (uint32_t rest = word; rest; rest &= rest - 1) {
-                            const int b = __builtin_ctz(rest);
-                            const int m = w * 32 + b;
-                            // nearest 'M' to the left within k-1 positions: rows at or before it belong to its group
-                            int plo = m - k + 1;
-                            if (k > 1) {
-                                const uint32_t left = (uint32_t)(raw >> (32 + b - (k - 1))) & ((1u << (k - 1)) - 1u);
-                                if (left) plo = m - (k - 1) + (31 - __builtin_clz(left)) + 1;
-                            }
-                            // first row of the range with pos > m: 8-ary search, the 7 probes of a level are independent
-                            // LDS reads (4 round trips for 2048 rows instead of 11 dependent ones)
-                            int a = lo, z = hi;
-                            while (z - a > 8) {
-                                const int step = (z - a + 7) >> 3;
-                                int pv[7];
 #pragma unroll
-                                for (int t = 1; t < 8; ++t) pv[t - 1] = s_pos[min(a + t * step, z - 1)];   // unconditional: one batch
-                                int c = 0;
-#pragma unroll
-                                for (int t = 1; t < 8; ++t) c += (int)(a + t * step < z) & (int)(pv[t - 1] <= m);
-                                const int nxt = a + (c + 1) * step;
-                                if (c > 0) a = a + c * step + 1;
-                                if (nxt < z) z = nxt;
-                            }
-                            {
-                                int pv[8];
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) pv[t] = s_pos[min(a + t, z - 1)];
-                                int c = 0;
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) c += (int)(a + t < z) & (int)(pv[t] <= m);
-                                a += c;
-                            }
-                            const int ub = a;
-                            int rv = ub - 1;
-                            while (rv >= lo && (s_fl[rv] & MC_F_MODEL_N)) --rv;
-                            if (rv < lo || s_pos[rv] < plo) continue;          // no row of this tile has first 'M' == m
-                            // the next unfiltered row must lie beyond the site (or belong to another read)
-                            int c = ub;
-                            while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
-                            bool closed = c < hi;                              // a row with pos > m follows in the tile
-                            if (!closed) {                                    // rare: look past the tile / the block
-                                int cp;
-                                bool cns;
-                                const int64_t cr = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, t0 + rv, cp, cns);
-                                closed = cr >= 0 && (cns || cp > m);
-                            }
-                            (void)block_continues;
-                            if (closed) {
-                                emit |= 1u << b;
-                                s_rv[lane * 32 + b] = (uint16_t)rv;
-                            }
+                        for (int j = 0; j < UPL; ++j) {
+                            const int wi = min(max((p0[j] >> 5) - sw0, 0), BW - 2);
+                            wlo[j] = sb[wi];
+                            whi[j] = sb[wi + 1];
                         }
-                        PH(5);
-                        // ---- ranks: exclusive prefix of the lanes' counts (site order = row order = record order) ----
-                        const int cnt = __popc(emit);
-                        int incl = cnt;
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const int v = __shfl_up(incl, o);
-                            if (lane >= o) incl += v;
-                        }
-                        const int round_total = __shfl(incl, 63);
-                        if (round_total == 0) continue;
-                        reserve(total + round_total);
-                        int rank = total + incl - cnt;
-                        total += round_total;
-                        PH(6);
-                        // ---- pass B: the payload of every closed window ----
-                        for (uint32_t rest = emit; rest; rest &= rest - 1, ++rank) {
-                            const int b = __builtin_ctz(rest);
-                            const int m = w * 32 + b;
-                            const int rv = s_rv[lane * 32 + b];
-                            const int64_t r = t0 + rv;
-                            // closing row
-                            int64_t close_row;
-                            int close_pos;
-                            bool close_ns = false;
-                            {
-                                int c = rv + 1;
-                                while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
-                                if (c < hi) { close_row = t0 + c; close_pos = s_pos[c]; }
-                                else close_row = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, r, close_pos, close_ns);
-                            }
-                            // rows r, r-1, ... r-31 -> slot codes
-                            uint32_t c0 = ~0u, c1 = ~0u, c2 = ~0u, c3 = ~0u;
-                            bool stopped = false;
-                            int j0 = 0;
-                            if (rv - 15 >= lo) {
-                                // the common case: the 16 rows ending at r are in LDS and in the block: read them with
-                                // independent loads (one round trip), then decide from registers
-                                int pj[16];
-                                uint32_t nmask = 0;
 #pragma unroll
-                                for (int j = 0; j < 16; ++j) {
-                                    pj[j] = s_pos[rv - j];
-                                    nmask |= (uint32_t)((s_fl[rv - j] >> 1) & 1u) << j;      // MC_F_MODEL_N is bit 1
-                                }
-#pragma unroll
-                                for (int j = 0; j < 16; ++j) {
-                                    if (stopped || ((nmask >> j) & 1u)) continue;
-                                    if (pj[j] < m - k + 1) { stopped = true; continue; }
-                                    const uint32_t code = (uint32_t)(m - pj[j]), bit = 1u << j;
-                                    if (!(code & 1u)) c0 &= ~bit;
-                                    if (!(code & 2u)) c1 &= ~bit;
-                                    if (!(code & 4u)) c2 &= ~bit;
-                                    c3 &= ~bit;
-                                }
-                                j0 = 16;
-                            }
-                            for (int j = j0; j < 32 && !stopped; ++j) {
-                                const int64_t rr = r - j;
-                                if (rr < lb_abs) { stopped = true; break; }
-                                int pj;
-                                bool nj;
-                                if (rr >= t0) { pj = s_pos[rr - t0]; nj = s_fl[rr - t0] & MC_F_MODEL_N; }
-                                else { pj = T.pos[rr]; nj = T.flags[rr] & MC_F_MODEL_N; }
-                                if (nj) continue;
-                                if (pj < m - k + 1) { stopped = true; break; }
-                                const uint32_t code = (uint32_t)(m - pj), bit = 1u << j;
-                                if (!(code & 1u)) c0 &= ~bit;
-                                if (!(code & 2u)) c1 &= ~bit;
-                                if (!(code & 4u)) c2 &= ~bit;
-                                c3 &= ~bit;
-                            }
-                            uint32_t pf = 0;
-                            if (close_ns) pf |= PF_CLOSE_NS;
-                            if (!stopped || d.stray_q != NO_STRAY) pf |= PF_SLOW;
-                            if (!close_ns && close_pos <= m + A.skip_thresh + 1 && site_off(close_pos) > 0) pf |= PF_MULTI;
-                            const long long slot = slot_of(rank);
-                            if (slot >= 0) {
-                                Payload P;
-                                P.r = r; P.close_row = close_row; P.m = m; P.close_pos = close_pos;
-                                P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
-                                P.flags = pf;
-                                P.nb = nb_abs;
-                                A.payload[slot] = P;
-                            }
+                        for (int j = 0; j < UPL; ++j) {
+                            const int u = j * 64 + lane, i0 = u * UROWS;
+                            const bool touches = i0 + UROWS > lo && i0 < hi;
+                            const bool full = i0 >= lo && i0 + UROWS <= hi;
+                            const int span = p1[j] - p0[j] + k;
+                            const int wi = (p0[j] >> 5) - sw0;
+                            const bool decidable = full && span <= 32 && wi >= 0 && wi + 1 < snw;
+                            const uint64_t bits = ((((uint64_t)whi[j] << 32) | wlo[j]) >> (p0[j] & 31)) &
+                                                  ((1ull << (span & 63)) - 1ull);
+                            const bool cand = touches && (!decidable || bits != 0ull);
+                            const unsigned long long bal = __ballot(cand);
+                            if (cand) s_cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)u;
+                            ncand += __popcll(bal);
                         }
-                        PH(7);
                     }
+                    PH(5);
+                    if (ncand == 0) continue;
+
+                    int nwin = 0;                                      // closed windows waiting in s_w_*
+                    // ---- pass 3 (16 lanes per window): slot codes of the rows r, r-1, ... r-31, then the payload ----
+                    auto flush = [&]() {
+                        if (nwin == 0) return;
+                        reserve(total + nwin);
+                        const int grp = lane >> 4, j = lane & 15;
+                        for (int wbase = 0; wbase < nwin; wbase += 4) {
+                            const bool havew = wbase + grp < nwin;
+                            const int wix = havew ? wbase + grp : 0;
+                            const int rv = s_w_rv[wix], m = s_w_m[wix];
+                            uint32_t c0 = ~0u, c1 = ~0u, c2 = ~0u, c3 = ~0u;
+                            bool stopped = !havew;
+                            for (int jb = 0; jb < 32; jb += 16) {
+                                if (!__ballot(!stopped)) break;
+                                const int rr = rv - jb - j;                              // tile-relative; may precede the tile
+                                const bool inb = rr >= lb_rel;
+                                const int rc = max(rr, 0);
+                                int pj = s_pos[rc];
+                                uint32_t fj = s_fl[rc];
+                                // rows before the tile: only if the walk gets that far without stopping (rare)
+                                const bool early = !stopped && inb && rr < 0;
+                                if (__ballot(early)) {
+                                    const unsigned long long kn = __ballot(!stopped && (!inb || (rr >= 0 && !(fj & MC_F_MODEL_N) &&
+                                                                                             pj < m - k + 1)));
+                                    const unsigned long long un = __ballot(early);
+                                    const uint32_t kn16 = (uint32_t)(kn >> (grp * 16)) & 0xFFFFu, un16 = (uint32_t)(un >> (grp * 16)) & 0xFFFFu;
+                                    const bool need = early && (kn16 == 0u || __builtin_ctz(un16) < __builtin_ctz(kn16));
+                                    if (need) {
+                                        const int2 g = far_pos_flag(G, t0 + rr);
+                                        pj = g.x; fj = (uint32_t)g.y;
+                                    }
+                                }
+                                const bool nj = fj & MC_F_MODEL_N;
+                                const bool stop_here = !stopped && (!inb || (!nj && pj < m - k + 1));
+                                const uint32_t st16 = (uint32_t)(__ballot(stop_here) >> (grp * 16)) & 0xFFFFu;
+                                const int first = st16 ? __builtin_ctz(st16) : 16;
+                                const bool inw = !stopped && inb && !nj && j < first;
+                                const uint32_t code = (uint32_t)(m - pj);
+                                const uint32_t b0 = (uint32_t)(__ballot(inw && !(code & 1u)) >> (grp * 16)) & 0xFFFFu;
+                                const uint32_t b1 = (uint32_t)(__ballot(inw && !(code & 2u)) >> (grp * 16)) & 0xFFFFu;
+                                const uint32_t b2 = (uint32_t)(__ballot(inw && !(code & 4u)) >> (grp * 16)) & 0xFFFFu;
+                                const uint32_t b3 = (uint32_t)(__ballot(inw) >> (grp * 16)) & 0xFFFFu;
+                                c0 &= ~(b0 << jb); c1 &= ~(b1 << jb); c2 &= ~(b2 << jb); c3 &= ~(b3 << jb);
+                                if (st16) stopped = true;
+                            }
+                            if (havew && j == 0) {
+                                const bool really_stopped = stopped;      // (havew: `stopped` started false)
+                                const long long slot = slot_of(total + wbase + grp);
+                                if (slot >= 0) {
+                                    Payload P;
+                                    P.r = t0 + rv; P.close_row = s_w_cr[wix]; P.m = m; P.close_pos = s_w_cp[wix];
+                                    P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
+                                    P.flags = s_w_pf[wix] | ((!really_stopped || d.stray_q != NO_STRAY) ? PF_SLOW : 0u);
+                                    P.nb = nb_abs;
+                                    A.payload[slot] = P;
+                                }
+                            }
+                        }
+                        total += nwin;
+                        nwin = 0;
+                    };
+
+                    // ---- pass 2 (one lane per row of the candidate units): is this row the last row of a window? ----
+                    // It is iff its k-mer holds an 'M' (first one: the site m, :176) and the next unfiltered row of the
+                    // read lies beyond m -- or there is none and another read (or the next shard) follows (:179).
+                    for (int base = 0; base < ncand * UROWS; base += 64) {
+                        const int e = base + lane;
+                        const bool have = e < ncand * UROWS;
+                        const int u = s_cand[have ? e / UROWS : 0];
+                        const int i = u * UROWS + (e % UROWS);
+                        const int p = s_pos[i], pn = s_pos[min(i + 1, TILE - 1)];
+                        const uint32_t f = s_fl[i], fn = s_fl[i + 1];
+                        bool closed = false, far = false;
+                        int m = 0, cp = 0;
+                        int64_t cr = 0;
+                        uint32_t pf = 0;
+                        if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
+                            bool ok;
+                            const int o = site_off(p, ok);
+                            if (!ok) far = true;
+                            else if (o >= 0) {
+                                m = p + o;
+                                int c = i + 1;
+                                if (c < hi && (fn & MC_F_MODEL_N)) {
+                                    ++c;
+                                    while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
+                                }
+                                if (c < hi) {
+                                    cp = c == i + 1 ? pn : s_pos[c];
+                                    cr = t0 + c;
+                                    closed = cp > m;
+                                    if (closed && cp <= m + A.skip_thresh + 1) {
+                                        bool ok2;
+                                        const int o2 = site_off(cp, ok2);
+                                        if (!ok2) far = true;
+                                        else if (o2 > 0) pf |= PF_MULTI;
+                                    }
+                                } else far = true;                        // the closing row lies past the tile / the block
+                            }
+                        }
+                        if (__ballot(far)) {                               // rare
+                            if (far) {
+                                const RowRes fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, t0 + i);
+                                closed = fr.closed; m = fr.m; cp = fr.cp; cr = fr.cr; pf = fr.pf;
+                            }
+                        }
+                        const unsigned long long bal = __ballot(closed);
+                        if (closed) {
+                            const int ix = nwin + __popcll(bal & ((1ull << lane) - 1ull));
+                            s_w_rv[ix] = (uint16_t)i; s_w_m[ix] = m; s_w_cp[ix] = cp; s_w_cr[ix] = cr; s_w_pf[ix] = (uint8_t)pf;
+                        }
+                        nwin += __popcll(bal);
+                        if (nwin > WCAP - 64) flush();
+                    }
+                    PH(6);
+                    flush();
+                    PH(7);
                 }
                 if (lane == 0) A.tile_cnt[tile] = total;
-            };
-            if (td.nnb <= NBMAX) run_tile(std::true_type{}); else run_tile(std::false_type{});
+            }
         }
         PH(2);
         __syncthreads();          // LDS is rewritten for the next tile
