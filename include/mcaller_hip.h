@@ -151,6 +151,30 @@ int mc_ctx_sync(mc_ctx *ctx);
 int mc_mlp_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 int mc_forest_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 
+/* ===== native `.diffs.<k>` row formatter (host), replaces the text assembly of the flush, extract_contexts.py:186-216 ===== */
+typedef struct mc_format_args {
+    const mc_calls_view *rec;          /* flush records in host memory (mc_fetch_records / _view)                  */
+    int64_t n_records;
+    int32_t k;
+    const mc_table_view *table;        /* seg_row_begin / seg_read / seg_contig are read                           */
+    const mc_ref_view *ref;            /* bases + strand masks: the marked strings the context is sliced from :194 */
+    const char *const *contig_names;   /* [ref->n_contigs]                                                         */
+    const char *const *read_names;     /* [table->n_reads] column 2 of the row                                :216 */
+    const char *const *read_qual_txt;  /* [table->n_reads] str(read2qual[...]), the k+1-th feature        :189-193 */
+    const char *tail_chrom;            /* chrom of records closed by the next shard's first row (or NULL)          */
+    const char *label_meth;            /* 'm6A' / 'm'+base                                                :200-204 */
+    const char *label_unmeth;          /* base                                                                :206 */
+    const uint8_t *submodel_of_char;   /* [256] as in mc_ctx_set_mlp; 255 = the KeyError path             :218-223 */
+} mc_format_args;
+/* Rows of records [first, *stop_at) as one malloc'ed text block (release with mc_free); records flagged
+ * MC_I_TOO_MANY produce no row.  *stop_at < n_records: that record needs the host's own handling (context leaving the
+ * contig, NaN probability, unknown sub-model key or complement, centre not 'M': the reference's exit/crash paths). */
+int mc_format_diffs(const mc_format_args *args, int64_t first, int32_t n_threads, char **text, int64_t *n_bytes,
+                    int64_t *n_rows, int64_t *stop_at);
+void mc_free(void *p);
+/* repr(float) == str(np.float64) of one value into out32 (NUL-terminated); returns its length. */
+int mc_repr_double(double v, char *out32);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,14 @@ class CallsView(C.Structure):
                 ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p)]
 
 
+class FormatArgs(C.Structure):
+    _fields_ = [('rec', C.POINTER(CallsView)), ('n_records', C.c_int64), ('k', C.c_int32),
+                ('table', C.POINTER(TableView)), ('ref', C.POINTER(RefView)),
+                ('contig_names', C.POINTER(C.c_char_p)), ('read_names', C.POINTER(C.c_char_p)),
+                ('read_qual_txt', C.POINTER(C.c_char_p)), ('tail_chrom', C.c_char_p),
+                ('label_meth', C.c_char_p), ('label_unmeth', C.c_char_p), ('submodel_of_char', C.c_void_p)]
+
+
 class Params(C.Structure):
     _fields_ = [('k', C.c_int32), ('skip_thresh', C.c_int32), ('qual_thresh', C.c_double),
                 ('tail_contig', C.c_int32), ('score', C.c_int32),
@@ -88,6 +96,11 @@ def lib():
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_forest_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_ctx_set_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.mc_free.argtypes = [C.c_void_p]
+        L.mc_free.restype = None
+        L.mc_repr_double.argtypes = [C.c_double, C.c_char_p]
         _lib = L
     return _lib
 
@@ -143,11 +156,11 @@ class Table(object):
         r0, r1 = int(self.seg_row_begin[s0]), int(self.seg_row_begin[s1])
         return Table(self.pos[r0:r1], self.event_e4[r0:r1], self.model_e4[r0:r1], self.event_idx[r0:r1],
                      self.flags[r0:r1], self.seg_row_begin[s0:s1 + 1] - r0, self.seg_read[s0:s1],
-                     self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names)
+                     self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner)
 
 
 def parse_eventalign(path, startline, endline, contig_names, n_threads=0):
-    """Native parser -> Table (copies out of the library's buffers)."""
+    """Native parser -> Table over the library's buffers (no copy; freed with the Table)."""
     L = lib()
     arr = (C.c_char_p * max(1, len(contig_names)))()
     for i, n in enumerate(contig_names):
@@ -155,21 +168,32 @@ def parse_eventalign(path, startline, endline, contig_names, n_threads=0):
     handle = C.c_void_p()
     check(L.mc_parse_eventalign(path.encode('utf-8'), int(startline), int(endline), arr, len(contig_names),
                                 int(n_threads), C.byref(handle)))
-    try:
-        v = TableView()
-        check(L.mc_parsed_view(handle, C.byref(v)))
-        n, ns = v.n_rows, v.n_seg
-        names = [L.mc_parsed_read_name(handle, i).decode('utf-8', 'surrogateescape') for i in range(v.n_reads)]
-        unknown = [L.mc_parsed_unknown_name(handle, i).decode('utf-8', 'surrogateescape')
-                   for i in range(L.mc_parsed_n_unknown(handle))]
-        t = Table(_from_ptr(v.pos, n, np.int32).copy(), _from_ptr(v.event_e4, n, np.int32).copy(),
-                  _from_ptr(v.model_e4, n, np.int32).copy(), _from_ptr(v.event_idx, n, np.int32).copy(),
-                  _from_ptr(v.flags, n, np.uint8).copy(), _from_ptr(v.seg_row_begin, ns + 1, np.int64).copy(),
-                  _from_ptr(v.seg_read, ns, np.int32).copy(), _from_ptr(v.seg_contig, ns, np.int32).copy(),
-                  v.n_reads, read_names=names, unknown=unknown)
-    finally:
-        L.mc_parsed_free(handle)
-    return t
+    owner = _Parsed(handle)          # the columns stay in the library's buffers (no copy); freed with the Table
+    v = TableView()
+    check(L.mc_parsed_view(handle, C.byref(v)))
+    n, ns = v.n_rows, v.n_seg
+    names = [L.mc_parsed_read_name(handle, i).decode('utf-8', 'surrogateescape') for i in range(v.n_reads)]
+    unknown = [L.mc_parsed_unknown_name(handle, i).decode('utf-8', 'surrogateescape')
+               for i in range(L.mc_parsed_n_unknown(handle))]
+    return Table(_from_ptr(v.pos, n, np.int32), _from_ptr(v.event_e4, n, np.int32), _from_ptr(v.model_e4, n, np.int32),
+                 _from_ptr(v.event_idx, n, np.int32), _from_ptr(v.flags, n, np.uint8),
+                 _from_ptr(v.seg_row_begin, ns + 1, np.int64), _from_ptr(v.seg_read, ns, np.int32),
+                 _from_ptr(v.seg_contig, ns, np.int32), v.n_reads, read_names=names, unknown=unknown, owner=owner)
+
+
+class _Parsed(object):
+    """Owns a mc_parsed handle: the Table built over it keeps it alive."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().mc_parsed_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def make_ref_view(arrays):
@@ -181,6 +205,51 @@ def make_ref_view(arrays):
     v.n_seq_bytes = len(arrays['seq'])
     v.n_words = len(arrays['mbits_fwd'])
     return v
+
+
+def _cstr_array(strings):
+    arr = (C.c_char_p * max(1, len(strings)))()
+    for i, s in enumerate(strings):
+        arr[i] = s if isinstance(s, bytes) else str(s).encode('utf-8', 'surrogateescape')
+    return arr
+
+
+class DiffsFormatter(object):
+    """mc_format_diffs over one (records, table, reference): rows of records [first, stop) as bytes."""
+
+    def __init__(self, rec, table, ref_arrays, contig_names, read_qual_txt, k, label_meth, label_unmeth,
+                 submodel_of_char, tail_chrom=None):
+        self._keep = (rec, table, ref_arrays)
+        self._rv, self._tv, self._fv = rec.view(), table.view(), make_ref_view(ref_arrays)
+        self._rv.capacity = rec.n
+        self._contigs, self._reads = _cstr_array(contig_names), _cstr_array(table.read_names)
+        self._quals = _cstr_array(read_qual_txt)
+        self._soc = np.ascontiguousarray(submodel_of_char, dtype=np.uint8)
+        a = FormatArgs()
+        a.rec, a.n_records, a.k = C.pointer(self._rv), rec.n, k
+        a.table, a.ref = C.pointer(self._tv), C.pointer(self._fv)
+        a.contig_names, a.read_names, a.read_qual_txt = self._contigs, self._reads, self._quals
+        a.tail_chrom = tail_chrom.encode('utf-8', 'surrogateescape') if tail_chrom is not None else None
+        a.label_meth, a.label_unmeth = label_meth.encode(), label_unmeth.encode()
+        a.submodel_of_char = _ptr(self._soc)
+        self._args = a
+
+    def rows(self, first, n_threads=0):
+        """-> (bytes, number of rows, stop): stop < n means record `stop` needs the host's own handling."""
+        text, nb, nr, stop = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().mc_format_diffs(C.byref(self._args), int(first), int(n_threads), C.byref(text), C.byref(nb),
+                                    C.byref(nr), C.byref(stop)))
+        try:
+            blob = C.string_at(text, nb.value)
+        finally:
+            lib().mc_free(text)
+        return blob, nr.value, stop.value
+
+
+def repr_double(x):
+    buf = C.create_string_buffer(40)
+    lib().mc_repr_double(float(x), buf)
+    return buf.value.decode()
 
 
 class Records(object):

@@ -1,0 +1,288 @@
+// Native `.diffs.<k>` row formatter (host side of libmcaller_hip.so).
+//
+// Replaces the per-observation text assembly of the reference's flush -- extract_contexts.py:186-216: the k slot
+// means printed with str(np.float64) (shortest round-trip repr, literal `0` for an empty slot :186), the read quality,
+// the 2k-1 context sliced from the marked strand and reverse-complemented for '-' reads (:194), the label from
+// p >= 0.5 (:200-206), str(np.round(p, 2)) (:207) and the row layout (:216) -- for flush records that are already
+// in host memory.  Records the host must look at itself (a context that leaves the contig, an unscored record, a
+// sub-model key that does not exist, a base without a complement: the reference's exit/crash paths) stop the run:
+// *stop_at names the first such record and the rows before it are returned.
+#include "../../include/mcaller_hip.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+void mc_set_error(const char *fmt, ...);
+
+namespace {
+
+// repr(float) / str(np.float64): shortest digits that round-trip, Python's layout rules (float_repr_style 'short':
+// exponent form iff decpt > 16 or decpt < -3; at least two exponent digits; ".0" appended to integers).
+inline char *put_repr(char *o, double v) {
+    if (std::isnan(v)) { memcpy(o, "nan", 3); return o + 3; }
+    if (std::isinf(v)) { if (v < 0) *o++ = '-'; memcpy(o, "inf", 3); return o + 3; }
+    if (std::signbit(v)) { *o++ = '-'; v = -v; }
+    if (v == 0.0) { memcpy(o, "0.0", 3); return o + 3; }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof(sci) - 1, v, std::chars_format::scientific);   // d[.ddd]e[+-]XX
+    *r.ptr = 0;
+    char digits[24];
+    int nd = 0;
+    const char *p = sci;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    const int exp10 = (int)strtol(p + 1, nullptr, 10);
+    const int decpt = exp10 + 1;
+    if (decpt > 16 || decpt < -3) {
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, (size_t)nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        int e = decpt - 1;
+        *o++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        char eb[8];
+        int ne = 0;
+        do { eb[ne++] = (char)('0' + e % 10); e /= 10; } while (e);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) *o++ = eb[--ne];
+        return o;
+    }
+    if (decpt <= 0) {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -decpt; ++i) *o++ = '0';
+        memcpy(o, digits, (size_t)nd); o += nd;
+        return o;
+    }
+    if (decpt >= nd) {
+        memcpy(o, digits, (size_t)nd); o += nd;
+        for (int i = nd; i < decpt; ++i) *o++ = '0';
+        *o++ = '.'; *o++ = '0';
+        return o;
+    }
+    memcpy(o, digits, (size_t)decpt); o += decpt;
+    *o++ = '.';
+    memcpy(o, digits + decpt, (size_t)(nd - decpt)); o += nd - decpt;
+    return o;
+}
+
+inline char *put_int(char *o, long long v) {
+    const auto r = std::to_chars(o, o + 24, v);
+    return r.ptr;
+}
+
+inline char *put_str(char *o, const char *s, size_t n) {
+    memcpy(o, s, n);
+    return o + n;
+}
+
+inline int comp_of(int c) {          // base_comps, extract_contexts.py:11; -1: KeyError there
+    switch (c) {
+        case 'A': return 'T';
+        case 'C': return 'G';
+        case 'T': return 'A';
+        case 'G': return 'C';
+        case 'N': return 'N';
+        case 'M': return 'M';
+        default: return -1;
+    }
+}
+
+struct Job {
+    const mc_format_args *a;
+    std::vector<size_t> name_len, qual_len, contig_len_txt;
+    size_t tail_len = 0, lab_pos_len = 0, lab_neg_len = 0;
+};
+
+// segment that holds row r: searchsorted(seg_row_begin, r, 'right') - 1
+inline int32_t seg_of_row(const mc_table_view *t, int64_t r) {
+    const int64_t *b = t->seg_row_begin, *e = b + t->n_seg + 1;
+    return (int32_t)(std::upper_bound(b, e, r) - b) - 1;
+}
+
+// marked context of record j into ctx[0..2k-1); false: the host has to handle this record
+inline bool build_context(const mc_format_args *a, int64_t j, char *ctx) {
+    const mc_calls_view *rec = a->rec;
+    const mc_ref_view *ref = a->ref;
+    const int k = a->k;
+    const uint32_t info = rec->info[j];
+    if (info & MC_I_EDGE) return false;
+    const int32_t seg = rec->site_seg[j];
+    if (seg < 0 || seg >= a->table->n_seg) return false;
+    const int32_t cid = a->table->seg_contig[seg];
+    if (cid < 0 || cid >= ref->n_contigs) return false;
+    const int64_t L = ref->contig_len[cid], m = rec->site_pos[j];
+    const int64_t lo = m - k + 1, hi = m + k;           // last_ref[mpos-k+1 : mpos+k]  (:194)
+    if (lo < 0 || hi > L) return false;
+    const bool rev = info & MC_I_REV;
+    const uint8_t *seq = ref->seq + ref->seq_off[cid];
+    const uint32_t *bits = (rev ? ref->mbits_rev : ref->mbits_fwd) + ref->word_off[cid];
+    const int n = 2 * k - 1;
+    for (int i = 0; i < n; ++i) {
+        const int64_t p = lo + i;
+        const int c = ((bits[p >> 5] >> (p & 31)) & 1u) ? 'M' : seq[p];
+        if (!rev) ctx[i] = (char)c;
+        else {
+            const int cc = comp_of(c);
+            if (cc < 0) return false;
+            ctx[n - 1 - i] = (char)cc;
+        }
+    }
+    if (ctx[k - 1] != 'M') return false;                 // :224-228
+    const unsigned char nxt = (unsigned char)ctx[k];
+    if (a->submodel_of_char[nxt] == 255) return false;   // :218-223
+    if (((info >> MC_I_NEXT_SHIFT) & 0xFFu) != nxt) return false;   // device and host disagree: let the host say so
+    return true;
+}
+
+inline bool native_ok(const mc_format_args *a, int64_t j) {
+    const uint32_t info = a->rec->info[j];
+    if (info & MC_I_TOO_MANY) return true;               // no text
+    if (std::isnan(a->rec->prob[j])) return false;
+    char ctx[2 * MC_MAX_K];
+    return build_context(a, j, ctx);
+}
+
+void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_t &n_rows) {
+    const mc_format_args *a = J.a;
+    const mc_calls_view *rec = a->rec;
+    const mc_table_view *t = a->table;
+    const int k = a->k;
+    std::vector<char> buf(1 << 16);
+    size_t used = 0;
+    n_rows = 0;
+    for (int64_t j = j0; j < j1; ++j) {
+        const uint32_t info = rec->info[j];
+        if (info & MC_I_TOO_MANY) continue;
+        const int32_t seg = rec->site_seg[j];
+        const int32_t rid = t->seg_read[seg];
+        const int32_t cseg = seg_of_row(t, rec->close_row[j]);
+        const char *chrom;
+        size_t chrom_len;
+        if (cseg >= t->n_seg) { chrom = a->tail_chrom; chrom_len = J.tail_len; }     // R8: the closing row's contig
+        else { const int32_t cc = t->seg_contig[cseg]; chrom = a->contig_names[cc]; chrom_len = J.contig_len_txt[(size_t)cc]; }
+        const size_t need = chrom_len + J.name_len[(size_t)rid] + J.qual_len[(size_t)rid] + (size_t)k * 32 + 160;
+        if (used + need > buf.size()) {
+            out.append(buf.data(), used);
+            used = 0;
+            if (need > buf.size()) buf.resize(need * 2);
+        }
+        char *o = buf.data() + used;
+        o = put_str(o, chrom, chrom_len); *o++ = '\t';
+        o = put_str(o, a->read_names[rid], J.name_len[(size_t)rid]); *o++ = '\t';
+        o = put_int(o, rec->site_pos[j]); *o++ = '\t';
+        build_context(a, j, o);
+        o += 2 * k - 1;
+        *o++ = '\t';
+        const uint32_t empty = info & MC_I_EMPTY_MASK;
+        const double *f = rec->feats + j * k;
+        for (int i = 0; i < k; ++i) {
+            if ((empty >> i) & 1u) *o++ = '0';                                     // literal int 0  (:186)
+            else o = put_repr(o, f[i]);
+            *o++ = ',';
+        }
+        o = put_str(o, a->read_qual_txt[rid], J.qual_len[(size_t)rid]); *o++ = '\t';
+        *o++ = (info & MC_I_REV) ? '-' : '+'; *o++ = '\t';
+        const double p1 = rec->prob[j];
+        if (p1 >= 0.5) o = put_str(o, a->label_meth, J.lab_pos_len);               // :200-206
+        else o = put_str(o, a->label_unmeth, J.lab_neg_len);
+        *o++ = '\t';
+        o = put_repr(o, std::nearbyint(p1 * 100.0) / 100.0);                       // np.round(p, 2)  (:207)
+        *o++ = '\n';
+        used = (size_t)(o - buf.data());
+        ++n_rows;
+    }
+    out.append(buf.data(), used);
+}
+
+}  // namespace
+
+extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n_threads, char **text, int64_t *n_bytes,
+                               int64_t *n_rows, int64_t *stop_at) {
+    *text = nullptr;
+    *n_bytes = 0;
+    *n_rows = 0;
+    *stop_at = first;
+    if (!a || !a->rec || !a->table || !a->ref || a->k < 1 || a->k > MC_MAX_K || first < 0 || first > a->n_records) {
+        mc_set_error("mc_format_diffs: bad arguments");
+        return -12;
+    }
+    const int64_t n = a->n_records;
+    int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (n - first) / 4096));
+
+    // pass 1: the first record the host must handle itself
+    std::vector<int64_t> stops((size_t)nt, n);
+    auto scan = [&](int w) {
+        const int64_t lo = first + (n - first) * w / nt, hi = first + (n - first) * (w + 1) / nt;
+        for (int64_t j = lo; j < hi; ++j)
+            if (!native_ok(a, j)) { stops[(size_t)w] = j; return; }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < nt; ++w) th.emplace_back(scan, w);
+        scan(0);
+        for (auto &x : th) x.join();
+    }
+    int64_t stop = n;
+    for (int64_t s : stops) stop = std::min(stop, s);
+    *stop_at = stop;
+
+    // pass 2: the rows of [first, stop), pieces in record order
+    Job J;
+    J.a = a;
+    const mc_table_view *t = a->table;
+    J.name_len.resize((size_t)std::max(t->n_reads, 0));
+    J.qual_len.resize((size_t)std::max(t->n_reads, 0));
+    for (int32_t i = 0; i < t->n_reads; ++i) {
+        J.name_len[(size_t)i] = a->read_names[i] ? strlen(a->read_names[i]) : 0;
+        J.qual_len[(size_t)i] = a->read_qual_txt[i] ? strlen(a->read_qual_txt[i]) : 0;
+    }
+    J.contig_len_txt.resize((size_t)std::max(a->ref->n_contigs, 0));
+    for (int32_t i = 0; i < a->ref->n_contigs; ++i) J.contig_len_txt[(size_t)i] = strlen(a->contig_names[i]);
+    J.tail_len = a->tail_chrom ? strlen(a->tail_chrom) : 0;
+    J.lab_pos_len = strlen(a->label_meth);
+    J.lab_neg_len = strlen(a->label_unmeth);
+    std::vector<std::string> parts((size_t)nt);
+    std::vector<int64_t> rows((size_t)nt, 0);
+    auto work = [&](int w) {
+        const int64_t lo = first + (stop - first) * w / nt, hi = first + (stop - first) * (w + 1) / nt;
+        format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w]);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < nt; ++w) th.emplace_back(work, w);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    size_t total = 0;
+    for (auto &p : parts) total += p.size();
+    char *outp = (char *)malloc(std::max<size_t>(total, 1));
+    if (!outp) {
+        mc_set_error("mc_format_diffs: out of memory (%zu bytes)", total);
+        return -10;
+    }
+    size_t off = 0;
+    for (int w = 0; w < nt; ++w) {
+        memcpy(outp + off, parts[(size_t)w].data(), parts[(size_t)w].size());
+        off += parts[(size_t)w].size();
+        *n_rows += rows[(size_t)w];
+    }
+    *text = outp;
+    *n_bytes = (int64_t)total;
+    return 0;
+}
+
+extern "C" void mc_free(void *p) { free(p); }
+
+// repr(float) alone (tests pin it against Python's)
+extern "C" int mc_repr_double(double v, char *out32) {
+    char *e = put_repr(out32, v);
+    *e = 0;
+    return (int)(e - out32);
+}

@@ -38,6 +38,12 @@ def writefi(data, fi):
             outfi.write('\t'.join(entry) + '\n')
 
 
+def write_text(blob, fi):
+    """writefi for rows that are already text."""
+    with open(fi, 'ab') as outfi:
+        outfi.write(blob)
+
+
 def fmt_float(x):
     """str(np.float64): shortest round-trip repr (what the reference's str(diff) prints)."""
     return repr(float(x))
@@ -116,7 +122,12 @@ def compute(P, k, skip_thresh, qual_thresh, modelset, base, train, device=None, 
 
 
 class Finisher(object):
-    """Flush records -> the reference's rows, counters and train dicts, in record (= file) order."""
+    """Flush records -> the reference's rows, counters and train dicts, in record (= file) order.
+
+    Predict mode: the rows are written by the native formatter (mc_format_diffs, all host cores); a record it hands
+    back (context leaving the contig, unscored, unknown sub-model key: the reference's exit/crash paths) goes through
+    `_one`, the literal per-record transcription of extract_contexts.py:179-239, which train mode uses throughout
+    (it has to build the Python lists the caller trains on)."""
 
     def __init__(self, P, k, base, train, modelset=None, pos_label=None, device=None, tail_chrom=None):
         self.P, self.k, self.base, self.train = P, k, base, train
@@ -124,91 +135,152 @@ class Finisher(object):
         self.device = device
         self.tail_chrom = tail_chrom
         if not train:
-            self.table, _, self.model_index, _ = submodel_setup(modelset, base)
+            self.table, _, self.model_index, self.soc = submodel_setup(modelset, base)
             self.model_keys = modelset.keys()
         else:
             self.table = base_models(base, False)                                 # :133
             self.model_keys = None
         self.signals = {bm: {} for bm in self.table.values()} if train else None
         self.contexts = {bm: {} for bm in self.table.values()} if train else None
-        self.rows = []          # every emitted row, in order
+        self.blobs = []         # emitted rows as text (bytes), in order
         self.num_observations = 0
         self.pos_set, self.multi, self.w_skips, self.skipped = set(), set(), set(), set()
+        self._n_pos = self._n_multi = self._n_wskips = self._n_skipped = None    # set by the vectorised counters
+
+    # ---- output ----
+    def text(self, max_rows=None):
+        """The rows as bytes; max_rows: only the first that many (the reference's 5000-row batches on an exit)."""
+        blob = b''.join(self.blobs)
+        if max_rows is None:
+            return blob
+        return b''.join(blob.splitlines(True)[:max_rows])
+
+    @property
+    def rows(self):
+        return [line.split('\t') for line in self.text().decode('utf-8', 'surrogateescape').splitlines()]
 
     def counters(self):
+        n_pos = len(self.pos_set) if self._n_pos is None else self._n_pos
+        n_multi = len(self.multi) if self._n_multi is None else self._n_multi
+        n_wskips = len(self.w_skips) if self._n_wskips is None else self._n_wskips
+        n_skipped = len(self.skipped) if self._n_skipped is None else self._n_skipped
         return ['thread finished processing...:', '%d observations' % self.num_observations,
-                '%d positions' % len(self.pos_set), '%d regions with multiple methylated bases' % len(self.multi),
-                '%d observations with skips included' % len(self.w_skips),
-                '%d observations with too many skips' % len(self.skipped)]
+                '%d positions' % n_pos, '%d regions with multiple methylated bases' % n_multi,
+                '%d observations with skips included' % n_wskips,
+                '%d observations with too many skips' % n_skipped]
+
+    def _bind(self, rec):
+        P, k, t = self.P, self.k, self.P.table
+        n = rec.n
+        self._rec = rec
+        self._feats = rec.feats[:n * k].reshape(n, k)
+        self._info = rec.info[:n]
+        self._site_pos = rec.site_pos[:n]
+        self._seg_of = rec.site_seg[:n]
+        self._close_seg = np.searchsorted(t.seg_row_begin, rec.close_row[:n], side='right') - 1
 
     def run(self, rec):
         """Returns None, or the exception (SystemExit / error) the reference would raise at that record."""
-        P, k, t = self.P, self.k, self.P.table
+        self._bind(rec)
         n = rec.n
-        feats = rec.feats[:n * k].reshape(n, k)
-        info = rec.info[:n]
-        site_pos = rec.site_pos[:n]
-        seg_of = rec.site_seg[:n]
-        close_seg = np.searchsorted(t.seg_row_begin, rec.close_row[:n], side='right') - 1
+        if self.train or n == 0:
+            for j in range(n):
+                stop = self._one(j)
+                if stop is not None:
+                    return stop
+            return None
+        P, t = self.P, self.P.table
+        label_meth = 'm6A' if self.base == 'A' else 'm' + self.base                # :200-204
+        fmt = _lib.DiffsFormatter(rec, t, P.ref.device_arrays(), P.ref.names, [str(q) for q in P.qual_obj], self.k,
+                                  label_meth, self.base, self.soc, tail_chrom=self.tail_chrom)
+        first, done_to, stop_exc = 0, n, None
+        while first < n:
+            blob, n_rows, stop = fmt.rows(first)
+            self.blobs.append(blob)
+            self.num_observations += n_rows
+            if stop >= n:
+                break
+            stop_exc = self._one(stop)                   # the record the formatter handed back
+            if stop_exc is not None:
+                done_to = stop
+                break
+            first = stop + 1
+        self._count(done_to)
+        return stop_exc
+
+    def _count(self, n):
+        """The four sets of :184-185,:234-239,:247-248 over records [0, n), vectorised (set sizes only)."""
+        info = self._info[:n]
+        rid = self.P.table.seg_read[self._seg_of[:n]].astype(np.int64)
+        key = (rid << 32) | (self._site_pos[:n].astype(np.int64) & 0xFFFFFFFF)
+        too = (info & _I.I_TOO_MANY) != 0
+        self._n_skipped = len(np.unique(key[too]))
+        self._n_wskips = len(np.unique(key[~too & ((info & _I.I_EMPTY_MASK) != 0)]))
+        self._n_pos = len(np.unique(self._site_pos[:n][~too]))
+        self._n_multi = len(np.unique(key[(info & _I.I_MULTI) != 0]))
+
+    def _one(self, j):
+        P, k, t = self.P, self.k, self.P.table
+        rec, feats = self._rec, self._feats
         names = t.read_names
         half = int((2 * k - 1) / 2)
-        for j in range(n):
-            inf = int(info[j])
-            seg = int(seg_of[j])
-            rid = int(t.seg_read[seg])
-            read, mpos = names[rid], int(site_pos[j])
-            rev = bool(inf & _I.I_REV)
-            if inf & _I.I_TOO_MANY:
-                self.skipped.add((read, mpos))                                    # :239
-            else:
-                empty = inf & _I.I_EMPTY_MASK
-                if empty:
-                    self.w_skips.add((read, mpos))                                # :184-185
-                diffs = [0 if (empty >> i) & 1 else float(feats[j, i]) for i in range(k)]
-                qual = P.qual_obj[rid]
-                diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[j, i]) for i in range(k)]
-                                     + [str(qual)])
-                cseg = int(close_seg[j])
-                chrom = self.tail_chrom if cseg >= t.n_seg else P.ref.names[int(t.seg_contig[cseg])]
-                last_ref = P.ref.meth[int(t.seg_contig[seg])][1 if rev else 0]
-                context = revcomp(last_ref[mpos - k + 1:mpos + k], rev)           # :194 (Python slicing rules)
-                line = read + '\t' + str(mpos) + '\t' + context + '\t' + diffs_txt + '\t' + strand(rev)
-                centre = int(len(context) / 2)
-                if context[centre] == 'M':                                        # IndexError propagates, as there
-                    try:
-                        twobase_model = self.table[context[centre:centre + 2]]
-                        if not self.train:
-                            mi = self.model_index[twobase_model]                  # KeyError: model[...] :199
-                            p1 = rec.prob[j]
-                            want = (inf >> _I.I_NEXT_SHIFT) & 0xFF
-                            if (inf & _I.I_EDGE) or np.isnan(p1):
-                                dev = self.device if self.device is not None else get_device()
-                                p1 = dev.mlp_forward(np.array([diffs + [float(qual)]], dtype=np.float64),
-                                                     np.array([mi], dtype=np.uint8))[0]
-                            elif len(context) > half + 1 and ord(context[half + 1]) != want:
-                                raise AssertionError('device and host disagree on the sub-model of %s' % line)
-                            if p1 >= 0.5:
-                                label = 'm6A' if self.base == 'A' else 'm' + self.base
-                            else:
-                                label = self.base
-                            label = label + '\t' + fmt_float(round2(p1))          # :207
+        inf = int(self._info[j])
+        seg = int(self._seg_of[j])
+        rid = int(t.seg_read[seg])
+        read, mpos = names[rid], int(self._site_pos[j])
+        rev = bool(inf & _I.I_REV)
+        if inf & _I.I_TOO_MANY:
+            self.skipped.add((read, mpos))                                    # :239
+        else:
+            empty = inf & _I.I_EMPTY_MASK
+            if empty:
+                self.w_skips.add((read, mpos))                                # :184-185
+            diffs = [0 if (empty >> i) & 1 else float(feats[j, i]) for i in range(k)]
+            qual = P.qual_obj[rid]
+            diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[j, i]) for i in range(k)]
+                                 + [str(qual)])
+            cseg = int(self._close_seg[j])
+            chrom = self.tail_chrom if cseg >= t.n_seg else P.ref.names[int(t.seg_contig[cseg])]
+            last_ref = P.ref.meth[int(t.seg_contig[seg])][1 if rev else 0]
+            context = revcomp(last_ref[mpos - k + 1:mpos + k], rev)           # :194 (Python slicing rules)
+            line = read + '\t' + str(mpos) + '\t' + context + '\t' + diffs_txt + '\t' + strand(rev)
+            centre = int(len(context) / 2)
+            if context[centre] == 'M':                                        # IndexError propagates, as there
+                try:
+                    twobase_model = self.table[context[centre:centre + 2]]
+                    if not self.train:
+                        mi = self.model_index[twobase_model]                  # KeyError: model[...] :199
+                        p1 = rec.prob[j]
+                        want = (inf >> _I.I_NEXT_SHIFT) & 0xFF
+                        if (inf & _I.I_EDGE) or np.isnan(p1):
+                            dev = self.device if self.device is not None else get_device()
+                            p1 = dev.mlp_forward(np.array([diffs + [float(qual)]], dtype=np.float64),
+                                                 np.array([mi], dtype=np.uint8))[0]
+                        elif len(context) > half + 1 and ord(context[half + 1]) != want:
+                            raise AssertionError('device and host disagree on the sub-model of %s' % line)
+                        if p1 >= 0.5:
+                            label = 'm6A' if self.base == 'A' else 'm' + self.base
                         else:
-                            label = self.pos_label[(chrom, mpos, strand(rev))]    # :210
-                            self.signals[twobase_model].setdefault(label, []).append(diffs + [qual])
-                            self.contexts[twobase_model].setdefault(label, []).append(context)
-                        self.rows.append([chrom, read, str(mpos), context, diffs_txt, strand(rev), label])
-                    except (IndexError, KeyError) as e:                           # :218-223
-                        print(line, '- Index or Key Error')
-                        print(list(self.model_keys or []), list(self.table.keys()), context[centre:centre + 2])
-                        print(e)
-                        return SystemExit(0)
-                else:                                                             # :224-228
-                    print(line)
+                            label = self.base
+                        label = label + '\t' + fmt_float(round2(p1))          # :207
+                    else:
+                        label = self.pos_label[(chrom, mpos, strand(rev))]    # :210
+                        self.signals[twobase_model].setdefault(label, []).append(diffs + [qual])
+                        self.contexts[twobase_model].setdefault(label, []).append(context)
+                    row = [chrom, read, str(mpos), context, diffs_txt, strand(rev), label]
+                    self.blobs.append(('\t'.join(row) + '\n').encode('utf-8', 'surrogateescape'))
+                except (IndexError, KeyError) as e:                           # :218-223
+                    print(line, '- Index or Key Error')
+                    print(list(self.model_keys or []), list(self.table.keys()), context[centre:centre + 2])
+                    print(e)
                     return SystemExit(0)
-                self.num_observations += 1
-                self.pos_set.add(mpos)
-            if inf & _I.I_MULTI:
-                self.multi.add((read, mpos))                                      # :247-248
+            else:                                                             # :224-228
+                print(line)
+                return SystemExit(0)
+            self.num_observations += 1
+            self.pos_set.add(mpos)
+        if inf & _I.I_MULTI:
+            self.multi.add((read, mpos))                                      # :247-248
         return None
 
 
@@ -237,9 +309,9 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
     if stop is not None:
         # the reference dies mid-file: only the 5000-row batches already flushed are on disk (:230-232)
         n_written = (fin.num_observations // 5000) * 5000
-        writefi(fin.rows[:n_written], tsv_output)
+        write_text(fin.text(n_written), tsv_output)
         raise stop
-    writefi(fin.rows, tsv_output)                                                 # :293
+    write_text(fin.text(), tsv_output)                                            # :293
     if timing:
         t_end = time.perf_counter()
         print('[mcaller_amd timing] rows=%d records=%d  parse+mark %.3f s | upload+kernels+fetch %.3f s (kernels %s ms) | '

@@ -130,3 +130,39 @@ def test_micro_cases(tmp_path):
             if H.plain_signals(fin.signals) != exp['train']['signals'] or fin.contexts != exp['train']['contexts']:
                 bad.append((case['seed'], case['flavour'], 'train dicts'))
     assert not bad, '%d of %d micro-cases differ: %s' % (len(bad), len(cases), bad[:10])
+
+
+def test_native_formatter_equals_per_record_path(td, tmp_path):
+    """mc_format_diffs (multi-threaded) writes the same bytes as the literal per-record transcription, on the dense
+    `-m A` run (2713 rows, empty-slot zeros with -s 2) and with records handed back to the host in between."""
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    read2qual = extract_read_quality(td['fastq'])
+    modelset = H.load_modelset('r95')
+    for skip in (0, 2):
+        P = ec.prepare(td['tsv'], td['fasta'], read2qual, 0, os.path.getsize(td['tsv']), 'A', 'A', None)
+        rec = H.oracle_records(P.table, P.ref.device_arrays(), P.qual, 6, skip, 0)
+        _, weights, _, soc = ec.submodel_setup(modelset, 'A')
+        H.oracle_score(rec, P.table, P.qual, weights, soc, 6)
+        native = ec.Finisher(P, 6, 'A', False, modelset=modelset)
+        with contextlib.redirect_stdout(io.StringIO()):
+            assert native.run(rec) is None
+        literal = ec.Finisher(P, 6, 'A', False, modelset=modelset)
+        literal._bind(rec)
+        for j in range(rec.n):
+            assert literal._one(j) is None
+        assert native.text() == literal.text() and native.num_observations == literal.num_observations > 2000
+        assert native.counters() == literal.counters()
+        # hand every 97th scored record back to the host (NaN probability -> the host asks the device classifier)
+        keep = rec.prob[:rec.n].copy()
+        scored = np.nonzero((rec.info[:rec.n] & ec._I.I_TOO_MANY) == 0)[0][::97]
+        handed_back = iter(scored)
+
+        class _Dev(object):
+            def mlp_forward(self, X, sub):           # records come back in order: answer with the value taken away
+                return np.array([keep[next(handed_back)]])
+        rec.prob[scored] = np.nan
+        mixed = ec.Finisher(P, 6, 'A', False, modelset=modelset, device=_Dev())
+        assert mixed.run(rec) is None
+        rec.prob[:rec.n] = keep
+        assert mixed.text() == literal.text() and mixed.counters() == literal.counters()

@@ -40,3 +40,24 @@ def test_float_formatting_matches_numpy_str():
         p = rng.random()
         assert fmt_float(round2(p)) == str(np.round(np.float64(p), 2))
         assert po.round_dec(p, 2) == float(np.round(np.float64(p), 2))
+
+
+def test_native_repr_matches_python():
+    """mc_repr_double (the native .diffs formatter's number printing) == repr(float) == str(np.float64)."""
+    import struct
+    from mcaller_amd._lib import repr_double
+    rng = random.Random(11)
+    vals = [0.0, -0.0, 1.0, -2.5, 1e-5, 1e-4, 9.999e-5, 0.0001, 0.001, 123456789.125, 1e15, 1e16, 9999999999999998.0, 1e17,
+            1.5e300, 5e-324, 2.2250738585072014e-308, 0.1 + 0.2, 7.055265349382997, float('inf'), float('-inf'), 100.0, 12.0]
+    vals += [rng.uniform(-10, 10) for _ in range(20000)] + [rng.uniform(-1e-3, 1e-3) for _ in range(5000)]
+    vals += [round(rng.uniform(-30, 30), 4) for _ in range(20000)]                    # what slot means look like
+    vals += [rng.randrange(-400000, 400000) / 10000.0 / rng.randrange(1, 9) for _ in range(20000)]
+    vals += [struct.unpack('<d', struct.pack('<Q', rng.getrandbits(64)))[0] for _ in range(20000)]   # any bit pattern
+    for v in vals:
+        if v != v:
+            assert repr_double(v) == 'nan'
+        else:
+            assert repr_double(v) == repr(v), v
+    for _ in range(5000):
+        p = rng.random()
+        assert repr_double(float(np.round(np.float64(p), 2))) == str(np.round(np.float64(p), 2))
