@@ -2,8 +2,9 @@
 """Per-position summary of an mCaller `.diffs.<n>` file: the BED writer of the reference's make_bed.py:67-164, plus the
 same reduction computed from flush records with an all-reduce over ranks (the one exchange step of the multi-GPU path).
 
-Supported: -f, -d, -t, -p (positions mode without the t-test columns is NOT offered: use the reference for those),
---control, --vo, --gff (without --vo statistics), --ref.  Plotting options are out of scope.
+Supported: -f, -d, -t, -p (per-position one-sample t-tests, make_bed.py:115-127; needs scipy, like the reference),
+--control, --vo, --gff (with --vo: fracLow/fracUp/identificationQv, make_bed.py:146-149), --ref.  Plotting options are
+out of scope.
 """
 import os
 import sys
@@ -11,6 +12,16 @@ import sys
 import numpy as np
 
 from .refmark import read_fasta, revcomp
+
+
+def make_pos_set(pos_list):
+    """make_bed.py:13-19: (chrom, start, end, strand) of every line longer than 3 characters."""
+    pos_set = set()
+    with open(pos_list, 'r') as fi:
+        for line in fi:
+            if len(line) > 3:
+                pos_set.add(tuple(line.strip().split('\t')[:4]))
+    return pos_set
 
 
 def check_thresh(locus_list, mod_thresh, depth_thresh, control):
@@ -40,11 +51,10 @@ def ref2context(ref, pos_dict):
 def aggregate_by_pos(meth_fi, aggfi, depth_thresh, mod_thresh, pos_list, control, verbose_results, gff, ref,
                      plot=False, plotdir=None, plotsummary=False):
     """make_bed.py:67-164 for the non-plotting, non-positions modes."""
-    if pos_list:
-        raise NotImplementedError('make_bed -p (per-position t-tests) is outside the accelerated path')
     if plot or plotsummary:
         raise NotImplementedError('plotting is out of scope')
-    pos_dict, pos_dict_verbose = {}, {}
+    pos_dict, pos_dict_verbose, values_dict = {}, {}, {}
+    pos_set = make_pos_set(pos_list) if pos_list else None
     for line in open(meth_fi, 'r'):
         try:
             csome, read, pos, context, values, strand, label, prob = tuple(line.split('\t'))
@@ -52,41 +62,63 @@ def aggregate_by_pos(meth_fi, aggfi, depth_thresh, mod_thresh, pos_list, control
             csome, read, pos, context, values, strand, label = tuple(line.split('\t'))
             prob = ''
         nextpos = str(int(pos) + 1)
-        if context[int(len(context) / 2)] != 'M':
+        if (pos_list and (csome, pos, nextpos, strand) not in pos_set) or context[int(len(context) / 2)] != 'M':
             continue
         key = (csome, pos, nextpos, context, strand)
         if key not in pos_dict:
             pos_dict[key] = []
             pos_dict_verbose[key] = []
+            values_dict[key] = []
+        if pos_list:
+            values_dict[key].append([float(v) for v in values.split(',')][:-1])
         pos_dict[key].append(1 if label[0] == 'm' else 0)
         if verbose_results:
             pos_dict_verbose[key].append(prob.strip())
-    print({key: [] for key in pos_dict})                               # make_bed.py:101 prints values_dict
+    print(values_dict)                                                 # make_bed.py:101
+    if pos_list:                                                       # make_bed.py:115-127
+        from scipy import stats
+        for locus in values_dict:
+            cols = np.asarray(values_dict[locus], dtype=np.float64)
+            pvals = []
+            for i in range(cols.shape[1]):
+                ttest = stats.ttest_1samp(cols[:, i], 0)
+                pvals.append((ttest[1], ttest[0]))
+            pval = (sum([-np.log10(x[0]) for x in pvals]), max([x[1] for x in pvals]))
+            values_dict[locus] = [np.round(x, 3) for x in [pval[1], pval[0]]]
     context_dict = ref2context(ref, pos_dict) if ref else None
     count = 0
     with open(aggfi, 'w') as outfi:
         for locus in pos_dict.keys():
-            if not check_thresh(pos_dict[locus], mod_thresh, depth_thresh, control):
+            a = (not pos_list) and check_thresh(pos_dict[locus], mod_thresh, depth_thresh, control)
+            b = pos_list and (locus[0], locus[1], locus[2], locus[4]) in pos_set
+            if not (a or b):
                 continue
             cx = context_dict[locus] if ref else locus[3]
             count += 1
             frac = np.mean(pos_dict[locus])
             if gff:
                 deets = 'coverage=' + str(len(pos_dict[locus])) + ';context=' + cx + ';IPDRatio=5;frac=' + str(frac)
-                if verbose_results:
-                    raise NotImplementedError('--gff --vo (scipy.stats.sem columns) is not offered')
+                if verbose_results:                                    # make_bed.py:146-149
+                    from scipy import stats
+                    probs = [float(x) for x in pos_dict_verbose[locus]]
+                    se_95 = 2 * stats.sem(probs)
+                    deets = (deets + ';fracLow=' + str(frac - se_95) + ';fracUp=' + str(frac + se_95) +
+                             ';identificationQv=' + str(int(100 * np.mean(probs))))
                 outfi.write('\t'.join([locus[0], 'kinModCall', 'm6A', locus[2], locus[2], '10', locus[4], '.', deets]) + '\n')
             else:
                 print(aggfi)
                 out_line = '\t'.join(list(locus)[:-1] + [str(np.mean(pos_dict[locus]))] + [locus[-1]] +
                                      [str(len(pos_dict[locus]))])
+                if pos_list:
+                    out_line = out_line + '\t' + '\t'.join([str(x) for x in values_dict[locus]])
                 if verbose_results:
                     out_line = out_line + '\t' + ','.join(pos_dict_verbose[locus])
                 outfi.write(out_line + '\n')
-    if not control:
-        print(count, 'methylated loci found with min depth', depth_thresh, 'reads')
-    else:
-        print(count, 'unmethylated loci found with min depth', depth_thresh, 'reads')
+    if not pos_list:
+        if not control:
+            print(count, 'methylated loci found with min depth', depth_thresh, 'reads')
+        else:
+            print(count, 'unmethylated loci found with min depth', depth_thresh, 'reads')
 
 
 # ---- the same reduction from flush records, summed over ranks -----------------------------------------------------
