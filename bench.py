@@ -103,39 +103,62 @@ def main():
         elapsed_max, calls_total = float(t[0]), int(c[0])
 
     # the one exchange step of the multi-GPU job: per-site counts summed over ranks (feeds make_bed).  Outside the timed
-    # steps; RCCL when torch's nccl backend comes up, else the gloo group that already carries the barrier.
+    # steps.  Counted on the device from the records of the last step and all-reduced with RCCL through the C ABI
+    # (mc_site_counts / mc_site_allreduce); if that fails (e.g. a plumbing test with two ranks on one GPU) the same
+    # reduction goes through torch.distributed (nccl, then gloo) from the host copy of the records.
     reduction = None
     if dist is not None:
+        from mcaller_amd import make_bed
+        index = make_bed.SiteIndex(ref.meth, 1)
+        e_native = None
         try:
-            from mcaller_amd import make_bed
-            import torch
-            index = make_bed.SiteIndex(ref.meth, 1)
-            counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
-            def reduce_with(backend):
-                group = dist.new_group(backend=backend) if backend == 'nccl' else None
-                packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
-                fmin = torch.from_numpy(counts[2].copy())
-                if backend == 'nccl':
-                    torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
-                    packed, fmin = packed.cuda(), fmin.cuda()
-                t_r = time.perf_counter()
-                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-                dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
-                if backend == 'nccl':
-                    torch.cuda.synchronize()
-                return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
-
-            backend = 'nccl'
+            uid = [None]
             try:
-                packed, fmin, ms = reduce_with('nccl')
-            except Exception as e_nccl:                        # noqa  (e.g. two ranks sharing one GPU in a plumbing test)
-                backend = 'gloo (nccl failed: %s)' % type(e_nccl).__name__
-                packed, fmin, ms = reduce_with('gloo')
-            total_obs = int(packed[1].sum().item())
-            reduction = {'backend': backend, 'ms': ms, 'observations': total_obs,
-                         'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
+                if rank == 0:
+                    uid = [Device.comm_unique_id()]           # loads librccl.so
+            finally:
+                dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
+                raise RuntimeError('rank 0 could not create an RCCL unique id')
+            dev.comm_init(world, rank, uid[0])
+            dev.site_counts(row_offset=rank * n_rows)
+            n_meth, n_total, fmin, ms = dev.site_allreduce()
         except Exception as e:                                 # noqa
-            reduction = {'error': '%s: %s' % (type(e).__name__, e)}
+            e_native = e
+        flags = [None] * world
+        dist.all_gather_object(flags, e_native is None)        # every rank takes the same branch
+        if all(flags):
+            reduction = {'backend': 'rccl (ncclAllReduce through the C ABI)', 'ms': ms, 'observations': int(n_total.sum()),
+                         'observations_expected': calls_total, 'bytes': int(index.n * 16), 'sites': int(index.n)}
+        else:
+            try:
+                import torch
+                counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
+
+                def reduce_with(backend):
+                    group = dist.new_group(backend=backend) if backend == 'nccl' else None
+                    packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
+                    fmin = torch.from_numpy(counts[2].copy())
+                    if backend == 'nccl':
+                        torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
+                        packed, fmin = packed.cuda(), fmin.cuda()
+                    t_r = time.perf_counter()
+                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                    dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
+                    if backend == 'nccl':
+                        torch.cuda.synchronize()
+                    return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
+
+                backend = 'torch nccl (native RCCL path failed: %s)' % e_native
+                try:
+                    packed, fmin, ms = reduce_with('nccl')
+                except Exception as e_nccl:                    # noqa
+                    backend = 'gloo (native: %s; torch nccl: %s)' % (e_native, type(e_nccl).__name__)
+                    packed, fmin, ms = reduce_with('gloo')
+                reduction = {'backend': backend, 'ms': ms, 'observations': int(packed[1].sum().item()),
+                             'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
+            except Exception as e:                             # noqa
+                reduction = {'error': '%s: %s' % (type(e).__name__, e)}
 
     if rank == 0:
         k1 = float(np.mean(k1_ms))

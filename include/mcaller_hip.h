@@ -151,6 +151,25 @@ int mc_ctx_sync(mc_ctx *ctx);
 int mc_mlp_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 int mc_forest_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 
+/* ===== per-site reduction feeding make_bed (make_bed.py:86-96,:134,:143,:154), the one exchange step of a multi-GPU job =====
+ * Sites = every 'M' of the marked strands, numbered per contig: '+' sites by position, then '-' sites by position
+ * (mcaller_amd.make_bed.SiteIndex uses the same order).  Each rank reduces the records of its own last
+ * mc_extract_features call on the device; mc_site_allreduce sums the counts and takes the minimum first-seen row over
+ * the ranks with ncclAllReduce (RCCL over xGMI; librccl.so is loaded on first use) and copies the result out. */
+#define MC_UNIQUE_ID_BYTES 128
+int64_t mc_site_count(mc_ctx *ctx);                       /* number of marked sites of the reference in the ctx */
+/* counts of this rank: n_meth / n_total per site (label 'm..' <=> p >= 0.5, :200) and the smallest close_row +
+ * row_offset (global row of the first occurrence, :134).  Records whose probability is NaN (scored by the host) are
+ * left out and counted in *n_pending: add them with mc_site_counts_add. */
+int mc_site_counts(mc_ctx *ctx, int64_t row_offset, int64_t *n_pending);
+int mc_site_counts_add(mc_ctx *ctx, const int64_t *site, const uint8_t *is_meth, const int64_t *first_row, int64_t n);
+int mc_comm_unique_id(uint8_t *out128);                   /* rank 0: ncclGetUniqueId; ship the bytes to every rank */
+int mc_comm_init(mc_ctx *ctx, int32_t world, int32_t rank, const uint8_t *unique_id128);   /* ncclCommInitRank */
+int mc_comm_destroy(mc_ctx *ctx);
+/* all-reduce (if a communicator with world > 1 is set) + D2H: n_meth[n], n_total[n] int32, first_row[n] int64
+ * (INT64_MAX: site not seen); *ms = time of the two collectives (hipEvents). */
+int mc_site_allreduce(mc_ctx *ctx, int32_t *n_meth, int32_t *n_total, int64_t *first_row, float *ms);
+
 /* ===== native `.diffs.<k>` row formatter (host), replaces the text assembly of the flush, extract_contexts.py:186-216 ===== */
 typedef struct mc_format_args {
     const mc_calls_view *rec;          /* flush records in host memory (mc_fetch_records / _view)                  */

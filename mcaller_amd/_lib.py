@@ -96,6 +96,14 @@ def lib():
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_forest_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_ctx_set_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.mc_site_count.argtypes = [C.c_void_p]
+        L.mc_site_count.restype = C.c_int64
+        L.mc_site_counts.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.mc_site_counts_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.mc_comm_unique_id.argtypes = [C.c_void_p]
+        L.mc_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.mc_comm_destroy.argtypes = [C.c_void_p]
+        L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_free.argtypes = [C.c_void_p]

@@ -115,6 +115,10 @@ struct DevRef {
     int64_t *contig_len = nullptr, *seq_off = nullptr, *word_off = nullptr;
     uint8_t *seq = nullptr;
     uint32_t *mf = nullptr, *mr = nullptr;
+    // site numbering for the per-site reduction: marked sites in (contig, strand, position) order
+    int32_t *rank_f = nullptr, *rank_r = nullptr;   // [n_words] set bits of the contig's mask before this word
+    int64_t *site_base = nullptr;                   // [2 * n_contigs] number of the first site of (contig, strand)
+    int64_t n_sites = 0;
 };
 
 struct DevRecords {
@@ -1831,6 +1835,12 @@ struct mc_ctx {
     int64_t last_n = 0;
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
+    // per-site reduction (mc_site_*): counts on the device, RCCL communicator
+    int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
+    int64_t *site_first = nullptr;    // [n_sites]
+    int64_t site_n = 0;
+    void *comm = nullptr;             // ncclComm_t
+    int comm_world = 1, comm_rank = 0;
 };
 
 template <typename Tp>
@@ -1886,6 +1896,8 @@ static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
     return 0;
 }
 
+extern "C" int mc_comm_destroy(mc_ctx *c);
+
 extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     *out = nullptr;
     int n = 0;
@@ -1931,6 +1943,9 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     free_pool(c->lit_allocs);
     if (c->qual) (void)hipFree(c->qual);
     if (c->cnt) (void)hipFree(c->cnt);
+    if (c->site_cnt) (void)hipFree(c->site_cnt);
+    if (c->site_first) (void)hipFree(c->site_first);
+    mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     free_pinned(c->H);
     (void)hipStreamDestroy(c->copy_stream);
@@ -1962,7 +1977,32 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     UP(R.seq, h->seq, h->n_seq_bytes, c->ref_allocs);
     UP(R.mf, h->mbits_fwd, h->n_words, c->ref_allocs);
     UP(R.mr, h->mbits_rev, h->n_words, c->ref_allocs);
+    // site numbers: per contig, all '+' sites then all '-' sites, ascending position
+    std::vector<int32_t> rank_f((size_t)h->n_words + 1), rank_r((size_t)h->n_words + 1);
+    std::vector<int64_t> base((size_t)h->n_contigs * 2 + 2);
+    int64_t n_sites = 0;
+    for (int32_t ci = 0; ci < h->n_contigs; ++ci) {
+        const int64_t w0 = h->word_off[ci], w1 = ci + 1 < h->n_contigs ? h->word_off[ci + 1] : h->n_words;
+        for (int st = 0; st < 2; ++st) {
+            const uint32_t *bits = st ? h->mbits_rev : h->mbits_fwd;
+            std::vector<int32_t> &rank = st ? rank_r : rank_f;
+            base[(size_t)ci * 2 + st] = n_sites;
+            int32_t run = 0;
+            for (int64_t w = w0; w < w1; ++w) {
+                rank[(size_t)w] = run;
+                run += __builtin_popcount(bits[w]);
+            }
+            n_sites += run;
+        }
+    }
+    R.n_sites = n_sites;
+    UP(R.rank_f, rank_f.data(), h->n_words, c->ref_allocs);
+    UP(R.rank_r, rank_r.data(), h->n_words, c->ref_allocs);
+    UP(R.site_base, base.data(), (size_t)h->n_contigs * 2, c->ref_allocs);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->site_cnt) { (void)hipFree(c->site_cnt); c->site_cnt = nullptr; }
+    if (c->site_first) { (void)hipFree(c->site_first); c->site_first = nullptr; }
+    c->site_n = 0;
     return 0;
 }
 
@@ -2377,4 +2417,225 @@ extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submode
 
 extern "C" int mc_forest_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
     return classifier_forward(c, true, X, submodel, n, p);
+}
+
+// ===================================================================================================
+// Per-site reduction feeding make_bed (make_bed.py:86-96: per (chrom, pos, strand) the list of 0/1 labels; :143,:154
+// its mean and length; :134 rows in first-occurrence order).  Each rank counts its own records on the device; the
+// one exchange step of the multi-GPU job is an all-reduce (sum of the counts, min of the first-seen row) over RCCL.
+// ===================================================================================================
+namespace {
+
+// site number of (contig, strand, position); -1 if the position is not a marked site
+__device__ __forceinline__ int64_t site_number(const DevRef &R, int contig, int rev, int64_t pos) {
+    if (contig < 0 || contig >= R.n_contigs || pos < 0 || pos >= R.contig_len[contig]) return -1;
+    const int64_t w = R.word_off[contig] + (pos >> 5);
+    const uint32_t word = (rev ? R.mr : R.mf)[w];
+    if (!((word >> (pos & 31)) & 1u)) return -1;
+    const int before = (rev ? R.rank_r : R.rank_f)[w] + __popc(word & ((1u << (pos & 31)) - 1u));
+    return R.site_base[contig * 2 + rev] + before;
+}
+
+__global__ void k_site_fill(int32_t *cnt, int64_t *first, int64_t n_sites) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < 2 * n_sites) cnt[i] = 0;
+    if (i < n_sites) first[i] = INT64_MAX;
+}
+
+// one thread per flush record: scored, unskipped records add to their site (label 'm...' <=> p >= 0.5, :200)
+__global__ void k_site_counts(DevRef R, DevRecords O, int64_t n, const int32_t *__restrict__ seg_contig, int64_t row_offset,
+                              int32_t *__restrict__ cnt, int64_t *__restrict__ first, int64_t n_sites,
+                              unsigned long long *__restrict__ status) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t info = O.info[j];
+    if (info & MC_I_TOO_MANY) return;
+    const double p = O.prob[j];
+    if (p != p) { atomicAdd(&status[0], 1ull); return; }           // scored by the host (edge records): added by the caller
+    const int64_t s = site_number(R, seg_contig[O.site_seg[j]], (info & MC_I_REV) ? 1 : 0, O.site_pos[j]);
+    if (s < 0) { atomicAdd(&status[1], 1ull); return; }
+    atomicAdd(&cnt[n_sites + s], 1);
+    if (p >= 0.5) atomicAdd(&cnt[s], 1);
+    atomicMin(reinterpret_cast<long long *>(&first[s]), (long long)(O.close_row[j] + row_offset));
+}
+
+}  // namespace
+
+static int ensure_site_buffers(mc_ctx *c) {
+    const int64_t n = c->R.n_sites;
+    if (c->site_cnt && c->site_n == n) return 0;
+    if (c->site_cnt) (void)hipFree(c->site_cnt);
+    if (c->site_first) (void)hipFree(c->site_first);
+    c->site_cnt = nullptr; c->site_first = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->site_cnt, std::max<size_t>((size_t)n * 8, 256)));
+    HIP_TRY(hipMalloc((void **)&c->site_first, std::max<size_t>((size_t)n * 8, 256)));
+    c->site_n = n;
+    return 0;
+}
+
+extern "C" int64_t mc_site_count(mc_ctx *c) { return c->R.n_sites; }
+
+extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int64_t *n_pending) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->R.mf) {
+        mc_set_error("mc_site_counts: no reference set");
+        return -12;
+    }
+    if (int rc = ensure_site_buffers(c)) return rc;
+    const int64_t ns = c->R.n_sites, n = c->last_n;
+    unsigned long long *status = nullptr;
+    HIP_TRY(hipMalloc((void **)&status, 16));
+    HIP_TRY(hipMemsetAsync(status, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
+    if (n > 0)
+        hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->R, c->O, n,
+                           (const int32_t *)c->T.seg_contig, row_offset, c->site_cnt, c->site_first, ns, status);
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    (void)hipFree(status);
+    if (h[1]) {
+        mc_set_error("mc_site_counts: %llu records name a position that is not a marked site", h[1]);
+        return -14;
+    }
+    if (n_pending) *n_pending = (int64_t)h[0];
+    return 0;
+}
+
+extern "C" int mc_site_counts_add(mc_ctx *c, const int64_t *site, const uint8_t *is_meth, const int64_t *first_row, int64_t n) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->site_cnt) {
+        mc_set_error("mc_site_counts_add: call mc_site_counts first");
+        return -12;
+    }
+    const int64_t ns = c->site_n;
+    if (n <= 0) return 0;
+    // rare (records the host scored itself): read-modify-write from the host
+    std::vector<int32_t> cnt((size_t)ns * 2);
+    std::vector<int64_t> first((size_t)ns);
+    HIP_TRY(hipMemcpy(cnt.data(), c->site_cnt, (size_t)ns * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first.data(), c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = site[i];
+        if (s < 0 || s >= ns) {
+            mc_set_error("mc_site_counts_add: site %lld out of range", (long long)s);
+            return -12;
+        }
+        cnt[(size_t)(ns + s)] += 1;
+        if (is_meth[i]) cnt[(size_t)s] += 1;
+        first[(size_t)s] = std::min(first[(size_t)s], first_row[i]);
+    }
+    HIP_TRY(hipMemcpy(c->site_cnt, cnt.data(), (size_t)ns * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->site_first, first.data(), (size_t)ns * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---- RCCL, loaded on first use (the library is only needed by multi-GPU jobs) ----
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.h) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        mc_set_error("cannot load librccl.so: %s", dlerror());
+        return -15;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GetErrorString) {
+        mc_set_error("librccl.so lacks an expected symbol");
+        dlclose(h);
+        return -15;
+    }
+    g_rccl.h = h;
+    return 0;
+}
+}  // namespace
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t _r = (expr);                                                                   \
+        if (_r != ncclSuccess) {                                                                    \
+            mc_set_error("%s failed: %s", #expr, g_rccl.GetErrorString(_r));                        \
+            return -15;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == MC_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int mc_comm_unique_id(uint8_t *out) {
+    if (int rc = rccl_load()) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(out, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int mc_comm_init(mc_ctx *c, int32_t world, int32_t rank, const uint8_t *unique_id) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (world < 1 || rank < 0 || rank >= world) {
+        mc_set_error("mc_comm_init: rank %d of %d", rank, world);
+        return -12;
+    }
+    if (int rc = rccl_load()) return rc;
+    mc_comm_destroy(c);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    c->comm_world = world;
+    c->comm_rank = rank;
+    return 0;
+}
+
+extern "C" int mc_comm_destroy(mc_ctx *c) {
+    if (c && c->comm && g_rccl.h) {
+        (void)hipSetDevice(c->device);
+        (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    }
+    if (c) c->comm = nullptr;
+    return 0;
+}
+
+extern "C" int mc_site_allreduce(mc_ctx *c, int32_t *n_meth, int32_t *n_total, int64_t *first_row, float *ms) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->site_cnt) {
+        mc_set_error("mc_site_allreduce: call mc_site_counts first");
+        return -12;
+    }
+    const int64_t ns = c->site_n;
+    if (ms) *ms = 0.f;
+    if (c->comm && c->comm_world > 1 && ns > 0) {
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        RCCL_TRY(g_rccl.AllReduce(c->site_cnt, c->site_cnt, (size_t)ns * 2, ncclInt32, ncclSum, (ncclComm_t)c->comm, c->stream));
+        RCCL_TRY(g_rccl.AllReduce(c->site_first, c->site_first, (size_t)ns, ncclInt64, ncclMin, (ncclComm_t)c->comm, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    }
+    if (ns > 0) {
+        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
 }

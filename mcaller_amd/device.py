@@ -120,6 +120,45 @@ class Device(object):
         return dict(strand_resolve=float(t[0]), window_scan=float(t[1]), emit=float(t[2]), classifier=float(t[3]),
                     total=float(t[4]))
 
+    # ---- per-site reduction feeding make_bed (the one exchange step of a multi-GPU job) ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId (call on rank 0, ship the 128 bytes to every rank)."""
+        buf = np.zeros(128, dtype=np.uint8)
+        check(lib().mc_comm_unique_id(_ptr(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, world, rank, unique_id):
+        """ncclCommInitRank on this GPU (RCCL over xGMI); collective over all ranks."""
+        uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        assert len(uid) == 128
+        check(lib().mc_comm_init(self._ctx, int(world), int(rank), _ptr(uid)))
+
+    def comm_destroy(self):
+        lib().mc_comm_destroy(self._ctx)
+
+    def site_counts(self, row_offset=0):
+        """Per-site counts of the last run's records, on the device.  Returns how many records the host scored itself
+        (NaN probability on the device): add those with site_counts_add."""
+        pending = C.c_int64(0)
+        check(lib().mc_site_counts(self._ctx, int(row_offset), C.byref(pending)))
+        return pending.value
+
+    def site_counts_add(self, site, is_meth, first_row):
+        site = np.ascontiguousarray(site, dtype=np.int64)
+        meth = np.ascontiguousarray(is_meth, dtype=np.uint8)
+        first = np.ascontiguousarray(first_row, dtype=np.int64)
+        check(lib().mc_site_counts_add(self._ctx, _ptr(site), _ptr(meth), _ptr(first), len(site)))
+
+    def site_allreduce(self):
+        """Sum / min over the ranks of the communicator (none: this rank alone) -> (n_meth, n_total, first, ms)."""
+        n = lib().mc_site_count(self._ctx)
+        n_meth, n_total = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+        ms = C.c_float(0)
+        check(lib().mc_site_allreduce(self._ctx, _ptr(n_meth), _ptr(n_total), _ptr(first), C.byref(ms)))
+        return n_meth, n_total, first, ms.value
+
     def mlp_forward(self, X, submodel):
         if getattr(self, '_clf', 'mlp') == 'forest':
             return self.classifier_forward(X, submodel)

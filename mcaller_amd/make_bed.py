@@ -184,6 +184,23 @@ def site_counts(rec, table, index, row_offset=0):
     return n_meth, n_total, first
 
 
+def add_pending_site_counts(dev, rec, table, index, row_offset=0, prob=None):
+    """Records the device could not score (NaN there; the host scored them: `prob`, default rec.prob) -> added to the
+    device-side counts of Device.site_counts()."""
+    from . import _lib
+    n = rec.n
+    info = rec.info[:n]
+    sel = ((info & _lib.I_TOO_MANY) == 0) & np.isnan(rec.prob[:n])
+    if prob is None or not sel.any():
+        return 0
+    p = np.asarray(prob)[:n]
+    contig = table.seg_contig[rec.site_seg[:n][sel]].astype(np.int64)
+    rev = ((info[sel] & _lib.I_REV) != 0).astype(np.int64)
+    key = index.keys(contig, rev, rec.site_pos[:n][sel].astype(np.int64))
+    dev.site_counts_add(key, (p[sel] >= 0.5).astype(np.uint8), rec.close_row[:n][sel] + row_offset)
+    return int(sel.sum())
+
+
 def allreduce_site_counts(n_meth, n_total, first, dist=None, backend_hint=None):
     """Sum / min over ranks through torch.distributed: nccl (= RCCL over xGMI, GPU tensors) or gloo (CPU tensors).
     Messages: 2 x 4 B + 8 B per site (~0.6 MB for E. coli GATC): latency-bound, no custom collective needed."""

@@ -94,3 +94,32 @@ def test_sharded_run_on_one_gpu_equals_the_whole():
     rec = shard.concat_records(parts, 6, ro, so, nr, tr)
     H.assert_records_equal(rec, whole, 6, prob_tol=0.0)
     dev.close()
+
+
+def test_site_reduction_on_device_equals_host(tmp_path):
+    """mc_site_counts + mc_site_allreduce (RCCL communicator of one rank: loads librccl, ncclCommInitRank, no exchange)
+    == the numpy reduction of the same records; and the BED written from it == make_bed on the .diffs text."""
+    from mcaller_amd import synth, make_bed
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    codes = synth.genome(length=60000, seed=4)
+    ref = synth.SynthRef(codes, motif='A')                 # dense: every site is hit by several reads
+    table, qual = synth.make_table(400000, seed=12, codes=codes, read_len=(1500, 6000))
+    _, weights, _, soc = submodel_setup(H.load_modelset('r95'), 'A')
+    dev = Device(0)
+    dev.set_reference(ref.device_arrays())
+    dev.set_read_quality(qual)
+    dev.set_mlp(weights, soc)
+    dev.upload_table(table)
+    rec = dev.extract(6, 0, 0.0)
+    index = make_bed.SiteIndex(ref.meth, 1)
+    want = make_bed.site_counts(rec, table, index, row_offset=1000)
+    dev.comm_init(1, 0, Device.comm_unique_id())
+    pending = dev.site_counts(row_offset=1000)
+    assert pending == int(np.isnan(rec.prob[:rec.n][(rec.info[:rec.n] & 0x200) == 0]).sum())
+    make_bed.add_pending_site_counts(dev, rec, table, index, row_offset=1000)
+    n_meth, n_total, first, ms = dev.site_allreduce()
+    assert index.n == len(n_meth) > 1000 and n_total.sum() > 10000
+    assert (n_meth == want[0]).all() and (n_total == want[1]).all() and (first == want[2]).all()
+    dev.comm_destroy()
+    dev.close()
