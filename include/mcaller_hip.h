@@ -170,6 +170,28 @@ int mc_comm_destroy(mc_ctx *ctx);
  * (INT64_MAX: site not seen); *ms = time of the two collectives (hipEvents). */
 int mc_site_allreduce(mc_ctx *ctx, int32_t *n_meth, int32_t *n_total, int64_t *first_row, float *ms);
 
+/* ===== the classifier fit behind --train (train_model.py:47,:62-65,:81-100): one-hidden-layer tanh/logistic perceptron, =====
+ * Adam, binary log-loss + L2, scikit-learn's MLPClassifier recipe (batches of min(200, n) rows, tol / n_iter_no_change
+ * stopping).  n_jobs independent fits run side by side, one workgroup each (the 5 GroupKFold fits + the final fit of a
+ * sub-model); job j trains on rows train_idx[train_off[j] .. train_off[j+1]) of X and is scored (accuracy, p > 0.5) on
+ * rows val_idx[val_off[j] .. val_off[j+1]).  Start weights: `init` ([n_jobs][n_in*n_hidden + 2*n_hidden + 1]: W1
+ * row-major, b1, W2, b2) or, if NULL, Glorot-uniform from seeds[j] (NULL: seed + j).  The epoch order is a keyed
+ * permutation of the row index (shuffle != 0) or the given order. */
+typedef struct mc_fit_params {
+    int32_t n_in, n_hidden;        /* k+1 inputs (<= MC_MAX_K+1), hidden units (<= 128; reference: 100)  */
+    int32_t batch_size;            /* scikit-learn 'auto': min(200, n); the kernel clamps to each job's n */
+    int32_t max_iter;              /* 200 */
+    int32_t n_iter_no_change;      /* 10  */
+    int32_t shuffle;               /* 1   */
+    double alpha, lr_init, beta1, beta2, epsilon, tol;   /* 0.001 (train_model.py:47), 0.001, 0.9, 0.999, 1e-8, 1e-4 */
+    uint64_t seed;
+} mc_fit_params;
+int mc_mlp_fit(mc_ctx *ctx, const mc_fit_params *prm, const double *X, const uint8_t *y, int64_t n_samples, int32_t n_jobs,
+               const int64_t *train_off, const int32_t *train_idx, const int64_t *val_off, const int32_t *val_idx,
+               const uint64_t *seeds, const double *init,
+               double *W1, double *b1, double *W2, double *b2,      /* per job: [n_in*n_hidden], [n_hidden], [n_hidden], [1] */
+               double *loss_curve /* [n_jobs*max_iter] */, int32_t *n_iter /* epochs run */, int64_t *val_correct);
+
 /* ===== native `.diffs.<k>` row formatter (host), replaces the text assembly of the flush, extract_contexts.py:186-216 ===== */
 typedef struct mc_format_args {
     const mc_calls_view *rec;          /* flush records in host memory (mc_fetch_records / _view)                  */

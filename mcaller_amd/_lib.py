@@ -50,6 +50,13 @@ class FormatArgs(C.Structure):
                 ('label_meth', C.c_char_p), ('label_unmeth', C.c_char_p), ('submodel_of_char', C.c_void_p)]
 
 
+class FitParams(C.Structure):
+    _fields_ = [('n_in', C.c_int32), ('n_hidden', C.c_int32), ('batch_size', C.c_int32), ('max_iter', C.c_int32),
+                ('n_iter_no_change', C.c_int32), ('shuffle', C.c_int32),
+                ('alpha', C.c_double), ('lr_init', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('epsilon', C.c_double), ('tol', C.c_double), ('seed', C.c_uint64)]
+
+
 class Params(C.Structure):
     _fields_ = [('k', C.c_int32), ('skip_thresh', C.c_int32), ('qual_thresh', C.c_double),
                 ('tail_contig', C.c_int32), ('score', C.c_int32),
@@ -104,6 +111,7 @@ def lib():
         L.mc_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.mc_comm_destroy.argtypes = [C.c_void_p]
         L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.mc_mlp_fit.argtypes = [C.c_void_p, C.POINTER(FitParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 13
         L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_free.argtypes = [C.c_void_p]

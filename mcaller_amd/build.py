@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['csrc/mc_device.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_common.cpp']
+SOURCES = ['csrc/mc_device.hip', 'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_common.cpp']
 OUT = os.path.join(HERE, 'libmcaller_hip.so')
 
 

@@ -1898,6 +1898,10 @@ static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
 
 extern "C" int mc_comm_destroy(mc_ctx *c);
 
+// for the other translation units of the library (mc_train.hip)
+int mc_internal_device(const mc_ctx *c) { return c->device; }
+hipStream_t mc_internal_stream(const mc_ctx *c) { return c->stream; }
+
 extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     *out = nullptr;
     int n = 0;

@@ -1,0 +1,440 @@
+// libmcaller_hip.so -- the classifier fit behind `--train` on the GPU (gfx950 / MI355X).  C ABI: include/mcaller_hip.h.
+//
+// The reference fits scikit-learn's MLPClassifier(hidden_layer_sizes=(100), alpha=0.001, activation='tanh') on the
+// labelled feature rows the hot path produced (train_model.py:47,:81-100) and scores it with 5-fold GroupKFold
+// (train_model.py:62-65,:92): six independent fits per sub-model.  Here every fit is ONE workgroup that runs the whole
+// Adam optimisation on chip:
+//
+//   * four waves; lane l of every wave owns hidden units l and l+64 (H <= 128): their input weights, bias, output weight,
+//     both Adam moments and the gradient accumulators live in that lane's registers -- nothing is re-read per step;
+//   * a minibatch (<= 200 rows of <= 9 doubles) is staged in LDS, the next one is prefetched into registers while the
+//     current one is processed; wave w takes rows w, w+4, ...: forward (tanh), one wave reduction for the output unit,
+//     logistic + log-loss, backward into the register accumulators;
+//   * per batch the four waves exchange their partial gradients through LDS and add them in a fixed order, so every wave
+//     holds the same totals and applies the same Adam update to its own copy of the parameters: results are
+//     deterministic and independent of scheduling;
+//   * epoch order: a 4-round Feistel permutation of the row index, cycle-walked into range (no shuffle buffer); start
+//     weights: Glorot-uniform from a counter-based generator -- both defined in oracle/mlp_fit_oracle.py, which restates
+//     the same optimiser on the CPU and is pinned against scikit-learn's own runs.
+//
+// The kernel is latency-bound by construction (one workgroup per fit; the fits of a training job run side by side on
+// different CUs); fp64 throughout, like scikit-learn.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mcaller_hip.h"
+
+void mc_set_error(const char *fmt, ...);
+int mc_internal_device(const mc_ctx *c);
+hipStream_t mc_internal_stream(const mc_ctx *c);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -10;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+namespace {
+
+constexpr int FW = 4;                  // waves per fit
+constexpr int FT = FW * 64;
+constexpr int DMAX = MC_MAX_K + 1;     // inputs: k slot means + read quality
+constexpr int HMAX = 128;              // two hidden units per lane
+constexpr int NC = 2 * (DMAX + 2);     // gradient components per lane: W1[DMAX][2], b1[2], W2[2]
+constexpr int NP = NC + 2;             // + the wave's loss sum and output-bias gradient
+
+struct FitJob {
+    long long tr_off, n_tr, va_off, n_va;
+    unsigned long long seed;
+};
+
+struct FitArgs {
+    const double *X;         // [n_samples * d]
+    const uint8_t *y;        // [n_samples] 0/1
+    const FitJob *jobs;
+    const int32_t *tr_idx, *va_idx;
+    int d, H, batch, max_iter, n_iter_no_change, shuffle;
+    double alpha, lr, beta1, beta2, eps, tol;
+    const double *init;      // optional start weights per job [d*H + 2H + 1], or null
+    double *W1, *b1, *W2, *b2;   // per job: [d*H], [H], [H], [1]
+    double *loss_curve;      // [n_jobs * max_iter]
+    int32_t *n_iter;         // [n_jobs]
+    long long *val_correct;  // [n_jobs]
+};
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double uniform01(unsigned long long seed, unsigned long long index) {
+    return (double)(splitmix64(seed + index * 0xD1342543DE82EF95ull) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
+// bijection of [0, n): 4-round Feistel network on the next even power of two, cycle-walked into range
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t i, uint32_t n, uint32_t key, int half, uint32_t mask) {
+    uint32_t x = i;
+    for (;;) {
+        uint32_t L = x >> half, R = x & mask;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t F = mix32(R * 0x9E3779B1u + key + r * 0x85EBCA6Bu) & mask;
+            const uint32_t nl = R;
+            R = L ^ F;
+            L = nl;
+        }
+        x = (L << half) | R;
+        if (x < n) return x;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double(*s_part)[NP][64] = reinterpret_cast<double(*)[NP][64]>(s_raw);                   // [FW][NP][64]
+    double *s_x = reinterpret_cast<double *>(s_raw + sizeof(double) * FW * NP * 64);        // [batch * d]
+    uint8_t *s_y = reinterpret_cast<uint8_t *>(s_x + (size_t)A.batch * A.d);                // [batch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int job = blockIdx.x;
+    const FitJob J = A.jobs[job];
+    const int d = A.d, H = A.H;
+    const uint32_t n = (uint32_t)J.n_tr;
+    const int B = (int)min((long long)A.batch, J.n_tr);
+    const int h[2] = {lane, lane + 64};
+    const bool valid[2] = {h[0] < H, h[1] < H};
+
+    // ---- parameters, moments, gradient accumulators: registers ----
+    double w1[DMAX][2], bb1[2], w2[2], b2;
+    double m_w1[DMAX][2], m_b1[2], m_w2[2], m_b2 = 0.0;
+    double v_w1[DMAX][2], v_b1[2], v_w2[2], v_b2 = 0.0;
+    {
+        const double bound_h = sqrt(6.0 / (double)(d + H)), bound_o = sqrt(6.0 / (double)(H + 1));
+        const double *init = A.init ? A.init + (size_t)job * ((size_t)d * H + 2 * (size_t)H + 1) : nullptr;
+        auto start = [&](unsigned long long idx, double bound) -> double {
+            return init ? init[idx] : -bound + 2.0 * bound * uniform01(J.seed, idx);
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) {
+                w1[i][j] = (valid[j] && i < d) ? start((unsigned long long)i * H + h[j], bound_h) : 0.0;
+                m_w1[i][j] = v_w1[i][j] = 0.0;
+            }
+            bb1[j] = valid[j] ? start((unsigned long long)d * H + h[j], bound_h) : 0.0;
+            w2[j] = valid[j] ? start((unsigned long long)d * H + H + h[j], bound_o) : 0.0;
+            m_b1[j] = v_b1[j] = m_w2[j] = v_w2[j] = 0.0;
+        }
+        b2 = start((unsigned long long)d * H + 2 * (unsigned long long)H, bound_o);
+    }
+
+    int bits = 2;
+    while (bits < 32 && (1ull << bits) < (unsigned long long)n) ++bits;
+    bits += bits & 1;
+    const int half = bits / 2;
+    const uint32_t mask = (1u << half) - 1u;
+
+    // row `slot` of the epoch's order -> registers of thread `slot % FT` (prefetch), later -> LDS
+    double xr[DMAX];
+    uint8_t yr = 0;
+    auto fetch = [&](uint32_t key, long long b0, int nb) {
+        if (tid < nb) {
+            const uint32_t pos = (uint32_t)(b0 + tid);
+            const uint32_t src = A.shuffle ? feistel_perm(pos, n, key, half, mask) : pos;
+            const long long sid = A.tr_idx[J.tr_off + src];
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) xr[i] = i < d ? A.X[sid * d + i] : 0.0;
+            yr = A.y[sid];
+        }
+    };
+    auto stage = [&](int nb) {
+        if (tid < nb) {
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i)
+                if (i < d) s_x[tid * d + i] = xr[i];
+            s_y[tid] = yr;
+        }
+    };
+
+    double b1t = 1.0, b2t = 1.0;               // beta^t
+    double best = INFINITY;
+    int no_improve = 0, n_epochs = 0;
+    const double feps = 2.220446049250313e-16;  // np.finfo(float64).eps: probabilities are clipped to [eps, 1-eps]
+
+    uint32_t key = (uint32_t)(splitmix64((J.seed ^ 0xA5A5A5A55A5A5A5Aull) + 0ull) & 0xFFFFFFFFull);
+    if (n > 0) fetch(key, 0, B);
+    for (int epoch = 0; epoch < A.max_iter && n > 0; ++epoch) {
+        double acc = 0.0;
+        for (long long b0 = 0; b0 < (long long)n; b0 += B) {
+            const int nb = (int)min((long long)B, (long long)n - b0);
+            stage(nb);
+            __syncthreads();
+            {   // prefetch the batch after this one (the next epoch's first batch at the end of an epoch)
+                long long nb0 = b0 + B;
+                uint32_t nkey = key;
+                if (nb0 >= (long long)n) {
+                    nb0 = 0;
+                    nkey = (uint32_t)(splitmix64((J.seed ^ 0xA5A5A5A55A5A5A5Aull) + (unsigned long long)(epoch + 1)) & 0xFFFFFFFFull);
+                }
+                fetch(nkey, nb0, (int)min((long long)B, (long long)n - nb0));
+            }
+            double g_w1[DMAX][2], g_b1[2] = {0.0, 0.0}, g_w2[2] = {0.0, 0.0}, g_b2 = 0.0, loss = 0.0;
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) g_w1[i][0] = g_w1[i][1] = 0.0;
+            for (int s = wave; s < nb; s += FW) {
+                double x[DMAX];
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i) x[i] = i < d ? s_x[s * d + i] : 0.0;
+                const double yy = (double)s_y[s];
+                double a[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double z = bb1[j];
+#pragma unroll
+                    for (int i = 0; i < DMAX; ++i) z += x[i] * w1[i][j];
+                    a[j] = valid[j] ? tanh(z) : 0.0;
+                }
+                const double out = b2 + wave_sum(a[0] * w2[0] + a[1] * w2[1]);
+                const double p = 1.0 / (1.0 + exp(-out));
+                const double pc = fmin(fmax(p, feps), 1.0 - feps);
+                loss -= yy > 0.0 ? log(pc) : log(1.0 - pc);
+                const double delta = p - yy;
+                g_b2 += delta;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    g_w2[j] += a[j] * delta;
+                    const double dh = delta * w2[j] * (1.0 - a[j] * a[j]);
+                    g_b1[j] += dh;
+#pragma unroll
+                    for (int i = 0; i < DMAX; ++i) g_w1[i][j] += x[i] * dh;
+                }
+            }
+            // ---- the four waves' partial sums -> LDS -> every wave adds them in the same order ----
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i) s_part[wave][(i * 2 + j)][lane] = g_w1[i][j];
+                s_part[wave][2 * DMAX + j][lane] = g_b1[j];
+                s_part[wave][2 * DMAX + 2 + j][lane] = g_w2[j];
+            }
+            s_part[wave][NC][lane] = loss;
+            s_part[wave][NC + 1][lane] = g_b2;
+            __syncthreads();
+            auto total = [&](int c) -> double {
+                double t = s_part[0][c][lane];
+#pragma unroll
+                for (int w = 1; w < FW; ++w) t += s_part[w][c][lane];
+                return t;
+            };
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i) g_w1[i][j] = total(i * 2 + j);
+                g_b1[j] = total(2 * DMAX + j);
+                g_w2[j] = total(2 * DMAX + 2 + j);
+            }
+            loss = total(NC);
+            g_b2 = total(NC + 1);
+            __syncthreads();                      // LDS is rewritten by the next batch
+
+            double sq = w2[0] * w2[0] + w2[1] * w2[1];
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) sq += w1[i][0] * w1[i][0] + w1[i][1] * w1[i][1];
+            const double values = wave_sum(sq);
+            const double inv_nb = 1.0 / (double)nb;
+            acc += (loss * inv_nb + 0.5 * A.alpha * values * inv_nb) * (double)nb;
+
+            // ---- Adam ----
+            b1t *= A.beta1;
+            b2t *= A.beta2;
+            const double lr_t = A.lr * sqrt(1.0 - b2t) / (1.0 - b1t);
+            auto adam = [&](double &p_, double &m_, double &v_, double g) {
+                m_ = A.beta1 * m_ + (1.0 - A.beta1) * g;
+                v_ = A.beta2 * v_ + (1.0 - A.beta2) * g * g;
+                p_ += -lr_t * m_ / (sqrt(v_) + A.eps);
+            };
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (valid[j]) {
+#pragma unroll
+                    for (int i = 0; i < DMAX; ++i)
+                        if (i < d) adam(w1[i][j], m_w1[i][j], v_w1[i][j], (g_w1[i][j] + A.alpha * w1[i][j]) * inv_nb);
+                    adam(bb1[j], m_b1[j], v_b1[j], g_b1[j] * inv_nb);
+                    adam(w2[j], m_w2[j], v_w2[j], (g_w2[j] + A.alpha * w2[j]) * inv_nb);
+                }
+            }
+            adam(b2, m_b2, v_b2, g_b2 * inv_nb);
+        }
+        const double epoch_loss = acc / (double)n;
+        if (tid == 0) A.loss_curve[(size_t)job * A.max_iter + epoch] = epoch_loss;
+        n_epochs = epoch + 1;
+        key = (uint32_t)(splitmix64((J.seed ^ 0xA5A5A5A55A5A5A5Aull) + (unsigned long long)(epoch + 1)) & 0xFFFFFFFFull);
+        if (epoch_loss > best - A.tol) ++no_improve;
+        else no_improve = 0;
+        if (epoch_loss < best) best = epoch_loss;
+        if (no_improve > A.n_iter_no_change) break;
+    }
+
+    // ---- results ----
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (valid[j]) {
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i)
+                    if (i < d) A.W1[(size_t)job * d * H + (size_t)i * H + h[j]] = w1[i][j];
+                A.b1[(size_t)job * H + h[j]] = bb1[j];
+                A.W2[(size_t)job * H + h[j]] = w2[j];
+            }
+        }
+        if (lane == 0) {
+            A.b2[job] = b2;
+            A.n_iter[job] = n_epochs;
+        }
+    }
+    // held-out rows: accuracy as scikit-learn scores it (predict: p > 0.5)
+    long long correct = 0;
+    for (long long s = wave; s < J.n_va; s += FW) {
+        const long long sid = A.va_idx[J.va_off + s];
+        double a[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double z = bb1[j];
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) z += (i < d ? A.X[sid * d + i] : 0.0) * w1[i][j];
+            a[j] = valid[j] ? tanh(z) : 0.0;
+        }
+        const double out = b2 + wave_sum(a[0] * w2[0] + a[1] * w2[1]);
+        const double p = 1.0 / (1.0 + exp(-out));
+        correct += ((p > 0.5) == (A.y[sid] != 0)) ? 1 : 0;
+    }
+    if (lane == 0 && J.n_va > 0) atomicAdd(reinterpret_cast<unsigned long long *>(&A.val_correct[job]), (unsigned long long)correct);
+}
+
+template <typename T>
+int to_device(std::vector<void *> &pool, T **dst, const T *src, size_t n, hipStream_t st) {
+    void *q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) {
+        mc_set_error("hipMalloc of %zu bytes failed", n * sizeof(T));
+        return -10;
+    }
+    pool.push_back(q);
+    *dst = (T *)q;
+    if (src && n) {
+        if (hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) {
+            mc_set_error("H2D copy of %zu bytes failed", n * sizeof(T));
+            return -10;
+        }
+    } else if (n) {
+        (void)hipMemsetAsync(q, 0, n * sizeof(T), st);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, const uint8_t *y, int64_t n_samples, int32_t n_jobs,
+                          const int64_t *train_off, const int32_t *train_idx, const int64_t *val_off, const int32_t *val_idx,
+                          const uint64_t *seeds, const double *init, double *W1, double *b1, double *W2, double *b2,
+                          double *loss_curve, int32_t *n_iter, int64_t *val_correct) {
+    HIP_TRY(hipSetDevice(mc_internal_device(c)));
+    hipStream_t st = mc_internal_stream(c);
+    if (!P || P->n_in < 1 || P->n_in > DMAX || P->n_hidden < 1 || P->n_hidden > HMAX || P->batch_size < 1 || P->max_iter < 1 ||
+        n_jobs < 1 || n_samples < 1) {
+        mc_set_error("mc_mlp_fit: unsupported shape (inputs 1..%d, hidden 1..%d)", DMAX, HMAX);
+        return -12;
+    }
+    const size_t lds = sizeof(double) * FW * NP * 64 + (size_t)P->batch_size * P->n_in * 8 + (size_t)P->batch_size;
+    if (P->batch_size > FT || lds > 64 * 1024) {
+        mc_set_error("mc_mlp_fit: batch size %d does not fit (max %d rows)", P->batch_size, FT);
+        return -12;
+    }
+    for (int j = 0; j < n_jobs; ++j) {
+        if (train_off[j + 1] < train_off[j] || val_off[j + 1] < val_off[j] || train_off[j + 1] - train_off[j] > (int64_t)1 << 31) {
+            mc_set_error("mc_mlp_fit: bad offsets for job %d", j);
+            return -12;
+        }
+        for (int64_t i = train_off[j]; i < train_off[j + 1]; ++i)
+            if (train_idx[i] < 0 || train_idx[i] >= n_samples) { mc_set_error("mc_mlp_fit: row index out of range"); return -12; }
+        for (int64_t i = val_off[j]; i < val_off[j + 1]; ++i)
+            if (val_idx[i] < 0 || val_idx[i] >= n_samples) { mc_set_error("mc_mlp_fit: row index out of range"); return -12; }
+    }
+    const int d = P->n_in, H = P->n_hidden;
+    std::vector<FitJob> jobs((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs[(size_t)j].tr_off = train_off[j];
+        jobs[(size_t)j].n_tr = train_off[j + 1] - train_off[j];
+        jobs[(size_t)j].va_off = val_off[j];
+        jobs[(size_t)j].n_va = val_off[j + 1] - val_off[j];
+        jobs[(size_t)j].seed = seeds ? seeds[j] : (uint64_t)(P->seed + (uint64_t)j);
+    }
+    std::vector<void *> pool;
+    auto cleanup = [&]() { for (void *p : pool) (void)hipFree(p); };
+    FitArgs A;
+    double *dX, *dinit = nullptr, *dW1, *db1, *dW2, *db2, *dcurve;
+    uint8_t *dy;
+    FitJob *djobs;
+    int32_t *dtr, *dva, *dnit;
+    long long *dcorrect;
+    const size_t per_job = (size_t)d * H + 2 * (size_t)H + 1;
+    int rc = 0;
+    rc |= to_device(pool, &dX, X, (size_t)n_samples * d, st);
+    rc |= to_device(pool, &dy, y, (size_t)n_samples, st);
+    rc |= to_device(pool, &djobs, jobs.data(), (size_t)n_jobs, st);
+    rc |= to_device(pool, &dtr, train_idx, (size_t)std::max<int64_t>(train_off[n_jobs], 1), st);
+    rc |= to_device(pool, &dva, val_idx, (size_t)std::max<int64_t>(val_off[n_jobs], 1), st);
+    if (init) rc |= to_device(pool, &dinit, init, per_job * n_jobs, st);
+    rc |= to_device<double>(pool, &dW1, nullptr, (size_t)n_jobs * d * H, st);
+    rc |= to_device<double>(pool, &db1, nullptr, (size_t)n_jobs * H, st);
+    rc |= to_device<double>(pool, &dW2, nullptr, (size_t)n_jobs * H, st);
+    rc |= to_device<double>(pool, &db2, nullptr, (size_t)n_jobs, st);
+    rc |= to_device<double>(pool, &dcurve, nullptr, (size_t)n_jobs * P->max_iter, st);
+    rc |= to_device<int32_t>(pool, &dnit, nullptr, (size_t)n_jobs, st);
+    rc |= to_device<long long>(pool, &dcorrect, nullptr, (size_t)n_jobs, st);
+    if (rc) { cleanup(); return -10; }
+    A.X = dX; A.y = dy; A.jobs = djobs; A.tr_idx = dtr; A.va_idx = dva;
+    A.d = d; A.H = H; A.batch = P->batch_size; A.max_iter = P->max_iter; A.n_iter_no_change = P->n_iter_no_change;
+    A.shuffle = P->shuffle;
+    A.alpha = P->alpha; A.lr = P->lr_init; A.beta1 = P->beta1; A.beta2 = P->beta2; A.eps = P->epsilon; A.tol = P->tol;
+    A.init = dinit; A.W1 = dW1; A.b1 = db1; A.W2 = dW2; A.b2 = db2; A.loss_curve = dcurve; A.n_iter = dnit; A.val_correct = dcorrect;
+    hipLaunchKernelGGL(k4_mlp_fit, dim3((unsigned)n_jobs), dim3(FT), lds, st, A);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(W1, dW1, (size_t)n_jobs * d * H * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b1, db1, (size_t)n_jobs * H * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(W2, dW2, (size_t)n_jobs * H * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b2, db2, (size_t)n_jobs * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(loss_curve, dcurve, (size_t)n_jobs * P->max_iter * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(n_iter, dnit, (size_t)n_jobs * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(val_correct, dcorrect, (size_t)n_jobs * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) {
+        mc_set_error("mc_mlp_fit failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    return 0;
+}

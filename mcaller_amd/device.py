@@ -159,6 +159,38 @@ class Device(object):
         check(lib().mc_site_allreduce(self._ctx, _ptr(n_meth), _ptr(n_total), _ptr(first), C.byref(ms)))
         return n_meth, n_total, first, ms.value
 
+    # ---- the classifier fit behind --train ----
+    def mlp_fit(self, X, y, jobs, hidden=100, alpha=0.001, lr_init=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                batch_size=200, max_iter=200, tol=1e-4, n_iter_no_change=10, shuffle=True, seed=1, seeds=None, init=None):
+        """Fit one 7-H-1 tanh/logistic perceptron per job on the GPU (mc_mlp_fit; all jobs side by side).
+        jobs: [(train_rows, validation_rows)] index arrays into X / y.  -> list of dicts W1, b1, W2, b2, loss_curve,
+        n_iter, val_correct, n_val."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.uint8)
+        n, d = X.shape
+        nj = len(jobs)
+        tr = [np.ascontiguousarray(j[0], dtype=np.int32) for j in jobs]
+        va = [np.ascontiguousarray(j[1], dtype=np.int32) for j in jobs]
+        tr_off = np.concatenate([[0], np.cumsum([len(a) for a in tr])]).astype(np.int64)
+        va_off = np.concatenate([[0], np.cumsum([len(a) for a in va])]).astype(np.int64)
+        tr_idx = np.ascontiguousarray(np.concatenate(tr + [np.zeros(1, np.int32)]))
+        va_idx = np.ascontiguousarray(np.concatenate(va + [np.zeros(1, np.int32)]))
+        prm = _lib.FitParams(d, int(hidden), int(batch_size), int(max_iter), int(n_iter_no_change), 1 if shuffle else 0,
+                             float(alpha), float(lr_init), float(beta1), float(beta2), float(epsilon), float(tol), int(seed))
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        ini = None
+        if init is not None:      # [(W1, b1, W2, b2)] per job
+            ini = np.ascontiguousarray(np.concatenate([np.concatenate([np.ravel(w[0]), np.ravel(w[1]), np.ravel(w[2]),
+                                                                       np.ravel([w[3]])]) for w in init]), dtype=np.float64)
+            assert len(ini) == nj * (d * hidden + 2 * hidden + 1)
+        W1 = np.zeros((nj, d, hidden)); b1 = np.zeros((nj, hidden)); W2 = np.zeros((nj, hidden)); b2 = np.zeros(nj)
+        curve = np.zeros((nj, max_iter)); n_iter = np.zeros(nj, dtype=np.int32); correct = np.zeros(nj, dtype=np.int64)
+        check(lib().mc_mlp_fit(self._ctx, C.byref(prm), _ptr(X), _ptr(y), n, nj, _ptr(tr_off), _ptr(tr_idx), _ptr(va_off),
+                               _ptr(va_idx), None if sd is None else _ptr(sd), None if ini is None else _ptr(ini),
+                               _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(curve), _ptr(n_iter), _ptr(correct)))
+        return [dict(W1=W1[j], b1=b1[j], W2=W2[j], b2=float(b2[j]), loss_curve=curve[j, :n_iter[j]].copy(),
+                     n_iter=int(n_iter[j]), val_correct=int(correct[j]), n_val=len(va[j])) for j in range(nj)]
+
     def mlp_forward(self, X, submodel):
         if getattr(self, '_clf', 'mlp') == 'forest':
             return self.classifier_forward(X, submodel)

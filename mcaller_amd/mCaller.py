@@ -34,19 +34,24 @@ def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_r
         training_pos_dict = None
     else:
         tsv_output = '.'.join(tsvname.split('.')[:-1]) + '.diffs.' + str(nvariables) + '.train'
-        if training_tsv:
-            raise NotImplementedError('--training_tsv (re-loading a labelled diffs file) is outside the GPU path')
-        training_pos_dict = pos2label(positions_list)
+        if training_tsv:                                    # mCaller.py:35-36
+            from .load_mCaller_data import tsv2matrix
+            ret = tsv2matrix(training_tsv, base)
+        else:
+            training_pos_dict = pos2label(positions_list)
 
     print('%d contigs' % num_refs)
     print('%d threads' % nprocs)
-    bytesize = os.path.getsize(tsvname)
-    ret = extract_features(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile, classifier, 0,
-                           endline=bytesize, train=train, pos_label=training_pos_dict, base=base, motif=motif,
-                           positions_list=positions_list)
+    if not training_tsv:
+        bytesize = os.path.getsize(tsvname)
+        ret = extract_features(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile, classifier, 0,
+                               endline=bytesize, train=train, pos_label=training_pos_dict, base=base, motif=motif,
+                               positions_list=positions_list)
     print('Finished extracting signals')
-    tmpfis = glob.glob('.'.join(tsvname.split('.')[:-1]) + '*.tmp[0-9]*')
-    if nprocs > 1:
+    tmpfis = [] if training_tsv else glob.glob('.'.join(tsvname.split('.')[:-1]) + '*.tmp[0-9]*')
+    if training_tsv:
+        pass
+    elif nprocs > 1:
         print('Merging files...')
         lines = set()
         for tmpfi in tmpfis:

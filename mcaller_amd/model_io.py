@@ -143,8 +143,9 @@ def load_model_file(path):
     with open(path, 'rb') as fh:
         raw = fh.read()
     if raw[:2] == b'PK':                                    # numpy .npz
-        keys = sorted(set(n.split('.')[0] for n in np.load(path).files))
-        return load_npz_weights(path, keys != ['general'])
+        files = np.load(path).files
+        keys = sorted(set(n.split('.')[0] for n in files if not n.startswith('__')))
+        return load_npz_weights(path, '__is_dict__' in files or keys != ['general'])
     obj = _ModelUnpickler(io.BytesIO(raw), encoding='latin1').load()
     if type(obj) != dict:                                   # extract_contexts.py:126-128
         return ModelSet({'general': _estimator_weights(obj, path)}, False)
@@ -154,6 +155,7 @@ def load_model_file(path):
 def load_npz_weights(path, is_dict):
     """Neutral weight export (tests/golden/models/*.npz): arrays '<key>.W1' ... '<key>.b2'."""
     z = np.load(path)
-    keys = sorted(set(n.split('.')[0] for n in z.files))
-    models = {k: MLPWeights(z[k + '.W1'], z[k + '.b1'], z[k + '.W2'], z[k + '.b2']) for k in keys}
+    keys = sorted(set(n.split('.')[0] for n in z.files if not n.startswith('__')))
+    models = {k: MLPWeights(z[k + '.W1'], z[k + '.b1'], z[k + '.W2'], z[k + '.b2'],
+                            classes=[str(c) for c in z[k + '.classes']] if k + '.classes' in z.files else None) for k in keys}
     return ModelSet(models, is_dict)

@@ -123,3 +123,39 @@ def test_site_reduction_on_device_equals_host(tmp_path):
     assert (n_meth == want[0]).all() and (n_total == want[1]).all() and (first == want[2]).all()
     dev.comm_destroy()
     dev.close()
+
+
+def test_train_cli_fits_on_the_gpu(td, tmp_path):
+    """`mCaller.py --train`: feature matrix from the HIP path, six fits in one mc_mlp_fit launch, model file written in
+    the reference's format (or the neutral .npz without scikit-learn) and readable by model_io."""
+    from mcaller_amd import mCaller, model_io
+    tsv = str(tmp_path / 'masonread1.eventalign.tsv')
+    shutil.copy(td['tsv'], tsv)
+    model = str(tmp_path / 'trained.pkl')
+    os.environ['MCALLER_SEED'] = '4'
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            mCaller.main(['-p', td['test_positions.txt'], '-r', td['fasta'], '-e', tsv, '-f', td['fastq'], '--train',
+                          '-d', model])
+    finally:
+        del os.environ['MCALLER_SEED']
+    out = buf.getvalue()
+    assert 'NN general model scores: ' in out and 'Cross validation accuracy: ' in out and 'Finished training' in out
+    scores = [float(x) for x in out.split('NN general model scores: ')[1].split('\n')[0].split(',')]
+    assert len(scores) == 5 and all(0.0 <= s <= 1.0 for s in scores)
+    assert open(str(tmp_path / 'masonread1.eventalign.diffs.6.train')).read() == \
+        open(os.path.join(H.GOLDEN, 'ref_outputs', 'train_positions_all.diffs.6.train')).read()
+    ms = model_io.load_model_file(model)
+    w = ms.models['general']
+    assert ms.twobase and w.W1.shape == (7, 100) and np.isfinite(w.W1).all() and np.abs(w.W1).max() > 0
+    # the same seed gives the same model (deterministic kernel)
+    model2 = str(tmp_path / 'trained2.pkl')
+    os.environ['MCALLER_SEED'] = '4'
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mCaller.main(['-p', td['test_positions.txt'], '-r', td['fasta'], '-e', tsv, '-f', td['fastq'], '--train',
+                          '-d', model2])
+    finally:
+        del os.environ['MCALLER_SEED']
+    assert (model_io.load_model_file(model2).models['general'].W1 == w.W1).all()
