@@ -151,7 +151,8 @@ struct Counters {          // device-side status block
     unsigned int overflow;
     unsigned int n_irregular;
     unsigned int n_big;
-    unsigned int pad[3];
+    unsigned int n_rare;       // windows left to k1_rare
+    unsigned int pad[2];
     unsigned long long next_chunk; // k1_scan's tile-chunk ticket counter
     unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
 };
@@ -462,18 +463,19 @@ struct TileDesc {      // per tile, written by k0_tiles after classification (pl
 };
 
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
-constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_SLOW = 4, PF_MULTI = 8;
+constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_SLOW = 4, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
+constexpr int WROWS = 64;   // rows a window payload describes
 
 struct __attribute__((aligned(16))) Payload {
     int64_t r;          // last row of the window
     int64_t close_row;  // row that closes it (:179); n_rows: in the next shard; -1 cannot occur (not emitted)
+    uint64_t code[4];   // bit planes: rows r-j, j = 0..63 -> slot (k-mer offset) 0..7, or 15 = not in the window
     int32_t m;          // the site
     int32_t close_pos;
-    uint32_t code[4];   // bit planes: rows r-j, j = 0..31 -> slot (k-mer offset) 0..7, or 15 = not in the window
     uint32_t flags;     // PF_*
     int32_t nb;         // name block
 };
-static_assert(sizeof(Payload) == 48, "Payload layout");
+static_assert(sizeof(Payload) == 64, "Payload layout");
 
 struct K1Args {
     DevTable T;
@@ -489,6 +491,7 @@ struct K1Args {
     DevRecords O;                 // records, file order
     Counters *cnt;
     int k, skip_thresh, tail_contig;
+    int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     int debug;                    // MCALLER_K1_DEBUG: cut k1_scan after a stage (timing experiments only)
 };
 
@@ -681,7 +684,12 @@ __device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc
 // the site (no nearer 'M' to its left, :269-270) and that the next unfiltered row lies beyond it or starts another read
 // (:179): that is a closed window.  The lane then walks the <= 32 rows before it in LDS and writes which rows belong to
 // which slot, plus the closing row, as a 48-byte payload (k1_emit turns payloads into records).
-__global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
+#ifdef MC_SCAN_WPE      // experiment: ask the register allocator for this many waves per SIMD
+#define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MC_SCAN_WPE, MC_SCAN_WPE)))
+#else
+#define MC_SCAN_ATTR
+#endif
+__global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
     __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
     __shared__ uint32_t s_bits[NBST][NTHREADS];
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                             if (lane == 0 && slot_of(total) >= 0) {
                                 Payload P;
                                 P.r = d.extra_row(); P.close_row = cr; P.m = d.extra_mpos; P.close_pos = cp;
-                                P.code[0] = P.code[1] = P.code[2] = P.code[3] = 0xFFFFFFFFu;
+                                P.code[0] = P.code[1] = P.code[2] = P.code[3] = ~0ull;
                                 P.flags = PF_EXTRA | (cns ? PF_CLOSE_NS : 0u);
                                 P.nb = nb_abs;
                                 A.payload[slot_of(total)] = P;
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                     const int64_t lb_abs = max(d.row_begin, d.first());
                     const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t1) - t0);
                     if (hi <= lo) continue;
-                    const int lb_rel = (int)max<int64_t>(lb_abs - t0, -64);      // window walks look back < 32 rows
+                    const int lb_rel = (int)max<int64_t>(lb_abs - t0, -2 * WROWS); // window walks look back < WROWS rows
                     PH(4);
 
                     // ---- pass 1 (all lanes): which units of UROWS rows can hold a site row at all? ----
@@ -889,9 +897,9 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                             const bool havew = wbase + grp < nwin;
                             const int wix = havew ? wbase + grp : 0;
                             const int rv = s_w_rv[wix], m = s_w_m[wix];
-                            uint32_t c0 = ~0u, c1 = ~0u, c2 = ~0u, c3 = ~0u;
+                            uint64_t c0 = ~0ull, c1 = ~0ull, c2 = ~0ull, c3 = ~0ull;
                             bool stopped = !havew;
-                            for (int jb = 0; jb < 32; jb += 16) {
+                            for (int jb = 0; jb < WROWS; jb += 16) {
                                 if (!__ballot(!stopped)) break;
                                 const int rr = rv - jb - j;                              // tile-relative; may precede the tile
                                 const bool inb = rr >= lb_rel;
@@ -921,7 +929,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                                 const uint32_t b1 = (uint32_t)(__ballot(inw && !(code & 2u)) >> (grp * 16)) & 0xFFFFu;
                                 const uint32_t b2 = (uint32_t)(__ballot(inw && !(code & 4u)) >> (grp * 16)) & 0xFFFFu;
                                 const uint32_t b3 = (uint32_t)(__ballot(inw) >> (grp * 16)) & 0xFFFFu;
-                                c0 &= ~(b0 << jb); c1 &= ~(b1 << jb); c2 &= ~(b2 << jb); c3 &= ~(b3 << jb);
+                                c0 &= ~((uint64_t)b0 << jb); c1 &= ~((uint64_t)b1 << jb); c2 &= ~((uint64_t)b2 << jb); c3 &= ~((uint64_t)b3 << jb);
                                 if (st16) stopped = true;
                             }
                             if (havew && j == 0) {
@@ -931,7 +939,7 @@ __global__ __launch_bounds__(NTHREADS) void k1_scan(K1Args A) {
                                     Payload P;
                                     P.r = t0 + rv; P.close_row = s_w_cr[wix]; P.m = m; P.close_pos = s_w_cp[wix];
                                     P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
-                                    P.flags = s_w_pf[wix] | ((!really_stopped || d.stray_q != NO_STRAY) ? PF_SLOW : 0u);
+                                    P.flags = s_w_pf[wix] | (!really_stopped ? PF_SLOW : 0u) | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
                                     P.nb = nb_abs;
                                     A.payload[slot] = P;
                                 }
@@ -1146,118 +1154,149 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
     A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
-constexpr int WROWS = 32;   // rows of a window payload
 
-// One wave per tile: where each of the tile's records (file order) finds its payload (arrival order).
-__global__ __launch_bounds__(256) void k1_list(K1Args A, int64_t *__restrict__ rec_slot) {
+// Eight lanes per tile: the tile's payloads (arrival order) are gathered into file order, so that k1_emit reads them
+// with unit stride.  The first record slot of the tile = the windows of all earlier groups of 1024 tiles (summed by the
+// eight lanes) + the tile's offset inside its group.
+__global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
-    const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (tile >= T.n_tiles) return;
+    constexpr int LG = 8;
+    const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LG;
+    const int l = threadIdx.x & (LG - 1);
+    const bool have = tile < T.n_tiles;
+    const int64_t tl = have ? tile : T.n_tiles - 1;
+    const int g = (int)(tl / GROUP);
+    long long part = 0;
+    for (int i = l; i < g; i += LG) part += A.group_sum[i];
+#pragma unroll
+    for (int o = LG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (!have) return;
     const int c = A.tile_cnt[tile];
-    if (tile == T.n_tiles - 1) {       // the last tile's wave also publishes the total
-        const int64_t tot = tile_slot(A.tile_local, A.group_sum, tile, lane) + c;
-        if (lane == 0) A.cnt->n_records = (unsigned long long)tot;
-    }
+    const int64_t first = part + A.tile_local[tile];
+    if (tile == T.n_tiles - 1 && l == 0) A.cnt->n_records = (unsigned long long)(first + c);   // the total
     if (c == 0) return;
-    const int64_t first = tile_slot(A.tile_local, A.group_sum, tile, lane);
-    if (first + c > A.O.capacity) { if (lane == 0) atomicOr(&A.cnt->overflow, 1u); return; }
-    for (int j = lane; j < c; j += 64) {
+    if (first + c > A.O.capacity) { if (l == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    for (int j = l; j < c; j += LG) {
         long long slot = tile * PT + j;
         if (j >= PT) {
             const long long cb = A.tile_chunk[tile * (TILE / 64) + (j >> 6)];
             if (cb < 0) { atomicOr(&A.cnt->overflow, 1u); continue; }
             slot = cb + (j & 63);
         }
-        rec_slot[first + j] = slot;
+        sorted[first + j] = A.payload[slot];
     }
 }
 
-// One thread per closed window: the (event, model) pairs of the 32 rows ending at the window's last row come in with
-// independent 8-byte loads from the interleaved column (one DRAM page per window); slot sums from registers in NumPy's
-// pairwise order.  Windows longer than 32 rows and blocks with a stray event (R5) take the row-at-a-time walk.
-__global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restrict__ rec_slot) {
-    const DevTable &T = A.T;
-    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (q >= (int64_t)A.cnt->n_records || q >= A.O.capacity) return;
-    const int k = A.k;
-    const Payload P = A.payload[rec_slot[q]];
+// Eight lanes per closed window, lane s = slot s of the window (k <= 8): the lane reads the payload's bit planes, picks
+// the rows of its slot (<= 64 rows back from the window's last row), fetches their (event, model) pairs from the
+// interleaved column (all lanes of a window hit the same DRAM page) and adds them in NumPy's pairwise order (n < 8:
+// sequentially from -0.0, oldest row first; 8..32: eight strided accumulators, then the tail).  The k slot means of a
+// window leave as k consecutive doubles, adjacent windows adjacent: the wave's stores are one contiguous run.  Windows
+// longer than 32 rows and blocks with a stray event (R5) take the row-at-a-time walk on the group's first lane.
+constexpr int EG = 8;            // lanes per window
+static_assert(EG >= MC_MAX_K, "one lane per slot");
+
+// Windows longer than WROWS rows (a handful per 10^8 rows, if any): k1_emit lists them, k1_rare walks them row by row,
+// one thread each, after the host has seen the count.
+__global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int64_t *__restrict__ rare_list, int64_t n_rare) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_rare) return;
+    const int64_t q = rare_list[i];
+    const Payload P = sorted[q];
     const NbDesc d = A.desc[P.nb];
-    const int64_t r = P.r;
+    RowSrc S{A.T.pos, A.T.ev, A.T.mu, A.T.flags, false, 0.0};
+    emit_record(A, S, d, P.nb, P.r, P.m, q);
+}
+
+__global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
+    const DevTable &T = A.T;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
+    const int s = lane & (EG - 1);
+    const int gsh = lane & ~(EG - 1);                        // first lane of my group
+    const int k = A.k;
+    // grid-stride over groups of 64/EG windows per wave (the record count is only known on the device)
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; (t - lane) / EG < n_rec; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = t / EG;
+    const bool live = q < n_rec;
+    Payload P;
+    P.flags = PF_EXTRA; P.nb = 0; P.r = 0; P.m = 0; P.close_row = 0; P.close_pos = 0;
+    P.code[0] = P.code[1] = P.code[2] = P.code[3] = ~0ull;
+    if (live) P = sorted[q];
+    const int64_t r = A.debug == 5 ? 40 + q * 8 : P.r;          // (timing experiment: sequential instead of scattered rows)
     const int m = P.m;
-    if (P.flags & PF_EXTRA) {
-        for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
-        A.O.site_pos[q] = m;
-        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
-        A.O.close_row[q] = P.close_row;
-        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && d.extra_multi()) ? MC_I_MULTI : 0u);
-        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
-        return;
-    }
-    if (P.flags & PF_SLOW) {
-        RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
-        emit_record(A, S, d, P.nb, r, m, q);
-        return;
-    }
-    const uint32_t c0 = P.code[0], c1 = P.code[1], c2 = P.code[2], c3 = P.code[3];
-    const uint32_t inwin = ~(c0 & c1 & c2 & c3);          // code 15 = not part of the window
-    // ---- fetch (event, model) of the window's rows ----
-    int32_t dv[WROWS];
-#pragma unroll
-    for (int j = 0; j < WROWS; ++j) {
-        const int64_t ra = (inwin >> j) & 1u ? r - j : r;
-        const int2 em = T.evmu[ra];
-        dv[j] = em.x - em.y;
-    }
-    // per-slot counts
-    int nskip = 0;
-    bool any8 = false, big = false;
-    unsigned long long cnt8 = 0;
-    for (int s2 = 0; s2 < k; ++s2) {
-        const uint32_t ms = (s2 & 1 ? c0 : ~c0) & (s2 & 2 ? c1 : ~c1) & (s2 & 4 ? c2 : ~c2) & ~c3;
-        const int n = __popc(ms);
-        nskip += (n == 0);
-        any8 |= (n >= 8);
-        big |= (n > 128);
-        cnt8 |= (unsigned long long)(n & 0xFF) << (8 * s2);
-    }
-    uint32_t info = d.rev ? MC_I_REV : 0u;
-    if (nskip > A.skip_thresh) {
-        info |= MC_I_TOO_MANY;
-        for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
-    } else {
-        double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, f5 = 0.0, f6 = 0.0, f7 = 0.0;
-        if (!any8) {
-            // every slot has < 8 events: sequential from -0.0, oldest row first (np.mean, :186)
-            f0 = f1 = f2 = f3 = f4 = f5 = f6 = f7 = -0.0;
-#pragma unroll
-            for (int j = WROWS - 1; j >= 0; --j) {
-                if (!((inwin >> j) & 1u)) continue;
-                const double v = (double)dv[j] / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
-                const int code = ((c0 >> j) & 1u) | (((c1 >> j) & 1u) << 1) | (((c2 >> j) & 1u) << 2);
-                switch (code) {
-                    case 0: f0 += v; break;
-                    case 1: f1 += v; break;
-                    case 2: f2 += v; break;
-                    case 3: f3 += v; break;
-                    case 4: f4 += v; break;
-                    case 5: f5 += v; break;
-                    case 6: f6 += v; break;
-                    default: f7 += v; break;
-                }
-            }
+    const bool fast = live && !(P.flags & (PF_EXTRA | PF_SLOW));
+    if (live && !fast && s == 0) {
+        if (P.flags & PF_EXTRA) {               // the one-event '+' window of a palindromic first site row (R5)
+            for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+            A.O.site_pos[q] = m;
+            A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+            A.O.close_row[q] = P.close_row;
+            A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
+            A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
         } else {
-            // a slot with 8..32 events: NumPy's eight strided accumulators, slot by slot
-            for (int s2 = 0; s2 < k; ++s2) {
-                const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
-                const int n8 = n < 8 ? 0 : n - (n % 8);
-                const uint32_t ms = (s2 & 1 ? c0 : ~c0) & (s2 & 2 ? c1 : ~c1) & (s2 & 4 ? c2 : ~c2) & ~c3;
-                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0, tail = -0.0;
-                int i = 0;
+            A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
+        }
+    }
+    // ---- my slot's rows: bit j of ms <=> row r-j belongs to slot s ----
+    const uint64_t c0 = P.code[0], c1 = P.code[1], c2 = P.code[2], c3 = P.code[3];
+    uint64_t ms = (s & 1 ? c0 : ~c0) & (s & 2 ? c1 : ~c1) & (s & 4 ? c2 : ~c2) & ~c3;
+    if (!fast || s >= k) ms = 0ull;
+    // the stray event of a palindromic first site row (R5): first in the slot of its pseudo-position
+    bool has_stray = false;
+    double stray_val = 0.0;
+    if (fast && (P.flags & PF_STRAY)) {
+        const NbDesc *ds = A.desc + P.nb;
+        const int sq = m - ds->stray_q;
+        if (s < k && sq == s) { has_stray = true; stray_val = (double)ds->stray_d / 10000.0; }
+    }
+    const int n = __popcll(ms) + (has_stray ? 1 : 0);
+    const uint32_t empties = (uint32_t)(__ballot(fast && s < k && n == 0) >> gsh) & 0xFFu;    // bit s: slot s is empty
+    if (!fast) continue;
+    const bool too_many = __popc(empties) > A.skip_thresh;
+    const bool rev = P.flags & PF_REV;
+    if (s < k) {
+        double f = 0.0;
+        if (!too_many && n > 0) {
+            double acc;
+            if (n < 8) {
+                // up to four rows fetched together (the usual case: ~2 events per position), the rest one by one
+                uint64_t mm = ms;
+                const int nr = n - (has_stray ? 1 : 0);
+                int2 e[4];
 #pragma unroll
-                for (int j = WROWS - 1; j >= 0; --j) {
-                    if (!((ms >> j) & 1u)) continue;
-                    const double v = (double)dv[j] / 10000.0;
+                for (int i = 0; i < 4; ++i) {
+                    int j = 0;
+                    if (mm) { j = 63 - __clzll(mm); mm &= ~(1ull << j); }
+                    e[i] = T.evmu[r - j];
+                }
+                acc = -0.0;
+                if (has_stray) acc += stray_val;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nr) acc += (double)(e[i].x - e[i].y) / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+                while (mm) {
+                    const int j = 63 - __clzll(mm);
+                    mm &= ~(1ull << j);
+                    const int2 em = T.evmu[r - j];
+                    acc += (double)(em.x - em.y) / 10000.0;
+                }
+            } else {
+                // 8..65 values: NumPy's eight strided accumulators over the first n - n%8, then the tail in order
+                const int n8 = n - (n % 8);
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
+                acc = -0.0;
+                uint64_t mm = ms;
+                bool stray_next = has_stray;
+                for (int i = 0; i < n; ++i) {
+                    double v;
+                    if (stray_next) { v = stray_val; stray_next = false; }
+                    else {
+                        const int j = 63 - __clzll(mm);
+                        mm &= ~(1ull << j);
+                        const int2 em = T.evmu[r - j];
+                        v = (double)(em.x - em.y) / 10000.0;
+                    }
                     if (i < n8) {
                         switch (i & 7) {
                             case 0: r0 += v; break;
@@ -1269,55 +1308,47 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const int64_t *__restri
                             case 6: r6 += v; break;
                             default: r7 += v; break;
                         }
-                        if (i == n8 - 1) tail = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                        if (i == n8 - 1) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
                     } else {
-                        tail += v;
+                        acc += v;
                     }
-                    ++i;
-                }
-                switch (s2) {
-                    case 0: f0 = tail; break;
-                    case 1: f1 = tail; break;
-                    case 2: f2 = tail; break;
-                    case 3: f3 = tail; break;
-                    case 4: f4 = tail; break;
-                    case 5: f5 = tail; break;
-                    case 6: f6 = tail; break;
-                    default: f7 = tail; break;
                 }
             }
+            f = (0.0 + acc) / (double)n;
         }
-        const double acc[MC_MAX_K] = {f0, f1, f2, f3, f4, f5, f6, f7};
-#pragma unroll
-        for (int s2 = 0; s2 < MC_MAX_K; ++s2) {
-            if (s2 >= k) continue;
-            const int dst = d.rev ? s2 : k - 1 - s2;      // :187-188
-            const int n = (int)((cnt8 >> (8 * s2)) & 0xFFull);
-            double f = 0.0;
-            if (n == 0) info |= 1u << dst;
-            else f = (0.0 + acc[s2]) / (double)n;
-            A.O.feats[q * k + dst] = f;
-        }
-        (void)big;    // a window of 32 rows cannot hold a slot of > 128 events
-        // context[k], the character after the 'M', picks the sub-model (:197)
-        const int64_t L = d.contig_len;
-        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
-            info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
-        } else {
-            const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
-            unsigned char ch;
-            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-        }
+        const int dst = (too_many || rev) ? s : k - 1 - s;           // :187-188
+        A.O.feats[q * k + dst] = f;
     }
-    if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
-    A.O.site_pos[q] = m;
-    A.O.site_seg[q] = T.nb_seg_begin[P.nb];
-    A.O.close_row[q] = P.close_row;
-    A.O.info[q] = info;
-    A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+    if (s == 0) {
+        uint32_t info = rev ? MC_I_REV : 0u;
+        if (too_many) info |= MC_I_TOO_MANY;
+        else {
+            // bit dst of the info word: feature dst came from an empty slot (:186)
+            uint32_t em = empties;
+            if (!rev) em = (__brev(empties) >> 24) >> (8 - k);
+            info |= em & MC_I_EMPTY_MASK;
+            // context[k], the character after the 'M', picks the sub-model (:197)
+            const NbDesc *dp = A.desc + P.nb;
+            const int64_t L = dp->contig_len;
+            if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
+                info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
+            } else {
+                const uint32_t *bits = (rev ? A.R.mr : A.R.mf) + dp->mask_off;
+                const uint8_t *seq = A.R.seq + A.R.seq_off[dp->contig];
+                unsigned char ch;
+                if (!rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
+                else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
+                info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+            }
+        }
+        if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
+        A.O.site_pos[q] = m;
+        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+        A.O.close_row[q] = P.close_row;
+        A.O.info[q] = info;
+        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    }
 }
 
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
@@ -1825,11 +1856,13 @@ struct mc_ctx {
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr;
     long long *tile_chunk = nullptr;
-    int64_t *rec_slot = nullptr;
+    Payload *payload_sorted = nullptr;   // payloads in file order (k1_list)
+    int64_t *rare_list = nullptr;
     Payload *payload = nullptr;
     long long payload_cap = 0;
     int n_cu = 256;
     int scan_wgs = MC_SCAN_WGS;    // resident k1_scan workgroups per CU (occupancy query; MCALLER_SCAN_WGS overrides)
+    int emit_wgs = 4;              // resident k1_emit workgroups per CU (occupancy query)
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
@@ -1926,7 +1959,9 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
         int occ = 0;       // resident k1_scan workgroups per CU: the grid is sized to it (tickets balance the rest)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1_scan, NTHREADS, 0) == hipSuccess && occ > 0) c->scan_wgs = occ;
         if (const char *e = getenv("MCALLER_SCAN_WGS")) { if (atoi(e) > 0) c->scan_wgs = atoi(e); }
-        if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: %d CUs, k1_scan occupancy %d workgroups/CU\n", c->n_cu, c->scan_wgs);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1_emit, 256, 0) == hipSuccess && occ > 0) c->emit_wgs = occ;
+        if (const char *e = getenv("MCALLER_EMIT_WGS")) { if (atoi(e) > 0) c->emit_wgs = atoi(e); }
+        if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: %d CUs, k1_scan occupancy %d workgroups/CU, k1_emit %d\n", c->n_cu, c->scan_wgs, c->emit_wgs);
     }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipMalloc((void **)&c->cnt, sizeof(Counters)));
@@ -2175,7 +2210,7 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
             return -10;
     }
     c->payload_cap = cap + (c->T.n_tiles + 1) * PT;
-    if (dev_alloc(c->rec_allocs, &c->rec_slot, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
+    if (dev_alloc(c->rec_allocs, &c->payload_sorted, (size_t)cap) || dev_alloc(c->rec_allocs, &c->rare_list, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
     c->last_k = k;
     c->O = c->Omain;
     return 0;
@@ -2288,16 +2323,16 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
         A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
         A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
-        A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig;
+        A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
         { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
         hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
                            c->stream, A);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
                            (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 64 + 255) / 256)), dim3(256), 0, c->stream, A, c->rec_slot);
-        hipLaunchKernelGGL(k1_emit, dim3((unsigned)((c->O.capacity + 255) / 256)), dim3(256), 0, c->stream, A,
-                           (const int64_t *)c->rec_slot);
+        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, c->stream, A, c->payload_sorted);
+        hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((c->O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
+                           c->stream, A, (const Payload *)c->payload_sorted);
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         Counters h;
         HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -2312,6 +2347,11 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         if (h.overflow) {                   // the buffers were a guess; the exact need is known now (+ shard skew)
             cap = std::max<int64_t>(cap * 2, n + n / 4 + 4096);
             continue;
+        }
+        if (h.n_rare) {
+            hipLaunchKernelGGL(k1_rare, dim3((h.n_rare + 63) / 64), dim3(64), 0, c->stream, A, (const Payload *)c->payload_sorted,
+                               (const int64_t *)c->rare_list, (int64_t)h.n_rare);
+            h.n_big = 1;                      // such a window may hold a slot of > 128 events: let k1_bigfix look
         }
         if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
         if (h.n_irregular) {

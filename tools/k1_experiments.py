@@ -15,7 +15,7 @@ table, qual = synth.make_table(n, seed=1000, codes=codes)
 _, weights, _, soc = submodel_setup(H.load_modelset('r95'), 'A')
 dev = Device(0)
 dev.set_reference(ref.device_arrays()); dev.upload_table(table); dev.set_read_quality(qual); dev.set_mlp(weights, soc)
-for dbg in (0, 0):
+for dbg in [int(x) for x in os.environ.get('K1_DEBUGS', '0,0').split(',')]:
     os.environ['MCALLER_K1_DEBUG'] = str(dbg)
     ts = []
     for it in range(8):
