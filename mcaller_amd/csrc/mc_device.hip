@@ -46,7 +46,7 @@ void mc_set_error(const char *fmt, ...);
 namespace {
 
 #ifndef MC_TILE
-#define MC_TILE 2048
+#define MC_TILE 3072
 #endif
 #ifndef MC_NTHREADS
 #define MC_NTHREADS 64
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         const int nb0 = td.nb0;
         // ... and the next tile's loads go out now; they land while this tile is processed
         const int64_t tile_n = tile_ahead(1);
-        if (tile_n < T.n_tiles) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);
+        if (tile_n < T.n_tiles && A.debug != 4) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);   // (4: timing experiment, walk only)
         PH(1);
 
         if (wave == 0 && A.debug != 3) {
