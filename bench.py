@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--events', type=float, default=1e8, help='event rows per GPU')
     ap.add_argument('--motif', default='GATC')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='one pass at a time (mc_extract_features) instead of two in flight')
     ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
     args = ap.parse_args()
 
@@ -70,26 +71,47 @@ def main():
     dev.set_read_quality(qual)
     dev.set_mlp(weights, soc)
 
-    def step():
+    # A step = one pass of the hot path over the resident table, records (slot means, sites, probabilities) landing in
+    # pinned host memory.  Passes are pipelined (the library's streaming interface, mc_extract_features_async /
+    # mc_wait_records): the copy-out of pass i runs on a second stream beside the kernels of pass i+1, two passes in
+    # flight at most; every pass's records are complete in host memory before the timed region ends.
+    # --no-pipeline times mc_extract_features instead (one pass at a time, host sync inside).
+    def step_sync():
         dev.run(6, 0, 0.0, tail_contig=-1, score=True)
-        return dev.fetch(copy=False)      # records land in pinned host memory inside the step
+        return dev.fetch(copy=False)
+
+    def run_steps(n_steps, on_done):
+        if args.no_pipeline:
+            for _ in range(n_steps):
+                on_done(step_sync())
+            return
+        dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+        for _ in range(n_steps - 1):
+            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+            on_done(dev.wait())
+        on_done(dev.wait())
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        rec = step()
-    k1_ms, tot_ms = [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
+    k1_ms, tot_ms, last = [], [], [None]
+
+    def on_done(rec):
+        last[0] = rec
         tm = dev.times_ms()
         k1_ms.append(tm['window_scan'] + tm['emit'])
         tot_ms.append(tm)
+
+    if args.warmup:
+        run_steps(args.warmup, on_done)
+    del k1_ms[:], tot_ms[:]
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps, on_done)          # the last wait() returns when the last pass's records are in host memory
     barrier()
     elapsed = time.perf_counter() - t0
+    rec = last[0]
     info = rec.info[:rec.n]
     n_calls = int(((info & _lib.I_TOO_MANY) == 0).sum())
 
@@ -183,6 +205,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
                                    'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
+                       'passes_in_flight': 1 if args.no_pipeline else 2,
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,6 +145,12 @@ struct DevForest {
 };
 
 constexpr int NSHARD = 8;  // record-slot counters, one per blockIdx & 7 (= XCD): no single hot atomic
+
+struct PassStatus {        // what the host needs to know about a finished pass (copied out with the records)
+    unsigned long long n_records;
+    unsigned int overflow, n_irregular, n_big, n_rare;
+    unsigned int pad[2];
+};
 
 struct Counters {          // device-side status block
     unsigned long long n_records;
@@ -1717,12 +1724,19 @@ __device__ __forceinline__ double tanh_1exp(double x) {
     return copysign((1.0 - t) / (1.0 + t), x);
 }
 
-__global__ __launch_bounds__(64) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
-                                              const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
-                                              const double *__restrict__ qual, const uint32_t *__restrict__ info,
-                                              const uint8_t *__restrict__ submodel_in, int64_t n,
-                                              double *__restrict__ prob) {
+// Eight lanes per record: lane `sub` of a group takes hidden units sub, sub+8, ... (four independent chains at a time: the
+// fp64 tanh is a long dependent sequence), the eight partial sums are combined with three butterfly steps.  203k records
+// alone would be 3k waves -- too few to fill 1024 SIMDs; this way the kernel runs 25k short waves.
+constexpr int K2L = 8;
+constexpr int K2_THREADS = 256;
+
+__global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+                                                     const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                     const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                     const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                     double *__restrict__ prob, const unsigned long long *__restrict__ n_dev) {
     extern __shared__ double s_w[];   // per model: W1[n_in*H] b1[H] W2[H] b2[1]
+    if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     const int H = M.n_hidden, NI = M.n_in;
     const int per = NI * H + 2 * H + 1;
     for (int i = threadIdx.x; i < M.n_models * per; i += blockDim.x) {
@@ -1735,54 +1749,53 @@ __global__ __launch_bounds__(64) void k2_mlp(DevMlp M, const double *__restrict_
         s_w[i] = v;
     }
     __syncthreads();
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    int mi;
-    double x[MC_MAX_K + 1];
-    if (submodel_in) {                       // plain batched call: X rows of n_in values
-        mi = submodel_in[r];
+    const int sub = (int)(threadIdx.x % K2L);
+    for (int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gid / K2L < n; gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = gid / K2L;
+        int mi;
+        double x[MC_MAX_K + 1];
+        if (submodel_in) {                       // plain batched call: X rows of n_in values
+            mi = submodel_in[r];
 #pragma unroll
-        for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
-    } else {                                 // flush records: k slot means + read quality (:189-193)
-        const uint32_t inf = info[r];
-        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
-        mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
-        const double q = qual[seg_read[site_seg[r]]];
+            for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+        } else {                                 // flush records: k slot means + read quality (:189-193)
+            const uint32_t inf = info[r];
+            if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) continue;
+            mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+            const double q = qual[seg_read[site_seg[r]]];
 #pragma unroll
-        for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+            for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+        }
+        if (mi >= M.n_models) continue;          // KeyError path (:218): the host decides
+        const double *w = s_w + (size_t)mi * per;
+        const double *b1 = w + NI * H, *w2 = b1 + H;
+        double z = 0.0;
+        for (int j0 = sub; j0 < H; j0 += 4 * K2L) {
+            const int j1 = j0 + K2L, j2 = j0 + 2 * K2L, j3 = j0 + 3 * K2L;
+            const bool v1 = j1 < H, v2 = j2 < H, v3 = j3 < H;
+            const int c1 = v1 ? j1 : j0, c2 = v2 ? j2 : j0, c3 = v3 ? j3 : j0;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int i = 0; i <= MC_MAX_K; ++i)
+                if (i < NI) {
+                    const double xi = x[i];
+                    a0 += xi * w[i * H + j0]; a1 += xi * w[i * H + c1];
+                    a2 += xi * w[i * H + c2]; a3 += xi * w[i * H + c3];
+                }
+            const double t0 = tanh_1exp(a0 + b1[j0]), t1 = tanh_1exp(a1 + b1[c1]), t2 = tanh_1exp(a2 + b1[c2]),
+                         t3 = tanh_1exp(a3 + b1[c3]);
+            z += t0 * w2[j0];
+            if (v1) z += t1 * w2[c1];
+            if (v2) z += t2 * w2[c2];
+            if (v3) z += t3 * w2[c3];
+        }
+#pragma unroll
+        for (int o = 1; o < K2L; o <<= 1) z += __shfl_xor(z, o);
+        if (sub == 0) {
+            z += w2[H];
+            prob[r] = 1.0 / (1.0 + exp(-z));
+        }
     }
-    if (mi >= M.n_models) return;            // KeyError path (:218): the host decides
-    const double *w = s_w + (size_t)mi * per;
-    const double *b1 = w + NI * H, *w2 = b1 + H;
-    // hidden units in groups of four independent chains (the fp64 tanh is a long dependent sequence); the sum over
-    // hidden units keeps its order j = 0, 1, 2, ...
-    double z = 0.0;
-    int j = 0;
-    for (; j + 4 <= H; j += 4) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int i = 0; i <= MC_MAX_K; ++i)
-            if (i < NI) {
-                const double xi = x[i];
-                a0 += xi * w[i * H + j]; a1 += xi * w[i * H + j + 1];
-                a2 += xi * w[i * H + j + 2]; a3 += xi * w[i * H + j + 3];
-            }
-        const double t0 = tanh_1exp(a0 + b1[j]), t1 = tanh_1exp(a1 + b1[j + 1]), t2 = tanh_1exp(a2 + b1[j + 2]),
-                     t3 = tanh_1exp(a3 + b1[j + 3]);
-        z += t0 * w2[j];
-        z += t1 * w2[j + 1];
-        z += t2 * w2[j + 2];
-        z += t3 * w2[j + 3];
-    }
-    for (; j < H; ++j) {
-        double a = 0.0;
-#pragma unroll
-        for (int i = 0; i <= MC_MAX_K; ++i)
-            if (i < NI) a += x[i] * w[i * H + j];
-        z += tanh_1exp(a + b1[j]) * w2[j];
-    }
-    z += w2[H];
-    prob[r] = 1.0 / (1.0 + exp(-z));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1828,6 +1841,30 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Pipelined passes: the status of a pass is frozen next to its records (the counters are reused by the next pass); the
+// host reads it on the copy stream and then moves exactly n records with the DMA engines while the next pass computes.
+// (A kernel that stores the records straight into pinned host memory reaches the same 54 GB/s, but every kernel of the
+// next pass that ENDS while it runs waits for it: the end-of-kernel cache write-back queues behind its PCIe writes --
+// measured with rocprofv3, see DESIGN.md.  DMA copies do not go through the shader caches.)
+// ---------------------------------------------------------------------------------------------------
+// (hipMemsetAsync would do, but the runtime's fill ends with a system-scope release, and that release waits behind the
+// PCIe writes of a copy-out running on the other stream: a plain kernel keeps the pass at agent scope)
+__global__ void k_zero_counters(Counters *cnt) {
+    unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
+    for (unsigned i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
+}
+
+__global__ void k_snapshot(const Counters *__restrict__ cnt, PassStatus *__restrict__ st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->n_records = cnt->n_records;
+        st->overflow = cnt->overflow;
+        st->n_irregular = cnt->n_irregular;
+        st->n_big = cnt->n_big;
+        st->n_rare = cnt->n_rare;
+    }
+}
+
 // ===================================================================================================
 // host side
 // ===================================================================================================
@@ -1868,6 +1905,19 @@ struct mc_ctx {
     int64_t last_n = 0;
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
+    // pipelined passes (mc_extract_features_async / mc_wait_records): two record sets, exported to pinned host memory
+    struct AsyncBuf {
+        DevRecords O;              // device records of the pass
+        DevRecords H;              // pinned host memory
+        PassStatus *st_dev = nullptr, *st_host = nullptr;
+        hipEvent_t ev_k2 = nullptr, ev_done = nullptr, ev_t[5] = {};
+        mc_params prm;
+        int64_t cap = 0;
+        int k = 0;
+        bool used = false, timed = false;
+        std::vector<void *> dev_allocs;
+    } ab[2];
+    int ab_head = 0, ab_tail = 0, ab_count = 0;
     // per-site reduction (mc_site_*): counts on the device, RCCL communicator
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
     int64_t *site_first = nullptr;    // [n_sites]
@@ -1930,6 +1980,7 @@ static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
 }
 
 extern "C" int mc_comm_destroy(mc_ctx *c);
+static void free_async(mc_ctx *c);
 
 // for the other translation units of the library (mc_train.hip)
 int mc_internal_device(const mc_ctx *c) { return c->device; }
@@ -1984,6 +2035,10 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->cnt) (void)hipFree(c->cnt);
     if (c->site_cnt) (void)hipFree(c->site_cnt);
     if (c->site_first) (void)hipFree(c->site_first);
+    free_async(c);
+    for (auto &b : c->ab) {
+        if (b.ev_k2) { (void)hipEventDestroy(b.ev_k2); (void)hipEventDestroy(b.ev_done); for (auto &e : b.ev_t) (void)hipEventDestroy(e); }
+    }
     mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     free_pinned(c->H);
@@ -2216,6 +2271,11 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
     return 0;
 }
 
+// k2_mlp blocks: enough for n records at K2L lanes each, at most a few per CU (the kernel strides over the rest)
+static unsigned k2_grid(const mc_ctx *c, int64_t n) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n * K2L + K2_THREADS - 1) / K2_THREADS, (int64_t)c->n_cu * 8));
+}
+
 static size_t mlp_lds_bytes(const DevMlp &M) {
     return (size_t)M.n_models * ((size_t)M.n_in * M.n_hidden + 2 * (size_t)M.n_hidden + 1) * 8;
 }
@@ -2276,9 +2336,46 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
     return 0;
 }
 
-extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_records) {
-    HIP_TRY(hipSetDevice(c->device));
-    *n_records = 0;
+// K0 (strand resolve) + K1 (scan, order, emit) of one pass into the record set O, on the ctx stream.  ev[0..3] are
+// recorded around the stages (mc_last_times_ms).
+static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &O, hipEvent_t *ev, K1Args *out_args) {
+    const DevTable &T = c->T;
+    const int k = prm->k;
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, c->stream, c->cnt);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
+    {
+        const int64_t threads = (int64_t)T.n_nb * 64;
+        hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                           c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
+        hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                           c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
+        hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->desc,
+                           (const int64_t *)c->nb_f0, prm->entry_read, c->cnt);
+        hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
+                           c->desc, k, c->tiles);
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    K1Args A;
+    A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
+    A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
+    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = c->cnt; A.k = k;
+    A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
+    { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+    hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
+                       c->stream, A);
+    if (ev) HIP_TRY(hipEventRecord(ev[2], c->stream));
+    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
+                       (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
+    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, c->stream, A, c->payload_sorted);
+    hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
+                       c->stream, A, (const Payload *)c->payload_sorted);
+    if (ev) HIP_TRY(hipEventRecord(ev[3], c->stream));
+    *out_args = A;
+    return 0;
+}
+
+// what every pass needs before it can be enqueued
+static int check_pass(mc_ctx *c, const mc_params *prm) {
     const DevTable &T = c->T;
     const int k = prm->k;
     if (k < 1 || k > MC_MAX_K) {
@@ -2298,6 +2395,15 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         mc_set_error("classifier expects %d inputs but num_variables+1 = %d", clf_in, k + 1);
         return -12;
     }
+    return 0;
+}
+
+extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_records) {
+    HIP_TRY(hipSetDevice(c->device));
+    *n_records = 0;
+    const DevTable &T = c->T;
+    const int k = prm->k;
+    if (int rc = check_pass(c, prm)) return rc;
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
 
@@ -2305,35 +2411,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
-        HIP_TRY(hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream));
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        {
-            const int64_t threads = (int64_t)T.n_nb * 64;
-            hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
-            hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
-            hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->desc,
-                               (const int64_t *)c->nb_f0, prm->entry_read, c->cnt);
-            hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                               c->desc, k, c->tiles);
-        }
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         K1Args A;
-        A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
-        A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
-        A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = c->O; A.cnt = c->cnt; A.k = k;
-        A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
-        { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-        hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
-                           c->stream, A);
-        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
-                           (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, c->stream, A, c->payload_sorted);
-        hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((c->O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
-                           c->stream, A, (const Payload *)c->payload_sorted);
-        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        if (int rc = enqueue_fast_path(c, prm, c->O, c->ev, &A)) return rc;
         Counters h;
         HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2366,9 +2445,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
                 hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, c->O.feats, k,
                                    c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob);
             else
-                hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M,
-                                   c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
-                                   c->O.prob);
+                hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M),
+                                   c->stream, c->M, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
+                                   (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr);
         }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         if (n > 0) {
@@ -2417,6 +2496,156 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
     return 0;
 }
 
+// ---- pipelined passes ----
+static void free_async(mc_ctx *c) {
+    for (auto &b : c->ab) {
+        free_pool(b.dev_allocs);
+        free_pinned(b.H);
+        if (b.st_host) (void)hipHostFree(b.st_host);
+        b.st_host = nullptr; b.st_dev = nullptr;
+        b.O = DevRecords();
+        b.cap = 0; b.k = 0; b.used = false;
+    }
+    c->ab_head = c->ab_tail = c->ab_count = 0;
+}
+
+static int pinned(void **host, size_t bytes) {
+    HIP_TRY(hipHostMalloc(host, std::max<size_t>(bytes, 256), hipHostMallocDefault));
+    return 0;
+}
+
+static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) {
+    if (b.cap >= cap && b.k == k) return 0;
+    if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
+    free_pool(b.dev_allocs);
+    free_pinned(b.H);
+    if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
+    if (dev_alloc(b.dev_allocs, &b.st_dev, 1)) return -10;
+    if (pinned((void **)&b.H.feats, (size_t)cap * k * 8) || pinned((void **)&b.H.site_pos, (size_t)cap * 4) ||
+        pinned((void **)&b.H.site_seg, (size_t)cap * 4) || pinned((void **)&b.H.close_row, (size_t)cap * 8) ||
+        pinned((void **)&b.H.info, (size_t)cap * 4) || pinned((void **)&b.H.prob, (size_t)cap * 8))
+        return -10;
+    b.H.capacity = cap;
+    if (!b.st_host && pinned((void **)&b.st_host, sizeof(PassStatus))) return -10;
+    if (!b.ev_k2) {
+        // events between device work only: no system-scope fence (it would stall behind the other stream's PCIe writes)
+        HIP_TRY(hipEventCreateWithFlags(&b.ev_k2, hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreate(&b.ev_done));
+        for (auto &e : b.ev_t) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+    }
+    b.cap = cap;
+    b.k = k;
+    b.used = false;
+    return 0;
+}
+
+extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
+    const bool trace_host = getenv("MCALLER_TRACE_HOST") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace_host) fprintf(stderr, "  async +%7.1f us %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count(), what);
+    };
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = check_pass(c, prm)) return rc;
+    if (c->F.left && prm->score) {
+        mc_set_error("mc_extract_features_async: the forest classifier runs in mc_extract_features only");
+        return -12;
+    }
+    if (c->ab_count >= 2) {
+        mc_set_error("mc_extract_features_async: two passes are in flight; call mc_wait_records first");
+        return -12;
+    }
+    const DevTable &T = c->T;
+    const int k = prm->k;
+    mc_ctx::AsyncBuf &b = c->ab[c->ab_head];
+    b.prm = *prm;
+    if (T.n_rows == 0 || T.n_nb == 0) {            // nothing to scan: an empty pass
+        if (int rc = ensure_async_buf(c, b, 1 << 16, k)) return rc;
+        memset(b.st_host, 0, sizeof(PassStatus));
+        b.used = false;
+        c->ab_head ^= 1;
+        c->ab_count += 1;
+        return 0;
+    }
+    const int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
+    if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
+    if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
+    lap("buffers ready");
+    if (b.used) HIP_TRY(hipStreamWaitEvent(c->stream, b.ev_done, 0));   // the record set is being reused
+    lap("stream wait enqueued");
+    K1Args A;
+    const bool timed = !getenv("MCALLER_ASYNC_NOEVENTS");
+    if (int rc = enqueue_fast_path(c, prm, b.O, timed ? b.ev_t : nullptr, &A)) return rc;
+    lap("K0+K1 enqueued");
+    hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, c->stream, (const Counters *)c->cnt, b.st_dev);
+    if (prm->score)
+        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), c->stream, c->M, b.O.feats, k,
+                           b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap, b.O.prob,
+                           (const unsigned long long *)&b.st_dev->n_records);
+    if (timed) HIP_TRY(hipEventRecord(b.ev_t[4], c->stream));
+    HIP_TRY(hipEventRecord(b.ev_k2, c->stream));
+    b.timed = timed;
+    // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
+    // copy-out of the previous pass, which mc_wait_records enqueues later)
+    HIP_TRY(hipGetLastError());
+    lap("export enqueued");
+    b.used = true;
+    c->ab_head ^= 1;
+    c->ab_count += 1;
+    return 0;
+}
+
+extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->ab_count == 0) {
+        mc_set_error("mc_wait_records: no pass in flight");
+        return -12;
+    }
+    mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
+    c->ab_tail ^= 1;
+    c->ab_count -= 1;
+    if (b.used) {                                                // the status first, then exactly n records (DMA)
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_k2, 0));
+        HIP_TRY(hipMemcpyAsync(b.st_host, b.st_dev, sizeof(PassStatus), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    }
+    const PassStatus st = *b.st_host;
+    if (b.used && !(st.overflow || st.n_irregular || st.n_big || st.n_rare) && st.n_records > 0) {
+        const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
+        const int k = b.k;
+        hipStream_t cs = c->copy_stream;
+        HIP_TRY(hipMemcpyAsync(b.H.feats, b.O.feats, n * k * 8, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b.H.site_pos, b.O.site_pos, n * 4, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b.H.site_seg, b.O.site_seg, n * 4, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b.H.close_row, b.O.close_row, n * 8, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b.H.info, b.O.info, n * 4, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b.H.prob, b.O.prob, n * 8, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipEventRecord(b.ev_done, cs));
+        HIP_TRY(hipEventSynchronize(b.ev_done));
+    }
+    if (st.overflow || st.n_irregular || st.n_big || st.n_rare) {
+        // a pass the fast path alone cannot finish (record buffers too small, irregular reads, very long windows):
+        // run it again through mc_extract_features, which handles all of that, and hand out its buffers
+        int64_t n = 0;
+        if (int rc = mc_extract_features(c, &b.prm, &n)) return rc;
+        *n_records = n;
+        return mc_fetch_records_view(c, out);
+    }
+    const int64_t n = (int64_t)st.n_records;
+    if (b.used && b.timed) {
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], b.ev_t[i], b.ev_t[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&c->times[4], b.ev_t[0], b.ev_t[4]));
+    }
+    c->O = b.O;                    // what mc_site_counts reduces: the records of the pass just handed out
+    c->last_n = n;
+    c->last_k = b.k ? b.k : c->last_k;
+    *n_records = n;
+    out->capacity = n;
+    out->feats = b.H.feats; out->site_pos = b.H.site_pos; out->site_seg = b.H.site_seg;
+    out->close_row = b.H.close_row; out->info = b.H.info; out->prob = b.H.prob;
+    return 0;
+}
+
 extern "C" int mc_last_times_ms(mc_ctx *c, float *out5) {
     for (int i = 0; i < 5; ++i) out5[i] = c->times[i];
     return 0;
@@ -2443,9 +2672,9 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
                            (const uint32_t *)nullptr, ds, n, dp);
     else
-        hipLaunchKernelGGL(k2_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
+        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                           (const uint32_t *)nullptr, ds, n, dp);
+                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());

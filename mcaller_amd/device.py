@@ -97,6 +97,21 @@ class Device(object):
         self._last = (n.value, int(k))
         return n.value
 
+    def run_async(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
+        """Enqueue one pass (K0+K1+K2 + copy-out into pinned host memory on a second stream); at most two in flight."""
+        p = Params(int(k), int(skip_thresh), float(qual_thresh), int(tail_contig), 1 if score else 0,
+                   int(entry_read), int(entry_first_idx))
+        check(lib().mc_extract_features_async(self._ctx, C.byref(p)))
+        self._async_k = getattr(self, '_async_k', []) + [int(k)]
+
+    def wait(self):
+        """Records of the oldest pass in flight: views of pinned buffers, valid until the second-next run_async."""
+        n, v = C.c_int64(0), _lib.CallsView()
+        check(lib().mc_wait_records(self._ctx, C.byref(n), C.byref(v)))
+        k = self._async_k.pop(0)
+        self._last = (n.value, k)
+        return Records.from_view(v, n.value, k, self)
+
     def fetch(self, copy=True):
         """Records of the last run.  copy=False: views of the context's pinned buffers (overwritten by the next run)."""
         n, k = self._last

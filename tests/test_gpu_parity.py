@@ -190,3 +190,86 @@ def test_fresh_random_cases(dev, tmp_path, flavour, n):
             raise AssertionError('seed %d (%s): %s' % (case['seed'], flavour, str(e)[:300]))
     print('%s: %d identical' % (flavour, n_ok))
     assert n_ok >= n // 2
+
+
+def test_pipelined_passes_equal_the_synchronous_path(dev, tmp_path):
+    """mc_extract_features_async / mc_wait_records: two passes in flight, records exported by a kernel into pinned host
+    memory -- identical to mc_extract_features, for different parameters per pass, and for passes the fast path cannot
+    finish alone (irregular reads: the micro-cases), which fall back inside mc_wait_records."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=600000, seed=13)
+    ref = synth.SynthRef(codes, motif='GATC')
+    table, qual = synth.make_table(700000, seed=31, codes=codes)
+    modelset = H.load_modelset('r95')
+    _, weights, _, soc = ec.submodel_setup(modelset, 'A')
+    dev.set_reference(ref.device_arrays())
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    dev.set_mlp(weights, soc)
+    params = [(6, 0, 0.0), (6, 1, 0.0), (6, 0, 9.0), (5, 2, 0.0), (6, 0, 0.0)]
+    sync = []
+    for k, skip, q in params:
+        if k != 6:
+            sync.append(None)
+            continue
+        sync.append(dev.extract(k, skip, q))
+    got = []
+    dev.run_async(*params[0])
+    for i in range(1, len(params)):
+        if params[i][0] == 6:
+            dev.run_async(*params[i])
+        else:
+            dev.run_async(params[i][0], params[i][1], params[i][2], score=False)      # features only: k+1 != model inputs
+        r = dev.wait()
+        got.append((r.n, r.feats[:r.n * r.k].copy(), r.site_pos[:r.n].copy(), r.info[:r.n].copy(), r.prob[:r.n].copy(),
+                    r.close_row[:r.n].copy(), r.site_seg[:r.n].copy()))
+    r = dev.wait()
+    got.append((r.n, r.feats[:r.n * r.k].copy(), r.site_pos[:r.n].copy(), r.info[:r.n].copy(), r.prob[:r.n].copy(),
+                r.close_row[:r.n].copy(), r.site_seg[:r.n].copy()))
+    for (k, skip, q), s_rec, g in zip(params, sync, got):
+        if s_rec is None:
+            orc = H.oracle_records(table, ref.device_arrays(), qual, k, skip, q)
+            assert g[0] == orc.n and (g[1] == orc.feats[:orc.n * k]).all() and (g[2] == orc.site_pos[:orc.n]).all()
+            continue
+        n = s_rec.n
+        assert g[0] == n > 100
+        assert (g[1] == s_rec.feats[:n * k]).all() and (g[2] == s_rec.site_pos[:n]).all() and (g[3] == s_rec.info[:n]).all()
+        assert (g[5] == s_rec.close_row[:n]).all() and (g[6] == s_rec.site_seg[:n]).all()
+        assert np.array_equal(g[4], s_rec.prob[:n], equal_nan=True)
+    # irregular reads: the pass is redone by the synchronous path inside wait()
+    n_checked = 0
+    for case in H.micro_cases()[:60]:
+        if case['expected']['outcome'] != 'ok' or case['args']['train']:
+            continue
+        d = tmp_path / ('p%d' % case['seed'])
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        from mcaller_amd.read_qual import extract_read_quality
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                P = ec.prepare(paths['tsv'], paths['fasta'], extract_read_quality(paths['fastq']), 0,
+                               os.path.getsize(paths['tsv']), case['args']['base'], case['args']['motif'], paths['positions'])
+        except BaseException:
+            continue
+        if P.fatal is not None or P.table.n_rows == 0:
+            continue
+        a = case['args']
+        ms = H.load_modelset(a['model'])
+        _, w, _, so = ec.submodel_setup(ms, a['base'])
+        if w[0].n_in != a['k'] + 1:
+            continue
+        dev.set_reference(P.ref.device_arrays())
+        dev.upload_table(P.table)
+        dev.set_read_quality(P.qual)
+        dev.set_mlp(w, so)
+        want = dev.extract(a['k'], a['skip_thresh'], a['qual_thresh'])
+        dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'])
+        dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'])
+        for _ in range(2):
+            r = dev.wait()
+            assert r.n == want.n
+            assert (r.feats[:r.n * r.k] == want.feats[:want.n * want.k]).all() and (r.info[:r.n] == want.info[:want.n]).all()
+            assert np.array_equal(r.prob[:r.n], want.prob[:want.n], equal_nan=True)
+        n_checked += 1
+    assert n_checked > 20
