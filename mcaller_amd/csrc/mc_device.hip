@@ -146,12 +146,6 @@ struct DevForest {
 
 constexpr int NSHARD = 8;  // record-slot counters, one per blockIdx & 7 (= XCD): no single hot atomic
 
-struct PassStatus {        // what the host needs to know about a finished pass (copied out with the records)
-    unsigned long long n_records;
-    unsigned int overflow, n_irregular, n_big, n_rare;
-    unsigned int pad[2];
-};
-
 struct Counters {          // device-side status block
     unsigned long long n_records;
     unsigned long long shard[NSHARD];
@@ -1842,12 +1836,31 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
-// Pipelined passes: the status of a pass is frozen next to its records (the counters are reused by the next pass); the
-// host reads it on the copy stream and then moves exactly n records with the DMA engines while the next pass computes.
+// Pipelined passes: every pass in flight has its own counters, strand-resolve output and record set; the host reads
+// the counters on the copy stream and then moves exactly n records with the DMA engines while the next pass computes.
 // (A kernel that stores the records straight into pinned host memory reaches the same 54 GB/s, but every kernel of the
 // next pass that ENDS while it runs waits for it: the end-of-kernel cache write-back queues behind its PCIe writes --
 // measured with rocprofv3, see DESIGN.md.  DMA copies do not go through the shader caches.)
 // ---------------------------------------------------------------------------------------------------
+// The five narrow record columns of a pass, first n entries each, one after the other in a staging block: the copy-out
+// is then two DMA transfers (slot means; everything else) instead of six with a gap after each.
+__global__ __launch_bounds__(256) void k_pack(DevRecords O, const Counters *__restrict__ cnt, unsigned char *__restrict__ out) {
+    const int64_t n = min((int64_t)cnt->n_records, O.capacity);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t *o_close = reinterpret_cast<int64_t *>(out);
+    double *o_prob = reinterpret_cast<double *>(out + 8 * n);
+    int32_t *o_pos = reinterpret_cast<int32_t *>(out + 16 * n);
+    int32_t *o_seg = reinterpret_cast<int32_t *>(out + 20 * n);
+    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + 24 * n);
+    for (int64_t i = t; i < n; i += stride) {
+        o_close[i] = O.close_row[i];
+        o_prob[i] = O.prob[i];
+        o_pos[i] = O.site_pos[i];
+        o_seg[i] = O.site_seg[i];
+        o_info[i] = O.info[i];
+    }
+}
+
 // (hipMemsetAsync would do, but the runtime's fill ends with a system-scope release, and that release waits behind the
 // PCIe writes of a copy-out running on the other stream: a plain kernel keeps the pass at agent scope)
 __global__ void k_zero_counters(Counters *cnt) {
@@ -1855,19 +1868,19 @@ __global__ void k_zero_counters(Counters *cnt) {
     for (unsigned i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
 }
 
-__global__ void k_snapshot(const Counters *__restrict__ cnt, PassStatus *__restrict__ st) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        st->n_records = cnt->n_records;
-        st->overflow = cnt->overflow;
-        st->n_irregular = cnt->n_irregular;
-        st->n_big = cnt->n_big;
-        st->n_rare = cnt->n_rare;
-    }
-}
-
 // ===================================================================================================
 // host side
 // ===================================================================================================
+constexpr int MC_PASSES_IN_FLIGHT = 3;   // one being copied out, one computing, one queued behind it
+
+// What K0 writes and K1 reads, per pass in flight
+struct K0Set {
+    NbDesc *desc = nullptr;
+    TileDesc *tiles = nullptr;
+    int64_t *nb_f0 = nullptr;
+    int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
+};
+
 struct mc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1909,14 +1922,19 @@ struct mc_ctx {
     struct AsyncBuf {
         DevRecords O;              // device records of the pass
         DevRecords H;              // pinned host memory
-        PassStatus *st_dev = nullptr, *st_host = nullptr;
-        hipEvent_t ev_k2 = nullptr, ev_done = nullptr, ev_t[5] = {};
+        K0Set K;                   // strand resolve output of the pass
+        Counters *cnt = nullptr;   // its counters (device) ...
+        Counters *st_host = nullptr; // ... and where the host reads them (pinned)
+        unsigned char *pack = nullptr, *pack_host = nullptr;   // narrow columns, packed (device staging, pinned host)
+        // stage boundaries: dependencies between the streams, and the kernel times
+        hipEvent_t ev_k0_start = nullptr, ev_k0_end = nullptr, ev_scan_start = nullptr, ev_scan_end = nullptr,
+                   ev_emit_end = nullptr, ev_k2_start = nullptr, ev_k2_end = nullptr, ev_done = nullptr;
         mc_params prm;
-        int64_t cap = 0;
+        int64_t cap = 0, n_nb = 0, n_tiles = 0;
         int k = 0;
-        bool used = false, timed = false;
+        bool used = false;
         std::vector<void *> dev_allocs;
-    } ab[2];
+    } ab[MC_PASSES_IN_FLIGHT];
     int ab_head = 0, ab_tail = 0, ab_count = 0;
     // per-site reduction (mc_site_*): counts on the device, RCCL communicator
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
@@ -1981,6 +1999,7 @@ static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
 
 extern "C" int mc_comm_destroy(mc_ctx *c);
 static void free_async(mc_ctx *c);
+static int sync_pass_streams(mc_ctx *c);
 
 // for the other translation units of the library (mc_train.hip)
 int mc_internal_device(const mc_ctx *c) { return c->device; }
@@ -2035,10 +2054,11 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->cnt) (void)hipFree(c->cnt);
     if (c->site_cnt) (void)hipFree(c->site_cnt);
     if (c->site_first) (void)hipFree(c->site_first);
+    (void)sync_pass_streams(c);
     free_async(c);
-    for (auto &b : c->ab) {
-        if (b.ev_k2) { (void)hipEventDestroy(b.ev_k2); (void)hipEventDestroy(b.ev_done); for (auto &e : b.ev_t) (void)hipEventDestroy(e); }
-    }
+    for (auto &b : c->ab)
+        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done})
+            if (e) (void)hipEventDestroy(e);
     mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     free_pinned(c->H);
@@ -2336,41 +2356,54 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
     return 0;
 }
 
-// K0 (strand resolve) + K1 (scan, order, emit) of one pass into the record set O, on the ctx stream.  ev[0..3] are
-// recorded around the stages (mc_last_times_ms).
-static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &O, hipEvent_t *ev, K1Args *out_args) {
+// K0 (strand resolve) of one pass on stream st: counters zeroed, first site rows, classification, tile descriptors.
+static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st) {
     const DevTable &T = c->T;
     const int k = prm->k;
-    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, c->stream, c->cnt);
-    if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
-    {
-        const int64_t threads = (int64_t)T.n_nb * 64;
-        hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                           c->qual, prm->qual_thresh, k, c->desc, c->nb_f0, c->nb_f0idx, c->nb_lastidx);
-        hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                           c->desc, c->nb_f0, prm->entry_read, k, prm->skip_thresh, c->cnt);
-        hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, c->stream, T, c->desc,
-                           (const int64_t *)c->nb_f0, prm->entry_read, c->cnt);
-        hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T, c->R,
-                           c->desc, k, c->tiles);
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, st, cnt);
+    const int64_t threads = (int64_t)T.n_nb * 64;
+    hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
+                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx);
+    hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
+                       K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt);
+    hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, K.desc,
+                       (const int64_t *)K.nb_f0, prm->entry_read, cnt);
+    hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, st, T, c->R,
+                       K.desc, k, K.tiles);
+    return 0;
+}
+
+// K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
+static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
+                      hipEvent_t ev_scan_end, K1Args *out_args) {
+    const DevTable &T = c->T;
     K1Args A;
-    A.T = T; A.R = c->R; A.desc = c->desc; A.tiles = c->tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
+    A.T = T; A.R = c->R; A.desc = K.desc; A.tiles = K.tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
-    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = c->cnt; A.k = k;
+    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
     { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
     hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
-                       c->stream, A);
-    if (ev) HIP_TRY(hipEventRecord(ev[2], c->stream));
-    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, c->stream,
+                       st, A);
+    if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
+    hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, c->stream, A, c->payload_sorted);
+    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, c->payload_sorted);
     hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
-                       c->stream, A, (const Payload *)c->payload_sorted);
-    if (ev) HIP_TRY(hipEventRecord(ev[3], c->stream));
+                       st, A, (const Payload *)c->payload_sorted);
     *out_args = A;
+    return 0;
+}
+
+// the synchronous pass: everything on the ctx stream, ev[0..3] around the stages (mc_last_times_ms)
+static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &O, hipEvent_t *ev, K1Args *out_args) {
+    K0Set K;
+    K.desc = c->desc; K.tiles = c->tiles; K.nb_f0 = c->nb_f0; K.nb_f0idx = c->nb_f0idx; K.nb_lastidx = c->nb_lastidx;
+    HIP_TRY(hipEventRecord(ev[0], c->stream));
+    if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream)) return rc;
+    HIP_TRY(hipEventRecord(ev[1], c->stream));
+    if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args)) return rc;
+    HIP_TRY(hipEventRecord(ev[3], c->stream));
     return 0;
 }
 
@@ -2406,6 +2439,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     if (int rc = check_pass(c, prm)) return rc;
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
+    if (c->ab_count) { if (int rc = sync_pass_streams(c)) return rc; }   // pipelined passes share the scratch: let them finish
 
     free_pool(c->lit_allocs);
     int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
@@ -2497,14 +2531,19 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
 }
 
 // ---- pipelined passes ----
+// A pass computes on the ctx stream (K0, K1, K2, packing, back to back with the next pass) and is copied out on
+// copy_stream when it is waited for.
 static void free_async(mc_ctx *c) {
     for (auto &b : c->ab) {
         free_pool(b.dev_allocs);
-        free_pinned(b.H);
+        if (b.H.feats) (void)hipHostFree(b.H.feats);
+        b.H = DevRecords();
+        if (b.pack_host) (void)hipHostFree(b.pack_host);
         if (b.st_host) (void)hipHostFree(b.st_host);
-        b.st_host = nullptr; b.st_dev = nullptr;
+        b.st_host = nullptr; b.cnt = nullptr; b.pack = nullptr; b.pack_host = nullptr;
         b.O = DevRecords();
-        b.cap = 0; b.k = 0; b.used = false;
+        b.K = K0Set();
+        b.cap = b.n_nb = b.n_tiles = 0; b.k = 0; b.used = false;
     }
     c->ab_head = c->ab_tail = c->ab_count = 0;
 }
@@ -2515,44 +2554,45 @@ static int pinned(void **host, size_t bytes) {
 }
 
 static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) {
-    if (b.cap >= cap && b.k == k) return 0;
+    const DevTable &T = c->T;
+    if (!b.ev_done) {
+        for (hipEvent_t *e : {&b.ev_k0_start, &b.ev_k0_end, &b.ev_scan_start, &b.ev_scan_end, &b.ev_emit_end, &b.ev_k2_start,
+                              &b.ev_k2_end, &b.ev_done})
+            HIP_TRY(hipEventCreate(e));
+    }
+    if (b.cap >= cap && b.k == k && b.n_nb >= T.n_nb && b.n_tiles >= T.n_tiles) return 0;
     if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
     free_pool(b.dev_allocs);
-    free_pinned(b.H);
+    if (b.H.feats) (void)hipHostFree(b.H.feats);
+    b.H = DevRecords();
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
-    if (dev_alloc(b.dev_allocs, &b.st_dev, 1)) return -10;
-    if (pinned((void **)&b.H.feats, (size_t)cap * k * 8) || pinned((void **)&b.H.site_pos, (size_t)cap * 4) ||
-        pinned((void **)&b.H.site_seg, (size_t)cap * 4) || pinned((void **)&b.H.close_row, (size_t)cap * 8) ||
-        pinned((void **)&b.H.info, (size_t)cap * 4) || pinned((void **)&b.H.prob, (size_t)cap * 8))
+    if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
+    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)T.n_nb + 1) || dev_alloc(b.dev_allocs, &b.K.tiles, (size_t)T.n_tiles + 1) ||
+        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)T.n_nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0idx, (size_t)T.n_nb + 1) ||
+        dev_alloc(b.dev_allocs, &b.K.nb_lastidx, (size_t)T.n_nb + 1))
         return -10;
+    if (dev_alloc(b.dev_allocs, &b.pack, (size_t)cap * 28 + 64)) return -10;
+    if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
+    if (pinned((void **)&b.H.feats, (size_t)cap * k * 8) || pinned((void **)&b.pack_host, (size_t)cap * 28 + 64)) return -10;
     b.H.capacity = cap;
-    if (!b.st_host && pinned((void **)&b.st_host, sizeof(PassStatus))) return -10;
-    if (!b.ev_k2) {
-        // events between device work only: no system-scope fence (it would stall behind the other stream's PCIe writes)
-        HIP_TRY(hipEventCreateWithFlags(&b.ev_k2, hipEventDisableSystemFence));
-        HIP_TRY(hipEventCreate(&b.ev_done));
-        for (auto &e : b.ev_t) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
-    }
+    if (!b.st_host && pinned((void **)&b.st_host, sizeof(Counters))) return -10;
     b.cap = cap;
     b.k = k;
+    b.n_nb = T.n_nb;
+    b.n_tiles = T.n_tiles;
     b.used = false;
     return 0;
 }
 
 extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
-    const bool trace_host = getenv("MCALLER_TRACE_HOST") != nullptr;
-    const auto t_in = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (trace_host) fprintf(stderr, "  async +%7.1f us %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count(), what);
-    };
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = check_pass(c, prm)) return rc;
     if (c->F.left && prm->score) {
         mc_set_error("mc_extract_features_async: the forest classifier runs in mc_extract_features only");
         return -12;
     }
-    if (c->ab_count >= 2) {
-        mc_set_error("mc_extract_features_async: two passes are in flight; call mc_wait_records first");
+    if (c->ab_count >= MC_PASSES_IN_FLIGHT) {
+        mc_set_error("mc_extract_features_async: %d passes are in flight; call mc_wait_records first", MC_PASSES_IN_FLIGHT);
         return -12;
     }
     const DevTable &T = c->T;
@@ -2561,37 +2601,44 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     b.prm = *prm;
     if (T.n_rows == 0 || T.n_nb == 0) {            // nothing to scan: an empty pass
         if (int rc = ensure_async_buf(c, b, 1 << 16, k)) return rc;
-        memset(b.st_host, 0, sizeof(PassStatus));
+        memset(b.st_host, 0, sizeof(Counters));
         b.used = false;
-        c->ab_head ^= 1;
+        c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
         c->ab_count += 1;
         return 0;
     }
     const int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
-    lap("buffers ready");
-    if (b.used) HIP_TRY(hipStreamWaitEvent(c->stream, b.ev_done, 0));   // the record set is being reused
-    lap("stream wait enqueued");
+    // the whole pass on the ctx stream, in order: K0, K1, K2, packing.  (Putting K0 and K2 on a second stream so that they
+    // run beside the neighbouring passes' scans was measured: 3 % more passes per second -- the copy-out is the limit by
+    // then -- for a scan that takes 20 % longer while it shares the CUs.  Not worth it; see DESIGN.md.)
+    hipStream_t st = c->stream;
+    HIP_TRY(hipEventRecord(b.ev_k0_start, st));
+    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st)) return rc;
+    HIP_TRY(hipEventRecord(b.ev_k0_end, st));
     K1Args A;
-    const bool timed = !getenv("MCALLER_ASYNC_NOEVENTS");
-    if (int rc = enqueue_fast_path(c, prm, b.O, timed ? b.ev_t : nullptr, &A)) return rc;
-    lap("K0+K1 enqueued");
-    hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, c->stream, (const Counters *)c->cnt, b.st_dev);
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, b.ev_scan_end, &A)) return rc;
+    HIP_TRY(hipEventRecord(b.ev_emit_end, st));
     if (prm->score)
-        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), c->stream, c->M, b.O.feats, k,
+        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, b.O.feats, k,
                            b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap, b.O.prob,
-                           (const unsigned long long *)&b.st_dev->n_records);
-    if (timed) HIP_TRY(hipEventRecord(b.ev_t[4], c->stream));
-    HIP_TRY(hipEventRecord(b.ev_k2, c->stream));
-    b.timed = timed;
+                           (const unsigned long long *)&b.cnt->n_records);
+    HIP_TRY(hipEventRecord(b.ev_k2_end, st));
+    hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, st, b.O, (const Counters *)b.cnt, b.pack);
+    HIP_TRY(hipEventRecord(b.ev_done, st));
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
     // copy-out of the previous pass, which mc_wait_records enqueues later)
     HIP_TRY(hipGetLastError());
-    lap("export enqueued");
     b.used = true;
-    c->ab_head ^= 1;
+    c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
     c->ab_count += 1;
+    return 0;
+}
+
+static int sync_pass_streams(mc_ctx *c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return 0;
 }
 
@@ -2602,28 +2649,29 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         return -12;
     }
     mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
-    c->ab_tail ^= 1;
+    c->ab_tail = (c->ab_tail + 1) % MC_PASSES_IN_FLIGHT;
     c->ab_count -= 1;
-    if (b.used) {                                                // the status first, then exactly n records (DMA)
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_k2, 0));
-        HIP_TRY(hipMemcpyAsync(b.st_host, b.st_dev, sizeof(PassStatus), hipMemcpyDeviceToHost, c->copy_stream));
+    if (b.used) {                                                // the counters first, then exactly n records (DMA)
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_done, 0));
+        HIP_TRY(hipMemcpyAsync(b.st_host, b.cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
     }
-    const PassStatus st = *b.st_host;
-    if (b.used && !(st.overflow || st.n_irregular || st.n_big || st.n_rare) && st.n_records > 0) {
+    const Counters st = *b.st_host;
+    const bool special = st.overflow || st.n_irregular || st.n_big || st.n_rare;
+    if (b.used && !special && st.n_records > 0) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
         const int k = b.k;
         hipStream_t cs = c->copy_stream;
         HIP_TRY(hipMemcpyAsync(b.H.feats, b.O.feats, n * k * 8, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.H.site_pos, b.O.site_pos, n * 4, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.H.site_seg, b.O.site_seg, n * 4, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.H.close_row, b.O.close_row, n * 8, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.H.info, b.O.info, n * 4, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.H.prob, b.O.prob, n * 8, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipEventRecord(b.ev_done, cs));
-        HIP_TRY(hipEventSynchronize(b.ev_done));
+        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, n * 28, hipMemcpyDeviceToHost, cs));
+        b.H.close_row = reinterpret_cast<int64_t *>(b.pack_host);
+        b.H.prob = reinterpret_cast<double *>(b.pack_host + 8 * n);
+        b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + 16 * n);
+        b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + 20 * n);
+        b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 24 * n);
+        HIP_TRY(hipStreamSynchronize(cs));
     }
-    if (st.overflow || st.n_irregular || st.n_big || st.n_rare) {
+    if (special) {
         // a pass the fast path alone cannot finish (record buffers too small, irregular reads, very long windows):
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
         int64_t n = 0;
@@ -2632,9 +2680,14 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         return mc_fetch_records_view(c, out);
     }
     const int64_t n = (int64_t)st.n_records;
-    if (b.used && b.timed) {
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], b.ev_t[i], b.ev_t[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&c->times[4], b.ev_t[0], b.ev_t[4]));
+    if (b.used) {
+        float t_k0 = 0, t_scan = 0, t_emit = 0, t_k2 = 0;
+        HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_k0_end));
+        HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_k0_end, b.ev_scan_end));
+        HIP_TRY(hipEventElapsedTime(&t_emit, b.ev_scan_end, b.ev_emit_end));
+        HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_emit_end, b.ev_k2_end));
+        c->times[0] = t_k0; c->times[1] = t_scan; c->times[2] = t_emit; c->times[3] = t_k2;
+        c->times[4] = t_k0 + t_scan + t_emit + t_k2;
     }
     c->O = b.O;                    // what mc_site_counts reduces: the records of the pass just handed out
     c->last_n = n;

@@ -17,10 +17,13 @@ dev.set_reference(ref.device_arrays()); dev.upload_table(table); dev.set_read_qu
 for rep in range(3):
     steps = 30
     t = time.perf_counter()
-    dev.run_async(6, 0, 0.0)
-    for _ in range(steps - 1):
+    depth = int(os.environ.get('DEPTH', '3'))
+    for _ in range(depth):
         dev.run_async(6, 0, 0.0)
+    for _ in range(steps - depth):
         r = dev.wait()
-    r = dev.wait()
+        dev.run_async(6, 0, 0.0)
+    for _ in range(depth):
+        r = dev.wait()
     dt = time.perf_counter() - t
     print('pipelined: %.3f ms per pass (%d records) env NOEVENTS=%s' % (dt / steps * 1e3, r.n, os.environ.get('MCALLER_ASYNC_NOEVENTS')))
