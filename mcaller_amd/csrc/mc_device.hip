@@ -106,6 +106,7 @@ struct DevTable {
     int32_t *nb_read = nullptr;       // [n_nb]
     uint8_t *nb_repeat = nullptr;     // [n_nb] read id seen in an earlier name block
     uint32_t *nb_vflags = nullptr;    // [n_nb]
+    NbDesc *nb_tmpl = nullptr;        // [n_nb] the pass-independent fields of the name-block descriptors (k_nb_template)
     int64_t n_tiles = 0;
     int32_t *tile_nb = nullptr;       // [n_tiles]
     int has_repeats = 0;
@@ -236,23 +237,58 @@ __global__ void k_interleave(DevTable T) {
 // One wave per name block.  Under the reference's rule for a read it has not seen a site row of yet
 // (`read_name != last_read`, :161-174) each unfiltered row is tested on the strand `rev = (col3 != col10)`;
 // the first row that holds an 'M' in its k-mer becomes the block's first site row f0.
+// (the fields of a descriptor that do not depend on the pass -- rows, contig, mask offset, read -- are prepared once per
+// table/reference by k_nb_template, so that a pass reads one 64-byte line per block instead of walking five tables)
+__global__ void k_nb_template(DevTable T, DevRef R) {
+    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (b >= T.n_nb) return;
+    NbDesc d;
+    d.row_begin = T.nb_row_begin[b];
+    d.row_end = T.nb_row_begin[b + 1];
+    d.contig = T.seg_contig[T.nb_seg_begin[b]];
+    d.mask_off = R.word_off[d.contig];
+    d.first_delta = -1;
+    d.contig_len = (int32_t)R.contig_len[d.contig];
+    d.read = T.nb_read[b];
+    d.stray_q = NO_STRAY;
+    d.stray_d = 0;
+    d.extra_mpos = 0;
+    d.mode = MODE_NONE;
+    d.rev = 0;
+    d.filtered = 0;
+    d.xflags = 0;
+    d.pad = T.nb_seg_begin[b + 1] - T.nb_seg_begin[b];      // segments (contigs) of the block
+    T.nb_tmpl[b] = d;
+}
+
 __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
                               int32_t *__restrict__ nb_lastidx) {
     const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= T.n_nb) return;
-    const int read = T.nb_read[b];
-    const bool filtered = qual[read] < qual_thresh;
+    NbDesc d = T.nb_tmpl[b];
+    const int n_seg = d.pad;
+    const bool filtered = qual[d.read] < qual_thresh;
+    const int32_t last_idx = T.idx[d.row_end - 1];
     int64_t f0 = -1;
     int f0rev = 0;
     if (!filtered) {
-        for (int seg = T.nb_seg_begin[b]; seg < T.nb_seg_begin[b + 1] && f0 < 0; ++seg) {
-            const int contig = T.seg_contig[seg];
-            const int64_t L = R.contig_len[contig];
-            const uint32_t *mf = R.mf + R.word_off[contig], *mr = R.mr + R.word_off[contig];
-            const int64_t se = T.seg_begin[seg + 1];
-            for (int64_t base = T.seg_begin[seg]; base < se && f0 < 0; base += 256) {
+        const int seg0 = n_seg == 1 ? 0 : T.nb_seg_begin[b];
+        for (int si = 0; si < n_seg && f0 < 0; ++si) {
+            int64_t L, sb, se;
+            const uint32_t *mf, *mr;
+            if (n_seg == 1) {                      // the usual case: everything is in the template
+                L = d.contig_len; sb = d.row_begin; se = d.row_end;
+                mf = R.mf + d.mask_off; mr = R.mr + d.mask_off;
+            } else {
+                const int seg = seg0 + si;
+                const int contig = T.seg_contig[seg];
+                L = R.contig_len[contig];
+                mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
+                sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
+            }
+            for (int64_t base = sb; base < se && f0 < 0; base += 256) {
                 // four stripes of 64 rows; all loads of the iteration are issued before any is used
                 uint32_t fl[4];
                 int ps[4];
@@ -288,26 +324,14 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
         }
     }
     if (lane == 0) {
-        NbDesc d;
-        d.row_begin = T.nb_row_begin[b];
-        d.row_end = T.nb_row_begin[b + 1];
-        d.contig = T.seg_contig[T.nb_seg_begin[b]];
-        d.mask_off = R.word_off[d.contig];
         d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
-        d.contig_len = (int32_t)R.contig_len[d.contig];
-        d.read = read;
-        d.stray_q = NO_STRAY;
-        d.stray_d = 0;
-        d.extra_mpos = 0;
-        d.mode = MODE_NONE;
         d.rev = (uint8_t)f0rev;
         d.filtered = filtered ? 1 : 0;
-        d.xflags = 0;
         d.pad = 0;
         desc[b] = d;
         nb_f0[b] = f0;
         nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
-        nb_lastidx[b] = T.idx[T.nb_row_begin[b + 1] - 1];
+        nb_lastidx[b] = last_idx;
     }
 }
 
@@ -1720,7 +1744,7 @@ __device__ __forceinline__ double tanh_1exp(double x) {
 
 // Eight lanes per record: lane `sub` of a group takes hidden units sub, sub+8, ... (four independent chains at a time: the
 // fp64 tanh is a long dependent sequence), the eight partial sums are combined with three butterfly steps.  203k records
-// alone would be 3k waves -- too few to fill 1024 SIMDs; this way the kernel runs 25k short waves.
+// alone would be 3k waves -- too few to fill 1024 SIMDs.
 constexpr int K2L = 8;
 constexpr int K2_THREADS = 256;
 
@@ -1743,51 +1767,71 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
         s_w[i] = v;
     }
     __syncthreads();
-    const int sub = (int)(threadIdx.x % K2L);
-    for (int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gid / K2L < n; gid += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = gid / K2L;
-        int mi;
-        double x[MC_MAX_K + 1];
-        if (submodel_in) {                       // plain batched call: X rows of n_in values
-            mi = submodel_in[r];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % K2L, grp = lane / K2L;
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // A wave takes K2C consecutive records at a time, finds the ones that are scored at all (skipped records and records
+    // whose context leaves the contig are not) and works through those, eight records per step: no lane idles on a
+    // record that needs no score.
+    constexpr int K2C = 16;
+    for (int64_t chunk = wave0 * K2C; chunk < n; chunk += n_waves * K2C) {
+        const int64_t rl = chunk + lane;
+        bool want = lane < K2C && rl < n;
+        if (want && !submodel_in) want = !(info[rl] & (MC_I_TOO_MANY | MC_I_EDGE));
+        unsigned long long todo = __ballot(want);
+        while (todo) {
+            // the grp-th record of this step = the grp-th set bit of todo
+            unsigned long long m = todo;
+            int64_t r = -1;
 #pragma unroll
-            for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
-        } else {                                 // flush records: k slot means + read quality (:189-193)
-            const uint32_t inf = info[r];
-            if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) continue;
-            mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
-            const double q = qual[seg_read[site_seg[r]]];
+            for (int g = 0; g < 64 / K2L; ++g) {
+                const int bit = m ? (int)__builtin_ctzll(m) : -1;
+                if (g == grp && bit >= 0) r = chunk + bit;
+                if (m) m &= m - 1;
+            }
+            todo = m;
+            if (r < 0) continue;
+            int mi;
+            double x[MC_MAX_K + 1];
+            if (submodel_in) {                       // plain batched call: X rows of n_in values
+                mi = submodel_in[r];
 #pragma unroll
-            for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
-        }
-        if (mi >= M.n_models) continue;          // KeyError path (:218): the host decides
-        const double *w = s_w + (size_t)mi * per;
-        const double *b1 = w + NI * H, *w2 = b1 + H;
-        double z = 0.0;
-        for (int j0 = sub; j0 < H; j0 += 4 * K2L) {
-            const int j1 = j0 + K2L, j2 = j0 + 2 * K2L, j3 = j0 + 3 * K2L;
-            const bool v1 = j1 < H, v2 = j2 < H, v3 = j3 < H;
-            const int c1 = v1 ? j1 : j0, c2 = v2 ? j2 : j0, c3 = v3 ? j3 : j0;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+            } else {                                 // flush records: k slot means + read quality (:189-193)
+                mi = M.sub_of_char[(info[r] >> MC_I_NEXT_SHIFT) & 0xFFu];
+                const double q = qual[seg_read[site_seg[r]]];
 #pragma unroll
-            for (int i = 0; i <= MC_MAX_K; ++i)
-                if (i < NI) {
-                    const double xi = x[i];
-                    a0 += xi * w[i * H + j0]; a1 += xi * w[i * H + c1];
-                    a2 += xi * w[i * H + c2]; a3 += xi * w[i * H + c3];
-                }
-            const double t0 = tanh_1exp(a0 + b1[j0]), t1 = tanh_1exp(a1 + b1[c1]), t2 = tanh_1exp(a2 + b1[c2]),
-                         t3 = tanh_1exp(a3 + b1[c3]);
-            z += t0 * w2[j0];
-            if (v1) z += t1 * w2[c1];
-            if (v2) z += t2 * w2[c2];
-            if (v3) z += t3 * w2[c3];
-        }
+                for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+            }
+            if (mi >= M.n_models) continue;          // KeyError path (:218): the host decides
+            const double *w = s_w + (size_t)mi * per;
+            const double *b1 = w + NI * H, *w2 = b1 + H;
+            double z = 0.0;
+            for (int j0 = sub; j0 < H; j0 += 4 * K2L) {
+                const int j1 = j0 + K2L, j2 = j0 + 2 * K2L, j3 = j0 + 3 * K2L;
+                const bool v1 = j1 < H, v2 = j2 < H, v3 = j3 < H;
+                const int c1 = v1 ? j1 : j0, c2 = v2 ? j2 : j0, c3 = v3 ? j3 : j0;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int o = 1; o < K2L; o <<= 1) z += __shfl_xor(z, o);
-        if (sub == 0) {
-            z += w2[H];
-            prob[r] = 1.0 / (1.0 + exp(-z));
+                for (int i = 0; i <= MC_MAX_K; ++i)
+                    if (i < NI) {
+                        const double xi = x[i];
+                        a0 += xi * w[i * H + j0]; a1 += xi * w[i * H + c1];
+                        a2 += xi * w[i * H + c2]; a3 += xi * w[i * H + c3];
+                    }
+                const double t0 = tanh_1exp(a0 + b1[j0]), t1 = tanh_1exp(a1 + b1[c1]), t2 = tanh_1exp(a2 + b1[c2]),
+                             t3 = tanh_1exp(a3 + b1[c3]);
+                z += t0 * w2[j0];
+                if (v1) z += t1 * w2[c1];
+                if (v2) z += t2 * w2[c2];
+                if (v3) z += t3 * w2[c3];
+            }
+#pragma unroll
+            for (int o = 1; o < K2L; o <<= 1) z += __shfl_xor(z, o);
+            if (sub == 0) {
+                z += w2[H];
+                prob[r] = 1.0 / (1.0 + exp(-z));
+            }
         }
     }
 }
@@ -1916,6 +1960,7 @@ struct mc_ctx {
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
+    bool tmpl_dirty = true;       // name-block descriptor templates must be rebuilt (new table or reference)
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
     // pipelined passes (mc_extract_features_async / mc_wait_records): two record sets, exported to pinned host memory
@@ -2082,6 +2127,7 @@ extern "C" int mc_ctx_sync(mc_ctx *c) {
 extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tmpl_dirty = true;
     free_pool(c->ref_allocs);
     DevRef &R = c->R;
     R.n_contigs = h->n_contigs;
@@ -2176,7 +2222,8 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     UP(T.nb_seg_begin, nb_seg.data(), nb_seg.size(), c->table_allocs);
     UP(T.nb_read, nb_read.data(), nb_read.size(), c->table_allocs);
     UP(T.nb_repeat, nb_rep.data(), nb_rep.size(), c->table_allocs);
-    if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1)) return -10;
+    if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &T.nb_tmpl, (size_t)T.n_nb + 1)) return -10;
+    c->tmpl_dirty = true;
     T.n_tiles = (n + TILE - 1) / TILE;
     if (dev_alloc(c->table_allocs, &T.tile_nb, (size_t)T.n_tiles + 1)) return -10;
     if (dev_alloc(c->table_allocs, &c->tiles, (size_t)T.n_tiles + 1) || dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
@@ -2292,8 +2339,8 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
 }
 
 // k2_mlp blocks: enough for n records at K2L lanes each, at most a few per CU (the kernel strides over the rest)
-static unsigned k2_grid(const mc_ctx *c, int64_t n) {
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n * K2L + K2_THREADS - 1) / K2_THREADS, (int64_t)c->n_cu * 8));
+static unsigned k2_grid(const mc_ctx *c, int64_t n) {       // one wave per 16 records, at most 8 blocks per CU
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 16 + 1 + K2_THREADS / 64 - 1) / (K2_THREADS / 64), (int64_t)c->n_cu * 8));
 }
 
 static size_t mlp_lds_bytes(const DevMlp &M) {
@@ -2360,6 +2407,10 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
 static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st) {
     const DevTable &T = c->T;
     const int k = prm->k;
+    if (c->tmpl_dirty) {
+        hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R);
+        c->tmpl_dirty = false;
+    }
     hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, st, cnt);
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
