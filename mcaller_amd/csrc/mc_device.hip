@@ -5,16 +5,22 @@
 //
 //   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone
 //                k_tile_nb       name block of the first row of every tile
-//   per call     k0_first_site   first site row of every name block under the "new read" strand rule
+//                k_interleave    (event, model) pairs interleaved: one DRAM page per window for k1_emit
+//                k_nb_template   the pass-independent fields of the name-block descriptors
+//   per pass     k0_first_site   first site row of every name block under the "new read" strand rule
 //                                (:161-174) -> strand of the block
-//                k0_classify     regular / no-sites / irregular per name block
-//                k1_scan         THE SCAN: one workgroup per tile of rows; columns are read once with
-//                                16-byte loads, (pos, event-model, site offset) are staged in LDS, and the
-//                                rows that end a window (last row whose first 'M' is the site) walk back
-//                                over the <= k positions of their window in LDS to build the slot means
-//                                (NumPy pairwise order, fp64) -> one flush record per closed window
-//                k1_group_scan/k1_list/k1_emit  per closed window: build the record, in file order
-//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64 (one lane per record)
+//                k0_classify / k0_extend / k0_tiles   regular / no-sites / irregular per name block; tile descriptors
+//                k1_scan         THE SCAN: persistent one-wave workgroups over tiles of 3072 rows; the position and
+//                                flag columns (5 B/row) go through registers (next tile in flight) into LDS; 8-row
+//                                units that can hold a site row are found from the strand bitmask, their rows are
+//                                tested for "last row of a window", and every closed window leaves a 64-byte
+//                                payload (which of the 64 rows before it belong to which slot, closing row)
+//                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
+//                k1_emit         eight lanes per window, one per slot: slot means in NumPy pairwise order (fp64)
+//                                from the (event, model) pairs of the window's rows -> one flush record
+//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64, eight lanes per record
+//                k3_forest       random-forest predict_proba;  k_literal / k_merge  irregular reads, row by row
+//                k_site_counts   per-site reduction (+ ncclAllReduce);  k_pack  record columns packed for the copy-out
 //
 // Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
 // index monotone in the direction the first site row implies, no site at contig position 0, read name not
