@@ -95,6 +95,12 @@ typedef struct mc_parsed mc_parsed;
 int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
                         const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
                         mc_parsed **out);
+/* The same for an exact byte range [byte_begin, byte_end) that starts at a line start (a piece of a file cut for several
+ * GPUs), and the cutter: n_parts+1 offsets, every cut at the first line of a read (column 4 changes), pieces of similar
+ * size -- a window never spans two reads (:179,:242), so pieces are scanned independently. */
+int mc_parse_eventalign_range(const char *path, int64_t byte_begin, int64_t byte_end,
+                              const char *const *contig_names, int32_t n_contigs, int32_t n_threads, mc_parsed **out);
+int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_t *cuts);
 int mc_parsed_view(const mc_parsed *p, mc_table_view *out);
 const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id);
 int64_t mc_parsed_n_unknown(const mc_parsed *p);                 /* rows dropped for an unknown contig */

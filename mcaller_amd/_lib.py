@@ -78,6 +78,8 @@ def lib():
         L.mc_version.restype = C.c_char_p
         L.mc_parse_eventalign.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.c_int32,
                                           C.c_int32, C.POINTER(C.c_void_p)]
+        L.mc_parse_eventalign_range.argtypes = L.mc_parse_eventalign.argtypes
+        L.mc_eventalign_read_cuts.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
         L.mc_parsed_view.argtypes = [C.c_void_p, C.POINTER(TableView)]
         L.mc_parsed_read_name.argtypes = [C.c_void_p, C.c_int32]
         L.mc_parsed_read_name.restype = C.c_char_p
@@ -177,15 +179,22 @@ class Table(object):
                      self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner)
 
 
-def parse_eventalign(path, startline, endline, contig_names, n_threads=0):
+def eventalign_read_cuts(path, n_parts):
+    """Byte offsets (n_parts + 1) cutting an eventalign file at the first lines of reads, pieces of similar size."""
+    cuts = np.zeros(n_parts + 1, dtype=np.int64)
+    check(lib().mc_eventalign_read_cuts(path.encode('utf-8'), int(n_parts), _ptr(cuts)))
+    return [int(c) for c in cuts]
+
+
+def parse_eventalign(path, startline, endline, contig_names, n_threads=0, exact_range=False):
     """Native parser -> Table over the library's buffers (no copy; freed with the Table)."""
     L = lib()
     arr = (C.c_char_p * max(1, len(contig_names)))()
     for i, n in enumerate(contig_names):
         arr[i] = n.encode('utf-8')
     handle = C.c_void_p()
-    check(L.mc_parse_eventalign(path.encode('utf-8'), int(startline), int(endline), arr, len(contig_names),
-                                int(n_threads), C.byref(handle)))
+    fn = L.mc_parse_eventalign_range if exact_range else L.mc_parse_eventalign
+    check(fn(path.encode('utf-8'), int(startline), int(endline), arr, len(contig_names), int(n_threads), C.byref(handle)))
     owner = _Parsed(handle)          # the columns stay in the library's buffers (no copy); freed with the Table
     v = TableView()
     check(L.mc_parsed_view(handle, C.byref(v)))

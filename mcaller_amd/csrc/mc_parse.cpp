@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -258,9 +259,96 @@ void parse_chunk(const char *base, int64_t lo, int64_t hi, const ContigMap &cont
 
 }  // namespace
 
+static int parse_file(const char *path, int64_t startline, int64_t endline, bool exact_range,
+                      const char *const *contig_names, int32_t n_contigs, int32_t n_threads, mc_parsed **out);
+
 extern "C" int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
                                    const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
                                    mc_parsed **out) {
+    return parse_file(path, startline, endline, false, contig_names, n_contigs, n_threads, out);
+}
+
+extern "C" int mc_parse_eventalign_range(const char *path, int64_t byte_begin, int64_t byte_end,
+                                         const char *const *contig_names, int32_t n_contigs, int32_t n_threads,
+                                         mc_parsed **out) {
+    return parse_file(path, byte_begin, byte_end, true, contig_names, n_contigs, n_threads, out);
+}
+
+// Byte offsets that cut the file into n_parts pieces of similar size, each cut at the start of a line whose read name
+// (column 4) differs from the line before it: a window never spans two reads (extract_contexts.py:179,242), so the pieces
+// can be scanned independently (one GPU each).  cuts[0] = 0, cuts[n_parts] = file size; pieces may be empty.
+extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_t *cuts) {
+    if (n_parts < 1) {
+        mc_set_error("mc_eventalign_read_cuts: n_parts %d", n_parts);
+        return -12;
+    }
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        mc_set_error("cannot open %s: %s", path, strerror(errno));
+        return -1;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        mc_set_error("cannot stat %s", path);
+        close(fd);
+        return -1;
+    }
+    const int64_t fsize = (int64_t)st.st_size;
+    const char *base = nullptr;
+    if (fsize > 0) {
+        base = (const char *)mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (base == MAP_FAILED) {
+            mc_set_error("cannot mmap %s: %s", path, strerror(errno));
+            close(fd);
+            return -1;
+        }
+    }
+    close(fd);
+    auto name_of = [&](int64_t line, int64_t line_end, Tok *name) -> bool {      // column 4 of a line, if it has one
+        Tok t[12];
+        const int n = split12(base + line, base + line_end, t);
+        if (n < 4) return false;
+        *name = t[3];
+        return true;
+    };
+    auto line_end_of = [&](int64_t line) -> int64_t {
+        const void *nl = memchr(base + line, '\n', (size_t)(fsize - line));
+        return nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
+    };
+    cuts[0] = 0;
+    for (int32_t i = 1; i < n_parts; ++i) {
+        int64_t c = fsize * i / n_parts;
+        if (c <= cuts[i - 1]) { cuts[i] = cuts[i - 1]; continue; }
+        // the line that contains byte c-1 ends at `line`: start there, remember the name of the line before it
+        int64_t line = c;
+        {
+            const void *nl = memchr(base + c - 1, '\n', (size_t)(fsize - (c - 1)));
+            line = nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
+        }
+        int64_t prev_begin = line - 1;                       // start of the line that ends at `line`
+        while (prev_begin > 0 && base[prev_begin - 1] != '\n') --prev_begin;
+        Tok prev;
+        bool have_prev = name_of(prev_begin, line, &prev);
+        int64_t cut = fsize;
+        while (line < fsize) {
+            const int64_t le = line_end_of(line);
+            Tok cur;
+            if (name_of(line, le, &cur)) {
+                if (have_prev && (cur.n != prev.n || memcmp(cur.p, prev.p, cur.n) != 0)) { cut = line; break; }
+                prev = cur;
+                have_prev = true;
+            }
+            line = le;
+        }
+        cuts[i] = std::max(cut, cuts[i - 1]);
+    }
+    cuts[n_parts] = fsize;
+    if (base) munmap((void *)base, (size_t)fsize);
+    return 0;
+}
+
+static int parse_file(const char *path, int64_t startline, int64_t endline, bool exact_range,
+                      const char *const *contig_names, int32_t n_contigs, int32_t n_threads, mc_parsed **out) {
     *out = nullptr;
     int fd = open(path, O_RDONLY);
     if (fd < 0) {
@@ -286,7 +374,12 @@ extern "C" int mc_parse_eventalign(const char *path, int64_t startline, int64_t 
     close(fd);
 
     int64_t lo = 0, hi = 0;
-    if (fsize > 0) consumed_range(base, fsize, startline, endline, &lo, &hi);
+    if (exact_range) {                  // [startline, endline) as given (a piece cut by mc_eventalign_read_cuts)
+        lo = std::min(std::max<int64_t>(startline, 0), fsize);
+        hi = std::min(std::max<int64_t>(endline, lo), fsize);
+    } else if (fsize > 0) {
+        consumed_range(base, fsize, startline, endline, &lo, &hi);
+    }
 
     ContigMap contig_map;
     std::vector<std::string> contig_store(contig_names, contig_names + n_contigs);

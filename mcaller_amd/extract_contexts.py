@@ -66,12 +66,13 @@ def _lookup_quality(read2qual, name):
         return read2qual[name.split(':')[0].split('_')[0]]
 
 
-def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list, n_threads=0):
+def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list, n_threads=0,
+            exact_range=False):
     """Parse + mark: the host-side pre-pass.  Returns a Prepared; `fatal` holds the exception the
     reference would hit at table row `len(table)` (the table is cut there)."""
     P = Prepared()
     ref = MarkedReference(fasta_input, base, motif, positions_list)
-    table = _lib.parse_eventalign(tsv_input, startline, endline, ref.names, n_threads)
+    table = _lib.parse_eventalign(tsv_input, startline, endline, ref.names, n_threads, exact_range=exact_range)
     for name in table.unknown:
         print('Error: could not find sequence for reference contig', name)       # :159
     P.fatal = None

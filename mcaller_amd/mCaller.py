@@ -23,7 +23,7 @@ def pos2label(positions):
 
 
 def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_refs, base, mod, nprocs, nvariables, train,
-                       modelfile, skip_thresh, qual_thresh, classifier, training_tsv, plot_training):
+                       modelfile, skip_thresh, qual_thresh, classifier, training_tsv, plot_training, n_gpus=1):
     """mCaller.py:25-115 without the process fan-out: one GPU pass, then the same file naming."""
     outdir = '/'.join(tsvname.split('/')[:-1])
     if len(outdir) > 1:
@@ -42,7 +42,13 @@ def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_r
 
     print('%d contigs' % num_refs)
     print('%d threads' % nprocs)
-    if not training_tsv:
+    sharded = False
+    if not training_tsv and not train and n_gpus > 1:        # reads shard over the GPUs of the node (multi_gpu.py)
+        from .multi_gpu import extract_features_sharded
+        sharded = extract_features_sharded(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile,
+                                           base, motif, positions_list, n_gpus)
+        ret = None
+    if not training_tsv and not sharded:
         bytesize = os.path.getsize(tsvname)
         ret = extract_features(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile, classifier, 0,
                                endline=bytesize, train=train, pos_label=training_pos_dict, base=base, motif=motif,
@@ -91,6 +97,8 @@ def main(argv=None):
     parser.add_argument('-c', '--classifier', type=str, required=False, help='use alternative classifier: options = NN (default), RF, LR, or NBC (non-default may significantly increase runtime)', default='NN')
     parser.add_argument('--plot_training', action='store_true', required=False, help='plot probabilities distributions for training positions (requires labels in positions file and --train)', default=False)
     parser.add_argument('-v', '--version', action='version', help='print version', version='%(prog)s v1.0')
+    parser.add_argument('--gpus', type=int, required=False, default=int(os.environ.get('MCALLER_GPUS', '1')),
+                        help='(mcaller_amd) GPUs of this node to shard the reads over (default 1, or $MCALLER_GPUS)')
     args = parser.parse_args(argv)
 
     if args.base == 'A':
@@ -127,7 +135,7 @@ def main(argv=None):
 
     distribute_threads(args.positions, args.motif, args.tsv, read2qual, args.reference, num_refs, base, mod, args.threads,
                        args.num_variables, args.train, modelfile, args.skip_thresh, args.qual_thresh, args.classifier,
-                       args.training_tsv if args.training_tsv else None, args.plot_training)
+                       args.training_tsv if args.training_tsv else None, args.plot_training, n_gpus=max(1, args.gpus))
 
 
 if __name__ == '__main__':

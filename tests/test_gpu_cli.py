@@ -159,3 +159,49 @@ def test_train_cli_fits_on_the_gpu(td, tmp_path):
     finally:
         del os.environ['MCALLER_SEED']
     assert (model_io.load_model_file(model2).models['general'].W1 == w.W1).all()
+
+
+def test_cli_sharded_over_two_workers_equals_one_gpu(tmp_path):
+    """`--gpus 2`: the file is cut at read starts, one worker process per piece (both on GPU 0 here), the pieces' rows
+    concatenated; output and counter lines equal the one-GPU run."""
+    from mcaller_amd import synth, mCaller
+    codes = synth.genome(length=300000, seed=21)
+    table, qual = synth.make_table(400000, seed=5, codes=codes, read_len=(1500, 6000))
+    d = str(tmp_path)
+    tsv = os.path.join(d, 'syn.eventalign.tsv')
+    synth.write_tsv(table, codes, tsv)
+    seq = synth.codes_to_str(codes)
+    with open(os.path.join(d, 'ref.fasta'), 'w') as fa:
+        fa.write('>ecoli_syn\n' + '\n'.join(seq[i:i + 60] for i in range(0, len(seq), 60)) + '\n')
+    with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
+        for i, name in enumerate(table.read_names):
+            fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + int(round(qual[i]))) * 10))
+    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    common = ['-m', 'GATC', '-r', os.path.join(d, 'ref.fasta'), '-e', tsv, '-f', os.path.join(d, 'reads.fastq'), '-d', model,
+              '-q', '8']
+    outs = []
+    from mcaller_amd import multi_gpu
+    real, took = multi_gpu.extract_features_sharded, []
+
+    def spy(*a, **kw):
+        took.append(real(*a, **kw))
+        return took[-1]
+    multi_gpu.extract_features_sharded = spy
+    for extra in ([], ['--gpus', '2'], ['--gpus', '3']):
+        out_path = tsv[:-4] + '.diffs.6'
+        if os.path.exists(out_path):
+            os.remove(out_path)
+        os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * (int(extra[1]) if extra else 1))
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                mCaller.main(common + extra)
+        finally:
+            del os.environ['MCALLER_SHARD_DEVICES']
+        lines = [l for l in buf.getvalue().split('\n') if 'observations' in l or 'positions' in l or 'regions' in l]
+        outs.append((open(out_path, 'rb').read(), lines))
+    multi_gpu.extract_features_sharded = real
+    assert took == [True, True]                               # the sharded path ran (no fall-back to one GPU)
+    assert outs[0][0].count(b'\n') > 200
+    assert outs[1] == outs[0] and outs[2] == outs[0]
+    assert not [f for f in os.listdir(d) if '.part' in f or '.tmp' in f]

@@ -82,3 +82,29 @@ def test_malformed_numbers_are_rejected(tmp_path):
     open(p, 'w').write(('c\t12\tACGTAC\tr\tt\t5\t80.1x\t1\t1\tACGTAC\t80.00\t1\t0\n') * 20)
     with pytest.raises(_lib.McError):
         _lib.parse_eventalign(p, 0, os.path.getsize(p), ['c'])
+
+
+def test_read_cuts_and_exact_ranges(tmp_path):
+    """mc_eventalign_read_cuts + mc_parse_eventalign_range: pieces cut at read starts, parsed one by one, concatenate to the
+    table of the whole file; no read name occurs in two pieces."""
+    from mcaller_amd import synth, _lib
+    codes = synth.genome(length=200000, seed=3)
+    table, qual = synth.make_table(60000, seed=8, codes=codes, read_len=(300, 1500))
+    tsv = str(tmp_path / 'syn.eventalign.tsv')
+    synth.write_tsv(table, codes, tsv)
+    size = os.path.getsize(tsv)
+    whole = _lib.parse_eventalign(tsv, 0, size, ['ecoli_syn'], exact_range=True)
+    assert whole.n_rows == table.n_rows and (whole.pos == table.pos).all()
+    for n_parts in (1, 2, 3, 7, 200):
+        cuts = _lib.eventalign_read_cuts(tsv, n_parts)
+        assert len(cuts) == n_parts + 1 and cuts[0] == 0 and cuts[-1] == size and cuts == sorted(cuts)
+        parts = [_lib.parse_eventalign(tsv, cuts[i], cuts[i + 1], ['ecoli_syn'], n_threads=1 + i % 3, exact_range=True)
+                 for i in range(n_parts)]
+        assert sum(p.n_rows for p in parts) == whole.n_rows
+        for col in ('pos', 'event_e4', 'model_e4', 'event_idx', 'flags'):
+            assert (np.concatenate([getattr(p, col) for p in parts]) == getattr(whole, col)).all(), col
+        names = [n for p in parts for n in p.read_names]
+        assert names == whole.read_names                      # every read in exactly one piece, order kept
+        if n_parts in (2, 3, 7):
+            rows = [p.n_rows for p in parts]
+            assert min(rows) > 0.5 * whole.n_rows / n_parts    # balanced
