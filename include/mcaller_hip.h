@@ -148,13 +148,13 @@ int mc_fetch_records(mc_ctx *ctx, const mc_calls_view *host_out);
  * capacity is set to the record count).  mc_extract_features already moved them there, overlapped with the classifier. */
 int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
 /* Pipelined passes, for callers that stream many tables / shards (or the same table, as bench.py does): a pass is only
- * ENQUEUED -- strand resolve, scan + emit, classifier on three streams, each pass with its own counters, strand-resolve
- * output and record set -- and copied out (DMA, exactly n records) when it is waited for, so the copy-out of pass i, the
- * classifier of pass i+1 and the strand resolve of pass i+2 run beside the scan and no host round trip sits inside a pass.  At most three passes are in flight (one being copied out, one
- * computing, one queued behind it).  mc_wait_records hands out the OLDEST pass: it copies its records out and returns a
- * view of the context's pinned buffers (valid until three more passes have been enqueued).  A pass that needs more than the fast path (irregular reads, windows longer than 64 rows,
- * record buffers too small) is re-run synchronously inside mc_wait_records -- results are the same, only slower.
- * MLP classifier only (the forest runs in mc_extract_features). */
+ * ENQUEUED -- strand resolve, scan + emit, classifier, packing of the narrow record columns, all on the ctx stream, each
+ * pass with its own counters, strand-resolve output and record set -- and copied out (two DMA transfers of exactly n
+ * records) when it is waited for, beside the kernels of the passes behind it; no host round trip sits inside a pass.  At
+ * most three passes are in flight (one being copied out, one computing, one queued).  mc_wait_records hands out the
+ * OLDEST pass and returns a view of the context's pinned buffers (valid until three more passes have been enqueued).  A
+ * pass that needs more than the fast path (irregular reads, record buffers too small) is re-run synchronously inside
+ * mc_wait_records -- results are the same, only slower.  MLP classifier only (the forest runs in mc_extract_features). */
 int mc_extract_features_async(mc_ctx *ctx, const mc_params *prm);
 int mc_wait_records(mc_ctx *ctx, int64_t *n_records, mc_calls_view *out);
 /* Kernel times of the last mc_extract_features, from hipEvents on the ctx stream, in ms:

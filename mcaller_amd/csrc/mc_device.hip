@@ -1417,9 +1417,7 @@ __device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
     return ret;
 }
 
-__global__ void k1_bigfix(K1Args A, int64_t n) {
-    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= n) return;
+__device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j) {
     const DevRecords &O = A.O;
     const uint32_t info = O.info[j];
     if (!(info & MC_I_BIG)) return;
@@ -1463,6 +1461,25 @@ __global__ void k1_bigfix(K1Args A, int64_t n) {
         O.feats[j * k + dst] = f;
     }
     O.info[j] = info & ~MC_I_BIG;
+}
+
+__global__ void k1_bigfix(K1Args A, int64_t n) {
+    const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j < n) bigfix_record(A, j);
+}
+
+// Pipelined passes: the windows k1_emit left to the row-by-row walk (their number is on the device only), each finished
+// by one thread, including the full pairwise recursion if a slot turns out to hold more than 128 events.
+__global__ void k1_rare_dev(K1Args A, const Payload *__restrict__ sorted, const int64_t *__restrict__ rare_list) {
+    const int64_t n_rare = (int64_t)A.cnt->n_rare;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rare; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = rare_list[i];
+        const Payload P = sorted[q];
+        const NbDesc d = A.desc[P.nb];
+        RowSrc S{A.T.pos, A.T.ev, A.T.mu, A.T.flags, false, 0.0};
+        emit_record(A, S, d, P.nb, P.r, P.m, q);
+        bigfix_record(A, q);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2676,6 +2693,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     HIP_TRY(hipEventRecord(b.ev_k0_end, st));
     K1Args A;
     if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, b.ev_scan_end, &A)) return rc;
+    hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
     HIP_TRY(hipEventRecord(b.ev_emit_end, st));
     if (prm->score)
         hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, b.O.feats, k,
@@ -2714,7 +2732,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
     }
     const Counters st = *b.st_host;
-    const bool special = st.overflow || st.n_irregular || st.n_big || st.n_rare;
+    const bool special = st.overflow || st.n_irregular;      // (long windows were finished on the device: k1_rare_dev)
     if (b.used && !special && st.n_records > 0) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
         const int k = b.k;
@@ -2728,8 +2746,11 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 24 * n);
         HIP_TRY(hipStreamSynchronize(cs));
     }
+    if (special && getenv("MCALLER_VERBOSE"))
+        fprintf(stderr, "mcaller_hip: pass re-run synchronously (overflow %u, irregular %u, big %u, rare %u, records %llu)\n",
+                st.overflow, st.n_irregular, st.n_big, st.n_rare, st.n_records);
     if (special) {
-        // a pass the fast path alone cannot finish (record buffers too small, irregular reads, very long windows):
+        // a pass the fast path alone cannot finish (record buffers too small, irregular reads):
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
         int64_t n = 0;
         if (int rc = mc_extract_features(c, &b.prm, &n)) return rc;

@@ -273,3 +273,42 @@ def test_pipelined_passes_equal_the_synchronous_path(dev, tmp_path):
             assert np.array_equal(r.prob[:r.n], want.prob[:want.n], equal_nan=True)
         n_checked += 1
     assert n_checked > 20
+
+
+@pytest.mark.parametrize('n_rows,motif,score', [
+    (100000000, 'GATC', True),      # BASELINE.json configs[2]: 10^8 events, -m GATC, NN classifier
+    (10000000, 'A', False),         # configs[4]-sized feature-matrix build (--train: features only), dense sites
+])
+def test_full_size_records_equal_the_oracle(n_rows, motif, score):
+    """The headline workload at its full size: every flush record of the HIP path (through the pipelined interface,
+    as bench.py runs it) equals the C oracle's -- integers and slot means bit for bit, probabilities to 1e-9."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome()
+    ref = synth.SynthRef(codes, motif=motif)
+    table, qual = synth.make_table(n_rows, seed=1000, codes=codes)
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    dev = Device(0)
+    try:
+        dev.set_reference(ref.device_arrays())
+        dev.upload_table(table)
+        dev.set_read_quality(qual)
+        dev.set_mlp(weights, soc)
+        dev.run_async(6, 0, 0.0, score=score)
+        dev.run_async(6, 0, 0.0, score=score)
+        first = dev.wait()
+        keep = (first.n, first.feats[:first.n * 6].copy(), first.prob[:first.n].copy())
+        rec = dev.wait()
+        assert rec.n == keep[0] and (rec.feats[:rec.n * 6] == keep[1]).all()          # passes are reproducible
+        assert np.array_equal(rec.prob[:rec.n], keep[2], equal_nan=True)
+        orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+        if score:
+            H.oracle_score(orc, table, qual, weights, soc, 6)
+        else:
+            rec.prob[:rec.n] = np.nan
+            orc.prob[:orc.n] = np.nan
+        H.assert_records_equal(rec, orc, 6)
+        assert rec.n > n_rows // 1000
+    finally:
+        dev.close()
