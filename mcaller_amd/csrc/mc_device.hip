@@ -662,10 +662,12 @@ constexpr int UPL = TILE / UROWS / 64; // ... units per lane
 constexpr int WCAP = 128;           // ... closed windows buffered in LDS before their payloads are written
 static_assert(TILE % (UROWS * 64) == 0, "whole units per lane");
 
-// columns of one tile in flight: 16 bytes of positions + 4 flag bytes per lane and quad
+// columns of one tile in flight: 16 bytes of positions per lane and quad of rows, 16 flag bytes per lane and 16 rows
+// (both columns move with 16-byte loads: 1 KB per wave instruction)
+static_assert(TILE % (NTHREADS * 16) == 0, "whole 16-byte flag loads");
 struct TileRegs {
     int4 p4[TILE / (NTHREADS * 4)];
-    uint32_t f4[TILE / (NTHREADS * 4)];
+    uint4 f16[TILE / (NTHREADS * 16)];
     uint32_t descw;                 // dword `tid` of the tile's name-block descriptors
     uint32_t maskw[NBST];           // word `tid` of the staged strand-mask windows
     uint32_t tdw;                   // dword `tid` of the TileDesc of the tile AFTER this one (same workgroup)
@@ -682,11 +684,13 @@ __device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc
     for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
         const int i0 = (j * NTHREADS + tid) * 4;
         R.p4[j] = make_int4(0, 0, 0, 0);
-        R.f4[j] = 0;
-        if (i0 < nrows) {   // arrays are padded to a multiple of TILE: the vector loads stay in bounds
-            R.p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-            R.f4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
-        }
+        if (i0 < nrows) R.p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);   // arrays are padded to a multiple of TILE:
+    }                                                                                    // the vector loads stay in bounds
+#pragma unroll
+    for (int j = 0; j < TILE / (NTHREADS * 16); ++j) {
+        const int i0 = (j * NTHREADS + tid) * 16;
+        R.f16[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (i0 < nrows) R.f16[j] = *reinterpret_cast<const uint4 *>(T.flags + t0 + i0);
     }
     const int nnb = min(td.nnb, NBMAX);
     const uint32_t *dsrc = reinterpret_cast<const uint32_t *>(A.desc + td.nb0);
@@ -792,8 +796,10 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * NTHREADS + tid) * 4;
             *reinterpret_cast<int4 *>(&s_pos[i0]) = R.p4[j];
-            *reinterpret_cast<uint32_t *>(&s_fl[i0]) = R.f4[j];
         }
+#pragma unroll
+        for (int j = 0; j < TILE / (NTHREADS * 16); ++j)
+            *reinterpret_cast<uint4 *>(&s_fl[(j * NTHREADS + tid) * 16]) = R.f16[j];
         __syncthreads();
         PH(0);
         const TileDesc td = s_td[cur];
