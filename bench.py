@@ -218,7 +218,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes': alg_bytes, 'kernel_ms': k1},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg: rank 0 at N=1 only
             n_cpu = min(n_rows, int(args.cpu_events))
             sub = table if n_cpu == n_rows else table.slice_segments(
                 0, int(np.searchsorted(table.seg_row_begin, n_cpu, side='left')))

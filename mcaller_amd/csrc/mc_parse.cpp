@@ -124,9 +124,30 @@ struct SvHash {
 
 }  // namespace
 
+// a column of the final table: raw memory, never zero-filled (every element is written by the piece that owns it)
+template <typename T>
+struct RawCol {
+    T *p = nullptr;
+    size_t n = 0;
+    RawCol() = default;
+    RawCol(const RawCol &) = delete;
+    RawCol &operator=(const RawCol &) = delete;
+    ~RawCol() { free(p); }
+    bool alloc(size_t count) {
+        free(p);
+        n = count;
+        p = (T *)malloc(std::max<size_t>(count, 1) * sizeof(T));
+        return p != nullptr;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+};
+
 struct mc_parsed {
-    std::vector<int32_t> pos, ev, mu, idx;
-    std::vector<uint8_t> flags;
+    RawCol<int32_t> pos, ev, mu, idx;
+    RawCol<uint8_t> flags;
     std::vector<int64_t> seg_begin;
     std::vector<int32_t> seg_read, seg_contig;
     std::vector<std::string> read_names;
@@ -168,6 +189,7 @@ struct Chunk {
     int rc = 0;
     std::string err;
     int64_t err_row = 0;
+    int64_t n_rows = 0;                    // rows of the piece, once its columns have been moved to the table
 };
 
 using ContigMap = std::unordered_map<std::string_view, int32_t, SvHash>;
@@ -425,25 +447,48 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
         total += (int64_t)chunks[(size_t)i].pos.size();
     }
     mc_parsed *P = new mc_parsed();
-    P->pos.resize((size_t)total);
-    P->ev.resize((size_t)total);
-    P->mu.resize((size_t)total);
-    P->idx.resize((size_t)total);
-    P->flags.resize((size_t)total);
+    if (!P->pos.alloc((size_t)total) || !P->ev.alloc((size_t)total) || !P->mu.alloc((size_t)total) ||
+        !P->idx.alloc((size_t)total) || !P->flags.alloc((size_t)total)) {
+        delete P;
+        mc_set_error("out of memory for %lld rows", (long long)total);
+        return -10;
+    }
+    // the pieces' columns go to their place in parallel (one thread per piece), and the pieces' memory is released there
+    {
+        std::vector<int64_t> offs((size_t)np + 1, 0);
+        for (int i = 0; i < np; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + (int64_t)chunks[(size_t)i].pos.size();
+        auto place = [&](int i) {
+            Chunk &C = chunks[(size_t)i];
+            const size_t n = C.pos.size();
+            const int64_t o = offs[(size_t)i];
+            if (n) {
+                memcpy(P->pos.data() + o, C.pos.data(), n * 4);
+                memcpy(P->ev.data() + o, C.ev.data(), n * 4);
+                memcpy(P->mu.data() + o, C.mu.data(), n * 4);
+                memcpy(P->idx.data() + o, C.idx.data(), n * 4);
+                memcpy(P->flags.data() + o, C.flags.data(), n);
+            }
+            C.n_rows = (int64_t)n;
+            std::vector<int32_t>().swap(C.pos);
+            std::vector<int32_t>().swap(C.ev);
+            std::vector<int32_t>().swap(C.mu);
+            std::vector<int32_t>().swap(C.idx);
+            std::vector<uint8_t>().swap(C.flags);
+        };
+        if (np == 1) place(0);
+        else {
+            std::vector<std::thread> th;
+            for (int i = 0; i < np; ++i) th.emplace_back(place, i);
+            for (auto &x : th) x.join();
+        }
+    }
     std::unordered_map<std::string, int32_t> read_map;
     int64_t off = 0;
     std::string prev_name;
     bool have_prev = false;
     for (int i = 0; i < np; ++i) {
         Chunk &C = chunks[(size_t)i];
-        const size_t n = C.pos.size();
-        if (n) {
-            memcpy(P->pos.data() + off, C.pos.data(), n * 4);
-            memcpy(P->ev.data() + off, C.ev.data(), n * 4);
-            memcpy(P->mu.data() + off, C.mu.data(), n * 4);
-            memcpy(P->idx.data() + off, C.idx.data(), n * 4);
-            memcpy(P->flags.data() + off, C.flags.data(), n);
-        }
+        const size_t n = (size_t)C.n_rows;
         std::vector<int32_t> name_id(C.names.size());
         for (size_t j = 0; j < C.names.size(); ++j) {
             auto it = read_map.find(C.names[j]);
@@ -477,10 +522,6 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
         }
         for (auto &u : C.unknown) P->unknown.push_back(std::move(u));
         off += (int64_t)n;
-        Chunk().pos.swap(C.pos);       // release piece memory early
-        Chunk().ev.swap(C.ev);
-        Chunk().mu.swap(C.mu);
-        Chunk().idx.swap(C.idx);
     }
     P->seg_begin.push_back(total);
     *out = P;
