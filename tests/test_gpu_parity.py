@@ -312,3 +312,51 @@ def test_full_size_records_equal_the_oracle(n_rows, motif, score):
         assert rec.n > n_rows // 1000
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize('k', [1, 2, 3, 4, 5, 7, 8])
+def test_other_window_lengths(dev, k):
+    """-n/--num_variables other than 6 (features only: the shipped models take 7 inputs), with skips, both paths."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=300000, seed=17)
+    ref = synth.SynthRef(codes, motif='GATC' if k % 2 else 'A')
+    table, qual = synth.make_table(200000, seed=40 + k, codes=codes, read_len=(800, 5000))
+    dev.set_reference(ref.device_arrays())
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    for skip in (0, min(k - 1, 2)):
+        orc = H.oracle_records(table, ref.device_arrays(), qual, k, skip, 0.0)
+        rec = dev.extract(k, skip, 0.0, score=False)
+        rec.prob[:rec.n] = np.nan
+        H.assert_records_equal(rec, orc, k)
+        dev.run_async(k, skip, 0.0, score=False)
+        rec2 = dev.wait()
+        rec2.prob[:rec2.n] = np.nan
+        H.assert_records_equal(rec2, orc, k)
+        assert rec.n > 50
+
+
+def test_empty_and_tiny_tables(dev):
+    """No rows, one row, fewer rows than a window: no records, no crash, both paths."""
+    from mcaller_amd import synth, _lib
+    codes = synth.genome(length=50000, seed=2)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(3000, seed=9, codes=codes, read_len=(500, 900))
+    dev.set_reference(ref.device_arrays())
+    dev.set_read_quality(qual)
+    for n_seg, n_rows in ((0, 0), (1, 1), (1, 3), (1, 40)):
+        sub = table.slice_segments(0, n_seg)
+        if n_seg:
+            r1 = min(n_rows, sub.n_rows)
+            sub = _lib.Table(sub.pos[:r1], sub.event_e4[:r1], sub.model_e4[:r1], sub.event_idx[:r1], sub.flags[:r1],
+                             np.array([0, r1], dtype=np.int64), sub.seg_read[:1], sub.seg_contig[:1], sub.n_reads,
+                             read_names=sub.read_names)
+        dev.upload_table(sub)
+        orc = H.oracle_records(sub, ref.device_arrays(), qual, 6, 0, 0.0)
+        rec = dev.extract(6, 0, 0.0, score=False)
+        assert rec.n == orc.n
+        dev.run_async(6, 0, 0.0, score=False)
+        assert dev.wait().n == orc.n
+        if orc.n:
+            rec.prob[:rec.n] = np.nan
+            H.assert_records_equal(rec, orc, 6)
