@@ -161,7 +161,8 @@ struct Counters {          // device-side status block
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
     unsigned int pad[2];
-    unsigned long long next_chunk; // k1_scan's tile-chunk ticket counter
+    struct { unsigned long long v; unsigned long long pad[15]; } ticket[NSHARD];   // k1_scan's tile-chunk ticket counters, one
+                                   // per XCD (workgroups are dealt to the XCDs round-robin), each on its own 128-byte line
     unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
 };
 
@@ -749,26 +750,36 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
 
-    // Tiles are handed out in chunks of CHUNK consecutive tiles from a ticket counter, so the grid need not match the
-    // residency the hardware grants (a static grid-stride split runs a second, unbalanced round when it does not).
-    // The ticket for the chunk after the current one is drawn when a chunk starts and first used CHUNK-2 tiles later.
-    constexpr int CHUNK = 4;
+    // Tiles are handed out in chunks of CHUNK consecutive tiles from ticket counters, so the grid need not match the
+    // residency the hardware grants (a static grid-stride split runs a second, unbalanced round when it does not) and
+    // tiles with many windows do not leave a tail.
+#ifndef MC_SCAN_CHUNK
+#define MC_SCAN_CHUNK 2
+#endif
+    constexpr int CHUNK = MC_SCAN_CHUNK;
     const int64_t n_chunks = (T.n_tiles + CHUNK - 1) / CHUNK;
+    // One counter per XCD: a single counter serialises ~8k same-address atomics (~10 ns each) per pass.  Ticket t of XCD x
+    // (= block index mod 8) is chunk gridDim.x + 8 t + x: every chunk beyond the grid's first round exactly once.
+    const unsigned xcd = blockIdx.x & (NSHARD - 1);
     auto draw = [&]() -> unsigned long long {       // tickets start after the chunks the grid takes by block index
         unsigned long long t = 0;
-        if (lane == 0) t = gridDim.x + atomicAdd(&A.cnt->next_chunk, 1ull);
+        if (lane == 0) t = gridDim.x + atomicAdd(&A.cnt->ticket[xcd].v, 1ull) * NSHARD + xcd;
         return t;
     };
     int64_t chunk = blockIdx.x;                     // the first chunk needs no ticket (no start-up storm on the counter)
     if (chunk >= n_chunks) return;
-    unsigned long long pending = draw();            // ticket of the next chunk, in lane 0 until needed
-    int64_t chunk_next = -1;                        // ... resolved lazily
+    // the tickets of the next two chunks are drawn ahead (in lane 0 until needed, resolved lazily): the look-ahead of two
+    // tiles may reach the chunk after next when a chunk is a single tile
+    unsigned long long pending = draw(), pending2 = draw();
+    int64_t chunk_next = -1, chunk_next2 = -1;
     int pin = 0;                                    // position inside the current chunk
-    // tile j steps after the current one (j <= 2): stays in the chunk or continues in the next chunk
+    // tile j steps after the current one (j <= 2): in this chunk, the next one, or the one after
     auto tile_ahead = [&](int j) -> int64_t {
         if (pin + j < CHUNK) return chunk * CHUNK + pin + j;
         if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
-        return chunk_next >= n_chunks ? T.n_tiles : chunk_next * CHUNK + (pin + j - CHUNK);
+        if (pin + j < 2 * CHUNK) return chunk_next >= n_chunks ? T.n_tiles : chunk_next * CHUNK + (pin + j - CHUNK);
+        if (chunk_next2 < 0) chunk_next2 = (int64_t)__shfl(pending2, 0);
+        return chunk_next2 >= n_chunks ? T.n_tiles : chunk_next2 * CHUNK + (pin + j - 2 * CHUNK);
     };
     int64_t tile = chunk * CHUNK;
 #ifdef MC_PROFILE
@@ -792,6 +803,14 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         s_bits[0][tid] = R.maskw[0];
         s_bits[1][tid] = R.maskw[1];
         if (tid < (int)(sizeof(TileDesc) / 4)) reinterpret_cast<uint32_t *>(&s_td[cur ^ 1])[tid] = R.tdw;
+        if (A.debug == 6) {            // (timing experiment: the columns are consumed from registers, never staged)
+            int x = 0;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) x ^= R.p4[j].x ^ R.p4[j].y ^ R.p4[j].z ^ R.p4[j].w;
+#pragma unroll
+            for (int j = 0; j < TILE / (NTHREADS * 16); ++j) x ^= (int)(R.f16[j].x ^ R.f16[j].w);
+            if (x == 0x12345678) s_pos[tid] = x;
+        } else {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * NTHREADS + tid) * 4;
@@ -800,6 +819,7 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
 #pragma unroll
         for (int j = 0; j < TILE / (NTHREADS * 16); ++j)
             *reinterpret_cast<uint4 *>(&s_fl[(j * NTHREADS + tid) * 16]) = R.f16[j];
+        }
         __syncthreads();
         PH(0);
         const TileDesc td = s_td[cur];
@@ -809,7 +829,7 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         if (tile_n < T.n_tiles && A.debug != 4) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);   // (4: timing experiment, walk only)
         PH(1);
 
-        if (wave == 0 && A.debug != 3) {
+        if (wave == 0 && A.debug != 3 && A.debug != 6) {
             // The walk works from LDS alone.  Whatever needs global memory (more name blocks than were staged, a closing
             // row beyond the tile, a window reaching back before it) is an out-of-line call -- see far_close().
             {
@@ -1053,9 +1073,11 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         if (++pin == CHUNK) {
             if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
             chunk = chunk_next;
-            chunk_next = -1;
+            pending = pending2;                     // the chunk after next moves up ...
+            chunk_next = chunk_next2;
+            chunk_next2 = -1;
             pin = 0;
-            if (chunk < n_chunks) pending = draw();
+            if (chunk < n_chunks) pending2 = draw(); // ... and another ticket is drawn behind it
         }
     }
 #ifdef MC_PROFILE
@@ -2463,7 +2485,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
     { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-    hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + 3) / 4, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,
+    hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + MC_SCAN_CHUNK - 1) / MC_SCAN_CHUNK, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,   // (chunks, not tiles)
                        st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
