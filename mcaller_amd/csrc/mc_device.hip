@@ -1275,13 +1275,24 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restri
     const int gsh = lane & ~(EG - 1);                        // first lane of my group
     const int k = A.k;
     // grid-stride over groups of 64/EG windows per wave (the record count is only known on the device)
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; (t - lane) / EG < n_rec; t += (int64_t)gridDim.x * blockDim.x) {
+    // (the payload of the wave's next round is fetched while the current one is worked on)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    Payload Pn;
+    Pn.flags = PF_EXTRA; Pn.nb = 0; Pn.r = 0; Pn.m = 0; Pn.close_row = 0; Pn.close_pos = 0;
+    Pn.code[0] = Pn.code[1] = Pn.code[2] = Pn.code[3] = ~0ull;
+    {
+        const int64_t q0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / EG;
+        if (q0 < n_rec) Pn = sorted[q0];
+    }
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; (t - lane) / EG < n_rec; t += stride) {
     const int64_t q = t / EG;
     const bool live = q < n_rec;
-    Payload P;
-    P.flags = PF_EXTRA; P.nb = 0; P.r = 0; P.m = 0; P.close_row = 0; P.close_pos = 0;
-    P.code[0] = P.code[1] = P.code[2] = P.code[3] = ~0ull;
-    if (live) P = sorted[q];
+    const Payload P = Pn;
+    {
+        const int64_t qn = (t + stride) / EG;
+        Pn.flags = PF_EXTRA;
+        if (qn < n_rec) Pn = sorted[qn];
+    }
     const int64_t r = A.debug == 5 ? 40 + q * 8 : P.r;          // (timing experiment: sequential instead of scattered rows)
     const int m = P.m;
     const bool fast = live && !(P.flags & (PF_EXTRA | PF_SLOW));
