@@ -216,6 +216,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'k1_scan + k1_group_scan + k1_list + k1_emit (feature extraction)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_gbs': (traffic / (k1 * 1e-3) / 1e9) if traffic else None,
                          'algorithmic_bytes': alg_bytes, 'kernel_ms': k1},
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg: rank 0 at N=1 only
