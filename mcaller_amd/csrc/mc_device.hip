@@ -2022,6 +2022,7 @@ struct mc_ctx {
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
+    int64_t ref_total_len = 0;    // bases of the marked reference (record capacity guess)
     bool tmpl_dirty = true;       // name-block descriptor templates must be rebuilt (new table or reference)
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
@@ -2218,6 +2219,8 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
         }
     }
     R.n_sites = n_sites;
+    c->ref_total_len = 0;
+    for (int32_t ci = 0; ci < h->n_contigs; ++ci) c->ref_total_len += h->contig_len[ci];
     UP(R.rank_f, rank_f.data(), h->n_words, c->ref_allocs);
     UP(R.rank_r, rank_r.data(), h->n_words, c->ref_allocs);
     UP(R.site_base, base.data(), (size_t)h->n_contigs * 2, c->ref_allocs);
@@ -2520,6 +2523,16 @@ static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &
     return 0;
 }
 
+// Record capacity to start with: a window closes about once per marked site a read covers -- rows x (sites per strand
+// position) x ~0.52 positions per row -- with 50 % head room, and never less than one per 64 rows (GATC in a random
+// genome: one per ~490 rows).  A pass that overflows it is repeated with what it actually needed.
+static int64_t guess_capacity(const mc_ctx *c) {
+    if (const char *e = getenv("MCALLER_RECORD_CAPACITY")) { if (atoll(e) > 0) return atoll(e); }   // (tests: force the overflow path)
+    const double density = c->ref_total_len > 0 ? (double)c->R.n_sites / (2.0 * (double)c->ref_total_len) : 0.0;
+    const int64_t by_sites = (int64_t)((double)c->T.n_rows * density * 0.52 * 1.5);
+    return std::max<int64_t>(1 << 16, std::max<int64_t>(c->T.n_rows / 64, by_sites) + 4096);
+}
+
 // what every pass needs before it can be enqueued
 static int check_pass(mc_ctx *c, const mc_params *prm) {
     const DevTable &T = c->T;
@@ -2555,7 +2568,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     if (c->ab_count) { if (int rc = sync_pass_streams(c)) return rc; }   // pipelined passes share the scratch: let them finish
 
     free_pool(c->lit_allocs);
-    int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
+    int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
         K1Args A;
@@ -2720,7 +2733,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
         c->ab_count += 1;
         return 0;
     }
-    const int64_t cap = std::max<int64_t>(std::max<int64_t>(1 << 16, T.n_rows / 64 + 4096), c->Omain.capacity);
+    const int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
     // the whole pass on the ctx stream, in order: K0, K1, K2, packing.  (Putting K0 and K2 on a second stream so that they

@@ -360,3 +360,34 @@ def test_empty_and_tiny_tables(dev):
         if orc.n:
             rec.prob[:rec.n] = np.nan
             H.assert_records_equal(rec, orc, 6)
+
+
+def test_record_buffers_too_small_are_grown(monkeypatch):
+    """A record capacity guess that is far too low (forced here): the synchronous path repeats the pass with what it
+    needed, the pipelined path re-runs the pass inside wait(); records equal the oracle either way."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    monkeypatch.setenv('MCALLER_RECORD_CAPACITY', '1000')
+    codes = synth.genome(length=200000, seed=23)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(300000, seed=77, codes=codes, read_len=(1000, 4000))
+    orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+    assert orc.n > 20000
+    for pipelined in (False, True):
+        dev = Device(0)
+        try:
+            dev.set_reference(ref.device_arrays())
+            dev.upload_table(table)
+            dev.set_read_quality(qual)
+            if pipelined:
+                dev.run_async(6, 0, 0.0, score=False)
+                dev.run_async(6, 0, 0.0, score=False)
+                recs = [dev.wait(), dev.wait()]
+            else:
+                recs = [dev.extract(6, 0, 0.0, score=False)]
+            for rec in recs:
+                rec.prob[:rec.n] = np.nan
+                orc.prob[:orc.n] = np.nan
+                H.assert_records_equal(rec, orc, 6)
+        finally:
+            dev.close()
