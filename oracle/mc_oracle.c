@@ -8,7 +8,7 @@
  * (mcaller_amd/) never does.
  *
  * Pinning: identical flush records to oracle/py_oracle.py on every committed micro-case and on the
- * reference's testdata (tests/test_oracle.py); py_oracle.py itself is pinned against the reference run
+ * reference's testdata (tests/test_oracle_pin.py, tests/test_host_pipeline.py); py_oracle.py itself is pinned against the reference run
  * in the build container (tests/golden/PIN_REPORT.json: 2000 micro-cases + 6 testdata runs, 0
  * differences).
  */
