@@ -2,7 +2,7 @@
 the HIP path -- synchronous and pipelined -- against the C oracle.  Prints the seeds that differ (none expected)."""
 import contextlib, io, os, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import casegen
 from mcaller_amd import extract_contexts as ec
 from mcaller_amd.device import Device

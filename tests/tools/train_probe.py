@@ -1,7 +1,7 @@
 """Time of the --train fit on the GPU (mc_mlp_fit: 5 GroupKFold fits + the final fit in one launch) vs the CPU oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mcaller_amd.device import Device
 from oracle import mlp_fit_oracle as mo
 
