@@ -1270,6 +1270,7 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
 __global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
+    if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
     const int s = lane & (EG - 1);
     const int gsh = lane & ~(EG - 1);                        // first lane of my group
@@ -1510,6 +1511,7 @@ __global__ void k1_bigfix(K1Args A, int64_t n) {
 // Pipelined passes: the windows k1_emit left to the row-by-row walk (their number is on the device only), each finished
 // by one thread, including the full pairwise recursion if a slot turns out to hold more than 128 events.
 __global__ void k1_rare_dev(K1Args A, const Payload *__restrict__ sorted, const int64_t *__restrict__ rare_list) {
+    if (A.cnt->overflow) return;
     const int64_t n_rare = (int64_t)A.cnt->n_rare;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rare; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t q = rare_list[i];
@@ -1814,8 +1816,10 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
-                                                     double *__restrict__ prob, const unsigned long long *__restrict__ n_dev) {
+                                                     double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                     const unsigned int *__restrict__ overflow) {
     extern __shared__ double s_w[];   // per model: W1[n_in*H] b1[H] W2[H] b2[1]
+    if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     const int H = M.n_hidden, NI = M.n_in;
     const int per = NI * H + 2 * H + 1;
@@ -2607,7 +2611,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
             else
                 hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M),
                                    c->stream, c->M, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
-                                   (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr);
+                                   (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr,
+                                   (const unsigned int *)nullptr);
         }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         if (n > 0) {
@@ -2750,7 +2755,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (prm->score)
         hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, b.O.feats, k,
                            b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap, b.O.prob,
-                           (const unsigned long long *)&b.cnt->n_records);
+                           (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
     HIP_TRY(hipEventRecord(b.ev_k2_end, st));
     hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, st, b.O, (const Counters *)b.cnt, b.pack);
     HIP_TRY(hipEventRecord(b.ev_done, st));
@@ -2857,7 +2862,7 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
     else
         hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr);
+                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
