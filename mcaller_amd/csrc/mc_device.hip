@@ -2066,6 +2066,10 @@ static int dev_alloc(std::vector<void *> &pool, Tp **p, size_t n) {
     }
     pool.push_back(q);
     *p = (Tp *)q;
+    // MCALLER_POISON: fill every fresh device allocation with 0xAB (tests: a kernel that reads memory nobody wrote shows up
+    // as a mismatch or a fault instead of silently reading zero pages)
+    static const bool poison = getenv("MCALLER_POISON") != nullptr;
+    if (poison) { (void)hipMemset(q, 0xAB, std::max<size_t>(n * sizeof(Tp), 256)); (void)hipDeviceSynchronize(); }
     return 0;
 }
 
