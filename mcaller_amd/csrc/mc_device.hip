@@ -1812,6 +1812,10 @@ __device__ __forceinline__ double tanh_1exp(double x) {
 constexpr int K2L = 8;
 constexpr int K2_THREADS = 256;
 
+// NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
+// unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
+// are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
+template <int NI_T>
 __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
@@ -1821,7 +1825,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     extern __shared__ double s_w[];   // per model: W1[n_in*H] b1[H] W2[H] b2[1]
     if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
-    const int H = M.n_hidden, NI = M.n_in;
+    const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in;
     const int per = NI * H + 2 * H + 1;
     for (int i = threadIdx.x; i < M.n_models * per; i += blockDim.x) {
         const int mi = i / per, j = i % per;
@@ -1858,16 +1862,17 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             todo = m;
             if (r < 0) continue;
             int mi;
-            double x[MC_MAX_K + 1];
+            constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
+            double x[NX];
             if (submodel_in) {                       // plain batched call: X rows of n_in values
                 mi = submodel_in[r];
 #pragma unroll
-                for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
             } else {                                 // flush records: k slot means + read quality (:189-193)
                 mi = M.sub_of_char[(info[r] >> MC_I_NEXT_SHIFT) & 0xFFu];
                 const double q = qual[seg_read[site_seg[r]]];
 #pragma unroll
-                for (int i = 0; i <= MC_MAX_K; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
             }
             if (mi >= M.n_models) continue;          // KeyError path (:218): the host decides
             const double *w = s_w + (size_t)mi * per;
@@ -1877,20 +1882,19 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                 const int j1 = j0 + K2L, j2 = j0 + 2 * K2L, j3 = j0 + 3 * K2L;
                 const bool v1 = j1 < H, v2 = j2 < H, v3 = j3 < H;
                 const int c1 = v1 ? j1 : j0, c2 = v2 ? j2 : j0, c3 = v3 ? j3 : j0;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                double a0 = b1[j0], a1 = b1[c1], a2 = b1[c2], a3 = b1[c3];
 #pragma unroll
-                for (int i = 0; i <= MC_MAX_K; ++i)
+                for (int i = 0; i < NX; ++i)
                     if (i < NI) {
                         const double xi = x[i];
-                        a0 += xi * w[i * H + j0]; a1 += xi * w[i * H + c1];
-                        a2 += xi * w[i * H + c2]; a3 += xi * w[i * H + c3];
+                        a0 = fma(xi, w[i * H + j0], a0); a1 = fma(xi, w[i * H + c1], a1);
+                        a2 = fma(xi, w[i * H + c2], a2); a3 = fma(xi, w[i * H + c3], a3);
                     }
-                const double t0 = tanh_1exp(a0 + b1[j0]), t1 = tanh_1exp(a1 + b1[c1]), t2 = tanh_1exp(a2 + b1[c2]),
-                             t3 = tanh_1exp(a3 + b1[c3]);
-                z += t0 * w2[j0];
-                if (v1) z += t1 * w2[c1];
-                if (v2) z += t2 * w2[c2];
-                if (v3) z += t3 * w2[c3];
+                const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), t2 = tanh_1exp(a2), t3 = tanh_1exp(a3);
+                z = fma(t0, w2[j0], z);
+                if (v1) z = fma(t1, w2[c1], z);
+                if (v2) z = fma(t2, w2[c2], z);
+                if (v3) z = fma(t3, w2[c3], z);
             }
 #pragma unroll
             for (int o = 1; o < K2L; o <<= 1) z += __shfl_xor(z, o);
@@ -2420,6 +2424,18 @@ static size_t mlp_lds_bytes(const DevMlp &M) {
     return (size_t)M.n_models * ((size_t)M.n_in * M.n_hidden + 2 * (size_t)M.n_hidden + 1) * 8;
 }
 
+// the classifier kernel: the 7-input instance (k = 6, the reference's models) or the general one
+static void launch_k2(mc_ctx *c, unsigned grid, hipStream_t st, const double *feats, int k, const int32_t *site_seg,
+                      const int32_t *seg_read, const double *qual, const uint32_t *info, const uint8_t *submodel_in, int64_t n,
+                      double *prob, const unsigned long long *n_dev, const unsigned int *overflow) {
+    if (c->M.n_in == 7)
+        hipLaunchKernelGGL(k2_mlp<7>, dim3(grid), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, feats, k, site_seg, seg_read, qual,
+                           info, submodel_in, n, prob, n_dev, overflow);
+    else
+        hipLaunchKernelGGL(k2_mlp<0>, dim3(grid), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, feats, k, site_seg, seg_read, qual,
+                           info, submodel_in, n, prob, n_dev, overflow);
+}
+
 static int alloc_records(std::vector<void *> &pool, DevRecords &D, int64_t cap, int k) {
     D.capacity = cap;
     if (dev_alloc(pool, &D.feats, (size_t)cap * k) || dev_alloc(pool, &D.site_pos, (size_t)cap) ||
@@ -2613,10 +2629,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
                 hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, c->O.feats, k,
                                    c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob);
             else
-                hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M),
-                                   c->stream, c->M, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
-                                   (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr,
-                                   (const unsigned int *)nullptr);
+                launch_k2(c, k2_grid(c, n), c->stream, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
+                          (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
         }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         if (n > 0) {
@@ -2757,9 +2771,8 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
     HIP_TRY(hipEventRecord(b.ev_emit_end, st));
     if (prm->score)
-        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, cap)), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, b.O.feats, k,
-                           b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap, b.O.prob,
-                           (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
+        launch_k2(c, k2_grid(c, cap), st, b.O.feats, k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap,
+                  b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
     HIP_TRY(hipEventRecord(b.ev_k2_end, st));
     hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, st, b.O, (const Counters *)b.cnt, b.pack);
     HIP_TRY(hipEventRecord(b.ev_done, st));
@@ -2864,9 +2877,8 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
                            (const uint32_t *)nullptr, ds, n, dp);
     else
-        hipLaunchKernelGGL(k2_mlp, dim3(k2_grid(c, n)), dim3(K2_THREADS), mlp_lds_bytes(c->M), c->stream, c->M, dX, ni - 1,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
+        launch_k2(c, k2_grid(c, n), c->stream, dX, ni - 1, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                  (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
