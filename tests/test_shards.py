@@ -79,3 +79,37 @@ def test_site_reduction_gloo_world2(tmp_path):
             assert p.wait(timeout=600) == 0
     a, b = open(out[0]).read(), open(out[1]).read()
     assert a == b and a.count('\n') > 50
+
+
+def test_bed_from_reduced_counts_equals_make_bed_on_the_diffs_text(tmp_path):
+    """The per-site reduction (site_counts -> write_bed_from_counts, what the all-reduce feeds) writes the same BED as the
+    reference-compatible text path (records -> .diffs rows -> make_bed), for depth and fraction thresholds."""
+    import contextlib
+    import io
+    from mcaller_amd import make_bed
+    from mcaller_amd import extract_contexts as ec
+    codes, ref, table, qual = make_workload(n_rows=120000, seed=44, motif='GATC', genome_len=30000)
+    modelset = H.load_modelset('r95')
+    _, weights, _, soc = ec.submodel_setup(modelset, 'A')
+    rec = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+    H.oracle_score(rec, table, qual, weights, soc, 6)
+
+    class P(object):
+        pass
+    P.table, P.ref, P.qual = table, ref, qual
+    P.qual_obj = [np.float64(q) for q in qual]
+    P.fatal = None
+    fin = ec.Finisher(P, 6, 'A', False, modelset=modelset)
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert fin.run(rec) is None
+    diffs = tmp_path / 'syn.eventalign.diffs.6'
+    diffs.write_bytes(fin.text())
+    index = make_bed.SiteIndex(ref.meth, 1)
+    counts = make_bed.site_counts(rec, table, index)
+    for depth, thresh in ((1, 0.5), (5, 0.5), (3, 0.2), (8, 0.8)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            make_bed.main(['-f', str(diffs), '-d', str(depth), '-t', str(thresh)])
+        want = (tmp_path / 'syn.methylation.summary.bed').read_text()
+        out = tmp_path / 'reduced.bed'
+        make_bed.write_bed_from_counts(str(out), counts[0], counts[1], counts[2], index, ref.names, ref.meth, 6, depth, thresh)
+        assert out.read_text() == want and want.count('\n') >= (3 if depth == 1 else 0)
