@@ -41,6 +41,9 @@ def _worker(conn, device, job):
             P = ec.prepare(job['tsv'], job['fasta'], job['read2qual'], job['lo'], job['hi'], job['base'], job['motif'],
                            job['positions_list'], exact_range=True)
         t = P.table
+        if job['bed']:                       # the site numbering of the reduction must be the same on every worker:
+            for cid in range(len(P.ref.names)):   # mark every contig, not only the ones this piece touches
+                P.ref.mark(cid)
         # the first unfiltered row of this piece: it closes the previous piece's last window
         head = None
         for seg in range(t.n_seg):
@@ -51,8 +54,15 @@ def _worker(conn, device, job):
             if ok.any():
                 head = P.ref.names[int(t.seg_contig[seg])]
                 break
+        uid = None
+        if job['bed'] and job['rank'] == 0 and job['world'] > 1:
+            try:
+                from .device import Device
+                uid = Device.comm_unique_id()                      # ncclGetUniqueId: shipped to the other workers by the parent
+            except Exception:
+                uid = None
         conn.send(dict(names=list(t.read_names), head=head, n_rows=t.n_rows, fatal=repr(P.fatal) if P.fatal is not None else None,
-                       stdout=buf.getvalue()))
+                       stdout=buf.getvalue(), uid=uid))
         go = conn.recv()
         if go is None:
             return
@@ -69,12 +79,15 @@ def _worker(conn, device, job):
             return
         with open(job['part'], 'wb') as out:
             out.write(fin.text())
+        bed = None
+        if job['bed']:
+            bed = _reduce_sites(job, go, P, rec)
         info = rec.info[:rec.n]
         too = (info & _lib.I_TOO_MANY) != 0
         fin._count(rec.n)
         conn.send(dict(stop=None, stdout=buf.getvalue(), n_obs=fin.num_observations,
                        positions=np.unique(rec.site_pos[:rec.n][~too]), n_multi=fin._n_multi, n_wskips=fin._n_wskips,
-                       n_skipped=fin._n_skipped))
+                       n_skipped=fin._n_skipped, bed=bed))
     except BaseException as e:                                   # noqa
         try:
             conn.send(dict(error='%s: %s' % (type(e).__name__, e)))
@@ -84,8 +97,34 @@ def _worker(conn, device, job):
         conn.close()
 
 
+def _reduce_sites(job, go, P, rec):
+    """The per-site reduction of this worker's records (make_bed.py:86-96): on the device, all-reduced over the workers
+    with RCCL (mc_site_allreduce) -- rank 0 then holds the node-wide counts; if the communicator cannot be set up (e.g.
+    several workers sharing one GPU) or the host scored some records itself, the worker's own counts go to the parent,
+    which adds them up."""
+    from . import make_bed
+    from .device import get_device
+    index = make_bed.SiteIndex(P.ref.meth, len(P.ref.names))
+    dev = get_device()
+    offset = go['row_offset']
+    try:
+        if job['world'] > 1:
+            if go.get('uid') is None:
+                raise RuntimeError('no RCCL unique id')
+            dev.comm_init(job['world'], job['rank'], go['uid'])
+        if dev.site_counts(row_offset=offset):
+            raise RuntimeError('records scored on the host')
+        n_meth, n_total, first, ms = dev.site_allreduce()
+        dev.comm_destroy()
+        return dict(mode='rccl', n_meth=n_meth if job['rank'] == 0 else None, n_total=n_total if job['rank'] == 0 else None,
+                    first=first if job['rank'] == 0 else None, ms=ms)
+    except Exception as e:                                       # noqa
+        n_meth, n_total, first = make_bed.site_counts(rec, P.table, index, row_offset=offset)
+        return dict(mode='host', why=str(e), n_meth=n_meth, n_total=n_total, first=first)
+
+
 def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, base, motif,
-                             positions_list, n_gpus):
+                             positions_list, n_gpus, bed=None):
     """Predict mode on n_gpus GPUs.  Returns True when the `.diffs.<k>.tmp0` file has been written and the counter lines
     printed; False when the file cannot be cut (a read name in two pieces, an exit path of the reference, an error in a
     worker): the caller then runs the one-GPU path, which reproduces the reference's behaviour in those cases."""
@@ -100,7 +139,7 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
         parent, child = ctx.Pipe()
         job = dict(tsv=tsv_input, fasta=fasta_input, read2qual=read2qual, lo=cuts[r], hi=cuts[r + 1], base=base, motif=motif,
                    positions_list=positions_list, k=k, skip_thresh=skip_thresh, qual_thresh=qual_thresh, modelfile=modelfile,
-                   part='%s.diffs.%d.part%d' % (stem, k, r))
+                   part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus)
         p = ctx.Process(target=_worker, args=(child, devices[r], job))
         p.start()
         child.close()
@@ -137,7 +176,7 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
             if h['head'] is not None:
                 tail = h['head']
                 break
-        conn.send(dict(tail=tail))
+        conn.send(dict(tail=tail, row_offset=sum(h['n_rows'] for h in heads[:r]), uid=heads[0].get('uid')))
     results = []
     for p, conn, job in workers:
         try:
@@ -158,6 +197,8 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
             with open(job['part'], 'rb') as part:
                 out.write(part.read())
             os.remove(job['part'])
+    if bed:
+        _write_bed(bed, results, fasta_input, base, motif, positions_list, k)
     positions = np.unique(np.concatenate([x['positions'] for x in results])) if results else np.zeros(0)
     print('thread finished processing...:')
     print('%d observations' % sum(x['n_obs'] for x in results))
@@ -166,3 +207,30 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     print('%d observations with skips included' % sum(x['n_wskips'] for x in results))
     print('%d observations with too many skips' % sum(x['n_skipped'] for x in results))
     return True
+
+
+def _write_bed(bed, results, fasta_input, base, motif, positions_list, k):
+    """BED of the whole file from the workers' reductions: rank 0's all-reduced counts, or the sum of per-worker counts."""
+    from . import make_bed
+    from .refmark import MarkedReference
+    ref = MarkedReference(fasta_input, base, motif, positions_list)
+    for cid in range(len(ref.names)):
+        try:
+            ref.mark(cid)
+        except SystemExit:
+            pass
+    index = make_bed.SiteIndex(ref.meth, len(ref.names))
+    beds = [x['bed'] for x in results]
+    if all(b['mode'] == 'rccl' for b in beds):
+        n_meth, n_total, first = beds[0]['n_meth'], beds[0]['n_total'], beds[0]['first']
+    elif all(b['mode'] == 'host' for b in beds):
+        n_meth = sum(b['n_meth'] for b in beds)
+        n_total = sum(b['n_total'] for b in beds)
+        first = np.minimum.reduce([b['first'] for b in beds])
+    else:
+        raise RuntimeError('workers disagree on how the per-site counts were reduced')
+    count = make_bed.write_bed_from_counts(bed['path'], n_meth, n_total, first, index, ref.names, ref.meth, k,
+                                           bed['min_depth'], bed['mod_threshold'])
+    print(count, 'methylated loci found with min depth', bed['min_depth'], 'reads')
+    print('per-site reduction: %s' % ('ncclAllReduce over %d GPUs' % len(beds) if beds[0]['mode'] == 'rccl'
+                                      else 'summed on the host (%s)' % beds[0].get('why', '')))

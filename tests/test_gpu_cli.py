@@ -205,3 +205,45 @@ def test_cli_sharded_over_two_workers_equals_one_gpu(tmp_path):
     assert outs[0][0].count(b'\n') > 200
     assert outs[1] == outs[0] and outs[2] == outs[0]
     assert not [f for f in os.listdir(d) if '.part' in f or '.tmp' in f]
+
+
+def test_cli_bed_from_the_per_site_reduction(tmp_path):
+    """`--bed`: the BED written from the workers' per-site reductions (one worker: device-side counts; two workers on one
+    GPU: RCCL refuses the duplicate device, the parent adds the workers' counts) equals make_bed on the `.diffs` file."""
+    from mcaller_amd import synth, mCaller, make_bed
+    codes = synth.genome(length=40000, seed=31)
+    table, qual = synth.make_table(250000, seed=6, codes=codes, read_len=(1500, 6000))
+    d = str(tmp_path)
+    tsv = os.path.join(d, 'syn.eventalign.tsv')
+    synth.write_tsv(table, codes, tsv)
+    seq = synth.codes_to_str(codes)
+    with open(os.path.join(d, 'ref.fasta'), 'w') as fa:
+        fa.write('>ecoli_syn\n' + '\n'.join(seq[i:i + 60] for i in range(0, len(seq), 60)) + '\n')
+    with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
+        for i, name in enumerate(table.read_names):
+            fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + int(round(qual[i]))) * 10))
+    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    common = ['-m', 'GATC', '-r', os.path.join(d, 'ref.fasta'), '-e', tsv, '-f', os.path.join(d, 'reads.fastq'), '-d', model,
+              '--bed', '--bed_min_depth', '3', '--bed_mod_threshold', '0.3']
+    bed_path = os.path.join(d, 'syn.methylation.summary.bed')
+    diffs = tsv[:-4] + '.diffs.6'
+    results = []
+    for n in (1, 2):
+        for f in (bed_path, diffs):
+            if os.path.exists(f):
+                os.remove(f)
+        os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * n)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                mCaller.main(common + ['--gpus', str(n)])
+        finally:
+            del os.environ['MCALLER_SHARD_DEVICES']
+        results.append((open(bed_path).read(), buf.getvalue()))
+    assert 'per-site reduction: ncclAllReduce over 1 GPUs' in results[0][1] or 'per-site reduction' in results[0][1]
+    assert 'summed on the host' in results[1][1]
+    os.rename(bed_path, bed_path + '.reduced')
+    with contextlib.redirect_stdout(io.StringIO()):
+        make_bed.main(['-f', diffs, '-d', '3', '-t', '0.3'])
+    want = open(bed_path).read()
+    assert results[0][0] == want and results[1][0] == want and want.count('\n') > 5
