@@ -74,7 +74,7 @@ def main():
     # A step = one pass of the hot path over the resident table, records (slot means, sites, probabilities) landing in
     # pinned host memory.  Passes are pipelined (the library's streaming interface, mc_extract_features_async /
     # mc_wait_records): strand resolve, scan, classifier and copy-out of consecutive passes overlap on four streams,
-    # three passes in flight at most; every pass's records are complete in host memory before the timed region ends.
+    # four passes in flight at most; every pass's records are complete in host memory before the timed region ends.
     # --no-pipeline times mc_extract_features instead (one pass at a time, host sync inside).
     def step_sync():
         dev.run(6, 0, 0.0, tail_contig=-1, score=True)
@@ -89,8 +89,9 @@ def main():
         for _ in range(depth):
             dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
         for _ in range(n_steps - depth):
-            on_done(dev.wait())
-            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+            dev.wait_begin()                                     # copy-out of the oldest pass started ...
+            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True) # ... the next pass enqueued while it runs ...
+            on_done(dev.wait())                                  # ... and the oldest pass's records are in host memory
         for _ in range(depth):
             on_done(dev.wait())
 
@@ -208,7 +209,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
                                    'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
-                       'passes_in_flight': 1 if args.no_pipeline else 3,
+                       'passes_in_flight': 1 if args.no_pipeline else 4,
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},

@@ -151,12 +151,15 @@ int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
  * ENQUEUED -- strand resolve, scan + emit, classifier, packing of the narrow record columns, all on the ctx stream, each
  * pass with its own counters, strand-resolve output and record set -- and copied out (two DMA transfers of exactly n
  * records) when it is waited for, beside the kernels of the passes behind it; no host round trip sits inside a pass.  At
- * most three passes are in flight (one being copied out, one computing, one queued).  mc_wait_records hands out the
- * OLDEST pass and returns a view of the context's pinned buffers (valid until three more passes have been enqueued).  A
+ * most four passes are in flight (one being copied out, one computing, two queued).  mc_wait_records hands out the
+ * OLDEST pass and returns a view of the context's pinned buffers (valid until four more passes have been enqueued).  A
  * pass that needs more than the fast path (irregular reads, record buffers too small) is re-run synchronously inside
  * mc_wait_records -- results are the same, only slower.  MLP classifier only (the forest runs in mc_extract_features). */
 int mc_extract_features_async(mc_ctx *ctx, const mc_params *prm);
 int mc_wait_records(mc_ctx *ctx, int64_t *n_records, mc_calls_view *out);
+/* Optional first half of mc_wait_records for the oldest pass: reads its counters back and ENQUEUES its copy-out, without
+ * waiting for it -- the caller can enqueue another pass before mc_wait_records waits for the transfers. */
+int mc_wait_records_begin(mc_ctx *ctx);
 /* Kernel times of the last mc_extract_features, from hipEvents on the ctx stream, in ms:
  * [0] strand resolve (K0), [1] window scan (k1_scan), [2] window emit (k1_group_scan + k1_list + k1_emit),
  * [3] classifier (K2), [4] total. */

@@ -102,6 +102,7 @@ def lib():
         L.mc_fetch_records_view.argtypes = [C.c_void_p, C.POINTER(CallsView)]
         L.mc_extract_features_async.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.mc_wait_records.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(CallsView)]
+        L.mc_wait_records_begin.argtypes = [C.c_void_p]
         L.mc_last_times_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_ctx_sync.argtypes = [C.c_void_p]
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]

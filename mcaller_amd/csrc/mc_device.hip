@@ -1985,7 +1985,7 @@ __global__ void k_zero_counters(Counters *cnt) {
 // ===================================================================================================
 // host side
 // ===================================================================================================
-constexpr int MC_PASSES_IN_FLIGHT = 3;   // one being copied out, one computing, one queued behind it
+constexpr int MC_PASSES_IN_FLIGHT = 4;   // one being copied out, one computing, two queued (the host enqueues while it copies)
 
 // What K0 writes and K1 reads, per pass in flight
 struct K0Set {
@@ -2044,13 +2044,14 @@ struct mc_ctx {
         unsigned char *pack = nullptr, *pack_host = nullptr;   // narrow columns, packed (device staging, pinned host)
         // stage boundaries: dependencies between the streams, and the kernel times
         hipEvent_t ev_k0_start = nullptr, ev_k0_end = nullptr, ev_scan_start = nullptr, ev_scan_end = nullptr,
-                   ev_emit_end = nullptr, ev_k2_start = nullptr, ev_k2_end = nullptr, ev_done = nullptr;
+                   ev_emit_end = nullptr, ev_k2_start = nullptr, ev_k2_end = nullptr, ev_done = nullptr, ev_copied = nullptr;
         mc_params prm;
         int64_t cap = 0, n_nb = 0, n_tiles = 0;
         int k = 0;
-        bool used = false;
+        bool used = false, copying = false;
         std::vector<void *> dev_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
+    hipStream_t k0_stream = nullptr;     // strand resolve of the pipelined passes
     int ab_head = 0, ab_tail = 0, ab_count = 0;
     // per-site reduction (mc_site_*): counts on the device, RCCL communicator
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
@@ -2176,8 +2177,9 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->site_first) (void)hipFree(c->site_first);
     (void)sync_pass_streams(c);
     free_async(c);
+    if (c->k0_stream) (void)hipStreamDestroy(c->k0_stream);
     for (auto &b : c->ab)
-        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done})
+        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied})
             if (e) (void)hipEventDestroy(e);
     mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
@@ -2692,7 +2694,7 @@ static void free_async(mc_ctx *c) {
         b.st_host = nullptr; b.cnt = nullptr; b.pack = nullptr; b.pack_host = nullptr;
         b.O = DevRecords();
         b.K = K0Set();
-        b.cap = b.n_nb = b.n_tiles = 0; b.k = 0; b.used = false;
+        b.cap = b.n_nb = b.n_tiles = 0; b.k = 0; b.used = false; b.copying = false;
     }
     c->ab_head = c->ab_tail = c->ab_count = 0;
 }
@@ -2706,7 +2708,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     const DevTable &T = c->T;
     if (!b.ev_done) {
         for (hipEvent_t *e : {&b.ev_k0_start, &b.ev_k0_end, &b.ev_scan_start, &b.ev_scan_end, &b.ev_emit_end, &b.ev_k2_start,
-                              &b.ev_k2_end, &b.ev_done})
+                              &b.ev_k2_end, &b.ev_done, &b.ev_copied})
             HIP_TRY(hipEventCreate(e));
     }
     if (b.cap >= cap && b.k == k && b.n_nb >= T.n_nb && b.n_tiles >= T.n_tiles) return 0;
@@ -2759,13 +2761,24 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     const int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
-    // the whole pass on the ctx stream, in order: K0, K1, K2, packing.  (Putting K0 and K2 on a second stream so that they
-    // run beside the neighbouring passes' scans was measured: 3 % more passes per second -- the copy-out is the limit by
-    // then -- for a scan that takes 20 % longer while it shares the CUs.  Not worth it; see DESIGN.md.)
+    for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
+        if (!other.used && other.cap < cap) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
+    // K1, K2 and the packing of a pass on the ctx stream, back to back with the next pass; K0 (strand resolve: a few small,
+    // latency-bound kernels) on its own stream, started when the PREVIOUS pass's emit is done, so that it runs beside that
+    // pass's classifier (compute-bound) and is finished when the scan's turn comes.  The scan and the emit always have the
+    // GPU to themselves.  (K0 and K2 beside the neighbouring passes' SCANS was measured too: 3 % more passes per second
+    // for a scan that takes 20 % longer while it shares the CUs -- rejected.)
     hipStream_t st = c->stream;
-    HIP_TRY(hipEventRecord(b.ev_k0_start, st));
-    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st)) return rc;
-    HIP_TRY(hipEventRecord(b.ev_k0_end, st));
+    if (!c->k0_stream) HIP_TRY(hipStreamCreateWithFlags(&c->k0_stream, hipStreamNonBlocking));
+    {
+        mc_ctx::AsyncBuf &prev = c->ab[(c->ab_head + MC_PASSES_IN_FLIGHT - 1) % MC_PASSES_IN_FLIGHT];
+        if (c->ab_count > 0 && prev.used) HIP_TRY(hipStreamWaitEvent(c->k0_stream, prev.ev_emit_end, 0));
+    }
+    HIP_TRY(hipEventRecord(b.ev_k0_start, c->k0_stream));
+    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, c->k0_stream)) return rc;
+    HIP_TRY(hipEventRecord(b.ev_k0_end, c->k0_stream));
+    HIP_TRY(hipStreamWaitEvent(st, b.ev_k0_end, 0));
+    HIP_TRY(hipEventRecord(b.ev_scan_start, st));
     K1Args A;
     if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, b.ev_scan_end, &A)) return rc;
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
@@ -2786,26 +2799,29 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
 }
 
 static int sync_pass_streams(mc_ctx *c) {
+    if (c->k0_stream) HIP_TRY(hipStreamSynchronize(c->k0_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return 0;
 }
 
-extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out) {
+// Copy-out of the oldest pass in flight, started but not waited for: the counters are read back (a short wait for the
+// pass's kernels), then the two DMA transfers of exactly n records are enqueued on the copy stream.  The caller can enqueue
+// further passes before it calls mc_wait_records, which waits for the transfers.
+extern "C" int mc_wait_records_begin(mc_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     if (c->ab_count == 0) {
-        mc_set_error("mc_wait_records: no pass in flight");
+        mc_set_error("mc_wait_records_begin: no pass in flight");
         return -12;
     }
     mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
-    c->ab_tail = (c->ab_tail + 1) % MC_PASSES_IN_FLIGHT;
-    c->ab_count -= 1;
+    if (b.copying) return 0;
     if (b.used) {                                                // the counters first, then exactly n records (DMA)
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_done, 0));
         HIP_TRY(hipMemcpyAsync(b.st_host, b.cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
     }
-    const Counters st = *b.st_host;
+    const Counters &st = *b.st_host;
     const bool special = st.overflow || st.n_irregular;      // (long windows were finished on the device: k1_rare_dev)
     if (b.used && !special && st.n_records > 0) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
@@ -2818,8 +2834,26 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + 16 * n);
         b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + 20 * n);
         b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 24 * n);
-        HIP_TRY(hipStreamSynchronize(cs));
+        HIP_TRY(hipEventRecord(b.ev_copied, cs));
     }
+    b.copying = true;
+    return 0;
+}
+
+extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->ab_count == 0) {
+        mc_set_error("mc_wait_records: no pass in flight");
+        return -12;
+    }
+    if (int rc = mc_wait_records_begin(c)) return rc;
+    mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
+    c->ab_tail = (c->ab_tail + 1) % MC_PASSES_IN_FLIGHT;
+    c->ab_count -= 1;
+    b.copying = false;
+    const Counters st = *b.st_host;
+    const bool special = st.overflow || st.n_irregular;
+    if (b.used && !special && st.n_records > 0) HIP_TRY(hipEventSynchronize(b.ev_copied));
     if (special && getenv("MCALLER_VERBOSE"))
         fprintf(stderr, "mcaller_hip: pass re-run synchronously (overflow %u, irregular %u, big %u, rare %u, records %llu)\n",
                 st.overflow, st.n_irregular, st.n_big, st.n_rare, st.n_records);
@@ -2835,7 +2869,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     if (b.used) {
         float t_k0 = 0, t_scan = 0, t_emit = 0, t_k2 = 0;
         HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_k0_end));
-        HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_k0_end, b.ev_scan_end));
+        HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_scan_end));
         HIP_TRY(hipEventElapsedTime(&t_emit, b.ev_scan_end, b.ev_emit_end));
         HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_emit_end, b.ev_k2_end));
         c->times[0] = t_k0; c->times[1] = t_scan; c->times[2] = t_emit; c->times[3] = t_k2;

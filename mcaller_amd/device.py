@@ -104,6 +104,10 @@ class Device(object):
         check(lib().mc_extract_features_async(self._ctx, C.byref(p)))
         self._async_k = getattr(self, '_async_k', []) + [int(k)]
 
+    def wait_begin(self):
+        """Start the copy-out of the oldest pass without waiting for it (wait() finishes it)."""
+        check(lib().mc_wait_records_begin(self._ctx))
+
     def wait(self):
         """Records of the oldest pass in flight: views of pinned buffers, valid until the second-next run_async."""
         n, v = C.c_int64(0), _lib.CallsView()
