@@ -111,8 +111,10 @@ def main():
         run_steps(args.warmup, on_done)
     del k1_ms[:], tot_ms[:]
     barrier()
+    dev.sync()                              # hipDeviceSynchronize: nothing of the warm-up is left on any stream
     t0 = time.perf_counter()
     run_steps(args.steps, on_done)          # the last wait() returns when the last pass's records are in host memory
+    dev.sync()
     barrier()
     elapsed = time.perf_counter() - t0
     rec = last[0]
@@ -213,7 +215,11 @@ def main():
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
-                       'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction},
+                       'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction,
+                       # SURVEY.md §8(d)'s three timings, calls/s on one GPU: kernels only; H2D of the table + one pass +
+                       # D2H of the records; file to file is measured by tools/file_to_file.py (profiles/r01_file_to_file.log)
+                       'calls_per_s_kernels_only': n_calls / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
+                       'calls_per_s_with_h2d': n_calls / (t_up + elapsed / args.steps)},
             'roofline': {'bound': 'hbm', 'kernel': 'k1_scan + k1_group_scan + k1_list + k1_emit (feature extraction)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -107,6 +107,17 @@ int64_t mc_parsed_n_unknown(const mc_parsed *p);                 /* rows dropped
 const char *mc_parsed_unknown_name(const mc_parsed *p, int64_t i); /* contig text of the i-th such row */
 void mc_parsed_free(mc_parsed *p);
 
+/* ===== FASTQ read quality (replaces read_qual.py:6-19) =====
+ * One (key, mean phred) pair per record, in file order: key = id.split(':')[0].split('_')[0] (:11-12), mean = exact
+ * integer sum of (ASCII - 33) / count in float64 (np.mean of the phred list, :11).  A path containing ".gz" is inflated
+ * (:7).  n_threads <= 0: one piece per core (pieces of at least 4 MB).  Errors (a title not starting with '@', a third
+ * line not starting with '+', sequence and quality of different lengths) are the ValueErrors Biopython raises there. */
+typedef struct mc_fastq mc_fastq;
+int mc_fastq_read_quality(const char *path, int32_t n_threads, mc_fastq **out);
+/* -> number of records; key_pool holds the keys, each followed by '\n'; key_off has n+1 offsets into it. */
+int64_t mc_fastq_view(const mc_fastq *f, const char **key_pool, const int64_t **key_off, const double **mean);
+void mc_fastq_free(mc_fastq *f);
+
 /* ===== device context ===== */
 typedef struct mc_ctx mc_ctx;
 int mc_ctx_create(int device, mc_ctx **out);

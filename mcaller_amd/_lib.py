@@ -80,6 +80,10 @@ def lib():
                                           C.c_int32, C.POINTER(C.c_void_p)]
         L.mc_parse_eventalign_range.argtypes = L.mc_parse_eventalign.argtypes
         L.mc_eventalign_read_cuts.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
+        L.mc_fastq_read_quality.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.mc_fastq_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.mc_fastq_view.restype = C.c_int64
+        L.mc_fastq_free.argtypes = [C.c_void_p]
         L.mc_parsed_view.argtypes = [C.c_void_p, C.POINTER(TableView)]
         L.mc_parsed_read_name.argtypes = [C.c_void_p, C.c_int32]
         L.mc_parsed_read_name.restype = C.c_char_p
@@ -178,6 +182,25 @@ class Table(object):
         return Table(self.pos[r0:r1], self.event_e4[r0:r1], self.model_e4[r0:r1], self.event_idx[r0:r1],
                      self.flags[r0:r1], self.seg_row_begin[s0:s1 + 1] - r0, self.seg_read[s0:s1],
                      self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner)
+
+
+def fastq_read_quality(path, n_threads=0):
+    """Native FASTQ reader -> (keys: list of str, means: float64 array), one entry per record in file order."""
+    L = lib()
+    handle = C.c_void_p()
+    if L.mc_fastq_read_quality(path.encode('utf-8'), int(n_threads), C.byref(handle)) != 0:
+        raise ValueError(L.mc_last_error().decode('utf-8', 'replace'))
+    try:
+        pool, off, mean = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = L.mc_fastq_view(handle, C.byref(pool), C.byref(off), C.byref(mean))
+        if n <= 0:
+            return [], np.zeros(0, dtype=np.float64)
+        offs = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_int64)), shape=(n + 1,))
+        text = C.string_at(pool, int(offs[n])).decode('utf-8')
+        means = np.ctypeslib.as_array(C.cast(mean, C.POINTER(C.c_double)), shape=(n,)).copy()
+        return text.split('\n')[:n], means
+    finally:
+        L.mc_fastq_free(handle)
 
 
 def eventalign_read_cuts(path, n_parts):

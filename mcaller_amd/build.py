@@ -4,7 +4,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['csrc/mc_device.hip', 'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_common.cpp']
+SOURCES = ['csrc/mc_device.hip', 'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_fastq.cpp',
+           'csrc/mc_common.cpp']
 OUT = os.path.join(HERE, 'libmcaller_hip.so')
 
 
@@ -15,7 +16,7 @@ def build_lib(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-           '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs
+           '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs + ['-ldl']
     for macro in ('MC_TILE', 'MC_SCAN_WGS', 'MC_PROFILE', 'MC_NTHREADS', 'MC_SCAN_WPE', 'MC_SCAN_CHUNK'):
         if os.environ.get(macro):
             cmd.insert(1, '-D%s=%s' % (macro, os.environ[macro]))

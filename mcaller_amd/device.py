@@ -133,6 +133,10 @@ class Device(object):
         self.run(k, skip_thresh, qual_thresh, **kw)
         return self.fetch()
 
+    def sync(self):
+        """hipDeviceSynchronize on this context's device (all of its streams)."""
+        check(lib().mc_ctx_sync(self._ctx))
+
     def times_ms(self):
         t = np.zeros(5, dtype=np.float32)
         check(lib().mc_last_times_ms(self._ctx, _ptr(t)))

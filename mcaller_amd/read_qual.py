@@ -3,6 +3,9 @@
 Keys are `id.split(':')[0].split('_')[0]` (read_qual.py:11-12), values np.float64 means of the
 per-base phred scores (exact integer sum / n).  `.gz` anywhere in the file name selects gzip, like
 the reference's `fastqfi.find(".gz")` test.
+
+`extract_read_quality` reads the file with the native multi-threaded reader (mc_fastq_read_quality, csrc/mc_fastq.cpp);
+`extract_read_quality_py` is the same contract in plain Python, kept as the statement the native reader is tested against.
 """
 import gzip
 
@@ -28,7 +31,13 @@ def _records(handle):
         yield title[1:].split(None, 1)[0], qual
 
 
-def extract_read_quality(fastqfi):
+def extract_read_quality(fastqfi, n_threads=0):
+    from . import _lib
+    keys, means = _lib.fastq_read_quality(fastqfi, n_threads)
+    return dict(zip(keys, means))                 # a later record of the same key replaces the earlier one (:12)
+
+
+def extract_read_quality_py(fastqfi):
     read2qual = {}
     opener = (lambda: gzip.open(fastqfi, 'rt')) if fastqfi.find('.gz') != -1 else (lambda: open(fastqfi, 'r'))
     with opener() as handle:
