@@ -85,13 +85,14 @@ def main():
             for _ in range(n_steps):
                 on_done(step_sync())
             return
-        depth = min(3, n_steps)                                  # passes in flight (the library allows three)
+        depth = min(3, n_steps)                                  # passes in flight (the library allows four)
         for _ in range(depth):
             dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+        dev.wait_begin()                                         # copy-out of the oldest pass started
         for _ in range(n_steps - depth):
-            dev.wait_begin()                                     # copy-out of the oldest pass started ...
-            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True) # ... the next pass enqueued while it runs ...
-            on_done(dev.wait())                                  # ... and the oldest pass's records are in host memory
+            dev.wait_begin()                                     # ... and of the one behind it, as soon as it is computed:
+            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True) # the transfers run back to back; the next pass enqueued;
+            on_done(dev.wait())                                  # the oldest pass's records are in host memory
         for _ in range(depth):
             on_done(dev.wait())
 

@@ -80,6 +80,11 @@ typedef struct mc_calls_view {
                             the closing row lies beyond this table (see tail_contig)             :216 */
     uint32_t *info;      /* MC_I_* */
     double  *prob;       /* p(m6A) from the MLP/forest; NaN where not scored                     :199 */
+    /* NULL: feats and prob hold one row per record (row j = record j).  Otherwise (mc_wait_records): they hold
+     * n_call_rows rows, one per record WITHOUT MC_I_TOO_MANY, in record order, and call_row[j] is the row of record j
+     * (-1 for a MC_I_TOO_MANY record: the reference only counts those, :239, nothing is stored for them). */
+    int32_t *call_row;
+    int64_t n_call_rows;
 } mc_calls_view;
 
 const char *mc_last_error(void);
@@ -159,17 +164,19 @@ int mc_fetch_records(mc_ctx *ctx, const mc_calls_view *host_out);
  * capacity is set to the record count).  mc_extract_features already moved them there, overlapped with the classifier. */
 int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
 /* Pipelined passes, for callers that stream many tables / shards (or the same table, as bench.py does): a pass is only
- * ENQUEUED -- strand resolve, scan + emit, classifier, packing of the narrow record columns, all on the ctx stream, each
- * pass with its own counters, strand-resolve output and record set -- and copied out (two DMA transfers of exactly n
- * records) when it is waited for, beside the kernels of the passes behind it; no host round trip sits inside a pass.  At
+ * ENQUEUED -- strand resolve, scan + emit, classifier, packing of what is copied out, all on the ctx stream, each
+ * pass with its own counters, strand-resolve output and record set -- and copied out (one DMA transfer: the narrow columns
+ * of the n records, then slot means and probabilities of the records that are calls, see mc_calls_view.call_row) when it
+ * is waited for, beside the kernels of the passes behind it; no host round trip sits inside a pass.  At
  * most four passes are in flight (one being copied out, one computing, two queued).  mc_wait_records hands out the
  * OLDEST pass and returns a view of the context's pinned buffers (valid until four more passes have been enqueued).  A
  * pass that needs more than the fast path (irregular reads, record buffers too small) is re-run synchronously inside
  * mc_wait_records -- results are the same, only slower.  MLP classifier only (the forest runs in mc_extract_features). */
 int mc_extract_features_async(mc_ctx *ctx, const mc_params *prm);
 int mc_wait_records(mc_ctx *ctx, int64_t *n_records, mc_calls_view *out);
-/* Optional first half of mc_wait_records for the oldest pass: reads its counters back and ENQUEUES its copy-out, without
- * waiting for it -- the caller can enqueue another pass before mc_wait_records waits for the transfers. */
+/* Optional first half of mc_wait_records, for the oldest pass in flight whose copy-out has not been started: waits for
+ * its kernels, reads its counters and ENQUEUES its copy-out without waiting for it.  Calling it for pass i+1 before
+ * mc_wait_records(pass i) keeps the DMA engine busy back to back (bench.py does).  No-op if every pass is being copied. */
 int mc_wait_records_begin(mc_ctx *ctx);
 /* Kernel times of the last mc_extract_features, from hipEvents on the ctx stream, in ms:
  * [0] strand resolve (K0), [1] window scan (k1_scan), [2] window emit (k1_group_scan + k1_list + k1_emit),

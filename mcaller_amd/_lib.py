@@ -39,7 +39,8 @@ class RefView(C.Structure):
 class CallsView(C.Structure):
     _fields_ = [('capacity', C.c_int64),
                 ('feats', C.c_void_p), ('site_pos', C.c_void_p), ('site_seg', C.c_void_p),
-                ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p)]
+                ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p),
+                ('call_row', C.c_void_p), ('n_call_rows', C.c_int64)]
 
 
 class FormatArgs(C.Structure):
@@ -323,6 +324,8 @@ class Records(object):
         v.capacity = self.capacity
         v.feats, v.site_pos, v.site_seg = _ptr(self.feats), _ptr(self.site_pos), _ptr(self.site_seg)
         v.close_row, v.info, v.prob = _ptr(self.close_row), _ptr(self.info), _ptr(self.prob)
+        if self.call_row is not None:
+            v.call_row, v.n_call_rows = _ptr(self.call_row), int(self.n_calls)
         return v
 
     @classmethod
@@ -335,5 +338,34 @@ class Records(object):
         r.site_seg = _from_ptr(v.site_seg, n, np.int32)
         r.close_row = _from_ptr(v.close_row, n, np.int64)
         r.info = _from_ptr(v.info, n, np.uint32)
-        r.prob = _from_ptr(v.prob, n, np.float64)
+        if v.call_row:                       # mc_wait_records: means / probabilities of the calls only, compacted
+            m = int(v.n_call_rows)
+            r.call_row = _from_ptr(v.call_row, n, np.int32)
+            r._n_calls = m
+            r.feats = _from_ptr(v.feats, m * k, np.float64)
+            r.prob = _from_ptr(v.prob, m, np.float64)
+        else:
+            r.prob = _from_ptr(v.prob, n, np.float64)
+        return r
+
+    call_row = None                          # None: feats / prob have one row per record
+
+    @property
+    def n_calls(self):
+        """Rows of feats / prob."""
+        return self._n_calls if self.call_row is not None else self.n
+
+    def by_record(self):
+        """A copy with one feats / prob row per record (zeros / NaN for the MC_I_TOO_MANY records of a compacted view)."""
+        if self.call_row is None:
+            return self
+        n, k = self.n, self.k
+        r = Records(n, k)
+        r.n = n
+        for name in ('site_pos', 'site_seg', 'close_row', 'info'):
+            getattr(r, name)[:n] = getattr(self, name)[:n]
+        kept = self.call_row[:n] >= 0
+        rows = self.call_row[:n][kept]
+        r.feats.reshape(-1, k)[:n][kept] = self.feats.reshape(-1, k)[rows]
+        r.prob[:n][kept] = self.prob[rows]
         return r

@@ -160,7 +160,7 @@ struct Counters {          // device-side status block
     unsigned int n_irregular;
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
-    unsigned int pad[2];
+    unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
     struct { unsigned long long v; unsigned long long pad[15]; } ticket[NSHARD];   // k1_scan's tile-chunk ticket counters, one
                                    // per XCD (workgroups are dealt to the XCDs round-robin), each on its own 128-byte line
     unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
@@ -1956,22 +1956,94 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 // next pass that ENDS while it runs waits for it: the end-of-kernel cache write-back queues behind its PCIe writes --
 // measured with rocprofv3, see DESIGN.md.  DMA copies do not go through the shader caches.)
 // ---------------------------------------------------------------------------------------------------
-// The five narrow record columns of a pass, first n entries each, one after the other in a staging block: the copy-out
-// is then two DMA transfers (slot means; everything else) instead of six with a gap after each.
-__global__ __launch_bounds__(256) void k_pack(DevRecords O, const Counters *__restrict__ cnt, unsigned char *__restrict__ out) {
+// What a pipelined pass hands to the DMA engine is ONE block: five narrow columns of all n flush records (closing row,
+// site, segment, info, call_row) and, behind them, the slot means and the probability of the records that are calls --
+// compacted: a record with MC_I_TOO_MANY is only counted by the host (:239), nothing reads its means, and at 6 % skips it
+// is every third record; call_row[j] is the row of record j in the compacted part (-1: none).  The copy-out is what bounds
+// a pass (PCIe, 52 GB/s), so bytes dropped here are time.  Two small kernels: per-chunk counts of kept records, then every
+// workgroup sums the counts before its chunk and packs the chunk.  The pass's counters go to pinned host memory from here
+// as well (a 96-byte store over PCIe): the host reads them after hipEventSynchronize(ev_done) and enqueues the transfer
+// at once, without a read-back on the copy stream in between.
+constexpr int PACK_WGS = 256, PACK_THREADS = 256;
+
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt,
+                                                             unsigned long long *__restrict__ chunk_cnt) {
+    __shared__ unsigned int s_wave[PACK_THREADS / 64];
+    const int64_t n = cnt->overflow ? 0 : min((int64_t)cnt->n_records, O.capacity);
+    const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    unsigned int kept = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) kept += (O.info[i] & MC_I_TOO_MANY) ? 0u : 1u;
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < PACK_THREADS / 64; ++w) t += s_wave[w];
+        chunk_cnt[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
+                                                       const unsigned long long *__restrict__ chunk_cnt,
+                                                       unsigned char *__restrict__ out, int k, Counters *__restrict__ host_status) {
+    static_assert(PACK_WGS == PACK_THREADS, "one chunk count per thread");
+    __shared__ unsigned long long s_sum[2][PACK_THREADS / 64];
+    __shared__ unsigned int s_wave[PACK_THREADS / 64];
+    __shared__ int s_row[PACK_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // kept records before this chunk, and in all chunks
+    unsigned long long v = chunk_cnt[tid], before = tid < (int)blockIdx.x ? v : 0ull;
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); before += __shfl_xor(before, o); }
+    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; }
+    __syncthreads();
+    unsigned long long total = 0, base = 0;
+    for (int w = 0; w < PACK_THREADS / 64; ++w) { total += s_sum[0][w]; base += s_sum[1][w]; }
+    constexpr unsigned head_words = offsetof(Counters, ticket) / 4;      // everything the host looks at
+    if (blockIdx.x == 0) {
+        if (tid < (int)head_words && tid != (int)(offsetof(Counters, n_kept) / 4) && tid != (int)(offsetof(Counters, n_kept) / 4 + 1))
+            reinterpret_cast<volatile unsigned int *>(host_status)[tid] = reinterpret_cast<const unsigned int *>(cnt)[tid];
+        if (tid == 0) *reinterpret_cast<volatile unsigned long long *>(&host_status->n_kept) = total;
+    }
+    if (cnt->overflow) return;                                           // (the host runs such a pass again, synchronously)
     const int64_t n = min((int64_t)cnt->n_records, O.capacity);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
     int64_t *o_close = reinterpret_cast<int64_t *>(out);
-    double *o_prob = reinterpret_cast<double *>(out + 8 * n);
-    int32_t *o_pos = reinterpret_cast<int32_t *>(out + 16 * n);
-    int32_t *o_seg = reinterpret_cast<int32_t *>(out + 20 * n);
-    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + 24 * n);
-    for (int64_t i = t; i < n; i += stride) {
-        o_close[i] = O.close_row[i];
-        o_prob[i] = O.prob[i];
-        o_pos[i] = O.site_pos[i];
-        o_seg[i] = O.site_seg[i];
-        o_info[i] = O.info[i];
+    int32_t *o_pos = reinterpret_cast<int32_t *>(out + 8 * n);
+    int32_t *o_seg = reinterpret_cast<int32_t *>(out + 12 * n);
+    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + 16 * n);
+    int32_t *o_row = reinterpret_cast<int32_t *>(out + 20 * n);
+    double *o_feats = reinterpret_cast<double *>(out + 24 * n);
+    double *o_prob = o_feats + (int64_t)total * k;
+    for (int64_t s = lo; s < hi; s += PACK_THREADS) {
+        const int64_t i = s + tid;
+        const bool valid = i < hi;
+        const uint32_t info = valid ? O.info[i] : MC_I_TOO_MANY;
+        const bool keep = !(info & MC_I_TOO_MANY);
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) s_wave[wave] = (unsigned int)__popcll(mask);
+        __syncthreads();
+        unsigned int in_strip = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull)), strip = 0;
+        for (int w = 0; w < PACK_THREADS / 64; ++w) { if (w < wave) in_strip += s_wave[w]; strip += s_wave[w]; }
+        s_row[tid] = keep ? (int)in_strip : -1;
+        if (valid) {
+            o_close[i] = O.close_row[i];
+            o_pos[i] = O.site_pos[i];
+            o_seg[i] = O.site_seg[i];
+            o_info[i] = info;
+            o_row[i] = keep ? (int32_t)(base + in_strip) : -1;
+            if (keep) o_prob[base + in_strip] = O.prob[i];
+        }
+        __syncthreads();
+        const double *src = O.feats + s * k;                             // the strip's slot means, all threads on consecutive words
+        double *dst = o_feats + (int64_t)base * k;
+        for (int idx = tid; idx < PACK_THREADS * k; idx += PACK_THREADS) {
+            const int r = idx / k, f = idx - r * k, row = s_row[r];
+            if (row >= 0) dst[(int64_t)row * k + f] = src[idx];
+        }
+        __syncthreads();
+        base += strip;
     }
 }
 
@@ -2040,8 +2112,12 @@ struct mc_ctx {
         DevRecords H;              // pinned host memory
         K0Set K;                   // strand resolve output of the pass
         Counters *cnt = nullptr;   // its counters (device) ...
-        Counters *st_host = nullptr; // ... and where the host reads them (pinned)
-        unsigned char *pack = nullptr, *pack_host = nullptr;   // narrow columns, packed (device staging, pinned host)
+        Counters *st_host = nullptr; // ... and where the host reads them (pinned; st_dev: the same block as the GPU sees it)
+        Counters *st_dev = nullptr;
+        unsigned char *pack = nullptr, *pack_host = nullptr;   // what is copied out, packed by k_pack (device staging, pinned host)
+        unsigned long long *chunk_cnt = nullptr;               // k_pack_count -> k_pack
+        int32_t *h_call_row = nullptr;                         // in pack_host: row of record j in the compacted means / probabilities
+        int64_t h_n_calls = 0;
         // stage boundaries: dependencies between the streams, and the kernel times
         hipEvent_t ev_k0_start = nullptr, ev_k0_end = nullptr, ev_scan_start = nullptr, ev_scan_end = nullptr,
                    ev_emit_end = nullptr, ev_k2_start = nullptr, ev_k2_end = nullptr, ev_done = nullptr, ev_copied = nullptr;
@@ -2051,7 +2127,7 @@ struct mc_ctx {
         bool used = false, copying = false;
         std::vector<void *> dev_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
-    hipStream_t k0_stream = nullptr;     // strand resolve of the pipelined passes
+    hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
     int ab_head = 0, ab_tail = 0, ab_count = 0;
     // per-site reduction (mc_site_*): counts on the device, RCCL communicator
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
@@ -2177,7 +2253,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->site_first) (void)hipFree(c->site_first);
     (void)sync_pass_streams(c);
     free_async(c);
-    if (c->k0_stream) (void)hipStreamDestroy(c->k0_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (auto &b : c->ab)
         for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied})
             if (e) (void)hipEventDestroy(e);
@@ -2678,6 +2754,8 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
     out->close_row = c->H.close_row;
     out->info = c->H.info;
     out->prob = c->H.prob;
+    out->call_row = nullptr;          // means and probabilities are stored for every record here
+    out->n_call_rows = 0;
     return 0;
 }
 
@@ -2687,7 +2765,6 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
 static void free_async(mc_ctx *c) {
     for (auto &b : c->ab) {
         free_pool(b.dev_allocs);
-        if (b.H.feats) (void)hipHostFree(b.H.feats);
         b.H = DevRecords();
         if (b.pack_host) (void)hipHostFree(b.pack_host);
         if (b.st_host) (void)hipHostFree(b.st_host);
@@ -2714,7 +2791,6 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     if (b.cap >= cap && b.k == k && b.n_nb >= T.n_nb && b.n_tiles >= T.n_tiles) return 0;
     if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
     free_pool(b.dev_allocs);
-    if (b.H.feats) (void)hipHostFree(b.H.feats);
     b.H = DevRecords();
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
@@ -2722,16 +2798,49 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
         dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)T.n_nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0idx, (size_t)T.n_nb + 1) ||
         dev_alloc(b.dev_allocs, &b.K.nb_lastidx, (size_t)T.n_nb + 1))
         return -10;
-    if (dev_alloc(b.dev_allocs, &b.pack, (size_t)cap * 28 + 64)) return -10;
+    if (cap >= (int64_t)1 << 31) {
+        mc_set_error("mc_extract_features_async: %lld flush records per pass (call_row is 32 bits wide); use mc_extract_features",
+                     (long long)cap);
+        return -12;
+    }
+    const size_t pack_bytes = (size_t)cap * (24 + ((size_t)k + 1) * 8) + 64;
+    if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_WGS)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
-    if (pinned((void **)&b.H.feats, (size_t)cap * k * 8) || pinned((void **)&b.pack_host, (size_t)cap * 28 + 64)) return -10;
+    if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
     b.H.capacity = cap;
-    if (!b.st_host && pinned((void **)&b.st_host, sizeof(Counters))) return -10;
+    if (!b.st_host) {
+        if (pinned((void **)&b.st_host, sizeof(Counters))) return -10;
+        HIP_TRY(hipHostGetDevicePointer((void **)&b.st_dev, b.st_host, 0));
+    }
     b.cap = cap;
     b.k = k;
     b.n_nb = T.n_nb;
     b.n_tiles = T.n_tiles;
     b.used = false;
+    return 0;
+}
+
+// Classifier of a pass whose emit has been enqueued (ev_emit_end recorded), on the side stream.
+static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b) {
+    const DevTable &T = c->T;
+    hipStream_t st = c->side_stream;
+    HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
+    HIP_TRY(hipEventRecord(b.ev_k2_start, st));
+    if (b.prm.score)
+        launch_k2(c, k2_grid(c, b.cap), st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr,
+                  b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
+    HIP_TRY(hipEventRecord(b.ev_k2_end, st));
+    return 0;
+}
+
+// Packing of a pass whose classifier has been enqueued (ev_k2_end recorded): what mc_wait_records_begin copies out.
+static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
+    hipStream_t s2 = c->side_stream;
+    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.chunk_cnt);
+    hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt,
+                       (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.st_dev);
+    HIP_TRY(hipEventRecord(b.ev_done, s2));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -2763,32 +2872,25 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
         if (!other.used && other.cap < cap) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
-    // K1, K2 and the packing of a pass on the ctx stream, back to back with the next pass; K0 (strand resolve: a few small,
-    // latency-bound kernels) on its own stream, started when the PREVIOUS pass's emit is done, so that it runs beside that
-    // pass's classifier (compute-bound) and is finished when the scan's turn comes.  The scan and the emit always have the
-    // GPU to themselves.  (K0 and K2 beside the neighbouring passes' SCANS was measured too: 3 % more passes per second
-    // for a scan that takes 20 % longer while it shares the CUs -- rejected.)
+    // K0 (strand resolve) and K1 (scan, ordering, emit) of a pass on the ctx stream, back to back with the next pass: nothing
+    // on the scan's path waits for another queue.  K2 (classifier) and the packing on the side stream, behind the pass's
+    // emit: they run beside K0 of the next pass (small latency-bound kernels) and the first microseconds of its scan.
+    // Measured on the 10^8-row table (rocprofv3 timelines), passes per second relative to this layout:
+    // K0 on the side stream beside K2 on the ctx stream -3 % (two cross-queue hand-overs of 15-25 us on the scan's path);
+    // K2 + packing deferred so that they run beside the next SCAN: the same (K2 gets one wave per SIMD there and takes 195 us
+    // instead of 68); separate streams for K0 and K2: they land on one hardware queue and serialise; low-priority side
+    // streams: time-sliced, 40 % slower.
     hipStream_t st = c->stream;
-    if (!c->k0_stream) HIP_TRY(hipStreamCreateWithFlags(&c->k0_stream, hipStreamNonBlocking));
-    {
-        mc_ctx::AsyncBuf &prev = c->ab[(c->ab_head + MC_PASSES_IN_FLIGHT - 1) % MC_PASSES_IN_FLIGHT];
-        if (c->ab_count > 0 && prev.used) HIP_TRY(hipStreamWaitEvent(c->k0_stream, prev.ev_emit_end, 0));
-    }
-    HIP_TRY(hipEventRecord(b.ev_k0_start, c->k0_stream));
-    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, c->k0_stream)) return rc;
-    HIP_TRY(hipEventRecord(b.ev_k0_end, c->k0_stream));
-    HIP_TRY(hipStreamWaitEvent(st, b.ev_k0_end, 0));
+    if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventRecord(b.ev_k0_start, st));
+    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st)) return rc;
     HIP_TRY(hipEventRecord(b.ev_scan_start, st));
     K1Args A;
     if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, b.ev_scan_end, &A)) return rc;
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
     HIP_TRY(hipEventRecord(b.ev_emit_end, st));
-    if (prm->score)
-        launch_k2(c, k2_grid(c, cap), st, b.O.feats, k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, cap,
-                  b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
-    HIP_TRY(hipEventRecord(b.ev_k2_end, st));
-    hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, st, b.O, (const Counters *)b.cnt, b.pack);
-    HIP_TRY(hipEventRecord(b.ev_done, st));
+    if (int rc = enqueue_k2(c, b)) return rc;
+    if (int rc = enqueue_pack(c, b)) return rc;
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
     // copy-out of the previous pass, which mc_wait_records enqueues later)
     HIP_TRY(hipGetLastError());
@@ -2799,27 +2901,29 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
 }
 
 static int sync_pass_streams(mc_ctx *c) {
-    if (c->k0_stream) HIP_TRY(hipStreamSynchronize(c->k0_stream));
+    if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return 0;
 }
 
-// Copy-out of the oldest pass in flight, started but not waited for: the counters are read back (a short wait for the
-// pass's kernels), then the two DMA transfers of exactly n records are enqueued on the copy stream.  The caller can enqueue
-// further passes before it calls mc_wait_records, which waits for the transfers.
+// Copy-out of the oldest pass in flight whose copy-out has not been started, started but not waited for: the counters are
+// read (k_pack left them in pinned memory; a wait for the pass's kernels), then one DMA transfer of exactly what the pass
+// produced is enqueued on the copy stream.  Called for pass i+1 before mc_wait_records(i), the transfers run back to back:
+// no host round trip sits between two copy-outs.  (No-op when every pass in flight is being copied out already.)
 extern "C" int mc_wait_records_begin(mc_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     if (c->ab_count == 0) {
         mc_set_error("mc_wait_records_begin: no pass in flight");
         return -12;
     }
-    mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
-    if (b.copying) return 0;
-    if (b.used) {                                                // the counters first, then exactly n records (DMA)
+    int at = c->ab_tail, left = c->ab_count;
+    while (left > 0 && c->ab[at].copying) { at = (at + 1) % MC_PASSES_IN_FLIGHT; --left; }
+    if (left == 0) return 0;
+    mc_ctx::AsyncBuf &b = c->ab[at];
+    if (b.used) {                                                // the counters (k_pack stored them in st_host), then exactly
+        HIP_TRY(hipEventSynchronize(b.ev_done));                 // n records with the DMA engines
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_done, 0));
-        HIP_TRY(hipMemcpyAsync(b.st_host, b.cnt, sizeof(Counters), hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipStreamSynchronize(c->copy_stream));
     }
     const Counters &st = *b.st_host;
     const bool special = st.overflow || st.n_irregular;      // (long windows were finished on the device: k1_rare_dev)
@@ -2827,13 +2931,16 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
         const int k = b.k;
         hipStream_t cs = c->copy_stream;
-        HIP_TRY(hipMemcpyAsync(b.H.feats, b.O.feats, n * k * 8, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, n * 28, hipMemcpyDeviceToHost, cs));
+        const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
+        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, n * 24 + m * ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, cs));
         b.H.close_row = reinterpret_cast<int64_t *>(b.pack_host);
-        b.H.prob = reinterpret_cast<double *>(b.pack_host + 8 * n);
-        b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + 16 * n);
-        b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + 20 * n);
-        b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 24 * n);
+        b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + 8 * n);
+        b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + 12 * n);
+        b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 16 * n);
+        b.h_call_row = reinterpret_cast<int32_t *>(b.pack_host + 20 * n);
+        b.H.feats = reinterpret_cast<double *>(b.pack_host + 24 * n);
+        b.H.prob = b.H.feats + m * (size_t)k;
+        b.h_n_calls = (int64_t)m;
         HIP_TRY(hipEventRecord(b.ev_copied, cs));
     }
     b.copying = true;
@@ -2846,7 +2953,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         mc_set_error("mc_wait_records: no pass in flight");
         return -12;
     }
-    if (int rc = mc_wait_records_begin(c)) return rc;
+    if (!c->ab[c->ab_tail].copying) { if (int rc = mc_wait_records_begin(c)) return rc; }
     mc_ctx::AsyncBuf &b = c->ab[c->ab_tail];
     c->ab_tail = (c->ab_tail + 1) % MC_PASSES_IN_FLIGHT;
     c->ab_count -= 1;
@@ -2868,10 +2975,10 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     const int64_t n = (int64_t)st.n_records;
     if (b.used) {
         float t_k0 = 0, t_scan = 0, t_emit = 0, t_k2 = 0;
-        HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_k0_end));
+        HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_scan_start));
         HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_scan_end));
         HIP_TRY(hipEventElapsedTime(&t_emit, b.ev_scan_end, b.ev_emit_end));
-        HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_emit_end, b.ev_k2_end));
+        HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_k2_start, b.ev_k2_end));
         c->times[0] = t_k0; c->times[1] = t_scan; c->times[2] = t_emit; c->times[3] = t_k2;
         c->times[4] = t_k0 + t_scan + t_emit + t_k2;
     }
@@ -2882,6 +2989,8 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->capacity = n;
     out->feats = b.H.feats; out->site_pos = b.H.site_pos; out->site_seg = b.H.site_seg;
     out->close_row = b.H.close_row; out->info = b.H.info; out->prob = b.H.prob;
+    out->call_row = n > 0 && b.used ? b.h_call_row : nullptr;
+    out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
     return 0;
 }
 

@@ -143,7 +143,7 @@ inline bool build_context(const mc_format_args *a, int64_t j, char *ctx) {
 inline bool native_ok(const mc_format_args *a, int64_t j) {
     const uint32_t info = a->rec->info[j];
     if (info & MC_I_TOO_MANY) return true;               // no text
-    if (std::isnan(a->rec->prob[j])) return false;
+    if (std::isnan(a->rec->prob[a->rec->call_row ? a->rec->call_row[j] : j])) return false;
     char ctx[2 * MC_MAX_K];
     return build_context(a, j, ctx);
 }
@@ -180,7 +180,8 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         o += 2 * k - 1;
         *o++ = '\t';
         const uint32_t empty = info & MC_I_EMPTY_MASK;
-        const double *f = rec->feats + j * k;
+        const int64_t row = rec->call_row ? rec->call_row[j] : j;                  // (compacted views: mc_wait_records)
+        const double *f = rec->feats + row * k;
         for (int i = 0; i < k; ++i) {
             if ((empty >> i) & 1u) *o++ = '0';                                     // literal int 0  (:186)
             else o = put_repr(o, f[i]);
@@ -188,7 +189,7 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         }
         o = put_str(o, a->read_qual_txt[rid], J.qual_len[(size_t)rid]); *o++ = '\t';
         *o++ = (info & MC_I_REV) ? '-' : '+'; *o++ = '\t';
-        const double p1 = rec->prob[j];
+        const double p1 = rec->prob[row];
         if (p1 >= 0.5) o = put_str(o, a->label_meth, J.lab_pos_len);               // :200-206
         else o = put_str(o, a->label_unmeth, J.lab_neg_len);
         *o++ = '\t';

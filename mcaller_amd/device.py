@@ -105,7 +105,7 @@ class Device(object):
         self._async_k = getattr(self, '_async_k', []) + [int(k)]
 
     def wait_begin(self):
-        """Start the copy-out of the oldest pass without waiting for it (wait() finishes it)."""
+        """Start the copy-out of the oldest pass whose copy-out has not been started, without waiting for it."""
         check(lib().mc_wait_records_begin(self._ctx))
 
     def wait(self):

@@ -174,7 +174,9 @@ class Finisher(object):
         P, k, t = self.P, self.k, self.P.table
         n = rec.n
         self._rec = rec
-        self._feats = rec.feats[:n * k].reshape(n, k)
+        m = rec.n_calls                       # (a compacted view, mc_wait_records: rows of the calls only, see Records.call_row)
+        self._feats = rec.feats[:m * k].reshape(m, k)
+        self._row = rec.call_row[:n] if rec.call_row is not None else None
         self._info = rec.info[:n]
         self._site_pos = rec.site_pos[:n]
         self._seg_of = rec.site_seg[:n]
@@ -236,9 +238,10 @@ class Finisher(object):
             empty = inf & _I.I_EMPTY_MASK
             if empty:
                 self.w_skips.add((read, mpos))                                # :184-185
-            diffs = [0 if (empty >> i) & 1 else float(feats[j, i]) for i in range(k)]
+            row = j if self._row is None else int(self._row[j])
+            diffs = [0 if (empty >> i) & 1 else float(feats[row, i]) for i in range(k)]
             qual = P.qual_obj[rid]
-            diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[j, i]) for i in range(k)]
+            diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[row, i]) for i in range(k)]
                                  + [str(qual)])
             cseg = int(self._close_seg[j])
             chrom = self.tail_chrom if cseg >= t.n_seg else P.ref.names[int(t.seg_contig[cseg])]
@@ -251,7 +254,7 @@ class Finisher(object):
                     twobase_model = self.table[context[centre:centre + 2]]
                     if not self.train:
                         mi = self.model_index[twobase_model]                  # KeyError: model[...] :199
-                        p1 = rec.prob[j]
+                        p1 = rec.prob[row]
                         want = (inf >> _I.I_NEXT_SHIFT) & 0xFF
                         if (inf & _I.I_EDGE) or np.isnan(p1):
                             dev = self.device if self.device is not None else get_device()

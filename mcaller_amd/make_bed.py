@@ -171,6 +171,7 @@ def site_counts(rec, table, index, row_offset=0):
     n_meth = np.zeros(index.n, dtype=np.int32)
     n_total = np.zeros(index.n, dtype=np.int32)
     first = np.full(index.n, np.iinfo(np.int64).max, dtype=np.int64)
+    rec = rec.by_record()
     n = rec.n
     info = rec.info[:n]
     ok = (info & _lib.I_TOO_MANY) == 0
@@ -188,6 +189,7 @@ def add_pending_site_counts(dev, rec, table, index, row_offset=0, prob=None):
     """Records the device could not score (NaN there; the host scored them: `prob`, default rec.prob) -> added to the
     device-side counts of Device.site_counts()."""
     from . import _lib
+    rec = rec.by_record()
     n = rec.n
     info = rec.info[:n]
     sel = ((info & _lib.I_TOO_MANY) == 0) & np.isnan(rec.prob[:n])

@@ -221,10 +221,10 @@ def test_pipelined_passes_equal_the_synchronous_path(dev, tmp_path):
             dev.run_async(*params[i])
         else:
             dev.run_async(params[i][0], params[i][1], params[i][2], score=False)      # features only: k+1 != model inputs
-        r = dev.wait()
+        r = dev.wait().by_record()
         got.append((r.n, r.feats[:r.n * r.k].copy(), r.site_pos[:r.n].copy(), r.info[:r.n].copy(), r.prob[:r.n].copy(),
                     r.close_row[:r.n].copy(), r.site_seg[:r.n].copy()))
-    r = dev.wait()
+    r = dev.wait().by_record()
     got.append((r.n, r.feats[:r.n * r.k].copy(), r.site_pos[:r.n].copy(), r.info[:r.n].copy(), r.prob[:r.n].copy(),
                 r.close_row[:r.n].copy(), r.site_seg[:r.n].copy()))
     for (k, skip, q), s_rec, g in zip(params, sync, got):
@@ -267,7 +267,7 @@ def test_pipelined_passes_equal_the_synchronous_path(dev, tmp_path):
         dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'])
         dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'])
         for _ in range(2):
-            r = dev.wait()
+            r = dev.wait().by_record()
             assert r.n == want.n
             assert (r.feats[:r.n * r.k] == want.feats[:want.n * want.k]).all() and (r.info[:r.n] == want.info[:want.n]).all()
             assert np.array_equal(r.prob[:r.n], want.prob[:want.n], equal_nan=True)
@@ -297,11 +297,11 @@ def test_full_size_records_equal_the_oracle(n_rows, motif, score):
         dev.set_mlp(weights, soc)
         dev.run_async(6, 0, 0.0, score=score)
         dev.run_async(6, 0, 0.0, score=score)
-        first = dev.wait()
-        keep = (first.n, first.feats[:first.n * 6].copy(), first.prob[:first.n].copy())
+        first = dev.wait()                    # (compacted views: slot means / probabilities of the calls only)
+        keep = (first.n, first.feats[:first.n_calls * 6].copy(), first.prob[:first.n_calls].copy())
         rec = dev.wait()
-        assert rec.n == keep[0] and (rec.feats[:rec.n * 6] == keep[1]).all()          # passes are reproducible
-        assert np.array_equal(rec.prob[:rec.n], keep[2], equal_nan=True)
+        assert rec.n == keep[0] and (rec.feats[:rec.n_calls * 6] == keep[1]).all()    # passes are reproducible
+        assert np.array_equal(rec.prob[:rec.n_calls], keep[2], equal_nan=True)
         orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
         if score:
             H.oracle_score(orc, table, qual, weights, soc, 6)
@@ -356,7 +356,7 @@ def test_empty_and_tiny_tables(dev):
         rec = dev.extract(6, 0, 0.0, score=False)
         assert rec.n == orc.n
         dev.run_async(6, 0, 0.0, score=False)
-        assert dev.wait().n == orc.n
+        assert dev.wait().by_record().n == orc.n
         if orc.n:
             rec.prob[:rec.n] = np.nan
             H.assert_records_equal(rec, orc, 6)

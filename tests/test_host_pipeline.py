@@ -166,3 +166,48 @@ def test_native_formatter_equals_per_record_path(td, tmp_path):
         assert mixed.run(rec) is None
         rec.prob[:rec.n] = keep
         assert mixed.text() == literal.text() and mixed.counters() == literal.counters()
+
+
+def _compacted(rec, k):
+    """The records as a pipelined pass hands them out (mc_wait_records): slot means / probabilities of the calls only."""
+    from mcaller_amd import _lib
+    n = rec.n
+    kept = (rec.info[:n] & _lib.I_TOO_MANY) == 0
+    c = _lib.Records.__new__(_lib.Records)
+    c.k, c.capacity, c.n = k, n, n
+    for name in ('site_pos', 'site_seg', 'close_row', 'info'):
+        setattr(c, name, getattr(rec, name)[:n].copy())
+    c.call_row = np.where(kept, np.cumsum(kept) - 1, -1).astype(np.int32)
+    c._n_calls = int(kept.sum())
+    c.feats = np.ascontiguousarray(rec.feats[:n * k].reshape(n, k)[kept]).reshape(-1)
+    c.prob = np.ascontiguousarray(rec.prob[:n][kept])
+    return c
+
+
+def test_rows_from_a_compacted_view(td, tmp_path):
+    """Finisher (native formatter and the per-record path) on a compacted view == on one row per record."""
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    read2qual = extract_read_quality(td['fastq'])
+    modelset = H.load_modelset('r95')
+    P = ec.prepare(td['tsv'], td['fasta'], read2qual, 0, os.path.getsize(td['tsv']), 'A', 'A', None)
+    rec = H.oracle_records(P.table, P.ref.device_arrays(), P.qual, 6, 1, 0)
+    _, weights, _, soc = ec.submodel_setup(modelset, 'A')
+    H.oracle_score(rec, P.table, P.qual, weights, soc, 6)
+    comp = _compacted(rec, 6)
+    assert 0 < comp.n_calls < comp.n
+    outs = []
+    for r in (rec, comp):
+        native = ec.Finisher(P, 6, 'A', False, modelset=modelset)
+        with contextlib.redirect_stdout(io.StringIO()):
+            assert native.run(r) is None
+        literal = ec.Finisher(P, 6, 'A', False, modelset=modelset)
+        literal._bind(r)
+        for j in range(r.n):
+            assert literal._one(j) is None
+        assert native.text() == literal.text()
+        outs.append((native.text(), native.counters()))
+    assert outs[0] == outs[1] and len(outs[0][0]) > 10000
+    back = comp.by_record()
+    assert np.array_equal(back.feats[:rec.n * 6], rec.feats[:rec.n * 6])
+    assert np.array_equal(back.prob[:rec.n], rec.prob[:rec.n], equal_nan=True)

@@ -32,3 +32,22 @@ for rep in range(3):
         r = dev.wait()
     dt = time.perf_counter() - t
     print('pipelined: %.3f ms per pass (%d records) env NOEVENTS=%s' % (dt / steps * 1e3, r.n, os.environ.get('MCALLER_ASYNC_NOEVENTS')))
+
+# where the host's time goes in the split loop (bench.py's): seconds inside each call, per pass
+steps, depth = 200, 3
+acc = dict(wait_begin=0.0, run_async=0.0, wait=0.0, times=0.0)
+t_all = time.perf_counter()
+for _ in range(depth):
+    dev.run_async(6, 0, 0.0)
+for _ in range(steps - depth):
+    t0 = time.perf_counter(); dev.wait_begin()
+    t1 = time.perf_counter(); dev.run_async(6, 0, 0.0)
+    t2 = time.perf_counter(); r = dev.wait()
+    t3 = time.perf_counter(); dev.times_ms()
+    t4 = time.perf_counter()
+    acc['wait_begin'] += t1 - t0; acc['run_async'] += t2 - t1; acc['wait'] += t3 - t2; acc['times'] += t4 - t3
+for _ in range(depth):
+    r = dev.wait()
+dt = time.perf_counter() - t_all
+print('split loop: %.3f ms per pass; host inside calls, ms per pass: %s' % (
+    dt / steps * 1e3, {k: round(v / (steps - depth) * 1e3, 4) for k, v in acc.items()}))
