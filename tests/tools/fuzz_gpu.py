@@ -47,7 +47,7 @@ for fi, fl in enumerate(flavours):
             rec = ec.compute(P, a['k'], a['skip_thresh'], a['qual_thresh'], modelset, a['base'], train, device=dev)
             H.assert_records_equal(rec, orc, a['k'])
             dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'], score=not train)
-            rec2 = dev.wait().by_record()
+            rec2 = dev.wait()                         # (compacted view: the helper checks call_row, then compares by record)
             H.assert_records_equal(rec2, orc, a['k'])
             done += 1
         except AssertionError as e:
