@@ -268,9 +268,54 @@ __global__ void k_nb_template(DevTable T, DevRef R) {
     T.nb_tmpl[b] = d;
 }
 
+// NS stripes of 64 rows from `base`: all loads of the round are issued before any is used.  -> first site row or -1
+template <int NS>
+__device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uint32_t *__restrict__ mf, const uint32_t *__restrict__ mr,
+                                                    int64_t L, int64_t base, int64_t se, int k, int lane, int &f0rev) {
+    uint32_t fl[NS];
+    int ps[NS];
+    uint64_t wf[NS], wr[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int64_t r = base + u * 64 + lane;
+        const int64_t ra = r < se ? r : se - 1;
+        fl[u] = r < se ? (uint32_t)T.flags[ra] : (uint32_t)MC_F_MODEL_N;
+        ps[u] = T.pos[ra];
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int64_t p = ps[u] < L ? ps[u] : 0;
+        const int64_t w0 = p >> 5;
+        wf[u] = ((uint64_t)mf[w0 + 1] << 32) | mf[w0];
+        wr[u] = ((uint64_t)mr[w0 + 1] << 32) | mr[w0];
+    }
+    int64_t f0 = -1;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int rev = (fl[u] & MC_F_KMER_EQ) ? 0 : 1;
+        uint64_t w = (rev ? wr[u] : wf[u]) >> (ps[u] & 31);
+        w &= (1ull << k) - 1ull;
+        const bool c = !(fl[u] & MC_F_MODEL_N) && ps[u] < L && w != 0ull;
+        const unsigned long long mask = __ballot(c);
+        if (mask && f0 < 0) {
+            const int first = __builtin_ctzll(mask);
+            f0 = base + u * 64 + first;
+            f0rev = __shfl(rev, first);
+        }
+    }
+    return f0;
+}
+
+// (also zeroes the pass's counters: nothing in here uses them, every later kernel of the pass does.  hipMemsetAsync would
+// do too, but the runtime's fill ends with a system-scope release, and that release waits behind the PCIe writes of a
+// copy-out running on the other stream)
 __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
-                              int32_t *__restrict__ nb_lastidx) {
+                              int32_t *__restrict__ nb_lastidx, Counters *__restrict__ cnt) {
+    if (blockIdx.x == 0) {
+        unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
+        for (unsigned i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
+    }
     const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= T.n_nb) return;
@@ -295,39 +340,14 @@ __global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ q
                 mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
                 sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
             }
-            for (int64_t base = sb; base < se && f0 < 0; base += 256) {
-                // four stripes of 64 rows; all loads of the iteration are issued before any is used
-                uint32_t fl[4];
-                int ps[4];
-                uint64_t wf[4], wr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t r = base + u * 64 + lane;
-                    const int64_t ra = r < se ? r : se - 1;
-                    fl[u] = r < se ? (uint32_t)T.flags[ra] : (uint32_t)MC_F_MODEL_N;
-                    ps[u] = T.pos[ra];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t p = ps[u] < L ? ps[u] : 0;
-                    const int64_t w0 = p >> 5;
-                    wf[u] = ((uint64_t)mf[w0 + 1] << 32) | mf[w0];
-                    wr[u] = ((uint64_t)mr[w0 + 1] << 32) | mr[w0];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rev = (fl[u] & MC_F_KMER_EQ) ? 0 : 1;
-                    uint64_t w = (rev ? wr[u] : wf[u]) >> (ps[u] & 31);
-                    w &= (1ull << k) - 1ull;
-                    const bool c = !(fl[u] & MC_F_MODEL_N) && ps[u] < L && w != 0ull;
-                    const unsigned long long mask = __ballot(c);
-                    if (mask && f0 < 0) {
-                        const int first = __builtin_ctzll(mask);
-                        f0 = base + u * 64 + first;
-                        f0rev = __shfl(rev, first);
-                    }
-                }
-            }
+            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): two rounds of
+            // 256 rows find f0 for most blocks, after that rounds of 1024 rows -- a round costs two dependent loads whatever
+            // its width.
+            int64_t base = sb;
+            for (int round = 0; round < 2 && base < se && f0 < 0; ++round, base += 256)
+                f0 = first_site_round<4>(T, mf, mr, L, base, se, k, lane, f0rev);
+            for (; base < se && f0 < 0; base += 1024)
+                f0 = first_site_round<16>(T, mf, mr, L, base, se, k, lane, f0rev);
         }
     }
     if (lane == 0) {
@@ -2047,13 +2067,6 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     }
 }
 
-// (hipMemsetAsync would do, but the runtime's fill ends with a system-scope release, and that release waits behind the
-// PCIe writes of a copy-out running on the other stream: a plain kernel keeps the pass at agent scope)
-__global__ void k_zero_counters(Counters *cnt) {
-    unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
-    for (unsigned i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
-}
-
 // ===================================================================================================
 // host side
 // ===================================================================================================
@@ -2578,10 +2591,9 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
         hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R);
         c->tmpl_dirty = false;
     }
-    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, st, cnt);
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx);
+                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx, cnt);
     hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
                        K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt);
     hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, K.desc,
