@@ -391,3 +391,49 @@ def test_record_buffers_too_small_are_grown(monkeypatch):
                 H.assert_records_equal(rec, orc, 6)
         finally:
             dev.close()
+
+
+@pytest.mark.gpu
+def test_copy_outs_queued_back_to_back():
+    """bench.py's loop: the copy-out of pass i+1 is started (mc_wait_records_begin) before pass i is waited for, with a new
+    pass enqueued in between; every pass, with its own parameters, equals the oracle; begin() with nothing left is a no-op."""
+    from mcaller_amd import synth, extract_contexts as ec
+    from mcaller_amd.device import Device
+    codes = synth.genome(length=400000, seed=3)
+    ref = synth.SynthRef(codes, motif='GATC')
+    table, qual = synth.make_table(600000, seed=77, codes=codes, read_len=(1000, 9000))
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    params = [(6, 0, 0.0), (6, 1, 0.0), (6, 2, 8.0), (6, 0, 9.5), (6, 1, 7.0), (6, 0, 0.0), (6, 3, 0.0)]
+    want = []
+    for k, skip, q in params:
+        orc = H.oracle_records(table, ref.device_arrays(), qual, k, skip, q)
+        H.oracle_score(orc, table, qual, weights, soc, k)
+        want.append(orc)
+    dev = Device(0)
+    try:
+        dev.set_reference(ref.device_arrays())
+        dev.upload_table(table)
+        dev.set_read_quality(qual)
+        dev.set_mlp(weights, soc)
+        depth, got = 3, []
+        for i in range(depth):
+            dev.run_async(*params[i])
+        dev.wait_begin()
+        for i in range(depth, len(params)):
+            dev.wait_begin()                       # the pass behind the oldest one
+            dev.wait_begin()                       # and the one behind that (bench.py stops at two; three must work too)
+            dev.run_async(*params[i])
+            got.append(dev.wait())
+            H.assert_records_equal(got[-1], want[len(got) - 1], 6)
+        for _ in range(depth):
+            dev.wait_begin()
+            dev.wait_begin()
+            dev.wait_begin()
+            dev.wait_begin()                       # nothing left to start: no-op
+            got.append(dev.wait())
+            H.assert_records_equal(got[-1], want[len(got) - 1], 6)
+        assert len(got) == len(params) and want[0].n > 500 and want[0].n != want[2].n   # (the quality threshold drops reads)
+        with pytest.raises(Exception):
+            dev.wait()                             # no pass in flight
+    finally:
+        dev.close()
