@@ -39,8 +39,8 @@ def dist_setup(n_gpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)     # 60 ms of timed work: the pipeline's fill and drain (one pass) amortise
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--events', type=float, default=1e8, help='event rows per GPU')
     ap.add_argument('--motif', default='GATC')
     ap.add_argument('--no-cpu-baseline', action='store_true')

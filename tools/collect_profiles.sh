@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --no-pipeline --no-cpu-baseline > $out/bench_sync.json 2>> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats_bench.json 2>> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/stats_bench.json 2>> $out/bench.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > /dev/null 2>> $out/bench.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline > /dev/null 2>> $out/bench.err
 python3 tools/pmc_summary.py $out/fetch $out/write $out/pmc.json "python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline"
