@@ -76,6 +76,20 @@ def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_r
         from . import make_bed
         make_bed.aggregate_by_pos(tsv_output, bed['path'], bed['min_depth'], bed['mod_threshold'], None, False, False, False, None)
 
+    if bed and bed.get('vo') and not train and not training_tsv:
+        # --bed_vo: the per-read probability lists of make_bed.py --vo (:114-115) come from the rows just written -- the
+        # concatenated file IS the gather of the workers' call records; the columns before them must be the reduced ones
+        from . import make_bed
+        reduced = open(bed['path']).read().splitlines() if os.path.exists(bed['path']) else None
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):      # (make_bed.py prints the file name once per row, :153)
+            make_bed.aggregate_by_pos(tsv_output, bed['path'], bed['min_depth'], bed['mod_threshold'], None, False, True, False, None)
+        if reduced is not None:
+            verbose = [line.rsplit('\t', 1)[0] for line in open(bed['path']).read().splitlines()]
+            if verbose != reduced:
+                raise RuntimeError('the per-site reduction and the rows written disagree on the BED file')
+
     if train:
         print('Training...')
         from .train_model import train_classifier
@@ -109,6 +123,8 @@ def main(argv=None):
     parser.add_argument('--bed', action='store_true', required=False, default=False,
                         help='(mcaller_amd) also write <stem>.methylation.summary.bed from the per-site reduction of the calls '
                              '(device-side counts, ncclAllReduce over the GPUs): what make_bed.py -f <diffs> writes')
+    parser.add_argument('--bed_vo', action='store_true', required=False, default=False,
+                        help='(mcaller_amd) with --bed: append the per-read probabilities of every site, like make_bed.py --vo')
     parser.add_argument('--bed_min_depth', type=int, required=False, default=15, help='(mcaller_amd) make_bed -d for --bed')
     parser.add_argument('--bed_mod_threshold', type=float, required=False, default=0.5, help='(mcaller_amd) make_bed -t for --bed')
     args = parser.parse_args(argv)
@@ -148,7 +164,7 @@ def main(argv=None):
     distribute_threads(args.positions, args.motif, args.tsv, read2qual, args.reference, num_refs, base, mod, args.threads,
                        args.num_variables, args.train, modelfile, args.skip_thresh, args.qual_thresh, args.classifier,
                        args.training_tsv if args.training_tsv else None, args.plot_training, n_gpus=max(1, args.gpus),
-                       bed=dict(min_depth=args.bed_min_depth, mod_threshold=args.bed_mod_threshold) if args.bed else None)
+                       bed=dict(min_depth=args.bed_min_depth, mod_threshold=args.bed_mod_threshold, vo=args.bed_vo) if args.bed else None)
 
 
 if __name__ == '__main__':

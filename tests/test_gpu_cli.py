@@ -247,3 +247,15 @@ def test_cli_bed_from_the_per_site_reduction(tmp_path):
         make_bed.main(['-f', diffs, '-d', '3', '-t', '0.3'])
     want = open(bed_path).read()
     assert results[0][0] == want and results[1][0] == want and want.count('\n') > 5
+    # --bed_vo: the same file with make_bed.py --vo's probability lists (two workers)
+    os.remove(diffs)
+    os.environ['MCALLER_SHARD_DEVICES'] = '0,0'
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mCaller.main(common + ['--gpus', '2', '--bed_vo'])
+    finally:
+        del os.environ['MCALLER_SHARD_DEVICES']
+    got_vo = open(bed_path).read()
+    with contextlib.redirect_stdout(io.StringIO()):
+        make_bed.main(['-f', diffs, '-d', '3', '-t', '0.3', '--vo'])
+    assert got_vo == open(bed_path).read() and got_vo != want and got_vo.count('\n') == want.count('\n')
