@@ -44,7 +44,7 @@ def main():
     ap.add_argument('--events', type=float, default=1e8, help='event rows per GPU')
     ap.add_argument('--motif', default='GATC')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-pipeline', action='store_true', help='one pass at a time (mc_extract_features) instead of two in flight')
+    ap.add_argument('--no-pipeline', action='store_true', help='one pass at a time (mc_extract_features) instead of the pipelined passes')
     ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
     args = ap.parse_args()
 
@@ -73,8 +73,9 @@ def main():
 
     # A step = one pass of the hot path over the resident table, records (slot means, sites, probabilities) landing in
     # pinned host memory.  Passes are pipelined (the library's streaming interface, mc_extract_features_async /
-    # mc_wait_records): strand resolve, scan, classifier and copy-out of consecutive passes overlap on four streams,
-    # four passes in flight at most; every pass's records are complete in host memory before the timed region ends.
+    # mc_wait_records): K0 + K1 of consecutive passes back to back on one stream, K2 + packing on a side stream, copy-outs
+    # back to back on a third, four passes in flight at most; every pass's records are complete in host memory before the
+    # timed region ends.
     # --no-pipeline times mc_extract_features instead (one pass at a time, host sync inside).
     def step_sync():
         dev.run(6, 0, 0.0, tail_contig=-1, score=True)
@@ -212,7 +213,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
                                    'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
-                       'passes_in_flight': 1 if args.no_pipeline else 4,
+                       'passes_in_flight': 1 if args.no_pipeline else min(3, args.steps),
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
