@@ -63,7 +63,9 @@ def main():
     modelset = H.load_modelset('r95')
     _, weights, _, soc = submodel_setup(modelset, 'A')
 
-    dev = Device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)   # (one-GPU boxes: test the N>1 plumbing)
+    dev_index = 0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local      # (one-GPU boxes: test the N>1 plumbing)
+    numa_node = Device.bind_host_to_numa_node(dev_index) if world > 1 else None  # pinned buffers next to the rank's GPU
+    dev = Device(dev_index)
     dev.set_reference(ref.device_arrays())
     t_up = time.time()
     dev.upload_table(table)
@@ -217,7 +219,7 @@ def main():
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]},
-                       'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction,
+                       'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction, 'numa_node_rank0': numa_node,
                        # SURVEY.md §8(d)'s three timings, calls/s on one GPU: kernels only; H2D of the table + one pass +
                        # D2H of the records; file to file is measured by tools/file_to_file.py (profiles/r01_file_to_file.log)
                        'calls_per_s_kernels_only': n_calls / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),

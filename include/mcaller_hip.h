@@ -126,6 +126,10 @@ void mc_fastq_free(mc_fastq *f);
 /* ===== device context ===== */
 typedef struct mc_ctx mc_ctx;
 int mc_ctx_create(int device, mc_ctx **out);
+/* One process per GPU on a multi-socket host: binds the calling thread (and the threads it starts later) to the cores of the
+ * NUMA node the GPU is attached to, so that the pinned buffers of its contexts are allocated there.  Call before
+ * mc_ctx_create.  -> node, or -1 if the topology is unknown (nothing changed).  Not an error code. */
+int mc_bind_to_device_numa_node(int device);
 void mc_ctx_destroy(mc_ctx *ctx);
 int mc_ctx_set_reference(mc_ctx *ctx, const mc_ref_view *host_ref);          /* H2D, replaces :154-160 */
 int mc_ctx_upload_table(mc_ctx *ctx, const mc_table_view *host_table);        /* H2D of the columns     */

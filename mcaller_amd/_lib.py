@@ -110,6 +110,7 @@ def lib():
         L.mc_wait_records_begin.argtypes = [C.c_void_p]
         L.mc_last_times_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_ctx_sync.argtypes = [C.c_void_p]
+        L.mc_bind_to_device_numa_node.argtypes = [C.c_int]
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_forest_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_ctx_set_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8

@@ -27,8 +27,10 @@
 // seen before) is argued in DESIGN.md; every other block is classified irregular and handled by the
 // literal per-run kernel (k_literal) so results never depend on a CPU path.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -2214,6 +2216,42 @@ static int sync_pass_streams(mc_ctx *c);
 // for the other translation units of the library (mc_train.hip)
 int mc_internal_device(const mc_ctx *c) { return c->device; }
 hipStream_t mc_internal_stream(const mc_ctx *c) { return c->stream; }
+
+// Multi-GPU hosts: one process per GPU, and what a process copies out lands in ITS pinned memory.  Bound to the cores of the
+// NUMA node the GPU hangs off, the process allocates there (first touch) and the DMA writes do not cross the socket link.
+// -> the node (>= 0) when the calling thread was bound, -1 when the topology does not say (nothing changed).
+extern "C" int mc_bind_to_device_numa_node(int device) {
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return -1;
+    for (char *p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return -1;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    char list[4096] = "";
+    if (FILE *f = fopen(path, "r")) { if (!fgets(list, (int)sizeof(list), f)) list[0] = 0; fclose(f); }
+    cpu_set_t *set = CPU_ALLOC(8192);
+    if (!set) return -1;
+    const size_t bytes = CPU_ALLOC_SIZE(8192);
+    CPU_ZERO_S(bytes, set);
+    int n_cpus = 0;
+    for (char *p = list; *p;) {                       // "0-63,128-191"
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+        for (long cpu = a; cpu <= b && cpu < 8192; ++cpu) { CPU_SET_S((size_t)cpu, bytes, set); ++n_cpus; }
+        while (*p == ',' || *p == '\n' || *p == ' ') ++p;
+    }
+    int rc = -1;
+    if (n_cpus > 0 && sched_setaffinity(0, bytes, set) == 0) rc = node;
+    CPU_FREE(set);
+    return rc;
+}
 
 extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     *out = nullptr;

@@ -22,6 +22,11 @@ class Device(object):
         check(lib().mc_ctx_create(self.index, C.byref(self._ctx)))
         self._keep = {}
 
+    @staticmethod
+    def bind_host_to_numa_node(device):
+        """One process per GPU: bind this process to the cores next to `device` (-> NUMA node, or -1: unknown, unchanged)."""
+        return int(lib().mc_bind_to_device_numa_node(int(device)))
+
     def close(self):
         if self._ctx:
             lib().mc_ctx_destroy(self._ctx)

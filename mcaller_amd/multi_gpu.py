@@ -34,6 +34,8 @@ def _worker(conn, device, job):
     os.environ['MCALLER_DEVICE'] = str(device)
     try:
         from . import _lib
+        if job['world'] > 1:
+            _lib.lib().mc_bind_to_device_numa_node(int(device))     # parser threads and pinned buffers next to this worker's GPU
         from . import extract_contexts as ec
         from .model_io import load_model_file
         buf = io.StringIO()

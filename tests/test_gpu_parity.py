@@ -437,3 +437,24 @@ def test_copy_outs_queued_back_to_back():
             dev.wait()                             # no pass in flight
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+def test_bind_to_the_numa_node_of_the_gpu():
+    """mc_bind_to_device_numa_node: -1 (topology unknown, nothing changed) or the node, with the thread bound to its cores."""
+    from mcaller_amd.device import Device
+    before = os.sched_getaffinity(0)
+    try:
+        node = Device.bind_host_to_numa_node(0)
+        after = os.sched_getaffinity(0)
+        assert node >= -1 and len(after) >= 1
+        if node < 0:
+            assert after == before
+        else:
+            cpus = set()
+            for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+                lo, _, hi = part.partition('-')
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            assert after == cpus & set(range(os.cpu_count() or max(cpus) + 1)) or after <= cpus
+    finally:
+        os.sched_setaffinity(0, before)
