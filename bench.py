@@ -64,7 +64,7 @@ def main():
     _, weights, _, soc = submodel_setup(modelset, 'A')
 
     dev_index = 0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local      # (one-GPU boxes: test the N>1 plumbing)
-    numa_node = Device.bind_host_to_numa_node(dev_index) if world > 1 else None  # pinned buffers next to the rank's GPU
+    numa_node = Device.bind_host_to_numa_node(dev_index) if (world > 1 or os.environ.get('MCALLER_BENCH_BIND')) else None  # pinned buffers next to the rank's GPU
     dev = Device(dev_index)
     dev.set_reference(ref.device_arrays())
     t_up = time.time()
