@@ -311,7 +311,7 @@ __device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uin
 // (also zeroes the pass's counters: nothing in here uses them, every later kernel of the pass does.  hipMemsetAsync would
 // do too, but the runtime's fill ends with a system-scope release, and that release waits behind the PCIe writes of a
 // copy-out running on the other stream)
-__global__ void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
+__global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
                               int32_t *__restrict__ nb_lastidx, Counters *__restrict__ cnt) {
     if (blockIdx.x == 0) {
@@ -1331,6 +1331,28 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restri
             A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
         }
     }
+    // ---- lane 0 of the group: what the info word and the segment column need from the descriptor and the reference.  These
+    // are three dependent loads (descriptor -> sequence offset -> base / mask word); issued here they are in flight beside
+    // the (event, model) loads below instead of behind them ----
+    uint32_t ctx_bits = 0u;               // MC_I_EDGE, or context[k] in its place
+    int32_t seg_of = 0;
+    if (fast && s == 0) {
+        const NbDesc *dp = A.desc + P.nb;
+        const int64_t L = dp->contig_len;
+        const bool rev0 = P.flags & PF_REV;
+        seg_of = T.nb_seg_begin[P.nb];
+        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
+            ctx_bits = MC_I_EDGE;                // the 2k-1 context leaves the contig: Python slicing decides
+        } else {
+            // context[k], the character after the 'M', picks the sub-model (:197)
+            const uint32_t *bits = (rev0 ? A.R.mr : A.R.mf) + dp->mask_off;
+            const uint8_t *seq = A.R.seq + A.R.seq_off[dp->contig];
+            unsigned char ch;
+            if (!rev0) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
+            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
+            ctx_bits = ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+        }
+    }
     // ---- my slot's rows: bit j of ms <=> row r-j belongs to slot s ----
     const uint64_t c0 = P.code[0], c1 = P.code[1], c2 = P.code[2], c3 = P.code[3];
     uint64_t ms = (s & 1 ? c0 : ~c0) & (s & 2 ? c1 : ~c1) & (s & 4 ? c2 : ~c2) & ~c3;
@@ -1420,23 +1442,11 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restri
             uint32_t em = empties;
             if (!rev) em = (__brev(empties) >> 24) >> (8 - k);
             info |= em & MC_I_EMPTY_MASK;
-            // context[k], the character after the 'M', picks the sub-model (:197)
-            const NbDesc *dp = A.desc + P.nb;
-            const int64_t L = dp->contig_len;
-            if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
-                info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
-            } else {
-                const uint32_t *bits = (rev ? A.R.mr : A.R.mf) + dp->mask_off;
-                const uint8_t *seq = A.R.seq + A.R.seq_off[dp->contig];
-                unsigned char ch;
-                if (!rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-                else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-                info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-            }
+            info |= ctx_bits;
         }
         if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
         A.O.site_pos[q] = m;
-        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+        A.O.site_seg[q] = seg_of;
         A.O.close_row[q] = P.close_row;
         A.O.info[q] = info;
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
