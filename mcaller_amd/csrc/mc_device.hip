@@ -1373,60 +1373,45 @@ __global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restri
     if (s < k) {
         double f = 0.0;
         if (!too_many && n > 0) {
-            double acc;
-            if (n < 8) {
-                // up to four rows fetched together (the usual case: ~2 events per position), the rest one by one
-                uint64_t mm = ms;
-                const int nr = n - (has_stray ? 1 : 0);
-                int2 e[4];
+            // The slot's values in order (the stray event first, then the rows from the oldest to the newest), eight at a time:
+            // all loads of a batch are issued before any value is used, so a slot costs one memory round trip per eight
+            // events -- the wave waits for its slowest lane, and with one load per loop iteration a single long slot
+            // among the 48 made the whole wave walk it event by event.
+            //   n < 8: NumPy adds sequentially, starting from -0.0.
+            //   n >= 8: eight strided accumulators over the first n - n%8 values (value i goes to accumulator i%8 = its
+            //   place in the batch), combined pairwise, then the tail in order.
+            const int n8 = n >= 8 ? n - (n % 8) : 0;
+            double acc = -0.0;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
+            uint64_t mm = ms;
+            bool stray_next = has_stray;
+            for (int base = 0; base < n; base += 8) {
+                int2 e[8];
+                bool is_stray[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int j = 0;
-                    if (mm) { j = 63 - __clzll(mm); mm &= ~(1ull << j); }
-                    e[i] = T.evmu[r - j];
-                }
-                acc = -0.0;
-                if (has_stray) acc += stray_val;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nr) acc += (double)(e[i].x - e[i].y) / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
-                while (mm) {
-                    const int j = 63 - __clzll(mm);
-                    mm &= ~(1ull << j);
-                    const int2 em = T.evmu[r - j];
-                    acc += (double)(em.x - em.y) / 10000.0;
-                }
-            } else {
-                // 8..65 values: NumPy's eight strided accumulators over the first n - n%8, then the tail in order
-                const int n8 = n - (n % 8);
-                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
-                acc = -0.0;
-                uint64_t mm = ms;
-                bool stray_next = has_stray;
-                for (int i = 0; i < n; ++i) {
-                    double v;
-                    if (stray_next) { v = stray_val; stray_next = false; }
-                    else {
-                        const int j = 63 - __clzll(mm);
-                        mm &= ~(1ull << j);
-                        const int2 em = T.evmu[r - j];
-                        v = (double)(em.x - em.y) / 10000.0;
-                    }
-                    if (i < n8) {
-                        switch (i & 7) {
-                            case 0: r0 += v; break;
-                            case 1: r1 += v; break;
-                            case 2: r2 += v; break;
-                            case 3: r3 += v; break;
-                            case 4: r4 += v; break;
-                            case 5: r5 += v; break;
-                            case 6: r6 += v; break;
-                            default: r7 += v; break;
+                for (int p = 0; p < 8; ++p) {
+                    is_stray[p] = false;
+                    e[p] = make_int2(0, 0);
+                    if (base + p < n) {
+                        if (stray_next) { stray_next = false; is_stray[p] = true; }
+                        else {
+                            const int j = 63 - __clzll(mm);
+                            mm &= ~(1ull << j);
+                            e[p] = T.evmu[r - j];
                         }
-                        if (i == n8 - 1) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                    } else {
-                        acc += v;
                     }
+                }
+                double v[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    v[p] = is_stray[p] ? stray_val : (double)(e[p].x - e[p].y) / 10000.0;   // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+                if (base + 8 <= n8) {
+                    r0 += v[0]; r1 += v[1]; r2 += v[2]; r3 += v[3]; r4 += v[4]; r5 += v[5]; r6 += v[6]; r7 += v[7];
+                    if (base + 8 == n8) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+                        if (base + p < n) acc += v[p];
                 }
             }
             f = (0.0 + acc) / (double)n;
