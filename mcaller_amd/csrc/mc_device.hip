@@ -1289,7 +1289,9 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
     emit_record(A, S, d, P.nb, P.r, P.m, q);
 }
 
-__global__ __launch_bounds__(256) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
+// (five waves per SIMD: the register allocator fits 94 VGPRs without scratch; left alone it takes 99 = four waves, and
+// six waves spill.  The kernel's time is rounds x latency, so resident waves count: 66 -> 60 us for list + emit.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
