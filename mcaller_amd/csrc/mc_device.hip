@@ -1289,6 +1289,15 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
     emit_record(A, S, d, P.nb, P.r, P.m, q);
 }
 
+// np.round(e - m, 4) == fl((E4 - M4) / 1e4) (:286) without the division: for EVERY int32 x the reciprocal-and-correct
+// sequence below equals the IEEE quotient x / 10000.0 bit for bit (tests/tools/div1e4_check.c goes through all 2^32) --
+// three fp64 operations instead of the ten of a division, eight times per slot and round in k1_emit.
+__device__ __forceinline__ double div1e4(int x) {
+    const double xd = (double)x, r = 1.0 / 10000.0;
+    const double q0 = xd * r;
+    return fma(fma(-q0, 10000.0, xd), r, q0);
+}
+
 // (five waves per SIMD: the register allocator fits 94 VGPRs without scratch; left alone it takes 99 = four waves, and
 // six waves spill.  The kernel's time is rounds x latency, so resident waves count: 66 -> 60 us for list + emit.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
@@ -1406,7 +1415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 double v[8];
 #pragma unroll
                 for (int p = 0; p < 8; ++p)
-                    v[p] = is_stray[p] ? stray_val : (double)(e[p].x - e[p].y) / 10000.0;   // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+                    v[p] = is_stray[p] ? stray_val : div1e4(e[p].x - e[p].y);
                 if (base + 8 <= n8) {
                     r0 += v[0]; r1 += v[1]; r2 += v[2]; r3 += v[3]; r4 += v[4]; r5 += v[5]; r6 += v[6]; r7 += v[7];
                     if (base + 8 == n8) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));

@@ -1,5 +1,8 @@
 """NumPy semantics the path depends on, restated in the oracle and in the host formatter."""
+import os
 import random
+
+import pytest
 
 import numpy as np
 
@@ -61,3 +64,16 @@ def test_native_repr_matches_python():
     for _ in range(5000):
         p = rng.random()
         assert repr_double(float(np.round(np.float64(p), 2))) == str(np.round(np.float64(p), 2))
+
+
+def test_division_by_1e4_without_dividing(tmp_path):
+    """k1_emit's div1e4() (reciprocal, two fma) is the IEEE quotient for every int32: proof by exhaustion, in C."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'div1e4_check.c')
+    exe = str(tmp_path / 'div1e4_check')
+    subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-mfma', '-o', exe, src, '-lm', '-lpthread'])
+    out = subprocess.check_output([exe], timeout=600).decode()
+    assert 'mismatches over all int32: 0' in out, out
