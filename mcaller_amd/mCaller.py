@@ -98,42 +98,61 @@ def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_r
         print('Finished training')
 
 
-def main(argv=None):
+# The reference's command line (mCaller.py:122-141), flag for flag and help text for help text, as data; then this build's
+# own options.  (flags, keyword arguments of add_argument)
+_SITE_CHOICE = (
+    (('-p', '--positions'), dict(type=str, help='file with a list of positions at which to classify bases (must be formatted as '
+                                                'space- or tab-separated file with chromosome, position, strand, and label if training)')),
+    (('-m', '--motif'), dict(type=str, help='classify every base of type --base in the motif specified instead (can be single one-mer)')),
+)
+_REFERENCE_FLAGS = (
+    (('-r', '--reference'), dict(type=str, required=True, help='fasta file with reference aligned to')),
+    (('-e', '--tsv'), dict(type=str, required=True, help='tsv file with nanopolish event alignment')),
+    (('-f', '--fastq'), dict(type=str, required=True, help='fastq file with nanopore reads')),
+    (('-t', '--threads'), dict(type=int, default=1, help='specify number of processes (default = 1)')),
+    (('-b', '--base'), dict(type=str, default='A', help='bases to classify as methylated or unmethylated (A or C, default A)')),
+    (('-n', '--num_variables'), dict(type=int, default=6, help='change the length of the context used to classify (default of 6 '
+                                                               'variables corresponds to 11-mer context (6*2-1))')),
+    (('--train',), dict(action='store_true', default=False, help='train a new model (requires labels in positions file)')),
+    (('--training_tsv',), dict(type=str, help='mCaller output file for training')),
+    (('-d', '--modelfile'), dict(type=str, help='model file name')),
+    (('-s', '--skip_thresh'), dict(type=int, default=0, help='number of skips to allow within an observation (default 0)')),
+    (('-q', '--qual_thresh'), dict(type=float, default=0, help='quality threshold for reads (default none)')),
+    (('-c', '--classifier'), dict(type=str, default='NN', help='use alternative classifier: options = NN (default), RF, LR, or NBC '
+                                                               '(non-default may significantly increase runtime)')),
+    (('--plot_training',), dict(action='store_true', default=False, help='plot probabilities distributions for training positions '
+                                                                         '(requires labels in positions file and --train)')),
+    (('-v', '--version'), dict(action='version', version='%(prog)s v1.0', help='print version')),
+)
+_OWN_FLAGS = (
+    (('--gpus',), dict(type=int, default=None, help='(mcaller_amd) GPUs of this node to shard the reads over (default 1, or $MCALLER_GPUS)')),
+    (('--bed',), dict(action='store_true', default=False,
+                      help='(mcaller_amd) also write <stem>.methylation.summary.bed from the per-site reduction of the calls '
+                           '(device-side counts, ncclAllReduce over the GPUs): what make_bed.py -f <diffs> writes')),
+    (('--bed_vo',), dict(action='store_true', default=False,
+                         help='(mcaller_amd) with --bed: append the per-read probabilities of every site, like make_bed.py --vo')),
+    (('--bed_min_depth',), dict(type=int, default=15, help='(mcaller_amd) make_bed -d for --bed')),
+    (('--bed_mod_threshold',), dict(type=float, default=0.5, help='(mcaller_amd) make_bed -t for --bed')),
+)
+
+
+def build_parser():
     from argparse import ArgumentParser
     parser = ArgumentParser(description='Classify bases as methylated or unmethylated', prog='mCaller')
-    all_or_some = parser.add_mutually_exclusive_group(required=True)
-    all_or_some.add_argument('-p', '--positions', type=str, required=False, help='file with a list of positions at which to classify bases (must be formatted as space- or tab-separated file with chromosome, position, strand, and label if training)')
-    all_or_some.add_argument('-m', '--motif', type=str, required=False, help='classify every base of type --base in the motif specified instead (can be single one-mer)')
-    parser.add_argument('-r', '--reference', type=str, required=True, help='fasta file with reference aligned to')
-    parser.add_argument('-e', '--tsv', type=str, required=True, help='tsv file with nanopolish event alignment')
-    parser.add_argument('-f', '--fastq', type=str, required=True, help='fastq file with nanopore reads')
-    parser.add_argument('-t', '--threads', type=int, required=False, help='specify number of processes (default = 1)', default=1)
-    parser.add_argument('-b', '--base', type=str, required=False, help='bases to classify as methylated or unmethylated (A or C, default A)', default='A')
-    parser.add_argument('-n', '--num_variables', type=int, required=False, help='change the length of the context used to classify (default of 6 variables corresponds to 11-mer context (6*2-1))', default=6)
-    parser.add_argument('--train', action='store_true', required=False, help='train a new model (requires labels in positions file)', default=False)
-    parser.add_argument('--training_tsv', type=str, required=False, help='mCaller output file for training')
-    parser.add_argument('-d', '--modelfile', type=str, required=False, help='model file name')
-    parser.add_argument('-s', '--skip_thresh', type=int, required=False, help='number of skips to allow within an observation (default 0)', default=0)
-    parser.add_argument('-q', '--qual_thresh', type=float, required=False, help='quality threshold for reads (default none)', default=0)
-    parser.add_argument('-c', '--classifier', type=str, required=False, help='use alternative classifier: options = NN (default), RF, LR, or NBC (non-default may significantly increase runtime)', default='NN')
-    parser.add_argument('--plot_training', action='store_true', required=False, help='plot probabilities distributions for training positions (requires labels in positions file and --train)', default=False)
-    parser.add_argument('-v', '--version', action='version', help='print version', version='%(prog)s v1.0')
-    parser.add_argument('--gpus', type=int, required=False, default=int(os.environ.get('MCALLER_GPUS', '1')),
-                        help='(mcaller_amd) GPUs of this node to shard the reads over (default 1, or $MCALLER_GPUS)')
-    parser.add_argument('--bed', action='store_true', required=False, default=False,
-                        help='(mcaller_amd) also write <stem>.methylation.summary.bed from the per-site reduction of the calls '
-                             '(device-side counts, ncclAllReduce over the GPUs): what make_bed.py -f <diffs> writes')
-    parser.add_argument('--bed_vo', action='store_true', required=False, default=False,
-                        help='(mcaller_amd) with --bed: append the per-read probabilities of every site, like make_bed.py --vo')
-    parser.add_argument('--bed_min_depth', type=int, required=False, default=15, help='(mcaller_amd) make_bed -d for --bed')
-    parser.add_argument('--bed_mod_threshold', type=float, required=False, default=0.5, help='(mcaller_amd) make_bed -t for --bed')
-    args = parser.parse_args(argv)
+    one_of = parser.add_mutually_exclusive_group(required=True)
+    for flags, kw in _SITE_CHOICE:
+        one_of.add_argument(*flags, **kw)
+    for flags, kw in _REFERENCE_FLAGS + _OWN_FLAGS:
+        parser.add_argument(*flags, **kw)
+    return parser
 
-    if args.base == 'A':
-        mod = 'm6A'
-    elif args.base == 'C':
-        mod = 'm5C'
-    else:
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.gpus is None:
+        args.gpus = int(os.environ.get('MCALLER_GPUS', '1'))
+    mod = {'A': 'm6A', 'C': 'm5C'}.get(args.base)                     # mCaller.py:144-150
+    if mod is None:
         print('classification only available for A or C bases so far')
         sys.exit(0)
 
