@@ -186,6 +186,12 @@ int mc_wait_records_begin(mc_ctx *ctx);
  * [0] strand resolve (K0), [1] window scan (k1_scan), [2] window emit (k1_group_scan + k1_list + k1_emit),
  * [3] classifier (K2), [4] total. */
 int mc_last_times_ms(mc_ctx *ctx, float *out5);
+/* Pipelined passes: the two hipEvents that only TIME a pass (start of K0, start of the scan) are recorded with every n-th
+ * pass (default 1 = every pass, 0 = never).  An event between two kernels costs the queue about 9 us on this GPU, 6 % of a
+ * pass of the headline workload.  mc_last_pass_timed: 1 if the pass mc_wait_records handed out last carried them, i.e.
+ * mc_last_times_ms is about that pass; for an untimed pass mc_last_times_ms keeps the values of the last timed one. */
+int mc_ctx_set_pass_timing(mc_ctx *ctx, int every_n);
+int mc_last_pass_timed(mc_ctx *ctx);
 int mc_ctx_sync(mc_ctx *ctx);
 
 /* Batched classifier alone (B2, extract_contexts.py:199): X[n*n_in] -> p[n]; host buffers. */

@@ -110,6 +110,8 @@ def lib():
         L.mc_wait_records_begin.argtypes = [C.c_void_p]
         L.mc_last_times_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.mc_ctx_sync.argtypes = [C.c_void_p]
+        L.mc_ctx_set_pass_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mc_last_pass_timed.argtypes = [C.c_void_p]
         L.mc_bind_to_device_numa_node.argtypes = [C.c_int]
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_forest_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]

@@ -2145,11 +2145,14 @@ struct mc_ctx {
         mc_params prm;
         int64_t cap = 0, n_nb = 0, n_tiles = 0;
         int k = 0;
-        bool used = false, copying = false;
+        bool used = false, copying = false, timed = true;
         std::vector<void *> dev_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
     hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
     int ab_head = 0, ab_tail = 0, ab_count = 0;
+    int timing_every = 1;          // pipelined passes: the two timing events go with every n-th pass (mc_ctx_set_pass_timing)
+    long long pass_seq = 0;
+    int last_timed = 1;            // whether the pass handed out last carried them
     // per-site reduction (mc_site_*): counts on the device, RCCL communicator
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
     int64_t *site_first = nullptr;    // [n_sites]
@@ -2938,9 +2941,12 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // streams: time-sliced, 40 % slower.
     hipStream_t st = c->stream;
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventRecord(b.ev_k0_start, st));
+    // (a hipEventRecord between two kernels costs this queue ~9 us -- rocprofv3 timeline -- so the two events that only time
+    // the pass, unlike ev_emit_end, which the side stream waits for, can be thinned out: mc_ctx_set_pass_timing)
+    b.timed = c->timing_every > 0 && (c->pass_seq++ % c->timing_every) == 0;
+    if (b.timed) HIP_TRY(hipEventRecord(b.ev_k0_start, st));
     if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st)) return rc;
-    HIP_TRY(hipEventRecord(b.ev_scan_start, st));
+    if (b.timed) HIP_TRY(hipEventRecord(b.ev_scan_start, st));
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
@@ -3027,11 +3033,13 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
         int64_t n = 0;
         if (int rc = mc_extract_features(c, &b.prm, &n)) return rc;
+        c->last_timed = 1;         // (mc_extract_features times every pass)
         *n_records = n;
         return mc_fetch_records_view(c, out);
     }
     const int64_t n = (int64_t)st.n_records;
-    if (b.used) {
+    c->last_timed = (b.used && b.timed) ? 1 : 0;
+    if (b.used && b.timed) {
         float t_k0 = 0, t_scan = 0, t_emit = 0, t_k2 = 0;
         HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_scan_start));
         HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_emit_end));     // scan + ordering + emit, one span
@@ -3051,6 +3059,14 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
     return 0;
 }
+
+extern "C" int mc_ctx_set_pass_timing(mc_ctx *c, int every_n) {
+    if (every_n < 0) { mc_set_error("mc_ctx_set_pass_timing: every_n < 0"); return -12; }
+    c->timing_every = every_n;
+    return 0;
+}
+
+extern "C" int mc_last_pass_timed(mc_ctx *c) { return c->last_timed; }
 
 extern "C" int mc_last_times_ms(mc_ctx *c, float *out5) {
     for (int i = 0; i < 5; ++i) out5[i] = c->times[i];

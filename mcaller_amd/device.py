@@ -143,6 +143,13 @@ class Device(object):
         """hipDeviceSynchronize on this context's device (all of its streams)."""
         check(lib().mc_ctx_sync(self._ctx))
 
+    def set_pass_timing(self, every_n):
+        """Pipelined passes: record the timing events with every n-th pass only (each costs the queue ~9 us); 0 = never."""
+        check(lib().mc_ctx_set_pass_timing(self._ctx, int(every_n)))
+
+    def last_pass_timed(self):
+        return bool(lib().mc_last_pass_timed(self._ctx))
+
     def times_ms(self):
         t = np.zeros(5, dtype=np.float32)
         check(lib().mc_last_times_ms(self._ctx, _ptr(t)))

@@ -458,3 +458,40 @@ def test_bind_to_the_numa_node_of_the_gpu():
             assert after == cpus & set(range(os.cpu_count() or max(cpus) + 1)) or after <= cpus
     finally:
         os.sched_setaffinity(0, before)
+
+
+@pytest.mark.gpu
+def test_pass_timing_interval():
+    """mc_ctx_set_pass_timing: the timing events go with every n-th pipelined pass; the records do not depend on it."""
+    from mcaller_amd import synth, extract_contexts as ec
+    from mcaller_amd.device import Device
+    codes = synth.genome(length=300000, seed=4)
+    ref = synth.SynthRef(codes, motif='GATC')
+    table, qual = synth.make_table(400000, seed=78, codes=codes, read_len=(1000, 9000))
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    dev = Device(0)
+    try:
+        dev.set_reference(ref.device_arrays())
+        dev.upload_table(table)
+        dev.set_read_quality(qual)
+        dev.set_mlp(weights, soc)
+        for every, want in ((3, [True, False, False, True, False, False]), (0, [False] * 3), (1, [True] * 3)):
+            dev.set_pass_timing(every)
+            seen = []
+            for _ in want:
+                dev.run_async(6, 0, 0.0)
+                rec = dev.wait()
+                seen.append(dev.last_pass_timed())
+                H.assert_records_equal(rec, orc, 6)
+                tm = dev.times_ms()
+                assert tm['total'] >= 0.0
+            if every == 3:                      # the count runs over all passes of the context: any rotation of the pattern
+                assert sum(seen) == 2 and seen[:3] == seen[3:]
+            else:
+                assert seen == want
+        with pytest.raises(Exception):
+            dev.set_pass_timing(-1)
+    finally:
+        dev.close()
