@@ -342,12 +342,11 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
                 mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
                 sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
             }
-            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): two rounds of
-            // 256 rows find f0 for most blocks, after that rounds of 1024 rows -- a round costs two dependent loads whatever
+            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): one round of
+            // 512 rows finds f0 for two blocks in three, after that rounds of 1024 rows -- a round costs two dependent loads whatever
             // its width.
             int64_t base = sb;
-            for (int round = 0; round < 2 && base < se && f0 < 0; ++round, base += 256)
-                f0 = first_site_round<4>(T, mf, mr, L, base, se, k, lane, f0rev);
+            if (base < se) { f0 = first_site_round<8>(T, mf, mr, L, base, se, k, lane, f0rev); base += 512; }
             for (; base < se && f0 < 0; base += 1024)
                 f0 = first_site_round<16>(T, mf, mr, L, base, se, k, lane, f0rev);
         }
