@@ -39,8 +39,8 @@ extern "C" {
 typedef struct mc_table_view {
     int64_t n_rows;
     const int32_t *pos;        /* col 2: 0-based k-mer start                                  :175 */
-    const int32_t *event_e4;   /* col 7: event_level_mean in units of 1e-4 pA                 :286 */
-    const int32_t *model_e4;   /* col 11: model_mean in units of 1e-4 pA                      :286 */
+    const int32_t *event_model_e4; /* [2*n_rows] per row: col 7 event_level_mean, col 11 model_mean, in units of 1e-4 pA,
+                                      interleaved -- the parser writes the pair, and a window's events are one DRAM page :286 */
     const int32_t *event_idx;  /* col 6                                                   :162,169 */
     const uint8_t *flags;      /* MC_F_*                                                           */
     int32_t n_seg;
@@ -89,6 +89,19 @@ typedef struct mc_calls_view {
 
 const char *mc_last_error(void);
 const char *mc_version(void);
+/* Cores this process may run on (sched_getaffinity) -- what the parser, the FASTQ reader and the row formatter size their
+ * thread counts by when n_threads <= 0: a worker bound to its GPU's NUMA node starts one thread per core of that node. */
+int mc_host_cores(void);
+
+/* ===== pinned host memory, recycled =====
+ * The DMA engines read a table at PCIe speed, beside running kernels, only from pinned memory.  Blocks handed back with
+ * mc_host_free are kept (up to keep_bytes of idle memory) and handed out again: pinning costs page-table work per page, a
+ * stream of shards allocates during its first two or three shards only.  With parser_uses_pool != 0 the columns of every
+ * table parsed from then on (mc_parse_eventalign*) live in such blocks.  Without a GPU the blocks are plain memory. */
+void *mc_host_alloc(int64_t bytes);
+void mc_host_free(void *p);
+int mc_host_is_pinned(const void *p);
+int mc_host_pool_config(int32_t parser_uses_pool, int64_t keep_bytes);   /* keep_bytes < 0: unchanged (default 8 GiB) */
 
 /* ===== native eventalign parser (host), replaces the line.split() ingest extract_contexts.py:140-152 ===== */
 typedef struct mc_parsed mc_parsed;
@@ -110,6 +123,7 @@ int mc_parsed_view(const mc_parsed *p, mc_table_view *out);
 const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id);
 int64_t mc_parsed_n_unknown(const mc_parsed *p);                 /* rows dropped for an unknown contig */
 const char *mc_parsed_unknown_name(const mc_parsed *p, int64_t i); /* contig text of the i-th such row */
+int32_t mc_parsed_n_pieces(const mc_parsed *p);                  /* pieces the range was cut into, one thread each */
 void mc_parsed_free(mc_parsed *p);
 
 /* ===== FASTQ read quality (replaces read_qual.py:6-19) =====
@@ -132,8 +146,25 @@ int mc_ctx_create(int device, mc_ctx **out);
 int mc_bind_to_device_numa_node(int device);
 void mc_ctx_destroy(mc_ctx *ctx);
 int mc_ctx_set_reference(mc_ctx *ctx, const mc_ref_view *host_ref);          /* H2D, replaces :154-160 */
-int mc_ctx_upload_table(mc_ctx *ctx, const mc_table_view *host_table);        /* H2D of the columns     */
+int mc_ctx_upload_table(mc_ctx *ctx, const mc_table_view *host_table);        /* H2D of the columns; returns when done */
 int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/* read2qual, :163-166   */
+
+/* ---- streaming distinct tables: a file as a sequence of shards (the reference's batch loop, :140-148) ----
+ * A ctx holds MC_TABLE_SLOTS resident tables.  mc_ctx_upload_table_async ENQUEUES the upload of a table into a free slot
+ * and makes it the current table (the one the passes enqueued afterwards scan): the columns travel on an upload stream of
+ * their own (DMA, beside the kernels of earlier passes; the source should be pinned: mc_host_alloc / a parser table with
+ * mc_host_pool_config(1, ..)), the per-table kernel (k_validate) follows on the ctx stream behind an event.  read_qual
+ * ([n_reads], read ids of THIS table; may be NULL: mc_ctx_set_read_quality applies) travels with the table.  No
+ * hipMalloc / hipFree happens per table once the slots are big enough: mc_ctx_reserve_tables sizes them (and the per-pass
+ * scratch and record sets) once for tables of up to max_rows rows, max_segs segments, max_reads reads; without it the
+ * first table that needs more re-allocates (synchronising).  The host buffers must stay untouched until
+ * mc_ctx_wait_upload(slot) returns.  A slot is free again when every pass that scanned its table has been handed out by
+ * mc_wait_records (and the next pass after it: the last records handed out may still be reduced by mc_site_counts); with
+ * no free slot the call fails (-12): wait for a pass first. */
+#define MC_TABLE_SLOTS 4
+int mc_ctx_reserve_tables(mc_ctx *ctx, int64_t max_rows, int32_t max_segs, int32_t max_reads);
+int mc_ctx_upload_table_async(mc_ctx *ctx, const mc_table_view *host_table, const double *read_qual, int32_t *slot);
+int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);
 /* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model;
  * submodel_of_char[256]: context[k] (ASCII) -> sub-model index, 255 = KeyError path (:197,:218). */
 int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden,

@@ -22,7 +22,7 @@ class McError(RuntimeError):
 
 class TableView(C.Structure):
     _fields_ = [('n_rows', C.c_int64),
-                ('pos', C.c_void_p), ('event_e4', C.c_void_p), ('model_e4', C.c_void_p),
+                ('pos', C.c_void_p), ('event_model_e4', C.c_void_p),
                 ('event_idx', C.c_void_p), ('flags', C.c_void_p),
                 ('n_seg', C.c_int32),
                 ('seg_row_begin', C.c_void_p), ('seg_read', C.c_void_p), ('seg_contig', C.c_void_p),
@@ -94,6 +94,16 @@ def lib():
         L.mc_parsed_unknown_name.restype = C.c_char_p
         L.mc_parsed_free.argtypes = [C.c_void_p]
         L.mc_parsed_free.restype = None
+        L.mc_parsed_n_pieces.argtypes = [C.c_void_p]
+        L.mc_host_alloc.argtypes = [C.c_int64]
+        L.mc_host_alloc.restype = C.c_void_p
+        L.mc_host_free.argtypes = [C.c_void_p]
+        L.mc_host_free.restype = None
+        L.mc_host_is_pinned.argtypes = [C.c_void_p]
+        L.mc_host_pool_config.argtypes = [C.c_int32, C.c_int64]
+        L.mc_ctx_reserve_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]
+        L.mc_ctx_upload_table_async.argtypes = [C.c_void_p, C.POINTER(TableView), C.c_void_p, C.POINTER(C.c_int32)]
+        L.mc_ctx_wait_upload.argtypes = [C.c_void_p, C.c_int32]
         L.mc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mc_ctx_destroy.argtypes = [C.c_void_p]
         L.mc_ctx_destroy.restype = None
@@ -150,14 +160,39 @@ def _from_ptr(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n)
 
 
+class PinnedArray(object):
+    """A numpy array over a block of the library's pinned host pool (mc_host_alloc); the block goes back to the pool
+    when the object dies."""
+
+    def __init__(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().mc_host_alloc(max(n, 1) + 64)
+        if not self.ptr:
+            raise MemoryError('mc_host_alloc(%d)' % n)
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mc_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class Table(object):
-    """Columnar event table on the host: numpy arrays + a TableView over them."""
+    """Columnar event table on the host: numpy arrays + a TableView over them.  The event and model currents are one
+    column of (event, model) pairs, `evmu` [n, 2]; `event_e4` / `model_e4` are its two halves (strided views)."""
 
     def __init__(self, pos, event_e4, model_e4, event_idx, flags, seg_row_begin, seg_read, seg_contig, n_reads,
-                 read_names=None, unknown=(), owner=None):
+                 read_names=None, unknown=(), owner=None, evmu=None):
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
-        self.event_e4 = np.ascontiguousarray(event_e4, dtype=np.int32)
-        self.model_e4 = np.ascontiguousarray(model_e4, dtype=np.int32)
+        if evmu is None:
+            evmu = np.empty((len(self.pos), 2), dtype=np.int32)
+            evmu[:, 0] = event_e4
+            evmu[:, 1] = model_e4
+        self.evmu = np.ascontiguousarray(evmu, dtype=np.int32).reshape(-1, 2)
         self.event_idx = np.ascontiguousarray(event_idx, dtype=np.int32)
         self.flags = np.ascontiguousarray(flags, dtype=np.uint8)
         self.seg_row_begin = np.ascontiguousarray(seg_row_begin, dtype=np.int64)
@@ -170,10 +205,32 @@ class Table(object):
         self.n_rows = len(self.pos)
         self.n_seg = len(self.seg_read)
 
+    @property
+    def event_e4(self):
+        return self.evmu[:, 0]
+
+    @property
+    def model_e4(self):
+        return self.evmu[:, 1]
+
+    def pinned(self):
+        """A copy whose columns sit in the pinned host pool (what mc_ctx_upload_table_async wants to read from)."""
+        keep = []
+
+        def pin(a):
+            h = PinnedArray(a.shape, a.dtype)
+            h.array[...] = a
+            keep.append(h)
+            return h.array
+        t = Table(pin(self.pos), None, None, pin(self.event_idx), pin(self.flags), self.seg_row_begin, self.seg_read,
+                  self.seg_contig, self.n_reads, read_names=self.read_names, unknown=self.unknown, evmu=pin(self.evmu))
+        t._owner = keep
+        return t
+
     def view(self):
         v = TableView()
         v.n_rows = self.n_rows
-        v.pos, v.event_e4, v.model_e4 = _ptr(self.pos), _ptr(self.event_e4), _ptr(self.model_e4)
+        v.pos, v.event_model_e4 = _ptr(self.pos), _ptr(self.evmu)
         v.event_idx, v.flags = _ptr(self.event_idx), _ptr(self.flags)
         v.n_seg = self.n_seg
         v.seg_row_begin, v.seg_read, v.seg_contig = _ptr(self.seg_row_begin), _ptr(self.seg_read), _ptr(self.seg_contig)
@@ -183,9 +240,10 @@ class Table(object):
     def slice_segments(self, s0, s1):
         """Sub-table of segments [s0, s1) (a shard); row indices restart at 0, read ids are kept."""
         r0, r1 = int(self.seg_row_begin[s0]), int(self.seg_row_begin[s1])
-        return Table(self.pos[r0:r1], self.event_e4[r0:r1], self.model_e4[r0:r1], self.event_idx[r0:r1],
+        return Table(self.pos[r0:r1], None, None, self.event_idx[r0:r1],
                      self.flags[r0:r1], self.seg_row_begin[s0:s1 + 1] - r0, self.seg_read[s0:s1],
-                     self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner)
+                     self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner,
+                     evmu=self.evmu[r0:r1])
 
 
 def fastq_read_quality(path, n_threads=0):
@@ -230,10 +288,13 @@ def parse_eventalign(path, startline, endline, contig_names, n_threads=0, exact_
     names = [L.mc_parsed_read_name(handle, i).decode('utf-8', 'surrogateescape') for i in range(v.n_reads)]
     unknown = [L.mc_parsed_unknown_name(handle, i).decode('utf-8', 'surrogateescape')
                for i in range(L.mc_parsed_n_unknown(handle))]
-    return Table(_from_ptr(v.pos, n, np.int32), _from_ptr(v.event_e4, n, np.int32), _from_ptr(v.model_e4, n, np.int32),
-                 _from_ptr(v.event_idx, n, np.int32), _from_ptr(v.flags, n, np.uint8),
-                 _from_ptr(v.seg_row_begin, ns + 1, np.int64), _from_ptr(v.seg_read, ns, np.int32),
-                 _from_ptr(v.seg_contig, ns, np.int32), v.n_reads, read_names=names, unknown=unknown, owner=owner)
+    t = Table(_from_ptr(v.pos, n, np.int32), None, None,
+              _from_ptr(v.event_idx, n, np.int32), _from_ptr(v.flags, n, np.uint8),
+              _from_ptr(v.seg_row_begin, ns + 1, np.int64), _from_ptr(v.seg_read, ns, np.int32),
+              _from_ptr(v.seg_contig, ns, np.int32), v.n_reads, read_names=names, unknown=unknown, owner=owner,
+              evmu=_from_ptr(v.event_model_e4, 2 * n, np.int32).reshape(-1, 2))
+    t.n_pieces = int(L.mc_parsed_n_pieces(handle))
+    return t
 
 
 class _Parsed(object):

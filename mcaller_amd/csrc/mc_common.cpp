@@ -1,8 +1,15 @@
-// Error text and version for libmcaller_hip.so (C ABI: include/mcaller_hip.h).
+// Error text, version, host core count and the pinned host buffer pool of libmcaller_hip.so (C ABI: include/mcaller_hip.h).
 #include "../../include/mcaller_hip.h"
 
+#include <hip/hip_runtime_api.h>
+#include <sched.h>
+
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[1024] = "";
 
@@ -14,4 +21,116 @@ void mc_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *mc_last_error(void) { return g_err; }
-extern "C" const char *mc_version(void) { return "mcaller_hip 0.1 (gfx950)"; }
+extern "C" const char *mc_version(void) { return "mcaller_hip 0.2 (gfx950)"; }
+
+// Cores this process may run on (sched_getaffinity), not the cores of the machine: a worker that bound itself to the NUMA
+// node of its GPU (mc_bind_to_device_numa_node), or a job inside a cpuset, starts that many parser / formatter threads.
+extern "C" int mc_host_cores(void) {
+    const int max_cpus = 8192;
+    cpu_set_t *set = CPU_ALLOC(max_cpus);
+    int n = 0;
+    if (set) {
+        const size_t bytes = CPU_ALLOC_SIZE(max_cpus);
+        CPU_ZERO_S(bytes, set);
+        if (sched_getaffinity(0, bytes, set) == 0) n = CPU_COUNT_S(bytes, set);
+        CPU_FREE(set);
+    }
+    if (n < 1) n = 1;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pinned host memory, recycled.  A table that is streamed to the GPU (mc_ctx_upload_table_async) has to sit in pinned
+// memory for the DMA engines to read it at PCIe speed and without a staging copy; pinning is expensive (page-table work
+// per 4 KB), so blocks are kept and handed out again: after the first two or three shards of a file no allocation happens.
+// Without a GPU (CPU-only test runs) the blocks are plain aligned memory.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Block {
+    void *p;
+    size_t bytes;
+    bool pinned, busy;
+};
+std::mutex g_pool_mu;
+std::vector<Block> g_pool;
+size_t g_keep_bytes = (size_t)8 << 30;
+int g_parser_uses_pool = 0;
+
+void release_block(Block &b) {
+    if (b.pinned) (void)hipHostFree(b.p);
+    else free(b.p);
+}
+}  // namespace
+
+int mc_parser_uses_pool() { return g_parser_uses_pool; }
+
+extern "C" void *mc_host_alloc(int64_t bytes_in) {
+    const size_t bytes = (size_t)std::max<int64_t>(bytes_in, 1);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_pool.size(); ++i) {
+            const Block &b = g_pool[i];
+            if (!b.busy && b.bytes >= bytes && (best < 0 || b.bytes < g_pool[(size_t)best].bytes)) best = (int)i;
+        }
+        if (best >= 0 && g_pool[(size_t)best].bytes <= 2 * bytes + ((size_t)4 << 20)) {
+            g_pool[(size_t)best].busy = true;
+            return g_pool[(size_t)best].p;
+        }
+    }
+    // a new block, with head room for the next table of about this size; 2 MB granules
+    size_t want = bytes + bytes / 8;
+    want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    Block nb{nullptr, want, true, true};
+    if (hipHostMalloc(&nb.p, want, hipHostMallocDefault) != hipSuccess || !nb.p) {
+        (void)hipGetLastError();
+        nb.pinned = false;
+        nb.p = aligned_alloc(4096, want);
+        if (!nb.p) return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(nb);
+    return nb.p;
+}
+
+extern "C" void mc_host_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t idle = 0;
+    int at = -1;
+    for (size_t i = 0; i < g_pool.size(); ++i) {
+        if (g_pool[i].p == p) at = (int)i;
+        else if (!g_pool[i].busy) idle += g_pool[i].bytes;
+    }
+    if (at < 0) return;                                  // not ours
+    Block &b = g_pool[(size_t)at];
+    b.busy = false;
+    if (idle + b.bytes > g_keep_bytes) {                 // more idle memory than we were told to keep: give it back
+        release_block(b);
+        g_pool.erase(g_pool.begin() + at);
+    }
+}
+
+extern "C" int mc_host_is_pinned(const void *p) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (const Block &b : g_pool)
+        if ((const char *)p >= (const char *)b.p && (const char *)p < (const char *)b.p + b.bytes) return b.pinned ? 1 : 0;
+    return 0;
+}
+
+extern "C" int mc_host_pool_config(int32_t parser_uses_pool, int64_t keep_bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_parser_uses_pool = parser_uses_pool ? 1 : 0;
+    if (keep_bytes >= 0) g_keep_bytes = (size_t)keep_bytes;
+    size_t idle = 0;
+    for (size_t i = 0; i < g_pool.size();) {
+        if (!g_pool[i].busy && idle + g_pool[i].bytes > g_keep_bytes) {
+            release_block(g_pool[i]);
+            g_pool.erase(g_pool.begin() + (long)i);
+            continue;
+        }
+        if (!g_pool[i].busy) idle += g_pool[i].bytes;
+        ++i;
+    }
+    return 0;
+}

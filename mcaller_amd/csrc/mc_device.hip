@@ -101,8 +101,8 @@ static_assert(sizeof(NbDesc) == 64, "NbDesc layout");
 
 struct DevTable {
     int64_t n_rows = 0;
-    int32_t *pos = nullptr, *ev = nullptr, *mu = nullptr, *idx = nullptr;
-    int2 *evmu = nullptr;     // (event, model) interleaved: one DRAM page per window for k1_emit
+    int32_t *pos = nullptr, *idx = nullptr;
+    int2 *evmu = nullptr;     // (event, model) pairs as the parser wrote them: one DRAM page per window for k1_emit
     uint8_t *flags = nullptr;
     int32_t n_seg = 0;
     int64_t *seg_begin = nullptr;
@@ -199,45 +199,122 @@ __device__ __forceinline__ unsigned char comp_char(unsigned char c) {
 // ---------------------------------------------------------------------------------------------------
 // upload-time kernels
 // ---------------------------------------------------------------------------------------------------
-// one wave per name block: monotonicity of positions / event indices over ALL rows of the block
-__global__ void k_validate(DevTable T) {
-    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= T.n_nb) return;
-    const int64_t rb = T.nb_row_begin[b], re = T.nb_row_begin[b + 1];
-    uint32_t f = 0;
-    for (int64_t r = rb + lane; r < re; r += 64) {
-        const int32_t p = T.pos[r];
-        if (p == 0) f |= V_POS0;
-        if (r > rb) {
-            const int32_t pp = T.pos[r - 1];
-            if (p < pp) f |= V_POS_DEC;
-            const int32_t i0 = T.idx[r - 1], i1 = T.idx[r];
-            f |= (i1 > i0) ? V_IDX_INC : (i1 < i0 ? V_IDX_DEC : V_IDX_EQ);
+// k_validate: per name block, are positions non-decreasing / event indices monotone over ALL its rows?  (What makes a
+// block "regular", see k0_classify.)  A flat stream over the position and event-index columns (8 B/row), one workgroup
+// per tile of the scan, every lane on consecutive 16-byte groups; the name-block starts inside the tile come from the
+// name-block table (one tile in eight has any), so the flag column is not read.  Each row is compared with the row before
+// it -- the neighbour lane's last row (one shuffle), the wave's first lane re-reads its predecessor -- and the flags are
+// OR-ed per name block: a tile that lies inside one block (the usual case) costs one atomic.  nb_vflags arrives zeroed
+// (V_MULTI_SEG preset) with the table's small arrays.
+constexpr int VT = 192;                 // threads per tile: 16 rows each
+constexpr int VQ = TILE / (VT * 4);     // 4-row groups per thread
+constexpr int VMAXNB = 64;              // name blocks of a tile whose flags are gathered in LDS (the rest: global atomics)
+static_assert(TILE % (VT * 4) == 0, "whole row groups per thread");
+
+__global__ __launch_bounds__(VT) void k_validate(DevTable T) {
+    __shared__ uint32_t s_start[TILE / 32];     // bit i: row t0+i starts a name block (i > 0)
+    __shared__ uint32_t s_pre[TILE / 32];       // name-block starts in the words before this one
+    __shared__ uint32_t s_vf[VMAXNB];
+    __shared__ uint32_t s_red[VT / 64];
+    const int64_t tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t t0 = tile * TILE;
+    const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
+    // ---- the columns: all loads go out first ----
+    int4 p4[VQ], i4[VQ];
+    int pp[VQ], ip[VQ];
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) {
+        const int i0 = (q * VT + tid) * 4;
+        p4[q] = make_int4(0, 0, 0, 0);
+        i4[q] = make_int4(0, 0, 0, 0);
+        pp[q] = ip[q] = 0;
+        if (i0 < nrows) {                       // (arrays are padded: whole groups stay in bounds)
+            p4[q] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+            i4[q] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0);
+            if (lane == 0 && t0 + i0 > 0) { pp[q] = T.pos[t0 + i0 - 1]; ip[q] = T.idx[t0 + i0 - 1]; }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
-    if (lane == 0) {
-        if (T.nb_seg_begin[b + 1] - T.nb_seg_begin[b] > 1) f |= V_MULTI_SEG;
-        T.nb_vflags[b] = f;
+    // ---- name-block starts inside the tile ----
+    const int nb0 = T.tile_nb[tile];
+    for (int i = tid; i < TILE / 32; i += VT) s_start[i] = 0u;
+    if (tid < VMAXNB) s_vf[tid] = 0u;
+    __syncthreads();
+    int n_in = 0;                               // blocks that start inside the tile (behind its first row)
+    for (int base = nb0 + 1;; base += VT) {
+        const int j = base + tid;
+        bool hit = false;
+        if (j < T.n_nb) {
+            const int64_t rb = T.nb_row_begin[j];
+            if (rb < t0 + nrows) {              // (rb > t0: nb0 is the last block that starts at or before t0)
+                hit = true;
+                atomicOr(&s_start[(int)(rb - t0) >> 5], 1u << ((int)(rb - t0) & 31));
+            }
+        }
+        const int c = __syncthreads_count(hit);
+        n_in += c;
+        if (c < VT) break;
     }
-}
-
-__global__ void k_tile_nb(DevTable T) {
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= T.n_tiles) return;
-    const int64_t row = t * TILE;
-    int lo = 0, hi = T.n_nb - 1;  // last block with row_begin <= row
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (T.nb_row_begin[mid] <= row) lo = mid; else hi = mid - 1;
+    if (n_in) {
+        if (tid < 64) {                         // prefix counts per word: one wave, two rounds of 64 words
+            uint32_t run = 0;
+            for (int w0 = 0; w0 < TILE / 32; w0 += 64) {
+                const int w = w0 + lane;
+                const uint32_t c = w < TILE / 32 ? __popc(s_start[w]) : 0u;
+                uint32_t incl = c;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                if (w < TILE / 32) s_pre[w] = run + incl - c;
+                run += __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
     }
-    T.tile_nb[t] = lo;
-}
-
-__global__ void k_interleave(DevTable T) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < T.n_rows) T.evmu[i] = make_int2(T.ev[i], T.mu[i]);
+    // ---- per row: compare with the row before it ----
+    uint32_t f_all = 0;
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) {
+        const int i0 = (q * VT + tid) * 4;
+        int prev_p = __shfl_up(p4[q].w, 1), prev_i = __shfl_up(i4[q].w, 1);
+        if (lane == 0) { prev_p = pp[q]; prev_i = ip[q]; }
+        const int ps[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w}, is[4] = {i4[q].x, i4[q].y, i4[q].z, i4[q].w};
+        uint32_t fg = 0;                        // flags of the group's rows that belong to the block of its first row
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            uint32_t f = 0;
+            bool start = (t0 + i == 0);
+            if (n_in) start = start || ((s_start[i >> 5] >> (i & 31)) & 1u);
+            if (i == 0 && t0 > 0) start = T.nb_row_begin[nb0] == t0;
+            if (i < nrows) {
+                if (ps[e] == 0) f |= V_POS0;
+                if (!start) {
+                    if (ps[e] < prev_p) f |= V_POS_DEC;
+                    f |= (is[e] > prev_i) ? V_IDX_INC : (is[e] < prev_i ? V_IDX_DEC : V_IDX_EQ);
+                }
+            }
+            prev_p = ps[e]; prev_i = is[e];
+            if (!n_in) fg |= f;
+            else if (f) {
+                const int bi = (int)(s_pre[i >> 5] + __popc(s_start[i >> 5] & ((2u << (i & 31)) - 1u)));   // starts in (t0, t0+i]
+                if (bi < VMAXNB) atomicOr(&s_vf[bi], f);
+                else atomicOr(&T.nb_vflags[nb0 + bi], f);
+            }
+        }
+        f_all |= fg;
+    }
+    if (!n_in) {                                // the whole tile is one name block: one atomic
+        for (int o = 32; o > 0; o >>= 1) f_all |= __shfl_xor(f_all, o);
+        if (lane == 0) s_red[tid >> 6] = f_all;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t f = 0;
+            for (int w = 0; w < VT / 64; ++w) f |= s_red[w];
+            if (f) atomicOr(&T.nb_vflags[nb0], f);
+        }
+    } else {
+        __syncthreads();
+        if (tid < VMAXNB && tid <= n_in && s_vf[tid]) atomicOr(&T.nb_vflags[nb0 + tid], s_vf[tid]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -421,7 +498,7 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
                 while (r1 < re && (T.flags[r1] & MC_F_MODEL_N)) ++r1;
                 d.first_delta = (int32_t)(f0 + 1 - d.row_begin);
                 d.rev = 1;
-                d.stray_d = T.ev[f0] - T.mu[f0];
+                { const int2 e0 = T.evmu[f0]; d.stray_d = e0.x - e0.y; }
                 d.extra_mpos = mpos_f;
                 if (r1 >= re) {
                     d.xflags |= 2;                          // closed by the next read (or lost at EOF)
@@ -462,7 +539,8 @@ constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events,
 constexpr int O_EXTRA = 14;              // meta nibble: the one-event '+' window of a palindromic f0 (R5)
 
 struct RowSrc {   // the columns, for window walks
-    const int32_t *g_pos, *g_ev, *g_mu;
+    const int32_t *g_pos;
+    const int2 *g_evmu;
     const uint8_t *g_flags;
     bool stray_pending;  // the next value handed out is the block's stray event (R5), not a row
     double stray_val;
@@ -477,8 +555,10 @@ __device__ __forceinline__ double next_val(RowSrc &S, int64_t &cur) {
     }
     for (;;) {
         const int64_t r = cur++;
-        if (!(S.g_flags[r] & MC_F_MODEL_N))
-            return (double)(S.g_ev[r] - S.g_mu[r]) / 10000.0;     // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+        if (!(S.g_flags[r] & MC_F_MODEL_N)) {
+            const int2 e = S.g_evmu[r];
+            return (double)(e.x - e.y) / 10000.0;                 // np.round(e-m,4) == fl((E4-M4)/1e4)  (:286)
+        }
     }
 }
 
@@ -545,8 +625,17 @@ struct K1Args {
     Counters *cnt;
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
-    int debug;                    // MCALLER_K1_DEBUG: cut k1_scan after a stage (timing experiments only)
+#ifdef MC_K1_EXPERIMENTS
+    int debug;                    // MCALLER_K1_DEBUG: cut k1_scan after a stage (timing experiments; results are WRONG)
+#endif
 };
+// Timing experiments of tools/k1_experiments.py exist in builds with -DMC_K1_EXPERIMENTS only: the shipped kernels carry
+// neither the branches nor the environment variable.
+#ifdef MC_K1_EXPERIMENTS
+#define K1X(n) (A.debug == (n))
+#else
+#define K1X(n) false
+#endif
 
 // One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
 __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
@@ -824,7 +913,7 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         s_bits[0][tid] = R.maskw[0];
         s_bits[1][tid] = R.maskw[1];
         if (tid < (int)(sizeof(TileDesc) / 4)) reinterpret_cast<uint32_t *>(&s_td[cur ^ 1])[tid] = R.tdw;
-        if (A.debug == 6) {            // (timing experiment: the columns are consumed from registers, never staged)
+        if (K1X(6)) {                  // (timing experiment: the columns are consumed from registers, never staged)
             int x = 0;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) x ^= R.p4[j].x ^ R.p4[j].y ^ R.p4[j].z ^ R.p4[j].w;
@@ -847,10 +936,10 @@ __global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
         const int nb0 = td.nb0;
         // ... and the next tile's loads go out now; they land while this tile is processed
         const int64_t tile_n = tile_ahead(1);
-        if (tile_n < T.n_tiles && A.debug != 4) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);   // (4: timing experiment, walk only)
+        if (tile_n < T.n_tiles && !K1X(4)) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);   // (4: timing experiment, walk only)
         PH(1);
 
-        if (wave == 0 && A.debug != 3 && A.debug != 6) {
+        if (wave == 0 && !K1X(3) && !K1X(6)) {
             // The walk works from LDS alone.  Whatever needs global memory (more name blocks than were staged, a closing
             // row beyond the tile, a window reaching back before it) is an out-of-line call -- see far_close().
             {
@@ -1284,7 +1373,7 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
     const int64_t q = rare_list[i];
     const Payload P = sorted[q];
     const NbDesc d = A.desc[P.nb];
-    RowSrc S{A.T.pos, A.T.ev, A.T.mu, A.T.flags, false, 0.0};
+    RowSrc S{A.T.pos, A.T.evmu, A.T.flags, false, 0.0};
     emit_record(A, S, d, P.nb, P.r, P.m, q);
 }
 
@@ -1326,7 +1415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         Pn.flags = PF_EXTRA;
         if (qn < n_rec) Pn = sorted[qn];
     }
-    const int64_t r = A.debug == 5 ? 40 + q * 8 : P.r;          // (timing experiment: sequential instead of scattered rows)
+    const int64_t r = K1X(5) ? 40 + q * 8 : P.r;                // (timing experiment: sequential instead of scattered rows)
     const int m = P.m;
     const bool fast = live && !(P.flags & (PF_EXTRA | PF_SLOW));
     if (live && !fast && s == 0) {
@@ -1500,7 +1589,7 @@ __device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j) {
         if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
     }
     const NbDesc d = A.desc[lo];
-    RowSrc S{T.pos, T.ev, T.mu, T.flags, false, 0.0};
+    RowSrc S{T.pos, T.evmu, T.flags, false, 0.0};
     // last row of the window: the last unfiltered row of the block before the closing row
     int64_t r = min(O.close_row[j], d.row_end) - 1;
     const int64_t lb = max(d.row_begin, d.first());
@@ -1544,7 +1633,7 @@ __global__ void k1_rare_dev(K1Args A, const Payload *__restrict__ sorted, const 
         const int64_t q = rare_list[i];
         const Payload P = sorted[q];
         const NbDesc d = A.desc[P.nb];
-        RowSrc S{A.T.pos, A.T.ev, A.T.mu, A.T.flags, false, 0.0};
+        RowSrc S{A.T.pos, A.T.evmu, A.T.flags, false, 0.0};
         emit_record(A, S, d, P.nb, P.r, P.m, q);
         bigfix_record(A, q);
     }
@@ -1769,7 +1858,7 @@ __global__ void k_literal(LitArgs A) {
                     last_read = name;
                     last_rev = rev;
                     last_seg = seg;
-                    if (A.write) slots[(size_t)sid[off] * cap + nslot[off]] = (double)(T.ev[r] - T.mu[r]) / 10000.0;
+                    if (A.write) { const int2 e = T.evmu[r]; slots[(size_t)sid[off] * cap + nslot[off]] = (double)(e.x - e.y) / 10000.0; }
                     nslot[off] += 1;
                 } else if (truthy()) {                                                   // :289-291
                     has_mpos = false;
@@ -2087,11 +2176,65 @@ struct K0Set {
     int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
 };
 
+// One resident table.  A ctx owns MC_TABLE_SLOTS of them so that a file can go through the GPU as a sequence of shards:
+// one being uploaded, one being scanned, the others waiting for their records to be handed out.  All device memory of a
+// slot is allocated once (mc_ctx_reserve_tables, or by the first table that needs more) -- an upload is DMA transfers and
+// two small kernels, no hipMalloc / hipFree.
+struct SmallLayout {       // byte offsets of a table's small arrays inside one block: the same on the pinned host stage and on the device
+    size_t seg_begin, seg_read, seg_contig, nb_row_begin, nb_seg_begin, nb_read, nb_repeat, nb_vflags, tile_nb, qual, total;
+};
+static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    SmallLayout L;
+    size_t o = 0;
+    L.seg_begin = o;    o = al(o + (size_t)(n_seg + 1) * 8);
+    L.seg_read = o;     o = al(o + (size_t)n_seg * 4);
+    L.seg_contig = o;   o = al(o + (size_t)n_seg * 4);
+    L.nb_row_begin = o; o = al(o + (size_t)(n_seg + 1) * 8);
+    L.nb_seg_begin = o; o = al(o + (size_t)(n_seg + 1) * 4);
+    L.nb_read = o;      o = al(o + (size_t)n_seg * 4);
+    L.nb_repeat = o;    o = al(o + (size_t)n_seg);
+    L.nb_vflags = o;    o = al(o + (size_t)(n_seg + 1) * 4);
+    L.tile_nb = o;      o = al(o + (size_t)(n_tiles + 1) * 4);
+    L.qual = o;         o = al(o + (size_t)n_reads * 8);
+    L.total = o;
+    return L;
+}
+
+struct TableSlot {
+    DevTable T;                        // the table in the slot (pointers into the slot's allocations)
+    int64_t cap_rows = 0, cap_segs = 0, cap_reads = 0;
+    int32_t *pos = nullptr, *idx = nullptr;
+    int2 *evmu = nullptr;
+    uint8_t *flags = nullptr;
+    NbDesc *nb_tmpl = nullptr;
+    unsigned char *small_dev = nullptr, *stage = nullptr;   // the small arrays: device block, pinned host stage
+    size_t small_cap = 0;
+    double *qual = nullptr;            // read qualities that travelled with the table (in small_dev), or nullptr
+    int32_t n_qual = 0;
+    hipEvent_t ev_uploaded = nullptr;  // the H2D transfers of the slot's table are done
+    int refs = 0;                      // passes in flight that scan this table
+    long long tmpl_ref = -1;           // reference version the name-block templates were built for (-1: not built)
+    std::vector<void *> allocs;
+};
+
 struct mc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
-    DevTable T;
+    DevTable T;                        // the current table: a copy of slots[cur].T
+    TableSlot slots[MC_TABLE_SLOTS];
+    int cur = -1;                      // slot of the current table
+    int held = -1;                     // slot of the pass handed out last (its records may still be reduced: mc_site_counts)
+    const int32_t *last_seg_contig = nullptr;   // ... and that table's segment -> contig column
+    bool in_rerun = false;             // mc_wait_records is re-running a pass synchronously
+    hipStream_t up_stream = nullptr;   // H2D of tables
+    int64_t res_rows = 0, res_segs = 0, res_reads = 0;     // mc_ctx_reserve_tables
+    long long ref_version = 0;
+    int64_t scratch_nb = 0, scratch_tiles = 0;             // what the per-pass scratch below is sized for
+    std::vector<void *> scratch_allocs;
+    double *qual_own = nullptr;        // mc_ctx_set_read_quality's buffer
+    int32_t n_qual_own = 0;
     DevRef R;
     DevMlp M;
     DevForest F;
@@ -2123,9 +2266,9 @@ struct mc_ctx {
     int last_k = 0;
     int64_t last_n = 0;
     int64_t ref_total_len = 0;    // bases of the marked reference (record capacity guess)
-    bool tmpl_dirty = true;       // name-block descriptor templates must be rebuilt (new table or reference)
     float times[5] = {0, 0, 0, 0, 0};
-    std::vector<void *> table_allocs, ref_allocs, mlp_allocs, rec_allocs;
+    std::vector<void *> ref_allocs, mlp_allocs, rec_allocs;
+    int64_t payload_tiles = 0;     // tiles the payload buffer was sized for
     // pipelined passes (mc_extract_features_async / mc_wait_records): two record sets, exported to pinned host memory
     struct AsyncBuf {
         DevRecords O;              // device records of the pass
@@ -2145,6 +2288,9 @@ struct mc_ctx {
         int64_t cap = 0, n_nb = 0, n_tiles = 0;
         int k = 0;
         bool used = false, copying = false, timed = true;
+        int slot = -1;             // table slot the pass scans
+        const double *qual = nullptr;   // read qualities it was enqueued with
+        int32_t n_qual = 0;
         std::vector<void *> dev_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
     hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
@@ -2220,6 +2366,7 @@ static int copy_out_features(mc_ctx *c, int64_t n, int k, hipStream_t st) {
 extern "C" int mc_comm_destroy(mc_ctx *c);
 static void free_async(mc_ctx *c);
 static int sync_pass_streams(mc_ctx *c);
+static void slot_free(TableSlot &S);
 
 // for the other translation units of the library (mc_train.hip)
 int mc_internal_device(const mc_ctx *c) { return c->device; }
@@ -2279,6 +2426,7 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -2299,14 +2447,18 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
 extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    free_pool(c->table_allocs);
+    (void)sync_pass_streams(c);
+    for (TableSlot &S : c->slots) {
+        slot_free(S);
+        if (S.ev_uploaded) (void)hipEventDestroy(S.ev_uploaded);
+    }
+    free_pool(c->scratch_allocs);
     free_pool(c->ref_allocs);
     free_pool(c->mlp_allocs);
     free_pool(c->forest_allocs);
     free_pool(c->rec_allocs);
     free_pool(c->lit_allocs);
-    if (c->qual) (void)hipFree(c->qual);
+    if (c->qual_own) (void)hipFree(c->qual_own);
     if (c->cnt) (void)hipFree(c->cnt);
     if (c->site_cnt) (void)hipFree(c->site_cnt);
     if (c->site_first) (void)hipFree(c->site_first);
@@ -2320,14 +2472,14 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     free_pinned(c->H);
     (void)hipStreamDestroy(c->copy_stream);
+    (void)hipStreamDestroy(c->up_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" int mc_ctx_sync(mc_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return sync_pass_streams(c);
 }
 
 #define UP(dst, src, n, pool)                                                                          \
@@ -2338,8 +2490,8 @@ extern "C" int mc_ctx_sync(mc_ctx *c) {
 
 extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->tmpl_dirty = true;
+    if (int rc = sync_pass_streams(c)) return rc;          // passes in flight read the old masks
+    c->ref_version += 1;                                   // the name-block templates of every slot are stale
     free_pool(c->ref_allocs);
     DevRef &R = c->R;
     R.n_contigs = h->n_contigs;
@@ -2380,93 +2532,219 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     return 0;
 }
 
-extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    free_pool(c->table_allocs);
-    DevTable &T = c->T;
-    T = DevTable();
-    T.n_rows = h->n_rows;
-    T.n_seg = h->n_seg;
-    T.n_reads = h->n_reads;
-    const int64_t n = h->n_rows;
-    const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
-    if (dev_alloc(c->table_allocs, &T.pos, (size_t)padded) || dev_alloc(c->table_allocs, &T.ev, (size_t)padded) ||
-        dev_alloc(c->table_allocs, &T.mu, (size_t)padded) || dev_alloc(c->table_allocs, &T.idx, (size_t)padded) ||
-        dev_alloc(c->table_allocs, &T.flags, (size_t)padded) || dev_alloc(c->table_allocs, &T.evmu, (size_t)padded))
-        return -10;
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(T.ev, h->event_e4, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(T.mu, h->model_e4, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(T.idx, h->event_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(T.flags, h->flags, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    }
-    UP(T.seg_begin, h->seg_row_begin, h->n_seg + 1, c->table_allocs);
-    UP(T.seg_read, h->seg_read, h->n_seg, c->table_allocs);
-    UP(T.seg_contig, h->seg_contig, h->n_seg, c->table_allocs);
+// ---- table slots ----
+static void slot_free(TableSlot &S) {
+    free_pool(S.allocs);
+    if (S.stage) (void)hipHostFree(S.stage);
+    S.stage = nullptr; S.small_dev = nullptr; S.small_cap = 0;
+    S.pos = S.idx = nullptr; S.evmu = nullptr; S.flags = nullptr; S.nb_tmpl = nullptr;
+    S.cap_rows = S.cap_segs = S.cap_reads = 0;
+    S.T = DevTable();
+    S.qual = nullptr; S.n_qual = 0; S.tmpl_ref = -1;
+}
 
-    // name blocks: maximal runs of segments with one read name (MC_F_NAME_START on the first row)
-    std::vector<int64_t> nb_row;
-    std::vector<int32_t> nb_seg, nb_read;
-    std::vector<uint8_t> nb_rep;
+// device memory + pinned stage of a slot for tables of up to (rows, segs, reads)
+static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int64_t reads) {
+    if (!S.ev_uploaded) HIP_TRY(hipEventCreateWithFlags(&S.ev_uploaded, hipEventDisableTiming));
+    if (S.pos && rows <= S.cap_rows && segs <= S.cap_segs && reads <= S.cap_reads) return 0;
+    // growing: whatever may still read the old arrays has to finish first (only ever happens without mc_ctx_reserve_tables)
+    if (int rc = sync_pass_streams(c)) return rc;
+    const bool fresh = !S.pos;
+    slot_free(S);
+    auto grow = [&](int64_t need, int64_t reserved) { return std::max<int64_t>(fresh ? need : need + need / 4, reserved); };
+    S.cap_rows = grow(rows, c->res_rows);
+    S.cap_segs = std::max<int64_t>(grow(segs, c->res_segs), 16);
+    S.cap_reads = std::max<int64_t>(grow(reads, c->res_reads), 16);
+    const int64_t padded = ((S.cap_rows + TILE - 1) / TILE) * TILE + TILE;
+    const SmallLayout L = small_layout(S.cap_segs, padded / TILE, S.cap_reads);
+    if (dev_alloc(S.allocs, &S.pos, (size_t)padded) || dev_alloc(S.allocs, &S.idx, (size_t)padded) ||
+        dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded) ||
+        dev_alloc(S.allocs, &S.nb_tmpl, (size_t)S.cap_segs + 1) || dev_alloc(S.allocs, &S.small_dev, L.total))
+        return -10;
+    HIP_TRY(hipHostMalloc((void **)&S.stage, L.total, hipHostMallocDefault));
+    S.small_cap = L.total;
+    return 0;
+}
+
+// the scratch all passes share (ordered by the ctx stream): tile descriptors / counts / chunks, strand-resolve output of
+// the synchronous pass
+static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
+    if (c->tiles && n_nb <= c->scratch_nb && n_tiles <= c->scratch_tiles) return 0;
+    if (int rc = sync_pass_streams(c)) return rc;
+    free_pool(c->scratch_allocs);
+    const int64_t res_tiles = c->res_rows ? (c->res_rows + TILE - 1) / TILE : 0;
+    const int64_t nb = std::max<int64_t>(std::max<int64_t>(n_nb, c->res_segs), c->scratch_nb);
+    const int64_t nt = std::max<int64_t>(std::max<int64_t>(n_tiles, res_tiles), c->scratch_tiles);
+    std::vector<void *> &P = c->scratch_allocs;
+    if (dev_alloc(P, &c->tiles, (size_t)nt + 1) || dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
+        dev_alloc(P, &c->nb_f0idx, (size_t)nb + 1) || dev_alloc(P, &c->nb_lastidx, (size_t)nb + 1) ||
+        dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * (TILE / 64)) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
+        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1))
+        return -10;
+    c->scratch_nb = nb;
+    c->scratch_tiles = nt;
+    return 0;
+}
+
+extern "C" int mc_ctx_reserve_tables(mc_ctx *c, int64_t max_rows, int32_t max_segs, int32_t max_reads) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (max_rows < 0 || max_segs < 0 || max_reads < 0) {
+        mc_set_error("mc_ctx_reserve_tables: negative size");
+        return -12;
+    }
+    c->res_rows = std::max(c->res_rows, max_rows);
+    c->res_segs = std::max<int64_t>(c->res_segs, max_segs);
+    c->res_reads = std::max<int64_t>(c->res_reads, max_reads);
+    for (TableSlot &S : c->slots)
+        if (int rc = slot_ensure(c, S, c->res_rows, c->res_segs, c->res_reads)) return rc;
+    return ensure_scratch(c, c->res_segs, (c->res_rows + TILE - 1) / TILE);
+}
+
+extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, const double *read_qual, int32_t *slot_out) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot_out) *slot_out = -1;
+    const int64_t n = h->n_rows;
+    if (n < 0 || h->n_seg < 0 || h->n_reads < 0 || (n > 0 && h->n_seg == 0)) {
+        mc_set_error("mc_ctx_upload_table_async: malformed table (%lld rows, %d segments, %d reads)", (long long)n, h->n_seg, h->n_reads);
+        return -12;
+    }
+    // ---- a free slot: not scanned by a pass in flight, not holding the records handed out last ----
+    int at = -1;
+    for (int i = 1; i <= MC_TABLE_SLOTS; ++i) {
+        const int sidx = (std::max(c->cur, 0) + i) % MC_TABLE_SLOTS;
+        if (c->slots[sidx].refs == 0 && sidx != c->held) { at = sidx; break; }
+    }
+    if (at < 0) {
+        mc_set_error("mc_ctx_upload_table_async: all %d table slots are being scanned; call mc_wait_records first", MC_TABLE_SLOTS);
+        return -12;
+    }
+    TableSlot &S = c->slots[at];
+    if (int rc = slot_ensure(c, S, n, h->n_seg, h->n_reads)) return rc;
+    HIP_TRY(hipEventSynchronize(S.ev_uploaded));          // the stage is about to be rewritten (long done: the slot was idle)
+
+    // ---- the small arrays, laid out in the pinned stage: segments, name blocks (maximal runs of segments with one read
+    //      name, MC_F_NAME_START on the first row), the name block of every tile's first row, read qualities ----
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    const SmallLayout L = small_layout(h->n_seg, n_tiles, read_qual ? h->n_reads : 0);
+    unsigned char *st = S.stage;
+    int64_t *seg_begin = (int64_t *)(st + L.seg_begin), *nb_row = (int64_t *)(st + L.nb_row_begin);
+    int32_t *seg_read = (int32_t *)(st + L.seg_read), *seg_contig = (int32_t *)(st + L.seg_contig);
+    int32_t *nb_seg = (int32_t *)(st + L.nb_seg_begin), *nb_read = (int32_t *)(st + L.nb_read), *tile_nb = (int32_t *)(st + L.tile_nb);
+    uint8_t *nb_rep = st + L.nb_repeat;
+    uint32_t *nb_vf = (uint32_t *)(st + L.nb_vflags);
+    if (h->n_seg > 0) {
+        memcpy(seg_begin, h->seg_row_begin, (size_t)(h->n_seg + 1) * 8);
+        memcpy(seg_read, h->seg_read, (size_t)h->n_seg * 4);
+        memcpy(seg_contig, h->seg_contig, (size_t)h->n_seg * 4);
+    } else seg_begin[0] = 0;
     std::vector<uint8_t> seen((size_t)std::max(h->n_reads, 1), 0);
     int has_rep = 0;
-    for (int32_t s = 0; s < h->n_seg; ++s) {
-        const int64_t rb = h->seg_row_begin[s];
-        if (s == 0 || (h->flags[rb] & MC_F_NAME_START)) {
-            nb_row.push_back(rb);
-            nb_seg.push_back(s);
-            const int32_t rd = h->seg_read[s];
+    int32_t n_nb = 0;
+    for (int32_t sg = 0; sg < h->n_seg; ++sg) {
+        const int64_t rb = h->seg_row_begin[sg];
+        if (rb < 0 || rb >= n || (sg > 0 && rb <= h->seg_row_begin[sg - 1])) {
+            mc_set_error("segment %d: row %lld out of order", sg, (long long)rb);
+            return -12;
+        }
+        if (sg == 0 || (h->flags[rb] & MC_F_NAME_START)) {
+            const int32_t rd = h->seg_read[sg];
             if (rd < 0 || rd >= h->n_reads) {
-                mc_set_error("segment %d: read id %d out of range", s, rd);
+                mc_set_error("segment %d: read id %d out of range", sg, rd);
                 return -12;
             }
-            nb_read.push_back(rd);
-            nb_rep.push_back(seen[(size_t)rd]);
+            nb_row[n_nb] = rb;
+            nb_seg[n_nb] = sg;
+            nb_read[n_nb] = rd;
+            nb_rep[n_nb] = seen[(size_t)rd];
             has_rep |= seen[(size_t)rd];
             seen[(size_t)rd] = 1;
+            if (n_nb > 0) nb_vf[n_nb - 1] = (sg - nb_seg[n_nb - 1] > 1) ? V_MULTI_SEG : 0u;
+            ++n_nb;
         }
     }
-    T.n_nb = (int32_t)nb_read.size();
-    nb_row.push_back(n);
-    nb_seg.push_back(h->n_seg);
-    T.has_repeats = has_rep;
-    UP(T.nb_row_begin, nb_row.data(), nb_row.size(), c->table_allocs);
-    UP(T.nb_seg_begin, nb_seg.data(), nb_seg.size(), c->table_allocs);
-    UP(T.nb_read, nb_read.data(), nb_read.size(), c->table_allocs);
-    UP(T.nb_repeat, nb_rep.data(), nb_rep.size(), c->table_allocs);
-    if (dev_alloc(c->table_allocs, &T.nb_vflags, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &T.nb_tmpl, (size_t)T.n_nb + 1)) return -10;
-    c->tmpl_dirty = true;
-    T.n_tiles = (n + TILE - 1) / TILE;
-    if (dev_alloc(c->table_allocs, &T.tile_nb, (size_t)T.n_tiles + 1)) return -10;
-    if (dev_alloc(c->table_allocs, &c->tiles, (size_t)T.n_tiles + 1) || dev_alloc(c->table_allocs, &c->desc, (size_t)T.n_nb + 1) || dev_alloc(c->table_allocs, &c->nb_f0, (size_t)T.n_nb + 1) ||
-        dev_alloc(c->table_allocs, &c->nb_f0idx, (size_t)T.n_nb + 1) ||
-        dev_alloc(c->table_allocs, &c->nb_lastidx, (size_t)T.n_nb + 1) ||
-        dev_alloc(c->table_allocs, &c->tile_chunk, ((size_t)T.n_tiles + 1) * (TILE / 64)) ||
-        dev_alloc(c->table_allocs, &c->tile_local, (size_t)T.n_tiles + 1) ||
-        dev_alloc(c->table_allocs, &c->group_sum, (size_t)(T.n_tiles / GROUP + 2)) ||
-        dev_alloc(c->table_allocs, &c->tile_cnt, (size_t)T.n_tiles + 1))
-        return -10;
-    if (T.n_nb > 0) {
-        const int64_t threads = (int64_t)T.n_nb * 64;
-        hipLaunchKernelGGL(k_validate, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, T);
-        hipLaunchKernelGGL(k_tile_nb, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, c->stream, T);
-        hipLaunchKernelGGL(k_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, T);
+    if (n_nb > 0) nb_vf[n_nb - 1] = (h->n_seg - nb_seg[n_nb - 1] > 1) ? V_MULTI_SEG : 0u;
+    nb_row[n_nb] = n;
+    nb_seg[n_nb] = h->n_seg;
+    nb_vf[n_nb] = 0u;
+    {
+        int32_t b = 0;                                     // last block that starts at or before the tile's first row
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            while (b + 1 < n_nb && nb_row[b + 1] <= t * TILE) ++b;
+            tile_nb[t] = b;
+        }
     }
+    if (read_qual && h->n_reads > 0) memcpy(st + L.qual, read_qual, (size_t)h->n_reads * 8);
+
+    // ---- the slot's table ----
+    DevTable &T = S.T;
+    T = DevTable();
+    T.n_rows = n; T.n_seg = h->n_seg; T.n_reads = h->n_reads; T.n_nb = n_nb; T.n_tiles = n_tiles; T.has_repeats = has_rep;
+    T.pos = S.pos; T.idx = S.idx; T.evmu = S.evmu; T.flags = S.flags; T.nb_tmpl = S.nb_tmpl;
+    unsigned char *dv = S.small_dev;
+    T.seg_begin = (int64_t *)(dv + L.seg_begin); T.seg_read = (int32_t *)(dv + L.seg_read); T.seg_contig = (int32_t *)(dv + L.seg_contig);
+    T.nb_row_begin = (int64_t *)(dv + L.nb_row_begin); T.nb_seg_begin = (int32_t *)(dv + L.nb_seg_begin);
+    T.nb_read = (int32_t *)(dv + L.nb_read); T.nb_repeat = dv + L.nb_repeat; T.nb_vflags = (uint32_t *)(dv + L.nb_vflags);
+    T.tile_nb = (int32_t *)(dv + L.tile_nb);
+    S.qual = read_qual ? (double *)(dv + L.qual) : nullptr;
+    S.n_qual = read_qual ? h->n_reads : 0;
+    S.tmpl_ref = -1;
+
+    // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out), then the per-table kernel on
+    //      the ctx stream behind the transfer ----
+    hipStream_t us = c->up_stream;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, us));
+        HIP_TRY(hipMemcpyAsync(T.evmu, h->event_model_e4, (size_t)n * 8, hipMemcpyHostToDevice, us));
+        HIP_TRY(hipMemcpyAsync(T.idx, h->event_idx, (size_t)n * 4, hipMemcpyHostToDevice, us));
+        HIP_TRY(hipMemcpyAsync(T.flags, h->flags, (size_t)n, hipMemcpyHostToDevice, us));
+    }
+    HIP_TRY(hipMemcpyAsync(dv, st, L.total, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipEventRecord(S.ev_uploaded, us));
+    HIP_TRY(hipStreamWaitEvent(c->stream, S.ev_uploaded, 0));
+    if (n_nb > 0) hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(VT), 0, c->stream, T);
     HIP_TRY(hipGetLastError());
+    c->T = T;
+    c->cur = at;
+    if (read_qual) { c->qual = S.qual; c->n_qual = S.n_qual; }
+    else { c->qual = c->qual_own; c->n_qual = c->n_qual_own; }       // mc_ctx_set_read_quality's table applies
+    if (slot_out) *slot_out = at;
+    return 0;
+}
+
+extern "C" int mc_ctx_wait_upload(mc_ctx *c, int32_t slot) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].ev_uploaded) {
+        mc_set_error("mc_ctx_wait_upload: slot %d", slot);
+        return -12;
+    }
+    HIP_TRY(hipEventSynchronize(c->slots[slot].ev_uploaded));
+    return 0;
+}
+
+extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
+    HIP_TRY(hipSetDevice(c->device));
+    // the one-table interface: whatever is in flight finishes first, so the caller's buffers are free on return and the
+    // slot that is taken over holds nothing anybody waits for
+    if (int rc = sync_pass_streams(c)) return rc;
+    if (c->ab_count == 0) {                                  // no pass to hand out any more: nothing is held
+        c->held = -1;
+        for (TableSlot &S : c->slots) S.refs = 0;
+    }
+    int32_t slot = -1;
+    if (int rc = mc_ctx_upload_table_async(c, h, nullptr, &slot)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 extern "C" int mc_ctx_set_read_quality(mc_ctx *c, const double *qual, int32_t n_reads) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->qual) (void)hipFree(c->qual);
-    c->qual = nullptr;
-    HIP_TRY(hipMalloc((void **)&c->qual, std::max<size_t>((size_t)n_reads * 8, 256)));
-    if (n_reads > 0) HIP_TRY(hipMemcpy(c->qual, qual, (size_t)n_reads * 8, hipMemcpyHostToDevice));
-    c->n_qual = n_reads;
+    if (int rc = sync_pass_streams(c)) return rc;            // passes in flight read the old buffer
+    if (c->qual_own) (void)hipFree(c->qual_own);
+    c->qual_own = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->qual_own, std::max<size_t>((size_t)n_reads * 8, 256)));
+    if (n_reads > 0) HIP_TRY(hipMemcpy(c->qual_own, qual, (size_t)n_reads * 8, hipMemcpyHostToDevice));
+    c->qual = c->qual_own;
+    c->n_qual = c->n_qual_own = n_reads;
     return 0;
 }
 
@@ -2535,8 +2813,9 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
 }
 
 static int ensure_records(mc_ctx *c, int64_t cap, int k) {
-    if (c->Omain.capacity >= cap && c->last_k == k) { c->O = c->Omain; return 0; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t need_tiles = std::max<int64_t>(c->T.n_tiles, c->scratch_tiles);
+    if (c->Omain.capacity >= cap && c->last_k == k && c->payload_tiles >= need_tiles) { c->O = c->Omain; return 0; }
+    if (int rc = sync_pass_streams(c)) return rc;
     free_pool(c->rec_allocs);
     for (DevRecords *D : {&c->Omain}) {
         D->capacity = cap;
@@ -2545,7 +2824,8 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
             dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
             return -10;
     }
-    c->payload_cap = cap + (c->T.n_tiles + 1) * PT;
+    c->payload_tiles = need_tiles;
+    c->payload_cap = cap + (need_tiles + 1) * PT;
     if (dev_alloc(c->rec_allocs, &c->payload_sorted, (size_t)cap) || dev_alloc(c->rec_allocs, &c->rare_list, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
     c->last_k = k;
     c->O = c->Omain;
@@ -2633,9 +2913,9 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
 static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st) {
     const DevTable &T = c->T;
     const int k = prm->k;
-    if (c->tmpl_dirty) {
+    if (c->cur >= 0 && c->slots[c->cur].tmpl_ref != c->ref_version) {      // once per (table, reference)
         hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R);
-        c->tmpl_dirty = false;
+        c->slots[c->cur].tmpl_ref = c->ref_version;
     }
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
@@ -2658,7 +2938,9 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
+#ifdef MC_K1_EXPERIMENTS
     { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+#endif
     hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + MC_SCAN_CHUNK - 1) / MC_SCAN_CHUNK, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,   // (chunks, not tiles)
                        st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
@@ -2689,8 +2971,9 @@ static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &
 static int64_t guess_capacity(const mc_ctx *c) {
     if (const char *e = getenv("MCALLER_RECORD_CAPACITY")) { if (atoll(e) > 0) return atoll(e); }   // (tests: force the overflow path)
     const double density = c->ref_total_len > 0 ? (double)c->R.n_sites / (2.0 * (double)c->ref_total_len) : 0.0;
-    const int64_t by_sites = (int64_t)((double)c->T.n_rows * density * 0.52 * 1.5);
-    return std::max<int64_t>(1 << 16, std::max<int64_t>(c->T.n_rows / 64, by_sites) + 4096);
+    const int64_t rows = std::max<int64_t>(c->T.n_rows, c->res_rows);        // (reserved: every later table fits, no re-allocation)
+    const int64_t by_sites = (int64_t)((double)rows * density * 0.52 * 1.5);
+    return std::max<int64_t>(1 << 16, std::max<int64_t>(rows / 64, by_sites) + 4096);
 }
 
 // what every pass needs before it can be enqueued
@@ -2726,6 +3009,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     c->last_n = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
     if (c->ab_count) { if (int rc = sync_pass_streams(c)) return rc; }   // pipelined passes share the scratch: let them finish
+    if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
+    c->last_seg_contig = T.seg_contig;
+    if (!c->in_rerun) c->held = c->cur;                                   // (a re-run inside mc_wait_records: held by the caller)
 
     free_pool(c->lit_allocs);
     int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
@@ -2855,11 +3141,12 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
     free_pool(b.dev_allocs);
     b.H = DevRecords();
+    const int64_t nb = std::max<int64_t>(T.n_nb, c->scratch_nb), nt = std::max<int64_t>(T.n_tiles, c->scratch_tiles);
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
-    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)T.n_nb + 1) || dev_alloc(b.dev_allocs, &b.K.tiles, (size_t)T.n_tiles + 1) ||
-        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)T.n_nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0idx, (size_t)T.n_nb + 1) ||
-        dev_alloc(b.dev_allocs, &b.K.nb_lastidx, (size_t)T.n_nb + 1))
+    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.tiles, (size_t)nt + 1) ||
+        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0idx, (size_t)nb + 1) ||
+        dev_alloc(b.dev_allocs, &b.K.nb_lastidx, (size_t)nb + 1))
         return -10;
     if (cap >= (int64_t)1 << 31) {
         mc_set_error("mc_extract_features_async: %lld flush records per pass (call_row is 32 bits wide); use mc_extract_features",
@@ -2877,8 +3164,8 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     }
     b.cap = cap;
     b.k = k;
-    b.n_nb = T.n_nb;
-    b.n_tiles = T.n_tiles;
+    b.n_nb = nb;
+    b.n_tiles = nt;
     b.used = false;
     return 0;
 }
@@ -2926,11 +3213,13 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
         if (int rc = ensure_async_buf(c, b, 1 << 16, k)) return rc;
         memset(b.st_host, 0, sizeof(Counters));
         b.used = false;
+        b.slot = -1;
         c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
         c->ab_count += 1;
         return 0;
     }
     const int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
+    if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
@@ -2963,12 +3252,17 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // copy-out of the previous pass, which mc_wait_records enqueues later)
     HIP_TRY(hipGetLastError());
     b.used = true;
+    b.slot = c->cur;
+    b.qual = c->qual;
+    b.n_qual = c->n_qual;
+    if (b.slot >= 0) c->slots[b.slot].refs += 1;        // the table stays in its slot until the pass has been handed out
     c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
     c->ab_count += 1;
     return 0;
 }
 
 static int sync_pass_streams(mc_ctx *c) {
+    if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
     if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
@@ -3026,6 +3320,13 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     c->ab_tail = (c->ab_tail + 1) % MC_PASSES_IN_FLIGHT;
     c->ab_count -= 1;
     b.copying = false;
+    // the pass leaves flight: its table stays put as "the table of the records handed out last" (mc_site_counts) until the
+    // next pass is handed out
+    if (b.slot >= 0) {
+        c->slots[b.slot].refs -= 1;
+        c->held = b.slot;
+        c->last_seg_contig = c->slots[b.slot].T.seg_contig;
+    }
     const Counters st = *b.st_host;
     const bool special = st.overflow || st.n_irregular;
     if (b.used && !special && st.n_records > 0) HIP_TRY(hipEventSynchronize(b.ev_copied));
@@ -3035,8 +3336,17 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     if (special) {
         // a pass the fast path alone cannot finish (record buffers too small, irregular reads):
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
+        // (on the table the pass was enqueued for, which need not be the current one any more)
         int64_t n = 0;
-        if (int rc = mc_extract_features(c, &b.prm, &n)) return rc;
+        const DevTable T_now = c->T;
+        const double *q_now = c->qual;
+        const int cur_now = c->cur, nq_now = c->n_qual;
+        if (b.slot >= 0) { c->T = c->slots[b.slot].T; c->qual = const_cast<double *>(b.qual); c->n_qual = b.n_qual; c->cur = b.slot; }
+        c->in_rerun = true;
+        const int rc = mc_extract_features(c, &b.prm, &n);
+        c->in_rerun = false;
+        c->T = T_now; c->qual = const_cast<double *>(q_now); c->n_qual = nq_now; c->cur = cur_now;
+        if (rc) return rc;
         c->last_timed = 1;         // (mc_extract_features times every pass)
         *n_records = n;
         return mc_fetch_records_view(c, out);
@@ -3187,7 +3497,8 @@ extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int64_t *n_pending)
     hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
     if (n > 0)
         hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->R, c->O, n,
-                           (const int32_t *)c->T.seg_contig, row_offset, c->site_cnt, c->site_first, ns, status);
+                           c->last_seg_contig ? c->last_seg_contig : (const int32_t *)c->T.seg_contig, row_offset, c->site_cnt,
+                           c->site_first, ns, status);
     unsigned long long h[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -183,7 +183,7 @@ extern "C" int mc_fastq_read_quality(const char *path, int32_t n_threads, mc_fas
         close(fd);
     }
     const char *end = base + size;
-    int nt = n_threads > 0 ? n_threads : int(std::thread::hardware_concurrency());
+    int nt = n_threads > 0 ? n_threads : mc_host_cores();       // the cores this process may use, not the machine's
     if (nt < 1) nt = 1;
     if (size / (size_t(1) << 22) + 1 < size_t(nt)) nt = int(size / (size_t(1) << 22) + 1);   // pieces of at least 4 MB
 

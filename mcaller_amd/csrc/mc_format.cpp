@@ -214,7 +214,7 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
         return -12;
     }
     const int64_t n = a->n_records;
-    int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nt = n_threads > 0 ? n_threads : mc_host_cores();                 // the cores this process may use
     nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (n - first) / 4096));
 
     // pass 1: the first record the host must handle itself

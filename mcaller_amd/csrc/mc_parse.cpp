@@ -30,6 +30,7 @@
 #include <vector>
 
 void mc_set_error(const char *fmt, ...);
+int mc_parser_uses_pool();      // mc_common.cpp: the columns of parsed tables live in the pinned host pool (mc_host_pool_config)
 
 namespace {
 
@@ -125,19 +126,27 @@ struct SvHash {
 
 }  // namespace
 
-// a column of the final table: raw memory, never zero-filled (every element is written by the piece that owns it)
+// a column of the final table: raw memory, never zero-filled (every element is written by the piece that owns it) --
+// plain, or a block of the pinned host pool when the table is going to be streamed to the GPU (mc_host_pool_config)
 template <typename T>
 struct RawCol {
     T *p = nullptr;
     size_t n = 0;
+    bool pooled = false;
     RawCol() = default;
     RawCol(const RawCol &) = delete;
     RawCol &operator=(const RawCol &) = delete;
-    ~RawCol() { free(p); }
+    ~RawCol() { release(); }
+    void release() {
+        if (pooled) mc_host_free(p); else free(p);
+        p = nullptr;
+    }
     bool alloc(size_t count) {
-        free(p);
+        release();
         n = count;
-        p = (T *)malloc(std::max<size_t>(count, 1) * sizeof(T));
+        pooled = mc_parser_uses_pool() != 0;
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 64;     // (the GPU side reads whole 16-byte groups)
+        p = pooled ? (T *)mc_host_alloc((int64_t)bytes) : (T *)malloc(bytes);
         return p != nullptr;
     }
     T *data() { return p; }
@@ -147,8 +156,9 @@ struct RawCol {
 };
 
 struct mc_parsed {
-    RawCol<int32_t> pos, ev, mu, idx;
+    RawCol<int32_t> pos, evmu, idx;        // evmu: (event, model) pairs, two entries per row
     RawCol<uint8_t> flags;
+    int n_pieces = 0;                      // pieces the byte range was cut into (one parser thread each)
     std::vector<int64_t> seg_begin;
     std::vector<int32_t> seg_read, seg_contig;
     std::vector<std::string> read_names;
@@ -180,7 +190,7 @@ namespace {
 // What one thread makes of its byte range.  Read names stay text here (one entry per change of name); ids are assigned
 // when the chunks are stitched together, in file order, so equal names get equal ids across the whole file.
 struct Chunk {
-    std::vector<int32_t> pos, ev, mu, idx;
+    std::vector<int32_t> pos, evmu, idx;   // evmu: (event, model) pairs
     std::vector<uint8_t> flags;
     std::vector<int64_t> seg_begin;        // local row index
     std::vector<int32_t> seg_name;         // index into names
@@ -201,8 +211,7 @@ using ContigMap = std::unordered_map<std::string_view, int32_t, SvHash>;
 void parse_chunk(int fd, int64_t lo, int64_t hi, const ContigMap &contig_map, Chunk &C) {
     size_t guess = (size_t)((hi - lo) / 100 + 16);
     C.pos.reserve(guess);
-    C.ev.reserve(guess);
-    C.mu.reserve(guess);
+    C.evmu.reserve(2 * guess);
     C.idx.reserve(guess);
     C.flags.reserve(guess);
     std::string last_contig_txt;
@@ -302,8 +311,8 @@ void parse_chunk(int fd, int64_t lo, int64_t hi, const ContigMap &contig_map, Ch
         }
         C.pos.push_back((int32_t)pos);
         C.idx.push_back((int32_t)idx);
-        C.ev.push_back((int32_t)e4);
-        C.mu.push_back((int32_t)m4);
+        C.evmu.push_back((int32_t)e4);
+        C.evmu.push_back((int32_t)m4);
         C.flags.push_back(fl);
     }
         have = n - usable;
@@ -447,7 +456,7 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
 
     // ---- cut [lo, hi) at line starts, one piece per thread ----
     // n_threads > 0: that many pieces; <= 0: one per core, but no piece smaller than 4 MB
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : mc_host_cores();      // the cores this process may use, not the machine's
     if (nt < 1) nt = 1;
     const int64_t min_piece = 4 << 20;
     if (n_threads <= 0 && (hi - lo) / nt < min_piece) nt = (int)std::max<int64_t>(1, (hi - lo) / min_piece);
@@ -488,7 +497,8 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
         total += (int64_t)chunks[(size_t)i].pos.size();
     }
     mc_parsed *P = new mc_parsed();
-    if (!P->pos.alloc((size_t)total) || !P->ev.alloc((size_t)total) || !P->mu.alloc((size_t)total) ||
+    P->n_pieces = np;
+    if (!P->pos.alloc((size_t)total) || !P->evmu.alloc((size_t)total * 2) ||
         !P->idx.alloc((size_t)total) || !P->flags.alloc((size_t)total)) {
         delete P;
         mc_set_error("out of memory for %lld rows", (long long)total);
@@ -504,15 +514,13 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
             const int64_t o = offs[(size_t)i];
             if (n) {
                 memcpy(P->pos.data() + o, C.pos.data(), n * 4);
-                memcpy(P->ev.data() + o, C.ev.data(), n * 4);
-                memcpy(P->mu.data() + o, C.mu.data(), n * 4);
+                memcpy(P->evmu.data() + 2 * o, C.evmu.data(), n * 8);
                 memcpy(P->idx.data() + o, C.idx.data(), n * 4);
                 memcpy(P->flags.data() + o, C.flags.data(), n);
             }
             C.n_rows = (int64_t)n;
             std::vector<int32_t>().swap(C.pos);
-            std::vector<int32_t>().swap(C.ev);
-            std::vector<int32_t>().swap(C.mu);
+            std::vector<int32_t>().swap(C.evmu);
             std::vector<int32_t>().swap(C.idx);
             std::vector<uint8_t>().swap(C.flags);
         };
@@ -574,8 +582,7 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
 extern "C" int mc_parsed_view(const mc_parsed *p, mc_table_view *out) {
     out->n_rows = (int64_t)p->pos.size();
     out->pos = p->pos.data();
-    out->event_e4 = p->ev.data();
-    out->model_e4 = p->mu.data();
+    out->event_model_e4 = p->evmu.data();
     out->event_idx = p->idx.data();
     out->flags = p->flags.data();
     out->n_seg = (int32_t)p->seg_read.size();
@@ -597,5 +604,7 @@ extern "C" const char *mc_parsed_unknown_name(const mc_parsed *p, int64_t i) {
     if (i < 0 || (size_t)i >= p->unknown.size()) return nullptr;
     return p->unknown[(size_t)i].c_str();
 }
+
+extern "C" int32_t mc_parsed_n_pieces(const mc_parsed *p) { return p->n_pieces; }
 
 extern "C" void mc_parsed_free(mc_parsed *p) { delete p; }

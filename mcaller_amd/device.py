@@ -48,6 +48,24 @@ class Device(object):
         check(lib().mc_ctx_upload_table(self._ctx, C.byref(v)))
         self.n_rows = table.n_rows
 
+    def reserve_tables(self, max_rows, max_segs, max_reads):
+        """Size the table slots, the per-pass scratch and the record sets once for a stream of tables up to these sizes."""
+        check(lib().mc_ctx_reserve_tables(self._ctx, int(max_rows), int(max_segs), int(max_reads)))
+
+    def upload_table_async(self, table, qual=None):
+        """Enqueue the upload of `table` (+ its read qualities) into a free slot and make it the current table; returns the
+        slot.  The table's arrays must stay alive and untouched until wait_upload(slot) (or until the records of a pass over
+        it have been handed out); they should be pinned (Table.pinned(), or parsed with the pool switched on)."""
+        v = table.view()
+        q = None if qual is None else np.ascontiguousarray(qual, dtype=np.float64)
+        slot = C.c_int32(-1)
+        check(lib().mc_ctx_upload_table_async(self._ctx, C.byref(v), None if q is None else _ptr(q), C.byref(slot)))
+        self.n_rows = table.n_rows
+        return slot.value
+
+    def wait_upload(self, slot):
+        check(lib().mc_ctx_wait_upload(self._ctx, int(slot)))
+
     def set_read_quality(self, qual):
         q = np.ascontiguousarray(qual, dtype=np.float64)
         check(lib().mc_ctx_set_read_quality(self._ctx, _ptr(q), len(q)))

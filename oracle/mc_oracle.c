@@ -201,7 +201,7 @@ int mco_extract_features(const mc_table_view *T, const mc_ref_view *R, const dou
                 m.last_read = name;
                 m.last_rev = rev;
                 m.last_seg = seg;
-                int64_t d = (int64_t)T->event_e4[r] - (int64_t)T->model_e4[r];
+                int64_t d = (int64_t)T->event_model_e4[2 * r] - (int64_t)T->event_model_e4[2 * r + 1];
                 slot_push(&m.slots[off], (double)d / 10000.0);                            /* :286 */
             } else if (m.has_mpos && m.mpos != 0) {                                       /* :289-291 */
                 m.has_mpos = 0;

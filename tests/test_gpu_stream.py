@@ -1,0 +1,191 @@
+"""Streaming distinct tables through the table slots of a context (mc_ctx_upload_table_async): the reference's batch
+loop (extract_contexts.py:140-148) as shards in flight.  Every shard's records must equal the C oracle's.
+Runs on a real MI355X only: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from mcaller_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=600000, seed=23)
+    ref = synth.SynthRef(codes, motif='GATC')
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    return codes, ref, weights, soc
+
+
+def _oracle(table, ref, qual, weights, soc, tail):
+    orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0, tail_contig=tail)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    return orc
+
+
+def _irregular(table, seed):
+    """Break a few reads of a regular table: positions going backwards, equal event indices, a read name that comes back."""
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(seed)
+    pos, idx = table.pos.copy(), table.event_idx.copy()
+    seg_read = table.seg_read.copy()
+    for seg in rng.choice(table.n_seg, size=max(1, table.n_seg // 6), replace=False):
+        r0, r1 = int(table.seg_row_begin[seg]), int(table.seg_row_begin[seg + 1])
+        if r1 - r0 < 8:
+            continue
+        r = int(rng.integers(r0 + 2, r1 - 2))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            pos[r] = pos[r - 1] - int(rng.integers(1, 4))
+        elif kind == 1:
+            idx[r] = idx[r - 1]
+        elif seg > 1:
+            seg_read[seg] = seg_read[seg - 2]
+    return _lib.Table(pos, None, None, idx, table.flags, table.seg_row_begin, seg_read, table.seg_contig, table.n_reads,
+                      read_names=table.read_names, evmu=table.evmu)
+
+
+def test_stream_distinct_shards_two_in_flight(dev, setup):
+    """Ten distinct shards (own rows, own read ids, own read qualities) streamed through the slots from pinned memory, two
+    passes in flight while the next shard uploads; one shard holds irregular reads (re-run on ITS table when handed out)."""
+    from mcaller_amd import synth
+    codes, ref, weights, soc = setup
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    shards = []
+    for i in range(10):
+        n_rows = [60000, 250000, 3072, 120001, 400000, 77, 180000, 300000, 6144, 90000][i]
+        t, q = synth.make_table(n_rows, seed=500 + i, codes=codes, read_len=(600, 6000) if i % 3 else (40, 300))
+        if i == 4:
+            t = _irregular(t, 9)
+        tail = -1 if i == 9 else 0                      # every shard but the last is followed by rows of contig 0
+        shards.append((t.pinned(), q, tail))
+    dev.reserve_tables(max(t.n_rows for t, _, _ in shards), max(t.n_seg for t, _, _ in shards),
+                       max(t.n_reads for t, _, _ in shards))
+    in_flight, n_checked = [], 0
+
+    def hand_out():
+        nonlocal n_checked
+        t, q, tail = in_flight.pop(0)
+        rec = dev.wait()
+        H.assert_records_equal(rec, _oracle(t, ref, q, weights, soc, tail), 6)
+        n_checked += 1
+
+    for t, q, tail in shards:
+        dev.upload_table_async(t, q)
+        dev.run_async(6, 0, 0.0, tail_contig=tail, score=True)
+        in_flight.append((t, q, tail))
+        if len(in_flight) > 2:
+            hand_out()
+    while in_flight:
+        hand_out()
+    assert n_checked == 10
+
+
+def test_stream_three_rounds_reuse_the_slots(dev, setup):
+    """The slots are reused round after round (no allocation: the sizes were reserved); smaller and bigger tables alternate,
+    so stale rows of an earlier table sit behind the current one."""
+    from mcaller_amd import synth
+    codes, ref, weights, soc = setup
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    dev.reserve_tables(300000, 4000, 4000)
+    prev = None
+    for i in range(13):
+        n_rows = 300000 if i % 2 == 0 else 20000 + 1000 * i
+        t, q = synth.make_table(n_rows, seed=900 + i, codes=codes, read_len=(300, 3000))
+        t = t.pinned()
+        dev.upload_table_async(t, q)
+        dev.run_async(6, 0, 0.0, tail_contig=0, score=True)
+        if prev is not None:
+            H.assert_records_equal(dev.wait(), _oracle(prev[0], ref, prev[1], weights, soc, 0), 6)
+        prev = (t, q)
+    H.assert_records_equal(dev.wait(), _oracle(prev[0], ref, prev[1], weights, soc, 0), 6)
+
+
+def test_upload_while_passes_are_in_flight(dev, setup):
+    """mc_ctx_upload_table (the one-table interface) while two passes over the previous table are in flight: they keep their
+    table (another slot takes the new one) and hand out that table's records; with every slot scanned the asynchronous
+    upload refuses with a clean error."""
+    from mcaller_amd import synth, _lib
+    codes, ref, weights, soc = setup
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    t1, q1 = synth.make_table(200000, seed=71, codes=codes, read_len=(500, 4000))
+    t2, q2 = synth.make_table(150000, seed=72, codes=codes, read_len=(500, 4000))
+    dev.upload_table(t1)
+    dev.set_read_quality(q1)
+    dev.run_async(6, 0, 0.0, score=True)
+    dev.run_async(6, 0, 0.0, score=True)
+    dev.upload_table(t2)                                  # pageable source, synchronous
+    dev.set_read_quality(q2)
+    dev.run_async(6, 0, 0.0, score=True)
+    o1, o2 = _oracle(t1, ref, q1, weights, soc, -1), _oracle(t2, ref, q2, weights, soc, -1)
+    H.assert_records_equal(dev.wait(), o1, 6)
+    H.assert_records_equal(dev.wait(), o1, 6)
+    H.assert_records_equal(dev.wait(), o2, 6)
+    # every slot busy
+    tables = []
+    for i in range(4):
+        t, q = synth.make_table(5000 + i, seed=80 + i, codes=codes, read_len=(300, 900))
+        tables.append((t.pinned(), q))
+    n_ok = 0
+    with pytest.raises(_lib.McError, match='table slots'):
+        for t, q in tables + tables:
+            dev.upload_table_async(t, q)
+            dev.run_async(6, 0, 0.0, score=True)
+            n_ok += 1
+    assert 2 <= n_ok <= 4
+    for i in range(n_ok):
+        t, q = tables[i]
+        H.assert_records_equal(dev.wait(), _oracle(t, ref, q, weights, soc, -1), 6)
+
+
+def test_validation_flags_many_small_and_broken_reads(dev, setup):
+    """k_validate: tiles that hold more name blocks than its LDS table (reads of 20-60 rows), every kind of irregular block
+    among them; the flags decide which path a block takes, so a wrong flag shows as a record mismatch."""
+    from mcaller_amd import synth
+    codes, _, weights, soc = setup
+    ref = synth.SynthRef(codes, motif='A')
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    for seed, rl in ((1, (12, 40)), (2, (30, 120)), (3, (2000, 9000))):
+        t, q = synth.make_table(40000, seed=seed, codes=codes, read_len=rl)
+        t = _irregular(t, seed)
+        dev.upload_table(t)
+        dev.set_read_quality(q)
+        rec = dev.extract(6, 1, 0.0, score=True)
+        orc = H.oracle_records(t, ref.device_arrays(), q, 6, 1, 0.0)
+        H.oracle_score(orc, t, q, weights, soc, 6)
+        H.assert_records_equal(rec, orc, 6)
+
+
+def test_parser_tables_come_from_the_pinned_pool(tmp_path):
+    from mcaller_amd import synth, _lib
+    codes = synth.genome(length=200000, seed=4)
+    table, _ = synth.make_table(30000, seed=6, codes=codes, read_len=(400, 2000))
+    tsv = str(tmp_path / 'p.eventalign.tsv')
+    synth.write_tsv(table, codes, tsv)
+    L = _lib.lib()
+    L.mc_host_pool_config(1, -1)
+    try:
+        t = _lib.parse_eventalign(tsv, 0, 1 << 40, ['ecoli_syn'], exact_range=True)
+        assert t.n_rows == table.n_rows and (t.evmu == table.evmu).all() and (t.pos == table.pos).all()
+        assert L.mc_host_is_pinned(t.pos.ctypes.data) == 1 and L.mc_host_is_pinned(t.evmu.ctypes.data) == 1
+        first = t.pos.ctypes.data
+        del t
+        t2 = _lib.parse_eventalign(tsv, 0, 1 << 40, ['ecoli_syn'], exact_range=True)
+        blocks = {t2.pos.ctypes.data, t2.evmu.ctypes.data, t2.event_idx.ctypes.data, t2.flags.ctypes.data}
+        assert first in blocks                           # the blocks of the freed table were handed out again
+    finally:
+        L.mc_host_pool_config(0, -1)

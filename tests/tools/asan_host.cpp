@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
         if (rows >= 0 && rows != v.n_rows) { fprintf(stderr, "row count depends on the thread count\n"); return 1; }
         rows = v.n_rows;
         long chk = 0;
-        for (int64_t i = 0; i < v.n_rows; ++i) chk += v.pos[i] + v.event_e4[i] + v.model_e4[i] + v.event_idx[i] + v.flags[i];
+        for (int64_t i = 0; i < v.n_rows; ++i) chk += v.pos[i] + v.event_model_e4[2 * i] + v.event_model_e4[2 * i + 1] + v.event_idx[i] + v.flags[i];
         for (int r = 0; r < v.n_reads; ++r) chk += (long)strlen(mc_parsed_read_name(p, r));
         printf("threads %d: %lld rows, %d segments, %d reads, checksum %ld, %lld rows of unknown contigs\n", threads,
                (long long)v.n_rows, v.n_seg, v.n_reads, chk, (long long)mc_parsed_n_unknown(p));
