@@ -6,14 +6,26 @@ D2H copy of the flush records) over one batch of synthetic eventalign rows that 
 Workload at N=1: BASELINE.json configs[2] -- synthetic 10^8 events, -m GATC, NN classifier (r95 two-base MLP),
 skip_thresh 0.  N>1: every rank scans its own 10^8-row shard of reads (weak scaling, no data-path collective).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the window-scan kernel
-(algorithmic bytes = 17 B/event row + 64 B/emitted call) and `cpu_baseline` (the C oracle,
-single host core, same workload sample).
+Prints ONE JSON line on rank 0.  Beside the contract's keys (`value` = the resident-table rate) it carries, at N=1:
+  config.device_e2e          distinct shards (10^8 rows in total) streamed from pinned host memory through the table slots:
+                             H2D + per-table kernel + pass + D2H of the records, next to the measured H2D-only rate
+  config.file_to_file        eventalign TSV -> .diffs.6 through the CLI (parser and row formatter included)
+  config.per_table_kernel_ms every kernel that touches a table once (upload-time k_validate included), hipEvent times
+  roofline                   `frac` = HBM bytes the named kernel actually moves (rocprofv3 PMC, `traffic_source`) / its live
+                             hipEvent time / 8 TB/s; `algorithmic` = SURVEY.md 8(d)'s 17 B/row + 64 B/call figure against
+                             the feature-extraction time (may exceed the peak: the kernels do not move those bytes);
+                             `per_table` = the algorithmic bytes against ALL kernels that touch the table
+  cpu_baseline               the C oracle on one host core; cpu_baseline_all_cores: the same on all cores;
+                             cpu_baseline_reference_like: the Python twin (oracle/py_oracle.py, one predict_proba-equivalent
+                             per observation) under multiprocessing on all host cores, byte-range fan-out like the
+                             reference's -t (mCaller.py:62-70), CPU model stated
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -22,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join(REPO, 'profiles', 'r02_pmc.json')
 
 
 def dist_setup(n_gpus):
@@ -36,6 +49,75 @@ def dist_setup(n_gpus):
     return rank, world, local, dist
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+# ---- the Python twin under multiprocessing (cpu_baseline_reference_like); workers import the oracle only ----
+_twin = {}
+
+
+def _twin_init(fastq, model_npz):
+    sys.path.insert(0, REPO)
+    from oracle import py_oracle
+    z = np.load(model_npz)
+    keys = sorted(set(n.split('.')[0] for n in z.files if not n.startswith('__')))
+    models = {k: (z[k + '.W1'], z[k + '.b1'], z[k + '.W2'], z[k + '.b2']) for k in keys}
+    models['__twobase__'] = True
+    _twin['models'] = models
+    _twin['r2q'] = py_oracle.read_fastq_quality(fastq)
+    _twin['fn'] = py_oracle.extract_features_oracle
+
+
+def _twin_ready(_):
+    time.sleep(0.05)
+    return os.getpid()
+
+
+def _twin_job(job):
+    tsv, fasta, lo, hi = job
+    res = _twin['fn'](tsv, fasta, _twin['r2q'], 6, 0, 0.0, _twin['models'], lo, hi, base='A', motif='GATC')
+    return len(res['rows'])
+
+
+def python_twin_baseline(paths, model_npz, n_rows_file):
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    size = os.path.getsize(paths['tsv'])
+    cores = len(os.sched_getaffinity(0))
+    sample = size if cores >= 64 else min(size, cores * (16 << 20))
+    n_jobs = cores
+    step = sample // n_jobs
+    jobs = [(paths['tsv'], paths['fasta'], i * step, (i + 1) * step if i + 1 < n_jobs else sample) for i in range(n_jobs)]
+    ctx = multiprocessing.get_context('spawn')           # never fork a process that holds a HIP context
+    # (an executor, not a Pool: a worker that dies in its initializer breaks it with an exception instead of being respawned for ever)
+    ex = ProcessPoolExecutor(max_workers=cores, mp_context=ctx, initializer=_twin_init, initargs=(paths['fastq'], model_npz))
+    try:
+        for f in [ex.submit(_twin_ready, i) for i in range(cores * 2)]:     # every worker up, models and qualities loaded
+            f.result(timeout=600)
+        t0 = time.perf_counter()
+        calls = sum(f.result(timeout=900) for f in [ex.submit(_twin_job, j) for j in jobs])
+        dt = time.perf_counter() - t0
+    finally:
+        procs = list((getattr(ex, '_processes', None) or {}).values())
+        ex.shutdown(wait=False, cancel_futures=True)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    rows = n_rows_file * sample / float(size)
+    return {'value': calls / dt, 'unit': 'calls/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'events_per_s': rows / dt,
+            'sample': 'pure-Python twin of extract_features (oracle/py_oracle.py: per-row window machine, one MLP forward per '
+                      'observation), multiprocessing over %d byte ranges of %.0f MB of eventalign text (~%.3g rows), %.2f s'
+                      % (n_jobs, sample / 1e6, rows, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -48,13 +130,18 @@ def main():
     ap.add_argument('--time-every', type=int, default=8,
                     help='pipelined passes: hipEvents that time a pass go with every n-th pass (one costs the queue ~9 us)')
     ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
+    ap.add_argument('--stream-shards', type=int, default=10, help='device end-to-end: distinct shards the rows arrive in (0: skip)')
+    ap.add_argument('--f2f-events', type=float, default=1e7, help='file to file: rows of eventalign text (0: skip)')
+    ap.add_argument('--kernels-only', action='store_true', help='skip device end-to-end, file to file and the CPU legs (profiling runs)')
     args = ap.parse_args()
+    if args.kernels_only:
+        args.stream_shards, args.f2f_events, args.no_cpu_baseline = 0, 0, True
 
     rank, world, local, dist = dist_setup(args.gpus)
     from mcaller_amd import synth, _lib
     from mcaller_amd.device import Device
     from mcaller_amd.extract_contexts import submodel_setup
-    from tests import helpers as H
+    from mcaller_amd.model_io import load_model_file, shipped_model
 
     n_rows = int(args.events)
     t_gen = time.time()
@@ -62,7 +149,8 @@ def main():
     ref = synth.SynthRef(codes, motif=args.motif)
     table, qual = synth.make_table(n_rows, seed=1000 + rank, codes=codes)
     t_gen = time.time() - t_gen
-    modelset = H.load_modelset('r95')
+    model_npz = shipped_model('r95_twobase_model_NN_6_m6A')
+    modelset = load_model_file(model_npz)
     _, weights, _, soc = submodel_setup(modelset, 'A')
 
     dev_index = 0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local      # (one-GPU boxes: test the N>1 plumbing)
@@ -70,8 +158,9 @@ def main():
     dev = Device(dev_index)
     dev.set_reference(ref.device_arrays())
     t_up = time.time()
-    dev.upload_table(table)
+    slot0 = dev.upload_table(table)
     t_up = time.time() - t_up
+    validate_ms = dev.upload_times_ms(slot0)[1]
     dev.set_read_quality(qual)
     dev.set_mlp(weights, soc)
 
@@ -108,8 +197,8 @@ def main():
     k1_ms, tot_ms, last = [], [], [None]
 
     # The kernel times come from hipEvents on the ctx stream.  An event between two kernels costs that queue ~9 us (6 % of a
-    # pass), so in the pipelined loop only every n-th pass carries the two events that do nothing but time it; kernel_ms and
-    # the roofline are averages over those passes of the timed region (one pass at a time: every pass).
+    # pass), so in the pipelined loop only every n-th pass carries the two events that do nothing but time it; kernel_ms is
+    # an average over those passes of the timed region (one pass at a time: every pass).
     time_every = 1 if args.no_pipeline else max(1, min(args.time_every, max(1, args.steps // 4)))
     dev.set_pass_timing(time_every)
 
@@ -124,7 +213,7 @@ def main():
         run_steps(args.warmup, on_done)
     del k1_ms[:], tot_ms[:]
     barrier()
-    dev.sync()                              # hipDeviceSynchronize: nothing of the warm-up is left on any stream
+    dev.sync()                              # nothing of the warm-up is left on any stream
     t0 = time.perf_counter()
     run_steps(args.steps, on_done)          # the last wait() returns when the last pass's records are in host memory
     dev.sync()
@@ -133,6 +222,7 @@ def main():
     rec = last[0]
     info = rec.info[:rec.n]
     n_calls = int(((info & _lib.I_TOO_MANY) == 0).sum())
+    n_records = int(rec.n)
 
     calls_total, elapsed_max = n_calls, elapsed
     if dist is not None:
@@ -201,6 +291,100 @@ def main():
             except Exception as e:                             # noqa
                 reduction = {'error': '%s: %s' % (type(e).__name__, e)}
 
+    # ---- the kernels one at a time (outside the timed region): hipEvents around every stage of a synchronous pass ----
+    sync_ms = []
+    for _ in range(6):
+        dev.run(6, 0, 0.0, tail_contig=-1, score=True)
+        sync_ms.append(dev.times_ms())
+    sync_ms = {k: float(np.median([t[k] for t in sync_ms[1:]])) for k in sync_ms[0]}
+
+    # ---- device end to end: distinct shards from pinned host memory through the table slots (N = 1) ----
+    device_e2e, shards = None, []
+    if world == 1 and args.stream_shards > 0:
+        try:
+            S = args.stream_shards
+            per = n_rows // S
+            for i in range(S):
+                t_i, q_i = synth.make_table(per, seed=5000 + i, codes=codes)
+                shards.append((t_i.pinned(), q_i, t_i if i == 0 else None))     # (the first one is also the file-to-file table)
+            dev.reserve_tables(max(s[0].n_rows for s in shards), max(s[0].n_seg for s in shards), max(s[0].n_reads for s in shards))
+            total_rows = sum(s[0].n_rows for s in shards)
+            total_bytes = 17.0 * total_rows
+
+            def stream_once(with_passes):
+                calls, in_flight = 0, 0
+                t_s = time.perf_counter()
+                slot = -1
+                for i, (tp, q, _) in enumerate(shards):
+                    slot = dev.upload_table_async(tp, q)
+                    if with_passes:
+                        dev.run_async(6, 0, 0.0, tail_contig=(0 if i + 1 < S else -1), score=True)
+                        in_flight += 1
+                        if in_flight > 2:
+                            r = dev.wait()
+                            calls += r.n_calls
+                            in_flight -= 1
+                while in_flight:
+                    r = dev.wait()
+                    calls += r.n_calls
+                    in_flight -= 1
+                if not with_passes:
+                    dev.wait_upload(slot)
+                dev.sync()
+                return time.perf_counter() - t_s, calls
+
+            stream_once(True)                                   # warm-up: record sets and pinned buffers allocated
+            h2d = sorted(stream_once(False)[0] for _ in range(3))
+            e2e = sorted((stream_once(True) for _ in range(5)), key=lambda x: x[0])
+            best, med = e2e[0], e2e[len(e2e) // 2]
+            device_e2e = {'shards': S, 'rows_per_shard': per, 'passes_in_flight': 2, 'source': 'pinned host memory (mc_host_alloc)',
+                          'seconds_best': best[0], 'seconds_median': med[0], 'calls': best[1],
+                          'events_per_s': total_rows / best[0], 'events_per_s_median': total_rows / med[0],
+                          'calls_per_s': best[1] / best[0],
+                          'h2d_only_seconds': h2d[0], 'h2d_only_events_per_s': total_rows / h2d[0],
+                          'h2d_only_GBps': total_bytes / h2d[0] / 1e9,
+                          'fraction_of_h2d_rate': h2d[0] / best[0]}
+        except Exception as e:                                  # noqa
+            device_e2e = {'error': '%s: %s' % (type(e).__name__, e)}
+
+    # ---- file to file: eventalign TSV -> .diffs.6 through the CLI (N = 1) ----
+    file_to_file, f2f_dir, f2f_paths, f2f_rows = None, None, None, 0
+    if world == 1 and rank == 0 and args.f2f_events > 0:
+        try:
+            import contextlib
+            import io
+            from mcaller_amd import mCaller
+            f2f_rows = int(args.f2f_events)
+            if shards and shards[0][2] is not None and shards[0][2].n_rows == f2f_rows:
+                t_f, q_f = shards[0][2], shards[0][1]
+            else:
+                t_f, q_f = synth.make_table(f2f_rows, seed=5000, codes=codes)
+            f2f_dir = tempfile.mkdtemp(prefix='mc_f2f_')
+            t_w = time.perf_counter()
+            f2f_paths = synth.write_inputs(t_f, q_f, codes, f2f_dir)
+            t_w = time.perf_counter() - t_w
+            dev.close()                                          # the CLI makes its own context
+            dev = None
+            runs = []
+            out_path = f2f_paths['tsv'][:-4] + '.diffs.6'
+            for _ in range(4):
+                if os.path.exists(out_path):
+                    os.remove(out_path)
+                t_r = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mCaller.main(['-m', 'GATC', '-r', f2f_paths['fasta'], '-e', f2f_paths['tsv'], '-f', f2f_paths['fastq'], '-d', model_npz])
+                runs.append(time.perf_counter() - t_r)
+            calls_f = sum(1 for _ in open(out_path, 'rb'))
+            best = min(runs[1:])
+            file_to_file = {'rows': f2f_rows, 'tsv_bytes': os.path.getsize(f2f_paths['tsv']), 'calls': calls_f,
+                            'seconds_first_run': runs[0], 'seconds_best': best, 'seconds_all': runs,
+                            'events_per_s': f2f_rows / best, 'calls_per_s': calls_f / best,
+                            'host_cores': len(os.sched_getaffinity(0)), 'inputs_written_s': t_w,
+                            'what': 'python -m mcaller_amd.mCaller -m GATC: FASTQ qualities, FASTA marking, native parser, '
+                                    'shards streamed through the GPU, native row formatter, .diffs.6 written (page cache warm)'}
+        except Exception as e:                                  # noqa
+            file_to_file = {'error': '%s: %s' % (type(e).__name__, e)}
+
     if rank == 0:
         k1 = float(np.mean(k1_ms))
         kernel_ms = {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]}
@@ -208,11 +392,19 @@ def main():
             kernel_ms['window_scan_and_emit'] = kernel_ms.pop('window_scan')
             del kernel_ms['emit']
         alg_bytes = 17.0 * n_rows + 64.0 * n_calls
-        traffic = None      # HBM bytes per step of the same kernels from the committed rocprofv3 PMC passes (same workload)
-        pmc = os.path.join(REPO, 'profiles', 'r01_pmc.json')
-        if os.path.exists(pmc) and n_rows == 100000000 and args.motif == 'GATC':
-            traffic = json.load(open(pmc)).get('feature_extraction_hbm_bytes_per_step')
-        achieved = alg_bytes / (k1 * 1e-3) / 1e9
+        # HBM bytes k1_scan moves per launch: rocprofv3 PMC passes of this workload (tools/collect_profiles.sh), committed
+        traffic, traffic_source = None, None
+        if os.path.exists(PMC_FILE) and n_rows == 100000000 and args.motif == 'GATC':
+            pmc = json.load(open(PMC_FILE))
+            traffic = pmc.get('per_launch_bytes_corrected', {}).get('k1_scan', {}).get('hbm_bytes')
+            traffic_source = ('profiles/r02_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` at commit %s '
+                              '(FETCH_SIZE x2, gfx950 correction); not re-measured in this run'
+                              % (pmc.get('workload', '?'), pmc.get('head', '?')))
+        scan_ms = sync_ms['window_scan']
+        per_table = {'k_validate': validate_ms, 'strand_resolve': sync_ms['strand_resolve'], 'window_scan': scan_ms,
+                     'order_and_emit': sync_ms['emit']}
+        per_table_ms = float(sum(per_table.values()))
+        achieved = (traffic / (scan_ms * 1e-3) / 1e9) if traffic else None
         out = {
             'metric': 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)',
             'value': calls_total * args.steps / elapsed_max,
@@ -229,21 +421,36 @@ def main():
             'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
                                    'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
                        'passes_in_flight': 1 if args.no_pipeline else min(3, args.steps),
-                       'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': int(rec.n),
+                       'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': n_records,
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': kernel_ms, 'kernel_ms_from_passes': len(tot_ms), 'timing_events_every_n_passes': time_every,
+                       'kernel_ms_one_pass_at_a_time': sync_ms,
+                       'per_table_kernel_ms': dict(per_table, total=per_table_ms, classifier=sync_ms['classifier']),
                        'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction, 'numa_node_rank0': numa_node,
-                       # SURVEY.md §8(d)'s three timings, calls/s on one GPU: kernels only; H2D of the table + one pass +
-                       # D2H of the records; file to file is measured by tools/file_to_file.py (profiles/r01_file_to_file.log)
+                       # SURVEY.md 8(d)'s three timings: kernels only; device end to end; file to file
                        'calls_per_s_kernels_only': n_calls / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
-                       'calls_per_s_with_h2d': n_calls / (t_up + elapsed / args.steps)},
-            'roofline': {'bound': 'hbm', 'kernel': 'k1_scan + k1_group_scan + k1_list + k1_emit (feature extraction)',
+                       'device_e2e': device_e2e,
+                       'device_e2e_events_per_s': (device_e2e or {}).get('events_per_s'),
+                       'file_to_file': file_to_file},
+            'roofline': {'bound': 'hbm', 'kernel': 'k1_scan',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_gbs': (traffic / (k1 * 1e-3) / 1e9) if traffic else None,
-                         'algorithmic_bytes': alg_bytes, 'kernel_ms': k1},
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
+                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'kernel_ms': scan_ms, 'kernel_ms_source': 'hipEvents around k1_scan, median of 5 synchronous passes after the timed region',
+                         'algorithmic': {'bytes': alg_bytes, 'what': '17 B/event row + 64 B/call (SURVEY.md 8(d))',
+                                         'kernels': 'k1_scan + k1_group_scan + k1_list + k1_emit (+ k1_rare_dev), pipelined',
+                                         'kernel_ms': k1, 'GBps': alg_bytes / (k1 * 1e-3) / 1e9,
+                                         'frac_of_peak': alg_bytes / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         'note': 'an effective rate: above 1.0 means the kernels do not move these bytes '
+                                                 '(the scan reads 5 of the 17 B/row)'},
+                         'per_table': {'kernels_ms': per_table, 'total_ms': per_table_ms,
+                                       'GBps': alg_bytes / (per_table_ms * 1e-3) / 1e9,
+                                       'frac': alg_bytes / (per_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       'what': 'algorithmic bytes / every kernel that touches the table once, upload-time '
+                                               'k_validate included (classifier excluded: it touches records, not rows)'}},
         }
-        if not args.no_cpu_baseline and world == 1:          # the CPU leg: rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1:          # the CPU legs: rank 0 at N=1 only
+            from tests import helpers as H                   # the checker (oracle/), timed as the CPU baseline
             n_cpu = min(n_rows, int(args.cpu_events))
             sub = table if n_cpu == n_rows else table.slice_segments(
                 0, int(np.searchsorted(table.seg_row_begin, n_cpu, side='left')))
@@ -257,7 +464,7 @@ def main():
             try:
                 from concurrent.futures import ThreadPoolExecutor
                 from mcaller_amd import shard
-                cores = min(os.cpu_count() or 1, 64)
+                cores = min(len(os.sched_getaffinity(0)), 64)
                 bounds = [b for b in shard.shard_bounds(sub, cores) if b[1] > b[0]]
                 subs = [(sub.slice_segments(lo, hi), shard.tail_contig(sub, qual, 0.0, hi)) for lo, hi in bounds]
 
@@ -271,16 +478,25 @@ def main():
                     mt_calls = sum(ex.map(one, subs))
                 dt2 = time.perf_counter() - t2
                 out['cpu_baseline_all_cores'] = {'value': mt_calls / dt2, 'unit': 'calls/s', 'cores': len(subs), 'kind': 'port',
+                                                 'cpu_model': cpu_model(),
                                                  'sample': 'same rows, sharded by read over %d threads, %.2f s' % (len(subs), dt2),
                                                  'events_per_s': sub.n_rows / dt2}
             except Exception as e:                              # noqa
                 out['cpu_baseline_all_cores'] = {'error': str(e)}
-            out['cpu_baseline'] = {'value': oc / dt, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
+            out['cpu_baseline'] = {'value': oc / dt, 'unit': 'calls/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(),
                                    'sample': '%d event rows of the same workload (C oracle: literal window machine + '
                                              'MLP, one host core, %.2f s)' % (sub.n_rows, dt),
                                    'events_per_s': sub.n_rows / dt}
+            if f2f_paths is not None:
+                try:
+                    out['cpu_baseline_reference_like'] = python_twin_baseline(f2f_paths, model_npz, f2f_rows)
+                except Exception as e:                          # noqa
+                    out['cpu_baseline_reference_like'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))
-    dev.close()
+    if f2f_dir:
+        shutil.rmtree(f2f_dir, ignore_errors=True)
+    if dev is not None:
+        dev.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -119,6 +119,11 @@ int mc_parse_eventalign(const char *path, int64_t startline, int64_t endline,
 int mc_parse_eventalign_range(const char *path, int64_t byte_begin, int64_t byte_end,
                               const char *const *contig_names, int32_t n_contigs, int32_t n_threads, mc_parsed **out);
 int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_t *cuts);
+/* ... the same inside the byte range [lo, hi) (lo at a line start): cuts[0] = lo, cuts[n_parts] = min(hi, file size); and
+ * the byte range the reference's batch loop consumes for (startline, endline) -- what mc_parse_eventalign parses (:141-148:
+ * the last < 500 bytes of a file can stay unread) -- for callers that cut that range into shards. */
+int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64_t hi, int32_t n_parts, int64_t *cuts);
+int mc_eventalign_consumed_range(const char *path, int64_t startline, int64_t endline, int64_t *lo, int64_t *hi);
 int mc_parsed_view(const mc_parsed *p, mc_table_view *out);
 const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id);
 int64_t mc_parsed_n_unknown(const mc_parsed *p);                 /* rows dropped for an unknown contig */
@@ -165,6 +170,9 @@ int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/*
 int mc_ctx_reserve_tables(mc_ctx *ctx, int64_t max_rows, int32_t max_segs, int32_t max_reads);
 int mc_ctx_upload_table_async(mc_ctx *ctx, const mc_table_view *host_table, const double *read_qual, int32_t *slot);
 int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);
+int mc_ctx_current_slot(mc_ctx *ctx);                       /* slot of the current table, -1: none */
+/* hipEvent times of the last upload into `slot` (waits for it): the H2D transfers, and k_validate behind them, in ms. */
+int mc_ctx_upload_times_ms(mc_ctx *ctx, int32_t slot, float *h2d_ms, float *validate_ms);
 /* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model;
  * submodel_of_char[256]: context[k] (ASCII) -> sub-model index, 255 = KeyError path (:197,:218). */
 int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden,
@@ -293,6 +301,11 @@ int mc_format_diffs(const mc_format_args *args, int64_t first, int32_t n_threads
 void mc_free(void *p);
 /* repr(float) == str(np.float64) of one value into out32 (NUL-terminated); returns its length. */
 int mc_repr_double(double v, char *out32);
+
+/* ===== measurement plumbing: a table as nanopolish-eventalign text (13 columns), written by all host cores =====
+ * For file-to-file timing on synthetic workloads (bench.py); seq = the contig's bases (k-mers of columns 3 and 10). */
+int mc_synth_write_tsv(const char *path, const mc_table_view *table, const char *seq, int64_t seq_len, const char *contig,
+                       const char *const *read_names, int32_t n_threads, int64_t *n_bytes);
 
 #ifdef __cplusplus
 }

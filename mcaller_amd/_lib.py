@@ -81,6 +81,8 @@ def lib():
                                           C.c_int32, C.POINTER(C.c_void_p)]
         L.mc_parse_eventalign_range.argtypes = L.mc_parse_eventalign.argtypes
         L.mc_eventalign_read_cuts.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
+        L.mc_eventalign_read_cuts_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+        L.mc_eventalign_consumed_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_fastq_read_quality.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
         L.mc_fastq_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.mc_fastq_view.restype = C.c_int64
@@ -95,6 +97,8 @@ def lib():
         L.mc_parsed_free.argtypes = [C.c_void_p]
         L.mc_parsed_free.restype = None
         L.mc_parsed_n_pieces.argtypes = [C.c_void_p]
+        L.mc_synth_write_tsv.argtypes = [C.c_char_p, C.POINTER(TableView), C.c_char_p, C.c_int64, C.c_char_p,
+                                         C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int64)]
         L.mc_host_alloc.argtypes = [C.c_int64]
         L.mc_host_alloc.restype = C.c_void_p
         L.mc_host_free.argtypes = [C.c_void_p]
@@ -104,6 +108,8 @@ def lib():
         L.mc_ctx_reserve_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]
         L.mc_ctx_upload_table_async.argtypes = [C.c_void_p, C.POINTER(TableView), C.c_void_p, C.POINTER(C.c_int32)]
         L.mc_ctx_wait_upload.argtypes = [C.c_void_p, C.c_int32]
+        L.mc_ctx_current_slot.argtypes = [C.c_void_p]
+        L.mc_ctx_upload_times_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mc_ctx_destroy.argtypes = [C.c_void_p]
         L.mc_ctx_destroy.restype = None
@@ -265,11 +271,23 @@ def fastq_read_quality(path, n_threads=0):
         L.mc_fastq_free(handle)
 
 
-def eventalign_read_cuts(path, n_parts):
-    """Byte offsets (n_parts + 1) cutting an eventalign file at the first lines of reads, pieces of similar size."""
+def eventalign_read_cuts(path, n_parts, lo=None, hi=None):
+    """Byte offsets (n_parts + 1) cutting an eventalign file (or its byte range [lo, hi)) at the first lines of reads,
+    pieces of similar size."""
     cuts = np.zeros(n_parts + 1, dtype=np.int64)
-    check(lib().mc_eventalign_read_cuts(path.encode('utf-8'), int(n_parts), _ptr(cuts)))
+    if lo is None and hi is None:
+        check(lib().mc_eventalign_read_cuts(path.encode('utf-8'), int(n_parts), _ptr(cuts)))
+    else:
+        check(lib().mc_eventalign_read_cuts_range(path.encode('utf-8'), int(lo or 0), int((1 << 62) if hi is None else hi),
+                                                  int(n_parts), _ptr(cuts)))
     return [int(c) for c in cuts]
+
+
+def eventalign_consumed_range(path, startline, endline):
+    """[lo, hi): the bytes the reference's batch loop reads for (startline, endline) (extract_contexts.py:141-148)."""
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    check(lib().mc_eventalign_consumed_range(path.encode('utf-8'), int(startline), int(endline), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def parse_eventalign(path, startline, endline, contig_names, n_threads=0, exact_range=False):

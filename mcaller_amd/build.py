@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['csrc/mc_device.hip', 'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_fastq.cpp',
-           'csrc/mc_common.cpp']
+           'csrc/mc_common.cpp', 'csrc/mc_synth.cpp']
 OUT = os.path.join(HERE, 'libmcaller_hip.so')
 
 

@@ -2213,6 +2213,7 @@ struct TableSlot {
     double *qual = nullptr;            // read qualities that travelled with the table (in small_dev), or nullptr
     int32_t n_qual = 0;
     hipEvent_t ev_uploaded = nullptr;  // the H2D transfers of the slot's table are done
+    hipEvent_t ev_up_start = nullptr, ev_val_start = nullptr, ev_valid = nullptr;   // ... begin; k_validate begins / is done
     int refs = 0;                      // passes in flight that scan this table
     long long tmpl_ref = -1;           // reference version the name-block templates were built for (-1: not built)
     std::vector<void *> allocs;
@@ -2450,7 +2451,8 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     (void)sync_pass_streams(c);
     for (TableSlot &S : c->slots) {
         slot_free(S);
-        if (S.ev_uploaded) (void)hipEventDestroy(S.ev_uploaded);
+        for (hipEvent_t e : {S.ev_uploaded, S.ev_up_start, S.ev_val_start, S.ev_valid})
+            if (e) (void)hipEventDestroy(e);
     }
     free_pool(c->scratch_allocs);
     free_pool(c->ref_allocs);
@@ -2545,7 +2547,10 @@ static void slot_free(TableSlot &S) {
 
 // device memory + pinned stage of a slot for tables of up to (rows, segs, reads)
 static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int64_t reads) {
-    if (!S.ev_uploaded) HIP_TRY(hipEventCreateWithFlags(&S.ev_uploaded, hipEventDisableTiming));
+    if (!S.ev_uploaded) {
+        for (hipEvent_t *e : {&S.ev_uploaded, &S.ev_up_start, &S.ev_val_start, &S.ev_valid}) HIP_TRY(hipEventCreate(e));
+        HIP_TRY(hipEventRecord(S.ev_valid, c->stream));           // (so that the first upload has something to wait for)
+    }
     if (S.pos && rows <= S.cap_rows && segs <= S.cap_segs && reads <= S.cap_reads) return 0;
     // growing: whatever may still read the old arrays has to finish first (only ever happens without mc_ctx_reserve_tables)
     if (int rc = sync_pass_streams(c)) return rc;
@@ -2692,6 +2697,8 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out), then the per-table kernel on
     //      the ctx stream behind the transfer ----
     hipStream_t us = c->up_stream;
+    HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));        // k_validate of the slot's previous table (it may never have been scanned)
+    HIP_TRY(hipEventRecord(S.ev_up_start, us));
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, us));
         HIP_TRY(hipMemcpyAsync(T.evmu, h->event_model_e4, (size_t)n * 8, hipMemcpyHostToDevice, us));
@@ -2701,7 +2708,9 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     HIP_TRY(hipMemcpyAsync(dv, st, L.total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(S.ev_uploaded, us));
     HIP_TRY(hipStreamWaitEvent(c->stream, S.ev_uploaded, 0));
+    HIP_TRY(hipEventRecord(S.ev_val_start, c->stream));
     if (n_nb > 0) hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(VT), 0, c->stream, T);
+    HIP_TRY(hipEventRecord(S.ev_valid, c->stream));
     HIP_TRY(hipGetLastError());
     c->T = T;
     c->cur = at;
@@ -2718,6 +2727,21 @@ extern "C" int mc_ctx_wait_upload(mc_ctx *c, int32_t slot) {
         return -12;
     }
     HIP_TRY(hipEventSynchronize(c->slots[slot].ev_uploaded));
+    return 0;
+}
+
+extern "C" int mc_ctx_current_slot(mc_ctx *c) { return c->cur; }
+
+extern "C" int mc_ctx_upload_times_ms(mc_ctx *c, int32_t slot, float *h2d_ms, float *validate_ms) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].ev_uploaded) {
+        mc_set_error("mc_ctx_upload_times_ms: slot %d", slot);
+        return -12;
+    }
+    TableSlot &S = c->slots[slot];
+    HIP_TRY(hipEventSynchronize(S.ev_valid));
+    if (h2d_ms) HIP_TRY(hipEventElapsedTime(h2d_ms, S.ev_up_start, S.ev_uploaded));
+    if (validate_ms) HIP_TRY(hipEventElapsedTime(validate_ms, S.ev_val_start, S.ev_valid));
     return 0;
 }
 

@@ -342,6 +342,12 @@ extern "C" int mc_parse_eventalign_range(const char *path, int64_t byte_begin, i
 // (column 4) differs from the line before it: a window never spans two reads (extract_contexts.py:179,242), so the pieces
 // can be scanned independently (one GPU each).  cuts[0] = 0, cuts[n_parts] = file size; pieces may be empty.
 extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_t *cuts) {
+    return mc_eventalign_read_cuts_range(path, 0, INT64_MAX, n_parts, cuts);
+}
+
+// The same for the byte range [lo, hi) of the file (lo at a line start; hi is clamped to the file size): cuts[0] = lo,
+// cuts[n_parts] = hi.
+extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64_t hi, int32_t n_parts, int64_t *cuts) {
     if (n_parts < 1) {
         mc_set_error("mc_eventalign_read_cuts: n_parts %d", n_parts);
         return -12;
@@ -357,10 +363,10 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
         close(fd);
         return -1;
     }
-    const int64_t fsize = (int64_t)st.st_size;
+    const int64_t file_size = (int64_t)st.st_size;
     const char *base = nullptr;
-    if (fsize > 0) {
-        base = (const char *)mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (file_size > 0) {
+        base = (const char *)mmap(nullptr, (size_t)file_size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (base == MAP_FAILED) {
             mc_set_error("cannot mmap %s: %s", path, strerror(errno));
             close(fd);
@@ -368,6 +374,8 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
         }
     }
     close(fd);
+    const int64_t fsize = std::min(std::max<int64_t>(hi, 0), file_size);     // (everything below works on [lo, fsize))
+    lo = std::min(std::max<int64_t>(lo, 0), fsize);
     auto name_of = [&](int64_t line, int64_t line_end, Tok *name) -> bool {      // column 4 of a line, if it has one
         Tok t[12];
         const int n = split12(base + line, base + line_end, t);
@@ -379,9 +387,9 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
         const void *nl = memchr(base + line, '\n', (size_t)(fsize - line));
         return nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
     };
-    cuts[0] = 0;
+    cuts[0] = lo;
     for (int32_t i = 1; i < n_parts; ++i) {
-        int64_t c = fsize * i / n_parts;
+        int64_t c = lo + (fsize - lo) * i / n_parts;
         if (c <= cuts[i - 1]) { cuts[i] = cuts[i - 1]; continue; }
         // the line that contains byte c-1 ends at `line`: start there, remember the name of the line before it
         int64_t line = c;
@@ -390,7 +398,7 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
             line = nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
         }
         int64_t prev_begin = line - 1;                       // start of the line that ends at `line`
-        while (prev_begin > 0 && base[prev_begin - 1] != '\n') --prev_begin;
+        while (prev_begin > lo && base[prev_begin - 1] != '\n') --prev_begin;
         Tok prev;
         bool have_prev = name_of(prev_begin, line, &prev);
         int64_t cut = fsize;
@@ -407,7 +415,38 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
         cuts[i] = std::max(cut, cuts[i - 1]);
     }
     cuts[n_parts] = fsize;
-    if (base) munmap((void *)base, (size_t)fsize);
+    if (base) munmap((void *)base, (size_t)file_size);
+    return 0;
+}
+
+// The byte range [*lo, *hi) the reference's batch loop consumes for (startline, endline) (:141-148): seek to
+// max(startline-500, 0), readlines(8000000) batches while linepos <= endline-500 -- the last < 500 bytes of a file can stay
+// unread.  What mc_parse_eventalign parses; exported so that a caller who cuts the range into shards cuts the same range.
+extern "C" int mc_eventalign_consumed_range(const char *path, int64_t startline, int64_t endline, int64_t *lo, int64_t *hi) {
+    *lo = *hi = 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        mc_set_error("cannot open %s: %s", path, strerror(errno));
+        return -1;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        mc_set_error("cannot stat %s", path);
+        close(fd);
+        return -1;
+    }
+    const int64_t fsize = (int64_t)st.st_size;
+    if (fsize > 0) {
+        const char *base = (const char *)mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (base == MAP_FAILED) {
+            mc_set_error("cannot mmap %s: %s", path, strerror(errno));
+            close(fd);
+            return -1;
+        }
+        consumed_range(base, fsize, startline, endline, lo, hi);
+        munmap((void *)base, (size_t)fsize);
+    }
+    close(fd);
     return 0;
 }
 

@@ -47,6 +47,10 @@ class Device(object):
         v = table.view()
         check(lib().mc_ctx_upload_table(self._ctx, C.byref(v)))
         self.n_rows = table.n_rows
+        return self.current_slot()
+
+    def current_slot(self):
+        return int(lib().mc_ctx_current_slot(self._ctx))
 
     def reserve_tables(self, max_rows, max_segs, max_reads):
         """Size the table slots, the per-pass scratch and the record sets once for a stream of tables up to these sizes."""
@@ -65,6 +69,12 @@ class Device(object):
 
     def wait_upload(self, slot):
         check(lib().mc_ctx_wait_upload(self._ctx, int(slot)))
+
+    def upload_times_ms(self, slot):
+        """(H2D ms, k_validate ms) of the last upload into `slot`; waits for it."""
+        a, b = C.c_float(0), C.c_float(0)
+        check(lib().mc_ctx_upload_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_read_quality(self, qual):
         q = np.ascontiguousarray(qual, dtype=np.float64)

@@ -152,8 +152,14 @@ def load_model_file(path):
     return ModelSet({_as_text(k): _estimator_weights(v, '%s[%s]' % (path, k)) for k, v in obj.items()}, True)
 
 
+def shipped_model(stem='r95_twobase_model_NN_6_m6A'):
+    """Path of a weight export shipped with the package (the reference keeps its .pkl models next to mCaller.py)."""
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'models', stem + '.npz')
+
+
 def load_npz_weights(path, is_dict):
-    """Neutral weight export (tests/golden/models/*.npz): arrays '<key>.W1' ... '<key>.b2'."""
+    """Neutral weight export (mcaller_amd/models/*.npz): arrays '<key>.W1' ... '<key>.b2'."""
     z = np.load(path)
     keys = sorted(set(n.split('.')[0] for n in z.files if not n.startswith('__')))
     models = {k: MLPWeights(z[k + '.W1'], z[k + '.b1'], z[k + '.W2'], z[k + '.b2'],

@@ -140,8 +140,36 @@ def tile_table(table, qual, times):
     return t, np.tile(qual, times)
 
 
+def write_tsv_native(table, codes, path, contig='ecoli_syn', n_threads=0):
+    """The same text as write_tsv, written by the library on all host cores (mc_synth_write_tsv).  -> bytes written."""
+    import ctypes as C
+    seq = codes_to_str(codes).encode('ascii')
+    names = _lib._cstr_array(table.read_names)
+    v = table.view()
+    nb = C.c_int64(0)
+    _lib.check(_lib.lib().mc_synth_write_tsv(path.encode('utf-8'), C.byref(v), seq, len(seq), contig.encode('ascii'), names,
+                                             int(n_threads), C.byref(nb)))
+    return nb.value
+
+
+def write_inputs(table, qual, codes, directory, stem='syn', contig='ecoli_syn'):
+    """TSV + FASTA + FASTQ of a synthetic workload in `directory` -> dict of paths (the FASTQ gives every read a constant
+    phred equal to its rounded quality)."""
+    import os
+    paths = dict(tsv=os.path.join(directory, stem + '.eventalign.tsv'), fasta=os.path.join(directory, 'ref.fasta'),
+                 fastq=os.path.join(directory, 'reads.fastq'))
+    write_tsv_native(table, codes, paths['tsv'], contig=contig)
+    with open(paths['fasta'], 'w') as fa:
+        s = codes_to_str(codes)
+        fa.write('>%s\n' % contig + '\n'.join(s[i:i + 60] for i in range(0, len(s), 60)) + '\n')
+    with open(paths['fastq'], 'w') as fq:
+        for i, name in enumerate(table.read_names):
+            fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + int(round(qual[i]))) * 10))
+    return paths
+
+
 def write_tsv(table, codes, path, contig='ecoli_syn'):
-    """Write a table as nanopolish-eventalign text (for file-to-file runs; slow, use on <= 10^6 rows)."""
+    """Write a table as nanopolish-eventalign text (pure Python: slow, use on <= 10^6 rows; write_tsv_native is the fast one)."""
     seq = codes_to_str(codes)
     comp = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
     with open(path, 'w') as out:

@@ -14,7 +14,7 @@ Outputs (all DATA: inputs + expected outputs + exported weight arrays, no refere
                                   rebuilt span of the FASTA) and its own golden outputs
   tests/golden/ref_outputs/       outputs of the reference run here (diffs.6 for -p, -m GATC, -m A,
                                   --train; make_bed BEDs; stdout counter lines)
-  tests/golden/models/*.npz       W1,b1,W2,b2 (+ meta) of every shipped estimator
+  mcaller_amd/models/*.npz        W1,b1,W2,b2 of every shipped estimator (meta: tests/golden/models/models_meta.json)
   tests/golden/micro_cases.json.gz  micro-cases with the reference's output for each
   tests/golden/PIN_REPORT.json    how many cases were compared, how many differed (must be 0)
 """
@@ -157,7 +157,9 @@ def export_models(outdir):
             arrays[key + '.W2'] = np.ascontiguousarray(est.coefs_[1], dtype=np.float64)
             arrays[key + '.b2'] = np.ascontiguousarray(est.intercepts_[1], dtype=np.float64)
         stem = fn[:-4]
-        np.savez(os.path.join(outdir, stem + '.npz'), **arrays)
+        pkg_models = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'mcaller_amd', 'models')   # shipped with the package
+        os.makedirs(pkg_models, exist_ok=True)
+        np.savez(os.path.join(pkg_models, stem + '.npz'), **arrays)
         # known answers: predict_proba on fixed probe vectors, per sub-model
         rng = np.random.default_rng(7)
         probes = np.concatenate([rng.normal(0, 2.5, size=(64, 6)), rng.uniform(6, 12, size=(64, 1))], axis=1)

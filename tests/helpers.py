@@ -9,6 +9,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
+MODELS = os.path.join(REPO, 'mcaller_amd', 'models')       # the weight exports the package ships
 MODEL_STEMS = {'r95': 'r95_twobase_model_NN_6_m6A', 'r94': 'r94_model_NN_6_m6A',
                'CAAY': 'CAAYNNNNNRTAC_model_6_m6A', 'CRAA': 'CRAANNNNNNNTGC_model_6_m6A'}
 
@@ -41,7 +42,7 @@ def model_meta():
 def load_modelset(tag):
     from mcaller_amd.model_io import load_npz_weights
     stem = MODEL_STEMS[tag]
-    return load_npz_weights(os.path.join(GOLDEN, 'models', stem + '.npz'), model_meta()[stem]['is_dict'])
+    return load_npz_weights(os.path.join(MODELS, stem + '.npz'), model_meta()[stem]['is_dict'])
 
 
 def oracle_records(table, ref_arrays, qual, k, skip_thresh, qual_thresh, tail_contig=-1, entry_read=-1,

@@ -21,7 +21,7 @@ def run_cli(td, tmp_path, extra):
     from mcaller_amd import mCaller
     tsv = str(tmp_path / 'masonread1.eventalign.tsv')
     shutil.copy(td['tsv'], tsv)
-    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         mCaller.main(extra + ['-r', td['fasta'], '-e', tsv, '-f', td['fastq'], '-d', model])
@@ -176,7 +176,7 @@ def test_cli_sharded_over_two_workers_equals_one_gpu(tmp_path):
     with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
         for i, name in enumerate(table.read_names):
             fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + int(round(qual[i]))) * 10))
-    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
     common = ['-m', 'GATC', '-r', os.path.join(d, 'ref.fasta'), '-e', tsv, '-f', os.path.join(d, 'reads.fastq'), '-d', model,
               '-q', '8']
     outs = []
@@ -222,7 +222,7 @@ def test_cli_bed_from_the_per_site_reduction(tmp_path):
     with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
         for i, name in enumerate(table.read_names):
             fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + int(round(qual[i]))) * 10))
-    model = os.path.join(H.GOLDEN, 'models', 'r95_twobase_model_NN_6_m6A.npz')
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
     common = ['-m', 'GATC', '-r', os.path.join(d, 'ref.fasta'), '-e', tsv, '-f', os.path.join(d, 'reads.fastq'), '-d', model,
               '--bed', '--bed_min_depth', '3', '--bed_mod_threshold', '0.3']
     bed_path = os.path.join(d, 'syn.methylation.summary.bed')

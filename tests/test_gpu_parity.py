@@ -69,7 +69,7 @@ def test_extract_features_dropin_text(td, tag, kw, tmp_path):
     shutil.copy(td['tsv'], tsv)
     r2q = extract_read_quality(td['fastq'])
     posf = td[kw['positions']] if 'positions' in kw else None
-    stem = os.path.join(H.GOLDEN, 'models')
+    stem = H.MODELS
     # the model file goes through the restricted unpickler in production; the fixtures carry arrays only, so
     # write a pickle-free stand-in: extract_features accepts the path of an .npz export as well
     model = os.path.join(stem, 'r95_twobase_model_NN_6_m6A.npz')
