@@ -245,9 +245,12 @@ int mc_forest_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int
 #define MC_UNIQUE_ID_BYTES 128
 int64_t mc_site_count(mc_ctx *ctx);                       /* number of marked sites of the reference in the ctx */
 /* counts of this rank: n_meth / n_total per site (label 'm..' <=> p >= 0.5, :200) and the smallest close_row +
- * row_offset (global row of the first occurrence, :134).  Records whose probability is NaN (scored by the host) are
- * left out and counted in *n_pending: add them with mc_site_counts_add. */
-int mc_site_counts(mc_ctx *ctx, int64_t row_offset, int64_t *n_pending);
+ * row_offset (global row of the first occurrence, :134).  Two kinds of records are left out and counted for the caller:
+ * *n_pending -- probability NaN on the device (the host scored them): add them with mc_site_counts_add;
+ * *n_cross_contig -- closed by a row of ANOTHER contig than the site's (tail_contig: the contig of the row after this
+ * table, as in mc_params): make_bed keys such a row on the closing row's contig (R8, :216), which is no site of the
+ * numbering -- the caller adds them to the BED as rows of their own. */
+int mc_site_counts(mc_ctx *ctx, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig);
 int mc_site_counts_add(mc_ctx *ctx, const int64_t *site, const uint8_t *is_meth, const int64_t *first_row, int64_t n);
 int mc_comm_unique_id(uint8_t *out128);                   /* rank 0: ncclGetUniqueId; ship the bytes to every rank */
 int mc_comm_init(mc_ctx *ctx, int32_t world, int32_t rank, const uint8_t *unique_id128);   /* ncclCommInitRank */

@@ -134,7 +134,7 @@ def lib():
         L.mc_ctx_set_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8
         L.mc_site_count.argtypes = [C.c_void_p]
         L.mc_site_count.restype = C.c_int64
-        L.mc_site_counts.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.mc_site_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_site_counts_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.mc_comm_unique_id.argtypes = [C.c_void_p]
         L.mc_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]

@@ -2227,7 +2227,7 @@ struct mc_ctx {
     TableSlot slots[MC_TABLE_SLOTS];
     int cur = -1;                      // slot of the current table
     int held = -1;                     // slot of the pass handed out last (its records may still be reduced: mc_site_counts)
-    const int32_t *last_seg_contig = nullptr;   // ... and that table's segment -> contig column
+    DevTable last_T;                   // ... and that table
     bool in_rerun = false;             // mc_wait_records is re-running a pass synchronously
     hipStream_t up_stream = nullptr;   // H2D of tables
     int64_t res_rows = 0, res_segs = 0, res_reads = 0;     // mc_ctx_reserve_tables
@@ -3034,7 +3034,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
     if (c->ab_count) { if (int rc = sync_pass_streams(c)) return rc; }   // pipelined passes share the scratch: let them finish
     if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
-    c->last_seg_contig = T.seg_contig;
+    c->last_T = T;
     if (!c->in_rerun) c->held = c->cur;                                   // (a re-run inside mc_wait_records: held by the caller)
 
     free_pool(c->lit_allocs);
@@ -3349,7 +3349,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     if (b.slot >= 0) {
         c->slots[b.slot].refs -= 1;
         c->held = b.slot;
-        c->last_seg_contig = c->slots[b.slot].T.seg_contig;
+        c->last_T = c->slots[b.slot].T;
     }
     const Counters st = *b.st_host;
     const bool special = st.overflow || st.n_irregular;
@@ -3474,17 +3474,32 @@ __global__ void k_site_fill(int32_t *cnt, int64_t *first, int64_t n_sites) {
     if (i < n_sites) first[i] = INT64_MAX;
 }
 
-// one thread per flush record: scored, unskipped records add to their site (label 'm...' <=> p >= 0.5, :200)
-__global__ void k_site_counts(DevRef R, DevRecords O, int64_t n, const int32_t *__restrict__ seg_contig, int64_t row_offset,
+// one thread per flush record: scored, unskipped records add to their site (label 'm...' <=> p >= 0.5, :200).  make_bed
+// keys a row on its chrom column, and that is the contig of the row that CLOSED the window (R8, :216): a record closed by a
+// row of another contig is no site of the numbering -- counted in status[2] and left to the caller (a handful per file: the
+// last window before a contig switch).
+__global__ void k_site_counts(DevRef R, DevRecords O, int64_t n, DevTable T, int tail_contig, int64_t row_offset,
                               int32_t *__restrict__ cnt, int64_t *__restrict__ first, int64_t n_sites,
                               unsigned long long *__restrict__ status) {
     const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint32_t info = O.info[j];
     if (info & MC_I_TOO_MANY) return;
+    const int site_contig = T.seg_contig[O.site_seg[j]];
+    const int64_t cr = O.close_row[j];
+    int close_contig = tail_contig;
+    if (cr < T.n_rows) {
+        int lo = 0, hi = T.n_seg - 1;                               // last segment that begins at or before the closing row
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (T.seg_begin[mid] <= cr) lo = mid; else hi = mid - 1;
+        }
+        close_contig = T.seg_contig[lo];
+    }
+    if (close_contig != site_contig) { atomicAdd(&status[2], 1ull); return; }
     const double p = O.prob[j];
     if (p != p) { atomicAdd(&status[0], 1ull); return; }           // scored by the host (edge records): added by the caller
-    const int64_t s = site_number(R, seg_contig[O.site_seg[j]], (info & MC_I_REV) ? 1 : 0, O.site_pos[j]);
+    const int64_t s = site_number(R, site_contig, (info & MC_I_REV) ? 1 : 0, O.site_pos[j]);
     if (s < 0) { atomicAdd(&status[1], 1ull); return; }
     atomicAdd(&cnt[n_sites + s], 1);
     if (p >= 0.5) atomicAdd(&cnt[s], 1);
@@ -3507,7 +3522,7 @@ static int ensure_site_buffers(mc_ctx *c) {
 
 extern "C" int64_t mc_site_count(mc_ctx *c) { return c->R.n_sites; }
 
-extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int64_t *n_pending) {
+extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig) {
     HIP_TRY(hipSetDevice(c->device));
     if (!c->R.mf) {
         mc_set_error("mc_site_counts: no reference set");
@@ -3516,15 +3531,15 @@ extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int64_t *n_pending)
     if (int rc = ensure_site_buffers(c)) return rc;
     const int64_t ns = c->R.n_sites, n = c->last_n;
     unsigned long long *status = nullptr;
-    HIP_TRY(hipMalloc((void **)&status, 16));
-    HIP_TRY(hipMemsetAsync(status, 0, 16, c->stream));
+    HIP_TRY(hipMalloc((void **)&status, 24));
+    HIP_TRY(hipMemsetAsync(status, 0, 24, c->stream));
     hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
     if (n > 0)
         hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->R, c->O, n,
-                           c->last_seg_contig ? c->last_seg_contig : (const int32_t *)c->T.seg_contig, row_offset, c->site_cnt,
+                           c->last_T.seg_contig ? c->last_T : c->T, (int)tail_contig, row_offset, c->site_cnt,
                            c->site_first, ns, status);
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, status, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     (void)hipFree(status);
@@ -3533,6 +3548,7 @@ extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int64_t *n_pending)
         return -14;
     }
     if (n_pending) *n_pending = (int64_t)h[0];
+    if (n_cross_contig) *n_cross_contig = (int64_t)h[2];
     return 0;
 }
 

@@ -201,11 +201,13 @@ class Device(object):
     def comm_destroy(self):
         lib().mc_comm_destroy(self._ctx)
 
-    def site_counts(self, row_offset=0):
+    def site_counts(self, row_offset=0, tail_contig=-1):
         """Per-site counts of the last run's records, on the device.  Returns how many records the host scored itself
-        (NaN probability on the device): add those with site_counts_add."""
-        pending = C.c_int64(0)
-        check(lib().mc_site_counts(self._ctx, int(row_offset), C.byref(pending)))
+        (NaN probability on the device): add those with site_counts_add.  Records closed by a row of another contig than
+        their site's are left out too (self.n_cross_contig; make_bed.cross_contig_records lists them)."""
+        pending, cross = C.c_int64(0), C.c_int64(0)
+        check(lib().mc_site_counts(self._ctx, int(row_offset), int(tail_contig), C.byref(pending), C.byref(cross)))
+        self.n_cross_contig = cross.value
         return pending.value
 
     def site_counts_add(self, site, is_meth, first_row):

@@ -67,14 +67,19 @@ def _lookup_quality(read2qual, name):
 
 
 def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list, n_threads=0,
-            exact_range=False):
+            exact_range=False, ref=None, quiet=False):
     """Parse + mark: the host-side pre-pass.  Returns a Prepared; `fatal` holds the exception the
-    reference would hit at table row `len(table)` (the table is cut there)."""
+    reference would hit at table row `len(table)` (the table is cut there).  `ref`: a MarkedReference to go on
+    with (the shards of one file share it); quiet: the "could not find sequence" lines are kept in P.messages
+    instead of being printed."""
     P = Prepared()
-    ref = MarkedReference(fasta_input, base, motif, positions_list)
+    if ref is None:
+        ref = MarkedReference(fasta_input, base, motif, positions_list)
     table = _lib.parse_eventalign(tsv_input, startline, endline, ref.names, n_threads, exact_range=exact_range)
-    for name in table.unknown:
-        print('Error: could not find sequence for reference contig', name)       # :159
+    P.messages = ['Error: could not find sequence for reference contig ' + name for name in table.unknown]   # :159
+    if not quiet:
+        for line in P.messages:
+            print(line)
     P.fatal = None
     qual_obj = [None] * table.n_reads
     cut_seg = None
@@ -143,6 +148,7 @@ class Finisher(object):
             self.model_keys = None
         self.signals = {bm: {} for bm in self.table.values()} if train else None
         self.contexts = {bm: {} for bm in self.table.values()} if train else None
+        self.host_scored = {}   # record -> probability, for the records the host had to score itself (edge contexts)
         self.blobs = []         # emitted rows as text (bytes), in order
         self.num_observations = 0
         self.pos_set, self.multi, self.w_skips, self.skipped = set(), set(), set(), set()
@@ -211,6 +217,14 @@ class Finisher(object):
         self._count(done_to)
         return stop_exc
 
+    def host_prob(self, rec):
+        """Probability per record (one row per record), the host-scored ones filled in."""
+        r = rec.by_record()
+        p = np.array(r.prob[:r.n], dtype=np.float64)
+        for j, v in self.host_scored.items():
+            p[j] = v
+        return p
+
     def _count(self, n):
         """The four sets of :184-185,:234-239,:247-248 over records [0, n), vectorised (set sizes only)."""
         info = self._info[:n]
@@ -260,6 +274,7 @@ class Finisher(object):
                             dev = self.device if self.device is not None else get_device()
                             p1 = dev.mlp_forward(np.array([diffs + [float(qual)]], dtype=np.float64),
                                                  np.array([mi], dtype=np.uint8))[0]
+                            self.host_scored[j] = float(p1)
                         elif len(context) > half + 1 and ord(context[half + 1]) != want:
                             raise AssertionError('device and host disagree on the sub-model of %s' % line)
                         if p1 >= 0.5:
@@ -288,6 +303,160 @@ class Finisher(object):
         return None
 
 
+STREAM_SHARD_BYTES = 128 << 20      # eventalign text per shard of a streamed file (~10^6 rows)
+
+
+def head_contig(P, qual_thresh):
+    """Contig id of the first row of P.table that passes the filters (:167-168), or None: the row that closes the last
+    window of the table before it (R6) and supplies that record's chrom column (R8)."""
+    t = P.table
+    for seg in range(t.n_seg):
+        if P.qual[t.seg_read[seg]] < qual_thresh:
+            continue
+        r0, r1 = int(t.seg_row_begin[seg]), int(t.seg_row_begin[seg + 1])
+        if ((t.flags[r0:r1] & _lib.F_MODEL_N) == 0).any():
+            return int(t.seg_contig[seg])
+    return None
+
+
+class _Unstreamable(Exception):
+    """The file needs the one-table path (an exit path of the reference, a read name in two shards, ...)."""
+
+
+def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base, motif,
+                    positions_list, n_shards=None, device=None):
+    """Predict mode over a whole file, as the reference's batch loop (:140-148) streams it -- here in shards cut at read
+    starts (a window never spans two reads, :179,:242): a parser thread fills pinned tables while the main thread keeps
+    uploads and passes in flight on the GPU (mc_ctx_upload_table_async / mc_extract_features_async, two passes in flight)
+    and formats the rows of the shards that come back; parse, H2D, kernels, D2H and formatting overlap.
+    -> (text of all rows, counter lines, messages) or raises _Unstreamable: nothing has been written then."""
+    import os
+    import queue
+    import threading
+    dev = device if device is not None else get_device()
+    lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
+    if n_shards is None:
+        n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or max(1, min(64, (hi - lo) // STREAM_SHARD_BYTES))
+    if n_shards < 2:
+        raise _Unstreamable('one shard')
+    cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
+    pieces = [(cuts[i], cuts[i + 1]) for i in range(n_shards) if cuts[i + 1] > cuts[i]]
+    if len(pieces) < 2:
+        raise _Unstreamable('one shard')
+    import contextlib
+    import io
+    ref = MarkedReference(fasta_input, base, motif, positions_list)
+    ref.quiet = True                   # (an exit path sends the file to the one-table path, which prints)
+    _, weights, _, soc = submodel_setup(modelset, base)
+    if weights[0].kind == 'forest':
+        raise _Unstreamable('the forest classifier runs one pass at a time')
+    dev.set_classifier(weights, soc)
+
+    L = _lib.lib()
+    L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
+    q = queue.Queue(maxsize=2)
+    stop_parsing = threading.Event()
+
+    def parser():
+        try:
+            for lo_i, hi_i in pieces:
+                if stop_parsing.is_set():
+                    break
+                q.put(prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True,
+                              ref=ref, quiet=True))
+            q.put(None)
+        except BaseException as e:                             # noqa
+            q.put(e)
+
+    th = threading.Thread(target=parser, daemon=True)
+    th.start()
+    blobs, messages, names_seen = [], [], set()
+    totals = dict(obs=0, multi=0, wskips=0, skipped=0)
+    positions = []
+    in_flight = []                  # (P, tail name) of the passes enqueued, oldest first
+    marked = [-1]
+
+    def hand_out():
+        P, tail = in_flight.pop(0)
+        rec = dev.wait()
+        fin = Finisher(P, k, base, False, modelset=modelset, device=dev, tail_chrom=tail)
+        with contextlib.redirect_stdout(io.StringIO()):        # (its exit paths print; the one-table path will)
+            stop = fin.run(rec)
+        if stop is not None:
+            raise _Unstreamable('an exit path of the reference')
+        blobs.append(fin.text())
+        n = rec.n
+        too = (rec.info[:n] & _I.I_TOO_MANY) != 0
+        positions.append(np.unique(rec.site_pos[:n][~too]))
+        totals['obs'] += fin.num_observations
+        totals['multi'] += len(fin.multi) if fin._n_multi is None else fin._n_multi
+        totals['wskips'] += len(fin.w_skips) if fin._n_wskips is None else fin._n_wskips
+        totals['skipped'] += len(fin.skipped) if fin._n_skipped is None else fin._n_skipped
+
+    def enqueue(P, tail_id):
+        n_marked = len(ref.meth)                               # (the parser thread marks contigs as they first appear)
+        if n_marked != marked[0]:                              # a contig marked since the last upload: new masks
+            while in_flight:
+                hand_out()
+            dev.set_reference(ref.device_arrays())
+            marked[0] = n_marked
+        dev.upload_table_async(P.table, P.qual)
+        dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=True)
+
+    try:
+        prev = None
+        while True:
+            P = q.get()
+            if isinstance(P, BaseException):
+                raise P
+            if P is not None:
+                if P.fatal is not None:
+                    raise _Unstreamable('an exit path of the reference')
+                if names_seen.intersection(P.table.read_names):
+                    raise _Unstreamable('a read name in two shards')       # `last_read` would cross the cut (:161)
+                names_seen.update(P.table.read_names)
+                messages.extend(P.messages)
+                if P.table.n_rows == 0:
+                    continue
+                head = head_contig(P, qual_thresh)
+                if head is None:
+                    raise _Unstreamable('a shard without a row that passes the filters')
+            if prev is not None:
+                tail_id = head if P is not None else -1
+                while len(in_flight) >= 2:
+                    hand_out()
+                enqueue(prev, tail_id)
+                in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None))
+            prev = P
+            if P is None:
+                break
+        while in_flight:
+            hand_out()
+    except BaseException:
+        stop_parsing.set()
+        try:
+            while True:
+                q.get_nowait()
+        except queue.Empty:
+            pass
+        try:
+            dev.sync()
+            while in_flight:                                   # nothing may stay in flight on the shared device
+                in_flight.pop(0)
+                dev.wait()
+        except Exception:                                      # noqa
+            pass
+        raise
+    finally:
+        L.mc_host_pool_config(0, -1)
+    n_pos = len(np.unique(np.concatenate(positions))) if positions else 0
+    counters = ['thread finished processing...:', '%d observations' % totals['obs'], '%d positions' % n_pos,
+                '%d regions with multiple methylated bases' % totals['multi'],
+                '%d observations with skips included' % totals['wskips'],
+                '%d observations with too many skips' % totals['skipped']]
+    return b''.join(blobs), counters, messages
+
+
 def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, classifier,
                      startline, endline=None, train=False, pos_label=None, base=None, motif=None,
                      positions_list=None):
@@ -301,6 +470,24 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
     modelset = None
     if not train:
         modelset = load_model_file(modelfile)                                     # :123-130
+
+    if not train and startline == 0 and endline is not None and os.environ.get('MCALLER_NO_STREAM') is None:
+        # a whole file in predict mode: streamed through the GPU in shards; whatever the shards cannot reproduce
+        # (the reference's exit paths, a read name that comes back later) takes the one-table path below from scratch
+        try:
+            text, counters, messages = stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh,
+                                                       modelset, endline, base, motif, positions_list)
+        except _Unstreamable:
+            pass
+        else:
+            for line in messages:
+                print(line)
+            write_text(text, tsv_output)                                          # :293
+            if timing:
+                print('[mcaller_amd timing] streamed in shards: total %.3f s' % (time.perf_counter() - t_start), file=sys.stderr)
+            for line in counters:                                                 # :295-301
+                print(line)
+            return None
 
     P = prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list)
     t_prep = time.perf_counter()

@@ -2,8 +2,8 @@
 """mCaller command line on MI355X -- same flags, output naming and messages as the reference's mCaller.py:118-184.
 
 `-t/--threads` is accepted for compatibility: the GPU path is one process per GPU and always produces the reference's
-single-process (`-t 1`) row order; with `-t N>1` the rows are passed through the same `sort | uniq` the reference applies
-after its workers (mCaller.py:106), in the C locale.
+single-process (`-t 1`) row order; with `-t N>1` the rows are passed through the `sort -n -k2 | uniq` the reference applies
+after its workers (mCaller.py:106): numeric prefix of the read name, then the whole line in the C locale.
 """
 import glob
 import os
@@ -22,80 +22,118 @@ def pos2label(positions):
             for pos in open(positions, 'r').read().split('\n') if len(pos.split()) > 1}
 
 
-def distribute_threads(positions_list, motif, tsvname, read2qual, refname, num_refs, base, mod, nprocs, nvariables, train,
-                       modelfile, skip_thresh, qual_thresh, classifier, training_tsv, plot_training, n_gpus=1, bed=None):
-    """mCaller.py:25-115 without the process fan-out: one GPU pass, then the same file naming."""
-    outdir = '/'.join(tsvname.split('/')[:-1])
-    if len(outdir) > 1:
-        outdir = outdir + '/'
-    print(outdir)
-    if not train:
-        tsv_output = '.'.join(tsvname.split('.')[:-1]) + '.diffs.' + str(nvariables)
-        training_pos_dict = None
-    else:
-        tsv_output = '.'.join(tsvname.split('.')[:-1]) + '.diffs.' + str(nvariables) + '.train'
-        if training_tsv:                                    # mCaller.py:35-36
+def numeric_key_k2(line):
+    """What `sort -n -k2` compares first (the reference merges its workers' files with `sort -n -k2 | uniq`, mCaller.py:106):
+    the key runs from the end of field 1 to the end of the line; its leading number -- blanks, an optional '-', digits,
+    an optional '.' and digits -- compares numerically, anything else counts as 0.  Read names are UUIDs that often start
+    with digits: '2289b392-...' sorts as 2289, 'cc1d...' as 0."""
+    from decimal import Decimal
+    i, n = 0, len(line)
+    while i < n and line[i:i + 1] not in (b' ', b'\t'):       # field 1
+        i += 1
+    while i < n and line[i:i + 1] in (b' ', b'\t'):
+        i += 1
+    j = i
+    if j < n and line[j:j + 1] == b'-':
+        j += 1
+    d0 = j
+    while j < n and line[j:j + 1].isdigit():
+        j += 1
+    if j < n and line[j:j + 1] == b'.':
+        j2 = j + 1
+        while j2 < n and line[j2:j2 + 1].isdigit():
+            j2 += 1
+        if j2 > j + 1:
+            j = j2
+    if j == d0:
+        return Decimal(0)
+    return Decimal(line[i:j].decode('ascii'))
+
+
+def merge_like_sort_uniq(paths, out_path):
+    """`sort -n -k2 | uniq` over the tmp files: numeric key of field 2, ties by the whole line (bytes, the C locale's
+    order -- the reference's last-resort order depends on the user's locale), duplicates dropped."""
+    lines = set()
+    for path in paths:
+        with open(path, 'rb') as fh:
+            lines.update(fh.read().splitlines(True))
+        os.remove(path)
+    with open(out_path, 'wb') as out:
+        out.writelines(sorted(lines, key=lambda l: (numeric_key_k2(l), l)))
+
+
+class Run(object):
+    """One invocation: what mCaller.py:25-115 does around extract_features, without its process fan-out (the GPU path is one
+    process per GPU and writes the single-process row order; `-t` only selects the reference's merge step)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self.stem = '.'.join(self.tsv.split('.')[:-1])
+        self.output = self.stem + '.diffs.' + str(self.k) + ('.train' if self.train else '')      # mCaller.py:31-35
+
+    def extract(self):
+        """-> (signals, contexts) in train mode, None else; leaves `<stem>.diffs.<k>[.train].tmp0` behind."""
+        if self.training_tsv:                               # mCaller.py:35-36: the matrix comes from an earlier run
             from .load_mCaller_data import tsv2matrix
-            ret = tsv2matrix(training_tsv, base)
+            return tsv2matrix(self.training_tsv, self.base)
+        if not self.train and (self.n_gpus > 1 or self.bed):     # reads shard over the GPUs of the node (multi_gpu.py)
+            from .multi_gpu import extract_features_sharded
+            if self.bed:
+                self.bed = dict(self.bed, path=self.output.split('.')[0] + '.methylation.summary.bed')   # make_bed.py:190
+            self.sharded = extract_features_sharded(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh,
+                                                    self.qual_thresh, self.modelfile, self.base, self.motif, self.positions,
+                                                    self.n_gpus, bed=self.bed)
+            if self.sharded:
+                return None
+        labels = pos2label(self.positions) if self.train else None
+        return extract_features(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh, self.qual_thresh,
+                                self.modelfile, self.classifier, 0, endline=os.path.getsize(self.tsv), train=self.train,
+                                pos_label=labels, base=self.base, motif=self.motif, positions_list=self.positions)
+
+    def collect(self):
+        """The tmp file(s) become `<stem>.diffs.<k>[.train]` (mCaller.py:94-109)."""
+        if self.training_tsv:
+            return
+        tmp = glob.glob(self.stem + '*.tmp[0-9]*')
+        if self.threads > 1:
+            print('Merging files...')
+            merge_like_sort_uniq(tmp, self.output)
         else:
-            training_pos_dict = pos2label(positions_list)
+            os.rename(tmp[0], self.output)
 
-    print('%d contigs' % num_refs)
-    print('%d threads' % nprocs)
-    sharded = False
-    if not training_tsv and not train and (n_gpus > 1 or bed):   # reads shard over the GPUs of the node (multi_gpu.py)
-        from .multi_gpu import extract_features_sharded
-        if bed:
-            bed = dict(bed, path=tsv_output.split('.')[0] + '.methylation.summary.bed')       # make_bed.py:190
-        sharded = extract_features_sharded(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile,
-                                           base, motif, positions_list, n_gpus, bed=bed)
-        ret = None
-    if not training_tsv and not sharded:
-        bytesize = os.path.getsize(tsvname)
-        ret = extract_features(tsvname, refname, read2qual, nvariables, skip_thresh, qual_thresh, modelfile, classifier, 0,
-                               endline=bytesize, train=train, pos_label=training_pos_dict, base=base, motif=motif,
-                               positions_list=positions_list)
-    print('Finished extracting signals')
-    tmpfis = [] if training_tsv else glob.glob('.'.join(tsvname.split('.')[:-1]) + '*.tmp[0-9]*')
-    if training_tsv:
-        pass
-    elif nprocs > 1:
-        print('Merging files...')
-        lines = set()
-        for tmpfi in tmpfis:
-            with open(tmpfi, 'rb') as fh:
-                lines.update(fh.read().splitlines(True))
-            os.remove(tmpfi)
-        with open(tsv_output, 'wb') as out:                 # `sort -n -k2 | uniq`: field 2 is not numeric, so the
-            out.writelines(sorted(lines))                   # order is the last-resort whole-line comparison
-    else:
-        os.rename(tmpfis[0], tsv_output)
-
-    if bed and not sharded and not train and not training_tsv:
-        # the sharded path declined (a read name in two pieces, an exit path ...): the BED comes from the rows just written
+    def summarise(self):
+        """--bed without a sharded run (it declined: a read name in two pieces, an exit path ...) and --bed_vo: from the rows
+        just written -- the concatenated file IS the gather of the workers' call records."""
+        if not self.bed or self.train or self.training_tsv:
+            return
         from . import make_bed
-        make_bed.aggregate_by_pos(tsv_output, bed['path'], bed['min_depth'], bed['mod_threshold'], None, False, False, False, None)
+        if not self.sharded:
+            make_bed.summarise_diffs(self.output, self.bed['path'], self.bed['min_depth'], self.bed['mod_threshold'])
+        if self.bed.get('vo'):
+            # make_bed.py --vo's per-read probability lists (:114-115); the columns before them must be the reduced ones
+            reduced = open(self.bed['path']).read().splitlines() if os.path.exists(self.bed['path']) else None
+            make_bed.summarise_diffs(self.output, self.bed['path'], self.bed['min_depth'], self.bed['mod_threshold'],
+                                     with_probs=True, quiet=True)
+            if reduced is not None:
+                verbose = [line.rsplit('\t', 1)[0] for line in open(self.bed['path']).read().splitlines()]
+                if verbose != reduced:
+                    raise RuntimeError('the per-site reduction and the rows written disagree on the BED file')
 
-    if bed and bed.get('vo') and not train and not training_tsv:
-        # --bed_vo: the per-read probability lists of make_bed.py --vo (:114-115) come from the rows just written -- the
-        # concatenated file IS the gather of the workers' call records; the columns before them must be the reduced ones
-        from . import make_bed
-        reduced = open(bed['path']).read().splitlines() if os.path.exists(bed['path']) else None
-        import contextlib
-        import io
-        with contextlib.redirect_stdout(io.StringIO()):      # (make_bed.py prints the file name once per row, :153)
-            make_bed.aggregate_by_pos(tsv_output, bed['path'], bed['min_depth'], bed['mod_threshold'], None, False, True, False, None)
-        if reduced is not None:
-            verbose = [line.rsplit('\t', 1)[0] for line in open(bed['path']).read().splitlines()]
-            if verbose != reduced:
-                raise RuntimeError('the per-site reduction and the rows written disagree on the BED file')
-
-    if train:
-        print('Training...')
-        from .train_model import train_classifier
-        signal_mat, context_array = ret
-        train_classifier(signal_mat, context_array, modelfile, classifier, plot_training)
-        print('Finished training')
+    def go(self):
+        outdir = '/'.join(self.tsv.split('/')[:-1])
+        print(outdir + '/' if len(outdir) > 1 else outdir)
+        print('%d contigs' % self.num_refs)
+        print('%d threads' % self.threads)
+        self.sharded = False
+        matrices = self.extract()
+        print('Finished extracting signals')
+        self.collect()
+        self.summarise()
+        if self.train:
+            print('Training...')
+            from .train_model import train_classifier
+            train_classifier(matrices[0], matrices[1], self.modelfile, self.classifier, self.plot_training)
+            print('Finished training')
 
 
 # The reference's command line (mCaller.py:122-141), flag for flag and help text for help text, as data; then this build's
@@ -149,41 +187,43 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.gpus is None:
-        args.gpus = int(os.environ.get('MCALLER_GPUS', '1'))
-    mod = {'A': 'm6A', 'C': 'm5C'}.get(args.base)                     # mCaller.py:144-150
-    if mod is None:
+    n_gpus = args.gpus if args.gpus is not None else int(os.environ.get('MCALLER_GPUS', '1'))
+    mods = {'A': 'm6A', 'C': 'm5C'}                                   # mCaller.py:144-150
+    if args.base not in mods:
         print('classification only available for A or C bases so far')
         sys.exit(0)
-
-    if not args.modelfile:
-        modelfile = (os.path.dirname(os.path.realpath(sys.argv[0])) + '/model_' + args.classifier + '_' +
-                     str(args.num_variables) + '_' + mod + '.pkl')
-    else:
-        modelfile = args.modelfile
-    if not args.train:
-        assert os.path.isfile(modelfile), 'model file not found at ' + modelfile
-
-    if args.motif and len(args.motif) == 1:
-        base = args.motif
-    else:
-        base = args.base
-
+    modelfile = args.modelfile or '%s/model_%s_%d_%s.pkl' % (os.path.dirname(os.path.realpath(sys.argv[0])), args.classifier,
+                                                              args.num_variables, mods[args.base])
+    assert args.train or os.path.isfile(modelfile), 'model file not found at ' + modelfile
     assert (args.skip_thresh < args.num_variables / 2), ('too many skips with only ' + str(args.num_variables) +
                                                          ' variables - try < half')
     assert os.path.isfile(args.fastq), 'fastq file not found at ' + args.fastq
-    read2qual = extract_read_quality(args.fastq)
+    # read qualities (native FASTQ reader) and the contig count, side by side
+    import threading
+    box = {}
 
+    def qualities():
+        try:
+            box['r2q'] = extract_read_quality(args.fastq)
+        except BaseException as e:                                   # noqa
+            box['err'] = e
+    th = threading.Thread(target=qualities)
+    th.start()
     try:
         num_refs = len(read_fasta(args.reference))
     except IOError:
+        th.join()
         print('reference file missing')
         sys.exit(0)
-
-    distribute_threads(args.positions, args.motif, args.tsv, read2qual, args.reference, num_refs, base, mod, args.threads,
-                       args.num_variables, args.train, modelfile, args.skip_thresh, args.qual_thresh, args.classifier,
-                       args.training_tsv if args.training_tsv else None, args.plot_training, n_gpus=max(1, args.gpus),
-                       bed=dict(min_depth=args.bed_min_depth, mod_threshold=args.bed_mod_threshold, vo=args.bed_vo) if args.bed else None)
+    th.join()
+    if 'err' in box:
+        raise box['err']
+    bed = dict(min_depth=args.bed_min_depth, mod_threshold=args.bed_mod_threshold, vo=args.bed_vo) if args.bed else None
+    Run(tsv=args.tsv, reference=args.reference, read2qual=box['r2q'], num_refs=num_refs, positions=args.positions,
+        motif=args.motif, base=args.motif if (args.motif and len(args.motif) == 1) else args.base, k=args.num_variables,
+        threads=args.threads, train=args.train, training_tsv=args.training_tsv or None, modelfile=modelfile,
+        skip_thresh=args.skip_thresh, qual_thresh=args.qual_thresh, classifier=args.classifier,
+        plot_training=args.plot_training, n_gpus=max(1, n_gpus), bed=bed).go()
 
 
 if __name__ == '__main__':

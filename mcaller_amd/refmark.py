@@ -68,8 +68,9 @@ def methylate_motifs(ref_seq, motif, meth_base):
     return ref_seq.replace(motif, 'M'.join(motif.split(meth_base)))
 
 
-def methylate_positions(ref_seq, positions, meth_base):
-    """extract_contexts.py:45-56; prints and exits like the reference on a wrong base."""
+def methylate_positions(ref_seq, positions, meth_base, quiet=False):
+    """extract_contexts.py:45-56; prints and exits like the reference on a wrong base (quiet: exits only -- a caller that
+    will go through the same contig again on another path lets that path do the printing)."""
     buf = bytearray(ref_seq, 'latin1')
     b, m = ord(meth_base), ord('M')
     for pos in positions:
@@ -78,8 +79,9 @@ def methylate_positions(ref_seq, positions, meth_base):
         if buf[pos] == b or buf[pos] == m:          # IndexError past the contig end, like the reference
             buf[pos] = m
         else:
-            print('Base {} does not correspond to methylated base - check reference positions are 0-based'
-                  ' - quitting thread now'.format(pos))
+            if not quiet:
+                print('Base {} does not correspond to methylated base - check reference positions are 0-based'
+                      ' - quitting thread now'.format(pos))
             sys.exit(0)
     return buf.decode('latin1')
 
@@ -93,16 +95,17 @@ def _positions_for(positions, contig, strand_char):
     return out
 
 
-def methylate_references(ref_seq, base, motif=None, positions=None, train=False, contig=None):
+def methylate_references(ref_seq, base, motif=None, positions=None, train=False, contig=None, quiet=False):
     """extract_contexts.py:60-73 -> (meth_fwd, meth_rev)."""
     if not positions and motif:
         meth_fwd = methylate_motifs(ref_seq, motif, base)
         meth_rev = methylate_motifs(ref_seq, revcomp(motif), base_comps[base])
     elif positions:
-        meth_fwd = methylate_positions(ref_seq, _positions_for(positions, contig, '+'), base)
-        meth_rev = methylate_positions(ref_seq, _positions_for(positions, contig, '-'), base_comps[base])
+        meth_fwd = methylate_positions(ref_seq, _positions_for(positions, contig, '+'), base, quiet)
+        meth_rev = methylate_positions(ref_seq, _positions_for(positions, contig, '-'), base_comps[base], quiet)
     else:
-        print('no motifs or positions specified')
+        if not quiet:
+            print('no motifs or positions specified')
         sys.exit(0)
     return meth_fwd, meth_rev
 
@@ -126,6 +129,8 @@ class MarkedReference(object):
         self.names = [r[0] for r in self.records]
         self.base, self.motif, self.positions_list = base, motif, positions_list
         self.meth = {}                                  # contig id -> (meth_fwd, meth_rev)
+        self.quiet = False                              # the exit paths of the marking do not print
+        self._arrays = (None, None)
 
     def first_index(self):
         idx = {}
@@ -137,11 +142,19 @@ class MarkedReference(object):
         if contig_id not in self.meth:
             name, seq = self.records[contig_id]
             self.meth[contig_id] = methylate_references(seq.upper(), self.base, motif=self.motif,
-                                                        positions=self.positions_list, contig=name)
+                                                        positions=self.positions_list, contig=name, quiet=self.quiet)
         return self.meth[contig_id]
 
     def device_arrays(self):
         """Concatenated arrays for mc_ref_view (unmarked contigs: empty sequence, all-zero masks)."""
+        key = tuple(sorted(self.meth))
+        if self._arrays[0] == key:
+            return self._arrays[1]
+        out = self._device_arrays()
+        self._arrays = (key, out)
+        return out
+
+    def _device_arrays(self):
         n = len(self.records)
         contig_len = np.zeros(n, dtype=np.int64)
         seq_off = np.zeros(n, dtype=np.int64)

@@ -156,6 +156,8 @@ def export_models(outdir):
             arrays[key + '.b1'] = np.ascontiguousarray(est.intercepts_[0], dtype=np.float64)
             arrays[key + '.W2'] = np.ascontiguousarray(est.coefs_[1], dtype=np.float64)
             arrays[key + '.b2'] = np.ascontiguousarray(est.intercepts_[1], dtype=np.float64)
+        if is_dict:
+            arrays['__is_dict__'] = np.array([1], dtype=np.uint8)     # (a dict with the single key 'general' stays a dict)
         stem = fn[:-4]
         pkg_models = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'mcaller_amd', 'models')   # shipped with the package
         os.makedirs(pkg_models, exist_ok=True)

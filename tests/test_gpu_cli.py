@@ -259,3 +259,45 @@ def test_cli_bed_from_the_per_site_reduction(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         make_bed.main(['-f', diffs, '-d', '3', '-t', '0.3', '--vo'])
     assert got_vo == open(bed_path).read() and got_vo != want and got_vo.count('\n') == want.count('\n')
+
+
+def test_cli_bed_over_several_contigs_equals_make_bed(tmp_path):
+    """`--bed` on files whose reads lie on several contigs: a window closed by a row of the NEXT contig is written with that
+    contig in its chrom column (R8), so make_bed files it under a (contig, position) that is no marked site -- the
+    reduction leaves such records to the host (mc_site_counts: n_cross_contig) and the BED equals make_bed's on the rows."""
+    from oracle import casegen
+    from mcaller_amd import mCaller, make_bed
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
+    n_done = n_cross = 0
+    for i in range(40):
+        case = casegen.gen_case(3000000 + i, flavour='multi_contig')
+        a = case['args']
+        if a['train'] or case['expected']['outcome'] != 'ok' or a['model'] != 'r95' or not case['expected']['text']:
+            continue
+        d = tmp_path / ('m%d' % i)
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        argv = ['-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model, '-b', a['base'],
+                '-s', str(a['skip_thresh']), '-q', str(a['qual_thresh']), '--bed', '--bed_min_depth', '1',
+                '--bed_mod_threshold', '0.0']
+        argv += ['-p', paths['positions']] if paths['positions'] else ['-m', a['motif']]
+        os.environ['MCALLER_SHARD_DEVICES'] = '0'
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                mCaller.main(argv)
+        finally:
+            del os.environ['MCALLER_SHARD_DEVICES']
+        diffs = paths['tsv'][:-4] + '.diffs.6'
+        assert open(diffs).read() == case['expected']['text']
+        bed = os.path.join(str(d), 'case.methylation.summary.bed')
+        got = open(bed).read()
+        with contextlib.redirect_stdout(io.StringIO()):
+            make_bed.main(['-f', diffs, '-d', '1', '-t', '0.0'])
+        assert got == open(bed).read(), case['seed']
+        n_done += 1
+        chroms = {}
+        for line in case['expected']['text'].splitlines():
+            f = line.split('\t')
+            chroms.setdefault((f[1], f[2], f[5]), set()).add(f[0])
+        n_cross += sum(1 for v in chroms.values() if len(v) > 1)
+    assert n_done >= 10

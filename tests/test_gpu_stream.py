@@ -189,3 +189,118 @@ def test_parser_tables_come_from_the_pinned_pool(tmp_path):
         assert first in blocks                           # the blocks of the freed table were handed out again
     finally:
         L.mc_host_pool_config(0, -1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# extract_features over a file, streamed in shards (mcaller_amd.extract_contexts.stream_features)
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_extract(paths, args, monkeypatch, shards):
+    """extract_features (the drop-in) on a case's files -> (outcome, text written, stdout lines)."""
+    import contextlib
+    import io
+    import os
+    from mcaller_amd.extract_contexts import extract_features
+    from mcaller_amd.read_qual import extract_read_quality
+    if shards:
+        monkeypatch.setenv('MCALLER_STREAM_SHARDS', str(shards))
+        monkeypatch.delenv('MCALLER_NO_STREAM', raising=False)
+    else:
+        monkeypatch.setenv('MCALLER_NO_STREAM', '1')
+    out = '.'.join(paths['tsv'].split('.')[:-1]) + '.diffs.%d.tmp0' % args['k']
+    if os.path.exists(out):
+        os.remove(out)
+    buf = io.StringIO()
+    outcome = 'ok'
+    with contextlib.redirect_stdout(buf):
+        try:
+            r2q = extract_read_quality(paths['fastq'])
+            extract_features(paths['tsv'], paths['fasta'], r2q, args['k'], args['skip_thresh'], args['qual_thresh'],
+                             os.path.join(H.MODELS, H.MODEL_STEMS[args['model']] + '.npz'), 'NN', 0,
+                             endline=os.path.getsize(paths['tsv']), train=False, pos_label=None, base=args['base'],
+                             motif=args['motif'], positions_list=paths['positions'])
+        except SystemExit:
+            outcome = 'exit'
+        except Exception as e:                             # noqa
+            outcome = 'crash:' + type(e).__name__
+    text = open(out).read() if os.path.exists(out) else ''
+    return outcome, text, [l for l in buf.getvalue().split('\n') if l.strip()]
+
+
+def test_streamed_micro_cases_reproduce_the_reference(tmp_path, monkeypatch):
+    """Every committed predict-mode micro-case (all quirk flavours, exit paths, several contigs) through extract_features
+    with the file cut into shards: the bytes written and the printed lines are the reference's (captured in the build
+    container).  Cases the shards cannot reproduce take the one-table path from scratch -- nothing may be printed twice."""
+    bad, n_ok = [], 0
+    for case in H.micro_cases():
+        if case['args']['train']:
+            continue
+        d = tmp_path / ('s%d' % case['seed'])
+        d.mkdir()
+        paths = H.materialise(case, str(d))
+        outcome, text, stdout = _run_extract(paths, case['args'], monkeypatch, shards=3)
+        exp = case['expected']
+        if (exp['outcome'] != 'ok') != (outcome != 'ok'):
+            bad.append((case['seed'], case['flavour'], 'outcome', exp['outcome'], outcome))
+        elif exp['outcome'] != 'ok':
+            if not outcome.startswith('crash') and (exp['text'] or '') != text:
+                bad.append((case['seed'], case['flavour'], 'partial text'))
+        elif (exp['text'] or '') != text:
+            bad.append((case['seed'], case['flavour'], 'text'))
+        elif exp['stdout'] != stdout:
+            bad.append((case['seed'], case['flavour'], 'stdout', exp['stdout'], stdout))
+        else:
+            n_ok += 1
+    assert not bad, '%d differ: %s' % (len(bad), bad[:8])
+    assert n_ok > 150
+
+
+@pytest.mark.parametrize('n_rows,motif,skip,qthresh,shards', [
+    (300000, 'GATC', 0, 0.0, 7),
+    (200000, 'A', 1, 0.0, 5),
+    (250000, 'GATC', 0, 9.0, 16),          # reads filtered by quality: shards whose first reads are skipped whole
+])
+def test_streamed_file_equals_the_one_table_path(tmp_path, monkeypatch, n_rows, motif, skip, qthresh, shards):
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=500000, seed=31)
+    table, qual = synth.make_table(n_rows, seed=n_rows % 97, codes=codes, read_len=(700, 5000))
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    paths['positions'] = None
+    args = dict(k=6, skip_thresh=skip, qual_thresh=qthresh, base='A', motif=motif, model='r95')
+    streamed_calls = []
+    real = ec.stream_features
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        streamed_calls.append(len(out[0]))
+        return out
+    monkeypatch.setattr(ec, 'stream_features', spy)
+    got = _run_extract(paths, args, monkeypatch, shards=shards)
+    assert streamed_calls and streamed_calls[0] > 0            # the shards really went through stream_features
+    want = _run_extract(paths, args, monkeypatch, shards=0)
+    assert got[0] == want[0] == 'ok'
+    assert got[2] == want[2]                                   # the counter lines
+    assert got[1] == want[1] and len(got[1]) > 1000            # the rows, byte for byte
+
+
+def test_streamed_rows_equal_the_python_oracle(tmp_path, monkeypatch):
+    """... and against the literal Python restatement of the reference (pinned to the reference itself) on a small file."""
+    from mcaller_amd import synth
+    from oracle import py_oracle
+    import numpy as np
+    codes = synth.genome(length=200000, seed=8)
+    table, qual = synth.make_table(50000, seed=12, codes=codes, read_len=(500, 2500))
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    paths['positions'] = None
+    args = dict(k=6, skip_thresh=0, qual_thresh=0.0, base='A', motif='GATC', model='r95')
+    outcome, text, stdout = _run_extract(paths, args, monkeypatch, shards=4)
+    assert outcome == 'ok'
+    z = np.load(H.MODELS + '/r95_twobase_model_NN_6_m6A.npz')
+    models = {k: (z[k + '.W1'], z[k + '.b1'], z[k + '.W2'], z[k + '.b2']) for k in ('MG', 'MH')}
+    models['__twobase__'] = True
+    import os
+    res = py_oracle.extract_features_oracle(paths['tsv'], paths['fasta'], py_oracle.read_fastq_quality(paths['fastq']), 6, 0, 0.0,
+                                            models, 0, os.path.getsize(paths['tsv']), base='A', motif='GATC')
+    want = ''.join('\t'.join(r) + '\n' for r in res['rows'])
+    assert text == want and len(res['rows']) > 30
+    assert stdout == [l for l in res['stdout'] if l.strip()] or stdout[-6:] == [l for l in res['stdout'] if l.strip()][-6:]

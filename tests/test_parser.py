@@ -108,3 +108,39 @@ def test_read_cuts_and_exact_ranges(tmp_path):
         if n_parts in (2, 3, 7):
             rows = [p.n_rows for p in parts]
             assert min(rows) > 0.5 * whole.n_rows / n_parts    # balanced
+
+
+def test_thread_counts_follow_the_affinity_mask(tmp_path):
+    """A worker bound to the cores next to its GPU (mc_bind_to_device_numa_node) must not start one parser thread per
+    MACHINE core: with n_threads <= 0 the pieces are counted from sched_getaffinity."""
+    import os
+    from mcaller_amd import synth, _lib
+    codes = synth.genome(length=300000, seed=2)
+    table, _ = synth.make_table(400000, seed=3, codes=codes, read_len=(500, 3000))
+    tsv = str(tmp_path / 'big.eventalign.tsv')
+    synth.write_tsv_native(table, codes, tsv)
+    assert os.path.getsize(tsv) > 40 << 20                    # enough text for > 8 pieces of 4 MB
+    before = os.sched_getaffinity(0)
+    try:
+        for cores in (1, 3, 4):
+            os.sched_setaffinity(0, set(sorted(before)[:cores]))
+            if len(os.sched_getaffinity(0)) != cores:
+                pytest.skip('cannot restrict the affinity mask here')
+            assert _lib.lib().mc_host_cores() == cores
+            t = _lib.parse_eventalign(tsv, 0, os.path.getsize(tsv), ['ecoli_syn'])
+            assert 1 <= t.n_pieces <= cores and t.n_rows == table.n_rows
+            assert (t.pos == table.pos).all() and (t.evmu == table.evmu).all()
+    finally:
+        os.sched_setaffinity(0, before)
+    assert _lib.lib().mc_host_cores() == len(before)
+
+
+def test_native_tsv_writer_equals_the_python_one(tmp_path):
+    from mcaller_amd import synth
+    codes = synth.genome(length=100000, seed=5)
+    table, _ = synth.make_table(30000, seed=8, codes=codes, read_len=(200, 1500))
+    a, b = str(tmp_path / 'a.tsv'), str(tmp_path / 'b.tsv')
+    synth.write_tsv(table, codes, a)
+    for nt in (1, 3, 0):
+        assert synth.write_tsv_native(table, codes, b, n_threads=nt) == os.path.getsize(a)
+        assert open(a, 'rb').read() == open(b, 'rb').read()
