@@ -420,7 +420,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                     continue
                 head = head_contig(P, qual_thresh)
                 if head is None:
-                    raise _Unstreamable('a shard without a row that passes the filters')
+                    continue                                   # no row passes the filters (:167-168): the loop never sees this shard
             if prev is not None:
                 tail_id = head if P is not None else -1
                 while len(in_flight) >= 2:
