@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmcaller_hip.so')
+LIB_PATH = os.environ.get('MCALLER_LIB') or os.path.join(_HERE, 'libmcaller_hip.so')      # (MCALLER_LIB: a variant build, tools/variants.sh)
 
 MC_MAX_K = 8
 F_KMER_EQ, F_MODEL_N, F_SEG_START, F_NAME_START = 1, 2, 4, 8

@@ -9,8 +9,15 @@ SOURCES = ['csrc/mc_device.hip', 'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc
 OUT = os.path.join(HERE, 'libmcaller_hip.so')
 
 
-def build_lib(force=False, verbose=True):
+def build_lib(force=False, verbose=True, out=None, defines=()):
+    """out / defines: a variant build for kernel experiments (tools/variants.sh), e.g. defines=('MC_TILE=2048',)."""
     srcs = [os.path.join(HERE, s) for s in SOURCES]
+    if out is not None:
+        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-pthread', '-o', out]
+        cmd += ['-D' + d for d in defines] + srcs + ['-ldl']
+        subprocess.check_call(cmd)
+        return out
     deps = srcs + [os.path.join(os.path.dirname(HERE), 'include', 'mcaller_hip.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

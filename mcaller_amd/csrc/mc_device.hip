@@ -55,17 +55,11 @@ void mc_set_error(const char *fmt, ...);
 namespace {
 
 #ifndef MC_TILE
-#define MC_TILE 3072
-#endif
-#ifndef MC_NTHREADS
-#define MC_NTHREADS 64
+#define MC_TILE 1024
 #endif
 constexpr int TILE = MC_TILE;       // rows per workgroup tile
-constexpr int NTHREADS = MC_NTHREADS; // k1_scan workgroup: one wave (the per-tile site walk is a single wave's work)
-constexpr int RPT = TILE / NTHREADS;  // rows per thread in the detection pass
-constexpr int NBMAX = NTHREADS / 16; // name-block descriptors staged in LDS per tile (one dword per thread)
-constexpr int NBST = 2;             // ... of which this many get their strand-mask window staged in LDS
-constexpr int BW = NTHREADS;         // words per staged mask window (one per thread)
+constexpr int NBST = 2;             // name blocks of a tile that get a window of their strand mask staged in LDS (k1_scan)
+constexpr int BW = 64;              // words per staged mask window (one per lane)
 constexpr int O_NONE = 15;
 
 // meta byte per staged row: bit0 valid (passes :167-168), bit1 first row of a name block, bits 2..5 offset of
@@ -163,9 +157,7 @@ struct Counters {          // device-side status block
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
-    struct { unsigned long long v; unsigned long long pad[15]; } ticket[NSHARD];   // k1_scan's tile-chunk ticket counters, one
-                                   // per XCD (workgroups are dealt to the XCDs round-robin), each on its own 128-byte line
-    unsigned long long prof[8];   // MC_PROFILE builds: cycles per phase of k1_scan, summed over workgroups
+    unsigned long long end_of_head;   // (k_pack copies everything before this field to the host)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -206,20 +198,21 @@ __device__ __forceinline__ unsigned char comp_char(unsigned char c) {
 // it -- the neighbour lane's last row (one shuffle), the wave's first lane re-reads its predecessor -- and the flags are
 // OR-ed per name block: a tile that lies inside one block (the usual case) costs one atomic.  nb_vflags arrives zeroed
 // (V_MULTI_SEG preset) with the table's small arrays.
-constexpr int VT = 192;                 // threads per tile: 16 rows each
-constexpr int VQ = TILE / (VT * 4);     // 4-row groups per thread
+constexpr int VTILE = 3072;             // rows per workgroup of k_validate (a multiple of the scan's tile)
+constexpr int VT = 256;                 // threads: VTILE / 256 rows each, in groups of four
+constexpr int VQ = VTILE / (VT * 4);    // 4-row groups per thread
 constexpr int VMAXNB = 64;              // name blocks of a tile whose flags are gathered in LDS (the rest: global atomics)
-static_assert(TILE % (VT * 4) == 0, "whole row groups per thread");
+static_assert(VTILE % (VT * 4) == 0 && VTILE % TILE == 0, "whole row groups per thread, whole scan tiles per workgroup");
 
 __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
-    __shared__ uint32_t s_start[TILE / 32];     // bit i: row t0+i starts a name block (i > 0)
-    __shared__ uint32_t s_pre[TILE / 32];       // name-block starts in the words before this one
+    __shared__ uint32_t s_start[VTILE / 32];    // bit i: row t0+i starts a name block (i > 0)
+    __shared__ uint32_t s_pre[VTILE / 32];       // name-block starts in the words before this one
     __shared__ uint32_t s_vf[VMAXNB];
     __shared__ uint32_t s_red[VT / 64];
     const int64_t tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t t0 = tile * TILE;
-    const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
+    const int64_t t0 = tile * VTILE;
+    const int nrows = (int)(min(t0 + (int64_t)VTILE, T.n_rows) - t0);
     // ---- the columns: all loads go out first ----
     int4 p4[VQ], i4[VQ];
     int pp[VQ], ip[VQ];
@@ -236,8 +229,8 @@ __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
         }
     }
     // ---- name-block starts inside the tile ----
-    const int nb0 = T.tile_nb[tile];
-    for (int i = tid; i < TILE / 32; i += VT) s_start[i] = 0u;
+    const int nb0 = T.tile_nb[tile * (VTILE / TILE)];
+    for (int i = tid; i < VTILE / 32; i += VT) s_start[i] = 0u;
     if (tid < VMAXNB) s_vf[tid] = 0u;
     __syncthreads();
     int n_in = 0;                               // blocks that start inside the tile (behind its first row)
@@ -258,12 +251,12 @@ __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
     if (n_in) {
         if (tid < 64) {                         // prefix counts per word: one wave, two rounds of 64 words
             uint32_t run = 0;
-            for (int w0 = 0; w0 < TILE / 32; w0 += 64) {
+            for (int w0 = 0; w0 < VTILE / 32; w0 += 64) {
                 const int w = w0 + lane;
-                const uint32_t c = w < TILE / 32 ? __popc(s_start[w]) : 0u;
+                const uint32_t c = w < VTILE / 32 ? __popc(s_start[w]) : 0u;
                 uint32_t incl = c;
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (w < TILE / 32) s_pre[w] = run + incl - c;
+                if (w < VTILE / 32) s_pre[w] = run + incl - c;
                 run += __shfl(incl, 63);
             }
         }
@@ -596,19 +589,18 @@ struct TileDesc {      // per tile, written by k0_tiles after classification (pl
 };
 
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
-constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_SLOW = 4, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
-constexpr int WROWS = 64;   // rows a window payload describes
+constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
+constexpr int WROWS = 64;   // rows before a window's last row that k1_emit looks at (longer windows: k1_rare)
 
 struct __attribute__((aligned(16))) Payload {
     int64_t r;          // last row of the window
     int64_t close_row;  // row that closes it (:179); n_rows: in the next shard; -1 cannot occur (not emitted)
-    uint64_t code[4];   // bit planes: rows r-j, j = 0..63 -> slot (k-mer offset) 0..7, or 15 = not in the window
     int32_t m;          // the site
     int32_t close_pos;
     uint32_t flags;     // PF_*
     int32_t nb;         // name block
 };
-static_assert(sizeof(Payload) == 64, "Payload layout");
+static_assert(sizeof(Payload) == 32, "Payload layout");
 
 struct K1Args {
     DevTable T;
@@ -617,7 +609,7 @@ struct K1Args {
     const TileDesc *tiles;
     Payload *payload;             // [payload_cap]
     long long payload_cap;
-    long long *tile_chunk;        // [n_tiles * TILE/64] first payload slot of the tile's chunk c >= 1 (chunk 0: tile * PT)
+    long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of 64 behind its own PT slots
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -625,17 +617,7 @@ struct K1Args {
     Counters *cnt;
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
-#ifdef MC_K1_EXPERIMENTS
-    int debug;                    // MCALLER_K1_DEBUG: cut k1_scan after a stage (timing experiments; results are WRONG)
-#endif
 };
-// Timing experiments of tools/k1_experiments.py exist in builds with -DMC_K1_EXPERIMENTS only: the shipped kernels carry
-// neither the branches nor the environment variable.
-#ifdef MC_K1_EXPERIMENTS
-#define K1X(n) (A.debug == (n))
-#else
-#define K1X(n) false
-#endif
 
 // One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
 __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
@@ -702,12 +684,8 @@ __device__ __forceinline__ int64_t find_close(const DevTable &T, const NbDesc *_
     return tail_contig >= 0 ? T.n_rows : -1;
 }
 
-// ---- k1_scan's rare paths, kept out of line ----
-// k1_scan keeps the next tile's loads in flight while it works on the staged one.  Any global load inlined into that
-// work -- even on a path that is never taken -- makes the compiler wait for ALL outstanding loads (vmcnt counts in
-// order) where the paths join.  So everything that has to touch global memory from the walk is a call: the waits
-// stay inside the callee.
-struct ScanGlobals {            // what the out-of-line paths need
+// ---- k1_scan's rare paths, kept out of line (everything they need comes from global memory) ----
+struct ScanGlobals {
     const int32_t *pos;
     const uint8_t *flags;
     const int64_t *nb_row_begin;
@@ -758,441 +736,295 @@ __device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbit
     return res;
 }
 
-// dword `lane` of the descriptors desc[0 .. n)
-__device__ __noinline__ uint32_t far_desc_word(const NbDesc *desc, int lane, int n) {
-    return lane < n * (int)(sizeof(NbDesc) / 4) ? reinterpret_cast<const uint32_t *>(desc)[lane] : 0u;
-}
+constexpr int PT = 16;              // payload slots reserved per tile; further chunks of 64 come from an atomic
+constexpr int NCHUNK = TILE / 64 + 1; // ... at most this many of them (one window per row, and one more per block start)
+constexpr int NQ = TILE / 256;      // k1_scan: stripes of 256 rows per tile -- every lane holds four consecutive rows of a stripe
+constexpr int NBR = 32;             // ... name blocks of a tile the register path handles (tiles of smaller reads: scan_tile_slowly)
+static_assert(TILE % 256 == 0, "whole stripes");
 
-__device__ __noinline__ int2 far_pos_flag(const ScanGlobals G, int64_t row) {
-    return make_int2(G.pos[row], (int)G.flags[row]);
-}
+struct __attribute__((aligned(16))) CandGroup {   // a group of four rows that may hold a site row, with the two rows behind it
+    int32_t pos[6];
+    uint32_t f4;        // flag bytes of the four rows
+    uint32_t nf_i0;     // flag bytes of the two rows behind them | first row of the group (tile-relative) << 16
+};
+static_assert(sizeof(CandGroup) == 32, "CandGroup layout");
 
-constexpr int PT = 64;              // payload slots reserved per tile; further chunks of 64 come from an atomic
-constexpr int UROWS = 8;            // k1_scan: rows per prefilter unit
-constexpr int UPL = TILE / UROWS / 64; // ... units per lane
-constexpr int WCAP = 128;           // ... closed windows buffered in LDS before their payloads are written
-static_assert(TILE % (UROWS * 64) == 0, "whole units per lane");
-
-// columns of one tile in flight: 16 bytes of positions per lane and quad of rows, 16 flag bytes per lane and 16 rows
-// (both columns move with 16-byte loads: 1 KB per wave instruction)
-static_assert(TILE % (NTHREADS * 16) == 0, "whole 16-byte flag loads");
-struct TileRegs {
-    int4 p4[TILE / (NTHREADS * 4)];
-    uint4 f16[TILE / (NTHREADS * 16)];
-    uint32_t descw;                 // dword `tid` of the tile's name-block descriptors
-    uint32_t maskw[NBST];           // word `tid` of the staged strand-mask windows
-    uint32_t tdw;                   // dword `tid` of the TileDesc of the tile AFTER this one (same workgroup)
+// payload slot of the tile's window number `rank`: the first PT in the tile's own strip, the rest in chunks of 64
+struct TileSlots {
+    const K1Args &A;
+    int64_t tile;
+    long long *s_chunk;           // [NCHUNK] first slot of the tile's chunks (LDS)
+    int total;                    // windows closed so far
+    int lane;
+    __device__ __forceinline__ long long slot_of(int rank) const {
+        return rank < PT ? tile * PT + rank : s_chunk[(rank - PT) >> 6] + ((rank - PT) & 63);
+    }
+    __device__ __forceinline__ void reserve(int new_total) {   // chunks for ranks < new_total (wave-uniform call)
+        const int c0 = total <= PT ? 0 : (total - PT + 63) >> 6, c1 = new_total <= PT ? 0 : (new_total - PT + 63) >> 6;
+        if (c1 > c0) {
+            if (lane == 0) {
+                const int n = c1 - c0;
+                const int sh = (int)(tile & (NSHARD - 1));
+                const long long per = (A.payload_cap - A.T.n_tiles * PT) / NSHARD;
+                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n * 64ull);
+                long long base = A.T.n_tiles * PT + sh * per + off;
+                if (off + n * 64LL > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+                for (int c = c0; c < c1; ++c) {
+                    s_chunk[c] = base < 0 ? -1 : base + (long long)(c - c0) * 64;
+                    A.tile_chunk[tile * NCHUNK + c] = s_chunk[c];
+                }
+            }
+            __threadfence_block();                  // lane 0's s_chunk entries, before any lane reads them
+        }
+    }
+    // the lanes with `closed` write their payloads, in lane order
+    __device__ __forceinline__ void put(bool closed, const Payload &P) {
+        const unsigned long long bal = __ballot(closed);
+        if (!bal) return;
+        const int n_new = __popcll(bal);
+        reserve(total + n_new);
+        if (closed) {
+            const long long slot = slot_of(total + __popcll(bal & ((1ull << lane) - 1ull)));
+            if (slot >= 0) A.payload[slot] = P;
+        }
+        total += n_new;
+    }
 };
 
-__device__ __forceinline__ void tile_issue_loads(const K1Args &A, const TileDesc &td, int64_t tile, int64_t tile_after,
-                                                 int tid, TileRegs &R) {
+// A tile that holds more name blocks than the register path keeps track of (reads of a few dozen rows): every row of a regular
+// block is examined from global memory, 64 rows at a time.  Exact, slow, rare.
+__device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc &td, int64_t tile, long long *s_chunk, int lane) {
     const DevTable &T = A.T;
-    const int64_t t0 = tile * TILE;
-    R.tdw = (tid < (int)(sizeof(TileDesc) / 4) && tile_after < T.n_tiles)
-                ? reinterpret_cast<const uint32_t *>(A.tiles + tile_after)[tid] : 0u;
-    const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
-#pragma unroll
-    for (int j = 0; j < TILE / (NTHREADS * 4); ++j) {
-        const int i0 = (j * NTHREADS + tid) * 4;
-        R.p4[j] = make_int4(0, 0, 0, 0);
-        if (i0 < nrows) R.p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);   // arrays are padded to a multiple of TILE:
-    }                                                                                    // the vector loads stay in bounds
-#pragma unroll
-    for (int j = 0; j < TILE / (NTHREADS * 16); ++j) {
-        const int i0 = (j * NTHREADS + tid) * 16;
-        R.f16[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (i0 < nrows) R.f16[j] = *reinterpret_cast<const uint4 *>(T.flags + t0 + i0);
+    ScanGlobals G;
+    G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
+    G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = A.k; G.skip_thresh = A.skip_thresh;
+    const int64_t t0 = tile * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
+    TileSlots S{A, tile, s_chunk, 0, lane};
+    for (int bi = 0; bi < td.nnb; ++bi) {
+        const int nb_abs = td.nb0 + bi;
+        const NbDesc d = A.desc[nb_abs];
+        if (d.mode != MODE_REGULAR) continue;
+        const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+        if (d.extra_row() >= t0 && d.extra_row() < t1) {
+            const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
+            Payload P;
+            P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
+            P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
+            P.nb = nb_abs;
+            S.put(lane == 0 && xc.row >= 0, P);
+        }
+        const int64_t lo = max(max(d.row_begin, d.first()), t0), hi = min(d.row_end, t1);
+        for (int64_t base = lo; base < hi; base += 64) {
+            const int64_t row = base + lane;
+            RowRes fr;
+            fr.closed = 0; fr.cr = 0; fr.m = 0; fr.cp = 0; fr.pf = 0;
+            if (row < hi && !(T.flags[row] & MC_F_MODEL_N)) fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, row);
+            Payload P;
+            P.r = row; P.close_row = fr.cr; P.m = fr.m; P.close_pos = fr.cp;
+            P.flags = fr.pf | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
+            P.nb = nb_abs;
+            S.put(fr.closed != 0, P);
+        }
     }
-    const int nnb = min(td.nnb, NBMAX);
-    const uint32_t *dsrc = reinterpret_cast<const uint32_t *>(A.desc + td.nb0);
-    R.descw = tid < nnb * (int)(sizeof(NbDesc) / 4) ? dsrc[tid] : 0u;
-    R.maskw[0] = tid < td.nwa ? ((td.reva ? A.R.mr : A.R.mf) + td.boffa)[tid] : 0u;
-    R.maskw[1] = tid < td.nwb ? ((td.revb ? A.R.mr : A.R.mf) + td.boffb)[tid] : 0u;
+    if (lane == 0) A.tile_cnt[tile] = S.total;
 }
 
-#ifdef MC_PROFILE
-#define PH(n) do { if (tid == 0) { const long long _t = clock64(); ph[n] += _t - ph_t; ph_t = _t; } } while (0)
-#else
-#define PH(n) do {} while (0)
-#endif
-
-#ifndef MC_SCAN_WGS
-#define MC_SCAN_WGS 16              // workgroups per CU the persistent grid is sized for (registers allow 16 waves per CU)
-#endif
-
-// k1_scan: persistent workgroups, tiles taken grid-stride.
-//
-// Per tile: the position and flag columns (5 B/row) are streamed into LDS -- the loads of tile i+1 (columns,
-// descriptors, mask words) are issued before tile i is processed, and its TileDesc one tile earlier still, so no memory
-// round trip sits on the per-tile critical path.  The work on a staged tile is driven by the SITES, not the rows: inside a
-// regular name block positions are non-decreasing, so for every 'M' of the block's strand mask that the tile's positions
-// can reach, one lane binary-searches the last row at a position <= the site (LDS), checks that this row's first 'M' is
-// the site (no nearer 'M' to its left, :269-270) and that the next unfiltered row lies beyond it or starts another read
-// (:179): that is a closed window.  The lane then walks the <= 32 rows before it in LDS and writes which rows belong to
-// which slot, plus the closing row, as a 48-byte payload (k1_emit turns payloads into records).
-#ifdef MC_SCAN_WPE      // experiment: ask the register allocator for this many waves per SIMD
-#define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MC_SCAN_WPE, MC_SCAN_WPE)))
-#else
-#define MC_SCAN_ATTR
-#endif
-__global__ __launch_bounds__(NTHREADS) MC_SCAN_ATTR void k1_scan(K1Args A) {
-    __shared__ __attribute__((aligned(16))) int32_t s_pos[TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fl[TILE + 16];
-    __shared__ uint32_t s_bits[NBST][NTHREADS];
-    __shared__ __attribute__((aligned(16))) NbDesc s_nb[NBMAX];
-    __shared__ uint16_t s_cand[TILE / UROWS];       // candidate units of the name block in hand, ascending
-    __shared__ int64_t s_w_cr[WCAP];                // closed windows waiting for their payload: closing row,
-    __shared__ int32_t s_w_m[WCAP], s_w_cp[WCAP];   // site, closing position,
-    __shared__ uint16_t s_w_rv[WCAP];               // last row (tile-relative),
-    __shared__ uint8_t s_w_pf[WCAP];                // PF_CLOSE_NS | PF_MULTI
-    __shared__ long long s_chunk[TILE / 64];        // first payload slot of the tile's 64-record chunks
-
-    static_assert(BW <= NTHREADS && NBMAX * sizeof(NbDesc) / 4 <= NTHREADS && sizeof(TileDesc) / 4 <= NTHREADS,
-                  "one dword per thread");
-    static_assert(NBST == 2, "two staged mask windows");
-    static_assert(NTHREADS == 64, "the walk is one wave's work, and one wave refills the staged descriptors");
+// k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier: the position and flag columns (5 B/row) go
+// from HBM into REGISTERS -- every lane holds four consecutive rows of each 256-row stripe, all loads of the tile are issued
+// before anything is used -- and 96 % of the rows never leave them: one 64-bit extract from the strand bitmask (a window of it
+// staged in LDS per tile) tells for a group of four rows whether any of their k-mers holds an 'M' at all.  Only the groups that
+// pass are written to an LDS list (with the two rows behind them); when all stripes are done -- the columns' registers are
+// free again -- one lane per row of the listed groups decides whether the row is the LAST row of a window: its k-mer holds an
+// 'M' (first one: the site m, :176) and the next unfiltered row of the read lies beyond m, or there is none and another read
+// (or the next shard) follows (:179).  Every closed window leaves a 32-byte payload (last row, site, closing row); which of the
+// rows before it belong to which slot is worked out by k1_emit, eight lanes per window.  Whatever needs more than the tile's
+// registers (a closing row beyond the tile or behind two 'N' rows, mask words outside the staged window) is an out-of-line call
+// that reads global memory.  Waves are short and light, many are resident per SIMD, their loads overlap: the kernel streams.
+// CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one group in 25 is listed) bails out to
+// scan_tile_slowly if a tile overflows it; the dense instance holds every group of the tile.
+template <int CG>
+__global__ __launch_bounds__(64) void k1_scan(K1Args A) {
+    __shared__ uint32_t s_bits[NBST][64];
+    __shared__ __attribute__((aligned(16))) CandGroup s_cand[CG];
+    __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
+    __shared__ uint16_t s_seg_end[NBR];             // candidate groups listed up to and including this name block
     const DevTable &T = A.T;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
     const int k = A.k;
+    const int64_t t0 = tile * TILE;
+    const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
+
+    // ---- the columns: every load of the tile goes out before anything is used ----
+    int4 p4[NQ];
+    uint32_t fl4[NQ];
+    if (nrows == TILE) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * 64 + lane) * 4;
+            p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+            fl4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * 64 + lane) * 4;
+            p4[j] = make_int4(0, 0, 0, 0);
+            fl4[j] = 0x02020202u;                   // (rows past the table: MC_F_MODEL_N, never looked at anyway)
+            if (i0 < nrows) {                       // (arrays are padded: whole groups stay in bounds)
+                p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+                fl4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
+            }
+        }
+    }
+    const TileDesc td = A.tiles[tile];
+    if (td.nnb > NBR) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }
+    s_bits[0][lane] = lane < td.nwa ? ((td.reva ? A.R.mr : A.R.mf) + td.boffa)[lane] : 0u;
+    s_bits[1][lane] = lane < td.nwb ? ((td.revb ? A.R.mr : A.R.mf) + td.boffb)[lane] : 0u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    // ---- all lanes, block by block and stripe by stripe: which groups of four rows can hold a site row at all? ----
+    // A group inside its block spans positions [p0, p3]; its rows' k-mers cover mask bits [p0, p3 + k).  One 64-bit extract from
+    // the staged mask window decides; groups cut by the block's ends, groups whose span does not fit the extract or the staged
+    // window are listed unconditionally.
+    int ncand = 0;
+    bool overflow = false;
+    for (int bi = 0; bi < td.nnb; ++bi) {
+        const NbDesc *dp = A.desc + td.nb0 + bi;
+        if (dp->mode == MODE_REGULAR) {
+            const int64_t lb_abs = max(dp->row_begin, dp->first());
+            const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(dp->row_end, t0 + (int64_t)nrows) - t0);
+            const int sw0 = bi == 0 ? td.w0a : td.w0b;
+            const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);  // (a third block of a tile: every lookup out of line)
+            const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (j * 256 + 256 <= lo || j * 256 >= hi) continue;      // (wave-uniform)
+                const int i0 = (j * 64 + lane) * 4;
+                const int4 p = p4[j];
+                const bool touches = i0 + 4 > lo && i0 < hi;
+                const bool full = i0 >= lo && i0 + 4 <= hi;
+                const int span = p.w - p.x + k;
+                const int wi = (p.x >> 5) - sw0;
+                const bool decidable = full && span > 0 && span <= 33 && wi >= 0 && wi + 1 < snw;
+                const int wc = min(max(wi, 0), BW - 2);
+                const uint64_t bits = ((((uint64_t)sb[wc + 1] << 32) | sb[wc]) >> (p.x & 31)) & ((1ull << (span & 63)) - 1ull);
+                const bool cand = touches && (!decidable || bits != 0ull);
+                const unsigned long long bal = __ballot(cand);
+                if (!bal) continue;
+                if (ncand + 64 > CG) { overflow = true; continue; }
+                // the two rows behind the group: the next lane's first two rows (lane 63: the next stripe's)
+                int nx = __shfl_down(p.x, 1), ny = __shfl_down(p.y, 1);
+                uint32_t nf = __shfl_down(fl4[j], 1);
+                if (j + 1 < NQ) {
+                    const int sx = __shfl(p4[(j + 1) % NQ].x, 0), sy = __shfl(p4[(j + 1) % NQ].y, 0);
+                    const uint32_t sf = __shfl(fl4[(j + 1) % NQ], 0);
+                    if (lane == 63) { nx = sx; ny = sy; nf = sf; }
+                }
+                if (cand) {
+                    CandGroup g;
+                    g.pos[0] = p.x; g.pos[1] = p.y; g.pos[2] = p.z; g.pos[3] = p.w; g.pos[4] = nx; g.pos[5] = ny;
+                    g.f4 = fl4[j];
+                    g.nf_i0 = (nf & 0xFFFFu) | ((uint32_t)i0 << 16);
+                    s_cand[ncand + __popcll(bal & below)] = g;
+                }
+                ncand += __popcll(bal);
+            }
+        }
+        if (lane == 0) s_seg_end[bi] = (uint16_t)ncand;
+    }
+    if (overflow) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }    // (nothing has been written yet)
+
+    // ---- one lane per row of the listed groups, block by block: is this row the last row of a window? ----
     ScanGlobals G;
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
-    constexpr int NQ = TILE / (NTHREADS * 4);      // row quads per thread
-
-    // Tiles are handed out in chunks of CHUNK consecutive tiles from ticket counters, so the grid need not match the
-    // residency the hardware grants (a static grid-stride split runs a second, unbalanced round when it does not) and
-    // tiles with many windows do not leave a tail.
-#ifndef MC_SCAN_CHUNK
-#define MC_SCAN_CHUNK 2
-#endif
-    constexpr int CHUNK = MC_SCAN_CHUNK;
-    const int64_t n_chunks = (T.n_tiles + CHUNK - 1) / CHUNK;
-    // One counter per XCD: a single counter serialises ~8k same-address atomics (~10 ns each) per pass.  Ticket t of XCD x
-    // (= block index mod 8) is chunk gridDim.x + 8 t + x: every chunk beyond the grid's first round exactly once.
-    const unsigned xcd = blockIdx.x & (NSHARD - 1);
-    auto draw = [&]() -> unsigned long long {       // tickets start after the chunks the grid takes by block index
-        unsigned long long t = 0;
-        if (lane == 0) t = gridDim.x + atomicAdd(&A.cnt->ticket[xcd].v, 1ull) * NSHARD + xcd;
-        return t;
-    };
-    int64_t chunk = blockIdx.x;                     // the first chunk needs no ticket (no start-up storm on the counter)
-    if (chunk >= n_chunks) return;
-    // the tickets of the next two chunks are drawn ahead (in lane 0 until needed, resolved lazily): the look-ahead of two
-    // tiles may reach the chunk after next when a chunk is a single tile
-    unsigned long long pending = draw(), pending2 = draw();
-    int64_t chunk_next = -1, chunk_next2 = -1;
-    int pin = 0;                                    // position inside the current chunk
-    // tile j steps after the current one (j <= 2): in this chunk, the next one, or the one after
-    auto tile_ahead = [&](int j) -> int64_t {
-        if (pin + j < CHUNK) return chunk * CHUNK + pin + j;
-        if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
-        if (pin + j < 2 * CHUNK) return chunk_next >= n_chunks ? T.n_tiles : chunk_next * CHUNK + (pin + j - CHUNK);
-        if (chunk_next2 < 0) chunk_next2 = (int64_t)__shfl(pending2, 0);
-        return chunk_next2 >= n_chunks ? T.n_tiles : chunk_next2 * CHUNK + (pin + j - 2 * CHUNK);
-    };
-    int64_t tile = chunk * CHUNK;
-#ifdef MC_PROFILE
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
-#endif
-    __shared__ __attribute__((aligned(16))) TileDesc s_td[2];   // [cur]: this tile, [cur ^ 1]: the workgroup's next tile
-    TileRegs R;
-    {
-        const TileDesc td0 = A.tiles[tile];
-        if (tid == 0) s_td[0] = td0;
-        tile_issue_loads(A, td0, tile, tile_ahead(1), tid, R);
-    }
-    int cur = 0;
-
-    for (; tile < T.n_tiles; cur ^= 1) {
-        const int64_t t0 = tile * TILE;
-        const int64_t t1 = min(t0 + (int64_t)TILE, T.n_rows);
-
-        // ---- this tile's descriptors, mask words and columns, the next tile's TileDesc: registers -> LDS ----
-        reinterpret_cast<uint32_t *>(s_nb)[tid] = R.descw;
-        s_bits[0][tid] = R.maskw[0];
-        s_bits[1][tid] = R.maskw[1];
-        if (tid < (int)(sizeof(TileDesc) / 4)) reinterpret_cast<uint32_t *>(&s_td[cur ^ 1])[tid] = R.tdw;
-        if (K1X(6)) {                  // (timing experiment: the columns are consumed from registers, never staged)
-            int x = 0;
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) x ^= R.p4[j].x ^ R.p4[j].y ^ R.p4[j].z ^ R.p4[j].w;
-#pragma unroll
-            for (int j = 0; j < TILE / (NTHREADS * 16); ++j) x ^= (int)(R.f16[j].x ^ R.f16[j].w);
-            if (x == 0x12345678) s_pos[tid] = x;
-        } else {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * NTHREADS + tid) * 4;
-            *reinterpret_cast<int4 *>(&s_pos[i0]) = R.p4[j];
+    TileSlots S{A, tile, s_chunk, 0, lane};
+    int seg_begin = 0;
+    for (int bi = 0; bi < td.nnb; ++bi) {
+        const int nb_abs = td.nb0 + bi;
+        const int seg_end = s_seg_end[bi];
+        const int first_g = seg_begin;
+        seg_begin = seg_end;
+        const NbDesc d = A.desc[nb_abs];
+        if (d.mode != MODE_REGULAR) continue;
+        const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+        const int sw0 = bi == 0 ? td.w0a : td.w0b;
+        const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
+        const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
+        // first 'M' in meth_ref[p:p+k] (:176,:270) from the staged mask window; ok = false when the window does not hold
+        // both words (the row then takes the out-of-line path)
+        auto site_off = [&](int p, bool &ok) -> int {
+            const int wi = (p >> 5) - sw0;
+            ok = wi >= 0 && wi + 1 < snw;
+            const int wc = min(max(wi, 0), BW - 2);
+            uint64_t bits = ((((uint64_t)sb[wc + 1]) << 32) | sb[wc]) >> (p & 31);
+            bits &= (1ull << k) - 1ull;
+            int o = bits ? (int)__builtin_ctzll(bits) : -1;
+            if (p >= d.contig_len) { o = -1; ok = true; }
+            return o;
+        };
+        // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
+        if (d.extra_row() >= t0 && d.extra_row() < t0 + nrows) {
+            const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
+            Payload P;
+            P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
+            P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
+            P.nb = nb_abs;
+            S.put(lane == 0 && xc.row >= 0, P);
         }
-#pragma unroll
-        for (int j = 0; j < TILE / (NTHREADS * 16); ++j)
-            *reinterpret_cast<uint4 *>(&s_fl[(j * NTHREADS + tid) * 16]) = R.f16[j];
-        }
-        __syncthreads();
-        PH(0);
-        const TileDesc td = s_td[cur];
-        const int nb0 = td.nb0;
-        // ... and the next tile's loads go out now; they land while this tile is processed
-        const int64_t tile_n = tile_ahead(1);
-        if (tile_n < T.n_tiles && !K1X(4)) tile_issue_loads(A, s_td[cur ^ 1], tile_n, tile_ahead(2), tid, R);   // (4: timing experiment, walk only)
-        PH(1);
-
-        if (wave == 0 && !K1X(3) && !K1X(6)) {
-            // The walk works from LDS alone.  Whatever needs global memory (more name blocks than were staged, a closing
-            // row beyond the tile, a window reaching back before it) is an out-of-line call -- see far_close().
-            {
-                int total = 0;                               // windows closed so far in this tile
-                for (int bi = 0; bi < td.nnb; ++bi) {
-                    if (bi >= NBMAX && (bi % NBMAX) == 0)          // rare: the tile overlaps more name blocks than were staged
-                        reinterpret_cast<uint32_t *>(s_nb)[lane] = far_desc_word(A.desc + nb0 + bi, lane, min(td.nnb - bi, NBMAX));
-                    const NbDesc d = s_nb[bi % NBMAX];
-                    if (d.mode != MODE_REGULAR) continue;
-                    const int nb_abs = nb0 + bi;
-                    const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-                    const int sw0 = bi == 0 ? td.w0a : td.w0b;
-                    const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
-                    const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
-                    // first 'M' in meth_ref[p:p+k] (:176,:270) from the staged mask window; ok = false when the window
-                    // does not hold both words (the row then takes the out-of-line path)
-                    auto site_off = [&](int p, bool &ok) -> int {
-                        const int wi = (p >> 5) - sw0;
-                        ok = wi >= 0 && wi + 1 < snw;
-                        const int wc = min(max(wi, 0), BW - 2);
-                        uint64_t bits = ((((uint64_t)sb[wc + 1]) << 32) | sb[wc]) >> (p & 31);
-                        bits &= (1ull << k) - 1ull;
-                        int o = bits ? (int)__builtin_ctzll(bits) : -1;
-                        if (p >= d.contig_len) { o = -1; ok = true; }
-                        return o;
-                    };
-                    auto slot_of = [&](int rank) -> long long {
-                        return rank < PT ? tile * PT + rank : s_chunk[rank >> 6] + (rank & 63);
-                    };
-                    auto reserve = [&](int new_total) {                 // chunks for ranks < new_total (wave-uniform call)
-                        const int c0 = (total + 63) >> 6, c1 = (new_total + 63) >> 6;     // chunks [max(c0,1), c1) are new
-                        if (c1 > max(c0, 1)) {
-                            long long base = 0;
-                            if (lane == 0) {
-                                const int cb = max(c0, 1), n = c1 - cb;
-                                const int sh = (int)(tile & (NSHARD - 1));
-                                const long long per = (A.payload_cap - T.n_tiles * PT) / NSHARD;
-                                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n * 64ull);
-                                base = T.n_tiles * PT + sh * per + off;
-                                if (off + n * 64LL > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
-                                for (int c = cb; c < c1; ++c) {
-                                    s_chunk[c] = base < 0 ? -1 : base + (long long)(c - cb) * 64;
-                                    A.tile_chunk[tile * (TILE / 64) + c] = s_chunk[c];
-                                }
-                            }
-                            __threadfence_block();        // lane 0's s_chunk entries, before any lane reads them
+        const int64_t lb_abs = max(d.row_begin, d.first());
+        const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t0 + (int64_t)nrows) - t0);
+        for (int base = first_g * 4; base < seg_end * 4; base += 64) {
+            const int idx = base + lane;
+            const bool have = idx < seg_end * 4;
+            const CandGroup *g = s_cand + (have ? idx >> 2 : first_g);
+            const int e = idx & 3;
+            const int p = g->pos[e], p1 = g->pos[e + 1], p2 = g->pos[e + 2];
+            const unsigned long long fb = (unsigned long long)g->f4 | ((unsigned long long)(g->nf_i0 & 0xFFFFu) << 32);
+            const uint32_t f = (uint32_t)(fb >> (8 * e)) & 0xFFu, f1 = (uint32_t)(fb >> (8 * e + 8)) & 0xFFu,
+                           f2 = (uint32_t)(fb >> (8 * e + 16)) & 0xFFu;
+            const int i = (int)(g->nf_i0 >> 16) + e;
+            bool closed = false, far = false;
+            int m = 0, cp = 0;
+            int64_t cr = 0;
+            uint32_t pf = 0;
+            if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
+                bool ok;
+                const int o = site_off(p, ok);
+                if (!ok) far = true;
+                else if (o >= 0) {
+                    m = p + o;
+                    // the next unfiltered row of the read inside the tile: the row behind this one, or the one behind an 'N' row
+                    int c = -1;
+                    if (i + 1 < hi && !(f1 & MC_F_MODEL_N)) { c = i + 1; cp = p1; }
+                    else if (i + 2 < hi && (f1 & MC_F_MODEL_N) && !(f2 & MC_F_MODEL_N)) { c = i + 2; cp = p2; }
+                    if (c >= 0) {
+                        cr = t0 + c;
+                        closed = cp > m;
+                        if (closed && cp <= m + A.skip_thresh + 1) {
+                            bool ok2;
+                            const int o2 = site_off(cp, ok2);
+                            if (!ok2) far = true;
+                            else if (o2 > 0) pf |= PF_MULTI;
                         }
-                    };
-
-                    // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
-                    if (d.extra_row() >= t0 && d.extra_row() < t1) {
-                        const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
-                        const int64_t cr = xc.row;
-                        const int cp = xc.pos;
-                        const bool cns = xc.ns;
-                        if (cr >= 0) {
-                            reserve(total + 1);
-                            if (lane == 0 && slot_of(total) >= 0) {
-                                Payload P;
-                                P.r = d.extra_row(); P.close_row = cr; P.m = d.extra_mpos; P.close_pos = cp;
-                                P.code[0] = P.code[1] = P.code[2] = P.code[3] = ~0ull;
-                                P.flags = PF_EXTRA | (cns ? PF_CLOSE_NS : 0u);
-                                P.nb = nb_abs;
-                                A.payload[slot_of(total)] = P;
-                            }
-                            total += 1;
-                        }
-                    }
-
-                    const int64_t lb_abs = max(d.row_begin, d.first());
-                    const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t1) - t0);
-                    if (hi <= lo) continue;
-                    const int lb_rel = (int)max<int64_t>(lb_abs - t0, -2 * WROWS); // window walks look back < WROWS rows
-                    PH(4);
-
-                    // ---- pass 1 (all lanes): which units of UROWS rows can hold a site row at all? ----
-                    // A full unit spans positions [p0, p1]; its rows' k-mers cover mask bits [p0, p1 + k).  One 64-bit
-                    // extract from the staged mask window decides; units cut by the block's ends, units whose span does
-                    // not fit the extract or the staged window go to pass 2 unconditionally.
-                    int ncand = 0;
-                    {
-                        int p0[UPL], p1[UPL];
-                        uint32_t wlo[UPL], whi[UPL];
-#pragma unroll
-                        for (int j = 0; j < UPL; ++j) {
-                            const int i0 = (j * 64 + lane) * UROWS;
-                            p0[j] = s_pos[i0];
-                            p1[j] = s_pos[i0 + UROWS - 1];
-                        }
-#pragma unroll
-                        for (int j = 0; j < UPL; ++j) {
-                            const int wi = min(max((p0[j] >> 5) - sw0, 0), BW - 2);
-                            wlo[j] = sb[wi];
-                            whi[j] = sb[wi + 1];
-                        }
-#pragma unroll
-                        for (int j = 0; j < UPL; ++j) {
-                            const int u = j * 64 + lane, i0 = u * UROWS;
-                            const bool touches = i0 + UROWS > lo && i0 < hi;
-                            const bool full = i0 >= lo && i0 + UROWS <= hi;
-                            const int span = p1[j] - p0[j] + k;
-                            const int wi = (p0[j] >> 5) - sw0;
-                            const bool decidable = full && span <= 32 && wi >= 0 && wi + 1 < snw;
-                            const uint64_t bits = ((((uint64_t)whi[j] << 32) | wlo[j]) >> (p0[j] & 31)) &
-                                                  ((1ull << (span & 63)) - 1ull);
-                            const bool cand = touches && (!decidable || bits != 0ull);
-                            const unsigned long long bal = __ballot(cand);
-                            if (cand) s_cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)u;
-                            ncand += __popcll(bal);
-                        }
-                    }
-                    PH(5);
-                    if (ncand == 0) continue;
-
-                    int nwin = 0;                                      // closed windows waiting in s_w_*
-                    // ---- pass 3 (16 lanes per window): slot codes of the rows r, r-1, ... r-31, then the payload ----
-                    auto flush = [&]() {
-                        if (nwin == 0) return;
-                        reserve(total + nwin);
-                        const int grp = lane >> 4, j = lane & 15;
-                        for (int wbase = 0; wbase < nwin; wbase += 4) {
-                            const bool havew = wbase + grp < nwin;
-                            const int wix = havew ? wbase + grp : 0;
-                            const int rv = s_w_rv[wix], m = s_w_m[wix];
-                            uint64_t c0 = ~0ull, c1 = ~0ull, c2 = ~0ull, c3 = ~0ull;
-                            bool stopped = !havew;
-                            for (int jb = 0; jb < WROWS; jb += 16) {
-                                if (!__ballot(!stopped)) break;
-                                const int rr = rv - jb - j;                              // tile-relative; may precede the tile
-                                const bool inb = rr >= lb_rel;
-                                const int rc = max(rr, 0);
-                                int pj = s_pos[rc];
-                                uint32_t fj = s_fl[rc];
-                                // rows before the tile: only if the walk gets that far without stopping (rare)
-                                const bool early = !stopped && inb && rr < 0;
-                                if (__ballot(early)) {
-                                    const unsigned long long kn = __ballot(!stopped && (!inb || (rr >= 0 && !(fj & MC_F_MODEL_N) &&
-                                                                                             pj < m - k + 1)));
-                                    const unsigned long long un = __ballot(early);
-                                    const uint32_t kn16 = (uint32_t)(kn >> (grp * 16)) & 0xFFFFu, un16 = (uint32_t)(un >> (grp * 16)) & 0xFFFFu;
-                                    const bool need = early && (kn16 == 0u || __builtin_ctz(un16) < __builtin_ctz(kn16));
-                                    if (need) {
-                                        const int2 g = far_pos_flag(G, t0 + rr);
-                                        pj = g.x; fj = (uint32_t)g.y;
-                                    }
-                                }
-                                const bool nj = fj & MC_F_MODEL_N;
-                                const bool stop_here = !stopped && (!inb || (!nj && pj < m - k + 1));
-                                const uint32_t st16 = (uint32_t)(__ballot(stop_here) >> (grp * 16)) & 0xFFFFu;
-                                const int first = st16 ? __builtin_ctz(st16) : 16;
-                                const bool inw = !stopped && inb && !nj && j < first;
-                                const uint32_t code = (uint32_t)(m - pj);
-                                const uint32_t b0 = (uint32_t)(__ballot(inw && !(code & 1u)) >> (grp * 16)) & 0xFFFFu;
-                                const uint32_t b1 = (uint32_t)(__ballot(inw && !(code & 2u)) >> (grp * 16)) & 0xFFFFu;
-                                const uint32_t b2 = (uint32_t)(__ballot(inw && !(code & 4u)) >> (grp * 16)) & 0xFFFFu;
-                                const uint32_t b3 = (uint32_t)(__ballot(inw) >> (grp * 16)) & 0xFFFFu;
-                                c0 &= ~((uint64_t)b0 << jb); c1 &= ~((uint64_t)b1 << jb); c2 &= ~((uint64_t)b2 << jb); c3 &= ~((uint64_t)b3 << jb);
-                                if (st16) stopped = true;
-                            }
-                            if (havew && j == 0) {
-                                const bool really_stopped = stopped;      // (havew: `stopped` started false)
-                                const long long slot = slot_of(total + wbase + grp);
-                                if (slot >= 0) {
-                                    Payload P;
-                                    P.r = t0 + rv; P.close_row = s_w_cr[wix]; P.m = m; P.close_pos = s_w_cp[wix];
-                                    P.code[0] = c0; P.code[1] = c1; P.code[2] = c2; P.code[3] = c3;
-                                    P.flags = s_w_pf[wix] | (!really_stopped ? PF_SLOW : 0u) | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
-                                    P.nb = nb_abs;
-                                    A.payload[slot] = P;
-                                }
-                            }
-                        }
-                        total += nwin;
-                        nwin = 0;
-                    };
-
-                    // ---- pass 2 (one lane per row of the candidate units): is this row the last row of a window? ----
-                    // It is iff its k-mer holds an 'M' (first one: the site m, :176) and the next unfiltered row of the
-                    // read lies beyond m -- or there is none and another read (or the next shard) follows (:179).
-                    for (int base = 0; base < ncand * UROWS; base += 64) {
-                        const int e = base + lane;
-                        const bool have = e < ncand * UROWS;
-                        const int u = s_cand[have ? e / UROWS : 0];
-                        const int i = u * UROWS + (e % UROWS);
-                        const int p = s_pos[i], pn = s_pos[min(i + 1, TILE - 1)];
-                        const uint32_t f = s_fl[i], fn = s_fl[i + 1];
-                        bool closed = false, far = false;
-                        int m = 0, cp = 0;
-                        int64_t cr = 0;
-                        uint32_t pf = 0;
-                        if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
-                            bool ok;
-                            const int o = site_off(p, ok);
-                            if (!ok) far = true;
-                            else if (o >= 0) {
-                                m = p + o;
-                                int c = i + 1;
-                                if (c < hi && (fn & MC_F_MODEL_N)) {
-                                    ++c;
-                                    while (c < hi && (s_fl[c] & MC_F_MODEL_N)) ++c;
-                                }
-                                if (c < hi) {
-                                    cp = c == i + 1 ? pn : s_pos[c];
-                                    cr = t0 + c;
-                                    closed = cp > m;
-                                    if (closed && cp <= m + A.skip_thresh + 1) {
-                                        bool ok2;
-                                        const int o2 = site_off(cp, ok2);
-                                        if (!ok2) far = true;
-                                        else if (o2 > 0) pf |= PF_MULTI;
-                                    }
-                                } else far = true;                        // the closing row lies past the tile / the block
-                            }
-                        }
-                        if (__ballot(far)) {                               // rare
-                            if (far) {
-                                const RowRes fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, t0 + i);
-                                closed = fr.closed; m = fr.m; cp = fr.cp; cr = fr.cr; pf = fr.pf;
-                            }
-                        }
-                        const unsigned long long bal = __ballot(closed);
-                        if (closed) {
-                            const int ix = nwin + __popcll(bal & ((1ull << lane) - 1ull));
-                            s_w_rv[ix] = (uint16_t)i; s_w_m[ix] = m; s_w_cp[ix] = cp; s_w_cr[ix] = cr; s_w_pf[ix] = (uint8_t)pf;
-                        }
-                        nwin += __popcll(bal);
-                        if (nwin > WCAP - 64) flush();
-                    }
-                    PH(6);
-                    flush();
-                    PH(7);
+                    } else far = true;              // past the tile / the block, or behind two 'N' rows
                 }
-                if (lane == 0) A.tile_cnt[tile] = total;
             }
-        }
-        PH(2);
-        __syncthreads();          // LDS is rewritten for the next tile
-        PH(3);
-        // advance to the next tile of the ticket stream
-        tile = tile_n;
-        if (++pin == CHUNK) {
-            if (chunk_next < 0) chunk_next = (int64_t)__shfl(pending, 0);
-            chunk = chunk_next;
-            pending = pending2;                     // the chunk after next moves up ...
-            chunk_next = chunk_next2;
-            chunk_next2 = -1;
-            pin = 0;
-            if (chunk < n_chunks) pending2 = draw(); // ... and another ticket is drawn behind it
+            if (__ballot(far)) {                       // rare
+                if (far) {
+                    const RowRes fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, t0 + i);
+                    closed = fr.closed; m = fr.m; cp = fr.cp; cr = fr.cr; pf = fr.pf;
+                }
+            }
+            Payload P;
+            P.r = t0 + i; P.close_row = cr; P.m = m; P.close_pos = cp;
+            P.flags = pf | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
+            P.nb = nb_abs;
+            S.put(closed, P);
         }
     }
-#ifdef MC_PROFILE
-    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&A.cnt->prof[i], (unsigned long long)ph[i]);
-#endif
+    if (lane == 0) A.tile_cnt[tile] = S.total;
 }
 
 // Tile counts -> first record slot of every tile, two levels: groups of 1024 tiles are scanned here (coalesced),
@@ -1348,20 +1180,20 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     for (int j = l; j < c; j += LG) {
         long long slot = tile * PT + j;
         if (j >= PT) {
-            const long long cb = A.tile_chunk[tile * (TILE / 64) + (j >> 6)];
+            const long long cb = A.tile_chunk[tile * NCHUNK + ((j - PT) >> 6)];
             if (cb < 0) { atomicOr(&A.cnt->overflow, 1u); continue; }
-            slot = cb + (j & 63);
+            slot = cb + ((j - PT) & 63);
         }
         sorted[first + j] = A.payload[slot];
     }
 }
 
-// Eight lanes per closed window, lane s = slot s of the window (k <= 8): the lane reads the payload's bit planes, picks
-// the rows of its slot (<= 64 rows back from the window's last row), fetches their (event, model) pairs from the
-// interleaved column (all lanes of a window hit the same DRAM page) and adds them in NumPy's pairwise order (n < 8:
-// sequentially from -0.0, oldest row first; 8..32: eight strided accumulators, then the tail).  The k slot means of a
-// window leave as k consecutive doubles, adjacent windows adjacent: the wave's stores are one contiguous run.  Windows
-// longer than 32 rows and blocks with a stray event (R5) take the row-at-a-time walk on the group's first lane.
+// Eight lanes per closed window, lane s = slot s of the window (k <= 8).  First the eight lanes together look at the 64 rows
+// before the window's last row (positions and flag bytes: 320 bytes around one place) and work out which row belongs to which
+// slot; then every lane fetches the (event, model) pairs of its slot's rows from the pair column (all lanes of a window hit
+// the same DRAM page) and adds them in NumPy's pairwise order (n < 8: sequentially from -0.0, oldest row first; 8..: eight
+// strided accumulators, then the tail).  The k slot means of a window leave as k consecutive doubles, adjacent windows
+// adjacent: the wave's stores are one contiguous run.  Windows longer than 64 rows go to k1_rare.
 constexpr int EG = 8;            // lanes per window
 static_assert(EG >= MC_MAX_K, "one lane per slot");
 
@@ -1401,7 +1233,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     Payload Pn;
     Pn.flags = PF_EXTRA; Pn.nb = 0; Pn.r = 0; Pn.m = 0; Pn.close_row = 0; Pn.close_pos = 0;
-    Pn.code[0] = Pn.code[1] = Pn.code[2] = Pn.code[3] = ~0ull;
     {
         const int64_t q0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / EG;
         if (q0 < n_rec) Pn = sorted[q0];
@@ -1415,28 +1246,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         Pn.flags = PF_EXTRA;
         if (qn < n_rec) Pn = sorted[qn];
     }
-    const int64_t r = K1X(5) ? 40 + q * 8 : P.r;                // (timing experiment: sequential instead of scattered rows)
+    const int64_t r = P.r;
     const int m = P.m;
-    const bool fast = live && !(P.flags & (PF_EXTRA | PF_SLOW));
-    if (live && !fast && s == 0) {
-        if (P.flags & PF_EXTRA) {               // the one-event '+' window of a palindromic first site row (R5)
-            for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
-            A.O.site_pos[q] = m;
-            A.O.site_seg[q] = T.nb_seg_begin[P.nb];
-            A.O.close_row[q] = P.close_row;
-            A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
-            A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
-        } else {
-            A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
+    const bool window = live && !(P.flags & PF_EXTRA);
+    if (live && !window && s == 0) {            // the one-event '+' window of a palindromic first site row (R5)
+        for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+        A.O.site_pos[q] = m;
+        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+        A.O.close_row[q] = P.close_row;
+        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
+        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    // ---- which of the rows before the window's last row belong to which slot?  Lane l of the group looks at rows r-l,
+    // r-l-8, ... r-l-56: eight independent loads of the position and of the flag byte, eight consecutive rows per load
+    // instruction and group.  A row is in the window iff it is unfiltered, not before the block's first tested row, and its
+    // k-mer offset m - pos is one of 0..k-1; positions are non-decreasing in a regular block, so the first unfiltered row
+    // with pos < m-k+1 (or the block's start) ends the window -- if none of the 64 rows does, the window is longer than
+    // what is looked at here and goes to the row-by-row kernel (k1_rare) ----
+    uint32_t W = 0xFFFFFFFFu;                   // my eight rows' slots, four bits each (15: not in the window)
+    bool stop_any = false;
+    const NbDesc *dp = A.desc + P.nb;
+    if (window) {
+        const int64_t lb = max(dp->row_begin, dp->first());
+        int pj[8];
+        uint32_t fj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t rr = r - (8 * e + s);
+            const int64_t rc = rr < 0 ? 0 : rr;
+            pj[e] = T.pos[rc];
+            fj[e] = T.flags[rc];
+        }
+        W = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t rr = r - (8 * e + s);
+            const bool inb = rr >= lb;
+            const bool nj = fj[e] & MC_F_MODEL_N;
+            const int code = m - pj[e];
+            const bool inw = inb && !nj && code >= 0 && code < k;
+            stop_any = stop_any || !inb || (!nj && code >= k);
+            W |= (inw ? (uint32_t)code : 15u) << (4 * e);
         }
     }
+    const bool covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
+    const bool fast = window && covered;
+    if (window && !covered && s == 0) A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
     // ---- lane 0 of the group: what the info word and the segment column need from the descriptor and the reference.  These
     // are three dependent loads (descriptor -> sequence offset -> base / mask word); issued here they are in flight beside
     // the (event, model) loads below instead of behind them ----
     uint32_t ctx_bits = 0u;               // MC_I_EDGE, or context[k] in its place
     int32_t seg_of = 0;
     if (fast && s == 0) {
-        const NbDesc *dp = A.desc + P.nb;
         const int64_t L = dp->contig_len;
         const bool rev0 = P.flags & PF_REV;
         seg_of = T.nb_seg_begin[P.nb];
@@ -1452,15 +1313,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             ctx_bits = ((uint32_t)ch) << MC_I_NEXT_SHIFT;
         }
     }
-    // ---- my slot's rows: bit j of ms <=> row r-j belongs to slot s ----
-    const uint64_t c0 = P.code[0], c1 = P.code[1], c2 = P.code[2], c3 = P.code[3];
-    uint64_t ms = (s & 1 ? c0 : ~c0) & (s & 2 ? c1 : ~c1) & (s & 4 ? c2 : ~c2) & ~c3;
+    // ---- my slot's rows: bit j of ms <=> row r-j belongs to slot s.  Every lane fetches the eight slot words of its group and
+    // picks the nibbles that equal its slot: bit 4e of Z <=> row r-l-8e is mine ----
+    uint32_t lo4 = 0u, hi4 = 0u;                // nibble e: rows of lanes 0..3 / 4..7 at distance 8e
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const uint32_t X = (uint32_t)__shfl((int)W, gsh + l) ^ ((uint32_t)s * 0x11111111u);
+        const uint32_t Z = ~(X | (X >> 1) | (X >> 2) | (X >> 3)) & 0x11111111u;
+        if (l < 4) lo4 |= Z << l; else hi4 |= Z << (l - 4);
+    }
+    auto spread = [](uint32_t x) -> uint64_t {  // nibble e -> the low half of byte e
+        uint64_t y = x;
+        y = (y | (y << 16)) & 0x0000FFFF0000FFFFull;
+        y = (y | (y << 8)) & 0x00FF00FF00FF00FFull;
+        y = (y | (y << 4)) & 0x0F0F0F0F0F0F0F0Full;
+        return y;
+    };
+    uint64_t ms = spread(lo4) | (spread(hi4) << 4);
     if (!fast || s >= k) ms = 0ull;
     // the stray event of a palindromic first site row (R5): first in the slot of its pseudo-position
     bool has_stray = false;
     double stray_val = 0.0;
     if (fast && (P.flags & PF_STRAY)) {
-        const NbDesc *ds = A.desc + P.nb;
+        const NbDesc *ds = dp;
         const int sq = m - ds->stray_q;
         if (s < k && sq == s) { has_stray = true; stray_val = (double)ds->stray_d / 10000.0; }
     }
@@ -2115,7 +1990,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     __syncthreads();
     unsigned long long total = 0, base = 0;
     for (int w = 0; w < PACK_THREADS / 64; ++w) { total += s_sum[0][w]; base += s_sum[1][w]; }
-    constexpr unsigned head_words = offsetof(Counters, ticket) / 4;      // everything the host looks at
+    constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;      // everything the host looks at
     if (blockIdx.x == 0) {
         if (tid < (int)head_words && tid != (int)(offsetof(Counters, n_kept) / 4) && tid != (int)(offsetof(Counters, n_kept) / 4 + 1))
             reinterpret_cast<volatile unsigned int *>(host_status)[tid] = reinterpret_cast<const unsigned int *>(cnt)[tid];
@@ -2261,7 +2136,6 @@ struct mc_ctx {
     Payload *payload = nullptr;
     long long payload_cap = 0;
     int n_cu = 256;
-    int scan_wgs = MC_SCAN_WGS;    // resident k1_scan workgroups per CU (occupancy query; MCALLER_SCAN_WGS overrides)
     int emit_wgs = 4;              // resident k1_emit workgroups per CU (occupancy query)
     Counters *cnt = nullptr;
     int last_k = 0;
@@ -2431,12 +2305,10 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
-        int occ = 0;       // resident k1_scan workgroups per CU: the grid is sized to it (tickets balance the rest)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1_scan, NTHREADS, 0) == hipSuccess && occ > 0) c->scan_wgs = occ;
-        if (const char *e = getenv("MCALLER_SCAN_WGS")) { if (atoi(e) > 0) c->scan_wgs = atoi(e); }
+        int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1_emit, 256, 0) == hipSuccess && occ > 0) c->emit_wgs = occ;
         if (const char *e = getenv("MCALLER_EMIT_WGS")) { if (atoi(e) > 0) c->emit_wgs = atoi(e); }
-        if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: %d CUs, k1_scan occupancy %d workgroups/CU, k1_emit %d\n", c->n_cu, c->scan_wgs, c->emit_wgs);
+        if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: %d CUs, k1_emit occupancy %d workgroups/CU\n", c->n_cu, c->emit_wgs);
     }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipMalloc((void **)&c->cnt, sizeof(Counters)));
@@ -2560,7 +2432,7 @@ static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int6
     S.cap_rows = grow(rows, c->res_rows);
     S.cap_segs = std::max<int64_t>(grow(segs, c->res_segs), 16);
     S.cap_reads = std::max<int64_t>(grow(reads, c->res_reads), 16);
-    const int64_t padded = ((S.cap_rows + TILE - 1) / TILE) * TILE + TILE;
+    const int64_t padded = ((S.cap_rows + VTILE - 1) / VTILE) * VTILE + VTILE;     // (whole tiles of the scan and of k_validate)
     const SmallLayout L = small_layout(S.cap_segs, padded / TILE, S.cap_reads);
     if (dev_alloc(S.allocs, &S.pos, (size_t)padded) || dev_alloc(S.allocs, &S.idx, (size_t)padded) ||
         dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded) ||
@@ -2583,7 +2455,7 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->tiles, (size_t)nt + 1) || dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->nb_f0idx, (size_t)nb + 1) || dev_alloc(P, &c->nb_lastidx, (size_t)nb + 1) ||
-        dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * (TILE / 64)) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
+        dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
         dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1))
         return -10;
     c->scratch_nb = nb;
@@ -2709,7 +2581,7 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     HIP_TRY(hipEventRecord(S.ev_uploaded, us));
     HIP_TRY(hipStreamWaitEvent(c->stream, S.ev_uploaded, 0));
     HIP_TRY(hipEventRecord(S.ev_val_start, c->stream));
-    if (n_nb > 0) hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(VT), 0, c->stream, T);
+    if (n_nb > 0) hipLaunchKernelGGL(k_validate, dim3((unsigned)((n + VTILE - 1) / VTILE)), dim3(VT), 0, c->stream, T);
     HIP_TRY(hipEventRecord(S.ev_valid, c->stream));
     HIP_TRY(hipGetLastError());
     c->T = T;
@@ -2962,11 +2834,10 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
-#ifdef MC_K1_EXPERIMENTS
-    { const char *dbg = getenv("MCALLER_K1_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
-#endif
-    hipLaunchKernelGGL(k1_scan, dim3((unsigned)std::min<int64_t>((T.n_tiles + MC_SCAN_CHUNK - 1) / MC_SCAN_CHUNK, (int64_t)c->n_cu * c->scan_wgs)), dim3(NTHREADS), 0,   // (chunks, not tiles)
-                       st, A);
+    // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
+    const bool dense = c->ref_total_len > 0 && (double)c->R.n_sites * 64.0 > (double)c->ref_total_len;
+    if (dense) hipLaunchKernelGGL(k1_scan<TILE / 4 + NBR + 64>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL(k1_scan<128>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
@@ -3048,11 +2919,6 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
         int64_t n = (int64_t)h.n_records;
-#ifdef MC_PROFILE
-        fprintf(stderr, "k1_scan phase cycles:");
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", h.prof[i]);
-        fprintf(stderr, "\n");
-#endif
         if (h.overflow) {                   // the buffers were a guess; the exact need is known now (+ shard skew)
             cap = std::max<int64_t>(cap * 2, n + n / 4 + 4096);
             continue;
