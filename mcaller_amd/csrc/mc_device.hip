@@ -738,16 +738,22 @@ __device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbit
 
 constexpr int PT = 16;              // payload slots reserved per tile; further chunks of 64 come from an atomic
 constexpr int NCHUNK = TILE / 64 + 1; // ... at most this many of them (one window per row, and one more per block start)
-constexpr int NQ = TILE / 256;      // k1_scan: stripes of 256 rows per tile -- every lane holds four consecutive rows of a stripe
+constexpr int NQ = TILE / 512;      // k1_scan: stripes of 512 rows per tile -- every lane holds EIGHT consecutive rows of a stripe
 constexpr int NBR = 32;             // ... name blocks of a tile the register path handles (tiles of smaller reads: scan_tile_slowly)
-static_assert(TILE % 256 == 0, "whole stripes");
+static_assert(TILE % 512 == 0, "whole stripes");
 
-struct __attribute__((aligned(16))) CandGroup {   // a group of four rows that may hold a site row, with the two rows behind it
-    int32_t pos[6];
-    uint32_t f4;        // flag bytes of the four rows
-    uint32_t nf_i0;     // flag bytes of the two rows behind them | first row of the group (tile-relative) << 16
+struct __attribute__((aligned(16))) CandUnit {    // eight rows that may hold a site row, with the two rows behind them
+    int32_t pos[10];
+    uint8_t fl[10];     // their flag bytes
+    uint16_t i0;        // first row of the unit (tile-relative)
+    uint32_t pad[3];
 };
-static_assert(sizeof(CandGroup) == 32, "CandGroup layout");
+static_assert(sizeof(CandUnit) == 64, "CandUnit layout");
+
+// bits [sh, sh+32) of the 64-bit value hi:lo (sh < 32): one v_alignbit
+__device__ __forceinline__ uint32_t bits_from(uint32_t lo, uint32_t hi, int sh) {
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+}
 
 // payload slot of the tile's window number `rank`: the first PT in the tile's own strip, the rest in chunks of 64
 struct TileSlots {
@@ -830,24 +836,24 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc
 }
 
 // k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier: the position and flag columns (5 B/row) go
-// from HBM into REGISTERS -- every lane holds four consecutive rows of each 256-row stripe, all loads of the tile are issued
-// before anything is used -- and 96 % of the rows never leave them: one 64-bit extract from the strand bitmask (a window of it
-// staged in LDS per tile) tells for a group of four rows whether any of their k-mers holds an 'M' at all.  Only the groups that
+// from HBM into REGISTERS -- every lane holds eight consecutive rows of each 512-row stripe, all loads of the tile are issued
+// before anything is used -- and 95 % of the rows never leave them: one 32-bit extract from the strand bitmask (a window of it
+// staged in LDS per tile) tells for a unit of eight rows whether any of their k-mers holds an 'M' at all.  Only the units that
 // pass are written to an LDS list (with the two rows behind them); when all stripes are done -- the columns' registers are
-// free again -- one lane per row of the listed groups decides whether the row is the LAST row of a window: its k-mer holds an
+// free again -- one lane per row of the listed units decides whether the row is the LAST row of a window: its k-mer holds an
 // 'M' (first one: the site m, :176) and the next unfiltered row of the read lies beyond m, or there is none and another read
 // (or the next shard) follows (:179).  Every closed window leaves a 32-byte payload (last row, site, closing row); which of the
 // rows before it belong to which slot is worked out by k1_emit, eight lanes per window.  Whatever needs more than the tile's
 // registers (a closing row beyond the tile or behind two 'N' rows, mask words outside the staged window) is an out-of-line call
 // that reads global memory.  Waves are short and light, many are resident per SIMD, their loads overlap: the kernel streams.
-// CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one group in 25 is listed) bails out to
-// scan_tile_slowly if a tile overflows it; the dense instance holds every group of the tile.
+// CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one unit in 20 is listed) bails out to
+// scan_tile_slowly if a tile overflows it; the dense instance holds every unit of the tile.
 template <int CG>
 __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
     __shared__ uint32_t s_bits[NBST][64];
-    __shared__ __attribute__((aligned(16))) CandGroup s_cand[CG];
+    __shared__ __attribute__((aligned(16))) CandUnit s_cand[CG];
     __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
-    __shared__ uint16_t s_seg_end[NBR];             // candidate groups listed up to and including this name block
+    __shared__ uint16_t s_seg_end[NBR];             // candidate units listed up to and including this name block
     const DevTable &T = A.T;
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -856,24 +862,26 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
     const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
 
     // ---- the columns: every load of the tile goes out before anything is used ----
-    int4 p4[NQ];
-    uint32_t fl4[NQ];
+    int4 pa[NQ], pb[NQ];                            // rows i0 .. i0+3, i0+4 .. i0+7 of the lane's unit in stripe j
+    uint2 fl8[NQ];
     if (nrows == TILE) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 4;
-            p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-            fl4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
+            const int i0 = (j * 64 + lane) * 8;
+            pa[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+            pb[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0 + 4);
+            fl8[j] = *reinterpret_cast<const uint2 *>(T.flags + t0 + i0);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 4;
-            p4[j] = make_int4(0, 0, 0, 0);
-            fl4[j] = 0x02020202u;                   // (rows past the table: MC_F_MODEL_N, never looked at anyway)
-            if (i0 < nrows) {                       // (arrays are padded: whole groups stay in bounds)
-                p4[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-                fl4[j] = *reinterpret_cast<const uint32_t *>(T.flags + t0 + i0);
+            const int i0 = (j * 64 + lane) * 8;
+            pa[j] = pb[j] = make_int4(0, 0, 0, 0);
+            fl8[j] = make_uint2(0x02020202u, 0x02020202u);   // (rows past the table: MC_F_MODEL_N, never looked at anyway)
+            if (i0 < nrows) {                       // (arrays are padded: whole units stay in bounds)
+                pa[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
+                pb[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0 + 4);
+                fl8[j] = *reinterpret_cast<const uint2 *>(T.flags + t0 + i0);
             }
         }
     }
@@ -883,9 +891,9 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
     s_bits[1][lane] = lane < td.nwb ? ((td.revb ? A.R.mr : A.R.mf) + td.boffb)[lane] : 0u;
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    // ---- all lanes, block by block and stripe by stripe: which groups of four rows can hold a site row at all? ----
-    // A group inside its block spans positions [p0, p3]; its rows' k-mers cover mask bits [p0, p3 + k).  One 64-bit extract from
-    // the staged mask window decides; groups cut by the block's ends, groups whose span does not fit the extract or the staged
+    // ---- all lanes, block by block and stripe by stripe: which units of eight rows can hold a site row at all? ----
+    // A unit inside its block spans positions [p0, p7]; its rows' k-mers cover mask bits [p0, p7 + k).  One 32-bit extract from
+    // the staged mask window decides; units cut by the block's ends, units whose span does not fit the extract or the staged
     // window are listed unconditionally.
     int ncand = 0;
     bool overflow = false;
@@ -899,34 +907,36 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
             const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                if (j * 256 + 256 <= lo || j * 256 >= hi) continue;      // (wave-uniform)
-                const int i0 = (j * 64 + lane) * 4;
-                const int4 p = p4[j];
-                const bool touches = i0 + 4 > lo && i0 < hi;
-                const bool full = i0 >= lo && i0 + 4 <= hi;
-                const int span = p.w - p.x + k;
-                const int wi = (p.x >> 5) - sw0;
-                const bool decidable = full && span > 0 && span <= 33 && wi >= 0 && wi + 1 < snw;
+                if (j * 512 + 512 <= lo || j * 512 >= hi) continue;      // (wave-uniform)
+                const int i0 = (j * 64 + lane) * 8;
+                const int p0 = pa[j].x, p7 = pb[j].w;
+                const bool touches = i0 + 8 > lo && i0 < hi;
+                const bool full = i0 >= lo && i0 + 8 <= hi;
+                const int span = p7 - p0 + k;
+                const int wi = (p0 >> 5) - sw0;
+                const bool decidable = full && span > 0 && span <= 32 && wi >= 0 && wi + 1 < snw;
                 const int wc = min(max(wi, 0), BW - 2);
-                const uint64_t bits = ((((uint64_t)sb[wc + 1] << 32) | sb[wc]) >> (p.x & 31)) & ((1ull << (span & 63)) - 1ull);
-                const bool cand = touches && (!decidable || bits != 0ull);
+                const uint32_t bits = bits_from(sb[wc], sb[wc + 1], p0 & 31) & (0xFFFFFFFFu >> ((32 - span) & 31));
+                const bool cand = touches && (!decidable || bits != 0u);
                 const unsigned long long bal = __ballot(cand);
                 if (!bal) continue;
-                if (ncand + 64 > CG) { overflow = true; continue; }
-                // the two rows behind the group: the next lane's first two rows (lane 63: the next stripe's)
-                int nx = __shfl_down(p.x, 1), ny = __shfl_down(p.y, 1);
-                uint32_t nf = __shfl_down(fl4[j], 1);
+                if (ncand + __popcll(bal) > CG) { overflow = true; continue; }
+                // the two rows behind the unit: the next lane's first two rows (lane 63: the next stripe's)
+                int nx = __shfl_down(pa[j].x, 1), ny = __shfl_down(pa[j].y, 1);
+                uint32_t nf = __shfl_down(fl8[j].x, 1);
                 if (j + 1 < NQ) {
-                    const int sx = __shfl(p4[(j + 1) % NQ].x, 0), sy = __shfl(p4[(j + 1) % NQ].y, 0);
-                    const uint32_t sf = __shfl(fl4[(j + 1) % NQ], 0);
+                    const int sx = __shfl(pa[(j + 1) % NQ].x, 0), sy = __shfl(pa[(j + 1) % NQ].y, 0);
+                    const uint32_t sf = __shfl(fl8[(j + 1) % NQ].x, 0);
                     if (lane == 63) { nx = sx; ny = sy; nf = sf; }
                 }
                 if (cand) {
-                    CandGroup g;
-                    g.pos[0] = p.x; g.pos[1] = p.y; g.pos[2] = p.z; g.pos[3] = p.w; g.pos[4] = nx; g.pos[5] = ny;
-                    g.f4 = fl4[j];
-                    g.nf_i0 = (nf & 0xFFFFu) | ((uint32_t)i0 << 16);
-                    s_cand[ncand + __popcll(bal & below)] = g;
+                    CandUnit *g = s_cand + (ncand + __popcll(bal & below));
+                    int4 *gp = reinterpret_cast<int4 *>(g);
+                    gp[0] = pa[j];
+                    gp[1] = pb[j];
+                    // pos[8], pos[9] | flag bytes 0..7 | flag bytes 8, 9 and the unit's first row
+                    gp[2] = make_int4(nx, ny, (int)fl8[j].x, (int)fl8[j].y);
+                    reinterpret_cast<uint32_t *>(g)[12] = (nf & 0xFFFFu) | ((uint32_t)i0 << 16);
                 }
                 ncand += __popcll(bal);
             }
@@ -935,11 +945,12 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
     }
     if (overflow) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }    // (nothing has been written yet)
 
-    // ---- one lane per row of the listed groups, block by block: is this row the last row of a window? ----
+    // ---- one lane per row of the listed units, block by block: is this row the last row of a window? ----
     ScanGlobals G;
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
+    const uint32_t kmask = (1u << k) - 1u;
     int seg_begin = 0;
     for (int bi = 0; bi < td.nnb; ++bi) {
         const int nb_abs = td.nb0 + bi;
@@ -958,9 +969,8 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
             const int wi = (p >> 5) - sw0;
             ok = wi >= 0 && wi + 1 < snw;
             const int wc = min(max(wi, 0), BW - 2);
-            uint64_t bits = ((((uint64_t)sb[wc + 1]) << 32) | sb[wc]) >> (p & 31);
-            bits &= (1ull << k) - 1ull;
-            int o = bits ? (int)__builtin_ctzll(bits) : -1;
+            const uint32_t bits = bits_from(sb[wc], sb[wc + 1], p & 31) & kmask;
+            int o = bits ? (int)__builtin_ctz(bits) : -1;
             if (p >= d.contig_len) { o = -1; ok = true; }
             return o;
         };
@@ -975,16 +985,14 @@ __global__ __launch_bounds__(64) void k1_scan(K1Args A) {
         }
         const int64_t lb_abs = max(d.row_begin, d.first());
         const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t0 + (int64_t)nrows) - t0);
-        for (int base = first_g * 4; base < seg_end * 4; base += 64) {
+        for (int base = first_g * 8; base < seg_end * 8; base += 64) {
             const int idx = base + lane;
-            const bool have = idx < seg_end * 4;
-            const CandGroup *g = s_cand + (have ? idx >> 2 : first_g);
-            const int e = idx & 3;
+            const bool have = idx < seg_end * 8;
+            const CandUnit *g = s_cand + (have ? idx >> 3 : first_g);
+            const int e = idx & 7;
             const int p = g->pos[e], p1 = g->pos[e + 1], p2 = g->pos[e + 2];
-            const unsigned long long fb = (unsigned long long)g->f4 | ((unsigned long long)(g->nf_i0 & 0xFFFFu) << 32);
-            const uint32_t f = (uint32_t)(fb >> (8 * e)) & 0xFFu, f1 = (uint32_t)(fb >> (8 * e + 8)) & 0xFFu,
-                           f2 = (uint32_t)(fb >> (8 * e + 16)) & 0xFFu;
-            const int i = (int)(g->nf_i0 >> 16) + e;
+            const uint32_t f = g->fl[e], f1 = g->fl[e + 1], f2 = g->fl[e + 2];
+            const int i = (int)g->i0 + e;
             bool closed = false, far = false;
             int m = 0, cp = 0;
             int64_t cr = 0;
@@ -2836,8 +2844,8 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const bool dense = c->ref_total_len > 0 && (double)c->R.n_sites * 64.0 > (double)c->ref_total_len;
-    if (dense) hipLaunchKernelGGL(k1_scan<TILE / 4 + NBR + 64>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
-    else hipLaunchKernelGGL(k1_scan<128>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    if (dense) hipLaunchKernelGGL(k1_scan<TILE / 8 + NBR>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL(k1_scan<64>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);

@@ -17,8 +17,8 @@ import sys
 
 
 def short(name):
-    name = name.replace('(anonymous namespace)::', '')
-    return name.split('(')[0]
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return name.split('(')[0].split('<')[0]
 
 
 def collect(d, counter):
