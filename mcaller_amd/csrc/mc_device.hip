@@ -55,7 +55,7 @@ void mc_set_error(const char *fmt, ...);
 namespace {
 
 #ifndef MC_TILE
-#define MC_TILE 1024
+#define MC_TILE 2048
 #endif
 constexpr int TILE = MC_TILE;       // rows per workgroup tile
 constexpr int NBST = 2;             // name blocks of a tile that get a window of their strand mask staged in LDS (k1_scan)
@@ -110,7 +110,8 @@ struct DevTable {
     uint32_t *nb_vflags = nullptr;    // [n_nb]
     NbDesc *nb_tmpl = nullptr;        // [n_nb] the pass-independent fields of the name-block descriptors (k_nb_template)
     int64_t n_tiles = 0;
-    int32_t *tile_nb = nullptr;       // [n_tiles]
+    int32_t *tile_nb = nullptr;       // [n_tiles] name block of the first row of every tile of the scan
+    int32_t *vtile_nb = nullptr;      // [ceil(n_rows / VTILE)] ... of every tile of k_validate
     int has_repeats = 0;
 };
 
@@ -198,11 +199,11 @@ __device__ __forceinline__ unsigned char comp_char(unsigned char c) {
 // it -- the neighbour lane's last row (one shuffle), the wave's first lane re-reads its predecessor -- and the flags are
 // OR-ed per name block: a tile that lies inside one block (the usual case) costs one atomic.  nb_vflags arrives zeroed
 // (V_MULTI_SEG preset) with the table's small arrays.
-constexpr int VTILE = 3072;             // rows per workgroup of k_validate (a multiple of the scan's tile)
+constexpr int VTILE = 3072;             // rows per workgroup of k_validate (its own tiling: T.vtile_nb)
 constexpr int VT = 256;                 // threads: VTILE / 256 rows each, in groups of four
 constexpr int VQ = VTILE / (VT * 4);    // 4-row groups per thread
 constexpr int VMAXNB = 64;              // name blocks of a tile whose flags are gathered in LDS (the rest: global atomics)
-static_assert(VTILE % (VT * 4) == 0 && VTILE % TILE == 0, "whole row groups per thread, whole scan tiles per workgroup");
+static_assert(VTILE % (VT * 4) == 0, "whole row groups per thread");
 
 __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
     __shared__ uint32_t s_start[VTILE / 32];    // bit i: row t0+i starts a name block (i > 0)
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
         }
     }
     // ---- name-block starts inside the tile ----
-    const int nb0 = T.tile_nb[tile * (VTILE / TILE)];
+    const int nb0 = T.vtile_nb[tile];
     for (int i = tid; i < VTILE / 32; i += VT) s_start[i] = 0u;
     if (tid < VMAXNB) s_vf[tid] = 0u;
     __syncthreads();
@@ -2064,7 +2065,7 @@ struct K0Set {
 // slot is allocated once (mc_ctx_reserve_tables, or by the first table that needs more) -- an upload is DMA transfers and
 // two small kernels, no hipMalloc / hipFree.
 struct SmallLayout {       // byte offsets of a table's small arrays inside one block: the same on the pinned host stage and on the device
-    size_t seg_begin, seg_read, seg_contig, nb_row_begin, nb_seg_begin, nb_read, nb_repeat, nb_vflags, tile_nb, qual, total;
+    size_t seg_begin, seg_read, seg_contig, nb_row_begin, nb_seg_begin, nb_read, nb_repeat, nb_vflags, tile_nb, vtile_nb, qual, total;
 };
 static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2079,6 +2080,7 @@ static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads)
     L.nb_repeat = o;    o = al(o + (size_t)n_seg);
     L.nb_vflags = o;    o = al(o + (size_t)(n_seg + 1) * 4);
     L.tile_nb = o;      o = al(o + (size_t)(n_tiles + 1) * 4);
+    L.vtile_nb = o;     o = al(o + (size_t)(n_tiles + 1) * 4);     // (never more tiles than the scan has: VTILE >= TILE)
     L.qual = o;         o = al(o + (size_t)n_reads * 8);
     L.total = o;
     return L;
@@ -2515,6 +2517,7 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     int64_t *seg_begin = (int64_t *)(st + L.seg_begin), *nb_row = (int64_t *)(st + L.nb_row_begin);
     int32_t *seg_read = (int32_t *)(st + L.seg_read), *seg_contig = (int32_t *)(st + L.seg_contig);
     int32_t *nb_seg = (int32_t *)(st + L.nb_seg_begin), *nb_read = (int32_t *)(st + L.nb_read), *tile_nb = (int32_t *)(st + L.tile_nb);
+    int32_t *vtile_nb = (int32_t *)(st + L.vtile_nb);
     uint8_t *nb_rep = st + L.nb_repeat;
     uint32_t *nb_vf = (uint32_t *)(st + L.nb_vflags);
     if (h->n_seg > 0) {
@@ -2557,6 +2560,11 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
             while (b + 1 < n_nb && nb_row[b + 1] <= t * TILE) ++b;
             tile_nb[t] = b;
         }
+        b = 0;
+        for (int64_t t = 0; t * VTILE < n; ++t) {
+            while (b + 1 < n_nb && nb_row[b + 1] <= t * VTILE) ++b;
+            vtile_nb[t] = b;
+        }
     }
     if (read_qual && h->n_reads > 0) memcpy(st + L.qual, read_qual, (size_t)h->n_reads * 8);
 
@@ -2570,6 +2578,7 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     T.nb_row_begin = (int64_t *)(dv + L.nb_row_begin); T.nb_seg_begin = (int32_t *)(dv + L.nb_seg_begin);
     T.nb_read = (int32_t *)(dv + L.nb_read); T.nb_repeat = dv + L.nb_repeat; T.nb_vflags = (uint32_t *)(dv + L.nb_vflags);
     T.tile_nb = (int32_t *)(dv + L.tile_nb);
+    T.vtile_nb = (int32_t *)(dv + L.vtile_nb);
     S.qual = read_qual ? (double *)(dv + L.qual) : nullptr;
     S.n_qual = read_qual ? h->n_reads : 0;
     S.tmpl_ref = -1;
