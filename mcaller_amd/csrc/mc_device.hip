@@ -592,6 +592,7 @@ struct TileDesc {      // per tile, written by k0_tiles after classification (pl
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
 constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
 constexpr int WROWS = 64;   // rows before a window's last row that k1_emit looks at (longer windows: k1_rare)
+constexpr int FRONT = 64;   // rows of padding in front of the pos / flags / pair columns, so that a look-back never leaves them
 
 struct __attribute__((aligned(16))) Payload {
     int64_t r;          // last row of the window
@@ -1267,38 +1268,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
     // ---- which of the rows before the window's last row belong to which slot?  Lane l of the group looks at rows r-l,
-    // r-l-8, ... r-l-56: eight independent loads of the position and of the flag byte, eight consecutive rows per load
-    // instruction and group.  A row is in the window iff it is unfiltered, not before the block's first tested row, and its
-    // k-mer offset m - pos is one of 0..k-1; positions are non-decreasing in a regular block, so the first unfiltered row
-    // with pos < m-k+1 (or the block's start) ends the window -- if none of the 64 rows does, the window is longer than
-    // what is looked at here and goes to the row-by-row kernel (k1_rare) ----
+    // r-l-8, r-l-16, r-l-24: four independent loads of the position and of the flag byte, eight consecutive rows per load
+    // instruction and group (the columns have FRONT rows of padding in front: no clamping).  A row is in the window iff it
+    // is unfiltered, not before the block's first tested row, and its k-mer offset m - pos is one of 0..k-1; positions are
+    // non-decreasing in a regular block, so the first unfiltered row with pos < m-k+1 (or the block's start) ends the window.
+    // One window in a hundred is longer than 32 rows: the groups that saw no end look at rows 32..63 in a second step; a
+    // window longer than 64 rows goes to the row-by-row kernel (k1_rare).  (Fewer rows looked at = fewer DRAM lines per
+    // window: the kernel's time is the number of scattered lines it touches.) ----
+    const NbDesc *dp = A.desc + P.nb;
     uint32_t W = 0xFFFFFFFFu;                   // my eight rows' slots, four bits each (15: not in the window)
     bool stop_any = false;
-    const NbDesc *dp = A.desc + P.nb;
-    if (window) {
-        const int64_t lb = max(dp->row_begin, dp->first());
-        int pj[8];
-        uint32_t fj[8];
+    int back = 0;
+    // rows r-l-8e, e = E0 .. E0+3 -> their nibbles of W
+    auto look = [&](const int E0) {
+        const int32_t *pp = T.pos + (r - s);
+        const uint8_t *fp = T.flags + (r - s);
+        int pj[4];
+        uint32_t fj[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t rr = r - (8 * e + s);
-            const int64_t rc = rr < 0 ? 0 : rr;
-            pj[e] = T.pos[rc];
-            fj[e] = T.flags[rc];
+        for (int e = 0; e < 4; ++e) {
+            pj[e] = pp[-8 * (E0 + e)];
+            fj[e] = fp[-8 * (E0 + e)];
         }
-        W = 0u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t rr = r - (8 * e + s);
-            const bool inb = rr >= lb;
+        for (int e = 0; e < 4; ++e) {
+            const bool inb = 8 * (E0 + e) <= back;          // not before the block's first tested row
             const bool nj = fj[e] & MC_F_MODEL_N;
             const int code = m - pj[e];
             const bool inw = inb && !nj && code >= 0 && code < k;
             stop_any = stop_any || !inb || (!nj && code >= k);
-            W |= (inw ? (uint32_t)code : 15u) << (4 * e);
+            W = (W & ~(15u << (4 * (E0 + e)))) | ((inw ? (uint32_t)code : 15u) << (4 * (E0 + e)));
         }
+    };
+    if (window) {
+        back = (int)min(r - max(dp->row_begin, dp->first()), (int64_t)1 << 20) - s;
+        look(0);
     }
-    const bool covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
+    bool covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
+    if (__ballot(window && !covered)) {             // (one round in twelve)
+        if (window && !covered) look(4);
+        covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
+    }
     const bool fast = window && covered;
     if (window && !covered && s == 0) A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
     // ---- lane 0 of the group: what the info word and the segment column need from the descriptor and the reference.  These
@@ -2442,10 +2452,14 @@ static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int6
     S.cap_rows = grow(rows, c->res_rows);
     S.cap_segs = std::max<int64_t>(grow(segs, c->res_segs), 16);
     S.cap_reads = std::max<int64_t>(grow(reads, c->res_reads), 16);
-    const int64_t padded = ((S.cap_rows + VTILE - 1) / VTILE) * VTILE + VTILE;     // (whole tiles of the scan and of k_validate)
+    const int64_t padded = ((S.cap_rows + VTILE - 1) / VTILE) * VTILE + VTILE + FRONT;     // (whole tiles of the scan and of k_validate)
     const SmallLayout L = small_layout(S.cap_segs, padded / TILE, S.cap_reads);
     if (dev_alloc(S.allocs, &S.pos, (size_t)padded) || dev_alloc(S.allocs, &S.idx, (size_t)padded) ||
-        dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded) ||
+        dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded))
+        return -10;
+    // (FRONT rows of padding before row 0 of the columns k1_emit looks back into: rows -1 .. -64 are readable)
+    S.pos += FRONT; S.evmu += FRONT; S.flags += FRONT;
+    if (
         dev_alloc(S.allocs, &S.nb_tmpl, (size_t)S.cap_segs + 1) || dev_alloc(S.allocs, &S.small_dev, L.total))
         return -10;
     HIP_TRY(hipHostMalloc((void **)&S.stage, L.total, hipHostMallocDefault));
