@@ -154,10 +154,14 @@ struct Counters {          // device-side status block
     unsigned long long n_records;
     unsigned long long shard[NSHARD];
     unsigned int overflow;
-    unsigned int n_irregular;
+    unsigned int pad_irregular;
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
+    // the pass in which a name block was last classified irregular (mc_params-independent pass number, never 0).  Written,
+    // never zeroed: k0_first_site classifies while it zeroes the other counters, so a count could lose updates -- a pass is
+    // special iff this equals its own number
+    unsigned long long irregular_pass;
     unsigned long long end_of_head;   // (k_pack copies everything before this field to the host)
 };
 
@@ -382,83 +386,14 @@ __device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uin
 // (also zeroes the pass's counters: nothing in here uses them, every later kernel of the pass does.  hipMemsetAsync would
 // do too, but the runtime's fill ends with a system-scope release, and that release waits behind the PCIe writes of a
 // copy-out running on the other stream)
-__global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
-                              NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
-                              int32_t *__restrict__ nb_lastidx, Counters *__restrict__ cnt) {
-    if (blockIdx.x == 0) {
-        unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
-        for (unsigned i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
-    }
-    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= T.n_nb) return;
-    NbDesc d = T.nb_tmpl[b];
-    const int n_seg = d.pad;
-    const bool filtered = qual[d.read] < qual_thresh;
-    const int32_t last_idx = T.idx[d.row_end - 1];
-    int64_t f0 = -1;
-    int f0rev = 0;
-    if (!filtered) {
-        const int seg0 = n_seg == 1 ? 0 : T.nb_seg_begin[b];
-        for (int si = 0; si < n_seg && f0 < 0; ++si) {
-            int64_t L, sb, se;
-            const uint32_t *mf, *mr;
-            if (n_seg == 1) {                      // the usual case: everything is in the template
-                L = d.contig_len; sb = d.row_begin; se = d.row_end;
-                mf = R.mf + d.mask_off; mr = R.mr + d.mask_off;
-            } else {
-                const int seg = seg0 + si;
-                const int contig = T.seg_contig[seg];
-                L = R.contig_len[contig];
-                mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
-                sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
-            }
-            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): one round of
-            // 512 rows finds f0 for two blocks in three, after that rounds of 1024 rows -- a round costs two dependent loads whatever
-            // its width.
-            int64_t base = sb;
-            if (base < se) { f0 = first_site_round<8>(T, mf, mr, L, base, se, k, lane, f0rev); base += 512; }
-            for (; base < se && f0 < 0; base += 1024)
-                f0 = first_site_round<16>(T, mf, mr, L, base, se, k, lane, f0rev);
-        }
-    }
-    if (lane == 0) {
-        d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
-        d.rev = (uint8_t)f0rev;
-        d.filtered = filtered ? 1 : 0;
-        d.pad = 0;
-        desc[b] = d;
-        nb_f0[b] = f0;
-        nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
-        nb_lastidx[b] = last_idx;
-    }
-}
-
-// One thread per name block: is the block regular?
-//
-// Regular = the sequential machine reduces to the local window rule (DESIGN.md): the read name is new
-// (`last_read` differs when the block starts), one contig, positions non-decreasing, event indices strictly
-// monotone, and every row after the first site row f0 takes the strand f0 was tested on.  One irregularity is
-// common enough (~1 % of reads) to be folded into the fast path exactly: a reverse read whose f0 is a
-// reverse-complement-palindromic k-mer (R5).  f0 is then scored on '+', opening a one-event '+' window; the
-// rows after it are all '-' (event index decreasing, :169).  What the machine does with that event depends only
-// on the next unfiltered row r1 (:179, :242-256, :272-279):
-//   pos(r1) >  site of the '+' window: the window is flushed with k-1 empty slots (a too-many-skips record);
-//              if r1 continues the chain (a '-' site row within skip_thresh+1) the event shifts with the slots
-//              and stays at its own position p, else it is dropped;
-//   pos(r1) <= site: if r1 is a '-' site row the strand flips, mpos is re-set to r1's site but the slots are
-//              kept: the event now sits at pseudo-position pos(r1)+o_r-o_f; else everything is cleared.
-// From then on the block behaves as a regular '-' block starting at f0+1 with one extra event, first in its
-// slot, at that (pseudo-)position.
-__global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, const int64_t *__restrict__ nb_f0,
-                            int entry_read, int k, int skip_thresh, Counters *cnt) {
-    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
-    if (b >= T.n_nb) return;
-    NbDesc d = desc[b];
-    const int64_t f0 = nb_f0[b];
+// (the body of the classification: block b with descriptor d and first site row f0; lookback: the block may see
+// name == last_read, i.e. the table repeats read names or continues a previous shard's read)
+__device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &R, NbDesc &d, int b, int64_t f0, bool lookback,
+                                               const int64_t *__restrict__ nb_f0, int entry_read, int k, int skip_thresh,
+                                               Counters *cnt, unsigned long long pass_no) {
     // `last_read` when the block starts = name of the latest earlier block that has a site row (:282)
     bool h1 = false;
-    if (T.nb_repeat[b] || entry_read >= 0) {
+    if (lookback && (T.nb_repeat[b] || entry_read >= 0)) {
         int j = b - 1;
         while (j >= 0 && nb_f0[j] < 0) --j;
         const int last_read = j >= 0 ? T.nb_read[j] : entry_read;
@@ -514,8 +449,90 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
         mode = regular ? MODE_REGULAR : MODE_IRREGULAR;
     }
     d.mode = mode;
+    if (mode == MODE_IRREGULAR) *reinterpret_cast<volatile unsigned long long *>(&cnt->irregular_pass) = pass_no;
+}
+
+// classify != 0: the block is classified here as well (classify_block, by the wave's first lane) -- for tables without
+// repeated read names that do not continue a previous shard's read, where no block looks at another block's result; the
+// separate k0_classify launch is then skipped.
+__global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
+                              NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
+                              int32_t *__restrict__ nb_lastidx, Counters *__restrict__ cnt, int classify, int skip_thresh,
+                              unsigned long long pass_no) {
+    if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
+        unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
+        for (unsigned i = threadIdx.x; i < offsetof(Counters, irregular_pass) / 4; i += blockDim.x) w[i] = 0u;
+    }
+    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= T.n_nb) return;
+    NbDesc d = T.nb_tmpl[b];
+    const int n_seg = d.pad;
+    // (the quality decides whether the rows are looked at at all, but its load is not waited for before theirs go out: the
+    // block's latency is a chain of dependent loads, and this removes one link)
+    const double q_read = qual[d.read];
+    const int32_t last_idx = T.idx[d.row_end - 1];
+    int64_t f0 = -1;
+    int f0rev = 0;
+    {
+        const int seg0 = n_seg == 1 ? 0 : T.nb_seg_begin[b];
+        for (int si = 0; si < n_seg && f0 < 0; ++si) {
+            int64_t L, sb, se;
+            const uint32_t *mf, *mr;
+            if (n_seg == 1) {                      // the usual case: everything is in the template
+                L = d.contig_len; sb = d.row_begin; se = d.row_end;
+                mf = R.mf + d.mask_off; mr = R.mr + d.mask_off;
+            } else {
+                const int seg = seg0 + si;
+                const int contig = T.seg_contig[seg];
+                L = R.contig_len[contig];
+                mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
+                sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
+            }
+            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): rounds of 1024
+            // rows -- a round costs two dependent loads whatever its width, and nine blocks in ten need one.
+            for (int64_t base = sb; base < se && f0 < 0; base += 1024)
+                f0 = first_site_round<16>(T, mf, mr, L, base, se, k, lane, f0rev);
+        }
+    }
+    const bool filtered = q_read < qual_thresh;
+    if (filtered) { f0 = -1; f0rev = 0; }
+    if (lane == 0) {
+        d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
+        d.rev = (uint8_t)f0rev;
+        d.filtered = filtered ? 1 : 0;
+        d.pad = 0;
+        nb_f0[b] = f0;
+        nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
+        nb_lastidx[b] = last_idx;
+        if (classify) classify_block(T, R, d, b, f0, false, nb_f0, -1, k, skip_thresh, cnt, pass_no);
+        desc[b] = d;
+    }
+}
+
+// One thread per name block: is the block regular?
+//
+// Regular = the sequential machine reduces to the local window rule (DESIGN.md): the read name is new
+// (`last_read` differs when the block starts), one contig, positions non-decreasing, event indices strictly
+// monotone, and every row after the first site row f0 takes the strand f0 was tested on.  One irregularity is
+// common enough (~1 % of reads) to be folded into the fast path exactly: a reverse read whose f0 is a
+// reverse-complement-palindromic k-mer (R5).  f0 is then scored on '+', opening a one-event '+' window; the
+// rows after it are all '-' (event index decreasing, :169).  What the machine does with that event depends only
+// on the next unfiltered row r1 (:179, :242-256, :272-279):
+//   pos(r1) >  site of the '+' window: the window is flushed with k-1 empty slots (a too-many-skips record);
+//              if r1 continues the chain (a '-' site row within skip_thresh+1) the event shifts with the slots
+//              and stays at its own position p, else it is dropped;
+//   pos(r1) <= site: if r1 is a '-' site row the strand flips, mpos is re-set to r1's site but the slots are
+//              kept: the event now sits at pseudo-position pos(r1)+o_r-o_f; else everything is cleared.
+// From then on the block behaves as a regular '-' block starting at f0+1 with one extra event, first in its
+// slot, at that (pseudo-)position.
+__global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, const int64_t *__restrict__ nb_f0,
+                            int entry_read, int k, int skip_thresh, Counters *cnt, unsigned long long pass_no) {
+    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    if (b >= T.n_nb) return;
+    NbDesc d = desc[b];
+    classify_block(T, R, d, b, nb_f0[b], true, nb_f0, entry_read, k, skip_thresh, cnt, pass_no);
     desc[b] = d;
-    if (mode == MODE_IRREGULAR) atomicAdd(&cnt->n_irregular, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1544,9 +1561,9 @@ constexpr uint32_t XR_POS0 = 4;      // NbDesc.xflags: irregular because of a si
 
 // After k0_classify: widen the irregular set so that every run starts and ends in a state the fast path knows.
 __global__ void k0_extend(DevTable T, NbDesc *__restrict__ desc, const int64_t *__restrict__ nb_f0, int entry_read,
-                          Counters *cnt) {
+                          Counters *cnt, unsigned long long pass_no) {
     const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
-    if (b >= T.n_nb || cnt->n_irregular == 0) return;
+    if (b >= T.n_nb || cnt->irregular_pass != pass_no) return;
     const NbDesc d = desc[b];
     if (d.mode != MODE_IRREGULAR) return;
     // (a) a block that sees name == last_read continues the state of the block that set last_read: take everything
@@ -2184,12 +2201,14 @@ struct mc_ctx {
         int k = 0;
         bool used = false, copying = false, timed = true;
         int slot = -1;             // table slot the pass scans
+        unsigned long long pass_no = 0;   // what Counters.irregular_pass holds if the pass classified a block irregular
         const double *qual = nullptr;   // read qualities it was enqueued with
         int32_t n_qual = 0;
         std::vector<void *> dev_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
     hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
     int ab_head = 0, ab_tail = 0, ab_count = 0;
+    unsigned long long pass_counter = 0, sync_pass_no = 0;   // pass numbers (never 0)
     int timing_every = 1;          // pipelined passes: the two timing events go with every n-th pass (mc_ctx_set_pass_timing)
     long long pass_seq = 0;
     int last_timed = 1;            // whether the pass handed out last carried them
@@ -2837,20 +2856,27 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
 }
 
 // K0 (strand resolve) of one pass on stream st: counters zeroed, first site rows, classification, tile descriptors.
-static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st) {
+// extend: also widen the irregular set (k0_extend) -- what the literal path of the synchronous pass needs; a pipelined pass
+// with an irregular block is thrown away and re-run synchronously, so it never looks at the result.
+static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st, unsigned long long pass_no,
+                      bool extend) {
     const DevTable &T = c->T;
     const int k = prm->k;
+    const bool lookback = T.has_repeats || prm->entry_read >= 0;      // a block may see name == last_read (:161)
     if (c->cur >= 0 && c->slots[c->cur].tmpl_ref != c->ref_version) {      // once per (table, reference)
         hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R);
         c->slots[c->cur].tmpl_ref = c->ref_version;
     }
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx, cnt);
-    hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt);
-    hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, K.desc,
-                       (const int64_t *)K.nb_f0, prm->entry_read, cnt);
+                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx, cnt, lookback ? 0 : 1,
+                       prm->skip_thresh, pass_no);
+    if (lookback)
+        hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
+                           K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt, pass_no);
+    if (extend)
+        hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, K.desc,
+                           (const int64_t *)K.nb_f0, prm->entry_read, cnt, pass_no);
     hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, st, T, c->R,
                        K.desc, k, K.tiles);
     return 0;
@@ -2884,7 +2910,7 @@ static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &
     K0Set K;
     K.desc = c->desc; K.tiles = c->tiles; K.nb_f0 = c->nb_f0; K.nb_f0idx = c->nb_f0idx; K.nb_lastidx = c->nb_lastidx;
     HIP_TRY(hipEventRecord(ev[0], c->stream));
-    if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream)) return rc;
+    if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream, c->sync_pass_no, true)) return rc;
     HIP_TRY(hipEventRecord(ev[1], c->stream));
     if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args)) return rc;
     HIP_TRY(hipEventRecord(ev[3], c->stream));
@@ -2944,6 +2970,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
         K1Args A;
+        c->sync_pass_no = ++c->pass_counter;
         if (int rc = enqueue_fast_path(c, prm, c->O, c->ev, &A)) return rc;
         Counters h;
         HIP_TRY(hipMemcpyAsync(&h, c->cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -2960,12 +2987,13 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
             h.n_big = 1;                      // such a window may hold a slot of > 128 events: let k1_bigfix look
         }
         if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
-        if (h.n_irregular) {
+        const bool irregular = h.irregular_pass == c->sync_pass_no;
+        if (irregular) {
             if (int rc = run_literal_path(c, prm, &n)) return rc;
         }
         // records -> pinned host memory; the slot means and indices travel while the classifier runs
         if (int rc = ensure_pinned(c, n, k)) return rc;
-        const bool early = n > 0 && !h.n_big && !h.n_irregular;
+        const bool early = n > 0 && !h.n_big && !irregular;
         if (early) { if (int rc = copy_out_features(c, n, k, c->copy_stream)) return rc; }
         if (prm->score && n > 0) {
             if (c->F.left)
@@ -3133,6 +3161,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (T.n_rows == 0 || T.n_nb == 0) {            // nothing to scan: an empty pass
         if (int rc = ensure_async_buf(c, b, 1 << 16, k)) return rc;
         memset(b.st_host, 0, sizeof(Counters));
+        b.pass_no = ++c->pass_counter;
         b.used = false;
         b.slot = -1;
         c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
@@ -3159,7 +3188,8 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // the pass, unlike ev_emit_end, which the side stream waits for, can be thinned out: mc_ctx_set_pass_timing)
     b.timed = c->timing_every > 0 && (c->pass_seq++ % c->timing_every) == 0;
     if (b.timed) HIP_TRY(hipEventRecord(b.ev_k0_start, st));
-    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st)) return rc;
+    b.pass_no = ++c->pass_counter;
+    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st, b.pass_no, false)) return rc;
     if (b.timed) HIP_TRY(hipEventRecord(b.ev_scan_start, st));
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
@@ -3209,7 +3239,7 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_done, 0));
     }
     const Counters &st = *b.st_host;
-    const bool special = st.overflow || st.n_irregular;      // (long windows were finished on the device: k1_rare_dev)
+    const bool special = st.overflow || st.irregular_pass == b.pass_no;      // (long windows were finished on the device: k1_rare_dev)
     if (b.used && !special && st.n_records > 0) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
         const int k = b.k;
@@ -3249,11 +3279,11 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         c->last_T = c->slots[b.slot].T;
     }
     const Counters st = *b.st_host;
-    const bool special = st.overflow || st.n_irregular;
+    const bool special = st.overflow || st.irregular_pass == b.pass_no;
     if (b.used && !special && st.n_records > 0) HIP_TRY(hipEventSynchronize(b.ev_copied));
     if (special && getenv("MCALLER_VERBOSE"))
         fprintf(stderr, "mcaller_hip: pass re-run synchronously (overflow %u, irregular %u, big %u, rare %u, records %llu)\n",
-                st.overflow, st.n_irregular, st.n_big, st.n_rare, st.n_records);
+                st.overflow, (unsigned)(st.irregular_pass == b.pass_no), st.n_big, st.n_rare, st.n_records);
     if (special) {
         // a pass the fast path alone cannot finish (record buffers too small, irregular reads):
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
