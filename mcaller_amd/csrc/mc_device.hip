@@ -1828,9 +1828,50 @@ __global__ void k_merge(DevRecords O, int64_t n_o, DevRecords L, int64_t n_l, De
 // ---------------------------------------------------------------------------------------------------
 // tanh(x) = sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}): one exp and one division; absolute error ~1e-16, far inside the
 // 1e-5 the probabilities are held to (the library tanh costs several times more and dominates this kernel)
+// e^a for a >= 0, written out: the library's exp and the IEEE division cost ~100 instructions per tanh, and the classifier
+// is 100 tanh per call -- this is ~30.  a = n ln2 + r, |r| <= ln2/2; e^r as its Taylor polynomial of degree 13 (remainder
+// < 5e-18), scaled by 2^n.  Relative error ~2e-16.
+__device__ __forceinline__ double exp_pos(double a) {
+    a = fmin(a, 708.0);
+    const double n = rint(a * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, a);      // ln2 in two pieces
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                      // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                    // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                   // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                   // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                  // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                    // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                   // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);                  // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                   // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                  // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                  // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// 1 / d for d >= 1: the hardware's reciprocal estimate and two Newton steps (relative error ~1e-16; no scaling needed, d is
+// never small, huge d gives 0)
+__device__ __forceinline__ double recip_ge1(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): absolute error ~1e-16, far inside the 1e-5 the probabilities are held to
 __device__ __forceinline__ double tanh_1exp(double x) {
-    const double t = exp(-2.0 * fabs(x));
-    return copysign((1.0 - t) / (1.0 + t), x);
+    const double q = recip_ge1(exp_pos(2.0 * fabs(x)) + 1.0);
+    return copysign(1.0 - (q + q), x);
+}
+
+// 1 / (1 + e^{-z})
+__device__ __forceinline__ double logistic(double z) {
+    const double q = recip_ge1(exp_pos(fabs(z)) + 1.0);     // 1 / (e^{|z|} + 1)
+    return z >= 0.0 ? 1.0 - q : q;
 }
 
 // Eight lanes per record: lane `sub` of a group takes hidden units sub, sub+8, ... (four independent chains at a time: the
@@ -1868,66 +1909,76 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     const int sub = lane % K2L, grp = lane / K2L;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     // A wave takes K2C consecutive records at a time, finds the ones that are scored at all (skipped records and records
-    // whose context leaves the contig are not) and works through those, eight records per step: no lane idles on a
-    // record that needs no score.
-    constexpr int K2C = 16;
+    // whose context leaves the contig are not), sub-model by sub-model, and works through those sixteen records per step:
+    // every group of eight lanes takes TWO records of one sub-model, so a weight read from LDS is used twice -- the LDS port
+    // (nine 8-byte reads per hidden unit) is as busy as the fp64 pipe in this kernel.
+    constexpr int K2C = 64;
+    constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
     for (int64_t chunk = wave0 * K2C; chunk < n; chunk += n_waves * K2C) {
         const int64_t rl = chunk + lane;
-        bool want = lane < K2C && rl < n;
-        if (want && !submodel_in) want = !(info[rl] & (MC_I_TOO_MANY | MC_I_EDGE));
-        unsigned long long todo = __ballot(want);
-        while (todo) {
-            // the grp-th record of this step = the grp-th set bit of todo
-            unsigned long long m = todo;
-            int64_t r = -1;
-#pragma unroll
-            for (int g = 0; g < 64 / K2L; ++g) {
-                const int bit = m ? (int)__builtin_ctzll(m) : -1;
-                if (g == grp && bit >= 0) r = chunk + bit;
-                if (m) m &= m - 1;
+        int mi_l = 255;                              // sub-model of record rl (255: not scored here)
+        if (rl < n) {
+            if (submodel_in) mi_l = submodel_in[rl];
+            else {
+                const uint32_t inf = info[rl];
+                if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) mi_l = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
             }
-            todo = m;
-            if (r < 0) continue;
-            int mi;
-            constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
-            double x[NX];
-            if (submodel_in) {                       // plain batched call: X rows of n_in values
-                mi = submodel_in[r];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
-            } else {                                 // flush records: k slot means + read quality (:189-193)
-                mi = M.sub_of_char[(info[r] >> MC_I_NEXT_SHIFT) & 0xFFu];
-                const double q = qual[seg_read[site_seg[r]]];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
-            }
-            if (mi >= M.n_models) continue;          // KeyError path (:218): the host decides
-            const double *w = s_w + (size_t)mi * per;
+        }
+        for (int mdl = 0; mdl < M.n_models; ++mdl) {         // (a key outside the models is the KeyError path, :218: the host decides)
+            unsigned long long todo = __ballot(mi_l == mdl);
+            const double *w = s_w + (size_t)mdl * per;
             const double *b1 = w + NI * H, *w2 = b1 + H;
-            double z = 0.0;
-            for (int j0 = sub; j0 < H; j0 += 4 * K2L) {
-                const int j1 = j0 + K2L, j2 = j0 + 2 * K2L, j3 = j0 + 3 * K2L;
-                const bool v1 = j1 < H, v2 = j2 < H, v3 = j3 < H;
-                const int c1 = v1 ? j1 : j0, c2 = v2 ? j2 : j0, c3 = v3 ? j3 : j0;
-                double a0 = b1[j0], a1 = b1[c1], a2 = b1[c2], a3 = b1[c3];
+            while (todo) {
+                // the records of this step: group g takes the set bits number 2g and 2g+1 of todo
+                unsigned long long mm = todo;
+                int64_t ra = -1, rb = -1;
 #pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    if (i < NI) {
-                        const double xi = x[i];
-                        a0 = fma(xi, w[i * H + j0], a0); a1 = fma(xi, w[i * H + c1], a1);
-                        a2 = fma(xi, w[i * H + c2], a2); a3 = fma(xi, w[i * H + c3], a3);
+                for (int g = 0; g < 64 / K2L; ++g) {
+                    const int bit_a = mm ? (int)__builtin_ctzll(mm) : -1;
+                    if (mm) mm &= mm - 1;
+                    const int bit_b = mm ? (int)__builtin_ctzll(mm) : -1;
+                    if (mm) mm &= mm - 1;
+                    if (g == grp) { ra = bit_a >= 0 ? chunk + bit_a : -1; rb = bit_b >= 0 ? chunk + bit_b : -1; }
+                }
+                todo = mm;
+                if (ra < 0) continue;
+                const int64_t rb_c = rb >= 0 ? rb : ra;
+                double xa[NX], xb[NX];
+                if (submodel_in) {                   // plain batched call: X rows of n_in values
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { xa[i] = i < NI ? feats[ra * NI + i] : 0.0; xb[i] = i < NI ? feats[rb_c * NI + i] : 0.0; }
+                } else {                             // flush records: k slot means + read quality (:189-193)
+                    const double qa = qual[seg_read[site_seg[ra]]], qb = qual[seg_read[site_seg[rb_c]]];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        xa[i] = i < k ? feats[ra * k + i] : (i == k ? qa : 0.0);
+                        xb[i] = i < k ? feats[rb_c * k + i] : (i == k ? qb : 0.0);
                     }
-                const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), t2 = tanh_1exp(a2), t3 = tanh_1exp(a3);
-                z = fma(t0, w2[j0], z);
-                if (v1) z = fma(t1, w2[c1], z);
-                if (v2) z = fma(t2, w2[c2], z);
-                if (v3) z = fma(t3, w2[c3], z);
-            }
+                }
+                double za = 0.0, zb = 0.0;
+                for (int j0 = sub; j0 < H; j0 += 2 * K2L) {
+                    const int j1 = j0 + K2L;
+                    const bool v1 = j1 < H;
+                    const int c1 = v1 ? j1 : j0;
+                    const double bb0 = b1[j0], bb1 = b1[c1];
+                    double a0 = bb0, a1 = bb1, c0 = bb0, c1v = bb1;     // (a: record a, c: record b; units j0, j1)
 #pragma unroll
-            for (int o = 1; o < K2L; o <<= 1) z += __shfl_xor(z, o);
-            if (sub == 0) {
-                z += w2[H];
-                prob[r] = 1.0 / (1.0 + exp(-z));
+                    for (int i = 0; i < NX; ++i)
+                        if (i < NI) {
+                            const double w0 = w[i * H + j0], w1 = w[i * H + c1];
+                            a0 = fma(xa[i], w0, a0); a1 = fma(xa[i], w1, a1);
+                            c0 = fma(xb[i], w0, c0); c1v = fma(xb[i], w1, c1v);
+                        }
+                    const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), u0 = tanh_1exp(c0), u1 = tanh_1exp(c1v);
+                    const double o0 = w2[j0], o1 = w2[c1];
+                    za = fma(t0, o0, za);
+                    zb = fma(u0, o0, zb);
+                    if (v1) { za = fma(t1, o1, za); zb = fma(u1, o1, zb); }
+                }
+#pragma unroll
+                for (int o = 1; o < K2L; o <<= 1) { za += __shfl_xor(za, o); zb += __shfl_xor(zb, o); }
+                if (sub == 0) prob[ra] = logistic(za + w2[H]);
+                if (sub == 1 && rb >= 0) prob[rb] = logistic(zb + w2[H]);
             }
         }
     }
@@ -2779,8 +2830,8 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
 }
 
 // k2_mlp blocks: enough for n records at K2L lanes each, at most a few per CU (the kernel strides over the rest)
-static unsigned k2_grid(const mc_ctx *c, int64_t n) {       // one wave per 16 records, at most 8 blocks per CU
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 16 + 1 + K2_THREADS / 64 - 1) / (K2_THREADS / 64), (int64_t)c->n_cu * 8));
+static unsigned k2_grid(const mc_ctx *c, int64_t n) {       // one wave per 64 records, at most 8 blocks per CU
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 64 + 1 + K2_THREADS / 64 - 1) / (K2_THREADS / 64), (int64_t)c->n_cu * 8));
 }
 
 static size_t mlp_lds_bytes(const DevMlp &M) {
