@@ -346,12 +346,9 @@ __global__ void k_nb_template(DevTable T, DevRef R) {
 }
 
 // NS stripes of 64 rows from `base`: all loads of the round are issued before any is used.  -> first site row or -1
+// NS stripes of 64 rows from `base`: their flags and positions ...
 template <int NS>
-__device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uint32_t *__restrict__ mf, const uint32_t *__restrict__ mr,
-                                                    int64_t L, int64_t base, int64_t se, int k, int lane, int &f0rev) {
-    uint32_t fl[NS];
-    int ps[NS];
-    uint64_t wf[NS], wr[NS];
+__device__ __forceinline__ void first_site_rows(const DevTable &T, int64_t base, int64_t se, int lane, uint32_t (&fl)[NS], int (&ps)[NS]) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const int64_t r = base + u * 64 + lane;
@@ -359,18 +356,27 @@ __device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uin
         fl[u] = r < se ? (uint32_t)T.flags[ra] : (uint32_t)MC_F_MODEL_N;
         ps[u] = T.pos[ra];
     }
+}
+
+// ... and the first site row among them (-1: none).  `prefetch` runs after the mask loads have been issued and before they are
+// waited for: the next round's rows travel with this round's masks.
+template <int NS, typename Prefetch>
+__device__ __forceinline__ int64_t first_site_among(const uint32_t *__restrict__ mf, const uint32_t *__restrict__ mr, int64_t L, int64_t base,
+                                                    int k, const uint32_t (&fl)[NS], const int (&ps)[NS], int &f0rev, Prefetch prefetch) {
+    uint64_t wm[NS];
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
+    for (int u = 0; u < NS; ++u) {               // (the mask of the strand the row is tested on: its flag came with its position)
         const int64_t p = ps[u] < L ? ps[u] : 0;
         const int64_t w0 = p >> 5;
-        wf[u] = ((uint64_t)mf[w0 + 1] << 32) | mf[w0];
-        wr[u] = ((uint64_t)mr[w0 + 1] << 32) | mr[w0];
+        const uint32_t *__restrict__ mm = (fl[u] & MC_F_KMER_EQ) ? mf : mr;
+        wm[u] = ((uint64_t)mm[w0 + 1] << 32) | mm[w0];
     }
+    prefetch();
     int64_t f0 = -1;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         const int rev = (fl[u] & MC_F_KMER_EQ) ? 0 : 1;
-        uint64_t w = (rev ? wr[u] : wf[u]) >> (ps[u] & 31);
+        uint64_t w = wm[u] >> (ps[u] & 31);
         w &= (1ull << k) - 1ull;
         const bool c = !(fl[u] & MC_F_MODEL_N) && ps[u] < L && w != 0ull;
         const unsigned long long mask = __ballot(c);
@@ -388,7 +394,7 @@ __device__ __forceinline__ int64_t first_site_round(const DevTable &T, const uin
 // copy-out running on the other stream)
 // (the body of the classification: block b with descriptor d and first site row f0; lookback: the block may see
 // name == last_read, i.e. the table repeats read names or continues a previous shard's read)
-__device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &R, NbDesc &d, int b, int64_t f0, bool lookback,
+__device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &R, NbDesc &d, int b, int64_t f0, uint32_t vf, bool lookback,
                                                const int64_t *__restrict__ nb_f0, int entry_read, int k, int skip_thresh,
                                                Counters *cnt, unsigned long long pass_no) {
     // `last_read` when the block starts = name of the latest earlier block that has a site row (:282)
@@ -405,7 +411,6 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
     } else if (h1) {
         mode = MODE_IRREGULAR;                            // rows see name == last_read: literal machine
     } else if (f0 >= 0) {
-        const uint32_t vf = T.nb_vflags[b];
         bool regular = !(vf & (V_POS_DEC | V_IDX_EQ | V_MULTI_SEG));
         const bool inc = vf & V_IDX_INC, dec = vf & V_IDX_DEC;
         if (inc && dec) regular = false;
@@ -456,9 +461,8 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
 // repeated read names that do not continue a previous shard's read, where no block looks at another block's result; the
 // separate k0_classify launch is then skipped.
 __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
-                              NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, int32_t *__restrict__ nb_f0idx,
-                              int32_t *__restrict__ nb_lastidx, Counters *__restrict__ cnt, int classify, int skip_thresh,
-                              unsigned long long pass_no) {
+                              NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, Counters *__restrict__ cnt, int classify,
+                              int skip_thresh, unsigned long long pass_no) {
     if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
         unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
         for (unsigned i = threadIdx.x; i < offsetof(Counters, irregular_pass) / 4; i += blockDim.x) w[i] = 0u;
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
     // (the quality decides whether the rows are looked at at all, but its load is not waited for before theirs go out: the
     // block's latency is a chain of dependent loads, and this removes one link)
     const double q_read = qual[d.read];
-    const int32_t last_idx = T.idx[d.row_end - 1];
+    const uint32_t vf = T.nb_vflags[b];          // (for the classification: in flight with everything else)
     int64_t f0 = -1;
     int f0rev = 0;
     {
@@ -489,10 +493,20 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
                 mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
                 sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
             }
-            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): rounds of 1024
-            // rows -- a round costs two dependent loads whatever its width, and nine blocks in ten need one.
-            for (int64_t base = sb; base < se && f0 < 0; base += 1024)
-                f0 = first_site_round<16>(T, mf, mr, L, base, se, k, lane, f0rev);
+            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): rounds of 512
+            // rows, two blocks in three need one.  A round is two dependent loads (rows, then their mask words); the rows of
+            // the round after it are requested together with the mask words, so every further round costs ONE.
+            constexpr int FS = 8;
+            uint32_t fl[FS], fl_next[FS];
+            int ps[FS], ps_next[FS];
+            if (sb < se) first_site_rows<FS>(T, sb, se, lane, fl, ps);
+            for (int64_t base = sb; base < se && f0 < 0; base += 64 * FS) {
+                const bool more = base + 64 * FS < se;
+                f0 = first_site_among<FS>(mf, mr, L, base, k, fl, ps, f0rev,
+                                          [&]() { if (more) first_site_rows<FS>(T, base + 64 * FS, se, lane, fl_next, ps_next); });
+#pragma unroll
+                for (int u = 0; u < FS; ++u) { fl[u] = fl_next[u]; ps[u] = ps_next[u]; }
+            }
         }
     }
     const bool filtered = q_read < qual_thresh;
@@ -503,9 +517,7 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
         d.filtered = filtered ? 1 : 0;
         d.pad = 0;
         nb_f0[b] = f0;
-        nb_f0idx[b] = f0 >= 0 ? T.idx[f0] : 0;
-        nb_lastidx[b] = last_idx;
-        if (classify) classify_block(T, R, d, b, f0, false, nb_f0, -1, k, skip_thresh, cnt, pass_no);
+        if (classify) classify_block(T, R, d, b, f0, vf, false, nb_f0, -1, k, skip_thresh, cnt, pass_no);
         desc[b] = d;
     }
 }
@@ -531,7 +543,7 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
     const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
     if (b >= T.n_nb) return;
     NbDesc d = desc[b];
-    classify_block(T, R, d, b, nb_f0[b], true, nb_f0, entry_read, k, skip_thresh, cnt, pass_no);
+    classify_block(T, R, d, b, nb_f0[b], T.nb_vflags[b], true, nb_f0, entry_read, k, skip_thresh, cnt, pass_no);
     desc[b] = d;
 }
 
@@ -2135,7 +2147,6 @@ struct K0Set {
     NbDesc *desc = nullptr;
     TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
-    int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
 };
 
 // One resident table.  A ctx owns MC_TABLE_SLOTS of them so that a file can go through the GPU as a sequence of shards:
@@ -2208,7 +2219,6 @@ struct mc_ctx {
     NbDesc *desc = nullptr;
     TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
-    int32_t *nb_f0idx = nullptr, *nb_lastidx = nullptr;
     DevRecords O;            // records of the last call (view: the fast path's buffers, or the merged ones)
     DevRecords Omain;        // the fast path's buffers
     DevRecords H;            // pinned host copy of the last call's records (mc_fetch_records_view)
@@ -2548,7 +2558,6 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     const int64_t nt = std::max<int64_t>(std::max<int64_t>(n_tiles, res_tiles), c->scratch_tiles);
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->tiles, (size_t)nt + 1) || dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
-        dev_alloc(P, &c->nb_f0idx, (size_t)nb + 1) || dev_alloc(P, &c->nb_lastidx, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
         dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1))
         return -10;
@@ -2920,7 +2929,7 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     }
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, K.nb_f0idx, K.nb_lastidx, cnt, lookback ? 0 : 1,
+                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1,
                        prm->skip_thresh, pass_no);
     if (lookback)
         hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
@@ -2959,7 +2968,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 // the synchronous pass: everything on the ctx stream, ev[0..3] around the stages (mc_last_times_ms)
 static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &O, hipEvent_t *ev, K1Args *out_args) {
     K0Set K;
-    K.desc = c->desc; K.tiles = c->tiles; K.nb_f0 = c->nb_f0; K.nb_f0idx = c->nb_f0idx; K.nb_lastidx = c->nb_lastidx;
+    K.desc = c->desc; K.tiles = c->tiles; K.nb_f0 = c->nb_f0;
     HIP_TRY(hipEventRecord(ev[0], c->stream));
     if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream, c->sync_pass_no, true)) return rc;
     HIP_TRY(hipEventRecord(ev[1], c->stream));
@@ -3145,8 +3154,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
     if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.tiles, (size_t)nt + 1) ||
-        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0idx, (size_t)nb + 1) ||
-        dev_alloc(b.dev_allocs, &b.K.nb_lastidx, (size_t)nb + 1))
+        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1))
         return -10;
     if (cap >= (int64_t)1 << 31) {
         mc_set_error("mc_extract_features_async: %lld flush records per pass (call_row is 32 bits wide); use mc_extract_features",
