@@ -362,14 +362,19 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             for lo_i, hi_i in pieces:
                 if stop_parsing.is_set():
                     break
-                q.put(prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True,
-                              ref=ref, quiet=True))
+                t_p = time.perf_counter()
+                P_i = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True,
+                              ref=ref, quiet=True)
+                clock['parse'] += time.perf_counter() - t_p
+                q.put(P_i)
             q.put(None)
         except BaseException as e:                             # noqa
             q.put(e)
 
     th = threading.Thread(target=parser, daemon=True)
     th.start()
+    import time
+    clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces))     # MCALLER_TIMING
     blobs, messages, names_seen = [], [], set()
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
     positions = []
@@ -377,6 +382,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     marked = [-1]
 
     def hand_out():
+        t_h = time.perf_counter()
+        try:
+            _hand_out()
+        finally:
+            clock['hand_out'] += time.perf_counter() - t_h
+
+    def _hand_out():
         P, tail = in_flight.pop(0)
         rec = dev.wait()
         fin = Finisher(P, k, base, False, modelset=modelset, device=dev, tail_chrom=tail)
@@ -406,7 +418,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     try:
         prev = None
         while True:
+            t_q = time.perf_counter()
             P = q.get()
+            clock['wait_parser'] += time.perf_counter() - t_q
             if isinstance(P, BaseException):
                 raise P
             if P is not None:
@@ -425,7 +439,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 tail_id = head if P is not None else -1
                 while len(in_flight) >= 2:
                     hand_out()
+                t_e = time.perf_counter()
                 enqueue(prev, tail_id)
+                clock['enqueue'] += time.perf_counter() - t_e
                 in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None))
             prev = P
             if P is None:
@@ -454,6 +470,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 '%d regions with multiple methylated bases' % totals['multi'],
                 '%d observations with skips included' % totals['wskips'],
                 '%d observations with too many skips' % totals['skipped']]
+    stream_features.last_clock = clock
     return b''.join(blobs), counters, messages
 
 
@@ -484,7 +501,11 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
                 print(line)
             write_text(text, tsv_output)                                          # :293
             if timing:
-                print('[mcaller_amd timing] streamed in shards: total %.3f s' % (time.perf_counter() - t_start), file=sys.stderr)
+                ck = getattr(stream_features, 'last_clock', {})
+                print('[mcaller_amd timing] streamed in %s shards: total %.3f s | parser thread %.3f s | main thread: waiting for '
+                      'the parser %.3f, upload + enqueue %.3f, wait + format %.3f' % (
+                          ck.get('shards'), time.perf_counter() - t_start, ck.get('parse', 0), ck.get('wait_parser', 0),
+                          ck.get('enqueue', 0), ck.get('hand_out', 0)), file=sys.stderr)
             for line in counters:                                                 # :295-301
                 print(line)
             return None
