@@ -134,3 +134,86 @@ extern "C" int mc_host_pool_config(int32_t parser_uses_pool, int64_t keep_bytes)
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Worker threads, kept.  The parser, the FASTQ reader and the row formatter run one task per piece of their input; a file
+// streamed in shards calls them once per shard, and starting a few dozen std::threads per call (one at a time, by the
+// caller) was half a shard's parse time.  mc_parallel_for hands the tasks to threads that stay around (as many as the
+// process may run on, created on first use, more when a call asks for more); the caller works too.  One job at a time: a
+// second caller that finds the pool busy (the formatter beside the parser thread) starts plain threads, as before.
+// ---------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
+namespace {
+struct Workers {
+    std::mutex job_mu;                      // one job at a time
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int n_tasks = 0, running = 0;
+    unsigned long long generation = 0;
+
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                f = fn;
+                if (!f) continue;
+                ++running;
+            }
+            for (int i; (i = next.fetch_add(1)) < n_tasks;) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--running == 0) done.notify_all();
+            }
+        }
+    }
+};
+Workers *g_workers = nullptr;               // (never destroyed: its threads may outlive static destructors)
+std::once_flag g_workers_once;
+}  // namespace
+
+void mc_parallel_for(int n, const std::function<void(int)> &f) {
+    if (n <= 0) return;
+    if (n == 1) { f(0); return; }
+    std::call_once(g_workers_once, [] { g_workers = new Workers(); });
+    Workers &W = *g_workers;
+    std::unique_lock<std::mutex> job(W.job_mu, std::try_to_lock);
+    if (!job.owns_lock()) {                 // the pool is busy with another caller's job: plain threads
+        std::vector<std::thread> th;
+        for (int i = 1; i < n; ++i) th.emplace_back(f, i);
+        f(0);
+        for (auto &x : th) x.join();
+        return;
+    }
+    const int want = std::min(n - 1, std::max(mc_host_cores() - 1, 0));
+    {
+        std::lock_guard<std::mutex> lk(W.mu);
+        while ((int)W.threads.size() < want) {
+            W.threads.emplace_back([&W] { W.loop(); });
+            W.threads.back().detach();
+        }
+        W.fn = &f;
+        W.n_tasks = n;
+        W.next.store(0);
+        ++W.generation;
+    }
+    W.wake.notify_all();
+    for (int i; (i = W.next.fetch_add(1)) < n;) f(i);          // the caller takes tasks as well
+    {
+        std::unique_lock<std::mutex> lk(W.mu);
+        // every task has been taken; wait for the threads that are still inside one -- and for late wakers to have
+        // looked at the (exhausted) counter: a thread that wakes up after this point sees next >= n_tasks and does nothing
+        W.done.wait(lk, [&] { return W.running == 0; });
+        W.fn = nullptr;
+    }
+}

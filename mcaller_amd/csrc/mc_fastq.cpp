@@ -22,11 +22,12 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <string>
-#include <thread>
 #include <vector>
 
 void mc_set_error(const char *fmt, ...);
+void mc_parallel_for(int n, const std::function<void(int)> &f);   // mc_common.cpp: tasks 0..n-1 on the kept worker threads
 
 struct mc_fastq {
     std::string pool;               // keys, '\n' after each
@@ -200,10 +201,7 @@ extern "C" int mc_fastq_read_quality(const char *path, int32_t n_threads, mc_fas
             if (!s) regular = false; else starts[size_t(t)] = s < starts[size_t(t) - 1] ? starts[size_t(t) - 1] : s;
         }
         if (regular) {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t)
-                th.emplace_back([&, t] { parse_records(starts[size_t(t)], starts[size_t(t) + 1], end, pieces[size_t(t)]); });
-            for (auto &x : th) x.join();
+            mc_parallel_for(nt, [&](int t) { parse_records(starts[size_t(t)], starts[size_t(t) + 1], end, pieces[size_t(t)]); });
             for (int t = 0; t < nt && regular; ++t) {
                 if (!pieces[size_t(t)].error.empty()) regular = false;
                 else if (starts[size_t(t)] < starts[size_t(t) + 1] && pieces[size_t(t)].stop != starts[size_t(t) + 1]) regular = false;

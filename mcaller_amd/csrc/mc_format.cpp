@@ -14,11 +14,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
-#include <thread>
 #include <vector>
 
 void mc_set_error(const char *fmt, ...);
+void mc_parallel_for(int n, const std::function<void(int)> &f);   // mc_common.cpp: tasks 0..n-1 on the kept worker threads
 
 namespace {
 
@@ -224,12 +225,7 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
         for (int64_t j = lo; j < hi; ++j)
             if (!native_ok(a, j)) { stops[(size_t)w] = j; return; }
     };
-    {
-        std::vector<std::thread> th;
-        for (int w = 1; w < nt; ++w) th.emplace_back(scan, w);
-        scan(0);
-        for (auto &x : th) x.join();
-    }
+    mc_parallel_for(nt, scan);
     int64_t stop = n;
     for (int64_t s : stops) stop = std::min(stop, s);
     *stop_at = stop;
@@ -255,12 +251,7 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
         const int64_t lo = first + (stop - first) * w / nt, hi = first + (stop - first) * (w + 1) / nt;
         format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w]);
     };
-    {
-        std::vector<std::thread> th;
-        for (int w = 1; w < nt; ++w) th.emplace_back(work, w);
-        work(0);
-        for (auto &x : th) x.join();
-    }
+    mc_parallel_for(nt, work);
     size_t total = 0;
     for (auto &p : parts) total += p.size();
     char *outp = (char *)malloc(std::max<size_t>(total, 1));

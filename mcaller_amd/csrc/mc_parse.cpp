@@ -23,14 +23,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <string_view>
-#include <thread>
 #include <unordered_map>
 #include <vector>
 
 void mc_set_error(const char *fmt, ...);
 int mc_parser_uses_pool();      // mc_common.cpp: the columns of parsed tables live in the pinned host pool (mc_host_pool_config)
+void mc_parallel_for(int n, const std::function<void(int)> &f);   // mc_common.cpp: tasks 0..n-1 on the kept worker threads
 
 namespace {
 
@@ -513,14 +514,7 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
     const int np = (int)cuts.size() - 1;
     lap("mapped, cut");
     std::vector<Chunk> chunks((size_t)np);
-    if (np == 1) {
-        parse_chunk(fd, cuts[0], cuts[1], contig_map, chunks[0]);
-    } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < np; ++i)
-            th.emplace_back([&, i] { parse_chunk(fd, cuts[(size_t)i], cuts[(size_t)i + 1], contig_map, chunks[(size_t)i]); });
-        for (auto &x : th) x.join();
-    }
+    mc_parallel_for(np, [&](int i) { parse_chunk(fd, cuts[(size_t)i], cuts[(size_t)i + 1], contig_map, chunks[(size_t)i]); });
     lap("pieces parsed");
     if (base) munmap((void *)base, (size_t)fsize);     // (only the few pages around the cuts were touched)
     close(fd);
@@ -563,12 +557,7 @@ static int parse_file(const char *path, int64_t startline, int64_t endline, bool
             std::vector<int32_t>().swap(C.idx);
             std::vector<uint8_t>().swap(C.flags);
         };
-        if (np == 1) place(0);
-        else {
-            std::vector<std::thread> th;
-            for (int i = 0; i < np; ++i) th.emplace_back(place, i);
-            for (auto &x : th) x.join();
-        }
+        mc_parallel_for(np, place);
     }
     lap("columns placed");
     std::unordered_map<std::string, int32_t> read_map;

@@ -10,11 +10,12 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
-#include <thread>
 #include <vector>
 
 void mc_set_error(const char *fmt, ...);
+void mc_parallel_for(int n, const std::function<void(int)> &f);   // mc_common.cpp: tasks 0..n-1 on the kept worker threads
 
 namespace {
 
@@ -105,11 +106,7 @@ extern "C" int mc_synth_write_tsv(const char *path, const mc_table_view *t, cons
         }
         out.resize((size_t)(p - &out[0]));
     };
-    {
-        std::vector<std::thread> th;
-        for (int i = 0; i < nt; ++i) th.emplace_back(work, i);
-        for (auto &x : th) x.join();
-    }
+    mc_parallel_for(nt, work);
     for (int i = 0; i < nt; ++i)
         if (rc[(size_t)i]) {
             close(fd);
@@ -128,11 +125,7 @@ extern "C" int mc_synth_write_tsv(const char *path, const mc_table_view *t, cons
             done += (size_t)w;
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int i = 0; i < nt; ++i) th.emplace_back(put, i);
-        for (auto &x : th) x.join();
-    }
+    mc_parallel_for(nt, put);
     close(fd);
     for (int i = 0; i < nt; ++i)
         if (wrc[(size_t)i]) {

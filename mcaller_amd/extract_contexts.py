@@ -331,8 +331,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     and formats the rows of the shards that come back; parse, H2D, kernels, D2H and formatting overlap.
     -> (text of all rows, counter lines, messages) or raises _Unstreamable: nothing has been written then."""
     import os
-    import queue
-    import threading
+    import time
     dev = device if device is not None else get_device()
     lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
     if n_shards is None:
@@ -354,27 +353,30 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
 
     L = _lib.lib()
     L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
-    q = queue.Queue(maxsize=2)
-    stop_parsing = threading.Event()
-
-    def parser():
-        try:
-            for lo_i, hi_i in pieces:
-                if stop_parsing.is_set():
-                    break
-                t_p = time.perf_counter()
-                P_i = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True,
-                              ref=ref, quiet=True)
-                clock['parse'] += time.perf_counter() - t_p
-                q.put(P_i)
-            q.put(None)
-        except BaseException as e:                             # noqa
-            q.put(e)
-
-    th = threading.Thread(target=parser, daemon=True)
-    th.start()
-    import time
     clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces))     # MCALLER_TIMING
+    # two parser threads take the shards in turn (the native parser spreads a shard over all cores, but opening, cutting,
+    # thread start-up and stitching are serial: two shards in the works hide that); at most three shards ahead of the GPU
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=2)
+
+    def parse_shard(lo_i, hi_i):
+        t_p = time.perf_counter()
+        P_i = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
+        clock['parse'] += time.perf_counter() - t_p
+        return P_i
+
+    ahead = []                      # futures of the shards being parsed, in file order
+    next_piece = [0]
+
+    def next_shard():
+        """The next shard in file order (None behind the last); keeps the parser threads busy."""
+        while next_piece[0] < len(pieces) and len(ahead) < 3:
+            ahead.append(pool.submit(parse_shard, *pieces[next_piece[0]]))
+            next_piece[0] += 1
+        if not ahead:
+            return None
+        return ahead.pop(0).result()
+
     blobs, messages, names_seen = [], [], set()
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
     positions = []
@@ -419,10 +421,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         prev = None
         while True:
             t_q = time.perf_counter()
-            P = q.get()
+            P = next_shard()
             clock['wait_parser'] += time.perf_counter() - t_q
-            if isinstance(P, BaseException):
-                raise P
             if P is not None:
                 if P.fatal is not None:
                     raise _Unstreamable('an exit path of the reference')
@@ -449,12 +449,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         while in_flight:
             hand_out()
     except BaseException:
-        stop_parsing.set()
-        try:
-            while True:
-                q.get_nowait()
-        except queue.Empty:
-            pass
+        next_piece[0] = len(pieces)
+        for f in ahead:
+            f.cancel()
         try:
             dev.sync()
             while in_flight:                                   # nothing may stay in flight on the shared device
@@ -464,6 +461,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             pass
         raise
     finally:
+        pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
     n_pos = len(np.unique(np.concatenate(positions))) if positions else 0
     counters = ['thread finished processing...:', '%d observations' % totals['obs'], '%d positions' % n_pos,

@@ -1,7 +1,9 @@
 // Host-side native code (parser, FASTQ reader) under AddressSanitizer + UBSan: a CPU-only build of the three host sources
 // driven over the reference's test data and a few irregular files.  (GPU sanitizers are not available on the pool.)
-//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -pthread tests/tools/asan_host.cpp mcaller_amd/csrc/mc_parse.cpp \
-//       mcaller_amd/csrc/mc_fastq.cpp mcaller_amd/csrc/mc_common.cpp -ldl -o /tmp/asan_host && /tmp/asan_host <tsv> <fastq>
+//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -pthread -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
+//       tests/tools/asan_host.cpp mcaller_amd/csrc/mc_parse.cpp mcaller_amd/csrc/mc_fastq.cpp mcaller_amd/csrc/mc_common.cpp \
+//       -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,/opt/rocm/lib -o /tmp/asan_host && /tmp/asan_host <tsv> <fastq>
+// (and the same with -fsanitize=thread: the kept worker threads of mc_parallel_for)
 #include "../../include/mcaller_hip.h"
 
 #include <cstdio>
