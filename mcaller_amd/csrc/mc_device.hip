@@ -1920,12 +1920,17 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     const int lane = threadIdx.x & 63;
     const int sub = lane % K2L, grp = lane / K2L;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    // A wave takes K2C consecutive records at a time, finds the ones that are scored at all (skipped records and records
-    // whose context leaves the contig are not), sub-model by sub-model, and works through those sixteen records per step:
-    // every group of eight lanes takes TWO records of one sub-model, so a weight read from LDS is used twice -- the LDS port
-    // (nine 8-byte reads per hidden unit) is as busy as the fp64 pipe in this kernel.
+    // A wave takes K2C consecutive records at a time and finds the ones that are scored at all (skipped records and records
+    // whose context leaves the contig are not).  Every group of eight lanes takes a PAIR of records of one sub-model, so a weight
+    // read from LDS is used twice -- the LDS port (nine 8-byte reads per hidden unit) is as busy as the fp64 pipe in this
+    // kernel.  The pairs are formed sub-model by sub-model (a record's place = its rank among the chunk's records of its
+    // sub-model; every lane writes its own into a 72-byte LDS list) and taken eight at a time, whatever their sub-models:
+    // the steps are full but for the last one.
     constexpr int K2C = 64;
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
+    __shared__ uint8_t s_pair_all[K2_THREADS / 64][K2C + 2 * 8];
+    uint8_t *s_pair = s_pair_all[threadIdx.x >> 6];
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int64_t chunk = wave0 * K2C; chunk < n; chunk += n_waves * K2C) {
         const int64_t rl = chunk + lane;
         int mi_l = 255;                              // sub-model of record rl (255: not scored here)
@@ -1936,62 +1941,60 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                 if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) mi_l = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
             }
         }
-        for (int mdl = 0; mdl < M.n_models; ++mdl) {         // (a key outside the models is the KeyError path, :218: the host decides)
-            unsigned long long todo = __ballot(mi_l == mdl);
+        int n_pairs = 0, my_place = -1;
+        for (int mdl = 0; mdl < min(M.n_models, 8); ++mdl) { // (a key outside the models is the KeyError path, :218: the host decides)
+            const unsigned long long bal = __ballot(mi_l == mdl);
+            if (mi_l == mdl) my_place = 2 * n_pairs + __popcll(bal & below);
+            n_pairs += (__popcll(bal) + 1) >> 1;
+        }
+        s_pair[lane] = 0xFF;
+        if (lane < 16) s_pair[K2C + lane] = 0xFF;
+        if (my_place >= 0) s_pair[my_place] = (uint8_t)lane;
+        for (int p0 = 0; p0 < n_pairs; p0 += 64 / K2L) {
+            const int pr = p0 + grp;
+            const int la = pr < n_pairs ? s_pair[2 * pr] : 0xFF, lb = pr < n_pairs ? s_pair[2 * pr + 1] : 0xFF;
+            const int mdl = __shfl(mi_l, la & 63);
+            if (la == 0xFF) continue;
+            const int64_t ra = chunk + la, rb = lb != 0xFF ? chunk + lb : -1;
+            const int64_t rb_c = rb >= 0 ? rb : ra;
             const double *w = s_w + (size_t)mdl * per;
             const double *b1 = w + NI * H, *w2 = b1 + H;
-            while (todo) {
-                // the records of this step: group g takes the set bits number 2g and 2g+1 of todo
-                unsigned long long mm = todo;
-                int64_t ra = -1, rb = -1;
+            double xa[NX], xb[NX];
+            if (submodel_in) {                       // plain batched call: X rows of n_in values
 #pragma unroll
-                for (int g = 0; g < 64 / K2L; ++g) {
-                    const int bit_a = mm ? (int)__builtin_ctzll(mm) : -1;
-                    if (mm) mm &= mm - 1;
-                    const int bit_b = mm ? (int)__builtin_ctzll(mm) : -1;
-                    if (mm) mm &= mm - 1;
-                    if (g == grp) { ra = bit_a >= 0 ? chunk + bit_a : -1; rb = bit_b >= 0 ? chunk + bit_b : -1; }
+                for (int i = 0; i < NX; ++i) { xa[i] = i < NI ? feats[ra * NI + i] : 0.0; xb[i] = i < NI ? feats[rb_c * NI + i] : 0.0; }
+            } else {                                 // flush records: k slot means + read quality (:189-193)
+                const double qa = qual[seg_read[site_seg[ra]]], qb = qual[seg_read[site_seg[rb_c]]];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    xa[i] = i < k ? feats[ra * k + i] : (i == k ? qa : 0.0);
+                    xb[i] = i < k ? feats[rb_c * k + i] : (i == k ? qb : 0.0);
                 }
-                todo = mm;
-                if (ra < 0) continue;
-                const int64_t rb_c = rb >= 0 ? rb : ra;
-                double xa[NX], xb[NX];
-                if (submodel_in) {                   // plain batched call: X rows of n_in values
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) { xa[i] = i < NI ? feats[ra * NI + i] : 0.0; xb[i] = i < NI ? feats[rb_c * NI + i] : 0.0; }
-                } else {                             // flush records: k slot means + read quality (:189-193)
-                    const double qa = qual[seg_read[site_seg[ra]]], qb = qual[seg_read[site_seg[rb_c]]];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        xa[i] = i < k ? feats[ra * k + i] : (i == k ? qa : 0.0);
-                        xb[i] = i < k ? feats[rb_c * k + i] : (i == k ? qb : 0.0);
-                    }
-                }
-                double za = 0.0, zb = 0.0;
-                for (int j0 = sub; j0 < H; j0 += 2 * K2L) {
-                    const int j1 = j0 + K2L;
-                    const bool v1 = j1 < H;
-                    const int c1 = v1 ? j1 : j0;
-                    const double bb0 = b1[j0], bb1 = b1[c1];
-                    double a0 = bb0, a1 = bb1, c0 = bb0, c1v = bb1;     // (a: record a, c: record b; units j0, j1)
-#pragma unroll
-                    for (int i = 0; i < NX; ++i)
-                        if (i < NI) {
-                            const double w0 = w[i * H + j0], w1 = w[i * H + c1];
-                            a0 = fma(xa[i], w0, a0); a1 = fma(xa[i], w1, a1);
-                            c0 = fma(xb[i], w0, c0); c1v = fma(xb[i], w1, c1v);
-                        }
-                    const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), u0 = tanh_1exp(c0), u1 = tanh_1exp(c1v);
-                    const double o0 = w2[j0], o1 = w2[c1];
-                    za = fma(t0, o0, za);
-                    zb = fma(u0, o0, zb);
-                    if (v1) { za = fma(t1, o1, za); zb = fma(u1, o1, zb); }
-                }
-#pragma unroll
-                for (int o = 1; o < K2L; o <<= 1) { za += __shfl_xor(za, o); zb += __shfl_xor(zb, o); }
-                if (sub == 0) prob[ra] = logistic(za + w2[H]);
-                if (sub == 1 && rb >= 0) prob[rb] = logistic(zb + w2[H]);
             }
+            double za = 0.0, zb = 0.0;
+            for (int j0 = sub; j0 < H; j0 += 2 * K2L) {
+                const int j1 = j0 + K2L;
+                const bool v1 = j1 < H;
+                const int c1 = v1 ? j1 : j0;
+                const double bb0 = b1[j0], bb1 = b1[c1];
+                double a0 = bb0, a1 = bb1, c0 = bb0, c1v = bb1;     // (a: record a, c: record b; units j0, j1)
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (i < NI) {
+                        const double w0 = w[i * H + j0], w1 = w[i * H + c1];
+                        a0 = fma(xa[i], w0, a0); a1 = fma(xa[i], w1, a1);
+                        c0 = fma(xb[i], w0, c0); c1v = fma(xb[i], w1, c1v);
+                    }
+                const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), u0 = tanh_1exp(c0), u1 = tanh_1exp(c1v);
+                const double o0 = w2[j0], o1 = w2[c1];
+                za = fma(t0, o0, za);
+                zb = fma(u0, o0, zb);
+                if (v1) { za = fma(t1, o1, za); zb = fma(u1, o1, zb); }
+            }
+#pragma unroll
+            for (int o = 1; o < K2L; o <<= 1) { za += __shfl_xor(za, o); zb += __shfl_xor(zb, o); }
+            if (sub == 0) prob[ra] = logistic(za + w2[H]);
+            if (sub == 1 && rb >= 0) prob[rb] = logistic(zb + w2[H]);
         }
     }
 }
