@@ -24,7 +24,7 @@ def build_lib(force=False, verbose=True, out=None, defines=()):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
            '-Wall', '-Wno-unused-function', '-Wno-unused-const-variable', '-pthread', '-o', OUT] + srcs + ['-ldl']
-    for macro in ('MC_TILE', 'MC_SCAN_WGS', 'MC_PROFILE', 'MC_NTHREADS', 'MC_SCAN_WPE', 'MC_SCAN_CHUNK', 'MC_K1_EXPERIMENTS'):
+    for macro in ('MC_TILE',):
         if os.environ.get(macro):
             cmd.insert(1, '-D%s=%s' % (macro, os.environ[macro]))
     if verbose:
