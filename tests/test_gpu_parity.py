@@ -495,3 +495,28 @@ def test_pass_timing_interval():
             dev.set_pass_timing(-1)
     finally:
         dev.close()
+
+
+def test_dense_cluster_in_a_sparse_reference(dev):
+    """A GATC-like motif picks the scan instance with the small candidate list; a stretch of (GATC)n in the genome makes every
+    unit of a tile a candidate there, the list overflows and the tile takes the exact row-by-row path.  Records == oracle."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=400000, seed=77)
+    codes[150000:190000] = np.tile(np.array([2, 0, 3, 1], dtype=np.uint8), 10000)      # GATCGATC...
+    ref = synth.SynthRef(codes, motif='GATC')
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    for seed, rl in ((21, (3000, 12000)), (22, (200, 900))):
+        table, qual = synth.make_table(400000, seed=seed, codes=codes, read_len=rl)
+        dev.upload_table(table)
+        dev.set_read_quality(qual)
+        for skip in (0, 1):
+            orc = H.oracle_records(table, ref.device_arrays(), qual, 6, skip, 0.0)
+            H.oracle_score(orc, table, qual, weights, soc, 6)
+            rec = dev.extract(6, skip, 0.0, score=True)
+            H.assert_records_equal(rec, orc, 6)
+            dev.run_async(6, skip, 0.0, score=True)
+            H.assert_records_equal(dev.wait(), orc, 6)
+        assert rec.n > 3000
