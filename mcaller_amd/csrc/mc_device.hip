@@ -640,7 +640,8 @@ struct K1Args {
     const TileDesc *tiles;
     Payload *payload;             // [payload_cap]
     long long payload_cap;
-    long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of 64 behind its own PT slots
+    long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of (1 << chunk_shift) behind its own PT slots
+    int chunk_shift;              // 6: chunks of 64 (sparse motifs); 8: chunks of 256 (a one-base motif: ~270 windows per tile)
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -794,24 +795,29 @@ struct TileSlots {
     int total;                    // windows closed so far
     int lane;
     __device__ __forceinline__ long long slot_of(int rank) const {
-        return rank < PT ? tile * PT + rank : s_chunk[(rank - PT) >> 6] + ((rank - PT) & 63);
+        const int cs = A.chunk_shift;
+        return rank < PT ? tile * PT + rank : s_chunk[(rank - PT) >> cs] + ((rank - PT) & ((1 << cs) - 1));
     }
     __device__ __forceinline__ void reserve(int new_total) {   // chunks for ranks < new_total (wave-uniform call)
-        const int c0 = total <= PT ? 0 : (total - PT + 63) >> 6, c1 = new_total <= PT ? 0 : (new_total - PT + 63) >> 6;
+        const int cs = A.chunk_shift, cm = (1 << cs) - 1;
+        const int c0 = total <= PT ? 0 : (total - PT + cm) >> cs, c1 = new_total <= PT ? 0 : (new_total - PT + cm) >> cs;
         if (c1 > c0) {
             if (lane == 0) {
                 const int n = c1 - c0;
                 const int sh = (int)(tile & (NSHARD - 1));
                 const long long per = (A.payload_cap - A.T.n_tiles * PT) / NSHARD;
-                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n * 64ull);
+                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n << cs);
                 long long base = A.T.n_tiles * PT + sh * per + off;
-                if (off + n * 64LL > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+                if (off + ((long long)n << cs) > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
                 for (int c = c0; c < c1; ++c) {
-                    s_chunk[c] = base < 0 ? -1 : base + (long long)(c - c0) * 64;
+                    s_chunk[c] = base < 0 ? -1 : base + ((long long)(c - c0) << cs);
                     A.tile_chunk[tile * NCHUNK + c] = s_chunk[c];
                 }
             }
-            __threadfence_block();                  // lane 0's s_chunk entries, before any lane reads them
+            // lane 0's s_chunk entries, before any lane reads them: LDS operations of one wave execute in order, so this only
+            // has to keep the compiler from moving the reads (a workgroup-scope fence would also wait for every payload store
+            // in flight -- 2 us, four times per tile in dense mode)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
     // the lanes with `closed` write their payloads, in lane order
@@ -1219,9 +1225,9 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     for (int j = l; j < c; j += LG) {
         long long slot = tile * PT + j;
         if (j >= PT) {
-            const long long cb = A.tile_chunk[tile * NCHUNK + ((j - PT) >> 6)];
+            const long long cb = A.tile_chunk[tile * NCHUNK + ((j - PT) >> A.chunk_shift)];
             if (cb < 0) { atomicOr(&A.cnt->overflow, 1u); continue; }
-            slot = cb + ((j - PT) & 63);
+            slot = cb + ((j - PT) & ((1 << A.chunk_shift) - 1));
         }
         sorted[first + j] = A.payload[slot];
     }
@@ -2245,6 +2251,7 @@ struct mc_ctx {
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> ref_allocs, mlp_allocs, rec_allocs;
     int64_t payload_tiles = 0;     // tiles the payload buffer was sized for
+    int payload_chunk = 0;         // ... and the chunk size
     // pipelined passes (mc_extract_features_async / mc_wait_records): two record sets, exported to pinned host memory
     struct AsyncBuf {
         DevRecords O;              // device records of the pass
@@ -2821,9 +2828,15 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
     return 0;
 }
 
+// marked positions are dense (a one-base motif): the scan instance that lists every unit of a tile, bigger payload chunks
+static bool dense_reference(const mc_ctx *c) {
+    return c->ref_total_len > 0 && (double)c->R.n_sites * 64.0 > (double)c->ref_total_len;
+}
+
 static int ensure_records(mc_ctx *c, int64_t cap, int k) {
     const int64_t need_tiles = std::max<int64_t>(c->T.n_tiles, c->scratch_tiles);
-    if (c->Omain.capacity >= cap && c->last_k == k && c->payload_tiles >= need_tiles) { c->O = c->Omain; return 0; }
+    const int chunk = dense_reference(c) ? 256 : 64;
+    if (c->Omain.capacity >= cap && c->last_k == k && c->payload_tiles >= need_tiles && c->payload_chunk >= chunk) { c->O = c->Omain; return 0; }
     if (int rc = sync_pass_streams(c)) return rc;
     free_pool(c->rec_allocs);
     for (DevRecords *D : {&c->Omain}) {
@@ -2834,7 +2847,9 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
             return -10;
     }
     c->payload_tiles = need_tiles;
-    c->payload_cap = cap + (need_tiles + 1) * PT;
+    // (the scan hands out payload slots beyond a tile's own PT in chunks; every tile may leave most of its last chunk unused)
+    c->payload_cap = cap + (need_tiles + 1) * (PT + chunk);
+    c->payload_chunk = chunk;
     if (dev_alloc(c->rec_allocs, &c->payload_sorted, (size_t)cap) || dev_alloc(c->rec_allocs, &c->rare_list, (size_t)cap) || dev_alloc(c->rec_allocs, &c->payload, (size_t)c->payload_cap)) return -10;
     c->last_k = k;
     c->O = c->Omain;
@@ -2954,8 +2969,9 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
+    const bool dense = dense_reference(c);
+    A.chunk_shift = dense ? 8 : 6;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
-    const bool dense = c->ref_total_len > 0 && (double)c->R.n_sites * 64.0 > (double)c->ref_total_len;
     if (dense) hipLaunchKernelGGL(k1_scan<TILE / 8 + NBR>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
     else hipLaunchKernelGGL(k1_scan<64>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
