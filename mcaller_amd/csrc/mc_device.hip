@@ -1850,8 +1850,12 @@ __global__ void k_merge(DevRecords O, int64_t n_o, DevRecords L, int64_t n_l, De
 // is 100 tanh per call -- this is ~30.  a = n ln2 + r, |r| <= ln2/2; e^r as its Taylor polynomial of degree 13 (remainder
 // < 5e-18), scaled by 2^n.  Relative error ~2e-16.
 __device__ __forceinline__ double exp_pos(double a) {
-    a = fmin(a, 708.0);
-    const double n = rint(a * 1.4426950408889634074);
+    a = fmin(a, 700.0);
+    // n = rint(a / ln2) without v_rndne / v_cvt / v_ldexp (quarter-rate fp64 instructions): adding 1.5 * 2^52 leaves the integer
+    // in the low mantissa bits, and 2^n is built from it with two integer instructions
+    const double magic = 6755399441055744.0;
+    const double t = fma(a, 1.4426950408889634074, magic);
+    const double n = t - magic;
     double r = fma(n, -6.93147180369123816490e-01, a);      // ln2 in two pieces
     r = fma(n, -1.90821492927058770002e-10, r);
     double p = 1.6059043836821613e-10;                      // 1/13!
@@ -1868,7 +1872,8 @@ __device__ __forceinline__ double exp_pos(double a) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+    const int ni = __double2loint(t);                       // n: 0 .. 1010
+    return p * __hiloint2double((ni + 1023) << 20, 0);      // 2^n
 }
 
 // 1 / d for d >= 1: the hardware's reciprocal estimate and two Newton steps (relative error ~1e-16; no scaling needed, d is
