@@ -1263,9 +1263,9 @@ __device__ __forceinline__ double div1e4(int x) {
     return fma(fma(-q0, 10000.0, xd), r, q0);
 }
 
-// (five waves per SIMD: the register allocator fits 94 VGPRs without scratch; left alone it takes 99 = four waves, and
-// six waves spill.  The kernel's time is rounds x latency, so resident waves count: 66 -> 60 us for list + emit.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
+// (six waves per SIMD: the register allocator fits 80 VGPRs without scratch; the kernel's time is rounds x latency, so resident
+// waves count -- four: 76 us for ordering + emit, five: 59, six: 55, seven (72 VGPRs, 20 bytes of scratch): 57)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
