@@ -885,8 +885,13 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc
 // that reads global memory.  Waves are short and light, many are resident per SIMD, their loads overlap: the kernel streams.
 // CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one unit in 20 is listed) bails out to
 // scan_tile_slowly if a tile overflows it; the dense instance holds every unit of the tile.
+#ifdef MC_SCAN_WPE                  // (variant builds, tools/variants.sh)
+#define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MC_SCAN_WPE, MC_SCAN_WPE)))
+#else
+#define MC_SCAN_ATTR
+#endif
 template <int CG>
-__global__ __launch_bounds__(64) void k1_scan(K1Args A) {
+__global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     __shared__ uint32_t s_bits[NBST][64];
     __shared__ __attribute__((aligned(16))) CandUnit s_cand[CG];
     __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
