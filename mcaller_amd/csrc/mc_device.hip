@@ -138,6 +138,7 @@ struct DevRecords {
 struct DevMlp {
     int32_t n_models = 0, n_in = 0, n_hidden = 0;
     double *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    double *wu = nullptr;      // per sub-model and hidden unit: W1[0..n_in)[j], b1[j], W2[j] -- what k2_mlp reads with scalar loads
     uint8_t *sub_of_char = nullptr;
 };
 
@@ -1847,38 +1848,55 @@ __global__ void k_merge(DevRecords O, int64_t n_o, DevRecords L, int64_t n_l, De
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; weights staged in LDS.
+// K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; the weights are scalar operands.
 // ---------------------------------------------------------------------------------------------------
-// tanh(x) = sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}): one exp and one division; absolute error ~1e-16, far inside the
-// 1e-5 the probabilities are held to (the library tanh costs several times more and dominates this kernel)
-// e^a for a >= 0, written out: the library's exp and the IEEE division cost ~100 instructions per tanh, and the classifier
-// is 100 tanh per call -- this is ~30.  a = n ln2 + r, |r| <= ln2/2; e^r as its Taylor polynomial of degree 13 (remainder
-// < 5e-18), scaled by 2^n.  Relative error ~2e-16.
-__device__ __forceinline__ double exp_pos(double a) {
-    a = fmin(a, 700.0);
-    // n = rint(a / ln2) without v_rndne / v_cvt / v_ldexp (quarter-rate fp64 instructions): adding 1.5 * 2^52 leaves the integer
-    // in the low mantissa bits, and 2^n is built from it with two integer instructions
-    const double magic = 6755399441055744.0;
-    const double t = fma(a, 1.4426950408889634074, magic);
-    const double n = t - magic;
-    double r = fma(n, -6.93147180369123816490e-01, a);      // ln2 in two pieces
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                      // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);                    // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                   // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                   // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                  // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                    // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                   // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);                  // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                   // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                  // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                  // 1/3!
-    p = fma(p, r, 0.5);
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)) and 1 / (1 + e^{-z}) = 1 - 1 / (e^{z} + 1) from one exponential each and a
+// reciprocal that FOUR of them share, written out: the library's exp and the IEEE division cost ~100 instructions per tanh,
+// and the classifier is 100 tanh per call -- this is 25.  Absolute error < 1e-15, far inside the 1e-9 the probabilities are
+// held to.
+//
+// e^{2t} + 1 for t >= 0:  t = n ln2/2 + r, |r| <= ln2/4;  e^{2r} = 1 + 2r + r^2 G(r) with G of degree 9 -- the interpolant of
+// (e^x - 1 - x) / x^2 at the Chebyshev nodes of [-ln2/2, ln2/2] (computed with 80 digits; relative error of e^x with the
+// coefficients rounded to double: 1.6e-17; the Taylor polynomial needs two more terms), its coefficients scaled by powers
+// of two for the argument x = 2r -- and e^{2t} = 2^n e^{2r}.  n = rint(2t / ln2) without v_rndne / v_cvt / v_ldexp
+// (quarter-rate fp64 instructions): adding 1.5 * 2^52 leaves the integer in the low mantissa bits, and 2^n is built from it
+// with one integer instruction.  e^0 = 1 exactly (tanh(0) = 0).
+//
+// The constants live in VGPRs on purpose (VgprConst): k2_mlp keeps the weights of four hidden units in SGPRs (72 of the
+// ~100 there are), and constants the compiler put there as well were spilled to VGPR lanes and read back inside the loop.
+struct VgprConst {
+    double v;
+    __device__ __forceinline__ explicit VgprConst(double x) : v(x) { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ operator double() const { return v; }
+};
+struct ExpConsts {
+    VgprConst two_log2e{2.8853900817779268}, magic{6755399441055744.0}, half_ln2_hi{-0.3465735901845619},
+        half_ln2_lo{-9.541074646352939e-11};
+    VgprConst t_max4{87.5};        // e^{2t} <= e^175: the product of four such (e^{2t} + 1) stays finite; tanh(87.5) = 1 in double
+    VgprConst g9{5.1405589494805136e-05}, g8{0.0002828297056809958}, g7{0.0014109321451518497}, g6{0.00634918945176432},
+        g5{0.02539682542470863}, g4{0.08888888907016779}, g3{0.26666666666656197}, g2{0.6666666666659861},
+        g1{1.3333333333333335}, g0{2.0000000000000004};
+};
+
+__device__ __forceinline__ double exp2t_plus1(double t, const ExpConsts &C) {      // (0 <= t <= 350)
+    const double tt = fma(t, C.two_log2e, C.magic);
+    const double n = tt - C.magic;
+    double r = fma(n, C.half_ln2_hi, t);                    // ln2/2 in two pieces
+    r = fma(n, C.half_ln2_lo, r);
+    double p = C.g9;
+    p = fma(p, r, C.g8);
+    p = fma(p, r, C.g7);
+    p = fma(p, r, C.g6);
+    p = fma(p, r, C.g5);
+    p = fma(p, r, C.g4);
+    p = fma(p, r, C.g3);
+    p = fma(p, r, C.g2);
+    p = fma(p, r, C.g1);
+    p = fma(p, r, C.g0);
+    p = fma(p, r, 2.0);
     p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const int ni = __double2loint(t);                       // n: 0 .. 1010
-    return p * __hiloint2double((ni + 1023) << 20, 0);      // 2^n
+    const int ni = __double2loint(tt);                      // n: 0 .. 1010
+    return fma(p, __hiloint2double((ni + 1023) << 20, 0), 1.0);     // p 2^n + 1
 }
 
 // 1 / d for d >= 1: the hardware's reciprocal estimate and two Newton steps (relative error ~1e-16; no scaling needed, d is
@@ -1890,23 +1908,100 @@ __device__ __forceinline__ double recip_ge1(double d) {
     return r;
 }
 
-// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): absolute error ~1e-16, far inside the 1e-5 the probabilities are held to
-__device__ __forceinline__ double tanh_1exp(double x) {
-    const double q = recip_ge1(exp_pos(2.0 * fabs(x)) + 1.0);
-    return copysign(1.0 - (q + q), x);
+__device__ __forceinline__ double tanh_1exp(double x, const ExpConsts &C) {
+    const double q = recip_ge1(exp2t_plus1(fmin(fabs(x), C.t_max4), C));
+    return copysign(fma(-2.0, q, 1.0), x);
 }
 
-// 1 / (1 + e^{-z})
-__device__ __forceinline__ double logistic(double z) {
-    const double q = recip_ge1(exp_pos(fabs(z)) + 1.0);     // 1 / (e^{|z|} + 1)
+// four at a time, step by step side by side (four independent chains in flight: the Horner scheme alone is a dependent
+// sequence of twelve), and one reciprocal, of the product of the four denominators (each <= e^175 + 1)
+__device__ __forceinline__ void tanh_4(double &x0, double &x1, double &x2, double &x3, const ExpConsts &C) {
+    double t[4] = {fmin(fabs(x0), C.t_max4), fmin(fabs(x1), C.t_max4), fmin(fabs(x2), C.t_max4), fmin(fabs(x3), C.t_max4)};
+    double tt[4], r[4], p[4], d[4];
+#define MC_EACH for (int c = 0; c < 4; ++c)
+#pragma unroll
+    MC_EACH tt[c] = fma(t[c], C.two_log2e, C.magic);
+#pragma unroll
+    MC_EACH r[c] = fma(tt[c] - C.magic, C.half_ln2_hi, t[c]);
+#pragma unroll
+    MC_EACH r[c] = fma(tt[c] - C.magic, C.half_ln2_lo, r[c]);
+#pragma unroll
+    MC_EACH p[c] = fma(C.g9, r[c], C.g8);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g7);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g6);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g5);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g4);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g3);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g2);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g1);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g0);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], 2.0);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], 1.0);
+#pragma unroll
+    MC_EACH d[c] = fma(p[c], __hiloint2double((__double2loint(tt[c]) + 1023) << 20, 0), 1.0);
+#undef MC_EACH
+    const double p01 = d[0] * d[1], p23 = d[2] * d[3];
+    const double rall = recip_ge1(p01 * p23);
+    const double r01 = rall * p23, r23 = rall * p01;        // 1 / (d0 d1), 1 / (d2 d3)
+    x0 = copysign(fma(-2.0, r01 * d[1], 1.0), x0);
+    x1 = copysign(fma(-2.0, r01 * d[0], 1.0), x1);
+    x2 = copysign(fma(-2.0, r23 * d[3], 1.0), x2);
+    x3 = copysign(fma(-2.0, r23 * d[2], 1.0), x3);
+}
+
+// 1 / (1 + e^{-z}) = (1 + tanh(z / 2)) / 2
+__device__ __forceinline__ double logistic(double z, const ExpConsts &C) {
+    const double q = recip_ge1(exp2t_plus1(fmin(0.5 * fabs(z), 350.0), C));   // 1 / (e^{|z|} + 1)
     return z >= 0.0 ? 1.0 - q : q;
 }
 
-// Eight lanes per record: lane `sub` of a group takes hidden units sub, sub+8, ... (four independent chains at a time: the
-// fp64 tanh is a long dependent sequence), the eight partial sums are combined with three butterfly steps.  203k records
-// alone would be 3k waves -- too few to fill 1024 SIMDs.
-constexpr int K2L = 8;
-constexpr int K2_THREADS = 256;
+// One lane per record, one hidden unit after the other inside the lane, the weights as SCALAR operands: the records a wave
+// takes belong to one sub-model, so W1[:, j], b1[j], W2[j] are the same for its 64 lanes -- they come through the scalar
+// cache into SGPRs (nine s_load'ed doubles per hidden unit) and the vector pipe issues nothing but the arithmetic:
+// 7 + ~30 + 1 fp64 instructions per hidden unit and record, no LDS reads, no address arithmetic, no butterfly.
+//
+// A workgroup takes a contiguous stretch of the records (the pass's records divided evenly over the workgroups, K2B at a
+// time) and
+//   A. finds the records that are scored at all (skipped records and records whose context leaves the contig are not) and
+//      lists them sub-model by sub-model in LDS, every sub-model's list padded to whole groups of 64; the read quality
+//      (a chain of three dependent loads per record) is fetched here, for all records at once;
+//   B. wave w computes quarter (w & 3) of the hidden units for groups (w >> 2), (w >> 2) + n_waves / 4, ...: the four
+//      SIMDs of the CU carry the same load whatever the number of groups, and a workgroup of 1024 records (~11 groups of
+//      the headline workload) keeps all of them busy.  Partial sums go to LDS;
+//   C. the quarters are added in a fixed order (the result does not depend on which wave ran when) and the logistic
+//      function gives the probability.
+// The earlier version (eight lanes per record, pairs of records per lane group, weights in LDS: 126 LDS reads and ~1200
+// VALU instructions per step of 16 records, 3.1 uneven waves per SIMD) took 53 us for the headline pass.
+constexpr int K2B = 1024;                       // records per workgroup iteration
+#ifndef MC_K2_THREADS
+#define MC_K2_THREADS 1024
+#endif
+constexpr int K2_THREADS = MC_K2_THREADS;
+constexpr int K2_WAVES = K2_THREADS / 64;
+constexpr int K2_MAXM = 8;                      // sub-models (mc_ctx_set_mlp refuses more)
+constexpr int K2_SLOTS = K2B + K2_MAXM * 64;    // list entries: every sub-model's part is padded to a multiple of 64
+constexpr int K2_SUB = K2B / 64;                // 64-record pieces of a stretch: the unit of the list's prefix sums
+static_assert(K2_WAVES >= 4 && K2_WAVES % 4 == 0 && K2B % K2_THREADS == 0, "four unit quarters; whole records per thread");
+static_assert(K2_SUB * K2_MAXM <= K2_THREADS && K2_MAXM * 64 <= K2_THREADS, "one thread per (piece, sub-model) / per pad entry");
+
+#ifdef MC_K2_TRACE      // (variant build for tools/k2_trace.py: 100 MHz time stamps of every wave's phases)
+__device__ unsigned long long g_k2_trace[1024 * 16 * 16];
+#define K2_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024) g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + (i)] = wall_clock64(); g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 8 + (i)] = clock64(); } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
+
+#define MC_SCALAR_MEM __attribute__((address_space(4)))    // constant address space: uniform loads from it are s_load
 
 // NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
 // unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
@@ -1918,100 +2013,181 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
                                                      double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
                                                      const unsigned int *__restrict__ overflow) {
-    extern __shared__ double s_w[];   // per model: W1[n_in*H] b1[H] W2[H] b2[1]
     if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
-    const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in;
-    const int per = NI * H + 2 * H + 1;
-    for (int i = threadIdx.x; i < M.n_models * per; i += blockDim.x) {
-        const int mi = i / per, j = i % per;
-        double v;
-        if (j < NI * H) v = M.W1[(size_t)mi * NI * H + j];
-        else if (j < NI * H + H) v = M.b1[(size_t)mi * H + (j - NI * H)];
-        else if (j < NI * H + 2 * H) v = M.W2[(size_t)mi * H + (j - NI * H - H)];
-        else v = M.b2[mi];
-        s_w[i] = v;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % K2L, grp = lane / K2L;
-    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    // A wave takes K2C consecutive records at a time and finds the ones that are scored at all (skipped records and records
-    // whose context leaves the contig are not).  Every group of eight lanes takes a PAIR of records of one sub-model, so a weight
-    // read from LDS is used twice -- the LDS port (nine 8-byte reads per hidden unit) is as busy as the fp64 pipe in this
-    // kernel.  The pairs are formed sub-model by sub-model (a record's place = its rank among the chunk's records of its
-    // sub-model; every lane writes its own into a 72-byte LDS list) and taken eight at a time, whatever their sub-models:
-    // the steps are full but for the last one.
-    constexpr int K2C = 64;
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
-    __shared__ uint8_t s_pair_all[K2_THREADS / 64][K2C + 2 * 8];
-    uint8_t *s_pair = s_pair_all[threadIdx.x >> 6];
+    const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
+    __shared__ uint16_t s_list[K2_SLOTS];       // record (offset in the stretch) of every list entry; 0xFFFF: padding
+    __shared__ double s_q[K2B];                 // read quality of the stretch's records
+    __shared__ double s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
+    __shared__ int s_cnt[K2_SUB][K2_MAXM], s_before[K2_SUB][K2_MAXM], s_tot[K2_MAXM], s_gmodel[K2_SLOTS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int64_t chunk = wave0 * K2C; chunk < n; chunk += n_waves * K2C) {
-        const int64_t rl = chunk + lane;
-        int mi_l = 255;                              // sub-model of record rl (255: not scored here)
-        if (rl < n) {
-            if (submodel_in) mi_l = submodel_in[rl];
-            else {
-                const uint32_t inf = info[rl];
-                if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) mi_l = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
-            }
-        }
-        int n_pairs = 0, my_place = -1;
-        for (int mdl = 0; mdl < min(M.n_models, 8); ++mdl) { // (a key outside the models is the KeyError path, :218: the host decides)
-            const unsigned long long bal = __ballot(mi_l == mdl);
-            if (mi_l == mdl) my_place = 2 * n_pairs + __popcll(bal & below);
-            n_pairs += (__popcll(bal) + 1) >> 1;
-        }
-        s_pair[lane] = 0xFF;
-        if (lane < 16) s_pair[K2C + lane] = 0xFF;
-        if (my_place >= 0) s_pair[my_place] = (uint8_t)lane;
-        for (int p0 = 0; p0 < n_pairs; p0 += 64 / K2L) {
-            const int pr = p0 + grp;
-            const int la = pr < n_pairs ? s_pair[2 * pr] : 0xFF, lb = pr < n_pairs ? s_pair[2 * pr + 1] : 0xFF;
-            const int mdl = __shfl(mi_l, la & 63);
-            if (la == 0xFF) continue;
-            const int64_t ra = chunk + la, rb = lb != 0xFF ? chunk + lb : -1;
-            const int64_t rb_c = rb >= 0 ? rb : ra;
-            const double *w = s_w + (size_t)mdl * per;
-            const double *b1 = w + NI * H, *w2 = b1 + H;
-            double xa[NX], xb[NX];
-            if (submodel_in) {                       // plain batched call: X rows of n_in values
+    const ExpConsts C;
+    K2_STAMP(0);
+    // Which quarter of the hidden units a wave takes: the one of the SIMD it runs on, so that the four SIMDs of the CU carry
+    // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  The waves
+    // register before the first barrier of the first stretch.  (If the workgroup's waves did not land on all four SIMDs:
+    // by wave number.)
+    __shared__ uint32_t s_simd_of_wave[K2_WAVES / 4];       // a byte per wave
+    const int simd = (int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3;      // HW_ID[5:4]
+    int quarter = 0, g_first = 0, g_step = 1;
+    bool placed = false;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    K2_STAMP(1);
+    for (int64_t base = lo; base < hi; base += K2B) {
+        // ---- A: the lists
+        // (the read quality is a chain of three dependent loads -- segment, read, quality: it starts with the first load of
+        // the stretch and is only waited for when the lists are done)
+        int mi[K2B / K2_THREADS], rank[K2B / K2_THREADS];
+        double qv[K2B / K2_THREADS];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { xa[i] = i < NI ? feats[ra * NI + i] : 0.0; xb[i] = i < NI ? feats[rb_c * NI + i] : 0.0; }
-            } else {                                 // flush records: k slot means + read quality (:189-193)
-                const double qa = qual[seg_read[site_seg[ra]]], qb = qual[seg_read[site_seg[rb_c]]];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    xa[i] = i < k ? feats[ra * k + i] : (i == k ? qa : 0.0);
-                    xb[i] = i < k ? feats[rb_c * k + i] : (i == k ? qb : 0.0);
+        for (int i = 0; i < K2B / K2_THREADS; ++i) {
+            const int off = i * K2_THREADS + tid;
+            const int64_t r = base + off;
+            mi[i] = 255;                            // sub-model of record r (255: not scored here)
+            qv[i] = 0.0;
+            if (r < hi) {
+                if (submodel_in) mi[i] = submodel_in[r];
+                else {
+                    const uint32_t inf = info[r];
+                    const int32_t seg = site_seg[r];
+                    if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) {
+                        mi[i] = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+                        qv[i] = qual[seg_read[seg]];
+                    }
                 }
             }
-            double za = 0.0, zb = 0.0;
-            for (int j0 = sub; j0 < H; j0 += 2 * K2L) {
-                const int j1 = j0 + K2L;
-                const bool v1 = j1 < H;
-                const int c1 = v1 ? j1 : j0;
-                const double bb0 = b1[j0], bb1 = b1[c1];
-                double a0 = bb0, a1 = bb1, c0 = bb0, c1v = bb1;     // (a: record a, c: record b; units j0, j1)
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-                    if (i < NI) {
-                        const double w0 = w[i * H + j0], w1 = w[i * H + c1];
-                        a0 = fma(xa[i], w0, a0); a1 = fma(xa[i], w1, a1);
-                        c0 = fma(xb[i], w0, c0); c1v = fma(xb[i], w1, c1v);
-                    }
-                const double t0 = tanh_1exp(a0), t1 = tanh_1exp(a1), u0 = tanh_1exp(c0), u1 = tanh_1exp(c1v);
-                const double o0 = w2[j0], o1 = w2[c1];
-                za = fma(t0, o0, za);
-                zb = fma(u0, o0, zb);
-                if (v1) { za = fma(t1, o1, za); zb = fma(u1, o1, zb); }
+            rank[i] = 0;
+            for (int m = 0; m < NM; ++m) {          // (a key outside the models is the KeyError path, :218: the host decides)
+                const unsigned long long bal = __ballot(mi[i] == m);
+                if (mi[i] == m) rank[i] = __popcll(bal & below);
+                if (lane == 0) s_cnt[off >> 6][m] = __popcll(bal);
             }
-#pragma unroll
-            for (int o = 1; o < K2L; o <<= 1) { za += __shfl_xor(za, o); zb += __shfl_xor(zb, o); }
-            if (sub == 0) prob[ra] = logistic(za + w2[H]);
-            if (sub == 1 && rb >= 0) prob[rb] = logistic(zb + w2[H]);
         }
+        if (!placed && lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
+        K2_STAMP(2);
+        __syncthreads();
+        if (!placed) {
+            uint32_t per_simd = 0;                  // a byte per SIMD: its waves
+            int slot = 0;                           // waves of this wave's SIMD with a smaller number
+            for (int w4 = 0; w4 < K2_WAVES / 4; ++w4) {
+                const uint32_t four = __builtin_amdgcn_readfirstlane(s_simd_of_wave[w4]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int sd = (four >> (8 * b)) & 3;
+                    per_simd += 1u << (8 * sd);
+                    slot += (w4 * 4 + b < wave && sd == simd) ? 1 : 0;
+                }
+            }
+            const bool by_simd = (per_simd & 0xFFu) && (per_simd & 0xFF00u) && (per_simd & 0xFF0000u) && (per_simd & 0xFF000000u);
+            quarter = by_simd ? simd : wave & 3;
+            g_first = by_simd ? slot : wave >> 2;
+            g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : K2_WAVES / 4;
+            placed = true;
+        }
+        if (tid < K2_SUB * K2_MAXM) {               // thread (piece c, sub-model m): the sub-model's records in pieces before c
+            const int c = tid / K2_MAXM, m = tid % K2_MAXM;
+            int all = 0, before = 0;
+            if (m < NM)
+                for (int c2 = 0; c2 < K2_SUB; ++c2) { const int v = s_cnt[c2][m]; all += v; before += c2 < c ? v : 0; }
+            s_before[c][m] = before;
+            if (c == 0) s_tot[m] = all;
+        }
+        __syncthreads();
+        int n_groups = 0;
+        {
+            int start[K2_MAXM];                     // first list entry of every sub-model
+#pragma unroll
+            for (int m = 0; m < K2_MAXM; ++m) { start[m] = n_groups * 64; n_groups += (s_tot[m] + 63) >> 6; }
+#pragma unroll
+            for (int i = 0; i < K2B / K2_THREADS; ++i) {
+                const int off = i * K2_THREADS + tid;
+                if (mi[i] < NM) {
+                    int st = 0;
+#pragma unroll
+                    for (int m = 0; m < K2_MAXM; ++m) st = mi[i] == m ? start[m] : st;
+                    s_list[st + s_before[off >> 6][mi[i]] + rank[i]] = (uint16_t)off;
+                }
+            }
+            if (tid < K2_MAXM * 64) {               // padding of sub-model tid / 64, and the sub-model of its groups
+                const int m = tid >> 6;
+                int st = 0;
+#pragma unroll
+                for (int m2 = 0; m2 < K2_MAXM; ++m2) st = m == m2 ? start[m2] : st;
+                const int tot = s_tot[m], g = (tot + 63) >> 6;
+                if (tot + lane < g * 64) s_list[st + tot + lane] = 0xFFFF;
+                if (lane < g) s_gmodel[(st >> 6) + lane] = m;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K2B / K2_THREADS; ++i) s_q[i * K2_THREADS + tid] = qv[i];
+        __syncthreads();
+        K2_STAMP(3);
+        // ---- B: a quarter of the hidden units for every fourth (eighth ...) group
+        const int u0 = quarter * H / 4, u1 = (quarter + 1) * H / 4;
+        for (int g = g_first; g < n_groups; g += g_step) {
+            const int mdl = __builtin_amdgcn_readfirstlane(s_gmodel[g]);
+            const int e = s_list[g * 64 + lane];
+            const int off = e == 0xFFFF ? s_list[g * 64] : e;       // (padding lanes compute the group's first record again)
+            const int64_t r = base + off;
+            double x[NX];
+            if (submodel_in) {                       // plain batched call: X rows of n_in values
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+            } else {                                 // flush records: k slot means + read quality (:189-193)
+                const double q = s_q[off];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+            }
+            const MC_SCALAR_MEM double *wu = (const MC_SCALAR_MEM double *)M.wu + ((size_t)mdl * H + u0) * S;
+            double z = 0.0;
+            int u = u0;
+            for (; u + 4 <= u1; u += 4, wu += 4 * S) {          // four independent chains: the fp64 tanh is a long dependent sequence
+                double a0 = x[0] * wu[0], a1 = x[0] * wu[S], a2 = x[0] * wu[2 * S], a3 = x[0] * wu[3 * S];
+#pragma unroll
+                for (int i = 1; i < NX; ++i)
+                    if (i < NI) {
+                        a0 = fma(x[i], wu[i], a0);
+                        a1 = fma(x[i], wu[S + i], a1);
+                        a2 = fma(x[i], wu[2 * S + i], a2);
+                        a3 = fma(x[i], wu[3 * S + i], a3);
+                    }
+                a0 += wu[NI]; a1 += wu[S + NI]; a2 += wu[2 * S + NI]; a3 += wu[3 * S + NI];     // (a second scalar operand in the first fma would cost two moves)
+                tanh_4(a0, a1, a2, a3, C);
+                z = fma(a0, wu[NI + 1], z);
+                z = fma(a1, wu[S + NI + 1], z);
+                z = fma(a2, wu[2 * S + NI + 1], z);
+                z = fma(a3, wu[3 * S + NI + 1], z);
+            }
+            for (; u < u1; ++u, wu += S) {
+                double a0 = x[0] * wu[0];
+#pragma unroll
+                for (int i = 1; i < NX; ++i)
+                    if (i < NI) a0 = fma(x[i], wu[i], a0);
+                z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
+            }
+            s_part[quarter][g * 64 + lane] = z;
+        }
+        K2_STAMP(4);
+        __syncthreads();
+        K2_STAMP(5);
+        // ---- C: the output unit
+        for (int t = tid; t < n_groups * 64; t += K2_THREADS) {
+            const int e = s_list[t];
+            if (e == 0xFFFF) continue;
+            const double z = ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t];
+            prob[base + e] = logistic(z + M.b2[s_gmodel[t >> 6]], C);
+        }
+        // (no barrier here: what the next stretch writes before its first barrier -- s_q, s_cnt -- was last read before the
+        // barrier above)
+        K2_STAMP(6);
+#ifdef MC_K2_TRACE
+        if (lane == 0 && blockIdx.x < 1024)
+            g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 7] = (unsigned)simd | (unsigned)quarter << 4 | (unsigned)g_first << 8 | (unsigned)g_step << 16 | (unsigned long long)n_groups << 24;
+#endif
     }
 }
 
@@ -2782,9 +2958,8 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
         mc_set_error("unsupported MLP shape: %d models, %d inputs, %d hidden", n_models, n_in, n_hidden);
         return -12;
     }
-    const size_t lds = (size_t)n_models * ((size_t)n_in * n_hidden + 2 * (size_t)n_hidden + 1) * 8;
-    if (lds > 64 * 1024) {
-        mc_set_error("MLP weights (%zu bytes) do not fit the LDS budget of k2_mlp", lds);
+    if (n_models > K2_MAXM) {
+        mc_set_error("MLP with %d sub-models: k2_mlp lists at most %d", n_models, K2_MAXM);
         return -12;
     }
     free_pool(c->mlp_allocs);
@@ -2798,6 +2973,17 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
     UP(M.b1, b1, (size_t)n_models * n_hidden, c->mlp_allocs);
     UP(M.W2, W2, (size_t)n_models * n_hidden, c->mlp_allocs);
     UP(M.b2, b2, (size_t)n_models, c->mlp_allocs);
+    // unit by unit: the n_in weights into hidden unit j, its bias, its output weight (alive until the copy has been waited for)
+    const size_t S = (size_t)n_in + 2;
+    std::vector<double> wu((size_t)n_models * n_hidden * S);
+    for (int m = 0; m < n_models; ++m)
+        for (int j = 0; j < n_hidden; ++j) {
+            double *u = &wu[((size_t)m * n_hidden + j) * S];
+            for (int i = 0; i < n_in; ++i) u[i] = W1[((size_t)m * n_in + i) * n_hidden + j];
+            u[n_in] = b1[(size_t)m * n_hidden + j];
+            u[n_in + 1] = W2[(size_t)m * n_hidden + j];
+        }
+    UP(M.wu, wu.data(), wu.size(), c->mlp_allocs);
     UP(M.sub_of_char, sub_of_char, 256, c->mlp_allocs);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -2866,13 +3052,13 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
     return 0;
 }
 
-// k2_mlp blocks: enough for n records at K2L lanes each, at most a few per CU (the kernel strides over the rest)
-static unsigned k2_grid(const mc_ctx *c, int64_t n) {       // one wave per 64 records, at most 8 blocks per CU
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 64 + 1 + K2_THREADS / 64 - 1) / (K2_THREADS / 64), (int64_t)c->n_cu * 8));
-}
-
-static size_t mlp_lds_bytes(const DevMlp &M) {
-    return (size_t)M.n_models * ((size_t)M.n_in * M.n_hidden + 2 * (size_t)M.n_hidden + 1) * 8;
+// k2_mlp workgroups: the records are divided evenly over them (the kernel does that with the count on the device); one
+// per CU, fewer for a handful of records
+#ifndef MC_K2_WG_PER_CU
+#define MC_K2_WG_PER_CU 1
+#endif
+static unsigned k2_grid(const mc_ctx *c, int64_t n) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)c->n_cu * MC_K2_WG_PER_CU));
 }
 
 // the classifier kernel: the 7-input instance (k = 6, the reference's models) or the general one
@@ -2880,10 +3066,10 @@ static void launch_k2(mc_ctx *c, unsigned grid, hipStream_t st, const double *fe
                       const int32_t *seg_read, const double *qual, const uint32_t *info, const uint8_t *submodel_in, int64_t n,
                       double *prob, const unsigned long long *n_dev, const unsigned int *overflow) {
     if (c->M.n_in == 7)
-        hipLaunchKernelGGL(k2_mlp<7>, dim3(grid), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, feats, k, site_seg, seg_read, qual,
+        hipLaunchKernelGGL(k2_mlp<7>, dim3(grid), dim3(K2_THREADS), 0, st, c->M, feats, k, site_seg, seg_read, qual,
                            info, submodel_in, n, prob, n_dev, overflow);
     else
-        hipLaunchKernelGGL(k2_mlp<0>, dim3(grid), dim3(K2_THREADS), mlp_lds_bytes(c->M), st, c->M, feats, k, site_seg, seg_read, qual,
+        hipLaunchKernelGGL(k2_mlp<0>, dim3(grid), dim3(K2_THREADS), 0, st, c->M, feats, k, site_seg, seg_read, qual,
                            info, submodel_in, n, prob, n_dev, overflow);
 }
 
@@ -3457,6 +3643,14 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
     (void)hipFree(ds);
     return 0;
 }
+
+#ifdef MC_K2_TRACE
+extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_trace), (size_t)n_words * 8));
+    return 0;
+}
+#endif
 
 extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
     return classifier_forward(c, false, X, submodel, n, p);

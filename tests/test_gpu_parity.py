@@ -157,6 +157,40 @@ def test_mlp_known_answers(dev):
             assert np.abs(p - want).max() < 1e-12, (tag, key, np.abs(p - want).max())
 
 
+@pytest.mark.parametrize('n_in,n_hidden,n_models', [(7, 100, 4), (7, 100, 1), (7, 10, 8), (7, 3, 2), (5, 37, 3), (9, 128, 2), (1, 1, 1)])
+def test_mlp_shapes_and_sizes(dev, n_in, n_hidden, n_models):
+    """K2 (one lane per record, a quarter of the hidden units per wave, lists per sub-model) against a plain numpy fp64
+    forward: every record count around the kernel's group (64) and stretch (1024) sizes, mixed sub-models, rows whose
+    sub-model is not in the model (they stay NaN, the host's KeyError path), hidden layers that do not divide by four."""
+    from mcaller_amd.model_io import MLPWeights
+    rng = np.random.default_rng(n_in * 1000 + n_hidden * 10 + n_models)
+    ws = [MLPWeights(rng.normal(0, 1.5, (n_in, n_hidden)), rng.normal(0, 1, n_hidden), rng.normal(0, 1.5, (n_hidden, 1)),
+                     rng.normal(0, 1, 1)) for _ in range(n_models)]
+    dev.set_mlp(ws, np.zeros(256, dtype=np.uint8))
+    for n in (1, 2, 63, 64, 65, 127, 129, 1023, 1024, 1025, 2049, 70001):
+        X = rng.normal(0, 2, (n, n_in))
+        X[rng.random(n) < 0.02] *= 200.0                       # saturated units, |activation| far beyond the clamp
+        if n > 3:
+            X[1] = 0.0
+        sub = rng.integers(0, n_models, n).astype(np.uint8)
+        if n > 10:
+            sub[rng.random(n) < 0.3] = 255                     # not scored
+            sub[5] = n_models                                  # a key the model does not hold
+        p = dev.mlp_forward(X, sub)
+        want = np.full(n, np.nan)
+        for m in range(n_models):
+            rows = sub == m
+            h = np.tanh(X[rows] @ ws[m].W1 + ws[m].b1)
+            z = h @ ws[m].W2.reshape(-1) + ws[m].b2[0]
+            want[rows] = 1.0 / (1.0 + np.exp(-z))
+        assert np.array_equal(np.isnan(p), np.isnan(want)), (n, int(np.isnan(p).sum()), int(np.isnan(want).sum()))
+        ok = ~np.isnan(want)
+        if ok.any():
+            assert np.abs(p[ok] - want[ok]).max() < 1e-12, (n, np.abs(p[ok] - want[ok]).max())
+    with pytest.raises(Exception):
+        dev.set_mlp(ws * 9, np.zeros(256, dtype=np.uint8))     # more sub-models than the kernel lists
+
+
 @pytest.mark.parametrize('flavour,n', [('quirk_pal', 150), ('plain', 60), ('dense', 60), ('skips', 60), ('heavy', 40),
                                        ('multi_contig', 40), ('qual', 40), ('quirk_names', 80), ('quirk_flip', 80),
                                        ('quirk_backwards', 80), ('quirk_pos0', 80), ('header', 30), ('n_context', 40)])

@@ -1,0 +1,45 @@
+"""Phase timeline of k2_mlp from the MC_K2_TRACE variant build (tools/variants.sh k2_trace "MC_K2_TRACE=1"):
+MCALLER_LIB=mcaller_amd/variants/k2_trace.so python tools/k2_trace.py [rows] [motif]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mcaller_amd import synth, _lib
+from mcaller_amd.device import Device
+from mcaller_amd.extract_contexts import submodel_setup
+from mcaller_amd.model_io import load_model_file, shipped_model
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10 ** 8
+motif = sys.argv[2] if len(sys.argv) > 2 else 'GATC'
+codes = synth.genome()
+ref = synth.SynthRef(codes, motif=motif)
+table, qual = synth.make_table(n, seed=1000, codes=codes)
+_, weights, _, soc = submodel_setup(load_model_file(shipped_model()), 'A')
+dev = Device(0)
+dev.set_reference(ref.device_arrays()); dev.upload_table(table); dev.set_read_quality(qual); dev.set_mlp(weights, soc)
+for _ in range(4):
+    dev.run(6, 0, 0.0)
+W = 16
+buf = np.zeros(1024 * W * 16, dtype=np.uint64)
+L = _lib.lib()
+L.mc_debug_k2_trace.argtypes = [C.c_void_p, C.c_int64]
+assert L.mc_debug_k2_trace(buf.ctypes.data, buf.size) == 0
+t = buf.reshape(1024, W, 16)
+used = (t[:, :, 0] > 0) & (t[:, :, 6] > 0)
+t0 = t[:, :, 0][used].min()
+names = ['entry', 'simd setup done', 'A: classified', 'lists built', 'B done', 'after barrier', 'C done']
+print('blocks with stamps:', int(used.any(axis=1).sum()), ' waves:', int(used.sum()))
+for i, nm in enumerate(names):
+    v = (t[:, :, i][used].astype(np.int64) - int(t0)) * 10      # ns
+    print('%-18s min %7d  mean %7d  p90 %7d  max %7d ns' % (nm, v.min(), v.mean(), np.percentile(v, 90), v.max()))
+info = t[:, :, 7][used]
+simd = info & 15; quarter = (info >> 4) & 15; gfirst = (info >> 8) & 255; gstep = (info >> 16) & 255; ng = info >> 24
+print('groups per block: min %d mean %.2f max %d' % (ng.min(), ng.mean(), ng.max()))
+print('g_step histogram:', np.bincount(gstep.astype(int)))
+print('quarter == simd for %.3f of the waves' % float((simd == quarter).mean()))
+b = t[0]
+dns = (t[:, :, 4][used].astype(np.int64) - t[:, :, 3][used].astype(np.int64)) * 10
+dcy = t[:, :, 12][used].astype(np.int64) - t[:, :, 11][used].astype(np.int64)
+print('clock64 ticks per ns during B: %.3f' % (dcy.sum() / dns.sum()))
+print('block 0: wave simd quarter g_first  B-time(ns)')
+for w in range(W):
+    i = int(b[w, 7])
+    print('   %2d  %d  %d  %d   %6d' % (w, i & 15, (i >> 4) & 15, (i >> 8) & 255, (int(b[w, 4]) - int(b[w, 3])) * 10))

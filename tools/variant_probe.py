@@ -35,7 +35,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--one':
     for _ in range(3): dev.wait()
     dev.sync()
     per = (time.perf_counter() - t0) / (60 - 10 + 3) * 1e3
-    print(json.dumps(dict(validate=round(val, 4), pipelined_ms=round(per, 4), records=int(n_rec), sha=h,
+    pr = np.asarray(rec.prob[:rec.n], dtype=np.float64)
+    print(json.dumps(dict(validate=round(val, 4), pipelined_ms=round(per, 4), records=int(n_rec), sha=h, prob_sum=repr(float(np.nansum(pr))),
                           **{k: round(float(np.median([t[k] for t in ts[3:]])), 4) for k in ts[0]})))
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else '1e8'
