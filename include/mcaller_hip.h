@@ -80,11 +80,16 @@ typedef struct mc_calls_view {
                             the closing row lies beyond this table (see tail_contig)             :216 */
     uint32_t *info;      /* MC_I_* */
     double  *prob;       /* p(m6A) from the MLP/forest; NaN where not scored                     :199 */
-    /* NULL: feats and prob hold one row per record (row j = record j).  Otherwise (mc_wait_records): they hold
-     * n_call_rows rows, one per record WITHOUT MC_I_TOO_MANY, in record order, and call_row[j] is the row of record j
-     * (-1 for a MC_I_TOO_MANY record: the reference only counts those, :239, nothing is stored for them). */
+    /* compacted == 0: feats and prob hold one row per record (row j = record j).  compacted != 0 (mc_wait_records): they
+     * hold n_call_rows rows, one per record WITHOUT MC_I_TOO_MANY, in record order (the reference only counts the others,
+     * :239, nothing is stored for them): the row of record j is the number of records before j without MC_I_TOO_MANY.
+     * call_row, if not NULL, holds that number for every record (-1 for a MC_I_TOO_MANY record); mc_wait_records leaves it
+     * NULL -- the copy-out over PCIe bounds a pass, a column the host can derive is not sent (mc_calls_expand fills one). */
     int32_t *call_row;
     int64_t n_call_rows;
+    /* mc_wait_records on a table of fewer than 2^31 - 1 rows: close_row is NULL and the closing rows are here. */
+    int32_t *close_row32;
+    int32_t compacted;
 } mc_calls_view;
 
 const char *mc_last_error(void);
@@ -301,6 +306,9 @@ typedef struct mc_format_args {
  * contig, NaN probability, unknown sub-model key or complement, centre not 'M': the reference's exit/crash paths). */
 int mc_format_diffs(const mc_format_args *args, int64_t first, int32_t n_threads, char **text, int64_t *n_bytes,
                     int64_t *n_rows, int64_t *stop_at);
+/* The columns mc_wait_records does not send, rebuilt on the host (all cores): call_row_out[n] (see mc_calls_view.call_row)
+ * and / or close_row_out[n] (64-bit closing rows); either may be NULL. */
+int mc_calls_expand(const mc_calls_view *rec, int64_t n_records, int32_t *call_row_out, int64_t *close_row_out);
 void mc_free(void *p);
 /* repr(float) == str(np.float64) of one value into out32 (NUL-terminated); returns its length. */
 int mc_repr_double(double v, char *out32);

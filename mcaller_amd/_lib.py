@@ -40,7 +40,7 @@ class CallsView(C.Structure):
     _fields_ = [('capacity', C.c_int64),
                 ('feats', C.c_void_p), ('site_pos', C.c_void_p), ('site_seg', C.c_void_p),
                 ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p),
-                ('call_row', C.c_void_p), ('n_call_rows', C.c_int64)]
+                ('call_row', C.c_void_p), ('n_call_rows', C.c_int64), ('close_row32', C.c_void_p), ('compacted', C.c_int32)]
 
 
 class FormatArgs(C.Structure):
@@ -141,6 +141,7 @@ def lib():
         L.mc_comm_destroy.argtypes = [C.c_void_p]
         L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.mc_mlp_fit.argtypes = [C.c_void_p, C.POINTER(FitParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 13
+        L.mc_calls_expand.argtypes = [C.POINTER(CallsView), C.c_int64, C.c_void_p, C.c_void_p]
         L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_free.argtypes = [C.c_void_p]
@@ -405,9 +406,15 @@ class Records(object):
         v = CallsView()
         v.capacity = self.capacity
         v.feats, v.site_pos, v.site_seg = _ptr(self.feats), _ptr(self.site_pos), _ptr(self.site_seg)
-        v.close_row, v.info, v.prob = _ptr(self.close_row), _ptr(self.info), _ptr(self.prob)
-        if self.call_row is not None:
-            v.call_row, v.n_call_rows = _ptr(self.call_row), int(self.n_calls)
+        v.info, v.prob = _ptr(self.info), _ptr(self.prob)
+        if self._close_row is not None or self._close_row32 is None:
+            v.close_row = _ptr(self.close_row)
+        else:
+            v.close_row32 = _ptr(self._close_row32)
+        if self._compacted:
+            v.compacted, v.n_call_rows = 1, int(self._n_calls)
+            if self._call_row is not None:
+                v.call_row = _ptr(self._call_row)
         return v
 
     @classmethod
@@ -418,11 +425,16 @@ class Records(object):
         r.feats = _from_ptr(v.feats, n * k, np.float64)
         r.site_pos = _from_ptr(v.site_pos, n, np.int32)
         r.site_seg = _from_ptr(v.site_seg, n, np.int32)
-        r.close_row = _from_ptr(v.close_row, n, np.int64)
+        if v.close_row:
+            r._close_row = _from_ptr(v.close_row, n, np.int64)
+        else:                                # mc_wait_records on tables below 2^31 - 1 rows: 32-bit closing rows
+            r._close_row32 = _from_ptr(v.close_row32, n, np.int32)
         r.info = _from_ptr(v.info, n, np.uint32)
-        if v.call_row:                       # mc_wait_records: means / probabilities of the calls only, compacted
+        if v.compacted:                      # mc_wait_records: means / probabilities of the calls only, compacted
             m = int(v.n_call_rows)
-            r.call_row = _from_ptr(v.call_row, n, np.int32)
+            r._compacted = True
+            if v.call_row:
+                r._call_row = _from_ptr(v.call_row, n, np.int32)
             r._n_calls = m
             r.feats = _from_ptr(v.feats, m * k, np.float64)
             r.prob = _from_ptr(v.prob, m, np.float64)
@@ -430,12 +442,39 @@ class Records(object):
             r.prob = _from_ptr(v.prob, n, np.float64)
         return r
 
-    call_row = None                          # None: feats / prob have one row per record
+    # closing rows and call rows: columns mc_wait_records does not send in full (mc_calls_view) are rebuilt on first use
+    _close_row = _close_row32 = _call_row = None
+    _compacted = False
+
+    @property
+    def close_row(self):
+        if self._close_row is None and self._close_row32 is not None:
+            self._close_row = self._close_row32.astype(np.int64)
+        return self._close_row
+
+    @close_row.setter
+    def close_row(self, a):
+        self._close_row = a
+
+    @property
+    def call_row(self):
+        """None: feats / prob have one row per record.  Else the row of every record in feats / prob (-1: MC_I_TOO_MANY)."""
+        if self._call_row is None and self._compacted:
+            keep = (self.info[:self.n] & I_TOO_MANY) == 0
+            rows = np.cumsum(keep, dtype=np.int64) - 1
+            rows[~keep] = -1
+            self._call_row = rows.astype(np.int32)
+        return self._call_row
+
+    @call_row.setter
+    def call_row(self, a):
+        self._call_row = a
+        self._compacted = a is not None
 
     @property
     def n_calls(self):
         """Rows of feats / prob."""
-        return self._n_calls if self.call_row is not None else self.n
+        return self._n_calls if self._compacted else self.n
 
     def by_record(self):
         """A copy with one feats / prob row per record (zeros / NaN for the MC_I_TOO_MANY records of a compacted view)."""

@@ -2241,15 +2241,27 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 // next pass that ENDS while it runs waits for it: the end-of-kernel cache write-back queues behind its PCIe writes --
 // measured with rocprofv3, see DESIGN.md.  DMA copies do not go through the shader caches.)
 // ---------------------------------------------------------------------------------------------------
-// What a pipelined pass hands to the DMA engine is ONE block: five narrow columns of all n flush records (closing row,
-// site, segment, info, call_row) and, behind them, the slot means and the probability of the records that are calls --
-// compacted: a record with MC_I_TOO_MANY is only counted by the host (:239), nothing reads its means, and at 6 % skips it
-// is every third record; call_row[j] is the row of record j in the compacted part (-1: none).  The copy-out is what bounds
-// a pass (PCIe, 52 GB/s), so bytes dropped here are time.  Two small kernels: per-chunk counts of kept records, then every
+// What a pipelined pass hands to the DMA engine is ONE block: four narrow columns of all n flush records (closing row --
+// 32 bits wide for tables below 2^31 - 1 rows --, site, segment, info) and, behind them, the slot means and the probability
+// of the records that are calls -- compacted: a record with MC_I_TOO_MANY is only counted by the host (:239), nothing reads
+// its means, and at 6 % skips it is every third record.  The row of record j in the compacted part is the number of
+// records before it without MC_I_TOO_MANY: the host derives it where it needs it (mc_calls_view) -- the copy-out is what
+// bounds a pass (PCIe, 55 GB/s), so bytes dropped here are time (16 instead of 24 narrow bytes per record: 12.8 -> 11.2 MB
+// per pass of the headline workload).  Two small kernels: per-chunk counts of kept records, then every
 // workgroup sums the counts before its chunk and packs the chunk.  The pass's counters go to pinned host memory from here
 // as well (a 96-byte store over PCIe): the host reads them after hipEventSynchronize(ev_done) and enqueues the transfer
 // at once, without a read-back on the copy stream in between.
 constexpr int PACK_WGS = 256, PACK_THREADS = 256;
+
+struct PackLayout { size_t pos, seg, info, feats; };       // byte offsets in the block (the closing rows come first)
+__host__ __device__ inline PackLayout pack_layout(int64_t n, int close32) {
+    PackLayout L;
+    L.pos = (size_t)n * (close32 ? 4 : 8);
+    L.seg = L.pos + (size_t)n * 4;
+    L.info = L.seg + (size_t)n * 4;
+    L.feats = (L.info + (size_t)n * 4 + 7) & ~(size_t)7;
+    return L;
+}
 
 __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt,
                                                              unsigned long long *__restrict__ chunk_cnt) {
@@ -2271,7 +2283,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const
 
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ chunk_cnt,
-                                                       unsigned char *__restrict__ out, int k, Counters *__restrict__ host_status) {
+                                                       unsigned char *__restrict__ out, int k, int close32,
+                                                       Counters *__restrict__ host_status) {
     static_assert(PACK_WGS == PACK_THREADS, "one chunk count per thread");
     __shared__ unsigned long long s_sum[2][PACK_THREADS / 64];
     __shared__ unsigned int s_wave[PACK_THREADS / 64];
@@ -2294,12 +2307,13 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     const int64_t n = min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    const PackLayout L = pack_layout(n, close32);
     int64_t *o_close = reinterpret_cast<int64_t *>(out);
-    int32_t *o_pos = reinterpret_cast<int32_t *>(out + 8 * n);
-    int32_t *o_seg = reinterpret_cast<int32_t *>(out + 12 * n);
-    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + 16 * n);
-    int32_t *o_row = reinterpret_cast<int32_t *>(out + 20 * n);
-    double *o_feats = reinterpret_cast<double *>(out + 24 * n);
+    int32_t *o_close32 = reinterpret_cast<int32_t *>(out);
+    int32_t *o_pos = reinterpret_cast<int32_t *>(out + L.pos);
+    int32_t *o_seg = reinterpret_cast<int32_t *>(out + L.seg);
+    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + L.info);
+    double *o_feats = reinterpret_cast<double *>(out + L.feats);
     double *o_prob = o_feats + (int64_t)total * k;
     for (int64_t s = lo; s < hi; s += PACK_THREADS) {
         const int64_t i = s + tid;
@@ -2313,11 +2327,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
         for (int w = 0; w < PACK_THREADS / 64; ++w) { if (w < wave) in_strip += s_wave[w]; strip += s_wave[w]; }
         s_row[tid] = keep ? (int)in_strip : -1;
         if (valid) {
-            o_close[i] = O.close_row[i];
+            if (close32) o_close32[i] = (int32_t)O.close_row[i];
+            else o_close[i] = O.close_row[i];
             o_pos[i] = O.site_pos[i];
             o_seg[i] = O.site_seg[i];
             o_info[i] = info;
-            o_row[i] = keep ? (int32_t)(base + in_strip) : -1;
             if (keep) o_prob[base + in_strip] = O.prob[i];
         }
         __syncthreads();
@@ -2448,7 +2462,8 @@ struct mc_ctx {
         Counters *st_dev = nullptr;
         unsigned char *pack = nullptr, *pack_host = nullptr;   // what is copied out, packed by k_pack (device staging, pinned host)
         unsigned long long *chunk_cnt = nullptr;               // k_pack_count -> k_pack
-        int32_t *h_call_row = nullptr;                         // in pack_host: row of record j in the compacted means / probabilities
+        int32_t *h_close32 = nullptr;                          // in pack_host: 32-bit closing rows (tables below 2^31 - 1 rows), else H.close_row
+        bool close32 = false;
         int64_t h_n_calls = 0;
         // stage boundaries: dependencies between the streams, and the kernel times
         hipEvent_t ev_k0_start = nullptr, ev_k0_end = nullptr, ev_scan_start = nullptr, ev_scan_end = nullptr,
@@ -3324,6 +3339,8 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
     out->prob = c->H.prob;
     out->call_row = nullptr;          // means and probabilities are stored for every record here
     out->n_call_rows = 0;
+    out->close_row32 = nullptr;
+    out->compacted = 0;
     return 0;
 }
 
@@ -3372,11 +3389,11 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
         dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1))
         return -10;
     if (cap >= (int64_t)1 << 31) {
-        mc_set_error("mc_extract_features_async: %lld flush records per pass (call_row is 32 bits wide); use mc_extract_features",
+        mc_set_error("mc_extract_features_async: %lld flush records per pass (call rows are 32 bits wide); use mc_extract_features",
                      (long long)cap);
         return -12;
     }
-    const size_t pack_bytes = (size_t)cap * (24 + ((size_t)k + 1) * 8) + 64;
+    const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8) + 64;
     if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_WGS)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
@@ -3411,7 +3428,7 @@ static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
     hipStream_t s2 = c->side_stream;
     hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.chunk_cnt);
     hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt,
-                       (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.st_dev);
+                       (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
     HIP_TRY(hipEventRecord(b.ev_done, s2));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -3472,6 +3489,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
     HIP_TRY(hipEventRecord(b.ev_emit_end, st));
     if (int rc = enqueue_k2(c, b)) return rc;
+    b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b)) return rc;
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
     // copy-out of the previous pass, which mc_wait_records enqueues later)
@@ -3519,13 +3537,14 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         const int k = b.k;
         hipStream_t cs = c->copy_stream;
         const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
-        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, n * 24 + m * ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, cs));
-        b.H.close_row = reinterpret_cast<int64_t *>(b.pack_host);
-        b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + 8 * n);
-        b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + 12 * n);
-        b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + 16 * n);
-        b.h_call_row = reinterpret_cast<int32_t *>(b.pack_host + 20 * n);
-        b.H.feats = reinterpret_cast<double *>(b.pack_host + 24 * n);
+        const PackLayout L = pack_layout((int64_t)n, b.close32 ? 1 : 0);
+        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, L.feats + m * ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, cs));
+        b.H.close_row = b.close32 ? nullptr : reinterpret_cast<int64_t *>(b.pack_host);
+        b.h_close32 = b.close32 ? reinterpret_cast<int32_t *>(b.pack_host) : nullptr;
+        b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + L.pos);
+        b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + L.seg);
+        b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + L.info);
+        b.H.feats = reinterpret_cast<double *>(b.pack_host + L.feats);
         b.H.prob = b.H.feats + m * (size_t)k;
         b.h_n_calls = (int64_t)m;
         HIP_TRY(hipEventRecord(b.ev_copied, cs));
@@ -3594,7 +3613,9 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->capacity = n;
     out->feats = b.H.feats; out->site_pos = b.H.site_pos; out->site_seg = b.H.site_seg;
     out->close_row = b.H.close_row; out->info = b.H.info; out->prob = b.H.prob;
-    out->call_row = n > 0 && b.used ? b.h_call_row : nullptr;
+    out->close_row32 = b.h_close32;
+    out->call_row = nullptr;       // (not sent: the row of record j is the number of records before it without MC_I_TOO_MANY)
+    out->compacted = 1;
     out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
     return 0;
 }

@@ -141,10 +141,36 @@ inline bool build_context(const mc_format_args *a, int64_t j, char *ctx) {
     return true;
 }
 
-inline bool native_ok(const mc_format_args *a, int64_t j) {
+inline int64_t close_row_of(const mc_calls_view *rec, int64_t j) {
+    return rec->close_row ? rec->close_row[j] : (int64_t)rec->close_row32[j];
+}
+
+// records [lo, hi) without MC_I_TOO_MANY
+int64_t kept_in(const mc_calls_view *rec, int64_t lo, int64_t hi) {
+    int64_t kept = 0;
+    for (int64_t j = lo; j < hi; ++j) kept += (rec->info[j] & MC_I_TOO_MANY) ? 0 : 1;
+    return kept;
+}
+
+// Row of feats / prob that belongs to record j, for a walk over consecutive records: compacted views without a call_row
+// column count the records without MC_I_TOO_MANY as they go (mc_calls_view)
+struct RowCursor {
+    const mc_calls_view *rec;
+    int64_t kept;           // records without MC_I_TOO_MANY before the current one (compacted views without call_row)
+    RowCursor(const mc_calls_view *r, int64_t first) : rec(r), kept(r->compacted && !r->call_row ? kept_in(r, 0, first) : 0) {}
+    // (call for every record in order; info = rec->info[j])
+    int64_t row(int64_t j, uint32_t info) {
+        if (!rec->compacted) return j;
+        if (rec->call_row) return rec->call_row[j];
+        return (info & MC_I_TOO_MANY) ? -1 : kept++;
+    }
+};
+
+inline bool native_ok(const mc_format_args *a, int64_t j, RowCursor &cur) {
     const uint32_t info = a->rec->info[j];
+    const int64_t row = cur.row(j, info);
     if (info & MC_I_TOO_MANY) return true;               // no text
-    if (std::isnan(a->rec->prob[a->rec->call_row ? a->rec->call_row[j] : j])) return false;
+    if (std::isnan(a->rec->prob[row])) return false;
     char ctx[2 * MC_MAX_K];
     return build_context(a, j, ctx);
 }
@@ -157,12 +183,14 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
     std::vector<char> buf(1 << 16);
     size_t used = 0;
     n_rows = 0;
+    RowCursor cur(rec, j0);
     for (int64_t j = j0; j < j1; ++j) {
         const uint32_t info = rec->info[j];
+        const int64_t row = cur.row(j, info);                                      // (compacted views: mc_wait_records)
         if (info & MC_I_TOO_MANY) continue;
         const int32_t seg = rec->site_seg[j];
         const int32_t rid = t->seg_read[seg];
-        const int32_t cseg = seg_of_row(t, rec->close_row[j]);
+        const int32_t cseg = seg_of_row(t, close_row_of(rec, j));
         const char *chrom;
         size_t chrom_len;
         if (cseg >= t->n_seg) { chrom = a->tail_chrom; chrom_len = J.tail_len; }     // R8: the closing row's contig
@@ -181,7 +209,6 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         o += 2 * k - 1;
         *o++ = '\t';
         const uint32_t empty = info & MC_I_EMPTY_MASK;
-        const int64_t row = rec->call_row ? rec->call_row[j] : j;                  // (compacted views: mc_wait_records)
         const double *f = rec->feats + row * k;
         for (int i = 0; i < k; ++i) {
             if ((empty >> i) & 1u) *o++ = '0';                                     // literal int 0  (:186)
@@ -222,8 +249,9 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     std::vector<int64_t> stops((size_t)nt, n);
     auto scan = [&](int w) {
         const int64_t lo = first + (n - first) * w / nt, hi = first + (n - first) * (w + 1) / nt;
+        RowCursor cur(a->rec, lo);
         for (int64_t j = lo; j < hi; ++j)
-            if (!native_ok(a, j)) { stops[(size_t)w] = j; return; }
+            if (!native_ok(a, j, cur)) { stops[(size_t)w] = j; return; }
     };
     mc_parallel_for(nt, scan);
     int64_t stop = n;
@@ -267,6 +295,34 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     }
     *text = outp;
     *n_bytes = (int64_t)total;
+    return 0;
+}
+
+extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t *call_row_out, int64_t *close_row_out) {
+    if (!rec || n < 0 || (n > 0 && !rec->info) || (close_row_out && n > 0 && !rec->close_row && !rec->close_row32)) {
+        mc_set_error("mc_calls_expand: bad arguments");
+        return -12;
+    }
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(mc_host_cores(), n / 16384));
+    std::vector<int64_t> kept((size_t)nt + 1, 0);
+    auto piece = [&](int w, int64_t &lo, int64_t &hi) { lo = n * w / nt; hi = n * (w + 1) / nt; };
+    if (call_row_out && rec->compacted && !rec->call_row)
+        mc_parallel_for(nt, [&](int w) { int64_t lo, hi; piece(w, lo, hi); kept[(size_t)w + 1] = kept_in(rec, lo, hi); });
+    for (int w = 0; w < nt; ++w) kept[(size_t)w + 1] += kept[(size_t)w];
+    mc_parallel_for(nt, [&](int w) {
+        int64_t lo, hi;
+        piece(w, lo, hi);
+        if (close_row_out)
+            for (int64_t j = lo; j < hi; ++j) close_row_out[j] = close_row_of(rec, j);
+        if (call_row_out) {
+            int64_t row = kept[(size_t)w];
+            for (int64_t j = lo; j < hi; ++j) {
+                if (!rec->compacted) call_row_out[j] = (int32_t)j;
+                else if (rec->call_row) call_row_out[j] = rec->call_row[j];
+                else call_row_out[j] = (rec->info[j] & MC_I_TOO_MANY) ? -1 : (int32_t)row++;
+            }
+        }
+    });
     return 0;
 }
 

@@ -3,6 +3,7 @@ oracle standing in for the GPU as the producer of flush records.  This pins (a) 
 outputs and (b) every host-side piece the HIP path shares: parser, bitmasks, context slicing, number formatting,
 counters, exit paths.  No GPU needed."""
 import contextlib
+import ctypes as C
 import io
 import os
 
@@ -168,8 +169,9 @@ def test_native_formatter_equals_per_record_path(td, tmp_path):
         assert mixed.text() == literal.text() and mixed.counters() == literal.counters()
 
 
-def _compacted(rec, k):
-    """The records as a pipelined pass hands them out (mc_wait_records): slot means / probabilities of the calls only."""
+def _compacted(rec, k, as_sent=False):
+    """The records as a pipelined pass hands them out (mc_wait_records): slot means / probabilities of the calls only.
+    as_sent: without the call_row column and with 32-bit closing rows, the way they cross PCIe."""
     from mcaller_amd import _lib
     n = rec.n
     kept = (rec.info[:n] & _lib.I_TOO_MANY) == 0
@@ -177,7 +179,11 @@ def _compacted(rec, k):
     c.k, c.capacity, c.n = k, n, n
     for name in ('site_pos', 'site_seg', 'close_row', 'info'):
         setattr(c, name, getattr(rec, name)[:n].copy())
-    c.call_row = np.where(kept, np.cumsum(kept) - 1, -1).astype(np.int32)
+    if as_sent:
+        c._close_row32, c._close_row = rec.close_row[:n].astype(np.int32), None
+        c._compacted = True
+    else:
+        c.call_row = np.where(kept, np.cumsum(kept) - 1, -1).astype(np.int32)
     c._n_calls = int(kept.sum())
     c.feats = np.ascontiguousarray(rec.feats[:n * k].reshape(n, k)[kept]).reshape(-1)
     c.prob = np.ascontiguousarray(rec.prob[:n][kept])
@@ -195,9 +201,10 @@ def test_rows_from_a_compacted_view(td, tmp_path):
     _, weights, _, soc = ec.submodel_setup(modelset, 'A')
     H.oracle_score(rec, P.table, P.qual, weights, soc, 6)
     comp = _compacted(rec, 6)
-    assert 0 < comp.n_calls < comp.n
+    sent = _compacted(rec, 6, as_sent=True)
+    assert 0 < comp.n_calls < comp.n and sent.n_calls == comp.n_calls
     outs = []
-    for r in (rec, comp):
+    for r in (rec, comp, sent):
         native = ec.Finisher(P, 6, 'A', False, modelset=modelset)
         with contextlib.redirect_stdout(io.StringIO()):
             assert native.run(r) is None
@@ -207,7 +214,15 @@ def test_rows_from_a_compacted_view(td, tmp_path):
             assert literal._one(j) is None
         assert native.text() == literal.text()
         outs.append((native.text(), native.counters()))
-    assert outs[0] == outs[1] and len(outs[0][0]) > 10000
-    back = comp.by_record()
-    assert np.array_equal(back.feats[:rec.n * 6], rec.feats[:rec.n * 6])
-    assert np.array_equal(back.prob[:rec.n], rec.prob[:rec.n], equal_nan=True)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0][0]) > 10000
+    for c in (comp, sent):
+        back = c.by_record()
+        assert np.array_equal(back.feats[:rec.n * 6], rec.feats[:rec.n * 6])
+        assert np.array_equal(back.prob[:rec.n], rec.prob[:rec.n], equal_nan=True)
+        assert np.array_equal(back.close_row[:rec.n], rec.close_row[:rec.n])
+    # the library's own expansion of the columns that are not sent (all cores)
+    from mcaller_amd import _lib
+    rows, close = np.empty(rec.n, dtype=np.int32), np.empty(rec.n, dtype=np.int64)
+    v = sent.view()
+    _lib.check(_lib.lib().mc_calls_expand(C.byref(v), rec.n, rows.ctypes.data, close.ctypes.data))
+    assert np.array_equal(rows, comp.call_row[:rec.n]) and np.array_equal(close, rec.close_row[:rec.n])
