@@ -166,6 +166,11 @@ struct Counters {          // device-side status block
     unsigned long long end_of_head;   // (k_pack copies everything before this field to the host)
 };
 
+// The small kernels on the ctx stream's critical path (strand resolve, tile descriptors, the ordering of the payloads) run
+// beside the previous pass's classifier, whose waves keep the vector pipes busy: with the default wave priority the
+// arbiter serves the older (classifier) waves first and these latency-bound kernels take twice as long.
+#define MC_FRONT_OF_THE_QUEUE __builtin_amdgcn_s_setprio(3)
+
 // ---------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------
@@ -464,6 +469,7 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
 __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, Counters *__restrict__ cnt, int classify,
                               int skip_thresh, unsigned long long pass_no) {
+    MC_FRONT_OF_THE_QUEUE;
     if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
         unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
         for (unsigned i = threadIdx.x; i < offsetof(Counters, irregular_pass) / 4; i += blockDim.x) w[i] = 0u;
@@ -654,6 +660,7 @@ struct K1Args {
 
 // One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
 __global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
+    MC_FRONT_OF_THE_QUEUE;
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= T.n_tiles) return;
     const int64_t t0 = t * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
@@ -1084,6 +1091,7 @@ constexpr int GROUP = 1024;
 
 __global__ __launch_bounds__(GROUP) void k1_group_scan(const int32_t *__restrict__ tile_cnt, int64_t n_tiles,
                                                        int32_t *__restrict__ tile_local, int64_t *__restrict__ group_sum) {
+    MC_FRONT_OF_THE_QUEUE;
     __shared__ int s_w[GROUP / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x * (int64_t)GROUP + tid;
@@ -1211,6 +1219,7 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
 // with unit stride.  The first record slot of the tile = the windows of all earlier groups of 1024 tiles (summed by the
 // eight lanes) + the tile's offset inside its group.
 __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ sorted) {
+    MC_FRONT_OF_THE_QUEUE;
     const DevTable &T = A.T;
     constexpr int LG = 8;
     const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LG;
@@ -2433,6 +2442,7 @@ struct mc_ctx {
     DevRecords H;            // pinned host copy of the last call's records (mc_fetch_records_view)
     int h_k = 0;
     hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream2 = nullptr;     // pipelined passes alternate between the two: no turnaround gap between transfers
     std::vector<void *> lit_allocs;
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
@@ -2462,6 +2472,8 @@ struct mc_ctx {
         Counters *st_dev = nullptr;
         unsigned char *pack = nullptr, *pack_host = nullptr;   // what is copied out, packed by k_pack (device staging, pinned host)
         unsigned long long *chunk_cnt = nullptr;               // k_pack_count -> k_pack
+        Payload *sorted = nullptr;                             // the pass's payloads in record order (k1_list -> k1_emit, k1_rare_dev)
+        int64_t *rare = nullptr;                               // records k1_emit leaves to k1_rare_dev
         int32_t *h_close32 = nullptr;                          // in pack_host: 32-bit closing rows (tables below 2^31 - 1 rows), else H.close_row
         bool close32 = false;
         int64_t h_n_calls = 0;
@@ -2612,6 +2624,7 @@ extern "C" int mc_ctx_create(int device, mc_ctx **out) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     {
         hipDeviceProp_t prop;
@@ -2657,6 +2670,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
     free_pinned(c->H);
     (void)hipStreamDestroy(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream2);
     (void)hipStreamDestroy(c->up_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -3173,13 +3187,13 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
-                      hipEvent_t ev_scan_end, K1Args *out_args) {
+                      hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tiles = K.tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
-    A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = c->rare_list;
+    A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     const bool dense = dense_reference(c);
     A.chunk_shift = dense ? 8 : 6;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
@@ -3188,9 +3202,9 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, c->payload_sorted);
+    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted);
     hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
-                       st, A, (const Payload *)c->payload_sorted);
+                       st, A, (const Payload *)sorted);
     *out_args = A;
     return 0;
 }
@@ -3202,7 +3216,7 @@ static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &
     HIP_TRY(hipEventRecord(ev[0], c->stream));
     if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream, c->sync_pass_no, true)) return rc;
     HIP_TRY(hipEventRecord(ev[1], c->stream));
-    if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args)) return rc;
+    if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args, c->payload_sorted, c->rare_list)) return rc;
     HIP_TRY(hipEventRecord(ev[3], c->stream));
     return 0;
 }
@@ -3395,6 +3409,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     }
     const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8) + 64;
     if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_WGS)) return -10;
+    if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
     b.H.capacity = cap;
@@ -3411,10 +3426,13 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
 }
 
 // Classifier of a pass whose emit has been enqueued (ev_emit_end recorded), on the side stream.
-static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b) {
+// In front of it the windows the emit left to the row-by-row kernel (longer than 64 rows; usually none): the pass has its
+// own sorted payloads and list, so this need not hold up the next pass's strand resolve on the ctx stream.
+static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     const DevTable &T = c->T;
     hipStream_t st = c->side_stream;
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
+    hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
     HIP_TRY(hipEventRecord(b.ev_k2_start, st));
     if (b.prm.score)
         launch_k2(c, k2_grid(c, b.cap), st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr,
@@ -3485,10 +3503,9 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A)) return rc;
-    hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)c->payload_sorted, (const int64_t *)c->rare_list);
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare)) return rc;
     HIP_TRY(hipEventRecord(b.ev_emit_end, st));
-    if (int rc = enqueue_k2(c, b)) return rc;
+    if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b)) return rc;
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
@@ -3509,6 +3526,7 @@ static int sync_pass_streams(mc_ctx *c) {
     if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream2));
     return 0;
 }
 
@@ -3526,16 +3544,19 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
     while (left > 0 && c->ab[at].copying) { at = (at + 1) % MC_PASSES_IN_FLIGHT; --left; }
     if (left == 0) return 0;
     mc_ctx::AsyncBuf &b = c->ab[at];
+    // (two copy streams, taken in turn: a transfer that is enqueued while the previous one runs starts beside its tail; on
+    // one stream 15-20 us pass between the end of one transfer and the start of the next -- rocprofv3 timeline -- which is
+    // 8 % of a pass that the copy-out bounds)
+    hipStream_t cs = (at & 1) ? c->copy_stream2 : c->copy_stream;
     if (b.used) {                                                // the counters (k_pack stored them in st_host), then exactly
         HIP_TRY(hipEventSynchronize(b.ev_done));                 // n records with the DMA engines
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.ev_done, 0));
+        HIP_TRY(hipStreamWaitEvent(cs, b.ev_done, 0));
     }
     const Counters &st = *b.st_host;
     const bool special = st.overflow || st.irregular_pass == b.pass_no;      // (long windows were finished on the device: k1_rare_dev)
     if (b.used && !special && st.n_records > 0) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)st.n_records, b.cap);
         const int k = b.k;
-        hipStream_t cs = c->copy_stream;
         const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
         const PackLayout L = pack_layout((int64_t)n, b.close32 ? 1 : 0);
         HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, L.feats + m * ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, cs));
