@@ -286,6 +286,39 @@ int mc_mlp_fit(mc_ctx *ctx, const mc_fit_params *prm, const double *X, const uin
                double *W1, double *b1, double *W2, double *b2,      /* per job: [n_in*n_hidden], [n_hidden], [n_hidden], [1] */
                double *loss_curve /* [n_jobs*max_iter] */, int32_t *n_iter /* epochs run */, int64_t *val_correct);
 
+/* ===== the eventalign text parsed on the GPU (replaces the row ingest, extract_contexts.py:140-152, for streamed shards) =====
+ * The host only moves bytes: mc_read_file_range preads a byte range into (pinned) memory with all cores;
+ * mc_ctx_parse_begin sends it and enqueues the kernels that split it into lines, tokenise (str.split()'s ASCII whitespace,
+ * first 12 tokens), convert (int(); floats in plain decimal form as units of 1e-4) and write the columns of a free table
+ * slot; mc_ctx_parse_end waits and hands out what the host needs for names: segments (first row, contig id, where the read
+ * name stands in the text, whether it starts a name block), the contig tokens the reference does not hold (file order) and
+ * the flag column; mc_ctx_parse_finish takes read ids and qualities: the slot is now what mc_ctx_upload_table_async would
+ * have left (current table).  status 1: the shard holds something this path does not reproduce bit for bit (a number form
+ * that needs strtod, a value out of range, more rows or segments than the slot holds; mc_last_error says which) -- call
+ * mc_ctx_parse_abandon and parse it with mc_parse_eventalign_range.  begin for the next shard may be called before end. */
+typedef struct mc_devparse_result {
+    int32_t status;
+    int64_t n_lines, n_rows;
+    int32_t n_seg, n_unknown;
+    const int64_t *seg_row_begin;     /* [n_seg] ascending                                              */
+    const int32_t *seg_contig;        /* [n_seg]                                                        */
+    const int64_t *seg_name_off;      /* [n_seg] offset of the segment's read name in the text          */
+    const int32_t *seg_name_len;
+    const uint8_t *seg_name_start;    /* [n_seg] 1: first segment of a name block (MC_F_NAME_START)     */
+    const int64_t *unknown_off;       /* [n_unknown] contig tokens of skipped lines (:156-160)          */
+    const int32_t *unknown_len;
+    const uint8_t *flags;             /* [n_rows] host copy of the flag column (pinned, owned by ctx)   */
+} mc_devparse_result;
+int mc_read_file_range(const char *path, int64_t byte_begin, int64_t byte_end, char *dst, int32_t n_threads);
+int mc_ctx_parse_begin(mc_ctx *ctx, const char *text, int64_t n_bytes, const char *const *contig_names, int32_t n_contigs,
+                       int64_t max_rows, int32_t *slot);
+int mc_ctx_parse_end(mc_ctx *ctx, int32_t slot, mc_devparse_result *out);
+int mc_ctx_parse_finish(mc_ctx *ctx, int32_t slot, const int32_t *seg_read, int32_t n_reads, const double *read_qual);
+int mc_ctx_parse_abandon(mc_ctx *ctx, int32_t slot);
+/* The columns of the table in `slot` copied back to the host (any may be NULL) -- what the parity tests compare. */
+int mc_ctx_fetch_columns(mc_ctx *ctx, int32_t slot, int64_t n_rows, int32_t *pos, int32_t *event_model_e4, int32_t *event_idx,
+                         uint8_t *flags);
+
 /* ===== native `.diffs.<k>` row formatter (host), replaces the text assembly of the flush, extract_contexts.py:186-216 ===== */
 typedef struct mc_format_args {
     const mc_calls_view *rec;          /* flush records in host memory (mc_fetch_records / _view)                  */

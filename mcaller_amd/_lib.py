@@ -36,6 +36,13 @@ class RefView(C.Structure):
                 ('n_seq_bytes', C.c_int64), ('n_words', C.c_int64)]
 
 
+class DevParseResult(C.Structure):
+    """mc_devparse_result (include/mcaller_hip.h)."""
+    _fields_ = [('status', C.c_int32), ('n_lines', C.c_int64), ('n_rows', C.c_int64), ('n_seg', C.c_int32), ('n_unknown', C.c_int32),
+                ('seg_row_begin', C.c_void_p), ('seg_contig', C.c_void_p), ('seg_name_off', C.c_void_p), ('seg_name_len', C.c_void_p),
+                ('seg_name_start', C.c_void_p), ('unknown_off', C.c_void_p), ('unknown_len', C.c_void_p), ('flags', C.c_void_p)]
+
+
 class CallsView(C.Structure):
     _fields_ = [('capacity', C.c_int64),
                 ('feats', C.c_void_p), ('site_pos', C.c_void_p), ('site_seg', C.c_void_p),
@@ -106,6 +113,13 @@ def lib():
         L.mc_host_is_pinned.argtypes = [C.c_void_p]
         L.mc_host_pool_config.argtypes = [C.c_int32, C.c_int64]
         L.mc_ctx_reserve_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]
+        L.mc_read_file_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
+        L.mc_ctx_parse_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int64,
+                                         C.POINTER(C.c_int32)]
+        L.mc_ctx_parse_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(DevParseResult)]
+        L.mc_ctx_parse_finish.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        L.mc_ctx_parse_abandon.argtypes = [C.c_void_p, C.c_int32]
+        L.mc_ctx_fetch_columns.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mc_ctx_upload_table_async.argtypes = [C.c_void_p, C.POINTER(TableView), C.c_void_p, C.POINTER(C.c_int32)]
         L.mc_ctx_wait_upload.argtypes = [C.c_void_p, C.c_int32]
         L.mc_ctx_current_slot.argtypes = [C.c_void_p]
@@ -237,8 +251,10 @@ class Table(object):
     def view(self):
         v = TableView()
         v.n_rows = self.n_rows
-        v.pos, v.event_model_e4 = _ptr(self.pos), _ptr(self.evmu)
-        v.event_idx, v.flags = _ptr(self.event_idx), _ptr(self.flags)
+        if self.pos is not None:                       # (a device-parsed table has its columns in a table slot only)
+            v.pos, v.event_model_e4 = _ptr(self.pos), _ptr(self.evmu)
+            v.event_idx = _ptr(self.event_idx)
+        v.flags = _ptr(self.flags)
         v.n_seg = self.n_seg
         v.seg_row_begin, v.seg_read, v.seg_contig = _ptr(self.seg_row_begin), _ptr(self.seg_read), _ptr(self.seg_contig)
         v.n_reads = self.n_reads
@@ -251,6 +267,52 @@ class Table(object):
                      self.flags[r0:r1], self.seg_row_begin[s0:s1 + 1] - r0, self.seg_read[s0:s1],
                      self.seg_contig[s0:s1], self.n_reads, read_names=self.read_names, owner=self._owner,
                      evmu=self.evmu[r0:r1])
+
+
+class TextBlock(object):
+    """A byte range of a file in the pinned host pool (what the device parser is given)."""
+
+    def __init__(self, path, lo, hi, n_threads=0):
+        self.n_bytes = int(hi - lo)
+        self._mem = PinnedArray((max(self.n_bytes, 1),), np.uint8)
+        self.array = self._mem.array
+        self.ptr = self._mem.ptr
+        if self.n_bytes:
+            check(lib().mc_read_file_range(path.encode('utf-8'), int(lo), int(hi), self.ptr, int(n_threads)))
+
+    def token(self, off, n):
+        return bytes(self.array[off:off + n]).decode('utf-8', 'surrogateescape')
+
+
+def device_table(res, text):
+    """Table whose columns the device parser has put into a table slot (mc_ctx_parse_end's result `res`, a DevParseResult;
+    `text`: the TextBlock it was made from): the host side holds the segments, the flag column and the names only."""
+    n, ns = int(res.n_rows), int(res.n_seg)
+    t = Table.__new__(Table)
+    t.pos = t.evmu = t.event_idx = None                # (on the device only)
+    t.flags = _from_ptr(res.flags, n, np.uint8).copy()
+    rows = _from_ptr(res.seg_row_begin, ns, np.int64)
+    t.seg_row_begin = np.concatenate([rows, np.array([n], dtype=np.int64)])
+    t.seg_contig = _from_ptr(res.seg_contig, ns, np.int32).copy()
+    off, ln = _from_ptr(res.seg_name_off, ns, np.int64), _from_ptr(res.seg_name_len, ns, np.int32)
+    ids, names, seg_read = {}, [], np.empty(ns, dtype=np.int32)
+    for i in range(ns):                                # read ids in the order the names first appear, like the host parser
+        name = text.token(int(off[i]), int(ln[i]))
+        rid = ids.get(name)
+        if rid is None:
+            rid = ids[name] = len(names)
+            names.append(name)
+        seg_read[i] = rid
+    t.seg_read = seg_read
+    t.seg_name_start = _from_ptr(res.seg_name_start, ns, np.uint8).copy()
+    t.n_reads, t.read_names = len(names), names
+    uo, ul = _from_ptr(res.unknown_off, int(res.n_unknown), np.int64), _from_ptr(res.unknown_len, int(res.n_unknown), np.int32)
+    t.unknown = [text.token(int(uo[i]), int(ul[i])) for i in range(int(res.n_unknown))]
+    t._owner = None
+    t.n_rows, t.n_seg = n, ns
+    t.n_pieces = 0
+    t.device_slot = None                               # set by Device.parse_end
+    return t
 
 
 def fastq_read_quality(path, n_threads=0):

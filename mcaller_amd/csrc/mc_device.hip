@@ -2393,6 +2393,8 @@ static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads)
     return L;
 }
 
+#include "mc_devparse.inc"
+
 struct TableSlot {
     DevTable T;                        // the table in the slot (pointers into the slot's allocations)
     int64_t cap_rows = 0, cap_segs = 0, cap_reads = 0;
@@ -2406,7 +2408,23 @@ struct TableSlot {
     int32_t n_qual = 0;
     hipEvent_t ev_uploaded = nullptr;  // the H2D transfers of the slot's table are done
     hipEvent_t ev_up_start = nullptr, ev_val_start = nullptr, ev_valid = nullptr;   // ... begin; k_validate begins / is done
-    int refs = 0;                      // passes in flight that scan this table
+    int refs = 0;                      // passes in flight that scan this table (+1 while the device parser fills the slot)
+    // the device parser (mc_ctx_parse_begin .. _finish)
+    char *text = nullptr;              // the shard's text on the device
+    int64_t cap_text = 0;
+    KpHead *kp_head = nullptr, *kp_head_h = nullptr;         // device result block, pinned host copy
+    KpSeg *kp_segs = nullptr, *kp_segs_h = nullptr;
+    KpUnknown *kp_unknown = nullptr, *kp_unknown_h = nullptr;
+    uint8_t *kp_flags_h = nullptr;     // pinned host copy of the flag column
+    int64_t kp_cap_flags = 0;
+    int kp_cap_segs = 0;
+    hipEvent_t ev_parsed = nullptr;
+    int kp_state = 0;                  // 0: idle, 1: parse enqueued, 2: results handed out (mc_ctx_parse_end)
+    int64_t kp_bytes = 0;
+    std::vector<int64_t> kp_seg_row, kp_seg_off, kp_unk_off;
+    std::vector<int32_t> kp_seg_contig, kp_seg_len, kp_unk_len;
+    std::vector<uint8_t> kp_seg_ns;
+    std::vector<void *> kp_allocs;
     long long tmpl_ref = -1;           // reference version the name-block templates were built for (-1: not built)
     std::vector<void *> allocs;
 };
@@ -2422,6 +2440,8 @@ struct mc_ctx {
     DevTable last_T;                   // ... and that table
     bool in_rerun = false;             // mc_wait_records is re-running a pass synchronously
     hipStream_t up_stream = nullptr;   // H2D of tables
+    KpScratch kp;                      // the device parser's line-indexed scratch and contig table
+    KpContigs kc;
     int64_t res_rows = 0, res_segs = 0, res_reads = 0;     // mc_ctx_reserve_tables
     long long ref_version = 0;
     int64_t scratch_nb = 0, scratch_tiles = 0;             // what the per-pass scratch below is sized for
@@ -2647,9 +2667,11 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     (void)sync_pass_streams(c);
     for (TableSlot &S : c->slots) {
         slot_free(S);
-        for (hipEvent_t e : {S.ev_uploaded, S.ev_up_start, S.ev_val_start, S.ev_valid})
+        for (hipEvent_t e : {S.ev_uploaded, S.ev_up_start, S.ev_val_start, S.ev_valid, S.ev_parsed})
             if (e) (void)hipEventDestroy(e);
     }
+    free_pool(c->kp.allocs);
+    free_pool(c->kc.allocs);
     free_pool(c->scratch_allocs);
     free_pool(c->ref_allocs);
     free_pool(c->mlp_allocs);
@@ -2732,8 +2754,17 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
 }
 
 // ---- table slots ----
+static void slot_free_parser(TableSlot &S) {
+    free_pool(S.kp_allocs);
+    for (void *p : {(void *)S.kp_head_h, (void *)S.kp_segs_h, (void *)S.kp_unknown_h, (void *)S.kp_flags_h})
+        if (p) (void)hipHostFree(p);
+    S.text = nullptr; S.cap_text = 0; S.kp_head = S.kp_head_h = nullptr; S.kp_segs = S.kp_segs_h = nullptr;
+    S.kp_unknown = S.kp_unknown_h = nullptr; S.kp_flags_h = nullptr; S.kp_cap_flags = 0; S.kp_cap_segs = 0; S.kp_state = 0;
+}
+
 static void slot_free(TableSlot &S) {
     free_pool(S.allocs);
+    slot_free_parser(S);
     if (S.stage) (void)hipHostFree(S.stage);
     S.stage = nullptr; S.small_dev = nullptr; S.small_cap = 0;
     S.pos = S.idx = nullptr; S.evmu = nullptr; S.flags = nullptr; S.nb_tmpl = nullptr;
@@ -2805,32 +2836,27 @@ extern "C" int mc_ctx_reserve_tables(mc_ctx *c, int64_t max_rows, int32_t max_se
     return ensure_scratch(c, c->res_segs, (c->res_rows + TILE - 1) / TILE);
 }
 
-extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, const double *read_qual, int32_t *slot_out) {
-    HIP_TRY(hipSetDevice(c->device));
-    if (slot_out) *slot_out = -1;
-    const int64_t n = h->n_rows;
-    if (n < 0 || h->n_seg < 0 || h->n_reads < 0 || (n > 0 && h->n_seg == 0)) {
-        mc_set_error("mc_ctx_upload_table_async: malformed table (%lld rows, %d segments, %d reads)", (long long)n, h->n_seg, h->n_reads);
-        return -12;
-    }
-    // ---- a free slot: not scanned by a pass in flight, not holding the records handed out last ----
-    int at = -1;
+// a free slot: not scanned by a pass in flight, not holding the records handed out last, not being filled by the device parser
+static int free_slot(mc_ctx *c, const char *who) {
     for (int i = 1; i <= MC_TABLE_SLOTS; ++i) {
         const int sidx = (std::max(c->cur, 0) + i) % MC_TABLE_SLOTS;
-        if (c->slots[sidx].refs == 0 && sidx != c->held) { at = sidx; break; }
+        if (c->slots[sidx].refs == 0 && sidx != c->held) return sidx;
     }
-    if (at < 0) {
-        mc_set_error("mc_ctx_upload_table_async: all %d table slots are being scanned; call mc_wait_records first", MC_TABLE_SLOTS);
-        return -12;
-    }
-    TableSlot &S = c->slots[at];
-    if (int rc = slot_ensure(c, S, n, h->n_seg, h->n_reads)) return rc;
-    HIP_TRY(hipEventSynchronize(S.ev_uploaded));          // the stage is about to be rewritten (long done: the slot was idle)
+    mc_set_error("%s: all %d table slots are being scanned; call mc_wait_records first", who, MC_TABLE_SLOTS);
+    return -1;
+}
 
-    // ---- the small arrays, laid out in the pinned stage: segments, name blocks (maximal runs of segments with one read
-    //      name, MC_F_NAME_START on the first row), the name block of every tile's first row, read qualities ----
+// What makes the rows in slot `at` a table: the small arrays (segments, name blocks -- maximal runs of segments with one read
+// name --, the name block of every tile's first row, read qualities) laid out in the pinned stage and sent, the per-table
+// kernel behind them; the table becomes the current one.  cols: the host columns to send first (mc_ctx_upload_table_async),
+// or nullptr: the device parser has put them into the slot already (mc_ctx_parse_finish).  seg_name_start[sg] (or, if
+// nullptr, MC_F_NAME_START of the segment's first row in cols->flags): the segment starts a name block.
+static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t *seg_row_begin, const int32_t *seg_read_in,
+                     const int32_t *seg_contig_in, const uint8_t *seg_name_start, int32_t n_reads, const double *read_qual,
+                     const mc_table_view *cols) {
+    TableSlot &S = c->slots[at];
     const int64_t n_tiles = (n + TILE - 1) / TILE;
-    const SmallLayout L = small_layout(h->n_seg, n_tiles, read_qual ? h->n_reads : 0);
+    const SmallLayout L = small_layout(n_seg, n_tiles, read_qual ? n_reads : 0);
     unsigned char *st = S.stage;
     int64_t *seg_begin = (int64_t *)(st + L.seg_begin), *nb_row = (int64_t *)(st + L.nb_row_begin);
     int32_t *seg_read = (int32_t *)(st + L.seg_read), *seg_contig = (int32_t *)(st + L.seg_contig);
@@ -2838,23 +2864,24 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     int32_t *vtile_nb = (int32_t *)(st + L.vtile_nb);
     uint8_t *nb_rep = st + L.nb_repeat;
     uint32_t *nb_vf = (uint32_t *)(st + L.nb_vflags);
-    if (h->n_seg > 0) {
-        memcpy(seg_begin, h->seg_row_begin, (size_t)(h->n_seg + 1) * 8);
-        memcpy(seg_read, h->seg_read, (size_t)h->n_seg * 4);
-        memcpy(seg_contig, h->seg_contig, (size_t)h->n_seg * 4);
+    if (n_seg > 0) {
+        memcpy(seg_begin, seg_row_begin, (size_t)n_seg * 8);
+        seg_begin[n_seg] = n;
+        memcpy(seg_read, seg_read_in, (size_t)n_seg * 4);
+        memcpy(seg_contig, seg_contig_in, (size_t)n_seg * 4);
     } else seg_begin[0] = 0;
-    std::vector<uint8_t> seen((size_t)std::max(h->n_reads, 1), 0);
+    std::vector<uint8_t> seen((size_t)std::max(n_reads, 1), 0);
     int has_rep = 0;
     int32_t n_nb = 0;
-    for (int32_t sg = 0; sg < h->n_seg; ++sg) {
-        const int64_t rb = h->seg_row_begin[sg];
-        if (rb < 0 || rb >= n || (sg > 0 && rb <= h->seg_row_begin[sg - 1])) {
+    for (int32_t sg = 0; sg < n_seg; ++sg) {
+        const int64_t rb = seg_row_begin[sg];
+        if (rb < 0 || rb >= n || (sg > 0 && rb <= seg_row_begin[sg - 1])) {
             mc_set_error("segment %d: row %lld out of order", sg, (long long)rb);
             return -12;
         }
-        if (sg == 0 || (h->flags[rb] & MC_F_NAME_START)) {
-            const int32_t rd = h->seg_read[sg];
-            if (rd < 0 || rd >= h->n_reads) {
+        if (sg == 0 || (seg_name_start ? seg_name_start[sg] != 0 : (cols->flags[rb] & MC_F_NAME_START) != 0)) {
+            const int32_t rd = seg_read_in[sg];
+            if (rd < 0 || rd >= n_reads) {
                 mc_set_error("segment %d: read id %d out of range", sg, rd);
                 return -12;
             }
@@ -2868,9 +2895,9 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
             ++n_nb;
         }
     }
-    if (n_nb > 0) nb_vf[n_nb - 1] = (h->n_seg - nb_seg[n_nb - 1] > 1) ? V_MULTI_SEG : 0u;
+    if (n_nb > 0) nb_vf[n_nb - 1] = (n_seg - nb_seg[n_nb - 1] > 1) ? V_MULTI_SEG : 0u;
     nb_row[n_nb] = n;
-    nb_seg[n_nb] = h->n_seg;
+    nb_seg[n_nb] = n_seg;
     nb_vf[n_nb] = 0u;
     {
         int32_t b = 0;                                     // last block that starts at or before the tile's first row
@@ -2884,12 +2911,12 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
             vtile_nb[t] = b;
         }
     }
-    if (read_qual && h->n_reads > 0) memcpy(st + L.qual, read_qual, (size_t)h->n_reads * 8);
+    if (read_qual && n_reads > 0) memcpy(st + L.qual, read_qual, (size_t)n_reads * 8);
 
     // ---- the slot's table ----
     DevTable &T = S.T;
     T = DevTable();
-    T.n_rows = n; T.n_seg = h->n_seg; T.n_reads = h->n_reads; T.n_nb = n_nb; T.n_tiles = n_tiles; T.has_repeats = has_rep;
+    T.n_rows = n; T.n_seg = n_seg; T.n_reads = n_reads; T.n_nb = n_nb; T.n_tiles = n_tiles; T.has_repeats = has_rep;
     T.pos = S.pos; T.idx = S.idx; T.evmu = S.evmu; T.flags = S.flags; T.nb_tmpl = S.nb_tmpl;
     unsigned char *dv = S.small_dev;
     T.seg_begin = (int64_t *)(dv + L.seg_begin); T.seg_read = (int32_t *)(dv + L.seg_read); T.seg_contig = (int32_t *)(dv + L.seg_contig);
@@ -2898,19 +2925,21 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     T.tile_nb = (int32_t *)(dv + L.tile_nb);
     T.vtile_nb = (int32_t *)(dv + L.vtile_nb);
     S.qual = read_qual ? (double *)(dv + L.qual) : nullptr;
-    S.n_qual = read_qual ? h->n_reads : 0;
+    S.n_qual = read_qual ? n_reads : 0;
     S.tmpl_ref = -1;
 
     // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out), then the per-table kernel on
     //      the ctx stream behind the transfer ----
     hipStream_t us = c->up_stream;
-    HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));        // k_validate of the slot's previous table (it may never have been scanned)
-    HIP_TRY(hipEventRecord(S.ev_up_start, us));
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(T.pos, h->pos, (size_t)n * 4, hipMemcpyHostToDevice, us));
-        HIP_TRY(hipMemcpyAsync(T.evmu, h->event_model_e4, (size_t)n * 8, hipMemcpyHostToDevice, us));
-        HIP_TRY(hipMemcpyAsync(T.idx, h->event_idx, (size_t)n * 4, hipMemcpyHostToDevice, us));
-        HIP_TRY(hipMemcpyAsync(T.flags, h->flags, (size_t)n, hipMemcpyHostToDevice, us));
+    if (cols) {
+        HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));    // k_validate of the slot's previous table (it may never have been scanned)
+        HIP_TRY(hipEventRecord(S.ev_up_start, us));
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(T.pos, cols->pos, (size_t)n * 4, hipMemcpyHostToDevice, us));
+            HIP_TRY(hipMemcpyAsync(T.evmu, cols->event_model_e4, (size_t)n * 8, hipMemcpyHostToDevice, us));
+            HIP_TRY(hipMemcpyAsync(T.idx, cols->event_idx, (size_t)n * 4, hipMemcpyHostToDevice, us));
+            HIP_TRY(hipMemcpyAsync(T.flags, cols->flags, (size_t)n, hipMemcpyHostToDevice, us));
+        }
     }
     HIP_TRY(hipMemcpyAsync(dv, st, L.total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(S.ev_uploaded, us));
@@ -2923,7 +2952,277 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
     c->cur = at;
     if (read_qual) { c->qual = S.qual; c->n_qual = S.n_qual; }
     else { c->qual = c->qual_own; c->n_qual = c->n_qual_own; }       // mc_ctx_set_read_quality's table applies
+    return 0;
+}
+
+extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, const double *read_qual, int32_t *slot_out) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot_out) *slot_out = -1;
+    const int64_t n = h->n_rows;
+    if (n < 0 || h->n_seg < 0 || h->n_reads < 0 || (n > 0 && h->n_seg == 0)) {
+        mc_set_error("mc_ctx_upload_table_async: malformed table (%lld rows, %d segments, %d reads)", (long long)n, h->n_seg, h->n_reads);
+        return -12;
+    }
+    const int at = free_slot(c, "mc_ctx_upload_table_async");
+    if (at < 0) return -12;
+    TableSlot &S = c->slots[at];
+    if (int rc = slot_ensure(c, S, n, h->n_seg, h->n_reads)) return rc;
+    HIP_TRY(hipEventSynchronize(S.ev_uploaded));          // the stage is about to be rewritten (long done: the slot was idle)
+    if (int rc = fill_slot(c, at, n, h->n_seg, h->seg_row_begin, h->seg_read, h->seg_contig, nullptr, h->n_reads, read_qual, h)) return rc;
     if (slot_out) *slot_out = at;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The device parser's host side (kernels: mc_devparse.inc).  mc_ctx_parse_begin sends a shard's text and enqueues the
+// kernels that turn it into the columns of a table slot; mc_ctx_parse_end waits and hands out what the host needs to name
+// things (segments with the place of their read name in the text, unknown contig tokens, the flag column);
+// mc_ctx_parse_finish takes the read ids and qualities and makes the slot's rows the current table -- from there on the slot
+// is what mc_ctx_upload_table_async would have left.  All on the upload stream; begin for shard i+1 may be called before end
+// for shard i.
+// ---------------------------------------------------------------------------------------------------
+static int kp_ensure_scratch(mc_ctx *c, int64_t cap_lines, int64_t n_tiles) {
+    KpScratch &K = c->kp;
+    if (K.cap_lines >= cap_lines && K.cap_tiles >= n_tiles) return 0;
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    free_pool(K.allocs);
+    K.cap_lines = std::max(cap_lines, K.cap_lines);
+    K.cap_tiles = std::max(n_tiles, K.cap_tiles);
+    const size_t n = (size_t)K.cap_lines + 256, nt = (size_t)std::max<int64_t>(K.cap_tiles, (K.cap_lines + 255) / 256) + 1;
+    if (dev_alloc(K.allocs, &K.line_start, n + 1) || dev_alloc(K.allocs, &K.pos, n) || dev_alloc(K.allocs, &K.idx, n) ||
+        dev_alloc(K.allocs, &K.ev, n) || dev_alloc(K.allocs, &K.mu, n) || dev_alloc(K.allocs, &K.contig, n) ||
+        dev_alloc(K.allocs, &K.name_off, n) || dev_alloc(K.allocs, &K.name_len, n) || dev_alloc(K.allocs, &K.fl, n) ||
+        dev_alloc(K.allocs, &K.status, n) || dev_alloc(K.allocs, &K.tile_cnt, nt) || dev_alloc(K.allocs, &K.tile_off, nt))
+        return -10;
+    return 0;
+}
+
+static int kp_set_contigs(mc_ctx *c, const char *const *names, int32_t n) {
+    KpContigs &C = c->kc;
+    bool same = (int)C.names.size() == n && C.hash;
+    for (int i = 0; same && i < n; ++i) same = C.names[(size_t)i] == names[i];
+    if (same) return 0;
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    free_pool(C.allocs);
+    C.names.assign(names, names + n);
+    int size = 16;
+    while (size < 2 * n + 2) size *= 2;
+    std::vector<uint32_t> hash((size_t)size, 0), off((size_t)std::max(n, 1)), len((size_t)std::max(n, 1));
+    std::vector<int32_t> id((size_t)size, -1);
+    std::string chars;
+    for (int i = 0; i < n; ++i) {
+        off[(size_t)i] = (uint32_t)chars.size();
+        len[(size_t)i] = (uint32_t)C.names[(size_t)i].size();
+        chars += C.names[(size_t)i];
+        uint32_t h = 2166136261u;
+        for (unsigned char ch : C.names[(size_t)i]) h = (h ^ ch) * 16777619u;
+        if (h == 0) h = 1;
+        bool dup = false;                                   // the first id of a name wins, like the FASTA scan (:77-81)
+        int slot = (int)(h & (uint32_t)(size - 1));
+        for (; hash[(size_t)slot]; slot = (slot + 1) & (size - 1))
+            if (hash[(size_t)slot] == h && C.names[(size_t)id[(size_t)slot]] == C.names[(size_t)i]) { dup = true; break; }
+        if (!dup) { hash[(size_t)slot] = h; id[(size_t)slot] = i; }
+    }
+    chars.push_back('\0');
+    C.table_mask = size - 1;
+    C.n = n;
+    hipStream_t us = c->up_stream;
+    if (dev_alloc(C.allocs, &C.hash, (size_t)size) || dev_alloc(C.allocs, &C.id, (size_t)size) ||
+        dev_alloc(C.allocs, &C.name_off, off.size()) || dev_alloc(C.allocs, &C.name_len, len.size()) ||
+        dev_alloc(C.allocs, &C.chars, chars.size()))
+        return -10;
+    HIP_TRY(hipMemcpyAsync(C.hash, hash.data(), (size_t)size * 4, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(C.id, id.data(), (size_t)size * 4, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(C.name_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(C.name_len, len.data(), len.size() * 4, hipMemcpyHostToDevice, us));
+    HIP_TRY(hipMemcpyAsync(C.chars, chars.data(), chars.size(), hipMemcpyHostToDevice, us));
+    HIP_TRY(hipStreamSynchronize(us));                      // (the vectors go out of scope)
+    return 0;
+}
+
+static int kp_ensure_slot(mc_ctx *c, TableSlot &S, int64_t n_bytes) {
+    if (!S.ev_parsed) HIP_TRY(hipEventCreate(&S.ev_parsed));
+    const int cap_segs = (int)std::min<int64_t>(S.cap_segs, 1 << 24);
+    if (S.text && S.cap_text >= n_bytes + 64 && S.kp_cap_flags >= S.cap_rows && S.kp_cap_segs >= cap_segs) return 0;
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    slot_free_parser(S);
+    S.cap_text = std::max<int64_t>(n_bytes + n_bytes / 8, (int64_t)1 << 20) + 64;
+    if (dev_alloc(S.kp_allocs, &S.text, (size_t)S.cap_text) || dev_alloc(S.kp_allocs, &S.kp_head, 1) ||
+        dev_alloc(S.kp_allocs, &S.kp_segs, (size_t)cap_segs) || dev_alloc(S.kp_allocs, &S.kp_unknown, (size_t)KP_MAX_UNKNOWN))
+        return -10;
+    S.kp_cap_segs = cap_segs;
+    S.kp_cap_flags = S.cap_rows;
+    HIP_TRY(hipHostMalloc((void **)&S.kp_head_h, sizeof(KpHead), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&S.kp_segs_h, (size_t)cap_segs * sizeof(KpSeg), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&S.kp_unknown_h, (size_t)KP_MAX_UNKNOWN * sizeof(KpUnknown), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&S.kp_flags_h, (size_t)std::max<int64_t>(S.cap_rows, 1), hipHostMallocDefault));
+    return 0;
+}
+
+extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, const char *const *contig_names, int32_t n_contigs,
+                                  int64_t max_rows, int32_t *slot_out) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot_out) *slot_out = -1;
+    if (!text || n_bytes < 0 || n_bytes >= ((int64_t)1 << 32) || n_contigs < 0 || max_rows < 0) {
+        mc_set_error("mc_ctx_parse_begin: bad arguments (%lld bytes of text; at most 4 GB per shard)", (long long)n_bytes);
+        return -12;
+    }
+    const int at = free_slot(c, "mc_ctx_parse_begin");
+    if (at < 0) return -12;
+    TableSlot &S = c->slots[at];
+    // rows: what the caller expects (the slots were sized by mc_ctx_reserve_tables, or grow here); a shard with more rows or
+    // segments than the slot holds comes back from mc_ctx_parse_end as "needs the host parser"
+    const int64_t rows = std::max<int64_t>(max_rows, 1);
+    if (int rc = slot_ensure(c, S, rows, std::max<int64_t>(rows / 16, 64), std::max<int64_t>(rows / 16, 64))) return rc;
+    if (int rc = kp_ensure_slot(c, S, n_bytes)) return rc;
+    const int64_t n_tiles = (n_bytes + KP_TILE - 1) / KP_TILE;
+    if (int rc = kp_ensure_scratch(c, S.cap_rows + 65536, n_tiles)) return rc;
+    if (int rc = kp_set_contigs(c, contig_names, n_contigs)) return rc;
+    KpScratch &K = c->kp;
+    hipStream_t us = c->up_stream;
+    HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));        // k_validate of the slot's previous table (it may never have been scanned)
+    HIP_TRY(hipEventRecord(S.ev_up_start, us));
+    static const KpHead zero_head = {0, 0, 0, 0, 0, 0x7fffffffffffffffll, 0, 0};
+    HIP_TRY(hipMemcpyAsync(S.kp_head, &zero_head, sizeof(KpHead), hipMemcpyHostToDevice, us));
+    if (n_bytes > 0) HIP_TRY(hipMemcpyAsync(S.text, text, (size_t)n_bytes, hipMemcpyHostToDevice, us));
+    if (n_tiles > 0) {
+        hipLaunchKernelGGL(kp_count, dim3((unsigned)n_tiles), dim3(KP_THREADS), 0, us, (const char *)S.text, n_bytes, K.tile_cnt);
+        hipLaunchKernelGGL(kp_scan, dim3(1), dim3(1024), 0, us, (const long long *)K.tile_cnt, n_tiles, K.tile_off, &S.kp_head->n_newlines);
+        hipLaunchKernelGGL(kp_starts, dim3((unsigned)n_tiles), dim3(KP_THREADS), 0, us, (const char *)S.text, n_bytes,
+                           (const long long *)K.tile_off, K.line_start, K.cap_lines, S.kp_head);
+        const int64_t cap_lines = K.cap_lines;
+        const unsigned line_blocks = (unsigned)((cap_lines + 255) / 256);
+        KpParseArgs PA;
+        PA.text = S.text; PA.n_bytes = n_bytes; PA.line_start = K.line_start; PA.head = S.kp_head; PA.head_w = S.kp_head;
+        PA.cap_lines = cap_lines; PA.c_hash = c->kc.hash; PA.c_id = c->kc.id; PA.c_off = c->kc.name_off; PA.c_len = c->kc.name_len;
+        PA.c_chars = c->kc.chars; PA.c_mask = c->kc.table_mask;
+        PA.pos = K.pos; PA.idx = K.idx; PA.ev = K.ev; PA.mu = K.mu; PA.contig = K.contig; PA.name_off = K.name_off; PA.name_len = K.name_len;
+        PA.fl = K.fl; PA.status = K.status;
+        hipLaunchKernelGGL(kp_parse, dim3(line_blocks), dim3(256), 0, us, PA);
+        hipLaunchKernelGGL(kp_count_rows, dim3(line_blocks), dim3(256), 0, us, (const uint8_t *)K.status, (const KpHead *)S.kp_head,
+                           cap_lines, K.tile_cnt);
+        hipLaunchKernelGGL(kp_scan, dim3(1), dim3(1024), 0, us, (const long long *)K.tile_cnt, (int64_t)line_blocks, K.tile_off,
+                           &S.kp_head->n_rows);
+        KpPlaceArgs QA;
+        QA.text = S.text; QA.head = S.kp_head; QA.head_w = S.kp_head; QA.cap_lines = cap_lines; QA.cap_rows = S.cap_rows;
+        QA.blk_off = K.tile_off; QA.pos = K.pos; QA.idx = K.idx; QA.ev = K.ev; QA.mu = K.mu; QA.contig = K.contig;
+        QA.name_off = K.name_off; QA.name_len = K.name_len; QA.fl = K.fl; QA.status = K.status;
+        QA.t_pos = S.pos; QA.t_idx = S.idx; QA.t_evmu = S.evmu; QA.t_flags = S.flags; QA.segs = S.kp_segs; QA.cap_segs = S.kp_cap_segs;
+        QA.unknown = S.kp_unknown;
+        hipLaunchKernelGGL(kp_place, dim3(line_blocks), dim3(256), 0, us, QA);
+    }
+    HIP_TRY(hipMemcpyAsync(S.kp_head_h, S.kp_head, sizeof(KpHead), hipMemcpyDeviceToHost, us));
+    HIP_TRY(hipEventRecord(S.ev_parsed, us));
+    HIP_TRY(hipGetLastError());
+    S.refs += 1;                                            // the slot is taken until mc_ctx_parse_finish / _abandon
+    S.kp_state = 1;
+    S.kp_bytes = n_bytes;
+    if (slot_out) *slot_out = at;
+    return 0;
+}
+
+static int kp_slot(mc_ctx *c, int32_t slot, int state, const char *who, TableSlot **S) {
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || c->slots[slot].kp_state != state) {
+        mc_set_error("%s: slot %d is not in that state", who, slot);
+        return -12;
+    }
+    *S = &c->slots[slot];
+    return 0;
+}
+
+extern "C" int mc_ctx_parse_end(mc_ctx *c, int32_t slot, mc_devparse_result *out) {
+    HIP_TRY(hipSetDevice(c->device));
+    TableSlot *Sp;
+    if (int rc = kp_slot(c, slot, 1, "mc_ctx_parse_end", &Sp)) return rc;
+    TableSlot &S = *Sp;
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(hipEventSynchronize(S.ev_parsed));
+    const KpHead H = *S.kp_head_h;
+    S.kp_state = 2;
+    out->n_lines = H.n_lines; out->n_rows = H.n_rows; out->n_seg = H.n_seg; out->n_unknown = H.n_unknown;
+    if (H.overflow || H.first_host_line != 0x7fffffffffffffffll || H.n_rows > S.cap_rows || H.n_seg > S.kp_cap_segs) {
+        out->status = 1;
+        if (H.first_host_line != 0x7fffffffffffffffll)
+            mc_set_error("device parser: line %lld needs the host parser (a number form or value beyond the fast path)", H.first_host_line);
+        else
+            mc_set_error("device parser: %lld lines, %lld rows, %d segments, %d unknown-contig lines do not fit the slot", H.n_lines, H.n_rows,
+                         H.n_seg, H.n_unknown);
+        return 0;
+    }
+    hipStream_t us = c->up_stream;
+    if (H.n_seg > 0) HIP_TRY(hipMemcpyAsync(S.kp_segs_h, S.kp_segs, (size_t)H.n_seg * sizeof(KpSeg), hipMemcpyDeviceToHost, us));
+    if (H.n_unknown > 0) HIP_TRY(hipMemcpyAsync(S.kp_unknown_h, S.kp_unknown, (size_t)H.n_unknown * sizeof(KpUnknown), hipMemcpyDeviceToHost, us));
+    if (H.n_rows > 0) HIP_TRY(hipMemcpyAsync(S.kp_flags_h, S.flags, (size_t)H.n_rows, hipMemcpyDeviceToHost, us));
+    HIP_TRY(hipStreamSynchronize(us));
+    // segments and unknown lines were listed in the order the lanes got there: file order is by row / by line
+    std::sort(S.kp_segs_h, S.kp_segs_h + H.n_seg, [](const KpSeg &a, const KpSeg &b) { return a.row < b.row; });
+    std::sort(S.kp_unknown_h, S.kp_unknown_h + H.n_unknown, [](const KpUnknown &a, const KpUnknown &b) { return a.line < b.line; });
+    S.kp_seg_row.resize((size_t)H.n_seg); S.kp_seg_off.resize((size_t)H.n_seg); S.kp_seg_contig.resize((size_t)H.n_seg);
+    S.kp_seg_len.resize((size_t)H.n_seg); S.kp_seg_ns.resize((size_t)H.n_seg);
+    for (int i = 0; i < H.n_seg; ++i) {
+        const KpSeg &g = S.kp_segs_h[i];
+        S.kp_seg_row[(size_t)i] = g.row; S.kp_seg_off[(size_t)i] = g.name_off; S.kp_seg_contig[(size_t)i] = g.contig;
+        S.kp_seg_len[(size_t)i] = g.name_len; S.kp_seg_ns[(size_t)i] = (uint8_t)g.name_start;
+    }
+    S.kp_unk_off.resize((size_t)H.n_unknown); S.kp_unk_len.resize((size_t)H.n_unknown);
+    for (int i = 0; i < H.n_unknown; ++i) { S.kp_unk_off[(size_t)i] = S.kp_unknown_h[i].off; S.kp_unk_len[(size_t)i] = S.kp_unknown_h[i].len; }
+    out->seg_row_begin = S.kp_seg_row.data(); out->seg_contig = S.kp_seg_contig.data(); out->seg_name_off = S.kp_seg_off.data();
+    out->seg_name_len = S.kp_seg_len.data(); out->seg_name_start = S.kp_seg_ns.data();
+    out->unknown_off = S.kp_unk_off.data(); out->unknown_len = S.kp_unk_len.data();
+    out->flags = S.kp_flags_h;
+    return 0;
+}
+
+extern "C" int mc_ctx_parse_finish(mc_ctx *c, int32_t slot, const int32_t *seg_read, int32_t n_reads, const double *read_qual) {
+    HIP_TRY(hipSetDevice(c->device));
+    TableSlot *Sp;
+    if (int rc = kp_slot(c, slot, 2, "mc_ctx_parse_finish", &Sp)) return rc;
+    TableSlot &S = *Sp;
+    const KpHead H = *S.kp_head_h;
+    if (H.n_seg > S.cap_segs || n_reads > S.cap_reads) {
+        // (the small arrays of the slot were sized for fewer segments / reads: grow them; the columns stay)
+        mc_set_error("mc_ctx_parse_finish: %d segments, %d reads: the slot holds %lld, %lld (mc_ctx_reserve_tables)", H.n_seg, n_reads,
+                     (long long)S.cap_segs, (long long)S.cap_reads);
+        return -12;
+    }
+    HIP_TRY(hipEventSynchronize(S.ev_uploaded));           // the stage is about to be rewritten (long done: the slot was idle)
+    S.kp_state = 0;
+    S.refs -= 1;
+    if (int rc = fill_slot(c, slot, H.n_rows, H.n_seg, S.kp_seg_row.data(), seg_read, S.kp_seg_contig.data(), S.kp_seg_ns.data(), n_reads,
+                           read_qual, nullptr))
+        return rc;
+    return 0;
+}
+
+extern "C" int mc_ctx_parse_abandon(mc_ctx *c, int32_t slot) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || c->slots[slot].kp_state == 0) {
+        mc_set_error("mc_ctx_parse_abandon: slot %d holds no parse", slot);
+        return -12;
+    }
+    TableSlot &S = c->slots[slot];
+    HIP_TRY(hipEventSynchronize(S.ev_parsed));
+    // (k_validate never ran on these rows: ev_valid still stands for the slot's previous table, which is all a later upload waits for)
+    S.kp_state = 0;
+    S.refs -= 1;
+    return 0;
+}
+
+// the columns of a slot's table back on the host (tests: the device parser's columns against the host parser's)
+extern "C" int mc_ctx_fetch_columns(mc_ctx *c, int32_t slot, int64_t n_rows, int32_t *pos, int32_t *event_model_e4, int32_t *event_idx,
+                                    uint8_t *flags) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].pos || n_rows < 0 || n_rows > c->slots[slot].cap_rows) {
+        mc_set_error("mc_ctx_fetch_columns: slot %d, %lld rows", slot, (long long)n_rows);
+        return -12;
+    }
+    TableSlot &S = c->slots[slot];
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (n_rows == 0) return 0;
+    if (pos) HIP_TRY(hipMemcpy(pos, S.pos, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+    if (event_model_e4) HIP_TRY(hipMemcpy(event_model_e4, S.evmu, (size_t)n_rows * 8, hipMemcpyDeviceToHost));
+    if (event_idx) HIP_TRY(hipMemcpy(event_idx, S.idx, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+    if (flags) HIP_TRY(hipMemcpy(flags, S.flags, (size_t)n_rows, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -60,12 +60,52 @@ class Device(object):
         """Enqueue the upload of `table` (+ its read qualities) into a free slot and make it the current table; returns the
         slot.  The table's arrays must stay alive and untouched until wait_upload(slot) (or until the records of a pass over
         it have been handed out); they should be pinned (Table.pinned(), or parsed with the pool switched on)."""
-        v = table.view()
         q = None if qual is None else np.ascontiguousarray(qual, dtype=np.float64)
+        if getattr(table, 'device_slot', None) is not None:          # parsed on the device: the columns are in the slot already
+            sr = np.ascontiguousarray(table.seg_read, dtype=np.int32)
+            check(lib().mc_ctx_parse_finish(self._ctx, int(table.device_slot), _ptr(sr), int(table.n_reads),
+                                            None if q is None else _ptr(q)))
+            self.n_rows = table.n_rows
+            slot, table.device_slot = table.device_slot, None
+            return slot
+        v = table.view()
         slot = C.c_int32(-1)
         check(lib().mc_ctx_upload_table_async(self._ctx, C.byref(v), None if q is None else _ptr(q), C.byref(slot)))
         self.n_rows = table.n_rows
         return slot.value
+
+    # ---- the eventalign text parsed on the device (mc_ctx_parse_*) ----
+    def parse_begin(self, text, contig_names, max_rows):
+        """Send a TextBlock and enqueue the parse into a free table slot -> slot."""
+        arr = (C.c_char_p * max(1, len(contig_names)))()
+        for i, n in enumerate(contig_names):
+            arr[i] = n.encode('utf-8')
+        slot = C.c_int32(-1)
+        check(lib().mc_ctx_parse_begin(self._ctx, text.ptr, int(text.n_bytes), arr, len(contig_names), int(max_rows), C.byref(slot)))
+        return slot.value
+
+    def parse_end(self, slot, text):
+        """-> the Table (columns on the device, in `slot`; upload_table_async finishes it), or None: the shard needs the host
+        parser (the slot has been given back)."""
+        res = _lib.DevParseResult()
+        check(lib().mc_ctx_parse_end(self._ctx, int(slot), C.byref(res)))
+        if res.status != 0:
+            self.parse_fallback_reason = lib().mc_last_error().decode('utf-8', 'replace')
+            check(lib().mc_ctx_parse_abandon(self._ctx, int(slot)))
+            return None
+        t = _lib.device_table(res, text)
+        t.device_slot = int(slot)
+        return t
+
+    def parse_abandon(self, slot):
+        check(lib().mc_ctx_parse_abandon(self._ctx, int(slot)))
+
+    def fetch_columns(self, slot, n_rows):
+        """(pos, evmu [n, 2], event_idx, flags) of the table in `slot`, copied back (tests)."""
+        pos, evmu = np.empty(n_rows, dtype=np.int32), np.empty((n_rows, 2), dtype=np.int32)
+        idx, fl = np.empty(n_rows, dtype=np.int32), np.empty(n_rows, dtype=np.uint8)
+        check(lib().mc_ctx_fetch_columns(self._ctx, int(slot), int(n_rows), _ptr(pos), _ptr(evmu), _ptr(idx), _ptr(fl)))
+        return pos, evmu, idx, fl
 
     def wait_upload(self, slot):
         check(lib().mc_ctx_wait_upload(self._ctx, int(slot)))
