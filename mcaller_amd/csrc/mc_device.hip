@@ -2418,9 +2418,9 @@ struct TableSlot {
     uint8_t *kp_flags_h = nullptr;     // pinned host copy of the flag column
     int64_t kp_cap_flags = 0;
     int kp_cap_segs = 0;
-    hipEvent_t ev_parsed = nullptr;
+    hipEvent_t ev_parsed = nullptr, ev_text_up = nullptr;
     int kp_state = 0;                  // 0: idle, 1: parse enqueued, 2: results handed out (mc_ctx_parse_end)
-    int64_t kp_bytes = 0;
+    int64_t kp_bytes = 0, kp_flags_sent = 0;
     std::vector<int64_t> kp_seg_row, kp_seg_off, kp_unk_off;
     std::vector<int32_t> kp_seg_contig, kp_seg_len, kp_unk_len;
     std::vector<uint8_t> kp_seg_ns;
@@ -2441,6 +2441,7 @@ struct mc_ctx {
     bool in_rerun = false;             // mc_wait_records is re-running a pass synchronously
     hipStream_t up_stream = nullptr;   // H2D of tables
     KpScratch kp;                      // the device parser's line-indexed scratch and contig table
+    hipStream_t parse_stream = nullptr;  // its kernels (the text of the next shard is on its way on up_stream meanwhile)
     KpContigs kc;
     int64_t res_rows = 0, res_segs = 0, res_reads = 0;     // mc_ctx_reserve_tables
     long long ref_version = 0;
@@ -2667,7 +2668,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     (void)sync_pass_streams(c);
     for (TableSlot &S : c->slots) {
         slot_free(S);
-        for (hipEvent_t e : {S.ev_uploaded, S.ev_up_start, S.ev_val_start, S.ev_valid, S.ev_parsed})
+        for (hipEvent_t e : {S.ev_uploaded, S.ev_up_start, S.ev_val_start, S.ev_valid, S.ev_parsed, S.ev_text_up})
             if (e) (void)hipEventDestroy(e);
     }
     free_pool(c->kp.allocs);
@@ -2694,6 +2695,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream2);
     (void)hipStreamDestroy(c->up_stream);
+    if (c->parse_stream) (void)hipStreamDestroy(c->parse_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2985,6 +2987,7 @@ static int kp_ensure_scratch(mc_ctx *c, int64_t cap_lines, int64_t n_tiles) {
     KpScratch &K = c->kp;
     if (K.cap_lines >= cap_lines && K.cap_tiles >= n_tiles) return 0;
     HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->parse_stream) HIP_TRY(hipStreamSynchronize(c->parse_stream));
     free_pool(K.allocs);
     K.cap_lines = std::max(cap_lines, K.cap_lines);
     K.cap_tiles = std::max(n_tiles, K.cap_tiles);
@@ -3003,6 +3006,7 @@ static int kp_set_contigs(mc_ctx *c, const char *const *names, int32_t n) {
     for (int i = 0; same && i < n; ++i) same = C.names[(size_t)i] == names[i];
     if (same) return 0;
     HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->parse_stream) HIP_TRY(hipStreamSynchronize(c->parse_stream));
     free_pool(C.allocs);
     C.names.assign(names, names + n);
     int size = 16;
@@ -3041,10 +3045,11 @@ static int kp_set_contigs(mc_ctx *c, const char *const *names, int32_t n) {
 }
 
 static int kp_ensure_slot(mc_ctx *c, TableSlot &S, int64_t n_bytes) {
-    if (!S.ev_parsed) HIP_TRY(hipEventCreate(&S.ev_parsed));
+    if (!S.ev_parsed) { HIP_TRY(hipEventCreate(&S.ev_parsed)); HIP_TRY(hipEventCreate(&S.ev_text_up)); }
     const int cap_segs = (int)std::min<int64_t>(S.cap_segs, 1 << 24);
     if (S.text && S.cap_text >= n_bytes + 64 && S.kp_cap_flags >= S.cap_rows && S.kp_cap_segs >= cap_segs) return 0;
     HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->parse_stream) HIP_TRY(hipStreamSynchronize(c->parse_stream));
     slot_free_parser(S);
     S.cap_text = std::max<int64_t>(n_bytes + n_bytes / 8, (int64_t)1 << 20) + 64;
     if (dev_alloc(S.kp_allocs, &S.text, (size_t)S.cap_text) || dev_alloc(S.kp_allocs, &S.kp_head, 1) ||
@@ -3079,17 +3084,29 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
     if (int rc = kp_ensure_scratch(c, S.cap_rows + 65536, n_tiles)) return rc;
     if (int rc = kp_set_contigs(c, contig_names, n_contigs)) return rc;
     KpScratch &K = c->kp;
-    hipStream_t us = c->up_stream;
-    HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));        // k_validate of the slot's previous table (it may never have been scanned)
-    HIP_TRY(hipEventRecord(S.ev_up_start, us));
-    static const KpHead zero_head = {0, 0, 0, 0, 0, 0x7fffffffffffffffll, 0, 0};
-    HIP_TRY(hipMemcpyAsync(S.kp_head, &zero_head, sizeof(KpHead), hipMemcpyHostToDevice, us));
-    if (n_bytes > 0) HIP_TRY(hipMemcpyAsync(S.text, text, (size_t)n_bytes, hipMemcpyHostToDevice, us));
+    if (!c->parse_stream) HIP_TRY(hipStreamCreateWithFlags(&c->parse_stream, hipStreamNonBlocking));
+    {   // the text on the upload stream, the kernels behind it on their own: the next shard's text travels while they run
+        hipStream_t up = c->up_stream;
+        HIP_TRY(hipStreamWaitEvent(up, S.ev_valid, 0));    // k_validate of the slot's previous table (it may never have been scanned)
+        HIP_TRY(hipEventRecord(S.ev_up_start, up));
+        static const KpHead zero_head = {0, 0, 0, 0, 0, 0x7fffffffffffffffll, 0, 0};
+        HIP_TRY(hipMemcpyAsync(S.kp_head, &zero_head, sizeof(KpHead), hipMemcpyHostToDevice, up));
+        if (n_bytes > 0) HIP_TRY(hipMemcpyAsync(S.text, text, (size_t)n_bytes, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipEventRecord(S.ev_text_up, up));
+    }
+    hipStream_t us = c->parse_stream;
+    const int kp_debug = getenv("MCALLER_KP_SYNC") ? atoi(getenv("MCALLER_KP_SYNC")) : 0;     // (finding the kernel that faults: bit i = wait behind step i)
+    int kp_step = 0;
+#define KP_STEP(name) do { if ((kp_debug >> kp_step++) & 1) { HIP_TRY(hipStreamSynchronize(us)); fprintf(stderr, "kp: %s ok\n", name); } } while (0)
+    HIP_TRY(hipStreamWaitEvent(us, S.ev_text_up, 0));
     if (n_tiles > 0) {
         hipLaunchKernelGGL(kp_count, dim3((unsigned)n_tiles), dim3(KP_THREADS), 0, us, (const char *)S.text, n_bytes, K.tile_cnt);
+        KP_STEP("kp_count");
         hipLaunchKernelGGL(kp_scan, dim3(1), dim3(1024), 0, us, (const long long *)K.tile_cnt, n_tiles, K.tile_off, &S.kp_head->n_newlines);
+        KP_STEP("kp_scan");
         hipLaunchKernelGGL(kp_starts, dim3((unsigned)n_tiles), dim3(KP_THREADS), 0, us, (const char *)S.text, n_bytes,
                            (const long long *)K.tile_off, K.line_start, K.cap_lines, S.kp_head);
+        KP_STEP("kp_starts");
         const int64_t cap_lines = K.cap_lines;
         const unsigned line_blocks = (unsigned)((cap_lines + 255) / 256);
         KpParseArgs PA;
@@ -3098,11 +3115,14 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
         PA.c_chars = c->kc.chars; PA.c_mask = c->kc.table_mask;
         PA.pos = K.pos; PA.idx = K.idx; PA.ev = K.ev; PA.mu = K.mu; PA.contig = K.contig; PA.name_off = K.name_off; PA.name_len = K.name_len;
         PA.fl = K.fl; PA.status = K.status;
-        hipLaunchKernelGGL(kp_parse, dim3(line_blocks), dim3(256), 0, us, PA);
+        hipLaunchKernelGGL(kp_parse, dim3(line_blocks), dim3(256), KP_STAGE + 16, us, PA);
+        KP_STEP("kp_parse");
         hipLaunchKernelGGL(kp_count_rows, dim3(line_blocks), dim3(256), 0, us, (const uint8_t *)K.status, (const KpHead *)S.kp_head,
                            cap_lines, K.tile_cnt);
+        KP_STEP("kp_count_rows");
         hipLaunchKernelGGL(kp_scan, dim3(1), dim3(1024), 0, us, (const long long *)K.tile_cnt, (int64_t)line_blocks, K.tile_off,
                            &S.kp_head->n_rows);
+        KP_STEP("kp_scan");
         KpPlaceArgs QA;
         QA.text = S.text; QA.head = S.kp_head; QA.head_w = S.kp_head; QA.cap_lines = cap_lines; QA.cap_rows = S.cap_rows;
         QA.blk_off = K.tile_off; QA.pos = K.pos; QA.idx = K.idx; QA.ev = K.ev; QA.mu = K.mu; QA.contig = K.contig;
@@ -3110,9 +3130,18 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
         QA.t_pos = S.pos; QA.t_idx = S.idx; QA.t_evmu = S.evmu; QA.t_flags = S.flags; QA.segs = S.kp_segs; QA.cap_segs = S.kp_cap_segs;
         QA.unknown = S.kp_unknown;
         hipLaunchKernelGGL(kp_place, dim3(line_blocks), dim3(256), 0, us, QA);
+        KP_STEP("kp_place");
     }
+    // what mc_ctx_parse_end hands out, on its way as soon as it exists: the head, the first segments and unknown tokens (a
+    // shard with more of them gets the rest when it is waited for), the flag column
     HIP_TRY(hipMemcpyAsync(S.kp_head_h, S.kp_head, sizeof(KpHead), hipMemcpyDeviceToHost, us));
+    HIP_TRY(hipMemcpyAsync(S.kp_segs_h, S.kp_segs, (size_t)std::min(S.kp_cap_segs, KP_EAGER_SEGS) * sizeof(KpSeg), hipMemcpyDeviceToHost, us));
+    HIP_TRY(hipMemcpyAsync(S.kp_unknown_h, S.kp_unknown, (size_t)KP_EAGER_UNKNOWN * sizeof(KpUnknown), hipMemcpyDeviceToHost, us));
+    HIP_TRY(hipMemcpyAsync(S.kp_flags_h, S.flags, (size_t)std::min<int64_t>(S.cap_rows, rows + rows / 4 + 4096), hipMemcpyDeviceToHost, us));
+    S.kp_flags_sent = std::min<int64_t>(S.cap_rows, rows + rows / 4 + 4096);
     HIP_TRY(hipEventRecord(S.ev_parsed, us));
+    KP_STEP("copies");
+#undef KP_STEP
     HIP_TRY(hipGetLastError());
     S.refs += 1;                                            // the slot is taken until mc_ctx_parse_finish / _abandon
     S.kp_state = 1;
@@ -3149,11 +3178,10 @@ extern "C" int mc_ctx_parse_end(mc_ctx *c, int32_t slot, mc_devparse_result *out
                          H.n_seg, H.n_unknown);
         return 0;
     }
-    hipStream_t us = c->up_stream;
-    if (H.n_seg > 0) HIP_TRY(hipMemcpyAsync(S.kp_segs_h, S.kp_segs, (size_t)H.n_seg * sizeof(KpSeg), hipMemcpyDeviceToHost, us));
-    if (H.n_unknown > 0) HIP_TRY(hipMemcpyAsync(S.kp_unknown_h, S.kp_unknown, (size_t)H.n_unknown * sizeof(KpUnknown), hipMemcpyDeviceToHost, us));
-    if (H.n_rows > 0) HIP_TRY(hipMemcpyAsync(S.kp_flags_h, S.flags, (size_t)H.n_rows, hipMemcpyDeviceToHost, us));
-    HIP_TRY(hipStreamSynchronize(us));
+    // (what did not travel with the head: blocking copies -- the streams are busy with the next shard)
+    if (H.n_seg > KP_EAGER_SEGS) HIP_TRY(hipMemcpy(S.kp_segs_h, S.kp_segs, (size_t)H.n_seg * sizeof(KpSeg), hipMemcpyDeviceToHost));
+    if (H.n_unknown > KP_EAGER_UNKNOWN) HIP_TRY(hipMemcpy(S.kp_unknown_h, S.kp_unknown, (size_t)H.n_unknown * sizeof(KpUnknown), hipMemcpyDeviceToHost));
+    if (H.n_rows > S.kp_flags_sent) HIP_TRY(hipMemcpy(S.kp_flags_h, S.flags, (size_t)H.n_rows, hipMemcpyDeviceToHost));
     // segments and unknown lines were listed in the order the lanes got there: file order is by row / by line
     std::sort(S.kp_segs_h, S.kp_segs_h + H.n_seg, [](const KpSeg &a, const KpSeg &b) { return a.row < b.row; });
     std::sort(S.kp_unknown_h, S.kp_unknown_h + H.n_unknown, [](const KpUnknown &a, const KpUnknown &b) { return a.line < b.line; });
@@ -3218,6 +3246,7 @@ extern "C" int mc_ctx_fetch_columns(mc_ctx *c, int32_t slot, int64_t n_rows, int
     }
     TableSlot &S = c->slots[slot];
     HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->parse_stream) HIP_TRY(hipStreamSynchronize(c->parse_stream));
     if (n_rows == 0) return 0;
     if (pos) HIP_TRY(hipMemcpy(pos, S.pos, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
     if (event_model_e4) HIP_TRY(hipMemcpy(event_model_e4, S.evmu, (size_t)n_rows * 8, hipMemcpyDeviceToHost));
@@ -3822,6 +3851,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
 
 static int sync_pass_streams(mc_ctx *c) {
     if (c->up_stream) HIP_TRY(hipStreamSynchronize(c->up_stream));
+    if (c->parse_stream) HIP_TRY(hipStreamSynchronize(c->parse_stream));
     if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));

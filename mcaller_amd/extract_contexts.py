@@ -76,6 +76,12 @@ def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, 
     if ref is None:
         ref = MarkedReference(fasta_input, base, motif, positions_list)
     table = _lib.parse_eventalign(tsv_input, startline, endline, ref.names, n_threads, exact_range=exact_range)
+    return prepare_table(P, table, ref, read2qual, quiet)
+
+
+def prepare_table(P, table, ref, read2qual, quiet=False):
+    """The part of `prepare` behind the parser: contigs marked as they first appear, read qualities looked up.  `table`: from
+    the host parser, or made on the device (Device.parse_end)."""
     P.messages = ['Error: could not find sequence for reference contig ' + name for name in table.unknown]   # :159
     if not quiet:
         for line in P.messages:
@@ -94,7 +100,7 @@ def prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, 
             P.fatal = e
             cut_seg = seg
             break
-    if cut_seg is not None:
+    if cut_seg is not None and table.pos is not None:      # (a device-parsed table is only ever streamed: fatal sends the file to the one-table path)
         table = table.slice_segments(0, cut_seg)
     P.ref, P.table, P.qual_obj = ref, table, qual_obj
     P.qual = np.array([float(q) if q is not None else np.nan for q in qual_obj], dtype=np.float64)
@@ -359,23 +365,52 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=2)
 
+    # The text is parsed on the GPU (mc_ctx_parse_*: the host threads only move the bytes into pinned memory -- on a box whose
+    # CPU time is rationed the parse is what a file costs) unless MCALLER_HOST_PARSER is set; a shard the device parser
+    # declines (a number form that needs strtod, ...) goes through the host parser.
+    on_device = not os.environ.get('MCALLER_HOST_PARSER')
+    if on_device:
+        biggest = max(b - a for a, b in pieces)
+        rows_cap = biggest // 48 + 65536
+        dev.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
+    clock['device_parsed'] = 0
+
     def parse_shard(lo_i, hi_i):
         t_p = time.perf_counter()
-        P_i = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
+        if on_device:
+            out = _lib.TextBlock(tsv_input, lo_i, hi_i)
+        else:
+            out = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
         clock['parse'] += time.perf_counter() - t_p
-        return P_i
+        return out
 
-    ahead = []                      # futures of the shards being parsed, in file order
+    ahead = []                      # futures of the shards being read / parsed by the host threads, in file order
+    parsing = []                    # (slot, text, piece) of the shards the device is parsing, in file order
     next_piece = [0]
 
     def next_shard():
-        """The next shard in file order (None behind the last); keeps the parser threads busy."""
+        """The next shard in file order (None behind the last); keeps the parser threads (and the device parser) busy."""
         while next_piece[0] < len(pieces) and len(ahead) < 3:
-            ahead.append(pool.submit(parse_shard, *pieces[next_piece[0]]))
+            ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
             next_piece[0] += 1
-        if not ahead:
+        if not on_device:
+            return ahead.pop(0)[0].result() if ahead else None
+        while ahead and len(parsing) < 2:
+            fut, piece = ahead.pop(0)
+            text = fut.result()
+            parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
+            while next_piece[0] < len(pieces) and len(ahead) < 3:
+                ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
+                next_piece[0] += 1
+        if not parsing:
             return None
-        return ahead.pop(0).result()
+        slot, text, piece = parsing.pop(0)
+        table = dev.parse_end(slot, text)
+        if table is None:                                      # declined: the host parser takes the shard
+            return prepare(tsv_input, None, read2qual, piece[0], piece[1], base, motif, positions_list, exact_range=True, ref=ref,
+                           quiet=True)
+        clock['device_parsed'] += 1
+        return prepare_table(Prepared(), table, ref, read2qual, quiet=True)
 
     blobs, messages, names_seen = [], [], set()
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
@@ -450,10 +485,16 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             hand_out()
     except BaseException:
         next_piece[0] = len(pieces)
-        for f in ahead:
+        for f, _ in ahead:
             f.cancel()
         try:
             dev.sync()
+            for slot, _, _ in parsing:                         # tables the device parser was filling: their slots go back
+                dev.parse_abandon(slot)
+            for P_left in (locals().get('P'), locals().get('prev')):
+                if P_left is not None and getattr(P_left.table, 'device_slot', None) is not None:
+                    dev.parse_abandon(P_left.table.device_slot)
+                    P_left.table.device_slot = None
             while in_flight:                                   # nothing may stay in flight on the shared device
                 in_flight.pop(0)
                 dev.wait()
@@ -500,10 +541,10 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
             write_text(text, tsv_output)                                          # :293
             if timing:
                 ck = getattr(stream_features, 'last_clock', {})
-                print('[mcaller_amd timing] streamed in %s shards: total %.3f s | parser thread %.3f s | main thread: waiting for '
-                      'the parser %.3f, upload + enqueue %.3f, wait + format %.3f' % (
-                          ck.get('shards'), time.perf_counter() - t_start, ck.get('parse', 0), ck.get('wait_parser', 0),
-                          ck.get('enqueue', 0), ck.get('hand_out', 0)), file=sys.stderr)
+                print('[mcaller_amd timing] streamed in %s shards (%s parsed on the device): total %.3f s | reader / parser threads '
+                      '%.3f s | main thread: waiting for the next table %.3f, upload + enqueue %.3f, wait + format %.3f' % (
+                          ck.get('shards'), ck.get('device_parsed'), time.perf_counter() - t_start, ck.get('parse', 0),
+                          ck.get('wait_parser', 0), ck.get('enqueue', 0), ck.get('hand_out', 0)), file=sys.stderr)
             for line in counters:                                                 # :295-301
                 print(line)
             return None

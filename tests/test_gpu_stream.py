@@ -140,7 +140,7 @@ def test_upload_while_passes_are_in_flight(dev, setup):
         t, q = synth.make_table(5000 + i, seed=80 + i, codes=codes, read_len=(300, 900))
         tables.append((t.pinned(), q))
     n_ok = 0
-    with pytest.raises(_lib.McError, match='table slots'):
+    with pytest.raises(_lib.McError, match='table slots|passes are in flight'):      # (eight slots, four passes in flight)
         for t, q in tables + tables:
             dev.upload_table_async(t, q)
             dev.run_async(6, 0, 0.0, score=True)
