@@ -171,7 +171,7 @@ int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/*
  * mc_ctx_wait_upload(slot) returns.  A slot is free again when every pass that scanned its table has been handed out by
  * mc_wait_records (and the next pass after it: the last records handed out may still be reduced by mc_site_counts); with
  * no free slot the call fails (-12): wait for a pass first. */
-#define MC_TABLE_SLOTS 8
+#define MC_TABLE_SLOTS 12
 int mc_ctx_reserve_tables(mc_ctx *ctx, int64_t max_rows, int32_t max_segs, int32_t max_reads);
 int mc_ctx_upload_table_async(mc_ctx *ctx, const mc_table_view *host_table, const double *read_qual, int32_t *slot);
 int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);

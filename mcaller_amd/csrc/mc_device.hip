@@ -2395,6 +2395,22 @@ static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads)
 
 #include "mc_devparse.inc"
 
+// dst / src: device memory or pinned host memory (hipHostMalloc), both 16-byte aligned
+static int copy_by_kernel(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    void *d = dst;
+    const void *s = src;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, dst) == hipSuccess && a.type == hipMemoryTypeHost) HIP_TRY(hipHostGetDevicePointer(&d, dst, 0));
+    else (void)hipGetLastError();
+    if (hipPointerGetAttributes(&a, src) == hipSuccess && a.type == hipMemoryTypeHost) HIP_TRY(hipHostGetDevicePointer((void **)&s, const_cast<void *>(src), 0));
+    else (void)hipGetLastError();
+    const unsigned blocks = (unsigned)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, st, (unsigned char *)d, (const unsigned char *)s, bytes);
+    return 0;
+}
+constexpr size_t COPY_BY_KERNEL_MAX = (size_t)4 << 20;      // larger transfers go to the DMA engines
+
 struct TableSlot {
     DevTable T;                        // the table in the slot (pointers into the slot's allocations)
     int64_t cap_rows = 0, cap_segs = 0, cap_reads = 0;
@@ -2932,7 +2948,9 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
 
     // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out), then the per-table kernel on
     //      the ctx stream behind the transfer ----
-    hipStream_t us = c->up_stream;
+    // (a device-parsed table: the upload stream is busy with the NEXT shard's text by now -- the small arrays go on the ctx
+    // stream, in front of the kernels that read them)
+    hipStream_t us = cols ? c->up_stream : c->stream;
     if (cols) {
         HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));    // k_validate of the slot's previous table (it may never have been scanned)
         HIP_TRY(hipEventRecord(S.ev_up_start, us));
@@ -2943,7 +2961,8 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
             HIP_TRY(hipMemcpyAsync(T.flags, cols->flags, (size_t)n, hipMemcpyHostToDevice, us));
         }
     }
-    HIP_TRY(hipMemcpyAsync(dv, st, L.total, hipMemcpyHostToDevice, us));
+    if (!cols && L.total <= COPY_BY_KERNEL_MAX) { if (int rc = copy_by_kernel(dv, st, L.total, us)) return rc; }     // (not behind the next shard's text)
+    else HIP_TRY(hipMemcpyAsync(dv, st, L.total, hipMemcpyHostToDevice, us));
     HIP_TRY(hipEventRecord(S.ev_uploaded, us));
     HIP_TRY(hipStreamWaitEvent(c->stream, S.ev_uploaded, 0));
     HIP_TRY(hipEventRecord(S.ev_val_start, c->stream));
@@ -3134,11 +3153,12 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
     }
     // what mc_ctx_parse_end hands out, on its way as soon as it exists: the head, the first segments and unknown tokens (a
     // shard with more of them gets the rest when it is waited for), the flag column
-    HIP_TRY(hipMemcpyAsync(S.kp_head_h, S.kp_head, sizeof(KpHead), hipMemcpyDeviceToHost, us));
-    HIP_TRY(hipMemcpyAsync(S.kp_segs_h, S.kp_segs, (size_t)std::min(S.kp_cap_segs, KP_EAGER_SEGS) * sizeof(KpSeg), hipMemcpyDeviceToHost, us));
-    HIP_TRY(hipMemcpyAsync(S.kp_unknown_h, S.kp_unknown, (size_t)KP_EAGER_UNKNOWN * sizeof(KpUnknown), hipMemcpyDeviceToHost, us));
-    HIP_TRY(hipMemcpyAsync(S.kp_flags_h, S.flags, (size_t)std::min<int64_t>(S.cap_rows, rows + rows / 4 + 4096), hipMemcpyDeviceToHost, us));
-    S.kp_flags_sent = std::min<int64_t>(S.cap_rows, rows + rows / 4 + 4096);
+    // (by kernel: a DMA transfer would queue behind the text of the shards that follow)
+    S.kp_flags_sent = std::min<int64_t>(S.cap_rows, std::min<int64_t>(rows + rows / 4 + 4096, (int64_t)COPY_BY_KERNEL_MAX));
+    if (int rc = copy_by_kernel(S.kp_segs_h, S.kp_segs, (size_t)std::min(S.kp_cap_segs, KP_EAGER_SEGS) * sizeof(KpSeg), us)) return rc;
+    if (int rc = copy_by_kernel(S.kp_unknown_h, S.kp_unknown, (size_t)KP_EAGER_UNKNOWN * sizeof(KpUnknown), us)) return rc;
+    if (int rc = copy_by_kernel(S.kp_flags_h, S.flags, (size_t)S.kp_flags_sent, us)) return rc;
+    if (int rc = copy_by_kernel(S.kp_head_h, S.kp_head, sizeof(KpHead), us)) return rc;
     HIP_TRY(hipEventRecord(S.ev_parsed, us));
     KP_STEP("copies");
 #undef KP_STEP
@@ -3888,7 +3908,10 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         const int k = b.k;
         const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
         const PackLayout L = pack_layout((int64_t)n, b.close32 ? 1 : 0);
-        HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, L.feats + m * ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, cs));
+        const size_t out_bytes = L.feats + m * ((size_t)k + 1) * 8;
+        // (a small record set -- a shard of a streamed file -- by kernel: the DMA engines may be busy with text, see k_copy_bytes)
+        if (out_bytes <= COPY_BY_KERNEL_MAX / 4) { if (int rc = copy_by_kernel(b.pack_host, b.pack, out_bytes, cs)) return rc; }
+        else HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, out_bytes, hipMemcpyDeviceToHost, cs));
         b.H.close_row = b.close32 ? nullptr : reinterpret_cast<int64_t *>(b.pack_host);
         b.h_close32 = b.close32 ? reinterpret_cast<int32_t *>(b.pack_host) : nullptr;
         b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + L.pos);

@@ -374,6 +374,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         rows_cap = biggest // 48 + 65536
         dev.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
     clock['device_parsed'] = 0
+    clock['events'] = []            # (MCALLER_TIMING=2: when the main thread did what)
+    t_zero = time.perf_counter()
+
+    def mark(what):
+        clock['events'].append((time.perf_counter() - t_zero, what))
 
     def parse_shard(lo_i, hi_i):
         t_p = time.perf_counter()
@@ -384,6 +389,24 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         clock['parse'] += time.perf_counter() - t_p
         return out
 
+    def mark_ahead():
+        """The first contig of the file is marked while the first shards are read and sent (marking E. coli takes 14 ms; the main
+        thread would do it when the first table comes back, with the GPU waiting).  An exit path of the marking is left to
+        the main thread: it marks again and meets it there."""
+        try:
+            with open(tsv_input, 'rb') as fh:
+                fh.seek(pieces[0][0])
+                for line in fh.read(1 << 16).splitlines():
+                    tok = line.split()
+                    if len(tok) >= 12 and tok[0].decode('utf-8', 'surrogateescape') in ref.names:
+                        cid = ref.names.index(tok[0].decode('utf-8', 'surrogateescape'))
+                        ref.mark(cid)                          # (ref.quiet: nothing is printed from here)
+                        ref.device_arrays()                    # (cached: the main thread's set_reference finds them made)
+                        return
+        except BaseException:                                  # noqa
+            pass
+
+    mark_thread = []                # started behind the first parse_begin: the readers and the first transfers do not wait for the interpreter lock
     ahead = []                      # futures of the shards being read / parsed by the host threads, in file order
     parsing = []                    # (slot, text, piece) of the shards the device is parsing, in file order
     next_piece = [0]
@@ -395,22 +418,32 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             next_piece[0] += 1
         if not on_device:
             return ahead.pop(0)[0].result() if ahead else None
-        while ahead and len(parsing) < 2:
+        while ahead and len(parsing) < 6:          # (their text goes over the link back to back; 12 table slots)
             fut, piece = ahead.pop(0)
             text = fut.result()
+            mark('text ready')
             parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
+            mark('parse_begin done')
+            if not mark_thread:
+                import threading
+                mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
+                mark_thread[0].start()
             while next_piece[0] < len(pieces) and len(ahead) < 3:
                 ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
                 next_piece[0] += 1
         if not parsing:
             return None
         slot, text, piece = parsing.pop(0)
+        mark('parse_end ...')
         table = dev.parse_end(slot, text)
+        mark('parse_end done')
         if table is None:                                      # declined: the host parser takes the shard
             return prepare(tsv_input, None, read2qual, piece[0], piece[1], base, motif, positions_list, exact_range=True, ref=ref,
                            quiet=True)
         clock['device_parsed'] += 1
-        return prepare_table(Prepared(), table, ref, read2qual, quiet=True)
+        P_new = prepare_table(Prepared(), table, ref, read2qual, quiet=True)
+        mark('prepared')
+        return P_new
 
     blobs, messages, names_seen = [], [], set()
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
@@ -427,7 +460,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
 
     def _hand_out():
         P, tail = in_flight.pop(0)
+        mark('wait ...')
         rec = dev.wait()
+        mark('records here')
         fin = Finisher(P, k, base, False, modelset=modelset, device=dev, tail_chrom=tail)
         with contextlib.redirect_stdout(io.StringIO()):        # (its exit paths print; the one-table path will)
             stop = fin.run(rec)
@@ -475,7 +510,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 while len(in_flight) >= 2:
                     hand_out()
                 t_e = time.perf_counter()
+                mark('enqueue ...')
                 enqueue(prev, tail_id)
+                mark('enqueued')
                 clock['enqueue'] += time.perf_counter() - t_e
                 in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None))
             prev = P
@@ -545,6 +582,9 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
                       '%.3f s | main thread: waiting for the next table %.3f, upload + enqueue %.3f, wait + format %.3f' % (
                           ck.get('shards'), ck.get('device_parsed'), time.perf_counter() - t_start, ck.get('parse', 0),
                           ck.get('wait_parser', 0), ck.get('enqueue', 0), ck.get('hand_out', 0)), file=sys.stderr)
+            if timing == '2':
+                for t_ev, what in getattr(stream_features, 'last_clock', {}).get('events', []):
+                    print('[mcaller_amd timing] %8.2f ms %s' % (t_ev * 1e3, what), file=sys.stderr)
             for line in counters:                                                 # :295-301
                 print(line)
             return None

@@ -131,6 +131,9 @@ class MarkedReference(object):
         self.meth = {}                                  # contig id -> (meth_fwd, meth_rev)
         self.quiet = False                              # the exit paths of the marking do not print
         self._arrays = (None, None)
+        self._upper = {}
+        import threading
+        self._lock = threading.RLock()
 
     def first_index(self):
         idx = {}
@@ -138,12 +141,19 @@ class MarkedReference(object):
             idx.setdefault(n, i)                        # first record with that id wins (:77-81)
         return idx
 
+    def upper(self, contig_id):
+        """The contig's sequence in upper case (:79), made once."""
+        if contig_id not in self._upper:
+            self._upper[contig_id] = self.records[contig_id][1].upper()
+        return self._upper[contig_id]
+
     def mark(self, contig_id):
-        if contig_id not in self.meth:
-            name, seq = self.records[contig_id]
-            self.meth[contig_id] = methylate_references(seq.upper(), self.base, motif=self.motif,
-                                                        positions=self.positions_list, contig=name, quiet=self.quiet)
-        return self.meth[contig_id]
+        with self._lock:                                # (a streamed file marks its first contig ahead of time, in a thread)
+            if contig_id not in self.meth:
+                name, seq = self.records[contig_id]
+                self.meth[contig_id] = methylate_references(self.upper(contig_id), self.base, motif=self.motif,
+                                                            positions=self.positions_list, contig=name, quiet=self.quiet)
+            return self.meth[contig_id]
 
     def device_arrays(self):
         """Concatenated arrays for mc_ref_view (unmarked contigs: empty sequence, all-zero masks)."""
@@ -165,7 +175,7 @@ class MarkedReference(object):
             seq_off[cid], word_off[cid] = so, wo
             if cid in self.meth:
                 mf, mr = self.meth[cid]
-                s = np.frombuffer(self.records[cid][1].upper().encode('latin1'), dtype=np.uint8)
+                s = np.frombuffer(self.upper(cid).encode('latin1'), dtype=np.uint8)
                 contig_len[cid] = len(s)
                 bf, br = m_bitmask(mf), m_bitmask(mr)
                 if len(bf) != len(br):                  # cannot happen: both come from one sequence

@@ -304,3 +304,40 @@ def test_streamed_rows_equal_the_python_oracle(tmp_path, monkeypatch):
     want = ''.join('\t'.join(r) + '\n' for r in res['rows'])
     assert text == want and len(res['rows']) > 30
     assert stdout == [l for l in res['stdout'] if l.strip()] or stdout[-6:] == [l for l in res['stdout'] if l.strip()][-6:]
+
+
+@pytest.mark.parametrize('host_parser', [False, True])
+def test_streamed_file_with_a_shard_the_device_parser_declines(tmp_path, monkeypatch, host_parser):
+    """One row in the middle writes its event mean with an exponent (float() takes it, the device parser's plain-decimal form does
+    not): that shard goes through the host parser, the others stay on the device; and the whole file through the host parser
+    (MCALLER_HOST_PARSER).  Same bytes as the one-table path either way."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=400000, seed=5)
+    table, qual = synth.make_table(240000, seed=3, codes=codes, read_len=(700, 4000))
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    paths['positions'] = None
+    lines = open(paths['tsv']).read().split('\n')
+    t = lines[130000].split('\t')
+    t[6] = '%.6e' % float(t[6])                                 # e.g. 8.123000e+01: the same value to float()
+    assert float(t[6]) == float(lines[130000].split('\t')[6])
+    lines[130000] = '\t'.join(t)
+    open(paths['tsv'], 'w').write('\n'.join(lines))
+    args = dict(k=6, skip_thresh=0, qual_thresh=0.0, base='A', motif='GATC', model='r95')
+    if host_parser:
+        monkeypatch.setenv('MCALLER_HOST_PARSER', '1')
+    clocks = []
+    real = ec.stream_features
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        clocks.append(dict(ec.stream_features.last_clock))
+        return out
+    monkeypatch.setattr(ec, 'stream_features', spy)
+    got = _run_extract(paths, args, monkeypatch, shards=6)
+    assert clocks and clocks[0]['shards'] == 6
+    assert clocks[0]['device_parsed'] == (0 if host_parser else 5)
+    monkeypatch.delenv('MCALLER_HOST_PARSER', raising=False)
+    want = _run_extract(paths, args, monkeypatch, shards=0)
+    assert got[0] == want[0] == 'ok' and got[2] == want[2]
+    assert got[1] == want[1] and len(got[1]) > 1000

@@ -19,7 +19,7 @@ with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
         q = int(round(qual[i]))
         fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + q) * 10))
 print('inputs written in %.1f s: %.1f MB of TSV, %d rows' % (time.time() - t, os.path.getsize(tsv) / 1e6, table.n_rows))
-os.environ['MCALLER_TIMING'] = '1'
+os.environ['MCALLER_TIMING'] = os.environ.get('MCALLER_TIMING', '1')
 model = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mcaller_amd', 'models', 'r95_twobase_model_NN_6_m6A.npz')
 for rep in range(6):
     out = tsv[:-4] + '.diffs.6'
