@@ -380,10 +380,76 @@ def main():
                             'seconds_first_run': runs[0], 'seconds_best': best, 'seconds_all': runs,
                             'events_per_s': f2f_rows / best, 'calls_per_s': calls_f / best,
                             'host_cores': len(os.sched_getaffinity(0)), 'inputs_written_s': t_w,
-                            'what': 'python -m mcaller_amd.mCaller -m GATC: FASTQ qualities, FASTA marking, native parser, '
-                                    'shards streamed through the GPU, native row formatter, .diffs.6 written (page cache warm)'}
+                            'what': 'python -m mcaller_amd.mCaller -m GATC: FASTQ qualities, FASTA marking, the text read into pinned '
+                                    'memory and parsed on the GPU (mc_ctx_parse_*), shards streamed through the table slots, native row '
+                                    'formatter, .diffs.6 written (page cache warm)'}
         except Exception as e:                                  # noqa
             file_to_file = {'error': '%s: %s' % (type(e).__name__, e)}
+
+    # ---- text end to end: the same file, its text already in pinned host memory, parsed on the GPU shard after shard, a pass
+    #      over every shard, records back in host memory (N = 1): what the link allows for eventalign TEXT ----
+    text_e2e = None
+    if file_to_file and 'error' not in file_to_file:
+        try:
+            from mcaller_amd import _lib
+            from mcaller_amd import extract_contexts as ec
+            from mcaller_amd.read_qual import extract_read_quality
+            from mcaller_amd.refmark import MarkedReference
+            d2 = ec.get_device()                                 # (the CLI runs above left reference and classifier in place)
+            tsv = f2f_paths['tsv']
+            ref2 = MarkedReference(f2f_paths['fasta'], 'A', 'GATC', None)
+            ref2.quiet = True
+            ref2.mark(0)
+            d2.set_reference(ref2.device_arrays())
+            r2q = extract_read_quality(f2f_paths['fastq'])
+            lo, hi = _lib.eventalign_consumed_range(tsv, 0, os.path.getsize(tsv))
+            cuts = _lib.eventalign_read_cuts(tsv, 8, lo, hi)
+            texts = [_lib.TextBlock(tsv, cuts[i], cuts[i + 1]) for i in range(8) if cuts[i + 1] > cuts[i]]
+            rows_cap = max(t.n_bytes for t in texts) // 48 + 65536
+            d2.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
+
+            def text_once():
+                calls, rows, in_flight, parsing = 0, 0, 0, []
+                t_s = time.perf_counter()
+
+                def finish_one(last):
+                    nonlocal calls, rows, in_flight
+                    slot, text = parsing.pop(0)
+                    table = d2.parse_end(slot, text)
+                    P_t = ec.prepare_table(ec.Prepared(), table, ref2, r2q, quiet=True)
+                    rows += table.n_rows
+                    d2.upload_table_async(P_t.table, P_t.qual)
+                    d2.run_async(6, 0, 0.0, tail_contig=(-1 if last else 0), score=True)
+                    in_flight += 1
+                    if in_flight > 2:
+                        calls += d2.wait().n_calls
+                        in_flight -= 1
+                for i, text in enumerate(texts):
+                    parsing.append((d2.parse_begin(text, ref2.names, rows_cap), text))
+                    if len(parsing) > 3:
+                        finish_one(False)
+                while parsing:
+                    finish_one(len(parsing) == 1)
+                while in_flight:
+                    calls += d2.wait().n_calls
+                    in_flight -= 1
+                d2.sync()
+                return time.perf_counter() - t_s, calls, rows
+
+            text_once()
+            runs_t = sorted((text_once() for _ in range(5)), key=lambda x: x[0])
+            best_t, n_bytes_t = runs_t[0], sum(t.n_bytes for t in texts)
+            text_e2e = {'shards': len(texts), 'text_bytes': n_bytes_t, 'rows': best_t[2], 'calls': best_t[1],
+                        'seconds_best': best_t[0], 'seconds_median': runs_t[len(runs_t) // 2][0],
+                        'events_per_s': best_t[2] / best_t[0], 'calls_per_s': best_t[1] / best_t[0],
+                        'text_GBps': n_bytes_t / best_t[0] / 1e9,
+                        'fraction_of_h2d_rate': (n_bytes_t / best_t[0] / 1e9) / device_e2e['h2d_only_GBps']
+                        if device_e2e and 'h2d_only_GBps' in device_e2e else None,
+                        'what': 'eventalign text in pinned host memory -> mc_ctx_parse_begin/_end/_finish (line starts, tokens, '
+                                'numbers, segments on the GPU) -> K0-K2 -> records in host memory; three shards of text ahead'}
+            del texts
+        except Exception as e:                                  # noqa
+            text_e2e = {'error': '%s: %s' % (type(e).__name__, e)}
 
     if rank == 0:
         k1 = float(np.mean(k1_ms))
@@ -431,7 +497,7 @@ def main():
                        'calls_per_s_kernels_only': n_calls / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
                        'device_e2e': device_e2e,
                        'device_e2e_events_per_s': (device_e2e or {}).get('events_per_s'),
-                       'file_to_file': file_to_file},
+                       'file_to_file': file_to_file, 'text_e2e': text_e2e},
             'roofline': {'bound': 'hbm', 'kernel': 'k1_scan',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -1,4 +1,5 @@
-"""A small copy beside a big one: the DMA engines take transfers in submission order whatever the stream (why the streaming path\nmoves its small transfers with a kernel, k_copy_bytes)."""
+"""A small copy beside a big one: the DMA engines take transfers in submission order whatever the stream (why the streaming
+path moves its small transfers with a kernel, k_copy_bytes)."""
 import torch, time
 big_h = torch.empty(150 << 20, dtype=torch.uint8).pin_memory()
 big_d = torch.empty(150 << 20, dtype=torch.uint8, device='cuda')
