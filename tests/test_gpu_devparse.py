@@ -128,3 +128,71 @@ def test_number_forms_that_need_the_host(dev, tmp_path):
     assert_same_table(dev, host, t, slot)
     assert t.n_rows == 3 and t.read_names == ['read1', 'read2']
     dev.parse_abandon(slot)
+
+
+def test_random_text_against_the_host_parser(dev, tmp_path):
+    """Seeded random files: odd whitespace, dropped tokens, blank lines, every number form float()/int() accept or reject, unknown
+    contigs, read names that come back, with and without a final newline.  Where the host parser raises the device parser must
+    decline; where it declines nothing is claimed; everywhere else every column is the host parser's."""
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(20261002)
+    seps = ['\t', '\t', '\t', ' ', '  ', '\t ', '\x0b', '\x0c', '\x1c']
+    ints = ['0', '7', '42', '+5', '-3', '123456', '2147483647', '2147483648', '12x', '', '1.0', '1e3', '٣']
+    floats = ['80.5', '79.25', '0.1234', '.5', '5.', '+81.0', '-3.75', '100', '80.12345', '8.05e1', 'inf', 'nan', '1_0.5', '0x1p3',
+              '999999999.9999', '1234567890.1', '--1', '80,5']
+    kmers = ['AAAAAA', 'ACGTAC', 'NNNNNN', 'acgtac', 'AAAAA', 'AAAAAAA']
+    contigs = ['c1', 'c2', 'chr_long_name.1', 'nope', 'C1', 'c1x']
+    names = ['r%d' % i for i in range(6)] + ['read-with-a-much-longer-name_0123456789abcdef', 'r0']
+    n_same = n_declined = n_raise = 0
+    for case in range(300):
+        n_lines = int(rng.integers(1, 400))
+        mode = case % 3                                 # 0: only forms the fast path takes; 1: anything; 2: odd but valid forms
+        weird = mode > 0
+        ints_m = ints if mode == 1 else ['0', '7', '+5', '-3', '2147483647', '00012']
+        floats_m = floats if mode == 1 else ['.5', '5.', '+81.0', '-3.75', '100', '80.12345', '8.05e1', '1E2', '0080.50']
+        lines, name = [], names[0]
+        for i in range(n_lines):
+            if rng.random() < 0.1:
+                name = names[int(rng.integers(len(names)))]
+            u = rng.random()
+            if weird and u < 0.03:
+                lines.append('')
+                continue
+            if weird and u < 0.06:
+                lines.append(seps[int(rng.integers(len(seps)))].join(['c1', '5', 'AAAAAA'][:int(rng.integers(1, 4))]))
+                continue
+            pick_i = (lambda: ints_m[int(rng.integers(len(ints_m)))]) if weird and rng.random() < 0.05 else (lambda: str(int(rng.integers(0, 5000))))
+            pick_f = (lambda: floats_m[int(rng.integers(len(floats_m)))]) if weird and rng.random() < 0.05 else (lambda: '%.2f' % rng.uniform(50, 120))
+            k1, k2 = kmers[int(rng.integers(len(kmers)))] if weird else 'ACGTAC', kmers[int(rng.integers(3))]
+            contig = contigs[int(rng.integers(len(contigs)))] if rng.random() < (0.15 if weird else 0.02) else 'c1'
+            tok = [contig, pick_i(), k1, name, 't', pick_i(), pick_f(), '1.0', '0.001', k2, pick_f(), '1.0', '0.1']
+            if mode == 1 and rng.random() < 0.02:
+                tok = tok[:int(rng.integers(10, 13))]
+            if weird and rng.random() < 0.02:
+                tok += ['extra', 'tokens']
+            sep = (lambda: seps[int(rng.integers(len(seps)))]) if weird else (lambda: '\t')
+            line = ''.join(t + sep() for t in tok[:-1]) + tok[-1]
+            if weird and rng.random() < 0.05:
+                line = ' ' + line + ' \r'
+            lines.append(line)
+        body = '\n'.join(lines) + ('\n' if rng.random() < 0.8 else '')
+        p = str(tmp_path / ('r%d.tsv' % case))
+        open(p, 'w', encoding='utf-8').write(body)
+        size = os.path.getsize(p)
+        text = _lib.TextBlock(p, 0, size)
+        slot = dev.parse_begin(text, ['c1', 'c2', 'chr_long_name.1', 'c1'], 4096)
+        t = dev.parse_end(slot, text)
+        try:
+            host = _lib.parse_eventalign(p, 0, size, ['c1', 'c2', 'chr_long_name.1', 'c1'], exact_range=True)
+        except _lib.McError:
+            assert t is None, 'case %d: the host parser raises, the device parser did not decline' % case
+            n_raise += 1
+            continue
+        if t is None:
+            n_declined += 1
+            continue
+        assert_same_table(dev, host, t, slot)
+        dev.parse_abandon(slot)
+        n_same += 1
+    print('random text: %d files column for column, %d declined, %d malformed' % (n_same, n_declined, n_raise))
+    assert n_same >= 100 and n_raise >= 10 and n_declined >= 10
