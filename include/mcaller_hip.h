@@ -97,6 +97,11 @@ const char *mc_version(void);
 /* Cores this process may run on (sched_getaffinity) -- what the parser, the FASTQ reader and the row formatter size their
  * thread counts by when n_threads <= 0: a worker bound to its GPU's NUMA node starts one thread per core of that node. */
 int mc_host_cores(void);
+/* The marking of a contig for a motif (extract_contexts.py:33-41,:60-73) without the interpreter lock: upper_out = seq
+ * upper-cased (ASCII), fwd_out / rev_out = upper_out with every occurrence of motif_fwd / motif_rev (left to right,
+ * non-overlapping, like str.replace) replaced by repl_fwd / repl_rev of the same length; all buffers n bytes. */
+int mc_mark_motifs(const char *seq, int64_t n, const char *motif_fwd, const char *repl_fwd, int32_t m_fwd,
+                   const char *motif_rev, const char *repl_rev, int32_t m_rev, char *upper_out, char *fwd_out, char *rev_out);
 
 /* ===== pinned host memory, recycled =====
  * The DMA engines read a table at PCIe speed, beside running kernels, only from pinned memory.  Blocks handed back with

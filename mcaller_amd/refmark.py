@@ -132,6 +132,7 @@ class MarkedReference(object):
         self.quiet = False                              # the exit paths of the marking do not print
         self._arrays = (None, None)
         self._upper = {}
+        self._upper_bytes = {}
         import threading
         self._lock = threading.RLock()
 
@@ -144,11 +145,39 @@ class MarkedReference(object):
     def upper(self, contig_id):
         """The contig's sequence in upper case (:79), made once."""
         if contig_id not in self._upper:
-            self._upper[contig_id] = self.records[contig_id][1].upper()
+            if contig_id in self._upper_bytes:
+                self._upper[contig_id] = str(memoryview(self._upper_bytes[contig_id]), 'ascii')
+            else:
+                self._upper[contig_id] = self.records[contig_id][1].upper()
         return self._upper[contig_id]
+
+    def _mark_motif_native(self, contig_id):
+        """Motif mode on a long ASCII contig: upper-casing and the two replacements in the library, without the interpreter
+        lock (mc_mark_motifs; the same strings as `methylate_references(seq.upper(), ...)`, tests/test_host_pipeline.py)."""
+        seq = self.records[contig_id][1]
+        motif_f, motif_r = self.motif, revcomp(self.motif)
+        repl_f, repl_r = 'M'.join(motif_f.split(self.base)), 'M'.join(motif_r.split(base_comps[self.base]))
+        if len(seq) < (1 << 16) or not seq.isascii() or not (motif_f + motif_r).isascii() or len(repl_f) != len(motif_f) \
+                or len(repl_r) != len(motif_r):
+            return
+        try:
+            import ctypes
+            from . import _lib
+            L = _lib.lib()
+        except (ImportError, OSError):
+            return
+        raw, n = seq.encode('ascii'), len(seq)
+        bufs = [np.empty(n, dtype=np.uint8) for _ in range(3)]        # (not zero-filled: every byte is written)
+        _lib.check(L.mc_mark_motifs(raw, n, motif_f.encode('ascii'), repl_f.encode('ascii'), len(motif_f), motif_r.encode('ascii'),
+                                    repl_r.encode('ascii'), len(motif_r), bufs[0].ctypes.data, bufs[1].ctypes.data,
+                                    bufs[2].ctypes.data))
+        self._upper_bytes[contig_id] = bufs[0]                        # (what device_arrays sends; the string is made on demand)
+        self.meth[contig_id] = (str(memoryview(bufs[1]), 'ascii'), str(memoryview(bufs[2]), 'ascii'))
 
     def mark(self, contig_id):
         with self._lock:                                # (a streamed file marks its first contig ahead of time, in a thread)
+            if contig_id not in self.meth and self.motif and not self.positions_list:
+                self._mark_motif_native(contig_id)
             if contig_id not in self.meth:
                 name, seq = self.records[contig_id]
                 self.meth[contig_id] = methylate_references(self.upper(contig_id), self.base, motif=self.motif,
@@ -175,7 +204,7 @@ class MarkedReference(object):
             seq_off[cid], word_off[cid] = so, wo
             if cid in self.meth:
                 mf, mr = self.meth[cid]
-                s = np.frombuffer(self.upper(cid).encode('latin1'), dtype=np.uint8)
+                s = self._upper_bytes[cid] if cid in self._upper_bytes else np.frombuffer(self.upper(cid).encode('latin1'), dtype=np.uint8)
                 contig_len[cid] = len(s)
                 bf, br = m_bitmask(mf), m_bitmask(mr)
                 if len(bf) != len(br):                  # cannot happen: both come from one sequence

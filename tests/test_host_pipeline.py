@@ -226,3 +226,27 @@ def test_rows_from_a_compacted_view(td, tmp_path):
     v = sent.view()
     _lib.check(_lib.lib().mc_calls_expand(C.byref(v), rec.n, rows.ctypes.data, close.ctypes.data))
     assert np.array_equal(rows, comp.call_row[:rec.n]) and np.array_equal(close, rec.close_row[:rec.n])
+
+
+def test_native_motif_marking_equals_str_replace(tmp_path):
+    """MarkedReference.mark on a long contig goes through mc_mark_motifs (upper-casing and the two str.replace calls of
+    extract_contexts.py:33-41 without the interpreter lock): the same strings and the same device arrays as the Python
+    statement, for motifs that overlap themselves, one-base motifs, motifs without the base, lower-case stretches."""
+    from mcaller_amd import refmark
+    rng = np.random.default_rng(5)
+    seq = ''.join(rng.choice(list('ACGT'), 150000))
+    seq = seq[:500].lower() + seq[500:70000] + 'GATCGATCGATCGATC' + 'AAAAAAAAA' + seq[70000:100000].lower() + seq[100000:] + 'GATC'
+    fa = str(tmp_path / 'r.fa')
+    open(fa, 'w').write('>c1 some description\n' + '\n'.join(seq[i:i + 61] for i in range(0, len(seq), 61)) + '\n>short\nACGATCGA\n')
+    for motif, base in (('GATC', 'A'), ('A', 'A'), ('C', 'C'), ('AAAA', 'A'), ('GATCGA', 'A'), ('TCGATC', 'C'), ('GATC', 'C'),
+                        ('GG', 'A'), ('CCAGG', 'C')):
+        native = refmark.MarkedReference(fa, base, motif, None)
+        plain = refmark.MarkedReference(fa, base, motif, None)
+        plain._mark_motif_native = lambda cid: None
+        for cid in (0, 1):
+            assert native.mark(cid) == plain.mark(cid), (motif, base, cid)
+        assert 0 in native._upper_bytes and 1 not in native._upper_bytes      # (the short contig takes the Python statement)
+        assert native.upper(0) == plain.upper(0) == seq.upper()
+        a, b = native.device_arrays(), plain.device_arrays()
+        assert all(np.array_equal(a[k], b[k]) for k in a), (motif, base)
+        assert native.mark(0) == refmark.methylate_references(seq.upper(), base, motif=motif)
