@@ -2727,19 +2727,22 @@ extern "C" int mc_ctx_sync(mc_ctx *c) {
         if ((n) > 0) HIP_TRY(hipMemcpyAsync((void *)(dst), (src), (size_t)(n) * sizeof(*(dst)), hipMemcpyHostToDevice, c->stream)); \
     } while (0)
 
+// passes in flight read the reference; the text uploads and the device parser do not
+static int sync_streams_that_read_the_reference(mc_ctx *c) {
+    if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream2));
+    return 0;
+}
+
 extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     HIP_TRY(hipSetDevice(c->device));
-    if (int rc = sync_pass_streams(c)) return rc;          // passes in flight read the old masks
+    if (int rc = sync_streams_that_read_the_reference(c)) return rc;
     c->ref_version += 1;                                   // the name-block templates of every slot are stale
     free_pool(c->ref_allocs);
     DevRef &R = c->R;
     R.n_contigs = h->n_contigs;
-    UP(R.contig_len, h->contig_len, h->n_contigs, c->ref_allocs);
-    UP(R.seq_off, h->seq_off, h->n_contigs, c->ref_allocs);
-    UP(R.word_off, h->word_off, h->n_contigs, c->ref_allocs);
-    UP(R.seq, h->seq, h->n_seq_bytes, c->ref_allocs);
-    UP(R.mf, h->mbits_fwd, h->n_words, c->ref_allocs);
-    UP(R.mr, h->mbits_rev, h->n_words, c->ref_allocs);
     // site numbers: per contig, all '+' sites then all '-' sites, ascending position
     std::vector<int32_t> rank_f((size_t)h->n_words + 1), rank_r((size_t)h->n_words + 1);
     std::vector<int64_t> base((size_t)h->n_contigs * 2 + 2);
@@ -2761,10 +2764,28 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     R.n_sites = n_sites;
     c->ref_total_len = 0;
     for (int32_t ci = 0; ci < h->n_contigs; ++ci) c->ref_total_len += h->contig_len[ci];
-    UP(R.rank_f, rank_f.data(), h->n_words, c->ref_allocs);
-    UP(R.rank_r, rank_r.data(), h->n_words, c->ref_allocs);
-    UP(R.site_base, base.data(), (size_t)h->n_contigs * 2, c->ref_allocs);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // Everything goes through ONE pinned stage and is moved by a kernel: while a file is streamed the DMA engines are busy
+    // with the text of the shards ahead, and a transfer submitted now would complete behind all of them (k_copy_bytes).
+    struct Piece { void **dev; const void *src; size_t bytes, off; };
+    size_t total = 0;
+    auto piece = [&](void **dev, const void *src, size_t bytes) { Piece p{dev, src, bytes, total}; total += (bytes + 255) & ~(size_t)255; return p; };
+    Piece pieces[] = {
+        piece((void **)&R.contig_len, h->contig_len, (size_t)h->n_contigs * 8), piece((void **)&R.seq_off, h->seq_off, (size_t)h->n_contigs * 8),
+        piece((void **)&R.word_off, h->word_off, (size_t)h->n_contigs * 8), piece((void **)&R.seq, h->seq, (size_t)h->n_seq_bytes),
+        piece((void **)&R.mf, h->mbits_fwd, (size_t)h->n_words * 4), piece((void **)&R.mr, h->mbits_rev, (size_t)h->n_words * 4),
+        piece((void **)&R.rank_f, rank_f.data(), (size_t)h->n_words * 4), piece((void **)&R.rank_r, rank_r.data(), (size_t)h->n_words * 4),
+        piece((void **)&R.site_base, base.data(), (size_t)h->n_contigs * 2 * 8)};
+    unsigned char *dev_block = nullptr, *stage = nullptr;
+    if (dev_alloc(c->ref_allocs, &dev_block, total + 256)) return -10;
+    HIP_TRY(hipHostMalloc((void **)&stage, total + 256, hipHostMallocDefault));
+    for (const Piece &p : pieces) {
+        if (p.bytes) memcpy(stage + p.off, p.src, p.bytes);
+        *p.dev = dev_block + p.off;
+    }
+    int rc = copy_by_kernel(dev_block, stage, total, c->stream);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { mc_set_error("mc_ctx_set_reference: the upload failed"); rc = -11; }
+    (void)hipHostFree(stage);
+    if (rc) return rc;
     if (c->site_cnt) { (void)hipFree(c->site_cnt); c->site_cnt = nullptr; }
     if (c->site_first) { (void)hipFree(c->site_first); c->site_first = nullptr; }
     c->site_n = 0;

@@ -341,7 +341,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     dev = device if device is not None else get_device()
     lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
     if n_shards is None:
-        n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or max(1, min(64, (hi - lo) // STREAM_SHARD_BYTES))
+        n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or max(1, min(1 << 16, (hi - lo) // STREAM_SHARD_BYTES))
     if n_shards < 2:
         raise _Unstreamable('one shard')
     cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
@@ -382,7 +382,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
 
     def parse_shard(lo_i, hi_i):
         t_p = time.perf_counter()
-        if on_device:
+        if on_device and hi_i - lo_i < (1 << 32) - 64:         # (mc_ctx_parse_begin: at most 4 GB of text per shard)
             out = _lib.TextBlock(tsv_input, lo_i, hi_i)
         else:
             out = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
@@ -418,9 +418,16 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             next_piece[0] += 1
         if not on_device:
             return ahead.pop(0)[0].result() if ahead else None
-        while ahead and len(parsing) < 6:          # (their text goes over the link back to back; 12 table slots)
+        # (their text goes over the link back to back; 12 table slots.  Until the reference masks are on the device only two:
+        # the masks travel over the same link, and the first pass waits for them)
+        while ahead and len(parsing) < (6 if marked[0] >= 0 else 2):
             fut, piece = ahead.pop(0)
             text = fut.result()
+            if not isinstance(text, _lib.TextBlock):           # a shard too long for the device parser: parsed by the host already
+                if parsing:                                    # (file order: the shards in front of it come first)
+                    ahead.insert(0, (fut, piece))
+                    break
+                return text
             mark('text ready')
             parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
             mark('parse_begin done')
