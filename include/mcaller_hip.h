@@ -173,7 +173,8 @@ int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/*
  * hipMalloc / hipFree happens per table once the slots are big enough: mc_ctx_reserve_tables sizes them (and the per-pass
  * scratch and record sets) once for tables of up to max_rows rows, max_segs segments, max_reads reads; without it the
  * first table that needs more re-allocates (synchronising).  The host buffers must stay untouched until
- * mc_ctx_wait_upload(slot) returns.  A slot is free again when every pass that scanned its table has been handed out by
+ * mc_ctx_wait_upload(slot) returns.  (A table can also arrive as TEXT and be parsed on the device: mc_ctx_parse_begin below.)
+ * A slot is free again when every pass that scanned its table has been handed out by
  * mc_wait_records (and the next pass after it: the last records handed out may still be reduced by mc_site_counts); with
  * no free slot the call fails (-12): wait for a pass first. */
 #define MC_TABLE_SLOTS 12
@@ -183,8 +184,9 @@ int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);
 int mc_ctx_current_slot(mc_ctx *ctx);                       /* slot of the current table, -1: none */
 /* hipEvent times of the last upload into `slot` (waits for it): the H2D transfers, and k_validate behind them, in ms. */
 int mc_ctx_upload_times_ms(mc_ctx *ctx, int32_t slot, float *h2d_ms, float *validate_ms);
-/* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model;
- * submodel_of_char[256]: context[k] (ASCII) -> sub-model index, 255 = KeyError path (:197,:218). */
+/* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model (at most 8 sub-models:
+ * the reference's models have two, 'MG' and 'MH', or one); submodel_of_char[256]: context[k] (ASCII) -> sub-model index,
+ * 255 = KeyError path (:197,:218). */
 int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden,
                    const double *W1, const double *b1, const double *W2, const double *b2,
                    const uint8_t *submodel_of_char);

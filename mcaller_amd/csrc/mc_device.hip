@@ -3,24 +3,28 @@
 // The reference's hot path (extract_contexts.py:147-291 + :199) as HIP kernels over a columnar event
 // table resident in HBM:
 //
-//   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone
-//                k_tile_nb       name block of the first row of every tile
-//                k_interleave    (event, model) pairs interleaved: one DRAM page per window for k1_emit
+//   text         kp_count / kp_scan / kp_starts / kp_parse / kp_count_rows / kp_place   the eventalign TEXT of a streamed shard
+//                                parsed on the device (mc_devparse.inc): line starts, tokens, numbers, name blocks and segments,
+//                                the columns written straight into a table slot
+//   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone (a flat stream over the
+//                                rows, 8 B/row)
 //                k_nb_template   the pass-independent fields of the name-block descriptors
-//   per pass     k0_first_site   first site row of every name block under the "new read" strand rule
-//                                (:161-174) -> strand of the block
-//                k0_classify / k0_extend / k0_tiles   regular / no-sites / irregular per name block; tile descriptors
-//                k1_scan         THE SCAN: persistent one-wave workgroups over tiles of 3072 rows; the position and
-//                                flag columns (5 B/row) go through registers (next tile in flight) into LDS; 8-row
-//                                units that can hold a site row are found from the strand bitmask, their rows are
-//                                tested for "last row of a window", and every closed window leaves a 64-byte
-//                                payload (which of the 64 rows before it belong to which slot, closing row)
+//   per pass     k0_first_site   first site row of every name block under the "new read" strand rule (:161-174) -> strand of
+//                                the block; classifies the block (regular / no sites / irregular) in the same wave
+//                k0_classify / k0_extend / k0_tiles   tables with repeated read names; irregular runs widened; tile descriptors
+//                k1_scan         THE SCAN: one wave per tile of 2048 rows, nothing persistent: the position and flag columns
+//                                (5 B/row) go from HBM into registers; units of eight rows that can hold a site row are found
+//                                with one extract from the strand bitmask and listed in LDS, their rows are tested for "last
+//                                row of a window"; every closed window leaves a 32-byte payload
 //                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
-//                k1_emit         eight lanes per window, one per slot: slot means in NumPy pairwise order (fp64)
-//                                from the (event, model) pairs of the window's rows -> one flush record
-//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64, eight lanes per record
+//                k1_emit         eight lanes per window: which of the rows before its last row belong to which slot, slot
+//                                means in NumPy pairwise order (fp64) from the rows' (event, model) pairs -> one flush record
+//                k1_rare_dev     windows longer than 64 rows, row by row
+//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64: one lane per record, weights as scalar operands,
+//                                a quarter of the hidden units per SIMD
 //                k3_forest       random-forest predict_proba;  k_literal / k_merge  irregular reads, row by row
 //                k_site_counts   per-site reduction (+ ncclAllReduce);  k_pack  record columns packed for the copy-out
+//                k_copy_bytes    small transfers by the compute units (the DMA engines serialise behind queued text)
 //
 // Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
 // index monotone in the direction the first site row implies, no site at contig position 0, read name not
