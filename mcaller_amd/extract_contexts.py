@@ -406,7 +406,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         except BaseException:                                  # noqa
             pass
 
-    mark_thread = []                # started behind the first parse_begin: the readers and the first transfers do not wait for the interpreter lock
+    mark_thread = []
+    if on_device:                   # (the marking runs in the library, without the interpreter lock: nobody waits for it but the first pass)
+        import threading
+        mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
+        mark_thread[0].start()
     ahead = []                      # futures of the shards being read / parsed by the host threads, in file order
     parsing = []                    # (slot, text, piece) of the shards the device is parsing, in file order
     next_piece = [0]
@@ -418,26 +422,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             next_piece[0] += 1
         if not on_device:
             return ahead.pop(0)[0].result() if ahead else None
-        # (their text goes over the link back to back; 12 table slots.  Until the reference masks are on the device only two:
-        # the masks travel over the same link, and the first pass waits for them)
-        while ahead and len(parsing) < (6 if marked[0] >= 0 else 2):
-            fut, piece = ahead.pop(0)
-            text = fut.result()
-            if not isinstance(text, _lib.TextBlock):           # a shard too long for the device parser: parsed by the host already
-                if parsing:                                    # (file order: the shards in front of it come first)
-                    ahead.insert(0, (fut, piece))
-                    break
-                return text
-            mark('text ready')
-            parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
-            mark('parse_begin done')
-            if not mark_thread:
-                import threading
-                mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
-                mark_thread[0].start()
-            while next_piece[0] < len(pieces) and len(ahead) < 3:
-                ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
-                next_piece[0] += 1
+        held_back = top_up()
+        if held_back is not None:
+            return held_back
         if not parsing:
             return None
         slot, text, piece = parsing.pop(0)
@@ -448,9 +435,30 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             return prepare(tsv_input, None, read2qual, piece[0], piece[1], base, motif, positions_list, exact_range=True, ref=ref,
                            quiet=True)
         clock['device_parsed'] += 1
+        top_up_quietly()                                       # (the marking of the first contig may be waited for next)
         P_new = prepare_table(Prepared(), table, ref, read2qual, quiet=True)
         mark('prepared')
         return P_new
+
+    def top_up():
+        """Text of the shards ahead on its way to the device (back to back over the link; 12 table slots), up to six shards --
+        four until the reference masks are there: they travel over the same link and the first pass waits for them.  Called
+        wherever the main thread is about to wait.  -> a shard the host parser had to take (too long), when it is its turn."""
+        while ahead and len(parsing) < (6 if marked[0] >= 0 else 4):
+            fut, piece = ahead.pop(0)
+            text = fut.result()
+            if not isinstance(text, _lib.TextBlock):           # a shard too long for the device parser: parsed by the host already
+                if parsing:                                    # (file order: the shards in front of it come first)
+                    ahead.insert(0, (fut, piece))
+                    break
+                return text
+            mark('text ready')
+            parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
+            mark('parse_begin done')
+            while next_piece[0] < len(pieces) and len(ahead) < 3:
+                ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
+                next_piece[0] += 1
+        return None
 
     blobs, messages, names_seen = [], [], set()
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
@@ -484,11 +492,21 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         totals['wskips'] += len(fin.w_skips) if fin._n_wskips is None else fin._n_wskips
         totals['skipped'] += len(fin.skipped) if fin._n_skipped is None else fin._n_skipped
 
+    def top_up_quietly():
+        held = top_up()
+        if held is not None:                                   # (a host-parsed shard whose turn has come: back in line)
+            from concurrent.futures import Future
+            fut_done = Future()
+            fut_done.set_result(held)
+            ahead.insert(0, (fut_done, (0, 0)))
+
     def enqueue(P, tail_id):
         n_marked = len(ref.meth)                               # (the parser thread marks contigs as they first appear)
         if n_marked != marked[0]:                              # a contig marked since the last upload: new masks
             while in_flight:
                 hand_out()
+            if on_device:
+                top_up_quietly()                               # (the link stays busy while the masks are made ready)
             dev.set_reference(ref.device_arrays())
             marked[0] = n_marked
         dev.upload_table_async(P.table, P.qual)
