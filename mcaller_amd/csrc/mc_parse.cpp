@@ -435,9 +435,13 @@ extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64
         return nl ? (int64_t)((const char *)nl - base) + 1 : fsize;
     };
     cuts[0] = lo;
-    for (int32_t i = 1; i < n_parts; ++i) {
+    // every cut is searched for on its own (a read is ~10^4 lines: the searches are the time), then put in order: a cut that
+    // would lie before the one in front of it collapses onto it (an empty piece)
+    std::vector<int64_t> found((size_t)n_parts, lo);
+    mc_parallel_for(n_parts - 1, [&](int task) {
+        const int32_t i = task + 1;
         int64_t c = lo + (fsize - lo) * i / n_parts;
-        if (c <= cuts[i - 1]) { cuts[i] = cuts[i - 1]; continue; }
+        if (c <= lo) { found[(size_t)i] = lo; return; }
         // the line that contains byte c-1 ends at `line`: start there, remember the name of the line before it
         int64_t line = c;
         {
@@ -459,8 +463,9 @@ extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64
             }
             line = le;
         }
-        cuts[i] = std::max(cut, cuts[i - 1]);
-    }
+        found[(size_t)i] = cut;
+    });
+    for (int32_t i = 1; i < n_parts; ++i) cuts[i] = std::max(found[(size_t)i], cuts[i - 1]);
     cuts[n_parts] = fsize;
     if (base) munmap((void *)base, (size_t)file_size);
     return 0;
