@@ -492,6 +492,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         totals['wskips'] += len(fin.w_skips) if fin._n_wskips is None else fin._n_wskips
         totals['skipped'] += len(fin.skipped) if fin._n_skipped is None else fin._n_skipped
 
+    def give_back(P_dropped):
+        """A table the device parser has put into a slot and that no pass will scan: the slot is free again."""
+        slot = getattr(P_dropped.table, 'device_slot', None)
+        if slot is not None:
+            dev.parse_abandon(slot)
+            P_dropped.table.device_slot = None
+
     def top_up_quietly():
         held = top_up()
         if held is not None:                                   # (a host-parsed shard whose turn has come: back in line)
@@ -526,9 +533,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 names_seen.update(P.table.read_names)
                 messages.extend(P.messages)
                 if P.table.n_rows == 0:
+                    give_back(P)
                     continue
                 head = head_contig(P, qual_thresh)
                 if head is None:
+                    give_back(P)
                     continue                                   # no row passes the filters (:167-168): the loop never sees this shard
             if prev is not None:
                 tail_id = head if P is not None else -1

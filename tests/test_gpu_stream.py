@@ -258,6 +258,7 @@ def test_streamed_micro_cases_reproduce_the_reference(tmp_path, monkeypatch):
     (300000, 'GATC', 0, 0.0, 7),
     (200000, 'A', 1, 0.0, 5),
     (250000, 'GATC', 0, 9.0, 16),          # reads filtered by quality: shards whose first reads are skipped whole
+    (220000, 'GATC', 0, 11.5, 30),         # ... nearly all reads: more shards dropped than there are table slots
 ])
 def test_streamed_file_equals_the_one_table_path(tmp_path, monkeypatch, n_rows, motif, skip, qthresh, shards):
     from mcaller_amd import synth
@@ -280,7 +281,7 @@ def test_streamed_file_equals_the_one_table_path(tmp_path, monkeypatch, n_rows, 
     want = _run_extract(paths, args, monkeypatch, shards=0)
     assert got[0] == want[0] == 'ok'
     assert got[2] == want[2]                                   # the counter lines
-    assert got[1] == want[1] and len(got[1]) > 1000            # the rows, byte for byte
+    assert got[1] == want[1] and (len(got[1]) > 1000 or qthresh > 11)      # the rows, byte for byte
 
 
 def test_streamed_rows_equal_the_python_oracle(tmp_path, monkeypatch):
