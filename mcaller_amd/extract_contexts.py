@@ -332,9 +332,11 @@ class _Unstreamable(Exception):
 def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base, motif,
                     positions_list, n_shards=None, device=None):
     """Predict mode over a whole file, as the reference's batch loop (:140-148) streams it -- here in shards cut at read
-    starts (a window never spans two reads, :179,:242): a parser thread fills pinned tables while the main thread keeps
-    uploads and passes in flight on the GPU (mc_ctx_upload_table_async / mc_extract_features_async, two passes in flight)
-    and formats the rows of the shards that come back; parse, H2D, kernels, D2H and formatting overlap.
+    starts (a window never spans two reads, :179,:242): two threads read the shards' text into pinned memory, the main
+    thread keeps the text of up to six shards on its way to the GPU, where it is parsed (mc_ctx_parse_begin / _end /
+    _finish; a shard the device parser declines, or every shard with MCALLER_HOST_PARSER, goes through the host parser and
+    mc_ctx_upload_table_async), two passes in flight (mc_extract_features_async), and formats the rows of the shards that
+    come back; reading, H2D, parsing, kernels, D2H and formatting overlap.
     -> (text of all rows, counter lines, messages) or raises _Unstreamable: nothing has been written then."""
     import os
     import time
@@ -360,8 +362,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     L = _lib.lib()
     L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
     clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces))     # MCALLER_TIMING
-    # two parser threads take the shards in turn (the native parser spreads a shard over all cores, but opening, cutting,
-    # thread start-up and stitching are serial: two shards in the works hide that); at most three shards ahead of the GPU
+    # two reader / parser threads take the shards in turn (the native calls spread a shard over all cores, but opening,
+    # cutting and stitching are serial: two shards in the works hide that); at most three shards ahead of the GPU
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=2)
 
@@ -371,7 +373,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     on_device = not os.environ.get('MCALLER_HOST_PARSER')
     if on_device:
         biggest = max(b - a for a, b in pieces)
-        rows_cap = biggest // 48 + 65536
+        rows_cap = min(biggest, (1 << 32) - 64) // 48 + 65536
         dev.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
     clock['device_parsed'] = 0
     clock['events'] = []            # (MCALLER_TIMING=2: when the main thread did what)
