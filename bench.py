@@ -363,11 +363,12 @@ def main():
             t_w = time.perf_counter()
             f2f_paths = synth.write_inputs(t_f, q_f, codes, f2f_dir)
             t_w = time.perf_counter() - t_w
+            os.sync()                                            # (the runs below read the page cache, not a file still being written back)
             dev.close()                                          # the CLI makes its own context
             dev = None
             runs = []
             out_path = f2f_paths['tsv'][:-4] + '.diffs.6'
-            for _ in range(4):
+            for _ in range(10):                                  # (the first runs still pin memory and warm the page cache)
                 if os.path.exists(out_path):
                     os.remove(out_path)
                 t_r = time.perf_counter()
