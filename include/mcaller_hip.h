@@ -161,6 +161,16 @@ int mc_ctx_create(int device, mc_ctx **out);
 int mc_bind_to_device_numa_node(int device);
 void mc_ctx_destroy(mc_ctx *ctx);
 int mc_ctx_set_reference(mc_ctx *ctx, const mc_ref_view *host_ref);          /* H2D, replaces :154-160 */
+/* The same from the raw bases, the site masks made on the GPU (the FASTA site-LUT builder, extract_contexts.py:33-41,:60-81,
+ * for a motif): host_ref->seq holds the FASTA bytes of EVERY contig (any case; ASCII), mbits_* are not read; motif_fwd /
+ * repl_fwd: the motif and what str.replace puts in its place ('M' for the base), *_rev: for the reverse complement and the
+ * complement base; 1..16 bases; the motifs must not be able to overlap themselves (no proper prefix is also a suffix -- then
+ * "left to right, non-overlapping" is "every occurrence").  Leaves the device reference exactly as mc_ctx_set_reference
+ * would with every contig marked (mc_ctx_fetch_reference copies it back: the parity tests). */
+int mc_ctx_set_reference_motif(mc_ctx *ctx, const mc_ref_view *host_ref, const char *motif_fwd, const char *repl_fwd, int32_t m_fwd,
+                               const char *motif_rev, const char *repl_rev, int32_t m_rev);
+int mc_ctx_fetch_reference(mc_ctx *ctx, uint8_t *seq, int64_t n_seq_bytes, uint32_t *mbits_fwd, uint32_t *mbits_rev,
+                           int32_t *rank_fwd, int32_t *rank_rev, int64_t n_words, int64_t *site_base, int64_t *n_sites);
 int mc_ctx_upload_table(mc_ctx *ctx, const mc_table_view *host_table);        /* H2D of the columns; returns when done */
 int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/* read2qual, :163-166   */
 

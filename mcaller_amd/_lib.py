@@ -115,6 +115,10 @@ def lib():
         L.mc_ctx_reserve_tables.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]
         L.mc_mark_motifs.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mc_ctx_set_reference_motif.argtypes = [C.c_void_p, C.POINTER(RefView), C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p,
+                                                 C.c_int32]
+        L.mc_ctx_fetch_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_void_p, C.POINTER(C.c_int64)]
         L.mc_read_file_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
         L.mc_ctx_parse_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int64,
                                          C.POINTER(C.c_int32)]

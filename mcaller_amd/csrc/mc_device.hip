@@ -2796,6 +2796,97 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     return 0;
 }
 
+// The reference from its raw bases, the masks made on the device (k_mark_*): h->seq holds the FASTA bytes of every contig
+// (any case), h->mbits_* are not read.  *_fwd: the motif and what str.replace puts in its place for the '+' strand, *_rev: for
+// the reverse complement; the motifs must not be able to overlap themselves (the caller checks; a one-base motif cannot).
+extern "C" int mc_ctx_set_reference_motif(mc_ctx *c, const mc_ref_view *h, const char *motif_fwd, const char *repl_fwd, int32_t m_fwd,
+                                          const char *motif_rev, const char *repl_rev, int32_t m_rev) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!h || h->n_contigs < 1 || !h->seq || m_fwd < 1 || m_fwd > 16 || m_rev < 1 || m_rev > 16 || !motif_fwd || !repl_fwd || !motif_rev ||
+        !repl_rev || h->n_words < 1) {
+        mc_set_error("mc_ctx_set_reference_motif: bad arguments (motifs of 1..16 bases)");
+        return -12;
+    }
+    if (int rc = sync_streams_that_read_the_reference(c)) return rc;
+    c->ref_version += 1;
+    free_pool(c->ref_allocs);
+    DevRef &R = c->R;
+    R.n_contigs = h->n_contigs;
+    c->ref_total_len = 0;
+    for (int32_t ci = 0; ci < h->n_contigs; ++ci) c->ref_total_len += h->contig_len[ci];
+    MarkMotif F, Rv;
+    memset(&F, 0, sizeof(F)); memset(&Rv, 0, sizeof(Rv));
+    memcpy(F.motif, motif_fwd, (size_t)m_fwd); memcpy(F.repl, repl_fwd, (size_t)m_fwd); F.m = m_fwd;
+    memcpy(Rv.motif, motif_rev, (size_t)m_rev); memcpy(Rv.repl, repl_rev, (size_t)m_rev); Rv.m = m_rev;
+    // one pinned stage for the small arrays and the bases, moved by a kernel (see mc_ctx_set_reference)
+    const size_t nc = (size_t)h->n_contigs, nb = (size_t)h->n_seq_bytes, nw = (size_t)h->n_words;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_len = 0, o_soff = al(nc * 8), o_woff = o_soff + al(nc * 8), o_raw = o_woff + al(nc * 8), in_total = o_raw + al(nb + 16);
+    unsigned char *dev_in = nullptr, *stage = nullptr;
+    uint8_t *seq = nullptr;
+    long long *cnt = nullptr, *off = nullptr, *total = nullptr;
+    std::vector<void *> tmp;                                 // scratch of this call
+    if (dev_alloc(c->ref_allocs, &dev_in, in_total) || dev_alloc(c->ref_allocs, &seq, nb + 16) || dev_alloc(c->ref_allocs, &R.mf, nw) ||
+        dev_alloc(c->ref_allocs, &R.mr, nw) || dev_alloc(c->ref_allocs, &R.rank_f, nw) || dev_alloc(c->ref_allocs, &R.rank_r, nw) ||
+        dev_alloc(c->ref_allocs, &R.site_base, nc * 2) || dev_alloc(tmp, &cnt, 2 * nw + 1) || dev_alloc(tmp, &off, 2 * nw + 1) ||
+        dev_alloc(tmp, &total, 1)) {
+        free_pool(tmp);
+        return -10;
+    }
+    HIP_TRY(hipHostMalloc((void **)&stage, in_total, hipHostMallocDefault));
+    memcpy(stage + o_len, h->contig_len, nc * 8);
+    memcpy(stage + o_soff, h->seq_off, nc * 8);
+    memcpy(stage + o_woff, h->word_off, nc * 8);
+    memcpy(stage + o_raw, h->seq, nb);
+    memset(stage + o_raw + nb, 0, 16);
+    R.contig_len = (int64_t *)(dev_in + o_len); R.seq_off = (int64_t *)(dev_in + o_soff); R.word_off = (int64_t *)(dev_in + o_woff);
+    R.seq = seq;
+    hipStream_t st = c->stream;
+    int rc = copy_by_kernel(dev_in, stage, in_total, st);
+    if (!rc) {
+        hipLaunchKernelGGL(k_mark_upper, dim3(1024), dim3(256), 0, st, (const uint8_t *)(dev_in + o_raw), seq, (int64_t)nb + 16);
+        const unsigned wb = (unsigned)((nw + 255) / 256);
+        hipLaunchKernelGGL(k_mark_words, dim3(wb), dim3(256), 0, st, (const uint8_t *)seq, (const int64_t *)R.contig_len,
+                           (const int64_t *)R.seq_off, (const int64_t *)R.word_off, h->n_contigs, (int64_t)nw, F, Rv, R.mf, R.mr, cnt);
+        hipLaunchKernelGGL(kp_scan, dim3(1), dim3(1024), 0, st, (const long long *)cnt, (int64_t)(2 * nw), off, total);
+        hipLaunchKernelGGL(k_mark_ranks, dim3(wb), dim3(256), 0, st, (const long long *)off, (const int64_t *)R.word_off, h->n_contigs,
+                           (int64_t)nw, R.rank_f, R.rank_r, R.site_base);
+        long long n_sites = 0;
+        if (hipMemcpyAsync(&n_sites, total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            mc_set_error("mc_ctx_set_reference_motif: the marking failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = -11;
+        }
+        R.n_sites = n_sites;
+    }
+    (void)hipHostFree(stage);
+    free_pool(tmp);
+    if (rc) return rc;
+    if (c->site_cnt) { (void)hipFree(c->site_cnt); c->site_cnt = nullptr; }
+    if (c->site_first) { (void)hipFree(c->site_first); c->site_first = nullptr; }
+    c->site_n = 0;
+    return 0;
+}
+
+// the reference as the device holds it, back on the host (tests: the masks made on the device against the host's marking)
+extern "C" int mc_ctx_fetch_reference(mc_ctx *c, uint8_t *seq, int64_t n_seq_bytes, uint32_t *mbits_fwd, uint32_t *mbits_rev, int32_t *rank_fwd,
+                                      int32_t *rank_rev, int64_t n_words, int64_t *site_base, int64_t *n_sites) {
+    HIP_TRY(hipSetDevice(c->device));
+    const DevRef &R = c->R;
+    if (!R.seq || !R.mf) {
+        mc_set_error("mc_ctx_fetch_reference: no reference set");
+        return -12;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (seq) HIP_TRY(hipMemcpy(seq, R.seq, (size_t)n_seq_bytes, hipMemcpyDeviceToHost));
+    if (mbits_fwd) HIP_TRY(hipMemcpy(mbits_fwd, R.mf, (size_t)n_words * 4, hipMemcpyDeviceToHost));
+    if (mbits_rev) HIP_TRY(hipMemcpy(mbits_rev, R.mr, (size_t)n_words * 4, hipMemcpyDeviceToHost));
+    if (rank_fwd) HIP_TRY(hipMemcpy(rank_fwd, R.rank_f, (size_t)n_words * 4, hipMemcpyDeviceToHost));
+    if (rank_rev) HIP_TRY(hipMemcpy(rank_rev, R.rank_r, (size_t)n_words * 4, hipMemcpyDeviceToHost));
+    if (site_base) HIP_TRY(hipMemcpy(site_base, R.site_base, (size_t)R.n_contigs * 16, hipMemcpyDeviceToHost));
+    if (n_sites) *n_sites = R.n_sites;
+    return 0;
+}
+
 // ---- table slots ----
 static void slot_free_parser(TableSlot &S) {
     free_pool(S.kp_allocs);
@@ -3934,9 +4025,14 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
         const PackLayout L = pack_layout((int64_t)n, b.close32 ? 1 : 0);
         const size_t out_bytes = L.feats + m * ((size_t)k + 1) * 8;
-        // (a small record set -- a shard of a streamed file -- by kernel: the DMA engines may be busy with text, see k_copy_bytes)
-        if (out_bytes <= COPY_BY_KERNEL_MAX / 4) { if (int rc = copy_by_kernel(b.pack_host, b.pack, out_bytes, cs)) return rc; }
-        else HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, out_bytes, hipMemcpyDeviceToHost, cs));
+        // (a small record set -- a shard of a streamed file -- by kernel: the DMA engines may be busy with text, see k_copy_bytes;
+        // and on the side stream, right behind the packing: the runtime folds the streams of a process onto four hardware
+        // queues, and a copy stream that shares one with the parse stream would wait behind the kernels of the shards ahead,
+        // which wait for their text)
+        if (out_bytes <= COPY_BY_KERNEL_MAX && c->side_stream) {
+            cs = c->side_stream;
+            if (int rc = copy_by_kernel(b.pack_host, b.pack, out_bytes, cs)) return rc;
+        } else HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, out_bytes, hipMemcpyDeviceToHost, cs));
         b.H.close_row = b.close32 ? nullptr : reinterpret_cast<int64_t *>(b.pack_host);
         b.h_close32 = b.close32 ? reinterpret_cast<int32_t *>(b.pack_host) : nullptr;
         b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + L.pos);

@@ -43,6 +43,24 @@ class Device(object):
         v = make_ref_view(arrays)
         check(lib().mc_ctx_set_reference(self._ctx, C.byref(v)))
 
+    def set_reference_motif(self, arrays, motif_fwd, repl_fwd, motif_rev, repl_rev):
+        """The reference from its raw bases, site masks made on the GPU (arrays: MarkedReference.raw_arrays(); motifs:
+        MarkedReference.motif_for_the_device())."""
+        v = _lib.make_ref_view(arrays)
+        v.n_words = int(arrays['n_words'])
+        check(lib().mc_ctx_set_reference_motif(self._ctx, C.byref(v), motif_fwd, repl_fwd, len(motif_fwd), motif_rev, repl_rev,
+                                               len(motif_rev)))
+
+    def fetch_reference(self, n_seq_bytes, n_words, n_contigs):
+        """(seq, mbits_fwd, mbits_rev, rank_fwd, rank_rev, site_base, n_sites) as the device holds them (tests)."""
+        seq = np.empty(n_seq_bytes, dtype=np.uint8)
+        mf, mr = np.empty(n_words, dtype=np.uint32), np.empty(n_words, dtype=np.uint32)
+        rf, rr = np.empty(n_words, dtype=np.int32), np.empty(n_words, dtype=np.int32)
+        base, n_sites = np.empty(2 * n_contigs, dtype=np.int64), C.c_int64(0)
+        check(lib().mc_ctx_fetch_reference(self._ctx, _ptr(seq), int(n_seq_bytes), _ptr(mf), _ptr(mr), _ptr(rf), _ptr(rr), int(n_words),
+                                           _ptr(base), C.byref(n_sites)))
+        return seq, mf, mr, rf, rr, base, n_sites.value
+
     def upload_table(self, table):
         v = table.view()
         check(lib().mc_ctx_upload_table(self._ctx, C.byref(v)))

@@ -361,6 +361,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
 
     L = _lib.lib()
     L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
+    masks_on_device = False            # (decided below, once the first shards are being read)
     clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces))     # MCALLER_TIMING
     # two reader / parser threads take the shards in turn (the native calls spread a shard over all cores, but opening,
     # cutting and stitching are serial: two shards in the works hide that); at most three shards ahead of the GPU
@@ -408,11 +409,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         except BaseException:                                  # noqa
             pass
 
+    # (started when three shards of text are on their way: what is left of the marking under the interpreter lock -- making
+    # Python strings of 2 x 4.6 MB -- would hold up the reader threads at the very start)
     mark_thread = []
-    if on_device:                   # (the marking runs in the library, without the interpreter lock: nobody waits for it but the first pass)
-        import threading
-        mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
-        mark_thread[0].start()
     ahead = []                      # futures of the shards being read / parsed by the host threads, in file order
     parsing = []                    # (slot, text, piece) of the shards the device is parsing, in file order
     next_piece = [0]
@@ -457,6 +456,10 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             mark('text ready')
             parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
             mark('parse_begin done')
+            if not mark_thread and (len(parsing) >= 3 or next_piece[0] >= len(pieces)):
+                import threading
+                mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
+                mark_thread[0].start()
             while next_piece[0] < len(pieces) and len(ahead) < 3:
                 ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
                 next_piece[0] += 1
@@ -466,7 +469,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     totals = dict(obs=0, multi=0, wskips=0, skipped=0)
     positions = []
     in_flight = []                  # (P, tail name) of the passes enqueued, oldest first
-    marked = [-1]
+    marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
     def hand_out():
         t_h = time.perf_counter()
@@ -511,7 +514,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
 
     def enqueue(P, tail_id):
         n_marked = len(ref.meth)                               # (the parser thread marks contigs as they first appear)
-        if n_marked != marked[0]:                              # a contig marked since the last upload: new masks
+        if not masks_on_device and n_marked != marked[0]:      # a contig marked since the last upload: new masks
             while in_flight:
                 hand_out()
             if on_device:
@@ -521,6 +524,18 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         dev.upload_table_async(P.table, P.qual)
         dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=True)
 
+    while next_piece[0] < len(pieces) and len(ahead) < 3:      # (the first shards are read while the masks are made)
+        ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
+        next_piece[0] += 1
+    # Motif mode: the site masks of every contig are made on the GPU, from the raw bases, before the first text is on its way
+    # (mc_ctx_set_reference_motif) -- the marked strings the rows' contexts are sliced from are made by a thread meanwhile and
+    # are not waited for by the passes.  (Not for motifs that can overlap themselves, positions mode, very long references:
+    # then the masks come from the host's marking, contig by contig as they appear.)
+    dev_motif = ref.motif_for_the_device() if not os.environ.get('MCALLER_HOST_PARSER') else None
+    if dev_motif is not None and sum(len(seq) for _, seq in ref.records) <= (256 << 20):
+        dev.set_reference_motif(ref.raw_arrays(), *dev_motif)
+        masks_on_device = True
+    marked[0] = 0 if masks_on_device else -1
     try:
         prev = None
         while True:

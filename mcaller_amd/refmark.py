@@ -184,6 +184,36 @@ class MarkedReference(object):
                                                             positions=self.positions_list, contig=name, quiet=self.quiet)
             return self.meth[contig_id]
 
+    def motif_for_the_device(self):
+        """(motif_fwd, repl_fwd, motif_rev, repl_rev) as bytes if the device can make the site masks itself
+        (mc_ctx_set_reference_motif): motif mode, ASCII, at most 16 bases, and neither motif can overlap itself (no proper
+        prefix is also a suffix -- str.replace's left-to-right, non-overlapping rule is then "every occurrence"); else None."""
+        if not self.motif or self.positions_list:
+            return None
+        try:
+            motif_f, motif_r = self.motif, revcomp(self.motif)
+            repl_f, repl_r = 'M'.join(motif_f.split(self.base)), 'M'.join(motif_r.split(base_comps[self.base]))
+        except KeyError:                                # (a letter revcomp does not know: the reference's own crash, elsewhere)
+            return None
+        for m, r in ((motif_f, repl_f), (motif_r, repl_r)):
+            if not (1 <= len(m) <= 16) or len(r) != len(m) or not m.isascii() or any(m[:i] == m[-i:] for i in range(1, len(m))):
+                return None
+        if not all(seq.isascii() for _, seq in self.records):
+            return None
+        return motif_f.encode('ascii'), repl_f.encode('ascii'), motif_r.encode('ascii'), repl_r.encode('ascii')
+
+    def raw_arrays(self):
+        """The arrays of mc_ref_view for mc_ctx_set_reference_motif: the raw bases of EVERY contig, laid out as device_arrays
+        would lay them out with every contig marked (mask words: ceil(len / 32) + 2 per contig)."""
+        n = len(self.records)
+        lens = np.array([len(seq) for _, seq in self.records], dtype=np.int64)
+        words = (lens + 31) // 32 + 2
+        seq_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        word_off = np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        raw = np.frombuffer(''.join(seq for _, seq in self.records).encode('ascii') + b'\0' * 8, dtype=np.uint8)
+        return dict(contig_len=lens, seq_off=seq_off, word_off=word_off, seq=raw, mbits_fwd=np.zeros(2, np.uint32),
+                    mbits_rev=np.zeros(2, np.uint32), n_words=int(words.sum()), n_seq_bytes=int(lens.sum()))
+
     def device_arrays(self):
         """Concatenated arrays for mc_ref_view (unmarked contigs: empty sequence, all-zero masks)."""
         key = tuple(sorted(self.meth))
