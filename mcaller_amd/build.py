@@ -19,6 +19,7 @@ def build_lib(force=False, verbose=True, out=None, defines=()):
         subprocess.check_call(cmd)
         return out
     deps = srcs + [os.path.join(os.path.dirname(HERE), 'include', 'mcaller_hip.h')]
+    deps += [os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc')) if f.endswith(('.inc', '.h'))]     # (included files)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
