@@ -144,3 +144,24 @@ def test_native_tsv_writer_equals_the_python_one(tmp_path):
     for nt in (1, 3, 0):
         assert synth.write_tsv_native(table, codes, b, n_threads=nt) == os.path.getsize(a)
         assert open(a, 'rb').read() == open(b, 'rb').read()
+
+
+def test_read_file_range_is_the_files_bytes(tmp_path):
+    """mc_read_file_range (what feeds the device parser): any byte range of a file, pieces read by several threads."""
+    import ctypes as C
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 9_500_000, dtype=np.uint8).tobytes()
+    p = str(tmp_path / 'blob.bin')
+    open(p, 'wb').write(data)
+    L = _lib.lib()
+    for lo, hi, nt in ((0, len(data), 0), (1, len(data) - 1, 3), (4_194_303, 4_194_305, 2), (5_000_000, 5_000_000, 1),
+                       (123, 8_388_731, 7)):
+        buf = np.zeros(max(hi - lo, 1), dtype=np.uint8)
+        _lib.check(L.mc_read_file_range(p.encode(), lo, hi, buf.ctypes.data, nt))
+        assert buf[:hi - lo].tobytes() == data[lo:hi]
+    buf = np.zeros(16, dtype=np.uint8)
+    assert L.mc_read_file_range(p.encode(), len(data) - 8, len(data) + 8, buf.ctypes.data, 1) != 0      # beyond the end
+    assert L.mc_read_file_range((p + '.nope').encode(), 0, 8, buf.ctypes.data, 1) != 0
+    t = _lib.TextBlock(p, 10, 1000)
+    assert t.n_bytes == 990 and bytes(t.array[:990]) == data[10:1000] and t.token(5, 3) == data[15:18].decode('utf-8', 'surrogateescape')
