@@ -196,3 +196,26 @@ def test_random_text_against_the_host_parser(dev, tmp_path):
         n_same += 1
     print('random text: %d files column for column, %d declined, %d malformed' % (n_same, n_declined, n_raise))
     assert n_same >= 100 and n_raise >= 10 and n_declined >= 10
+
+
+def test_lines_too_long_for_the_staging_buffer(dev, tmp_path):
+    """A workgroup's 256 lines that do not fit the 48 KB LDS stage are read in place (a 13th token of 60 KB: ignored by both
+    parsers); a read name longer than 65535 bytes is left to the host parser."""
+    row = 'c1\t{pos}\tAAAAAA\tread{r}\tt\t{pos}\t80.5\t1.0\t0.001\tAAAAAA\t81.25\t1.0\t0.1'
+    lines = [row.format(pos=i, r=i // 40) for i in range(700)]
+    lines[300] += '\t' + 'x' * 60000
+    lines[301] += ' ' + 'y' * 70000 + ' z'
+    p = str(tmp_path / 'long.tsv')
+    open(p, 'w').write('\n'.join(lines) + '\n')
+    host, t, slot, text = both_parsers(dev, p, ['c1'])
+    assert_same_table(dev, host, t, slot)
+    assert t.n_rows == 700
+    dev.parse_abandon(slot)
+    lines[10] = row.format(pos=10, r=0).replace('read0', 'r' * 70000)
+    open(p, 'w').write('\n'.join(lines) + '\n')
+    from mcaller_amd import _lib
+    text = _lib.TextBlock(p, 0, os.path.getsize(p))
+    slot = dev.parse_begin(text, ['c1'], 4096)
+    assert dev.parse_end(slot, text) is None
+    host = _lib.parse_eventalign(p, 0, os.path.getsize(p), ['c1'], exact_range=True)       # (the host parser takes it)
+    assert host.n_rows == 700 and max(len(n) for n in host.read_names) == 70000
