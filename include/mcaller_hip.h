@@ -90,6 +90,15 @@ typedef struct mc_calls_view {
     /* mc_wait_records on a table of fewer than 2^31 - 1 rows: close_row is NULL and the closing rows are here. */
     int32_t *close_row32;
     int32_t compacted;
+    /* mc_wait_records: feats is NULL and the slot means of call row r, slot s, are packed -- a slot mean that is
+     * fl(d / 10^4) for a 32-bit integer d (every slot that holds one event is; the host divides again and gets the same
+     * double) travels as d in feats_lo32[r*k + s]; one that is not has bit s of feats_wide[r] set, its low 32 bits in
+     * feats_lo32[r*k + s] and its high 32 bits in feats_hi32[j], j = the number of wide slots before it in (row, slot)
+     * order.  mc_format_diffs reads that layout; mc_calls_expand unpacks it. */
+    const int32_t *feats_lo32;
+    const uint32_t *feats_hi32;
+    const uint8_t *feats_wide;
+    int64_t n_wide;
 } mc_calls_view;
 
 const char *mc_last_error(void);
@@ -356,9 +365,10 @@ typedef struct mc_format_args {
  * contig, NaN probability, unknown sub-model key or complement, centre not 'M': the reference's exit/crash paths). */
 int mc_format_diffs(const mc_format_args *args, int64_t first, int32_t n_threads, char **text, int64_t *n_bytes,
                     int64_t *n_rows, int64_t *stop_at);
-/* The columns mc_wait_records does not send, rebuilt on the host (all cores): call_row_out[n] (see mc_calls_view.call_row)
- * and / or close_row_out[n] (64-bit closing rows); either may be NULL. */
-int mc_calls_expand(const mc_calls_view *rec, int64_t n_records, int32_t *call_row_out, int64_t *close_row_out);
+/* The columns mc_wait_records does not send, rebuilt on the host (all cores): call_row_out[n] (see mc_calls_view.call_row),
+ * close_row_out[n] (64-bit closing rows), feats_out[n_call_rows * k] (the slot means as doubles); any may be NULL. */
+int mc_calls_expand(const mc_calls_view *rec, int64_t n_records, int32_t k, int32_t *call_row_out, int64_t *close_row_out,
+                    double *feats_out);
 void mc_free(void *p);
 /* repr(float) == str(np.float64) of one value into out32 (NUL-terminated); returns its length. */
 int mc_repr_double(double v, char *out32);

@@ -47,7 +47,8 @@ class CallsView(C.Structure):
     _fields_ = [('capacity', C.c_int64),
                 ('feats', C.c_void_p), ('site_pos', C.c_void_p), ('site_seg', C.c_void_p),
                 ('close_row', C.c_void_p), ('info', C.c_void_p), ('prob', C.c_void_p),
-                ('call_row', C.c_void_p), ('n_call_rows', C.c_int64), ('close_row32', C.c_void_p), ('compacted', C.c_int32)]
+                ('call_row', C.c_void_p), ('n_call_rows', C.c_int64), ('close_row32', C.c_void_p), ('compacted', C.c_int32),
+                ('feats_lo32', C.c_void_p), ('feats_hi32', C.c_void_p), ('feats_wide', C.c_void_p), ('n_wide', C.c_int64)]
 
 
 class FormatArgs(C.Structure):
@@ -161,7 +162,7 @@ def lib():
         L.mc_comm_destroy.argtypes = [C.c_void_p]
         L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.mc_mlp_fit.argtypes = [C.c_void_p, C.POINTER(FitParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 13
-        L.mc_calls_expand.argtypes = [C.POINTER(CallsView), C.c_int64, C.c_void_p, C.c_void_p]
+        L.mc_calls_expand.argtypes = [C.POINTER(CallsView), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_free.argtypes = [C.c_void_p]
@@ -473,8 +474,13 @@ class Records(object):
     def view(self):
         v = CallsView()
         v.capacity = self.capacity
-        v.feats, v.site_pos, v.site_seg = _ptr(self.feats), _ptr(self.site_pos), _ptr(self.site_seg)
+        v.site_pos, v.site_seg = _ptr(self.site_pos), _ptr(self.site_seg)
         v.info, v.prob = _ptr(self.info), _ptr(self.prob)
+        if self._feats is None and self._packed is not None:           # slot means as mc_wait_records sent them
+            lo, hi, wide = self._packed
+            v.feats_lo32, v.feats_hi32, v.feats_wide, v.n_wide = _ptr(lo), _ptr(hi), _ptr(wide), len(hi)
+        else:
+            v.feats = _ptr(self.feats)
         if self._close_row is not None or self._close_row32 is None:
             v.close_row = _ptr(self.close_row)
         else:
@@ -490,7 +496,8 @@ class Records(object):
         """Zero-copy wrap of library-owned buffers (valid until the next call on the owning context)."""
         r = cls.__new__(cls)
         r.k, r.capacity, r.n, r._owner = k, n, n, owner
-        r.feats = _from_ptr(v.feats, n * k, np.float64)
+        if v.feats:
+            r.feats = _from_ptr(v.feats, n * k, np.float64)
         r.site_pos = _from_ptr(v.site_pos, n, np.int32)
         r.site_seg = _from_ptr(v.site_seg, n, np.int32)
         if v.close_row:
@@ -504,15 +511,33 @@ class Records(object):
             if v.call_row:
                 r._call_row = _from_ptr(v.call_row, n, np.int32)
             r._n_calls = m
-            r.feats = _from_ptr(v.feats, m * k, np.float64)
+            if v.feats:
+                r.feats = _from_ptr(v.feats, m * k, np.float64)
+            else:                            # packed slot means (mc_calls_view.feats_lo32): unpacked on first use
+                r._packed = (_from_ptr(v.feats_lo32, m * k, np.int32), _from_ptr(v.feats_hi32, int(v.n_wide), np.uint32),
+                             _from_ptr(v.feats_wide, m, np.uint8))
             r.prob = _from_ptr(v.prob, m, np.float64)
         else:
             r.prob = _from_ptr(v.prob, n, np.float64)
         return r
 
-    # closing rows and call rows: columns mc_wait_records does not send in full (mc_calls_view) are rebuilt on first use
-    _close_row = _close_row32 = _call_row = None
+    # closing rows, call rows, slot means: columns mc_wait_records does not send in full (mc_calls_view) are rebuilt on first use
+    _close_row = _close_row32 = _call_row = _feats = _packed = None
     _compacted = False
+
+    @property
+    def feats(self):
+        """Slot means, k per row of feats / prob (row-major, flat)."""
+        if self._feats is None and self._packed is not None:
+            out = np.empty(max(1, self._n_calls * self.k), dtype=np.float64)
+            v = self.view()
+            check(lib().mc_calls_expand(C.byref(v), int(self.n), int(self.k), None, None, _ptr(out)))
+            self._feats = out[:self._n_calls * self.k]
+        return self._feats
+
+    @feats.setter
+    def feats(self, a):
+        self._feats = a
 
     @property
     def close_row(self):

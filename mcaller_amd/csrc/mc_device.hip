@@ -137,6 +137,7 @@ struct DevRecords {
     int64_t *close_row = nullptr;
     uint32_t *info = nullptr;
     double *prob = nullptr;
+    uint8_t *wmask = nullptr;   // bit s: slot mean s is not fl(d / 1e4) (travels as 64 bits); 0xFF: not looked at yet (k_pack looks)
 };
 
 struct DevMlp {
@@ -163,6 +164,7 @@ struct Counters {          // device-side status block
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
+    unsigned long long n_wide; // slot means of those records that travel as 64 bits (k_pack: the others as 32-bit integers)
     // the pass in which a name block was last classified irregular (mc_params-independent pass number, never 0).  Written,
     // never zeroed: k0_first_site classifies while it zeroes the other counters, so a count could lose updates -- a pass is
     // special iff this equals its own number
@@ -178,6 +180,25 @@ struct Counters {          // device-side status block
 // ---------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------
+// np.round(e - m, 4) == fl((E4 - M4) / 1e4) (:286) without the division: for EVERY int32 x the reciprocal-and-correct
+// sequence below equals the IEEE quotient x / 10000.0 bit for bit (tests/tools/div1e4_check.c goes through all 2^32) --
+// three fp64 operations instead of the ten of a division, eight times per slot and round in k1_emit.
+__device__ __forceinline__ double div1e4(int x) {
+    const double xd = (double)x, r = 1.0 / 10000.0;
+    const double q0 = xd * r;
+    return fma(fma(-q0, 10000.0, xd), r, q0);
+}
+
+// a slot mean that is fl(d / 1e4) for a 32-bit integer d travels as d (k_pack); the emit notes which are not (DevRecords.wmask)
+__device__ __forceinline__ bool slot_is_narrow(double v, int32_t *d_out) {
+    const double t = rint(v * 1e4);
+    if (!(fabs(t) < 2147483648.0)) return false;            // (NaN too)
+    const int32_t d = (int32_t)t;
+    if (__double_as_longlong(div1e4(d)) != __double_as_longlong(v)) return false;     // bit for bit (-0.0 is wide); div1e4(d) == d / 1e4
+    *d_out = d;
+    return true;
+}
+
 __device__ __forceinline__ int first_m(const uint32_t *__restrict__ bits, int64_t L, int64_t pos, int k) {
     if (pos >= L) return -1;
     const int64_t w0 = pos >> 5;
@@ -1202,6 +1223,7 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
     A.O.site_seg[slot] = T.nb_seg_begin[nb_abs];        // regular blocks have one segment
     A.O.close_row[slot] = close_row;
     A.O.info[slot] = info;
+    A.O.wmask[slot] = 0xFF;                  // (which slot means need 64 bits: k_pack looks)
     A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
@@ -1215,6 +1237,7 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
     A.O.site_seg[slot] = A.T.nb_seg_begin[nb_abs];
     A.O.close_row[slot] = close_row;
     A.O.info[slot] = MC_I_TOO_MANY | ((!close_ns && d.extra_multi()) ? MC_I_MULTI : 0u);
+    A.O.wmask[slot] = 0xFF;
     A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
@@ -1273,15 +1296,6 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
     emit_record(A, S, d, P.nb, P.r, P.m, q);
 }
 
-// np.round(e - m, 4) == fl((E4 - M4) / 1e4) (:286) without the division: for EVERY int32 x the reciprocal-and-correct
-// sequence below equals the IEEE quotient x / 10000.0 bit for bit (tests/tools/div1e4_check.c goes through all 2^32) --
-// three fp64 operations instead of the ten of a division, eight times per slot and round in k1_emit.
-__device__ __forceinline__ double div1e4(int x) {
-    const double xd = (double)x, r = 1.0 / 10000.0;
-    const double q0 = xd * r;
-    return fma(fma(-q0, 10000.0, xd), r, q0);
-}
-
 // (six waves per SIMD: the register allocator fits 80 VGPRs without scratch; the kernel's time is rounds x latency, so resident
 // waves count -- four: 76 us for ordering + emit, five: 59, six: 55, seven (72 VGPRs, 20 bytes of scratch): 57)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
@@ -1315,6 +1329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const bool window = live && !(P.flags & PF_EXTRA);
     if (live && !window && s == 0) {            // the one-event '+' window of a palindromic first site row (R5)
         for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+        A.O.wmask[q] = 0;
         A.O.site_pos[q] = m;
         A.O.site_seg[q] = T.nb_seg_begin[P.nb];
         A.O.close_row[q] = P.close_row;
@@ -1417,6 +1432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if (!fast) continue;
     const bool too_many = __popc(empties) > A.skip_thresh;
     const bool rev = P.flags & PF_REV;
+    unsigned wide_bit = 0u;
     if (s < k) {
         double f = 0.0;
         if (!too_many && n > 0) {
@@ -1465,8 +1481,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
         const int dst = (too_many || rev) ? s : k - 1 - s;           // :187-188
         A.O.feats[q * k + dst] = f;
+        int32_t as_int;
+        if (!too_many && !slot_is_narrow(f, &as_int)) wide_bit = 1u << dst;
     }
+    wide_bit |= (unsigned)__shfl_xor((int)wide_bit, 1);              // the group's eight lanes: which slot means need 64 bits
+    wide_bit |= (unsigned)__shfl_xor((int)wide_bit, 2);
+    wide_bit |= (unsigned)__shfl_xor((int)wide_bit, 4);
     if (s == 0) {
+        A.O.wmask[q] = (uint8_t)wide_bit;
         uint32_t info = rev ? MC_I_REV : 0u;
         if (too_many) info |= MC_I_TOO_MANY;
         else {
@@ -1565,6 +1587,7 @@ __device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j) {
         O.feats[j * k + dst] = f;
     }
     O.info[j] = info & ~MC_I_BIG;
+    O.wmask[j] = 0xFF;
 }
 
 __global__ void k1_bigfix(K1Args A, int64_t n) {
@@ -1753,6 +1776,7 @@ __global__ void k_literal(LitArgs A) {
             A.L.site_seg[j] = last_seg;
             A.L.close_row[j] = close_row;
             A.L.info[j] = info;
+            A.L.wmask[j] = 0xFF;
             A.L.prob[j] = __longlong_as_double(0x7ff8000000000000LL);
         }
         ++out;
@@ -1857,6 +1881,7 @@ __global__ void k_merge(DevRecords O, int64_t n_o, DevRecords L, int64_t n_l, De
     M.site_seg[d] = S.site_seg[j];
     M.close_row[d] = S.close_row[j];
     M.info[d] = S.info[j];
+    M.wmask[d] = S.wmask[j];
     M.prob[d] = S.prob[j];
 }
 
@@ -2276,21 +2301,49 @@ __host__ __device__ inline PackLayout pack_layout(int64_t n, int close32) {
     return L;
 }
 
-__global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt,
+// The slot means of the m calls behind the narrow columns.  A slot mean is very often fl(d / 10^4) for an integer d -- every
+// slot that holds ONE event is (its value is fl((E4 - M4) / 10^4), section 2 of DESIGN.md), 53 % of the slots of the headline
+// workload -- and then d travels, 32 bits, and the host divides again (IEEE division: the same double); the others travel
+// as they are, their low half in the slot's place and their high half in a compact list behind, one bit per slot says which.
+//   lo32[m * k] | prob[m] (f64) | wide mask[m] (u8, bit s: slot s is 64 bits wide) | hi32[n_wide]
+struct PackTail { size_t lo32, prob, wmask, hi32, end; };
+__host__ __device__ inline PackTail pack_tail(size_t feats_off, size_t m, int k, size_t n_wide) {
+    PackTail T;
+    T.lo32 = feats_off;
+    T.prob = (T.lo32 + m * (size_t)k * 4 + 7) & ~(size_t)7;
+    T.wmask = T.prob + m * 8;
+    T.hi32 = (T.wmask + m + 3) & ~(size_t)3;
+    T.end = T.hi32 + n_wide * 4;
+    return T;
+}
+
+// chunk_cnt[b] = kept records of chunk b, chunk_cnt[PACK_WGS + b] = their wide slots
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt, int k,
                                                              unsigned long long *__restrict__ chunk_cnt) {
-    __shared__ unsigned int s_wave[PACK_THREADS / 64];
+    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
     const int64_t n = cnt->overflow ? 0 : min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
-    unsigned int kept = 0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) kept += (O.info[i] & MC_I_TOO_MANY) ? 0u : 1u;
-    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = kept;
+    unsigned int kept = 0, wide = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) {
+        if (O.info[i] & MC_I_TOO_MANY) continue;
+        kept += 1u;
+        const unsigned wm = O.wmask[i];                      // (k1_emit's note; 0xFF: a record of the rare paths, looked at here)
+        if (wm != 0xFFu) wide += (unsigned)__popc(wm);
+        else
+            for (int f = 0; f < k; ++f) {
+                int32_t d;
+                wide += slot_is_narrow(O.feats[i * k + f], &d) ? 0u : 1u;
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_xor(kept, o); wide += __shfl_xor(wide, o); }
+    if ((threadIdx.x & 63) == 0) { s_wave[0][threadIdx.x >> 6] = kept; s_wave[1][threadIdx.x >> 6] = wide; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < PACK_THREADS / 64; ++w) t += s_wave[w];
+        unsigned long long t = 0, w = 0;
+        for (int j = 0; j < PACK_THREADS / 64; ++j) { t += s_wave[0][j]; w += s_wave[1][j]; }
         chunk_cnt[blockIdx.x] = t;
+        chunk_cnt[PACK_WGS + blockIdx.x] = w;
     }
 }
 
@@ -2299,63 +2352,109 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
                                                        unsigned char *__restrict__ out, int k, int close32,
                                                        Counters *__restrict__ host_status) {
     static_assert(PACK_WGS == PACK_THREADS, "one chunk count per thread");
-    __shared__ unsigned long long s_sum[2][PACK_THREADS / 64];
-    __shared__ unsigned int s_wave[PACK_THREADS / 64];
-    __shared__ int s_row[PACK_THREADS];
+    __shared__ unsigned long long s_sum[4][PACK_THREADS / 64];
+    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
+    __shared__ double s_feats[PACK_THREADS * MC_MAX_K];     // the strip's slot means, loaded with consecutive lanes on consecutive words
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // kept records before this chunk, and in all chunks
+    // kept records (and their wide slots) before this chunk, and in all chunks
     unsigned long long v = chunk_cnt[tid], before = tid < (int)blockIdx.x ? v : 0ull;
-    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); before += __shfl_xor(before, o); }
-    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; }
+    unsigned long long w = chunk_cnt[PACK_WGS + tid], wbefore = tid < (int)blockIdx.x ? w : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o); before += __shfl_xor(before, o);
+        w += __shfl_xor(w, o); wbefore += __shfl_xor(wbefore, o);
+    }
+    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; s_sum[2][wave] = w; s_sum[3][wave] = wbefore; }
     __syncthreads();
-    unsigned long long total = 0, base = 0;
-    for (int w = 0; w < PACK_THREADS / 64; ++w) { total += s_sum[0][w]; base += s_sum[1][w]; }
+    unsigned long long total = 0, base = 0, total_wide = 0, wbase = 0;
+    for (int j = 0; j < PACK_THREADS / 64; ++j) { total += s_sum[0][j]; base += s_sum[1][j]; total_wide += s_sum[2][j]; wbase += s_sum[3][j]; }
     constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;      // everything the host looks at
+    constexpr int kept_word = (int)(offsetof(Counters, n_kept) / 4);          // (n_kept and n_wide: two words each, set below)
+    static_assert(offsetof(Counters, n_wide) == offsetof(Counters, n_kept) + 8, "n_kept, n_wide side by side");
     if (blockIdx.x == 0) {
-        if (tid < (int)head_words && tid != (int)(offsetof(Counters, n_kept) / 4) && tid != (int)(offsetof(Counters, n_kept) / 4 + 1))
+        if (tid < (int)head_words && (tid < kept_word || tid >= kept_word + 4))
             reinterpret_cast<volatile unsigned int *>(host_status)[tid] = reinterpret_cast<const unsigned int *>(cnt)[tid];
-        if (tid == 0) *reinterpret_cast<volatile unsigned long long *>(&host_status->n_kept) = total;
+        if (tid == 0) {
+            *reinterpret_cast<volatile unsigned long long *>(&host_status->n_kept) = total;
+            *reinterpret_cast<volatile unsigned long long *>(&host_status->n_wide) = total_wide;
+        }
     }
     if (cnt->overflow) return;                                           // (the host runs such a pass again, synchronously)
     const int64_t n = min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
     const PackLayout L = pack_layout(n, close32);
+    const PackTail T = pack_tail(L.feats, (size_t)total, k, (size_t)total_wide);
     int64_t *o_close = reinterpret_cast<int64_t *>(out);
     int32_t *o_close32 = reinterpret_cast<int32_t *>(out);
     int32_t *o_pos = reinterpret_cast<int32_t *>(out + L.pos);
     int32_t *o_seg = reinterpret_cast<int32_t *>(out + L.seg);
     uint32_t *o_info = reinterpret_cast<uint32_t *>(out + L.info);
-    double *o_feats = reinterpret_cast<double *>(out + L.feats);
-    double *o_prob = o_feats + (int64_t)total * k;
+    int32_t *o_lo = reinterpret_cast<int32_t *>(out + T.lo32);
+    double *o_prob = reinterpret_cast<double *>(out + T.prob);
+    uint8_t *o_mask = out + T.wmask;
+    uint32_t *o_hi = reinterpret_cast<uint32_t *>(out + T.hi32);
     for (int64_t s = lo; s < hi; s += PACK_THREADS) {
         const int64_t i = s + tid;
         const bool valid = i < hi;
         const uint32_t info = valid ? O.info[i] : MC_I_TOO_MANY;
         const bool keep = !(info & MC_I_TOO_MANY);
-        const unsigned long long mask = __ballot(keep);
-        if (lane == 0) s_wave[wave] = (unsigned int)__popcll(mask);
+        {
+            const int64_t n_here = min((int64_t)PACK_THREADS, hi - s) * k;
+            for (int64_t j = tid; j < n_here; j += PACK_THREADS) s_feats[j] = O.feats[s * k + j];
+        }
         __syncthreads();
-        unsigned int in_strip = (unsigned int)__popcll(mask & ((1ull << lane) - 1ull)), strip = 0;
-        for (int w = 0; w < PACK_THREADS / 64; ++w) { if (w < wave) in_strip += s_wave[w]; strip += s_wave[w]; }
-        s_row[tid] = keep ? (int)in_strip : -1;
+        // the record's slot means: 32-bit integers where they are fl(d / 1e4), both halves where they are not
+        int32_t lo32[MC_MAX_K];
+        uint32_t hi32[MC_MAX_K];
+        unsigned int wmask = 0, n_w = 0;
+        if (keep) {
+            const unsigned noted = O.wmask[i];
+            for (int f = 0; f < k; ++f) {
+                const double x = s_feats[tid * k + f];
+                int32_t d = 0;
+                const bool narrow = noted != 0xFFu ? !((noted >> f) & 1u) : slot_is_narrow(x, &d);
+                if (narrow) lo32[f] = noted != 0xFFu ? (int32_t)rint(x * 1e4) : d;
+                else {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+                    lo32[f] = (int32_t)(uint32_t)bits;
+                    hi32[n_w++] = (uint32_t)(bits >> 32);
+                    wmask |= 1u << f;
+                }
+            }
+        }
+        // places: rank among the strip's kept records; wide slots before this record's
+        const unsigned long long kmask = __ballot(keep);
+        unsigned int w_incl = n_w;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int y = __shfl_up(w_incl, o);
+            if (lane >= o) w_incl += y;
+        }
+        if (lane == 63) s_wave[1][wave] = w_incl;
+        if (lane == 0) s_wave[0][wave] = (unsigned int)__popcll(kmask);
+        __syncthreads();
+        unsigned int in_strip = (unsigned int)__popcll(kmask & ((1ull << lane) - 1ull)), strip = 0, w_off = w_incl - n_w, w_strip = 0;
+        for (int j = 0; j < PACK_THREADS / 64; ++j) {
+            if (j < wave) { in_strip += s_wave[0][j]; w_off += s_wave[1][j]; }
+            strip += s_wave[0][j];
+            w_strip += s_wave[1][j];
+        }
         if (valid) {
             if (close32) o_close32[i] = (int32_t)O.close_row[i];
             else o_close[i] = O.close_row[i];
             o_pos[i] = O.site_pos[i];
             o_seg[i] = O.site_seg[i];
             o_info[i] = info;
-            if (keep) o_prob[base + in_strip] = O.prob[i];
-        }
-        __syncthreads();
-        const double *src = O.feats + s * k;                             // the strip's slot means, all threads on consecutive words
-        double *dst = o_feats + (int64_t)base * k;
-        for (int idx = tid; idx < PACK_THREADS * k; idx += PACK_THREADS) {
-            const int r = idx / k, f = idx - r * k, row = s_row[r];
-            if (row >= 0) dst[(int64_t)row * k + f] = src[idx];
+            if (keep) {
+                const unsigned long long row = base + in_strip;
+                o_prob[row] = O.prob[i];
+                o_mask[row] = (uint8_t)wmask;
+                for (int f = 0; f < k; ++f) o_lo[row * k + f] = lo32[f];
+                for (unsigned int j = 0; j < n_w; ++j) o_hi[wbase + w_off + j] = hi32[j];
+            }
         }
         __syncthreads();
         base += strip;
+        wbase += w_strip;
     }
 }
 
@@ -2515,6 +2614,10 @@ struct mc_ctx {
         unsigned long long *chunk_cnt = nullptr;               // k_pack_count -> k_pack
         Payload *sorted = nullptr;                             // the pass's payloads in record order (k1_list -> k1_emit, k1_rare_dev)
         int64_t *rare = nullptr;                               // records k1_emit leaves to k1_rare_dev
+        int32_t *h_lo32 = nullptr;                             // in pack_host: the slot means' 32-bit parts, the wide ones' high halves,
+        uint32_t *h_hi32 = nullptr;                            // the mask byte of every call (mc_calls_view)
+        unsigned char *h_wmask = nullptr;
+        int64_t h_n_wide = 0;
         int32_t *h_close32 = nullptr;                          // in pack_host: 32-bit closing rows (tables below 2^31 - 1 rows), else H.close_row
         bool close32 = false;
         int64_t h_n_calls = 0;
@@ -3532,7 +3635,8 @@ static int ensure_records(mc_ctx *c, int64_t cap, int k) {
         D->capacity = cap;
         if (dev_alloc(c->rec_allocs, &D->feats, (size_t)cap * k) || dev_alloc(c->rec_allocs, &D->site_pos, (size_t)cap) ||
             dev_alloc(c->rec_allocs, &D->site_seg, (size_t)cap) || dev_alloc(c->rec_allocs, &D->close_row, (size_t)cap) ||
-            dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap))
+            dev_alloc(c->rec_allocs, &D->info, (size_t)cap) || dev_alloc(c->rec_allocs, &D->prob, (size_t)cap) ||
+            dev_alloc(c->rec_allocs, &D->wmask, (size_t)cap))
             return -10;
     }
     c->payload_tiles = need_tiles;
@@ -3570,7 +3674,7 @@ static int alloc_records(std::vector<void *> &pool, DevRecords &D, int64_t cap, 
     D.capacity = cap;
     if (dev_alloc(pool, &D.feats, (size_t)cap * k) || dev_alloc(pool, &D.site_pos, (size_t)cap) ||
         dev_alloc(pool, &D.site_seg, (size_t)cap) || dev_alloc(pool, &D.close_row, (size_t)cap) ||
-        dev_alloc(pool, &D.info, (size_t)cap) || dev_alloc(pool, &D.prob, (size_t)cap))
+        dev_alloc(pool, &D.info, (size_t)cap) || dev_alloc(pool, &D.prob, (size_t)cap) || dev_alloc(pool, &D.wmask, (size_t)cap))
         return -10;
     return 0;
 }
@@ -3819,6 +3923,7 @@ extern "C" int mc_fetch_records_view(mc_ctx *c, mc_calls_view *out) {
     out->n_call_rows = 0;
     out->close_row32 = nullptr;
     out->compacted = 0;
+    out->feats_lo32 = nullptr; out->feats_hi32 = nullptr; out->feats_wide = nullptr; out->n_wide = 0;
     return 0;
 }
 
@@ -3871,8 +3976,8 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
                      (long long)cap);
         return -12;
     }
-    const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8) + 64;
-    if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_WGS)) return -10;
+    const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8 + 1) + 128;       // (every slot mean 64 bits wide at worst, a mask byte per call)
+    if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)2 * PACK_WGS)) return -10;
     if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
@@ -3908,7 +4013,7 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
 // Packing of a pass whose classifier has been enqueued (ev_k2_end recorded): what mc_wait_records_begin copies out.
 static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
     hipStream_t s2 = c->side_stream;
-    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.chunk_cnt);
+    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.k, b.chunk_cnt);
     hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt,
                        (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
     HIP_TRY(hipEventRecord(b.ev_done, s2));
@@ -4024,7 +4129,9 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         const int k = b.k;
         const size_t m = (size_t)std::min<unsigned long long>(st.n_kept, n);
         const PackLayout L = pack_layout((int64_t)n, b.close32 ? 1 : 0);
-        const size_t out_bytes = L.feats + m * ((size_t)k + 1) * 8;
+        const size_t n_wide = (size_t)std::min<unsigned long long>(st.n_wide, (unsigned long long)m * (size_t)k);
+        const PackTail PT_ = pack_tail(L.feats, m, k, n_wide);
+        const size_t out_bytes = PT_.end;
         // (a small record set -- a shard of a streamed file -- by kernel: the DMA engines may be busy with text, see k_copy_bytes;
         // and on the side stream, right behind the packing: the runtime folds the streams of a process onto four hardware
         // queues, and a copy stream that shares one with the parse stream would wait behind the kernels of the shards ahead,
@@ -4038,8 +4145,12 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         b.H.site_pos = reinterpret_cast<int32_t *>(b.pack_host + L.pos);
         b.H.site_seg = reinterpret_cast<int32_t *>(b.pack_host + L.seg);
         b.H.info = reinterpret_cast<uint32_t *>(b.pack_host + L.info);
-        b.H.feats = reinterpret_cast<double *>(b.pack_host + L.feats);
-        b.H.prob = b.H.feats + m * (size_t)k;
+        b.H.feats = nullptr;                                             // (they travel as 32-bit integers where they can)
+        b.h_lo32 = reinterpret_cast<int32_t *>(b.pack_host + PT_.lo32);
+        b.H.prob = reinterpret_cast<double *>(b.pack_host + PT_.prob);
+        b.h_wmask = b.pack_host + PT_.wmask;
+        b.h_hi32 = reinterpret_cast<uint32_t *>(b.pack_host + PT_.hi32);
+        b.h_n_wide = (int64_t)n_wide;
         b.h_n_calls = (int64_t)m;
         HIP_TRY(hipEventRecord(b.ev_copied, cs));
     }
@@ -4110,6 +4221,11 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->close_row32 = b.h_close32;
     out->call_row = nullptr;       // (not sent: the row of record j is the number of records before it without MC_I_TOO_MANY)
     out->compacted = 1;
+    const bool packed = n > 0 && b.used;
+    out->feats_lo32 = packed ? b.h_lo32 : nullptr;
+    out->feats_hi32 = packed ? b.h_hi32 : nullptr;
+    out->feats_wide = packed ? b.h_wmask : nullptr;
+    out->n_wide = packed ? b.h_n_wide : 0;
     out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
     return 0;
 }

@@ -154,15 +154,40 @@ int64_t kept_in(const mc_calls_view *rec, int64_t lo, int64_t hi) {
 
 // Row of feats / prob that belongs to record j, for a walk over consecutive records: compacted views without a call_row
 // column count the records without MC_I_TOO_MANY as they go (mc_calls_view)
+// wide slots (mc_calls_view.feats_wide) of call rows [0, row)
+int64_t wide_before(const mc_calls_view *rec, int64_t row) {
+    int64_t w = 0;
+    for (int64_t r = 0; r < row; ++r) w += __builtin_popcount(rec->feats_wide[r]);
+    return w;
+}
+
 struct RowCursor {
     const mc_calls_view *rec;
     int64_t kept;           // records without MC_I_TOO_MANY before the current one (compacted views without call_row)
-    RowCursor(const mc_calls_view *r, int64_t first) : rec(r), kept(r->compacted && !r->call_row ? kept_in(r, 0, first) : 0) {}
+    int64_t wide;           // packed slot means: wide slots before the current call row
+    bool wide_known;
+    RowCursor(const mc_calls_view *r, int64_t first)
+        : rec(r), kept(r->compacted && !r->call_row ? kept_in(r, 0, first) : 0), wide(0), wide_known(false) {}
     // (call for every record in order; info = rec->info[j])
     int64_t row(int64_t j, uint32_t info) {
         if (!rec->compacted) return j;
         if (rec->call_row) return rec->call_row[j];
         return (info & MC_I_TOO_MANY) ? -1 : kept++;
+    }
+    // the k slot means of call row `row` (rows must come in ascending order) into f[]
+    void feats(int64_t row, int k, double *f) {
+        if (rec->feats) { memcpy(f, rec->feats + row * k, (size_t)k * sizeof(double)); return; }
+        if (!wide_known) { wide = wide_before(rec, row); wide_known = true; }
+        const unsigned mask = rec->feats_wide[row];
+        const int32_t *lo = rec->feats_lo32 + row * k;
+        for (int s = 0; s < k; ++s) {
+            if ((mask >> s) & 1u) {
+                const uint64_t bits = ((uint64_t)rec->feats_hi32[wide++] << 32) | (uint32_t)lo[s];
+                memcpy(&f[s], &bits, 8);
+            } else {
+                f[s] = (double)lo[s] / 1e4;
+            }
+        }
     }
 };
 
@@ -209,7 +234,8 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         o += 2 * k - 1;
         *o++ = '\t';
         const uint32_t empty = info & MC_I_EMPTY_MASK;
-        const double *f = rec->feats + row * k;
+        double f[MC_MAX_K];
+        cur.feats(row, k, f);
         for (int i = 0; i < k; ++i) {
             if ((empty >> i) & 1u) *o++ = '0';                                     // literal int 0  (:186)
             else o = put_repr(o, f[i]);
@@ -298,17 +324,40 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     return 0;
 }
 
-extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t *call_row_out, int64_t *close_row_out) {
-    if (!rec || n < 0 || (n > 0 && !rec->info) || (close_row_out && n > 0 && !rec->close_row && !rec->close_row32)) {
+extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t k, int32_t *call_row_out, int64_t *close_row_out,
+                               double *feats_out) {
+    if (!rec || n < 0 || (n > 0 && !rec->info) || (close_row_out && n > 0 && !rec->close_row && !rec->close_row32) ||
+        (feats_out && (k < 1 || k > MC_MAX_K || (!rec->feats && !(rec->feats_lo32 && rec->feats_wide))))) {
         mc_set_error("mc_calls_expand: bad arguments");
         return -12;
     }
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(mc_host_cores(), n / 16384));
-    std::vector<int64_t> kept((size_t)nt + 1, 0);
     auto piece = [&](int w, int64_t &lo, int64_t &hi) { lo = n * w / nt; hi = n * (w + 1) / nt; };
-    if (call_row_out && rec->compacted && !rec->call_row)
+    const bool count_rows = rec->compacted && !rec->call_row && (call_row_out || feats_out);
+    std::vector<int64_t> kept((size_t)nt + 1, 0), wide((size_t)nt + 1, 0);
+    if (count_rows)
         mc_parallel_for(nt, [&](int w) { int64_t lo, hi; piece(w, lo, hi); kept[(size_t)w + 1] = kept_in(rec, lo, hi); });
     for (int w = 0; w < nt; ++w) kept[(size_t)w + 1] += kept[(size_t)w];
+    const bool packed = feats_out && !rec->feats;
+    // (call rows are numbered in record order: the rows of piece w are [first_row(w), first_row(w + 1)))
+    auto first_row = [&](int w) -> int64_t {
+        if (!rec->compacted) { int64_t lo, hi; piece(std::min(w, nt - 1), lo, hi); return w >= nt ? n : lo; }
+        if (rec->call_row) {
+            if (w >= nt) return rec->n_call_rows;
+            int64_t lo, hi; piece(w, lo, hi);
+            for (int64_t j = lo; j < n; ++j) if (rec->call_row[j] >= 0) return rec->call_row[j];
+            return rec->n_call_rows;
+        }
+        return kept[(size_t)w];
+    };
+    if (packed) {
+        mc_parallel_for(nt, [&](int w) {
+            int64_t c = 0;
+            for (int64_t r = first_row(w), e = first_row(w + 1); r < e; ++r) c += __builtin_popcount(rec->feats_wide[r]);
+            wide[(size_t)w + 1] = c;
+        });
+        for (int w = 0; w < nt; ++w) wide[(size_t)w + 1] += wide[(size_t)w];
+    }
     mc_parallel_for(nt, [&](int w) {
         int64_t lo, hi;
         piece(w, lo, hi);
@@ -320,6 +369,17 @@ extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t *cal
                 if (!rec->compacted) call_row_out[j] = (int32_t)j;
                 else if (rec->call_row) call_row_out[j] = rec->call_row[j];
                 else call_row_out[j] = (rec->info[j] & MC_I_TOO_MANY) ? -1 : (int32_t)row++;
+            }
+        }
+        if (feats_out) {
+            const int64_t r0 = first_row(w), r1 = first_row(w + 1);
+            if (rec->feats) {
+                if (r1 > r0) memcpy(feats_out + r0 * k, rec->feats + r0 * k, (size_t)(r1 - r0) * (size_t)k * sizeof(double));
+            } else {
+                RowCursor cur(rec, lo);
+                cur.wide = wide[(size_t)w];
+                cur.wide_known = true;
+                for (int64_t r = r0; r < r1; ++r) cur.feats(r, k, feats_out + r * k);
             }
         }
     });

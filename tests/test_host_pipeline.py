@@ -179,13 +179,26 @@ def _compacted(rec, k, as_sent=False):
     c.k, c.capacity, c.n = k, n, n
     for name in ('site_pos', 'site_seg', 'close_row', 'info'):
         setattr(c, name, getattr(rec, name)[:n].copy())
+    dense = np.ascontiguousarray(rec.feats[:n * k].reshape(n, k)[kept]).reshape(-1)
+    c._n_calls = int(kept.sum())
     if as_sent:
         c._close_row32, c._close_row = rec.close_row[:n].astype(np.int32), None
         c._compacted = True
+        # the slot means packed like k_pack packs them: 32-bit d where the mean is fl(d / 1e4), both halves where it is not
+        d = np.rint(dense * 1e4)
+        ok = np.abs(d) < 2147483648.0
+        back = np.where(ok, d, 0.0).astype(np.int32).astype(np.float64) / 1e4
+        narrow = ok & (back.view(np.uint64) == dense.view(np.uint64))
+        bits = dense.view(np.uint64)
+        lo = np.where(narrow, np.where(ok, d, 0.0).astype(np.int32), (bits & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+        hi = (bits[~narrow] >> 32).astype(np.uint32)
+        wide = (~narrow).reshape(-1, k)
+        mask = (wide * (1 << np.arange(k))).sum(axis=1).astype(np.uint8)
+        c._packed = (np.ascontiguousarray(lo, dtype=np.int32), np.ascontiguousarray(hi), np.ascontiguousarray(mask))
+        assert 0 < len(hi) < len(dense)                      # (some of each kind)
     else:
         c.call_row = np.where(kept, np.cumsum(kept) - 1, -1).astype(np.int32)
-    c._n_calls = int(kept.sum())
-    c.feats = np.ascontiguousarray(rec.feats[:n * k].reshape(n, k)[kept]).reshape(-1)
+        c.feats = dense
     c.prob = np.ascontiguousarray(rec.prob[:n][kept])
     return c
 
@@ -223,9 +236,14 @@ def test_rows_from_a_compacted_view(td, tmp_path):
     # the library's own expansion of the columns that are not sent (all cores)
     from mcaller_amd import _lib
     rows, close = np.empty(rec.n, dtype=np.int32), np.empty(rec.n, dtype=np.int64)
-    v = sent.view()
-    _lib.check(_lib.lib().mc_calls_expand(C.byref(v), rec.n, rows.ctypes.data, close.ctypes.data))
+    dense = np.empty(sent.n_calls * 6, dtype=np.float64)
+    fresh = _compacted(rec, 6, as_sent=True)                  # (nothing unpacked yet)
+    v = fresh.view()
+    assert not v.feats and v.feats_lo32 and v.n_wide > 0
+    _lib.check(_lib.lib().mc_calls_expand(C.byref(v), rec.n, 6, rows.ctypes.data, close.ctypes.data, dense.ctypes.data))
     assert np.array_equal(rows, comp.call_row[:rec.n]) and np.array_equal(close, rec.close_row[:rec.n])
+    assert np.array_equal(dense.view(np.uint64), comp.feats.view(np.uint64))       # bit for bit
+    assert np.array_equal(fresh.feats.view(np.uint64), comp.feats.view(np.uint64))
 
 
 def test_native_motif_marking_equals_str_replace(tmp_path):

@@ -2,7 +2,7 @@
 # kernel averages of a file-to-file run (CLI, streaming): tools/f2f_profile.sh <rows>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/f2f; mkdir -p gpurun_out/f2f
-rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d gpurun_out/f2f/p -- python3 tools/file_to_file.py ${1:-1e7} > gpurun_out/f2f/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d gpurun_out/f2f/p -- python3 tools/file_to_file.py ${1:-1e7} > gpurun_out/f2f/log.txt 2>&1
 find gpurun_out/f2f/p -name "*kernel_stats.csv" -exec cp {} gpurun_out/f2f/kernel_stats.csv \;
 python3 - <<P
 import csv

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
 for mode in sync pipe; do
   extra=""; [ $mode = sync ] && extra="--no-pipeline"
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/$mode -- python3 bench.py --steps 50 --warmup 5 --kernels-only $extra "$@" > gpurun_out/$tag/$mode.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/$mode -- python3 bench.py --steps 50 --warmup 5 --kernels-only $extra "$@" > gpurun_out/$tag/$mode.log 2>&1
   find gpurun_out/$tag/$mode -name "*kernel_stats.csv" -exec cp {} gpurun_out/$tag/${mode}_stats.csv \;
   rm -rf gpurun_out/$tag/$mode
 done

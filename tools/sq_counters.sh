@@ -7,7 +7,7 @@ rm -rf gpurun_out/sq; mkdir -p gpurun_out/sq
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/sq/p$i -- python3 bench.py --steps 2 --warmup 1 --kernels-only $extra > gpurun_out/sq/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/sq/p$i -- python3 bench.py --steps 2 --warmup 1 --kernels-only $extra > gpurun_out/sq/p$i.log 2>&1
 done
 python3 - <<'P'
 import csv, glob, collections
