@@ -223,6 +223,10 @@ def main():
     info = rec.info[:rec.n]
     n_calls = int(((info & _lib.I_TOO_MANY) == 0).sum())
     n_records = int(rec.n)
+    # what a pipelined pass sends over PCIe (mc_calls_view): 16 B per record; per call k 32-bit slot words, the probability and
+    # the mask of its wide slots; the high words of the wide slots
+    packed = getattr(rec, '_packed', None)
+    copy_out_bytes = None if packed is None else 16 * n_records + n_calls * (4 * 6 + 8 + 1) + 4 * int(len(packed[1]))
 
     calls_total, elapsed_max = n_calls, elapsed
     if dist is not None:
@@ -489,6 +493,7 @@ def main():
                                    'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
                        'passes_in_flight': 1 if args.no_pipeline else min(3, args.steps),
                        'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': n_records,
+                       'copy_out_bytes_per_pass': copy_out_bytes,
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
                        'kernel_ms': kernel_ms, 'kernel_ms_from_passes': len(tot_ms), 'timing_events_every_n_passes': time_every,
                        'kernel_ms_one_pass_at_a_time': sync_ms,

@@ -31,6 +31,7 @@
 // seen before) is argued in DESIGN.md; every other block is classified irregular and handled by the
 // literal per-run kernel (k_literal) so results never depend on a CPU path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -174,8 +175,12 @@ struct Counters {          // device-side status block
 
 // The small kernels on the ctx stream's critical path (strand resolve, tile descriptors, the ordering of the payloads) run
 // beside the previous pass's classifier, whose waves keep the vector pipes busy: with the default wave priority the
-// arbiter serves the older (classifier) waves first and these latency-bound kernels take twice as long.
+// arbiter serves the older (classifier) waves first and these latency-bound kernels take twice as long.  (Not the scan and
+// the emit: with the raised priority a pipelined pass takes 0.204 / 0.208 ms instead of 0.200.)
 #define MC_FRONT_OF_THE_QUEUE __builtin_amdgcn_s_setprio(3)
+#ifndef MC_EVENTS_ON_KERNELS
+#define MC_EVENTS_ON_KERNELS 1
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // device helpers
@@ -3755,7 +3760,7 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
-                      hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list) {
+                      hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, hipEvent_t ev_emit_end = nullptr) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tiles = K.tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
@@ -3771,8 +3776,15 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
     hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted);
-    hipLaunchKernelGGL(k1_emit, dim3((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs)), dim3(256), 0,
-                       st, A, (const Payload *)sorted);
+    // (ev_emit_end rides on the emit's own dispatch packet: a hipEventRecord behind it is a barrier packet of its own and
+    // costs the queue 5-9 us)
+    const dim3 emit_grid((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs));
+    if (ev_emit_end && MC_EVENTS_ON_KERNELS)
+        hipExtLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
+    else {
+        hipLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, A, (const Payload *)sorted);
+        if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
+    }
     *out_args = A;
     return 0;
 }
@@ -4002,11 +4014,11 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     hipStream_t st = c->side_stream;
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
-    HIP_TRY(hipEventRecord(b.ev_k2_start, st));
+    if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
     if (b.prm.score)
         launch_k2(c, k2_grid(c, b.cap), st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr,
                   b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
-    HIP_TRY(hipEventRecord(b.ev_k2_end, st));
+    if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_end, st));
     return 0;
 }
 
@@ -4014,9 +4026,14 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
 static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
     hipStream_t s2 = c->side_stream;
     hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.k, b.chunk_cnt);
-    hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt,
-                       (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
-    HIP_TRY(hipEventRecord(b.ev_done, s2));
+    if (MC_EVENTS_ON_KERNELS)
+        hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, nullptr, b.ev_done, 0, b.O, (const Counters *)b.cnt,
+                              (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
+    else {
+        hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt,
+                           (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
+        HIP_TRY(hipEventRecord(b.ev_done, s2));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -4059,7 +4076,11 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // K0 on the side stream beside K2 on the ctx stream -3 % (two cross-queue hand-overs of 15-25 us on the scan's path);
     // K2 + packing deferred so that they run beside the next SCAN: the same (K2 gets one wave per SIMD there and takes 195 us
     // instead of 68); separate streams for K0 and K2: they land on one hardware queue and serialise; low-priority side
-    // streams: time-sliced, 40 % slower.
+    // streams: time-sliced, 40 % slower; K0 of the next pass on a stream of its own, enqueued a whole pass ahead (it touches
+    // nothing but the pass's own buffers): 0.286 ms per pass instead of 0.206 (a fifth stream shares a hardware queue), 0.238
+    // with GPU_MAX_HW_QUEUES=8 -- which by itself costs 9 % (0.225); odd and even passes on two streams, the scan of a pass
+    // waiting for the ordering kernels of the pass before it (the scratch they share) so that it runs beside that pass's emit,
+    // one copy stream: 0.268 ms -- the kernels take what they take alone, the queues hand over slowly.
     hipStream_t st = c->stream;
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     // (a hipEventRecord between two kernels costs this queue ~9 us -- rocprofv3 timeline -- so the two events that only time
@@ -4072,8 +4093,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare)) return rc;
-    HIP_TRY(hipEventRecord(b.ev_emit_end, st));
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.ev_emit_end)) return rc;
     if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b)) return rc;
