@@ -40,7 +40,9 @@ typedef struct mc_table_view {
     int64_t n_rows;
     const int32_t *pos;        /* col 2: 0-based k-mer start                                  :175 */
     const int32_t *event_model_e4; /* [2*n_rows] per row: col 7 event_level_mean, col 11 model_mean, in units of 1e-4 pA,
-                                      interleaved -- the parser writes the pair, and a window's events are one DRAM page :286 */
+                                      interleaved -- the parser writes the pair, and a window's events are one DRAM page :286.
+                                      |value| < 10^9 (the kernels take event - model in 32 bits; both parsers refuse a row
+                                      beyond that, or hand over the rounded difference and a model of 0) */
     const int32_t *event_idx;  /* col 6                                                   :162,169 */
     const uint8_t *flags;      /* MC_F_*                                                           */
     int32_t n_seg;

@@ -4080,7 +4080,9 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // nothing but the pass's own buffers): 0.286 ms per pass instead of 0.206 (a fifth stream shares a hardware queue), 0.238
     // with GPU_MAX_HW_QUEUES=8 -- which by itself costs 9 % (0.225); odd and even passes on two streams, the scan of a pass
     // waiting for the ordering kernels of the pass before it (the scratch they share) so that it runs beside that pass's emit,
-    // one copy stream: 0.268 ms -- the kernels take what they take alone, the queues hand over slowly.
+    // one copy stream: 0.268 ms -- the kernels take what they take alone, the queues hand over slowly; the classifier in front
+    // of k1_rare_dev (and once more behind it, if that kernel had a window to finish), so that it starts 8 us earlier and
+    // runs less beside the scan: 0.2055 instead of 0.1985.
     hipStream_t st = c->stream;
     if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     // (a hipEventRecord between two kernels costs this queue ~9 us -- rocprofv3 timeline -- so the two events that only time

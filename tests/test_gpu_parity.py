@@ -309,6 +309,55 @@ def test_pipelined_passes_equal_the_synchronous_path(dev, tmp_path):
     assert n_checked > 20
 
 
+@pytest.mark.parametrize('flavour', ['largest', 'mixed', 'equal_events'])
+def test_packed_slot_means_at_the_edges_of_the_32_bit_form(dev, flavour):
+    """mc_wait_records sends a slot mean as the integer d where it is fl(d / 10^4) (mc_calls_view.feats_lo32) and as two
+    32-bit halves where it is not: currents at the edge of what a table may hold (|value| < 10^9, differences up to 2*10^9),
+    ordinary ones next to them, and slots whose events are all equal (a mean of several events that is fl(d / 10^4)) -- the
+    unpacked means are the oracle's doubles bit for bit."""
+    from mcaller_amd import synth, _lib
+    codes = synth.genome(length=300000, seed=17)
+    ref = synth.SynthRef(codes, motif='GATC')
+    table, qual = synth.make_table(400000, seed=71, codes=codes)
+    rng = np.random.default_rng(5)
+    n = table.n_rows
+    ev, mu = table.evmu[:, 0].astype(np.int64), table.evmu[:, 1].astype(np.int64)
+    keep_n = mu == 0                                        # (NNNNNN rows keep their model current of 0)
+    top = 10 ** 9 - 1
+    if flavour == 'largest':                                # |event - model| up to 2e9 - 2
+        ev = rng.choice([top, top - 1, top - 7, 999999000], size=n) * rng.choice([-1, 1], size=n)
+        mu = np.where(keep_n, 0, -np.sign(ev) * rng.choice([top, top - 1, top - 3, 999990000], size=n))
+    elif flavour == 'mixed':                                # one row in three far out
+        far = rng.random(n) < 0.33
+        ev = np.where(far, rng.integers(-top, top, size=n), ev)
+    else:                                                   # every event of a position the same: means of equal numbers
+        ev = np.where(keep_n, ev, mu + (table.pos.astype(np.int64) * 7919 % 40001 - 20000) * 100)
+    table.evmu[:, 0] = ev
+    table.evmu[:, 1] = mu
+    dev.set_reference(ref.device_arrays())
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    for skip in (0, 2):
+        want = H.oracle_records(table, ref.device_arrays(), qual, 6, skip, 0.0)
+        dev.run_async(6, skip, 0.0, score=False)
+        dev.run_async(6, skip, 0.0, score=False)
+        for _ in range(2):
+            raw = dev.wait()
+            lo, hi, wide = raw._packed
+            got = raw.by_record()
+            assert got.n == want.n > 500
+            assert (got.info[:got.n] == want.info[:want.n]).all() and (got.site_pos[:got.n] == want.site_pos[:want.n]).all()
+            a, b = got.feats[:got.n * 6].view(np.uint64), want.feats[:want.n * 6].view(np.uint64)
+            kept = np.repeat((want.info[:want.n] & _lib.I_TOO_MANY) == 0, 6)
+            assert (a[kept] == b[kept]).all()
+        n_slots = len(lo)
+        print('%s, skip %d: %d of %d slot means travel wide' % (flavour, skip, len(hi), n_slots))
+        if flavour == 'equal_events':                       # (x + x + x) / 3 is not always x: a few are left
+            assert len(hi) < 0.05 * n_slots
+        else:
+            assert 0 < len(hi) < n_slots
+
+
 @pytest.mark.parametrize('n_rows,motif,score', [
     (100000000, 'GATC', True),      # BASELINE.json configs[2]: 10^8 events, -m GATC, NN classifier
     (10000000, 'A', False),         # configs[4]-sized feature-matrix build (--train: features only), dense sites
