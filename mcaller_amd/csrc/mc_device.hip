@@ -2288,9 +2288,10 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 // 32 bits wide for tables below 2^31 - 1 rows --, site, segment, info) and, behind them, the slot means and the probability
 // of the records that are calls -- compacted: a record with MC_I_TOO_MANY is only counted by the host (:239), nothing reads
 // its means, and at 6 % skips it is every third record.  The row of record j in the compacted part is the number of
-// records before it without MC_I_TOO_MANY: the host derives it where it needs it (mc_calls_view) -- the copy-out is what
-// bounds a pass (PCIe, 55 GB/s), so bytes dropped here are time (16 instead of 24 narrow bytes per record: 12.8 -> 11.2 MB
-// per pass of the headline workload).  Two small kernels: per-chunk counts of kept records, then every
+// records before it without MC_I_TOO_MANY: the host derives it where it needs it (mc_calls_view) -- the copy-out was what
+// bounded a pass (PCIe, 55 GB/s), so bytes dropped here were time (16 instead of 24 narrow bytes per record: 12.8 -> 11.2 MB
+// per pass of the headline workload; the slot means as 32-bit integers where they can be, see pack_tail: 8.75 MB, and the
+// kernels of the ctx stream are the bound).  Two small kernels: per-chunk counts of kept records, then every
 // workgroup sums the counts before its chunk and packs the chunk.  The pass's counters go to pinned host memory from here
 // as well (a 96-byte store over PCIe): the host reads them after hipEventSynchronize(ev_done) and enqueues the transfer
 // at once, without a read-back on the copy stream in between.
