@@ -199,7 +199,7 @@ def main():
     # The kernel times come from hipEvents on the ctx stream.  An event between two kernels costs that queue ~9 us (6 % of a
     # pass), so in the pipelined loop only every n-th pass carries the two events that do nothing but time it; kernel_ms is
     # an average over those passes of the timed region (one pass at a time: every pass).
-    time_every = 1 if args.no_pipeline else max(1, min(args.time_every, max(1, args.steps // 4)))
+    time_every = 1 if args.no_pipeline else max(1, min(args.time_every, max(1, args.steps // 2)))
     dev.set_pass_timing(time_every)
 
     def on_done(rec):
