@@ -242,58 +242,77 @@ def main():
     # (mc_site_counts / mc_site_allreduce); if that fails (e.g. a plumbing test with two ranks on one GPU) the same
     # reduction goes through torch.distributed (nccl, then gloo) from the host copy of the records.
     reduction = None
+    reduction_hung = False
     if dist is not None:
-        from mcaller_amd import make_bed
-        index = make_bed.SiteIndex(ref.meth, 1)
-        e_native = None
-        try:
-            uid = [None]
-            try:
-                if rank == 0:
-                    uid = [Device.comm_unique_id()]           # loads librccl.so
-            finally:
-                dist.broadcast_object_list(uid, src=0)
-            if uid[0] is None:
-                raise RuntimeError('rank 0 could not create an RCCL unique id')
-            dev.comm_init(world, rank, uid[0])
-            dev.site_counts(row_offset=rank * n_rows)
-            n_meth, n_total, fmin, ms = dev.site_allreduce()
-        except Exception as e:                                 # noqa
-            e_native = e
-        flags = [None] * world
-        dist.all_gather_object(flags, e_native is None)        # every rank takes the same branch
-        if all(flags):
-            reduction = {'backend': 'rccl (ncclAllReduce through the C ABI)', 'ms': ms, 'observations': int(n_total.sum()),
-                         'observations_expected': calls_total, 'bytes': int(index.n * 16), 'sites': int(index.n)}
-        else:
-            try:
-                import torch
-                counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
+        import threading
+        box = {}
 
-                def reduce_with(backend):
-                    group = dist.new_group(backend=backend) if backend == 'nccl' else None
-                    packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
-                    fmin = torch.from_numpy(counts[2].copy())
-                    if backend == 'nccl':
-                        torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
-                        packed, fmin = packed.cuda(), fmin.cuda()
-                    t_r = time.perf_counter()
-                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-                    dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
-                    if backend == 'nccl':
-                        torch.cuda.synchronize()
-                    return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
-
-                backend = 'torch nccl (native RCCL path failed: %s)' % e_native
+        def site_reduction_leg():
+            reduction = None
+            from mcaller_amd import make_bed
+            index = make_bed.SiteIndex(ref.meth, 1)
+            e_native = None
+            try:
+                uid = [None]
                 try:
-                    packed, fmin, ms = reduce_with('nccl')
-                except Exception as e_nccl:                    # noqa
-                    backend = 'gloo (native: %s; torch nccl: %s)' % (e_native, type(e_nccl).__name__)
-                    packed, fmin, ms = reduce_with('gloo')
-                reduction = {'backend': backend, 'ms': ms, 'observations': int(packed[1].sum().item()),
-                             'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
-            except Exception as e:                             # noqa
-                reduction = {'error': '%s: %s' % (type(e).__name__, e)}
+                    if rank == 0:
+                        uid = [Device.comm_unique_id()]           # loads librccl.so
+                finally:
+                    dist.broadcast_object_list(uid, src=0)
+                if uid[0] is None:
+                    raise RuntimeError('rank 0 could not create an RCCL unique id')
+                dev.comm_init(world, rank, uid[0])
+                dev.site_counts(row_offset=rank * n_rows)
+                n_meth, n_total, fmin, ms = dev.site_allreduce()
+            except Exception as e:                                 # noqa
+                e_native = e
+            flags = [None] * world
+            dist.all_gather_object(flags, e_native is None)        # every rank takes the same branch
+            if all(flags):
+                reduction = {'backend': 'rccl (ncclAllReduce through the C ABI)', 'ms': ms, 'observations': int(n_total.sum()),
+                             'observations_expected': calls_total, 'bytes': int(index.n * 16), 'sites': int(index.n)}
+            else:
+                try:
+                    import torch
+                    counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
+
+                    def reduce_with(backend):
+                        group = dist.new_group(backend=backend) if backend == 'nccl' else None
+                        packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
+                        fmin = torch.from_numpy(counts[2].copy())
+                        if backend == 'nccl':
+                            torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
+                            packed, fmin = packed.cuda(), fmin.cuda()
+                        t_r = time.perf_counter()
+                        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                        dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
+                        if backend == 'nccl':
+                            torch.cuda.synchronize()
+                        return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
+
+                    backend = 'torch nccl (native RCCL path failed: %s)' % e_native
+                    try:
+                        packed, fmin, ms = reduce_with('nccl')
+                    except Exception as e_nccl:                    # noqa
+                        backend = 'gloo (native: %s; torch nccl: %s)' % (e_native, type(e_nccl).__name__)
+                        packed, fmin, ms = reduce_with('gloo')
+                    reduction = {'backend': backend, 'ms': ms, 'observations': int(packed[1].sum().item()),
+                                 'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
+                except Exception as e:                             # noqa
+                    reduction = {'error': '%s: %s' % (type(e).__name__, e)}
+
+            box['reduction'] = reduction
+
+        # (a collective that never returns -- a rank that died, a fabric that does not come up -- must not take the measured
+        # line with it: the leg runs beside the main thread and is given two minutes)
+        th = threading.Thread(target=site_reduction_leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('MCALLER_BENCH_REDUCTION_TIMEOUT', '120')))
+        if th.is_alive():
+            reduction_hung = True
+            reduction = {'error': 'the per-site reduction did not return within its time limit'}
+        else:
+            reduction = box.get('reduction')
 
     # ---- the kernels one at a time (outside the timed region): hipEvents around every stage of a synchronous pass ----
     sync_ms = []
@@ -567,6 +586,9 @@ def main():
         print(json.dumps(out))
     if f2f_dir:
         shutil.rmtree(f2f_dir, ignore_errors=True)
+    if reduction_hung:                   # (a thread is stuck inside a collective: no orderly shutdown)
+        sys.stdout.flush()
+        os._exit(0)
     if dev is not None:
         dev.close()
     if dist is not None:
