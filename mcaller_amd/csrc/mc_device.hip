@@ -1302,7 +1302,9 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
 }
 
 // (six waves per SIMD: the register allocator fits 80 VGPRs without scratch; the kernel's time is rounds x latency, so resident
-// waves count -- four: 76 us for ordering + emit, five: 59, six: 55, seven (72 VGPRs, 20 bytes of scratch): 57)
+// waves count -- four: 76 us for ordering + emit, five: 59, six: 55, seven (72 VGPRs, 20 bytes of scratch): 57.  Six lanes per
+// window for k <= 6, ten windows per wave instead of eight: 66 us -- six loads per lane and step instead of four, the lane
+// arithmetic of groups that are not a power of two, and 20 bytes of scratch eat more than the fifth fewer waves give)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
