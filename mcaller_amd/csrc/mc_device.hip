@@ -2297,7 +2297,16 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
 // workgroup sums the counts before its chunk and packs the chunk.  The pass's counters go to pinned host memory from here
 // as well (a 96-byte store over PCIe): the host reads them after hipEventSynchronize(ev_done) and enqueues the transfer
 // at once, without a read-back on the copy stream in between.
-constexpr int PACK_WGS = 256, PACK_THREADS = 256;
+// (512 x 512: beside the next pass's scan the two kernels wait for memory most of the time, and twice the lanes have twice the
+// loads in flight -- k_pack 96 -> 46 us there, and the scan it runs beside 106 -> 96 us; pipelined pass with 256 x 256: 0.2013 ms,
+// 448 or 512: 0.193-0.195, 576: 0.203, 640: 0.207, 768: 0.215, 1024: 0.231; 256 x 512, 384 x 384: 0.195-0.197)
+#ifndef MC_PACK_WGS
+#define MC_PACK_WGS 512
+#endif
+#ifndef MC_PACK_THREADS
+#define MC_PACK_THREADS 512
+#endif
+constexpr int PACK_WGS = MC_PACK_WGS, PACK_THREADS = MC_PACK_THREADS;
 
 struct PackLayout { size_t pos, seg, info, feats; };       // byte offsets in the block (the closing rows come first)
 __host__ __device__ inline PackLayout pack_layout(int64_t n, int close32) {
@@ -2359,14 +2368,14 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
                                                        const unsigned long long *__restrict__ chunk_cnt,
                                                        unsigned char *__restrict__ out, int k, int close32,
                                                        Counters *__restrict__ host_status) {
-    static_assert(PACK_WGS == PACK_THREADS, "one chunk count per thread");
+    static_assert(PACK_WGS <= PACK_THREADS && PACK_THREADS % 64 == 0, "one chunk count per thread");
     __shared__ unsigned long long s_sum[4][PACK_THREADS / 64];
     __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
     __shared__ double s_feats[PACK_THREADS * MC_MAX_K];     // the strip's slot means, loaded with consecutive lanes on consecutive words
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // kept records (and their wide slots) before this chunk, and in all chunks
-    unsigned long long v = chunk_cnt[tid], before = tid < (int)blockIdx.x ? v : 0ull;
-    unsigned long long w = chunk_cnt[PACK_WGS + tid], wbefore = tid < (int)blockIdx.x ? w : 0ull;
+    unsigned long long v = tid < PACK_WGS ? chunk_cnt[tid] : 0ull, before = tid < (int)blockIdx.x ? v : 0ull;
+    unsigned long long w = tid < PACK_WGS ? chunk_cnt[PACK_WGS + tid] : 0ull, wbefore = tid < (int)blockIdx.x ? w : 0ull;
     for (int o = 32; o > 0; o >>= 1) {
         v += __shfl_xor(v, o); before += __shfl_xor(before, o);
         w += __shfl_xor(w, o); wbefore += __shfl_xor(wbefore, o);
