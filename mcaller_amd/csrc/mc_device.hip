@@ -103,6 +103,8 @@ struct DevTable {
     int32_t *pos = nullptr, *idx = nullptr;
     int2 *evmu = nullptr;     // (event, model) pairs as the parser wrote them: one DRAM page per window for k1_emit
     uint8_t *flags = nullptr;
+    int2 *unit_pp = nullptr;  // [ceil(n_rows / 8)] positions of the first and the last row of every unit of eight rows (k_validate):
+                              // all the scan's filter looks at -- 1 B/row instead of the 5 B/row of the position and flag columns
     int32_t n_seg = 0;
     int64_t *seg_begin = nullptr;
     int32_t *seg_read = nullptr, *seg_contig = nullptr;
@@ -178,6 +180,9 @@ struct Counters {          // device-side status block
 // arbiter serves the older (classifier) waves first and these latency-bound kernels take twice as long.  (Not the scan and
 // the emit: with the raised priority a pipelined pass takes 0.204 / 0.208 ms instead of 0.200.)
 #define MC_FRONT_OF_THE_QUEUE __builtin_amdgcn_s_setprio(3)
+#ifndef MC_SCAN_SUMMARY
+#define MC_SCAN_SUMMARY 1
+#endif
 #ifndef MC_EVENTS_ON_KERNELS
 #define MC_EVENTS_ON_KERNELS 1
 #endif
@@ -267,6 +272,10 @@ __global__ __launch_bounds__(VT) void k_validate(DevTable T) {
             p4[q] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
             i4[q] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0);
             if (lane == 0 && t0 + i0 > 0) { pp[q] = T.pos[t0 + i0 - 1]; ip[q] = T.idx[t0 + i0 - 1]; }
+            // the unit summary: the group of four rows is the first or the second half of a unit of eight -- consecutive threads
+            // write consecutive words
+            const int64_t g4 = (t0 + i0) >> 2;
+            reinterpret_cast<int32_t *>(T.unit_pp)[g4] = (g4 & 1) ? p4[q].w : p4[q].x;
         }
     }
     // ---- name-block starts inside the tile ----
@@ -928,8 +937,9 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc
 #else
 #define MC_SCAN_ATTR
 #endif
-template <int CG>
+template <int CG, bool SUM>
 __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
+    static_assert(!SUM || CG <= 64, "one lane per listed unit fetches its rows");
     __shared__ uint32_t s_bits[NBST][64];
     __shared__ __attribute__((aligned(16))) CandUnit s_cand[CG];
     __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
@@ -942,9 +952,21 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
 
     // ---- the columns: every load of the tile goes out before anything is used ----
+    // (SUM: only the unit summaries -- first and last position of the lane's unit in stripe j --; the units that pass the
+    // filter, one in twenty, fetch their rows afterwards, one lane per listed unit)
     int4 pa[NQ], pb[NQ];                            // rows i0 .. i0+3, i0+4 .. i0+7 of the lane's unit in stripe j
     uint2 fl8[NQ];
-    if (nrows == TILE) {
+    if (SUM) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * 64 + lane) * 8;
+            int2 pp = make_int2(0, 0);
+            if (i0 < nrows) pp = T.unit_pp[(t0 + i0) >> 3];
+            pa[j] = make_int4(pp.x, 0, 0, 0);
+            pb[j] = make_int4(0, 0, 0, pp.y);
+            fl8[j] = make_uint2(0u, 0u);
+        }
+    } else if (nrows == TILE) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int i0 = (j * 64 + lane) * 8;
@@ -1001,6 +1023,11 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
                 const unsigned long long bal = __ballot(cand);
                 if (!bal) continue;
                 if (ncand + __popcll(bal) > CG) { overflow = true; continue; }
+                if (SUM) {                          // (the rows come later)
+                    if (cand) reinterpret_cast<uint32_t *>(s_cand + (ncand + __popcll(bal & below)))[12] = (uint32_t)i0 << 16;
+                    ncand += __popcll(bal);
+                    continue;
+                }
                 // the two rows behind the unit: the next lane's first two rows (lane 63: the next stripe's)
                 int nx = __shfl_down(pa[j].x, 1), ny = __shfl_down(pa[j].y, 1);
                 uint32_t nf = __shfl_down(fl8[j].x, 1);
@@ -1024,6 +1051,24 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
         if (lane == 0) s_seg_end[bi] = (uint16_t)ncand;
     }
     if (overflow) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }    // (nothing has been written yet)
+    if (SUM) __syncthreads();                       // (one wave: orders the list's words between the lanes)
+    if (SUM && lane < ncand) {
+        // the rows of the listed units and the two rows behind each (the columns are padded beyond the table's last row)
+        CandUnit *g = s_cand + lane;
+        const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
+        const int32_t *pr = T.pos + t0 + i0;
+        const uint8_t *fr = T.flags + t0 + i0;
+        const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
+        const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
+        const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
+        const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
+        int4 *gp = reinterpret_cast<int4 *>(g);
+        gp[0] = a;
+        gp[1] = b4;
+        gp[2] = make_int4(nx.x, nx.y, (int)f8.x, (int)f8.y);
+        reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
+    }
+    if (SUM) __syncthreads();
 
     // ---- one lane per row of the listed units, block by block: is this row the last row of a window? ----
     ScanGlobals G;
@@ -2537,6 +2582,7 @@ struct TableSlot {
     int32_t *pos = nullptr, *idx = nullptr;
     int2 *evmu = nullptr;
     uint8_t *flags = nullptr;
+    int2 *unit_pp = nullptr;
     NbDesc *nb_tmpl = nullptr;
     unsigned char *small_dev = nullptr, *stage = nullptr;   // the small arrays: device block, pinned host stage
     size_t small_cap = 0;
@@ -3021,7 +3067,7 @@ static void slot_free(TableSlot &S) {
     slot_free_parser(S);
     if (S.stage) (void)hipHostFree(S.stage);
     S.stage = nullptr; S.small_dev = nullptr; S.small_cap = 0;
-    S.pos = S.idx = nullptr; S.evmu = nullptr; S.flags = nullptr; S.nb_tmpl = nullptr;
+    S.pos = S.idx = nullptr; S.evmu = nullptr; S.flags = nullptr; S.nb_tmpl = nullptr; S.unit_pp = nullptr;
     S.cap_rows = S.cap_segs = S.cap_reads = 0;
     S.T = DevTable();
     S.qual = nullptr; S.n_qual = 0; S.tmpl_ref = -1;
@@ -3045,7 +3091,8 @@ static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int6
     const int64_t padded = ((S.cap_rows + VTILE - 1) / VTILE) * VTILE + VTILE + FRONT;     // (whole tiles of the scan and of k_validate)
     const SmallLayout L = small_layout(S.cap_segs, padded / TILE, S.cap_reads);
     if (dev_alloc(S.allocs, &S.pos, (size_t)padded) || dev_alloc(S.allocs, &S.idx, (size_t)padded) ||
-        dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded))
+        dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded) ||
+        dev_alloc(S.allocs, &S.unit_pp, (size_t)padded / 8 + 8))
         return -10;
     // (FRONT rows of padding before row 0 of the columns k1_emit looks back into: rows -1 .. -64 are readable)
     S.pos += FRONT; S.evmu += FRONT; S.flags += FRONT;
@@ -3171,7 +3218,7 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
     DevTable &T = S.T;
     T = DevTable();
     T.n_rows = n; T.n_seg = n_seg; T.n_reads = n_reads; T.n_nb = n_nb; T.n_tiles = n_tiles; T.has_repeats = has_rep;
-    T.pos = S.pos; T.idx = S.idx; T.evmu = S.evmu; T.flags = S.flags; T.nb_tmpl = S.nb_tmpl;
+    T.pos = S.pos; T.idx = S.idx; T.evmu = S.evmu; T.flags = S.flags; T.nb_tmpl = S.nb_tmpl; T.unit_pp = S.unit_pp;
     unsigned char *dv = S.small_dev;
     T.seg_begin = (int64_t *)(dv + L.seg_begin); T.seg_read = (int32_t *)(dv + L.seg_read); T.seg_contig = (int32_t *)(dv + L.seg_contig);
     T.nb_row_begin = (int64_t *)(dv + L.nb_row_begin); T.nb_seg_begin = (int32_t *)(dv + L.nb_seg_begin);
@@ -3782,8 +3829,8 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     const bool dense = dense_reference(c);
     A.chunk_shift = dense ? 8 : 6;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
-    if (dense) hipLaunchKernelGGL(k1_scan<TILE / 8 + NBR>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
-    else hipLaunchKernelGGL(k1_scan<64>, dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    if (dense) hipLaunchKernelGGL((k1_scan<TILE / 8 + NBR, false>), dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((k1_scan<64, MC_SCAN_SUMMARY != 0>), dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
