@@ -483,10 +483,11 @@ def main():
             del kernel_ms['emit']
         alg_bytes = 17.0 * n_rows + 64.0 * n_calls
         # HBM bytes k1_scan moves per launch: rocprofv3 PMC passes of this workload (tools/collect_profiles.sh), committed
-        traffic, traffic_source = None, None
+        traffic, traffic_source, validate_bytes = None, None, None
         if os.path.exists(PMC_FILE) and n_rows == 100000000 and args.motif == 'GATC':
             pmc = json.load(open(PMC_FILE))
             traffic = pmc.get('per_launch_bytes_corrected', {}).get('k1_scan', {}).get('hbm_bytes')
+            validate_bytes = pmc.get('per_launch_bytes_corrected', {}).get('k_validate', {}).get('hbm_bytes')
             traffic_source = ('profiles/r02_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` at commit %s '
                               '(FETCH_SIZE x2, gfx950 correction); not re-measured in this run'
                               % (pmc.get('workload', '?'), pmc.get('head', '?')))
@@ -528,12 +529,20 @@ def main():
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
                          'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel_ms': scan_ms, 'kernel_ms_source': 'hipEvents around k1_scan, median of 5 synchronous passes after the timed region',
+                         'note': 'k1_scan no longer streams the position and flag columns (5 B/row: 0.54 GB in 87-90 us = 0.75 of '
+                                 'peak, profiles/ at commit 2e70cde): its filter reads a 1 B/row summary column and only the '
+                                 'units of eight rows that pass fetch their rows -- 0.20 GB, a third less time; what bounds it now is '
+                                 'latency and instruction issue, and the pipelined pass is bounded by the PCIe copy-out of its records. '
+                                 'The table\'s one bandwidth-bound kernel is k_validate (`stream`).',
+                         'stream': {'kernel': 'k_validate (once per table, at upload)', 'traffic': validate_bytes, 'kernel_ms': validate_ms,
+                                    'achieved': (validate_bytes / (validate_ms * 1e-3) / 1e9) if validate_bytes and validate_ms else None,
+                                    'frac': (validate_bytes / (validate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if validate_bytes and validate_ms else None},
                          'algorithmic': {'bytes': alg_bytes, 'what': '17 B/event row + 64 B/call (SURVEY.md 8(d))',
                                          'kernels': 'k1_scan + k1_group_scan + k1_list + k1_emit (+ k1_rare_dev), pipelined',
                                          'kernel_ms': k1, 'GBps': alg_bytes / (k1 * 1e-3) / 1e9,
                                          'frac_of_peak': alg_bytes / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                          'note': 'an effective rate: above 1.0 means the kernels do not move these bytes '
-                                                 '(the scan reads 5 of the 17 B/row)'},
+                                                 '(the scan reads 1 of the 17 B/row and the rows of one unit in twenty)'},
                          'per_table': {'kernels_ms': per_table, 'total_ms': per_table_ms,
                                        'GBps': alg_bytes / (per_table_ms * 1e-3) / 1e9,
                                        'frac': alg_bytes / (per_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

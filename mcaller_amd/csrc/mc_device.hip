@@ -7,15 +7,18 @@
 //                                parsed on the device (mc_devparse.inc): line starts, tokens, numbers, name blocks and segments,
 //                                the columns written straight into a table slot
 //   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone (a flat stream over the
-//                                rows, 8 B/row)
+//                                rows, 8 B/row); writes the unit summaries the scan reads (first / last position of every
+//                                eight rows)
 //                k_nb_template   the pass-independent fields of the name-block descriptors
 //   per pass     k0_first_site   first site row of every name block under the "new read" strand rule (:161-174) -> strand of
 //                                the block; classifies the block (regular / no sites / irregular) in the same wave
 //                k0_classify / k0_extend / k0_tiles   tables with repeated read names; irregular runs widened; tile descriptors
-//                k1_scan         THE SCAN: one wave per tile of 2048 rows, nothing persistent: the position and flag columns
-//                                (5 B/row) go from HBM into registers; units of eight rows that can hold a site row are found
-//                                with one extract from the strand bitmask and listed in LDS, their rows are tested for "last
-//                                row of a window"; every closed window leaves a 32-byte payload
+//                k1_scan         THE SCAN: one wave per tile of 2048 rows, nothing persistent: the summaries of the tile's units
+//                                of eight rows (1 B/row) go from HBM into registers; units that can hold a site row are found
+//                                with one extract from the strand bitmask and listed in LDS, the listed units fetch their rows,
+//                                which are tested for "last row of a window"; every closed window leaves a 32-byte payload.
+//                                (One-base motifs, where every unit passes: the instance that streams the position and flag
+//                                columns, 5 B/row, into registers.)
 //                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
 //                k1_emit         eight lanes per window: which of the rows before its last row belong to which slot, slot
 //                                means in NumPy pairwise order (fp64) from the rows' (event, model) pairs -> one flush record
