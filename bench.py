@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- m6A calls/sec of the hot path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path (strand resolve + window scan + record ordering + MLP classifier, then the
-D2H copy of the flush records) over one batch of synthetic eventalign rows that is already resident in HBM.
+A "step" = one pass of the hot path over one batch of synthetic eventalign rows that is already resident in HBM, doing
+EVERYTHING a table costs when it is scanned once, as every table of a file is: strand resolve, the scan that streams the
+position and event-index columns and validates every row, record ordering, window emit, MLP classifier, packing and the D2H
+copy of the flush records.  Two distinct tables are resident and taken in turn; before each step the table is declared new
+(mc_ctx_select_table(as_new)), so no step uses what an earlier pass over the same rows learned (validation flags, unit
+summaries).  The rate of repeated passes over one validated table is reported beside it as config.resident_rescan.
 Workload at N=1: BASELINE.json configs[2] -- synthetic 10^8 events, -m GATC, NN classifier (r95 two-base MLP),
-skip_thresh 0.  N>1: every rank scans its own 10^8-row shard of reads (weak scaling, no data-path collective).
+skip_thresh 0.  N>1: every rank scans its own 10^8-row shards of reads (weak scaling, no data-path collective).
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts the N ranks itself.
 
-Prints ONE JSON line on rank 0.  Beside the contract's keys (`value` = the resident-table rate) it carries, at N=1:
+Prints ONE JSON line on rank 0.  Beside the contract's keys it carries, at N=1:
   config.device_e2e          distinct shards (10^8 rows in total) streamed from pinned host memory through the table slots:
                              H2D + per-table kernel + pass + D2H of the records, next to the measured H2D-only rate
   config.file_to_file        eventalign TSV -> .diffs.6 through the CLI (parser and row formatter included)
-  config.per_table_kernel_ms every kernel that touches a table once (upload-time k_validate included), hipEvent times
-  roofline                   `frac` = HBM bytes the named kernel actually moves (rocprofv3 PMC, `traffic_source`) / its live
-                             hipEvent time / 8 TB/s; `algorithmic` = SURVEY.md 8(d)'s 17 B/row + 64 B/call figure against
-                             the feature-extraction time (may exceed the peak: the kernels do not move those bytes);
-                             `per_table` = the algorithmic bytes against ALL kernels that touch the table
+  config.per_table_kernel_ms every kernel that touches a table once, hipEvent times, one pass at a time
+  roofline                   `achieved` = SURVEY.md 8(d)'s algorithmic bytes (17 B/row + 64 B/call) / the summed live hipEvent
+                             times of ALL kernels that touch the table once (strand resolve, validating scan, ordering,
+                             emit); `frac` = that / 8 TB/s; `traffic` = the HBM bytes those kernels move (rocprofv3 PMC
+                             passes, profiles/), quoted only if the PMC file was collected on the kernel sources that are
+                             running (hash recorded in the file), else null; `scan` = the same for the dominant kernel alone
   cpu_baseline               the C oracle on one host core; cpu_baseline_all_cores: the same on all cores;
                              cpu_baseline_reference_like: the Python twin (oracle/py_oracle.py, one predict_proba-equivalent
                              per observation) under multiprocessing on all host cores, byte-range fan-out like the
@@ -34,7 +40,18 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(REPO, 'profiles', 'r02_pmc.json')
+PMC_FILE = os.path.join(REPO, 'profiles', 'r03_pmc.json')
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc']
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the library was built from (tools/pmc_summary.py records the same in the PMC file)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(REPO, rel), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def dist_setup(n_gpus):
@@ -47,6 +64,43 @@ def dist_setup(n_gpus):
         dist_mod.init_process_group(backend='gloo', init_method='env://')
         dist = dist_mod
     return rank, world, local, dist
+
+
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` with no launcher around it: this process starts the N ranks (fresh interpreters, one per GPU;
+    it never touches a GPU itself), hands them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like torch.distributed.run would, and
+    waits.  Rank 0 prints the JSON line.  A rank that dies takes the others down and the exit code with it."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env['MCALLER_BENCH_SPAWNED'] = '1'
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        left = list(procs)
+        while left:
+            for pr in list(left):
+                code = pr.poll()
+                if code is None:
+                    continue
+                left.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write('bench.py: rank %d exited with code %d; stopping the others\n' % (procs.index(pr), code))
+                    for other in left:
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 def cpu_model():
@@ -133,11 +187,30 @@ def main():
     ap.add_argument('--stream-shards', type=int, default=10, help='device end-to-end: distinct shards the rows arrive in (0: skip)')
     ap.add_argument('--f2f-events', type=float, default=1e7, help='file to file: rows of eventalign text (0: skip)')
     ap.add_argument('--kernels-only', action='store_true', help='skip device end-to-end, file to file and the CPU legs (profiling runs)')
+    ap.add_argument('--rescan-only', action='store_true',
+                    help='profiling runs: the timed steps re-scan ONE validated table (config.resident_rescan) instead of full passes')
+    ap.add_argument('--dry-ranks', action='store_true',
+                    help='launch plumbing only (CPU test): the ranks rendezvous, rank 0 prints n_gpus, nothing touches a GPU')
     args = ap.parse_args()
     if args.kernels_only:
         args.stream_shards, args.f2f_events, args.no_cpu_baseline = 0, 0, True
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank, world, local, dist = dist_setup(args.gpus)
+    if args.dry_ranks:
+        total = world
+        if dist is not None:
+            import torch
+            t = torch.tensor([1.0], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            total = int(t[0])
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'dry_ranks': True, 'n_gpus': world, 'ranks_seen': total, 'launcher': 'bench.py itself'
+                              if os.environ.get('MCALLER_BENCH_SPAWNED') else 'environment'}))
+        return
     from mcaller_amd import synth, _lib
     from mcaller_amd.device import Device
     from mcaller_amd.extract_contexts import submodel_setup
@@ -147,8 +220,11 @@ def main():
     t_gen = time.time()
     codes = synth.genome()
     ref = synth.SynthRef(codes, motif=args.motif)
-    table, qual = synth.make_table(n_rows, seed=1000 + rank, codes=codes)
-    t_gen = time.time() - t_gen
+    # two distinct tables per rank, resident side by side: consecutive steps never touch the same rows
+    n_tables = 1 if args.rescan_only else 2
+    tables = [synth.make_table(n_rows, seed=1000 + rank + 500 * i, codes=codes) for i in range(n_tables)]
+    table, qual = tables[0]
+    t_gen = (time.time() - t_gen) / n_tables
     model_npz = shipped_model('r95_twobase_model_NN_6_m6A')
     modelset = load_model_file(model_npz)
     _, weights, _, soc = submodel_setup(modelset, 'A')
@@ -157,35 +233,50 @@ def main():
     numa_node = Device.bind_host_to_numa_node(dev_index) if (world > 1 or os.environ.get('MCALLER_BENCH_BIND')) else None  # pinned buffers next to the rank's GPU
     dev = Device(dev_index)
     dev.set_reference(ref.device_arrays())
-    t_up = time.time()
-    slot0 = dev.upload_table(table)
-    t_up = time.time() - t_up
-    validate_ms = dev.upload_times_ms(slot0)[1]
-    dev.set_read_quality(qual)
     dev.set_mlp(weights, soc)
+    t_up = time.time()
+    slots = []
+    for t_i, q_i in tables:                                      # (the read qualities travel with their table)
+        slots.append(dev.upload_table_async(t_i.pinned() if world == 1 else t_i, q_i))
+        dev.wait_upload(slots[-1])
+    dev.sync()
+    t_up = (time.time() - t_up) / n_tables
 
-    # A step = one pass of the hot path over the resident table, records (slot means, sites, probabilities) landing in
-    # pinned host memory.  Passes are pipelined (the library's streaming interface, mc_extract_features_async /
-    # mc_wait_records): K0 + K1 of consecutive passes back to back on one stream, K2 + packing on a side stream, copy-outs
-    # back to back on a third, four passes in flight at most; every pass's records are complete in host memory before the
-    # timed region ends.
+    # A step = one FULL pass of the hot path over a resident table -- what a table costs when it is scanned once: the table is
+    # declared new (nothing an earlier pass learned is used), the scan streams positions and event indices and validates every
+    # row; records (slot means, sites, probabilities) land in pinned host memory.  The two tables are taken in turn.  Passes
+    # are pipelined (the library's streaming interface, mc_extract_features_async / mc_wait_records): K0 + K1 of consecutive
+    # passes back to back on one stream, K2 + packing on a side stream, copy-outs back to back on a third, four passes in
+    # flight at most; every pass's records are complete in host memory before the timed region ends.
     # --no-pipeline times mc_extract_features instead (one pass at a time, host sync inside).
-    def step_sync():
+    step_no = [0]
+
+    def next_table(full):
+        i = step_no[0] % n_tables
+        step_no[0] += 1
+        dev.select_table(slots[i], as_new=full)
+
+    def step_sync(full):
+        next_table(full)
         dev.run(6, 0, 0.0, tail_contig=-1, score=True)
         return dev.fetch(copy=False)
 
-    def run_steps(n_steps, on_done):
+    def run_steps(n_steps, on_done, full=True):
         if args.no_pipeline:
             for _ in range(n_steps):
-                on_done(step_sync())
+                on_done(step_sync(full))
             return
         depth = min(3, n_steps)                                  # passes in flight (the library allows four)
-        for _ in range(depth):
+
+        def enqueue():
+            next_table(full)
             dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+        for _ in range(depth):
+            enqueue()
         dev.wait_begin()                                         # copy-out of the oldest pass started
         for _ in range(n_steps - depth):
             dev.wait_begin()                                     # ... and of the one behind it, as soon as it is computed:
-            dev.run_async(6, 0, 0.0, tail_contig=-1, score=True) # the transfers run back to back; the next pass enqueued;
+            enqueue()                                            # the transfers run back to back; the next pass enqueued;
             on_done(dev.wait())                                  # the oldest pass's records are in host memory
         for _ in range(depth):
             on_done(dev.wait())
@@ -194,7 +285,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    k1_ms, tot_ms, last = [], [], [None]
+    k1_ms, tot_ms, last, calls_seen = [], [], [None], [0, 0]
 
     # The kernel times come from hipEvents on the ctx stream.  An event between two kernels costs that queue ~9 us (6 % of a
     # pass), so in the pipelined loop only every n-th pass carries the two events that do nothing but time it; kernel_ms is
@@ -204,21 +295,26 @@ def main():
 
     def on_done(rec):
         last[0] = rec
+        calls_seen[0] += int(rec.n_calls) if getattr(rec, '_compacted', False) else int(((rec.info[:rec.n] & _lib.I_TOO_MANY) == 0).sum())
+        calls_seen[1] += 1
         if args.no_pipeline or dev.last_pass_timed():
             tm = dev.times_ms()
             k1_ms.append(tm['window_scan'] + tm['emit'])
             tot_ms.append(tm)
 
+    full = not args.rescan_only
     if args.warmup:
-        run_steps(args.warmup, on_done)
+        run_steps(args.warmup, on_done, full)
     del k1_ms[:], tot_ms[:]
+    calls_seen[:] = [0, 0]
     barrier()
     dev.sync()                              # nothing of the warm-up is left on any stream
     t0 = time.perf_counter()
-    run_steps(args.steps, on_done)          # the last wait() returns when the last pass's records are in host memory
+    run_steps(args.steps, on_done, full)    # the last wait() returns when the last pass's records are in host memory
     dev.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    calls_in_region = calls_seen[0]         # calls of all timed steps of this rank (the two tables differ by a few)
     rec = last[0]
     info = rec.info[:rec.n]
     n_calls = int(((info & _lib.I_TOO_MANY) == 0).sum())
@@ -228,14 +324,41 @@ def main():
     packed = getattr(rec, '_packed', None)
     copy_out_bytes = None if packed is None else 16 * n_records + n_calls * (4 * 6 + 8 + 1) + 4 * int(len(packed[1]))
 
-    calls_total, elapsed_max = n_calls, elapsed
+    calls_total, elapsed_max, calls_region_total = n_calls, elapsed, calls_in_region
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([n_calls], dtype=torch.float64)
+        c = torch.tensor([n_calls, calls_in_region], dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        elapsed_max, calls_total = float(t[0]), int(c[0])
+        elapsed_max, calls_total, calls_region_total = float(t[0]), int(c[0]), int(c[1])
+
+    # ---- the rate of repeated passes over ONE validated table (config.resident_rescan): what round 2 reported as `value` ----
+    rescan = None
+    if full and not args.no_pipeline:
+        dev.select_table(slots[0])
+        n_tables_saved, n_tables = n_tables, 1
+        step_no[0] = 0
+        saved = (list(k1_ms), list(tot_ms), last[0], list(calls_seen))
+        run_steps(max(args.warmup, 4), on_done, False)         # (the second pass streams the positions, the third builds the summaries)
+        dev.sync()
+        barrier()
+        t_r = time.perf_counter()
+        run_steps(args.steps, on_done, False)
+        dev.sync()
+        barrier()
+        t_r = time.perf_counter() - t_r
+        rescan = {'ms_per_pass': t_r / args.steps * 1e3, 'calls_per_s': n_calls * args.steps / t_r,
+                  'what': 'pipelined passes over one table that earlier passes have validated and summarised (k_summarize): the '
+                          'scan reads the 1 B/row unit summaries; no table of a file is ever scanned like this'}
+        n_tables = n_tables_saved
+        rec_red, table_red = last[0], tables[0][0]            # (the records the device holds now: what the site reduction reduces)
+        k1_ms[:], tot_ms[:] = saved[0], saved[1]
+        last[0] = saved[2]
+        calls_seen[:] = saved[3]
+    else:
+        rec_red, table_red = rec, tables[(step_no[0] - 1) % n_tables][0]
+    n_calls_red = int(((rec_red.info[:rec_red.n] & _lib.I_TOO_MANY) == 0).sum())
 
     # the one exchange step of the multi-GPU job: per-site counts summed over ranks (feeds make_bed).  Outside the timed
     # steps.  Counted on the device from the records of the last step and all-reduced with RCCL through the C ABI
@@ -267,14 +390,16 @@ def main():
             except Exception as e:                                 # noqa
                 e_native = e
             flags = [None] * world
-            dist.all_gather_object(flags, e_native is None)        # every rank takes the same branch
+            dist.all_gather_object(flags, (e_native is None, n_calls_red))     # every rank takes the same branch
+            expected = sum(f[1] for f in flags)
+            flags = [f[0] for f in flags]
             if all(flags):
                 reduction = {'backend': 'rccl (ncclAllReduce through the C ABI)', 'ms': ms, 'observations': int(n_total.sum()),
-                             'observations_expected': calls_total, 'bytes': int(index.n * 16), 'sites': int(index.n)}
+                             'observations_expected': expected, 'bytes': int(index.n * 16), 'sites': int(index.n)}
             else:
                 try:
                     import torch
-                    counts = make_bed.site_counts(rec, table, index, row_offset=rank * n_rows)
+                    counts = make_bed.site_counts(rec_red, table_red, index, row_offset=rank * n_rows)
 
                     def reduce_with(backend):
                         group = dist.new_group(backend=backend) if backend == 'nccl' else None
@@ -297,6 +422,7 @@ def main():
                         backend = 'gloo (native: %s; torch nccl: %s)' % (e_native, type(e_nccl).__name__)
                         packed, fmin, ms = reduce_with('gloo')
                     reduction = {'backend': backend, 'ms': ms, 'observations': int(packed[1].sum().item()),
+                                 'observations_expected': expected,
                                  'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
                 except Exception as e:                             # noqa
                     reduction = {'error': '%s: %s' % (type(e).__name__, e)}
@@ -314,10 +440,10 @@ def main():
         else:
             reduction = box.get('reduction')
 
-    # ---- the kernels one at a time (outside the timed region): hipEvents around every stage of a synchronous pass ----
+    # ---- the kernels one at a time (outside the timed region): hipEvents around every stage of a synchronous FULL pass ----
     sync_ms = []
-    for _ in range(6):
-        dev.run(6, 0, 0.0, tail_contig=-1, score=True)
+    for _ in range(7):
+        step_sync(full)
         sync_ms.append(dev.times_ms())
     sync_ms = {k: float(np.median([t[k] for t in sync_ms[1:]])) for k in sync_ms[0]}
 
@@ -476,29 +602,40 @@ def main():
             text_e2e = {'error': '%s: %s' % (type(e).__name__, e)}
 
     if rank == 0:
-        k1 = float(np.mean(k1_ms))
         kernel_ms = {k: float(np.mean([t[k] for t in tot_ms])) for k in tot_ms[0]}
         if kernel_ms.get('emit') == 0.0:      # pipelined passes time scan + ordering + emit as one span (no event in between)
             kernel_ms['window_scan_and_emit'] = kernel_ms.pop('window_scan')
             del kernel_ms['emit']
-        alg_bytes = 17.0 * n_rows + 64.0 * n_calls
-        # HBM bytes k1_scan moves per launch: rocprofv3 PMC passes of this workload (tools/collect_profiles.sh), committed
-        traffic, traffic_source, validate_bytes = None, None, None
-        if os.path.exists(PMC_FILE) and n_rows == 100000000 and args.motif == 'GATC':
-            pmc = json.load(open(PMC_FILE))
-            traffic = pmc.get('per_launch_bytes_corrected', {}).get('k1_scan', {}).get('hbm_bytes')
-            validate_bytes = pmc.get('per_launch_bytes_corrected', {}).get('k_validate', {}).get('hbm_bytes')
-            traffic_source = ('profiles/r02_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` at commit %s '
-                              '(FETCH_SIZE x2, gfx950 correction); not re-measured in this run'
-                              % (pmc.get('workload', '?'), pmc.get('head', '?')))
+        calls_per_step = calls_region_total / float(args.steps * world)          # (per rank and step: the two tables differ by a few)
+        alg_bytes = 17.0 * n_rows + 64.0 * calls_per_step
+        # every kernel that touches a table once, one full pass at a time (hipEvents on the ctx stream)
         scan_ms = sync_ms['window_scan']
-        per_table = {'k_validate': validate_ms, 'strand_resolve': sync_ms['strand_resolve'], 'window_scan': scan_ms,
-                     'order_and_emit': sync_ms['emit']}
+        per_table = {'strand_resolve': sync_ms['strand_resolve'], 'window_scan': scan_ms, 'order_and_emit': sync_ms['emit']}
         per_table_ms = float(sum(per_table.values()))
-        achieved = (traffic / (scan_ms * 1e-3) / 1e9) if traffic else None
+        achieved = alg_bytes / (per_table_ms * 1e-3) / 1e9
+        # HBM bytes those kernels move per table: rocprofv3 PMC passes of this workload (tools/collect_profiles.sh), committed under
+        # profiles/ -- quoted only if they were collected on the kernel sources this library was built from
+        traffic, traffic_source, scan_traffic, per_kernel_traffic = None, None, None, None
+        src_hash = kernel_source_hash()
+        if os.path.exists(PMC_FILE) and n_rows == 100000000 and args.motif == 'GATC' and full:
+            pmc = json.load(open(PMC_FILE))
+            if pmc.get('kernel_source_sha16') == src_hash:
+                per = pmc.get('per_launch_bytes_corrected', {})
+                names = pmc.get('per_table_kernels') or []
+                if names and all(n in per for n in names):
+                    per_kernel_traffic = {n: per[n].get('hbm_bytes') for n in names}
+                    traffic = float(sum(per_kernel_traffic.values()))
+                    scan_traffic = per.get('k1_scan', {}).get('hbm_bytes')
+                    traffic_source = ('%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` at commit %s, kernel sources %s '
+                                      '(FETCH_SIZE x2, gfx950 correction); sum over %s; not re-measured in this run'
+                                      % (os.path.relpath(PMC_FILE, REPO), pmc.get('workload', '?'), pmc.get('head', '?'), src_hash,
+                                         ' + '.join(names)))
+            else:
+                traffic_source = ('%s was collected on other kernel sources (%s, running %s): no traffic figure'
+                                  % (os.path.relpath(PMC_FILE, REPO), pmc.get('kernel_source_sha16'), src_hash))
         out = {
             'metric': 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)',
-            'value': calls_total * args.steps / elapsed_max,
+            'value': calls_region_total / elapsed_max,
             'unit': 'calls/s',
             'n_gpus': world,
             'steps': args.steps,
@@ -509,45 +646,50 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
-            'config': {'workload': 'synthetic %.0e eventalign rows per GPU, -m %s, NN classifier (r95 two-base MLP), '
-                                   'skip_thresh 0, table resident in HBM' % (n_rows, args.motif),
+            'config': {'workload': 'synthetic %.0e eventalign rows per GPU and step, -m %s, NN classifier (r95 two-base MLP), '
+                                   'skip_thresh 0; %s' % (n_rows, args.motif,
+                                                          'two resident tables taken in turn, every step a FULL pass (the table '
+                                                          'declared new: positions + event indices streamed, every row validated)'
+                                                          if full else 'ONE validated resident table re-scanned (--rescan-only)'),
+                       'step': 'full pass' if full else 'resident rescan',
                        'passes_in_flight': 1 if args.no_pipeline else min(3, args.steps),
-                       'events_per_gpu': n_rows, 'calls_per_gpu': n_calls, 'flush_records_per_gpu': n_records,
+                       'events_per_gpu': n_rows, 'calls_per_gpu': calls_per_step, 'flush_records_per_gpu': n_records,
                        'copy_out_bytes_per_pass': copy_out_bytes,
                        'events_per_s': n_rows * world * args.steps / elapsed_max,
+                       'algorithmic_GBps_of_the_step': alg_bytes * world / (elapsed_max / args.steps) / 1e9,
                        'kernel_ms': kernel_ms, 'kernel_ms_from_passes': len(tot_ms), 'timing_events_every_n_passes': time_every,
                        'kernel_ms_one_pass_at_a_time': sync_ms,
                        'per_table_kernel_ms': dict(per_table, total=per_table_ms, classifier=sync_ms['classifier']),
+                       'resident_rescan': rescan,
                        'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction, 'numa_node_rank0': numa_node,
                        # SURVEY.md 8(d)'s three timings: kernels only; device end to end; file to file
-                       'calls_per_s_kernels_only': n_calls / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
+                       'calls_per_s_kernels_only': calls_per_step / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
                        'device_e2e': device_e2e,
                        'device_e2e_events_per_s': (device_e2e or {}).get('events_per_s'),
                        'file_to_file': file_to_file, 'text_e2e': text_e2e},
-            'roofline': {'bound': 'hbm', 'kernel': 'k1_scan',
+            'roofline': {'bound': 'hbm',
+                         'kernel': 'every kernel that touches a table once: k0_first_site + k1_scan (validating) + k1_group_scan + '
+                                   'k1_list + k1_emit',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
-                         'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel_ms': scan_ms, 'kernel_ms_source': 'hipEvents around k1_scan, median of 5 synchronous passes after the timed region',
-                         'note': 'k1_scan no longer streams the position and flag columns (5 B/row: 0.54 GB in 87-90 us = 0.75 of '
-                                 'peak, profiles/ at commit 2e70cde): its filter reads a 1 B/row summary column and only the '
-                                 'units of eight rows that pass fetch their rows -- 0.20 GB, a third less time; what bounds it now is '
-                                 'latency and instruction issue, and the pipelined pass is bounded by the PCIe copy-out of its records. '
-                                 'The table\'s one bandwidth-bound kernel is k_validate (`stream`).',
-                         'stream': {'kernel': 'k_validate (once per table, at upload)', 'traffic': validate_bytes, 'kernel_ms': validate_ms,
-                                    'achieved': (validate_bytes / (validate_ms * 1e-3) / 1e9) if validate_bytes and validate_ms else None,
-                                    'frac': (validate_bytes / (validate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if validate_bytes and validate_ms else None},
-                         'algorithmic': {'bytes': alg_bytes, 'what': '17 B/event row + 64 B/call (SURVEY.md 8(d))',
-                                         'kernels': 'k1_scan + k1_group_scan + k1_list + k1_emit (+ k1_rare_dev), pipelined',
-                                         'kernel_ms': k1, 'GBps': alg_bytes / (k1 * 1e-3) / 1e9,
-                                         'frac_of_peak': alg_bytes / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         'note': 'an effective rate: above 1.0 means the kernels do not move these bytes '
-                                                 '(the scan reads 1 of the 17 B/row and the rows of one unit in twenty)'},
-                         'per_table': {'kernels_ms': per_table, 'total_ms': per_table_ms,
-                                       'GBps': alg_bytes / (per_table_ms * 1e-3) / 1e9,
-                                       'frac': alg_bytes / (per_table_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       'what': 'algorithmic bytes / every kernel that touches the table once, upload-time '
-                                               'k_validate included (classifier excluded: it touches records, not rows)'}},
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'traffic_source': traffic_source, 'traffic_per_kernel': per_kernel_traffic,
+                         'algorithmic_bytes': alg_bytes, 'algorithmic_bytes_what': '17 B/event row + 64 B/call (SURVEY.md 8(d))',
+                         'kernels_ms': per_table, 'kernel_ms': per_table_ms,
+                         'kernel_ms_source': 'hipEvents on the ctx stream around the stages of synchronous full passes, median of 6 '
+                                             'after the timed region (the classifier touches records, not rows: not in the sum)',
+                         'scan': {'kernel': 'k1_scan<64, SCAN_VALIDATE>: streams 8 of the 17 B/row (positions, event indices), '
+                                            'validates every row, lists and decides the candidate units',
+                                  'kernel_ms': scan_ms, 'streamed_bytes': 8.0 * n_rows,
+                                  'streamed_GBps': 8.0 * n_rows / (scan_ms * 1e-3) / 1e9,
+                                  'streamed_frac': 8.0 * n_rows / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  'traffic': scan_traffic,
+                                  'traffic_frac': (scan_traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if scan_traffic else None},
+                         'pipelined': {'what': 'the same algorithmic bytes over the ctx-stream spans of the timed (pipelined) steps',
+                                       'kernel_ms': float(np.mean([t['total'] - t['classifier'] for t in tot_ms])),
+                                       'frac': alg_bytes / (float(np.mean([t['total'] - t['classifier'] for t in tot_ms])) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'note': 'the event/model pairs (8 of the 17 B/row) are only read for the rows of closed windows and the flag '
+                                 'bytes only for the listed units, so the kernels move about half the algorithmic bytes: a frac '
+                                 'near 1 would not mean 8 TB/s of traffic'},
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU legs: rank 0 at N=1 only
             from tests import helpers as H                   # the checker (oracle/), timed as the CPU baseline

@@ -189,7 +189,9 @@ int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/*
  * A ctx holds MC_TABLE_SLOTS resident tables.  mc_ctx_upload_table_async ENQUEUES the upload of a table into a free slot
  * and makes it the current table (the one the passes enqueued afterwards scan): the columns travel on an upload stream of
  * their own (DMA, beside the kernels of earlier passes; the source should be pinned: mc_host_alloc / a parser table with
- * mc_host_pool_config(1, ..)), the per-table kernel (k_validate) follows on the ctx stream behind an event.  read_qual
+ * mc_host_pool_config(1, ..)); no kernel runs at upload -- the FIRST pass over a table validates it while it scans (are the
+ * positions of every read non-decreasing, its event indices strictly monotone: what lets the window rule stand in for the
+ * reference's sequential machine, :161-176), later passes over the same table use what it found.  read_qual
  * ([n_reads], read ids of THIS table; may be NULL: mc_ctx_set_read_quality applies) travels with the table.  No
  * hipMalloc / hipFree happens per table once the slots are big enough: mc_ctx_reserve_tables sizes them (and the per-pass
  * scratch and record sets) once for tables of up to max_rows rows, max_segs segments, max_reads reads; without it the
@@ -203,7 +205,12 @@ int mc_ctx_reserve_tables(mc_ctx *ctx, int64_t max_rows, int32_t max_segs, int32
 int mc_ctx_upload_table_async(mc_ctx *ctx, const mc_table_view *host_table, const double *read_qual, int32_t *slot);
 int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);
 int mc_ctx_current_slot(mc_ctx *ctx);                       /* slot of the current table, -1: none */
-/* hipEvent times of the last upload into `slot` (waits for it): the H2D transfers, and k_validate behind them, in ms. */
+/* Makes the table resident in `slot` the current one again.  as_new != 0: the next pass treats it like a table it has never
+ * seen -- it does everything the first pass over a table does (positions and event indices streamed, every row validated),
+ * whatever earlier passes learned (measurement: the cost of a table that is scanned once, without the upload). */
+int mc_ctx_select_table(mc_ctx *ctx, int32_t slot, int32_t as_new);
+/* hipEvent time of the last upload into `slot` (waits for it): the H2D transfers, in ms.  *validate_ms is 0: nothing runs at
+ * upload any more (the validation is part of the first pass's scan). */
 int mc_ctx_upload_times_ms(mc_ctx *ctx, int32_t slot, float *h2d_ms, float *validate_ms);
 /* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model (at most 8 sub-models:
  * the reference's models have two, 'MG' and 'MH', or one); submodel_of_char[256]: context[k] (ASCII) -> sub-model index,

@@ -6,19 +6,24 @@
 //   text         kp_count / kp_scan / kp_starts / kp_parse / kp_count_rows / kp_place   the eventalign TEXT of a streamed shard
 //                                parsed on the device (mc_devparse.inc): line starts, tokens, numbers, name blocks and segments,
 //                                the columns written straight into a table slot
-//   upload time  k_validate      per name block: are positions non-decreasing / event indices monotone (a flat stream over the
-//                                rows, 8 B/row); writes the unit summaries the scan reads (first / last position of every
-//                                eight rows)
+//   per table     (nothing runs at upload: the first pass over a table validates it while it scans)
 //                k_nb_template   the pass-independent fields of the name-block descriptors
+//                k_summarize     a table that is scanned a second time gets unit summaries (first / last position of every
+//                                eight rows): every further scan reads 1 B/row instead of streaming the columns
 //   per pass     k0_first_site   first site row of every name block under the "new read" strand rule (:161-174) -> strand of
-//                                the block; classifies the block (regular / no sites / irregular) in the same wave
-//                k0_classify / k0_extend / k0_tiles   tables with repeated read names; irregular runs widened; tile descriptors
-//                k1_scan         THE SCAN: one wave per tile of 2048 rows, nothing persistent: the summaries of the tile's units
-//                                of eight rows (1 B/row) go from HBM into registers; units that can hold a site row are found
-//                                with one extract from the strand bitmask and listed in LDS, the listed units fetch their rows,
-//                                which are tested for "last row of a window"; every closed window leaves a 32-byte payload.
-//                                (One-base motifs, where every unit passes: the instance that streams the position and flag
-//                                columns, 5 B/row, into registers.)
+//                                the block; classifies the block (regular / no sites / irregular) in the same workgroup.  On
+//                                a table no pass has validated yet the classification rests on the block's first rows
+//                                (direction of the event index, position 0) and the scan confirms it
+//                k0_classify / k0_extend   tables with repeated read names; irregular runs widened
+//                k1_scan         THE SCAN: one wave per tile of 2048 rows, nothing persistent.  First pass over a table: the
+//                                position and event-index columns (8 B/row) go from HBM into registers and every row is
+//                                compared with the row before it (positions non-decreasing? event index strictly monotone?
+//                                -- what makes a name block "regular"); units of eight rows that can hold a site row are
+//                                found with one extract from the strand bitmask (two words per unit, straight from L2) and
+//                                listed in LDS, the listed units fetch their flag bytes, their rows are tested for "last row
+//                                of a window"; every closed window leaves a 32-byte payload.  Later passes over the same
+//                                table read the unit summaries instead (1 B/row); one-base motifs, where every unit passes,
+//                                stream the positions.
 //                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
 //                k1_emit         eight lanes per window: which of the rows before its last row belong to which slot, slot
 //                                means in NumPy pairwise order (fp64) from the rows' (event, model) pairs -> one flush record
@@ -66,8 +71,6 @@ namespace {
 #define MC_TILE 2048
 #endif
 constexpr int TILE = MC_TILE;       // rows per workgroup tile
-constexpr int NBST = 2;             // name blocks of a tile that get a window of their strand mask staged in LDS (k1_scan)
-constexpr int BW = 64;              // words per staged mask window (one per lane)
 constexpr int O_NONE = 15;
 
 // meta byte per staged row: bit0 valid (passes :167-168), bit1 first row of a name block, bits 2..5 offset of
@@ -76,7 +79,8 @@ constexpr uint32_t M_VALID = 1, M_NS = 2;
 
 enum : uint8_t { MODE_NONE = 0, MODE_REGULAR = 1, MODE_IRREGULAR = 2 };
 
-// validation flags per name block (k_validate)
+// validation flags per name block: what its rows look like when each is compared with the row before it (the first pass's
+// scan ORs them together, k1_scan; V_MULTI_SEG comes from the host with the table)
 constexpr uint32_t V_POS_DEC = 1, V_IDX_INC = 2, V_IDX_DEC = 4, V_IDX_EQ = 8, V_POS0 = 16, V_MULTI_SEG = 32;
 
 constexpr int32_t NO_STRAY = INT32_MIN;
@@ -94,7 +98,9 @@ struct __attribute__((aligned(16))) NbDesc {
     int32_t stray_d;    // its value, (event - model) in 1e-4 pA
     int32_t extra_mpos; // site of the one-event '+' window such a row opens (R5)
     uint8_t mode, rev, filtered, xflags;   // xflags: bit0 extra_multi, bit1 has the '+' window (its row = first - 1)
-    int32_t pad;
+    uint32_t vf;        // the validation flags (V_*) the classification rests on: the table's (validated tables), or what the
+                        // block's first rows say (first pass: the scan marks the pass if a later row says otherwise).
+                        // In the template (k_nb_template): the number of segments of the block
     __host__ __device__ int64_t first() const { return first_delta < 0 ? -1 : row_begin + first_delta; }
     __host__ __device__ int64_t extra_row() const { return (xflags & 2) ? row_begin + first_delta - 1 : -1; }
     __host__ __device__ bool extra_multi() const { return xflags & 1; }
@@ -106,8 +112,8 @@ struct DevTable {
     int32_t *pos = nullptr, *idx = nullptr;
     int2 *evmu = nullptr;     // (event, model) pairs as the parser wrote them: one DRAM page per window for k1_emit
     uint8_t *flags = nullptr;
-    int2 *unit_pp = nullptr;  // [ceil(n_rows / 8)] positions of the first and the last row of every unit of eight rows (k_validate):
-                              // all the scan's filter looks at -- 1 B/row instead of the 5 B/row of the position and flag columns
+    int2 *unit_pp = nullptr;  // [ceil(n_rows / 8)] positions of the first and the last row of every unit of eight rows (k_summarize,
+                              // when a table is scanned a second time): all the filter of a repeated scan looks at -- 1 B/row
     int32_t n_seg = 0;
     int64_t *seg_begin = nullptr;
     int32_t *seg_read = nullptr, *seg_contig = nullptr;
@@ -121,7 +127,6 @@ struct DevTable {
     NbDesc *nb_tmpl = nullptr;        // [n_nb] the pass-independent fields of the name-block descriptors (k_nb_template)
     int64_t n_tiles = 0;
     int32_t *tile_nb = nullptr;       // [n_tiles] name block of the first row of every tile of the scan
-    int32_t *vtile_nb = nullptr;      // [ceil(n_rows / VTILE)] ... of every tile of k_validate
     int has_repeats = 0;
 };
 
@@ -166,7 +171,8 @@ struct Counters {          // device-side status block
     unsigned long long n_records;
     unsigned long long shard[NSHARD];
     unsigned int overflow;
-    unsigned int pad_irregular;
+    unsigned int violation;    // first pass over a table: a row contradicts what a regular block was classified on (the pass is
+                               // repeated on the table's complete validation flags)
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
@@ -238,129 +244,17 @@ __device__ __forceinline__ unsigned char comp_char(unsigned char c) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// upload-time kernels
+// per-table kernels
 // ---------------------------------------------------------------------------------------------------
-// k_validate: per name block, are positions non-decreasing / event indices monotone over ALL its rows?  (What makes a
-// block "regular", see k0_classify.)  A flat stream over the position and event-index columns (8 B/row), one workgroup
-// per tile of the scan, every lane on consecutive 16-byte groups; the name-block starts inside the tile come from the
-// name-block table (one tile in eight has any), so the flag column is not read.  Each row is compared with the row before
-// it -- the neighbour lane's last row (one shuffle), the wave's first lane re-reads its predecessor -- and the flags are
-// OR-ed per name block: a tile that lies inside one block (the usual case) costs one atomic.  nb_vflags arrives zeroed
-// (V_MULTI_SEG preset) with the table's small arrays.
-constexpr int VTILE = 3072;             // rows per workgroup of k_validate (its own tiling: T.vtile_nb)
-constexpr int VT = 256;                 // threads: VTILE / 256 rows each, in groups of four
-constexpr int VQ = VTILE / (VT * 4);    // 4-row groups per thread
-constexpr int VMAXNB = 64;              // name blocks of a tile whose flags are gathered in LDS (the rest: global atomics)
-static_assert(VTILE % (VT * 4) == 0, "whole row groups per thread");
-
-__global__ __launch_bounds__(VT) void k_validate(DevTable T) {
-    __shared__ uint32_t s_start[VTILE / 32];    // bit i: row t0+i starts a name block (i > 0)
-    __shared__ uint32_t s_pre[VTILE / 32];       // name-block starts in the words before this one
-    __shared__ uint32_t s_vf[VMAXNB];
-    __shared__ uint32_t s_red[VT / 64];
-    const int64_t tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t t0 = tile * VTILE;
-    const int nrows = (int)(min(t0 + (int64_t)VTILE, T.n_rows) - t0);
-    // ---- the columns: all loads go out first ----
-    int4 p4[VQ], i4[VQ];
-    int pp[VQ], ip[VQ];
-#pragma unroll
-    for (int q = 0; q < VQ; ++q) {
-        const int i0 = (q * VT + tid) * 4;
-        p4[q] = make_int4(0, 0, 0, 0);
-        i4[q] = make_int4(0, 0, 0, 0);
-        pp[q] = ip[q] = 0;
-        if (i0 < nrows) {                       // (arrays are padded: whole groups stay in bounds)
-            p4[q] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-            i4[q] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0);
-            if (lane == 0 && t0 + i0 > 0) { pp[q] = T.pos[t0 + i0 - 1]; ip[q] = T.idx[t0 + i0 - 1]; }
-            // the unit summary: the group of four rows is the first or the second half of a unit of eight -- consecutive threads
-            // write consecutive words
-            const int64_t g4 = (t0 + i0) >> 2;
-            reinterpret_cast<int32_t *>(T.unit_pp)[g4] = (g4 & 1) ? p4[q].w : p4[q].x;
-        }
-    }
-    // ---- name-block starts inside the tile ----
-    const int nb0 = T.vtile_nb[tile];
-    for (int i = tid; i < VTILE / 32; i += VT) s_start[i] = 0u;
-    if (tid < VMAXNB) s_vf[tid] = 0u;
-    __syncthreads();
-    int n_in = 0;                               // blocks that start inside the tile (behind its first row)
-    for (int base = nb0 + 1;; base += VT) {
-        const int j = base + tid;
-        bool hit = false;
-        if (j < T.n_nb) {
-            const int64_t rb = T.nb_row_begin[j];
-            if (rb < t0 + nrows) {              // (rb > t0: nb0 is the last block that starts at or before t0)
-                hit = true;
-                atomicOr(&s_start[(int)(rb - t0) >> 5], 1u << ((int)(rb - t0) & 31));
-            }
-        }
-        const int c = __syncthreads_count(hit);
-        n_in += c;
-        if (c < VT) break;
-    }
-    if (n_in) {
-        if (tid < 64) {                         // prefix counts per word: one wave, two rounds of 64 words
-            uint32_t run = 0;
-            for (int w0 = 0; w0 < VTILE / 32; w0 += 64) {
-                const int w = w0 + lane;
-                const uint32_t c = w < VTILE / 32 ? __popc(s_start[w]) : 0u;
-                uint32_t incl = c;
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (w < VTILE / 32) s_pre[w] = run + incl - c;
-                run += __shfl(incl, 63);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- per row: compare with the row before it ----
-    uint32_t f_all = 0;
-#pragma unroll
-    for (int q = 0; q < VQ; ++q) {
-        const int i0 = (q * VT + tid) * 4;
-        int prev_p = __shfl_up(p4[q].w, 1), prev_i = __shfl_up(i4[q].w, 1);
-        if (lane == 0) { prev_p = pp[q]; prev_i = ip[q]; }
-        const int ps[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w}, is[4] = {i4[q].x, i4[q].y, i4[q].z, i4[q].w};
-        uint32_t fg = 0;                        // flags of the group's rows that belong to the block of its first row
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = i0 + e;
-            uint32_t f = 0;
-            bool start = (t0 + i == 0);
-            if (n_in) start = start || ((s_start[i >> 5] >> (i & 31)) & 1u);
-            if (i == 0 && t0 > 0) start = T.nb_row_begin[nb0] == t0;
-            if (i < nrows) {
-                if (ps[e] == 0) f |= V_POS0;
-                if (!start) {
-                    if (ps[e] < prev_p) f |= V_POS_DEC;
-                    f |= (is[e] > prev_i) ? V_IDX_INC : (is[e] < prev_i ? V_IDX_DEC : V_IDX_EQ);
-                }
-            }
-            prev_p = ps[e]; prev_i = is[e];
-            if (!n_in) fg |= f;
-            else if (f) {
-                const int bi = (int)(s_pre[i >> 5] + __popc(s_start[i >> 5] & ((2u << (i & 31)) - 1u)));   // starts in (t0, t0+i]
-                if (bi < VMAXNB) atomicOr(&s_vf[bi], f);
-                else atomicOr(&T.nb_vflags[nb0 + bi], f);
-            }
-        }
-        f_all |= fg;
-    }
-    if (!n_in) {                                // the whole tile is one name block: one atomic
-        for (int o = 32; o > 0; o >>= 1) f_all |= __shfl_xor(f_all, o);
-        if (lane == 0) s_red[tid >> 6] = f_all;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t f = 0;
-            for (int w = 0; w < VT / 64; ++w) f |= s_red[w];
-            if (f) atomicOr(&T.nb_vflags[nb0], f);
-        }
-    } else {
-        __syncthreads();
-        if (tid < VMAXNB && tid <= n_in && s_vf[tid]) atomicOr(&T.nb_vflags[nb0 + tid], s_vf[tid]);
-    }
+// k_summarize: the unit summaries of a table that is scanned again (other parameters; a resident table): first and last
+// position of every unit of eight rows, 1 B/row -- what the filter of a repeated scan reads instead of the columns.  A flat
+// stream over the positions; the thread that holds the first or the second half of a unit writes one word, consecutive
+// threads consecutive words.  (A table that is scanned once never pays for this: its scan streams the columns themselves.)
+__global__ __launch_bounds__(256) void k_summarize(DevTable T) {
+    const int64_t g4 = blockIdx.x * (int64_t)256 + threadIdx.x;       // group of four rows (the columns are padded to whole tiles)
+    if (g4 * 4 >= T.n_rows) return;
+    const int4 p = *reinterpret_cast<const int4 *>(T.pos + g4 * 4);
+    reinterpret_cast<int32_t *>(T.unit_pp)[g4] = (g4 & 1) ? p.w : p.x;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -389,7 +283,7 @@ __global__ void k_nb_template(DevTable T, DevRef R) {
     d.rev = 0;
     d.filtered = 0;
     d.xflags = 0;
-    d.pad = T.nb_seg_begin[b + 1] - T.nb_seg_begin[b];      // segments (contigs) of the block
+    d.vf = (uint32_t)(T.nb_seg_begin[b + 1] - T.nb_seg_begin[b]);      // segments (contigs) of the block
     T.nb_tmpl[b] = d;
 }
 
@@ -508,9 +402,15 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
 // classify != 0: the block is classified here as well (classify_block, by the wave's first lane) -- for tables without
 // repeated read names that do not continue a previous shard's read, where no block looks at another block's result; the
 // separate k0_classify launch is then skipped.
+// hyp != 0: no pass has validated the table yet (its first pass is this one).  The validation flags the classification needs
+// -- which way the event index runs, whether position 0 occurs -- are then taken from the block's first rows: in a regular
+// block every pair of rows says the same as the first pair, and positions do not decrease, so position 0 can only be the
+// first row's.  The pass's scan compares EVERY row with the row before it (k1_scan, validate_units) and marks the pass if a row of
+// a block classified regular says otherwise; whatever the first rows say is true of the block, so it is OR-ed into the
+// table's flags here and the scan adds the rest: after the pass the table's flags are complete.
 __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, Counters *__restrict__ cnt, int classify,
-                              int skip_thresh, unsigned long long pass_no) {
+                              int skip_thresh, unsigned long long pass_no, int hyp) {
     MC_FRONT_OF_THE_QUEUE;
     if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
         unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
@@ -520,11 +420,19 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
     const int lane = threadIdx.x & 63;
     if (b >= T.n_nb) return;
     NbDesc d = T.nb_tmpl[b];
-    const int n_seg = d.pad;
+    const int n_seg = (int)d.vf;
     // (the quality decides whether the rows are looked at at all, but its load is not waited for before theirs go out: the
     // block's latency is a chain of dependent loads, and this removes one link)
     const double q_read = qual[d.read];
-    const uint32_t vf = T.nb_vflags[b];          // (for the classification: in flight with everything else)
+    // (for the classification: in flight with everything else)
+    uint32_t vf;
+    if (hyp) {
+        const int64_t r1 = d.row_begin + 1 < d.row_end ? d.row_begin + 1 : d.row_begin;
+        const int p_first = T.pos[d.row_begin], i_first = T.idx[d.row_begin], i_second = T.idx[r1];
+        vf = n_seg > 1 ? V_MULTI_SEG : 0u;
+        if (r1 != d.row_begin) vf |= i_second > i_first ? V_IDX_INC : (i_second < i_first ? V_IDX_DEC : V_IDX_EQ);
+        if (p_first == 0) vf |= V_POS0;
+    } else vf = T.nb_vflags[b];
     int64_t f0 = -1;
     int f0rev = 0;
     {
@@ -564,7 +472,8 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
         d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
         d.rev = (uint8_t)f0rev;
         d.filtered = filtered ? 1 : 0;
-        d.pad = 0;
+        d.vf = vf;
+        if (hyp && vf) atomicOr(&T.nb_vflags[b], vf);
         nb_f0[b] = f0;
         if (classify) classify_block(T, R, d, b, f0, vf, false, nb_f0, -1, k, skip_thresh, cnt, pass_no);
         desc[b] = d;
@@ -592,19 +501,20 @@ __global__ void k0_classify(DevTable T, DevRef R, NbDesc *__restrict__ desc, con
     const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
     if (b >= T.n_nb) return;
     NbDesc d = desc[b];
-    classify_block(T, R, d, b, nb_f0[b], T.nb_vflags[b], true, nb_f0, entry_read, k, skip_thresh, cnt, pass_no);
+    classify_block(T, R, d, b, nb_f0[b], d.vf, true, nb_f0, entry_read, k, skip_thresh, cnt, pass_no);
     desc[b] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K1: the window scan, as two launches
 //
-//   k1_scan  streams the position and flag columns (5 B/row), stages them in LDS with the per-row site offset
-//            (first 'M' in the row's k-mer, looked up in a window of the strand bitmask staged in LDS), and decides
-//            for every site row whether it is the LAST row of its window: the next unfiltered row starts another
-//            read or lies beyond the site (:179).  Output: a 48-byte payload per closed window + a count per tile.
-//   k1_emit  one lane per closed window: walks back over the <= k positions of the window, reading the event and
-//            model columns only for these rows, and builds the flush record (slot means in NumPy pairwise order).
+//   k1_scan  streams the position column (and, on a table's first pass, the event-index column, validating every row),
+//            finds the units of eight rows that can hold a site row at all (one extract from the strand bitmask per unit)
+//            and decides for every site row of those whether it is the LAST row of its window: the next unfiltered row
+//            starts another read or lies beyond the site (:179).  Output: a 32-byte payload per closed window + a count
+//            per tile.
+//   k1_emit  eight lanes per closed window: which of the rows before its last row belong to which slot, reading the event
+//            and model columns only for these rows, and builds the flush record (slot means in NumPy pairwise order).
 //            Records land in file order (slot = exclusive scan of the tile counts + rank inside the tile).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events, finished by k1_bigfix
@@ -658,15 +568,6 @@ __device__ __forceinline__ double leaf_sum(RowSrc &S, int64_t &cur, int n) {
     return res;
 }
 
-struct TileDesc {      // per tile, written by k0_tiles after classification (plain scalars: stays in registers)
-    int32_t nb0;       // name block of the tile's first row
-    int32_t nnb;       // name blocks that overlap the tile
-    int32_t w0a, w0b;  // first word of the strand-mask window staged for block nb0 / nb0+1 (relative to the contig's mask)
-    int32_t nwa, nwb;  // words staged (0: none)
-    int64_t boffa, boffb; // word offset of that window in the concatenated mask arrays
-    int32_t reva, revb;   // which strand's mask
-};
-
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
 constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
 constexpr int WROWS = 64;   // rows before a window's last row that k1_emit looks at (longer windows: k1_rare)
@@ -686,7 +587,6 @@ struct K1Args {
     DevTable T;
     DevRef R;
     const NbDesc *desc;
-    const TileDesc *tiles;
     Payload *payload;             // [payload_cap]
     long long payload_cap;
     long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of (1 << chunk_shift) behind its own PT slots
@@ -698,48 +598,8 @@ struct K1Args {
     Counters *cnt;
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
+    unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
 };
-
-// One thread per tile: which name blocks overlap it, and which words of the strand masks its rows can touch.
-__global__ void k0_tiles(DevTable T, DevRef R, const NbDesc *__restrict__ desc, int k, TileDesc *__restrict__ tiles) {
-    MC_FRONT_OF_THE_QUEUE;
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= T.n_tiles) return;
-    const int64_t t0 = t * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
-    TileDesc td;
-    td.nb0 = T.tile_nb[t];
-    int nnb = 1;
-    while (td.nb0 + nnb < T.n_nb && T.nb_row_begin[td.nb0 + nnb] < t1) ++nnb;
-    td.nnb = nnb;
-    td.w0a = td.w0b = td.nwa = td.nwb = td.reva = td.revb = 0;
-    td.boffa = td.boffb = 0;
-    for (int sb = 0; sb < NBST; ++sb) {
-        if (sb >= nnb) continue;
-        const NbDesc d = desc[td.nb0 + sb];
-        if (d.mode != MODE_REGULAR) continue;
-        const int64_t lo = max(d.row_begin, t0), hi = min(d.row_end, t1);
-        const int64_t wmax = ((d.contig_len + 31) >> 5) + 1;       // the mask has 2 zero words of padding
-        if (hi <= lo) continue;
-        const int64_t w0 = max<int64_t>((T.pos[lo] >> 5) - 1, 0);        // one word to the left: nearest-left-'M' lookups
-        const int64_t w1 = min<int64_t>(((int64_t)T.pos[hi - 1] + k) >> 5, wmax - 1) + 1;
-        const int64_t nw = w1 - w0 + 1;
-        if (nw > 0 && nw <= BW) {
-            if (sb == 0) { td.w0a = (int32_t)w0; td.nwa = (int32_t)nw; td.boffa = d.mask_off + w0; td.reva = d.rev; }
-            else { td.w0b = (int32_t)w0; td.nwb = (int32_t)nw; td.boffb = d.mask_off + w0; td.revb = d.rev; }
-        }
-    }
-    tiles[t] = td;
-}
-
-// first 'M' offset from a window of the strand bitmask staged in LDS (words [w0, w0+nw) of the contig's mask)
-__device__ __forceinline__ int first_m_lds(const uint32_t *s_bits, int w0, int64_t L, int pos, int k) {
-    if (pos >= L) return -1;
-    const int wi = (pos >> 5) - w0;
-    const uint64_t lo = s_bits[wi], hi = s_bits[wi + 1];
-    uint64_t w = ((hi << 32) | lo) >> (pos & 31);
-    w &= (1ull << k) - 1ull;
-    return w ? __builtin_ctzll(w) : -1;
-}
 
 // The row that closes a window whose last row is r (in name block nb_abs, which ends at my_end): the next
 // unfiltered row in the file (:179).  Returns its index (T.n_rows when it lies in the next shard, -1 when there is
@@ -828,7 +688,7 @@ struct __attribute__((aligned(16))) CandUnit {    // eight rows that may hold a 
     int32_t pos[10];
     uint8_t fl[10];     // their flag bytes
     uint16_t i0;        // first row of the unit (tile-relative)
-    uint32_t pad[3];
+    uint32_t mw[3];     // two words of the block's strand mask, and the word they start at (-1: none)
 };
 static_assert(sizeof(CandUnit) == 64, "CandUnit layout");
 
@@ -886,15 +746,15 @@ struct TileSlots {
 
 // A tile that holds more name blocks than the register path keeps track of (reads of a few dozen rows): every row of a regular
 // block is examined from global memory, 64 rows at a time.  Exact, slow, rare.
-__device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc &td, int64_t tile, long long *s_chunk, int lane) {
+__device__ __forceinline__ void scan_tile_slowly(const K1Args &A, int nb0, int nnb, int64_t tile, long long *s_chunk, int lane) {
     const DevTable &T = A.T;
     ScanGlobals G;
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = A.k; G.skip_thresh = A.skip_thresh;
     const int64_t t0 = tile * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
     TileSlots S{A, tile, s_chunk, 0, lane};
-    for (int bi = 0; bi < td.nnb; ++bi) {
-        const int nb_abs = td.nb0 + bi;
+    for (int bi = 0; bi < nnb; ++bi) {
+        const int nb_abs = nb0 + bi;
         const NbDesc d = A.desc[nb_abs];
         if (d.mode != MODE_REGULAR) continue;
         const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
@@ -922,17 +782,68 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc
     if (lane == 0) A.tile_cnt[tile] = S.total;
 }
 
-// k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier: the position and flag columns (5 B/row) go
-// from HBM into REGISTERS -- every lane holds eight consecutive rows of each 512-row stripe, all loads of the tile are issued
-// before anything is used -- and 95 % of the rows never leave them: one 32-bit extract from the strand bitmask (a window of it
-// staged in LDS per tile) tells for a unit of eight rows whether any of their k-mers holds an 'M' at all.  Only the units that
-// pass are written to an LDS list (with the two rows behind them); when all stripes are done -- the columns' registers are
-// free again -- one lane per row of the listed units decides whether the row is the LAST row of a window: its k-mer holds an
-// 'M' (first one: the site m, :176) and the next unfiltered row of the read lies beyond m, or there is none and another read
-// (or the next shard) follows (:179).  Every closed window leaves a 32-byte payload (last row, site, closing row); which of the
-// rows before it belong to which slot is worked out by k1_emit, eight lanes per window.  Whatever needs more than the tile's
-// registers (a closing row beyond the tile or behind two 'N' rows, mask words outside the staged window) is an out-of-line call
-// that reads global memory.  Waves are short and light, many are resident per SIMD, their loads overlap: the kernel streams.
+// ---- validation: what the rows of a name block look like when each is compared with the row before it (first pass over a
+// table; what makes a block "regular", see classify_block) ----
+// A name block's flags (V_*) that the classification of the pass did not rest on have come to light in a tile: they go into the
+// table's flags, and if the block was taken for regular the pass cannot be finished by the fast path (mc_wait_records repeats
+// it on the table's flags, which are complete by then).  Called by one lane.
+__device__ __forceinline__ void note_validation(const K1Args &A, int nb_abs, uint32_t seen) {
+    const NbDesc *dp = A.desc + nb_abs;
+    if (!(seen & ~dp->vf)) return;
+    atomicOr(&A.T.nb_vflags[nb_abs], seen);
+    if (dp->mode == MODE_REGULAR) {
+        *reinterpret_cast<volatile unsigned int *>(&A.cnt->violation) = 1u;
+        *reinterpret_cast<volatile unsigned long long *>(&A.cnt->irregular_pass) = A.pass_no;
+    }
+}
+
+__device__ __forceinline__ uint32_t row_vflags(int p, int x, int prev_p, int prev_x, bool has_pred) {
+    uint32_t f = p == 0 ? V_POS0 : 0u;
+    if (has_pred) {
+        if (p < prev_p) f |= V_POS_DEC;
+        f |= x > prev_x ? V_IDX_INC : (x < prev_x ? V_IDX_DEC : V_IDX_EQ);
+    }
+    return f;
+}
+
+// ... of a tile with more name blocks than the register path handles: row by row from global memory (exact, slow, rare)
+__device__ __forceinline__ void validate_tile_slowly(const K1Args &A, int nb0, int64_t t0, int nrows, int lane) {
+    const DevTable &T = A.T;
+    for (int base = 0; base < nrows; base += 64) {
+        const int64_t row = t0 + base + lane;
+        if (base + lane >= nrows) continue;
+        int b = nb0;
+        while (b + 1 < T.n_nb && T.nb_row_begin[b + 1] <= row) ++b;
+        const bool has_pred = row > T.nb_row_begin[b];
+        const uint32_t f = row_vflags(T.pos[row], T.idx[row], has_pred ? T.pos[row - 1] : 0, has_pred ? T.idx[row - 1] : 0, has_pred);
+        note_validation(A, b, f);
+    }
+}
+
+constexpr int SCAN_VALIDATE = 0;    // a table's first pass: positions and event indices streamed (8 B/row), every row validated
+constexpr int SCAN_STREAM = 1;      // a validated table, positions streamed (4 B/row): one-base motifs, where every unit is listed
+constexpr int SCAN_SUMMARY = 2;     // a validated table that has unit summaries (k_summarize): 1 B/row
+
+// k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier.
+//
+// The columns go from HBM into REGISTERS -- every lane holds eight consecutive rows (a unit) of each 512-row stripe, all loads of
+// the tile are issued before anything is used.  On a table's first pass (SCAN_VALIDATE) these are the positions and the event
+// indices, 8 B/row, and every row is compared with the row before it -- its neighbour in the lane, the previous lane's last row
+// (one shuffle), the row before the tile -- which gives the validation flags of the tile's name blocks: a tile inside one block
+// (eleven in twelve) ends with wave-wide flags that are held against what the block was classified on, and nothing is written
+// unless they say more.  The comparisons run while the mask words below are on their way.
+//
+// 95 % of the units never leave the registers: one 32-bit extract from the strand bitmask (two words per unit, fetched
+// straight from L2 -- the masks of a bacterial genome are 0.6 MB per strand) tells whether any of the unit's k-mers holds an
+// 'M' at all.  Only the units that pass are written to an LDS list, with the two rows behind them and their mask words; one
+// lane per listed unit then fetches the unit's flag bytes (and, where the filter read unit summaries instead of the column,
+// its rows), and when all stripes are done -- the columns' registers are free again -- one lane per row of the listed units
+// decides whether the row is the LAST row of a window: its k-mer holds an 'M' (first one: the site m, :176) and the next
+// unfiltered row of the read lies beyond m, or there is none and another read (or the next shard) follows (:179).  Every
+// closed window leaves a 32-byte payload (last row, site, closing row); which of the rows before it belong to which slot is
+// worked out by k1_emit, eight lanes per window.  Whatever needs more than the list holds (a closing row beyond the tile or
+// behind two 'N' rows, mask words beyond the unit's two) is an out-of-line call that reads global memory.  Waves are short
+// and light, many are resident per SIMD, their loads overlap: the kernel streams.
 // CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one unit in 20 is listed) bails out to
 // scan_tile_slowly if a tile overflows it; the dense instance holds every unit of the tile.
 #ifdef MC_SCAN_WPE                  // (variant builds, tools/variants.sh)
@@ -940,10 +851,9 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, const TileDesc
 #else
 #define MC_SCAN_ATTR
 #endif
-template <int CG, bool SUM>
+template <int CG, int MODE>
 __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
-    static_assert(!SUM || CG <= 64, "one lane per listed unit fetches its rows");
-    __shared__ uint32_t s_bits[NBST][64];
+    static_assert(CG <= 64 || MODE != SCAN_SUMMARY, "one lane per listed unit fetches its rows: at most one round of 64");
     __shared__ __attribute__((aligned(16))) CandUnit s_cand[CG];
     __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
     __shared__ uint16_t s_seg_end[NBR];             // candidate units listed up to and including this name block
@@ -955,123 +865,197 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
 
     // ---- the columns: every load of the tile goes out before anything is used ----
-    // (SUM: only the unit summaries -- first and last position of the lane's unit in stripe j --; the units that pass the
-    // filter, one in twenty, fetch their rows afterwards, one lane per listed unit)
+    // (SCAN_SUMMARY: only the unit summaries -- first and last position of the lane's unit in stripe j)
     int4 pa[NQ], pb[NQ];                            // rows i0 .. i0+3, i0+4 .. i0+7 of the lane's unit in stripe j
-    uint2 fl8[NQ];
-    if (SUM) {
+    int4 xa[NQ], xb[NQ];                            // ... their event indices (SCAN_VALIDATE)
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 8;
-            int2 pp = make_int2(0, 0);
-            if (i0 < nrows) pp = T.unit_pp[(t0 + i0) >> 3];
-            pa[j] = make_int4(pp.x, 0, 0, 0);
-            pb[j] = make_int4(0, 0, 0, pp.y);
-            fl8[j] = make_uint2(0u, 0u);
-        }
-    } else if (nrows == TILE) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 8;
-            pa[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-            pb[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0 + 4);
-            fl8[j] = *reinterpret_cast<const uint2 *>(T.flags + t0 + i0);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 8;
-            pa[j] = pb[j] = make_int4(0, 0, 0, 0);
-            fl8[j] = make_uint2(0x02020202u, 0x02020202u);   // (rows past the table: MC_F_MODEL_N, never looked at anyway)
-            if (i0 < nrows) {                       // (arrays are padded: whole units stay in bounds)
+    for (int j = 0; j < NQ; ++j) {
+        const int i0 = (j * 64 + lane) * 8;
+        pa[j] = pb[j] = xa[j] = xb[j] = make_int4(0, 0, 0, 0);
+        if (i0 < nrows) {                           // (arrays are padded: whole units stay in bounds)
+            if (MODE == SCAN_SUMMARY) {
+                const int2 pp = T.unit_pp[(t0 + i0) >> 3];
+                pa[j].x = pp.x;
+                pb[j].w = pp.y;
+            } else {
                 pa[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
                 pb[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0 + 4);
-                fl8[j] = *reinterpret_cast<const uint2 *>(T.flags + t0 + i0);
+                if (MODE == SCAN_VALIDATE) {
+                    xa[j] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0);
+                    xb[j] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0 + 4);
+                }
             }
         }
     }
-    const TileDesc td = A.tiles[tile];
-    if (td.nnb > NBR) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }
-    s_bits[0][lane] = lane < td.nwa ? ((td.reva ? A.R.mr : A.R.mf) + td.boffa)[lane] : 0u;
-    s_bits[1][lane] = lane < td.nwb ? ((td.revb ? A.R.mr : A.R.mf) + td.boffb)[lane] : 0u;
+    int before_p = 0, before_x = 0;                 // the row before the tile (the first row's predecessor, if it is in its block)
+    if (MODE == SCAN_VALIDATE && t0 > 0) { before_p = T.pos[t0 - 1]; before_x = T.idx[t0 - 1]; }
+
+    // ---- the name blocks that overlap the tile: nb0 .. nb0 + nnb - 1 ----
+    const int nb0 = T.tile_nb[tile];
+    int nnb = 1;
+    while (nb0 + nnb < T.n_nb && A.desc[nb0 + nnb - 1].row_end < t0 + nrows) ++nnb;
+    if (nnb > NBR) {
+        if (MODE == SCAN_VALIDATE) validate_tile_slowly(A, nb0, t0, nrows, lane);
+        scan_tile_slowly(A, nb0, nnb, tile, s_chunk, lane);
+        return;
+    }
     const unsigned long long below = (1ull << lane) - 1ull;
 
+    // ---- the mask words of the units: a unit that lies wholly inside one of the tile's first two blocks (from the block's first
+    // tested row on) spans positions [p0, p7]; its rows' k-mers cover mask bits [p0, p7 + k) of that block's strand.  If that is
+    // at most 32 bits, the two words from p0 >> 5 decide whether the unit can hold a site row; units cut by a block's ends,
+    // units of a third block, spans that do not fit are listed unconditionally ----
+    uint32_t mlo[NQ], mhi[NQ];
+    bool decidable[NQ];
+    {
+        const NbDesc *da = A.desc + nb0, *db = A.desc + nb0 + (nnb > 1 ? 1 : 0);
+        const bool rega = da->mode == MODE_REGULAR, regb = nnb > 1 && db->mode == MODE_REGULAR;
+        const int loa = (int)(max(max(da->row_begin, da->first()), t0) - t0), hia = (int)(min(da->row_end, t0 + (int64_t)nrows) - t0);
+        const int lob = (int)(max(max(db->row_begin, db->first()), t0) - t0), hib = (int)(min(db->row_end, t0 + (int64_t)nrows) - t0);
+        const uint32_t *ga = (da->rev ? A.R.mr : A.R.mf) + da->mask_off, *gb = (db->rev ? A.R.mr : A.R.mf) + db->mask_off;
+        const int nwa = ((da->contig_len + 31) >> 5) + 2, nwb = ((db->contig_len + 31) >> 5) + 2;     // (two zero words behind every contig's mask)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * 64 + lane) * 8;
+            const int p0 = pa[j].x, p7 = pb[j].w;
+            const bool ina = rega && i0 >= loa && i0 + 8 <= hia, inb = regb && i0 >= lob && i0 + 8 <= hib;
+            const uint32_t span = (uint32_t)p7 - (uint32_t)p0 + (uint32_t)k;
+            const int w = p0 >> 5;
+            decidable[j] = (ina || inb) && span - 1u < 32u && p0 >= 0 && w + 1 < (ina ? nwa : nwb);
+            mlo[j] = mhi[j] = 0u;
+            if (decidable[j]) {
+                const uint32_t *g = (ina ? ga : gb) + w;
+                mlo[j] = g[0];
+                mhi[j] = g[1];
+            }
+        }
+    }
+
+    // ---- first pass over the table: every row against the row before it (while the mask words are on their way) ----
+    if (MODE == SCAN_VALIDATE) {
+        for (int bi = 0; bi < nnb; ++bi) {
+            const NbDesc *dp = A.desc + nb0 + bi;
+            const int64_t rb = dp->row_begin;
+            const int vlo = (int)(max(rb, t0) - t0), vhi = (int)(min(dp->row_end, t0 + (int64_t)nrows) - t0);
+            const int pred_from = rb < t0 ? 0 : vlo + 1;      // rows from here on have their predecessor in the block
+            bool pos_dec = false, x_inc = false, x_dec = false, x_eq = false, pos0 = false;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (j * 512 + 512 <= vlo || j * 512 >= vhi) continue;      // (wave-uniform)
+                const int i0 = (j * 64 + lane) * 8;
+                // the row before the unit: the previous lane's last row (lane 0: the previous stripe's, or the row before the tile)
+                int qp = __shfl_up(pb[j].w, 1), qx = __shfl_up(xb[j].w, 1);
+                {
+                    const int sp = j > 0 ? __shfl(pb[(j + NQ - 1) % NQ].w, 63) : before_p;
+                    const int sx = j > 0 ? __shfl(xb[(j + NQ - 1) % NQ].w, 63) : before_x;
+                    if (lane == 0) { qp = sp; qx = sx; }
+                }
+                const int ps[8] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w, pb[j].x, pb[j].y, pb[j].z, pb[j].w};
+                const int xs[8] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w, xb[j].x, xb[j].y, xb[j].z, xb[j].w};
+                if (i0 >= pred_from && i0 + 8 <= vhi) {     // the unit and the row before it inside the block: the usual case
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int pp = e ? ps[e - 1] : qp, px = e ? xs[e - 1] : qx;
+                        pos_dec |= ps[e] < pp;
+                        x_inc |= xs[e] > px;
+                        x_dec |= xs[e] < px;
+                        x_eq |= xs[e] == px;
+                    }
+                    const uint32_t m01 = min((uint32_t)ps[0], (uint32_t)ps[1]), m23 = min((uint32_t)ps[2], (uint32_t)ps[3]);
+                    const uint32_t m45 = min((uint32_t)ps[4], (uint32_t)ps[5]), m67 = min((uint32_t)ps[6], (uint32_t)ps[7]);
+                    pos0 |= min(min(m01, m23), min(m45, m67)) == 0u;
+                } else if (i0 + 8 > vlo && i0 < vhi) {      // a unit cut by the block's ends (or the block's very first rows)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = i0 + e;
+                        const bool in = i >= vlo && i < vhi, pred = in && i >= pred_from;
+                        const int pp = e ? ps[e - 1] : qp, px = e ? xs[e - 1] : qx;
+                        pos_dec |= pred && ps[e] < pp;
+                        x_inc |= pred && xs[e] > px;
+                        x_dec |= pred && xs[e] < px;
+                        x_eq |= pred && xs[e] == px;
+                        pos0 |= in && ps[e] == 0;
+                    }
+                }
+            }
+            const uint32_t seen = (__ballot(pos_dec) ? V_POS_DEC : 0u) | (__ballot(x_inc) ? V_IDX_INC : 0u) | (__ballot(x_dec) ? V_IDX_DEC : 0u) |
+                                  (__ballot(x_eq) ? V_IDX_EQ : 0u) | (__ballot(pos0) ? V_POS0 : 0u);
+            if (lane == 0) note_validation(A, nb0 + bi, seen);
+        }
+    }
+
     // ---- all lanes, block by block and stripe by stripe: which units of eight rows can hold a site row at all? ----
-    // A unit inside its block spans positions [p0, p7]; its rows' k-mers cover mask bits [p0, p7 + k).  One 32-bit extract from
-    // the staged mask window decides; units cut by the block's ends, units whose span does not fit the extract or the staged
-    // window are listed unconditionally.
     int ncand = 0;
     bool overflow = false;
-    for (int bi = 0; bi < td.nnb; ++bi) {
-        const NbDesc *dp = A.desc + td.nb0 + bi;
+    for (int bi = 0; bi < nnb; ++bi) {
+        const NbDesc *dp = A.desc + nb0 + bi;
         if (dp->mode == MODE_REGULAR) {
             const int64_t lb_abs = max(dp->row_begin, dp->first());
             const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(dp->row_end, t0 + (int64_t)nrows) - t0);
-            const int sw0 = bi == 0 ? td.w0a : td.w0b;
-            const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);  // (a third block of a tile: every lookup out of line)
-            const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 if (j * 512 + 512 <= lo || j * 512 >= hi) continue;      // (wave-uniform)
                 const int i0 = (j * 64 + lane) * 8;
                 const int p0 = pa[j].x, p7 = pb[j].w;
-                const bool touches = i0 + 8 > lo && i0 < hi;
-                const bool full = i0 >= lo && i0 + 8 <= hi;
+                const bool touches = i0 + 8 > lo && i0 < hi;             // (a decidable unit touches its own block only)
                 const int span = p7 - p0 + k;
-                const int wi = (p0 >> 5) - sw0;
-                const bool decidable = full && span > 0 && span <= 32 && wi >= 0 && wi + 1 < snw;
-                const int wc = min(max(wi, 0), BW - 2);
-                const uint32_t bits = bits_from(sb[wc], sb[wc + 1], p0 & 31) & (0xFFFFFFFFu >> ((32 - span) & 31));
-                const bool cand = touches && (!decidable || bits != 0u);
+                const uint32_t bits = bits_from(mlo[j], mhi[j], p0 & 31) & (0xFFFFFFFFu >> ((32 - span) & 31));
+                const bool cand = touches && (!decidable[j] || bits != 0u);
                 const unsigned long long bal = __ballot(cand);
                 if (!bal) continue;
                 if (ncand + __popcll(bal) > CG) { overflow = true; continue; }
-                if (SUM) {                          // (the rows come later)
-                    if (cand) reinterpret_cast<uint32_t *>(s_cand + (ncand + __popcll(bal & below)))[12] = (uint32_t)i0 << 16;
-                    ncand += __popcll(bal);
-                    continue;
-                }
                 // the two rows behind the unit: the next lane's first two rows (lane 63: the next stripe's)
-                int nx = __shfl_down(pa[j].x, 1), ny = __shfl_down(pa[j].y, 1);
-                uint32_t nf = __shfl_down(fl8[j].x, 1);
-                if (j + 1 < NQ) {
-                    const int sx = __shfl(pa[(j + 1) % NQ].x, 0), sy = __shfl(pa[(j + 1) % NQ].y, 0);
-                    const uint32_t sf = __shfl(fl8[(j + 1) % NQ].x, 0);
-                    if (lane == 63) { nx = sx; ny = sy; nf = sf; }
+                int nx = 0, ny = 0;
+                if (MODE != SCAN_SUMMARY) {
+                    nx = __shfl_down(pa[j].x, 1);
+                    ny = __shfl_down(pa[j].y, 1);
+                    if (j + 1 < NQ) {
+                        const int sx = __shfl(pa[(j + 1) % NQ].x, 0), sy = __shfl(pa[(j + 1) % NQ].y, 0);
+                        if (lane == 63) { nx = sx; ny = sy; }
+                    }
                 }
                 if (cand) {
                     CandUnit *g = s_cand + (ncand + __popcll(bal & below));
                     int4 *gp = reinterpret_cast<int4 *>(g);
-                    gp[0] = pa[j];
-                    gp[1] = pb[j];
-                    // pos[8], pos[9] | flag bytes 0..7 | flag bytes 8, 9 and the unit's first row
-                    gp[2] = make_int4(nx, ny, (int)fl8[j].x, (int)fl8[j].y);
-                    reinterpret_cast<uint32_t *>(g)[12] = (nf & 0xFFFFu) | ((uint32_t)i0 << 16);
+                    if (MODE != SCAN_SUMMARY) {     // (the rows are in the registers; their flag bytes come later)
+                        gp[0] = pa[j];
+                        gp[1] = pb[j];
+                        reinterpret_cast<int2 *>(g)[4] = make_int2(nx, ny);
+                    }
+                    // the unit's first row | its two mask words and the word they start at (-1: none, every lookup out of line)
+                    gp[3] = make_int4((int)((uint32_t)i0 << 16), (int)mlo[j], (int)mhi[j], decidable[j] ? (p0 >> 5) : -1);
                 }
                 ncand += __popcll(bal);
             }
         }
         if (lane == 0) s_seg_end[bi] = (uint16_t)ncand;
     }
-    if (overflow) { scan_tile_slowly(A, td, tile, s_chunk, lane); return; }    // (nothing has been written yet)
-    if (SUM) __syncthreads();                       // (one wave: orders the list's words between the lanes)
-    if (SUM && lane < ncand) {
-        // the rows of the listed units and the two rows behind each (the columns are padded beyond the table's last row)
-        CandUnit *g = s_cand + lane;
-        const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
-        const int32_t *pr = T.pos + t0 + i0;
-        const uint8_t *fr = T.flags + t0 + i0;
-        const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
-        const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
-        const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
-        const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
-        int4 *gp = reinterpret_cast<int4 *>(g);
-        gp[0] = a;
-        gp[1] = b4;
-        gp[2] = make_int4(nx.x, nx.y, (int)f8.x, (int)f8.y);
-        reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
+    if (overflow) { scan_tile_slowly(A, nb0, nnb, tile, s_chunk, lane); return; }    // (nothing has been written yet)
+    __syncthreads();                                // (one wave: orders the list's words between the lanes)
+    for (int base = 0; base < ncand; base += 64) {
+        // the flag bytes of the listed units and of the two rows behind each (the columns are padded beyond the table's last
+        // row); SCAN_SUMMARY: their positions as well
+        const int gi = base + lane;
+        if (gi < ncand) {
+            CandUnit *g = s_cand + gi;
+            const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
+            const uint8_t *fr = T.flags + t0 + i0;
+            const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
+            const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
+            if (MODE == SCAN_SUMMARY) {
+                const int32_t *pr = T.pos + t0 + i0;
+                const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
+                const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
+                int4 *gp = reinterpret_cast<int4 *>(g);
+                gp[0] = a;
+                gp[1] = b4;
+                reinterpret_cast<int2 *>(g)[4] = nx;
+            }
+            reinterpret_cast<uint2 *>(g)[5] = f8;
+            reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
+        }
     }
-    if (SUM) __syncthreads();
+    __syncthreads();
 
     // ---- one lane per row of the listed units, block by block: is this row the last row of a window? ----
     ScanGlobals G;
@@ -1080,24 +1064,21 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     TileSlots S{A, tile, s_chunk, 0, lane};
     const uint32_t kmask = (1u << k) - 1u;
     int seg_begin = 0;
-    for (int bi = 0; bi < td.nnb; ++bi) {
-        const int nb_abs = td.nb0 + bi;
+    for (int bi = 0; bi < nnb; ++bi) {
+        const int nb_abs = nb0 + bi;
         const int seg_end = s_seg_end[bi];
         const int first_g = seg_begin;
         seg_begin = seg_end;
         const NbDesc d = A.desc[nb_abs];
         if (d.mode != MODE_REGULAR) continue;
         const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-        const int sw0 = bi == 0 ? td.w0a : td.w0b;
-        const int snw = bi == 0 ? td.nwa : (bi == 1 ? td.nwb : 0);
-        const uint32_t *sb = bi == 0 ? s_bits[0] : s_bits[1];
-        // first 'M' in meth_ref[p:p+k] (:176,:270) from the staged mask window; ok = false when the window does not hold
-        // both words (the row then takes the out-of-line path)
-        auto site_off = [&](int p, bool &ok) -> int {
-            const int wi = (p >> 5) - sw0;
-            ok = wi >= 0 && wi + 1 < snw;
-            const int wc = min(max(wi, 0), BW - 2);
-            const uint32_t bits = bits_from(sb[wc], sb[wc + 1], p & 31) & kmask;
+        // first 'M' in meth_ref[p:p+k] (:176,:270) from the unit's two mask words; ok = false when they do not hold all k bits
+        // (the row then takes the out-of-line path)
+        auto site_off = [&](const CandUnit *g, int p, bool &ok) -> int {
+            const int wb = (int)g->mw[2], wi = (p >> 5) - wb, sh = p & 31;
+            const uint32_t two = bits_from(g->mw[0], g->mw[1], sh), one = g->mw[1] >> sh;
+            ok = wb >= 0 && (wi == 0 || (wi == 1 && sh + k <= 32));
+            const uint32_t bits = (wi == 0 ? two : one) & kmask;
             int o = bits ? (int)__builtin_ctz(bits) : -1;
             if (p >= d.contig_len) { o = -1; ok = true; }
             return o;
@@ -1127,7 +1108,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             uint32_t pf = 0;
             if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
                 bool ok;
-                const int o = site_off(p, ok);
+                const int o = site_off(g, p, ok);
                 if (!ok) far = true;
                 else if (o >= 0) {
                     m = p + o;
@@ -1140,7 +1121,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
                         closed = cp > m;
                         if (closed && cp <= m + A.skip_thresh + 1) {
                             bool ok2;
-                            const int o2 = site_off(cp, ok2);
+                            const int o2 = site_off(g, cp, ok2);
                             if (!ok2) far = true;
                             else if (o2 > 0) pf |= PF_MULTI;
                         }
@@ -1222,6 +1203,7 @@ __device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const Nb
         if (T.flags[rr] & MC_F_MODEL_N) continue;
         const int p = T.pos[rr];
         if (p < m - k + 1) break;
+        if (p > m) continue;        // (cannot happen in a regular block; a block taken for regular on its first rows may not be)
         const int sh = 8 * (m - p);
         if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
         else cnt8 += 1ull << sh;
@@ -1625,6 +1607,7 @@ __device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j) {
         if (T.flags[rr] & MC_F_MODEL_N) continue;
         const int p = T.pos[rr];
         if (p < m - k + 1) break;
+        if (p > m) continue;        // (see emit_record)
         cnt[m - p] += 1;
         ws = rr;
     }
@@ -2531,16 +2514,15 @@ constexpr int MC_PASSES_IN_FLIGHT = 4;   // one being copied out, one computing,
 // What K0 writes and K1 reads, per pass in flight
 struct K0Set {
     NbDesc *desc = nullptr;
-    TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
 };
 
 // One resident table.  A ctx owns MC_TABLE_SLOTS of them so that a file can go through the GPU as a sequence of shards:
 // one being uploaded, one being scanned, the others waiting for their records to be handed out.  All device memory of a
-// slot is allocated once (mc_ctx_reserve_tables, or by the first table that needs more) -- an upload is DMA transfers and
-// two small kernels, no hipMalloc / hipFree.
+// slot is allocated once (mc_ctx_reserve_tables, or by the first table that needs more) -- an upload is DMA transfers, no kernel
+// (the first pass over the table validates it while it scans), no hipMalloc / hipFree.
 struct SmallLayout {       // byte offsets of a table's small arrays inside one block: the same on the pinned host stage and on the device
-    size_t seg_begin, seg_read, seg_contig, nb_row_begin, nb_seg_begin, nb_read, nb_repeat, nb_vflags, tile_nb, vtile_nb, qual, total;
+    size_t seg_begin, seg_read, seg_contig, nb_row_begin, nb_seg_begin, nb_read, nb_repeat, nb_vflags, tile_nb, qual, total;
 };
 static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2555,7 +2537,6 @@ static SmallLayout small_layout(int64_t n_seg, int64_t n_tiles, int64_t n_reads)
     L.nb_repeat = o;    o = al(o + (size_t)n_seg);
     L.nb_vflags = o;    o = al(o + (size_t)(n_seg + 1) * 4);
     L.tile_nb = o;      o = al(o + (size_t)(n_tiles + 1) * 4);
-    L.vtile_nb = o;     o = al(o + (size_t)(n_tiles + 1) * 4);     // (never more tiles than the scan has: VTILE >= TILE)
     L.qual = o;         o = al(o + (size_t)n_reads * 8);
     L.total = o;
     return L;
@@ -2592,8 +2573,14 @@ struct TableSlot {
     double *qual = nullptr;            // read qualities that travelled with the table (in small_dev), or nullptr
     int32_t n_qual = 0;
     hipEvent_t ev_uploaded = nullptr;  // the H2D transfers of the slot's table are done
-    hipEvent_t ev_up_start = nullptr, ev_val_start = nullptr, ev_valid = nullptr;   // ... begin; k_validate begins / is done
+    hipEvent_t ev_up_start = nullptr, ev_val_start = nullptr, ev_valid = nullptr;   // ... begin; the small arrays are in place (ctx stream)
     int refs = 0;                      // passes in flight that scan this table (+1 while the device parser fills the slot)
+    // What the passes enqueued so far leave behind for the next one (host-side notes; the work is ordered by the ctx stream):
+    int passes = 0;                    // passes enqueued over this table.  The first streams positions and event indices and
+                                       // completes the validation flags (k1_scan, SCAN_VALIDATE); later ones classify on the flags.
+                                       // A table that comes back a third time (other parameters, a resident table) is worth
+                                       // unit summaries (k_summarize): from then on a scan reads 1 B/row
+    bool summarized = false;           // ... the summaries exist
     // the device parser (mc_ctx_parse_begin .. _finish)
     char *text = nullptr;              // the shard's text on the device
     int64_t cap_text = 0;
@@ -2641,7 +2628,6 @@ struct mc_ctx {
     double *qual = nullptr;
     int32_t n_qual = 0;
     NbDesc *desc = nullptr;
-    TileDesc *tiles = nullptr;
     int64_t *nb_f0 = nullptr;
     DevRecords O;            // records of the last call (view: the fast path's buffers, or the merged ones)
     DevRecords Omain;        // the fast path's buffers
@@ -3091,7 +3077,7 @@ static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int6
     S.cap_rows = grow(rows, c->res_rows);
     S.cap_segs = std::max<int64_t>(grow(segs, c->res_segs), 16);
     S.cap_reads = std::max<int64_t>(grow(reads, c->res_reads), 16);
-    const int64_t padded = ((S.cap_rows + VTILE - 1) / VTILE) * VTILE + VTILE + FRONT;     // (whole tiles of the scan and of k_validate)
+    const int64_t padded = ((S.cap_rows + TILE - 1) / TILE) * TILE + TILE + FRONT;     // (whole tiles of the scan)
     const SmallLayout L = small_layout(S.cap_segs, padded / TILE, S.cap_reads);
     if (dev_alloc(S.allocs, &S.pos, (size_t)padded) || dev_alloc(S.allocs, &S.idx, (size_t)padded) ||
         dev_alloc(S.allocs, &S.evmu, (size_t)padded) || dev_alloc(S.allocs, &S.flags, (size_t)padded) ||
@@ -3110,14 +3096,14 @@ static int slot_ensure(mc_ctx *c, TableSlot &S, int64_t rows, int64_t segs, int6
 // the scratch all passes share (ordered by the ctx stream): tile descriptors / counts / chunks, strand-resolve output of
 // the synchronous pass
 static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
-    if (c->tiles && n_nb <= c->scratch_nb && n_tiles <= c->scratch_tiles) return 0;
+    if (c->desc && n_nb <= c->scratch_nb && n_tiles <= c->scratch_tiles) return 0;
     if (int rc = sync_pass_streams(c)) return rc;
     free_pool(c->scratch_allocs);
     const int64_t res_tiles = c->res_rows ? (c->res_rows + TILE - 1) / TILE : 0;
     const int64_t nb = std::max<int64_t>(std::max<int64_t>(n_nb, c->res_segs), c->scratch_nb);
     const int64_t nt = std::max<int64_t>(std::max<int64_t>(n_tiles, res_tiles), c->scratch_tiles);
     std::vector<void *> &P = c->scratch_allocs;
-    if (dev_alloc(P, &c->tiles, (size_t)nt + 1) || dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
+    if (dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
         dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1))
         return -10;
@@ -3165,7 +3151,6 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
     int64_t *seg_begin = (int64_t *)(st + L.seg_begin), *nb_row = (int64_t *)(st + L.nb_row_begin);
     int32_t *seg_read = (int32_t *)(st + L.seg_read), *seg_contig = (int32_t *)(st + L.seg_contig);
     int32_t *nb_seg = (int32_t *)(st + L.nb_seg_begin), *nb_read = (int32_t *)(st + L.nb_read), *tile_nb = (int32_t *)(st + L.tile_nb);
-    int32_t *vtile_nb = (int32_t *)(st + L.vtile_nb);
     uint8_t *nb_rep = st + L.nb_repeat;
     uint32_t *nb_vf = (uint32_t *)(st + L.nb_vflags);
     if (n_seg > 0) {
@@ -3209,11 +3194,6 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
             while (b + 1 < n_nb && nb_row[b + 1] <= t * TILE) ++b;
             tile_nb[t] = b;
         }
-        b = 0;
-        for (int64_t t = 0; t * VTILE < n; ++t) {
-            while (b + 1 < n_nb && nb_row[b + 1] <= t * VTILE) ++b;
-            vtile_nb[t] = b;
-        }
     }
     if (read_qual && n_reads > 0) memcpy(st + L.qual, read_qual, (size_t)n_reads * 8);
 
@@ -3227,18 +3207,19 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
     T.nb_row_begin = (int64_t *)(dv + L.nb_row_begin); T.nb_seg_begin = (int32_t *)(dv + L.nb_seg_begin);
     T.nb_read = (int32_t *)(dv + L.nb_read); T.nb_repeat = dv + L.nb_repeat; T.nb_vflags = (uint32_t *)(dv + L.nb_vflags);
     T.tile_nb = (int32_t *)(dv + L.tile_nb);
-    T.vtile_nb = (int32_t *)(dv + L.vtile_nb);
     S.qual = read_qual ? (double *)(dv + L.qual) : nullptr;
     S.n_qual = read_qual ? n_reads : 0;
     S.tmpl_ref = -1;
+    S.passes = 0;                                          // (the first pass over these rows validates them)
+    S.summarized = false;
 
-    // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out), then the per-table kernel on
-    //      the ctx stream behind the transfer ----
+    // ---- H2D on the upload stream (nothing reads the slot: its passes have been handed out); the ctx stream waits for the
+    //      transfer ----
     // (a device-parsed table: the upload stream is busy with the NEXT shard's text by now -- the small arrays go on the ctx
     // stream, in front of the kernels that read them)
     hipStream_t us = cols ? c->up_stream : c->stream;
     if (cols) {
-        HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));    // k_validate of the slot's previous table (it may never have been scanned)
+        HIP_TRY(hipStreamWaitEvent(us, S.ev_valid, 0));    // the small arrays of the slot's previous table (it may never have been scanned)
         HIP_TRY(hipEventRecord(S.ev_up_start, us));
         if (n > 0) {
             HIP_TRY(hipMemcpyAsync(T.pos, cols->pos, (size_t)n * 4, hipMemcpyHostToDevice, us));
@@ -3252,7 +3233,6 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
     HIP_TRY(hipEventRecord(S.ev_uploaded, us));
     HIP_TRY(hipStreamWaitEvent(c->stream, S.ev_uploaded, 0));
     HIP_TRY(hipEventRecord(S.ev_val_start, c->stream));
-    if (n_nb > 0) hipLaunchKernelGGL(k_validate, dim3((unsigned)((n + VTILE - 1) / VTILE)), dim3(VT), 0, c->stream, T);
     HIP_TRY(hipEventRecord(S.ev_valid, c->stream));
     HIP_TRY(hipGetLastError());
     c->T = T;
@@ -3392,7 +3372,7 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
     if (!c->parse_stream) HIP_TRY(hipStreamCreateWithFlags(&c->parse_stream, hipStreamNonBlocking));
     {   // the text on the upload stream, the kernels behind it on their own: the next shard's text travels while they run
         hipStream_t up = c->up_stream;
-        HIP_TRY(hipStreamWaitEvent(up, S.ev_valid, 0));    // k_validate of the slot's previous table (it may never have been scanned)
+        HIP_TRY(hipStreamWaitEvent(up, S.ev_valid, 0));    // the small arrays of the slot's previous table (it may never have been scanned)
         HIP_TRY(hipEventRecord(S.ev_up_start, up));
         static const KpHead zero_head = {0, 0, 0, 0, 0, 0x7fffffffffffffffll, 0, 0};
         HIP_TRY(hipMemcpyAsync(S.kp_head, &zero_head, sizeof(KpHead), hipMemcpyHostToDevice, up));
@@ -3536,7 +3516,7 @@ extern "C" int mc_ctx_parse_abandon(mc_ctx *c, int32_t slot) {
     }
     TableSlot &S = c->slots[slot];
     HIP_TRY(hipEventSynchronize(S.ev_parsed));
-    // (k_validate never ran on these rows: ev_valid still stands for the slot's previous table, which is all a later upload waits for)
+    // (ev_valid still stands for the slot's previous table, which is all a later upload waits for)
     S.kp_state = 0;
     S.refs -= 1;
     return 0;
@@ -3572,6 +3552,24 @@ extern "C" int mc_ctx_wait_upload(mc_ctx *c, int32_t slot) {
 }
 
 extern "C" int mc_ctx_current_slot(mc_ctx *c) { return c->cur; }
+
+// A resident table becomes the current one again (the passes enqueued afterwards scan it).  as_new != 0: what earlier passes
+// left behind for later ones is set aside -- the next pass does everything the first pass over a table does (classification on
+// the blocks' first rows, positions and event indices streamed, every row validated).
+extern "C" int mc_ctx_select_table(mc_ctx *c, int32_t slot, int32_t as_new) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].T.pos || c->slots[slot].kp_state != 0) {
+        mc_set_error("mc_ctx_select_table: slot %d holds no table", slot);
+        return -12;
+    }
+    TableSlot &S = c->slots[slot];
+    c->T = S.T;
+    c->cur = slot;
+    if (S.qual) { c->qual = S.qual; c->n_qual = S.n_qual; }
+    else { c->qual = c->qual_own; c->n_qual = c->n_qual_own; }
+    if (as_new) S.passes = 0;
+    return 0;
+}
 
 extern "C" int mc_ctx_upload_times_ms(mc_ctx *c, int32_t slot, float *h2d_ms, float *validate_ms) {
     HIP_TRY(hipSetDevice(c->device));
@@ -3793,11 +3791,38 @@ static int run_literal_path(mc_ctx *c, const mc_params *prm, int64_t *n_io) {
     return 0;
 }
 
-// K0 (strand resolve) of one pass on stream st: counters zeroed, first site rows, classification, tile descriptors.
+// How a pass goes about its table: decided when it is enqueued, from what the passes before it have left (TableSlot.passes).
+struct PassPlan {
+    bool first;          // no pass has validated the table: classification on the blocks' first rows, the scan validates every row
+    int scan_mode;       // SCAN_*
+};
+static PassPlan plan_pass(mc_ctx *c, hipStream_t st) {
+    PassPlan P;
+    P.first = true;
+    P.scan_mode = SCAN_VALIDATE;
+    if (c->cur < 0) return P;
+    TableSlot &S = c->slots[c->cur];
+    const bool dense = dense_reference(c);                 // (a one-base motif: every unit is listed, summaries would not help)
+    if (S.passes > 0) {
+        P.first = false;
+        P.scan_mode = SCAN_STREAM;
+        if (!dense && S.passes >= 2) {
+            if (!S.summarized && S.T.n_rows > 0) {
+                hipLaunchKernelGGL(k_summarize, dim3((unsigned)((S.T.n_rows / 4 + 256) / 256)), dim3(256), 0, st, S.T);
+                S.summarized = true;
+            }
+            P.scan_mode = SCAN_SUMMARY;
+        }
+    }
+    S.passes += 1;
+    return P;
+}
+
+// K0 (strand resolve) of one pass on stream st: counters zeroed, first site rows, classification.
 // extend: also widen the irregular set (k0_extend) -- what the literal path of the synchronous pass needs; a pipelined pass
 // with an irregular block is thrown away and re-run synchronously, so it never looks at the result.
 static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, hipStream_t st, unsigned long long pass_no,
-                      bool extend) {
+                      bool extend, const PassPlan &plan) {
     const DevTable &T = c->T;
     const int k = prm->k;
     const bool lookback = T.has_repeats || prm->entry_read >= 0;      // a block may see name == last_read (:161)
@@ -3808,32 +3833,40 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     const int64_t threads = (int64_t)T.n_nb * 64;
     hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
                        c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1,
-                       prm->skip_thresh, pass_no);
+                       prm->skip_thresh, pass_no, plan.first ? 1 : 0);
     if (lookback)
         hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
                            K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt, pass_no);
     if (extend)
         hipLaunchKernelGGL(k0_extend, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, K.desc,
                            (const int64_t *)K.nb_f0, prm->entry_read, cnt, pass_no);
-    hipLaunchKernelGGL(k0_tiles, dim3((unsigned)((T.n_tiles + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       K.desc, k, K.tiles);
     return 0;
 }
 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
-                      hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, hipEvent_t ev_emit_end = nullptr) {
+                      hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
+                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr) {
     const DevTable &T = c->T;
     K1Args A;
-    A.T = T; A.R = c->R; A.desc = K.desc; A.tiles = K.tiles; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
+    A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
+    A.pass_no = pass_no;
     const bool dense = dense_reference(c);
     A.chunk_shift = dense ? 8 : 6;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
-    if (dense) hipLaunchKernelGGL((k1_scan<TILE / 8 + NBR, false>), dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
-    else hipLaunchKernelGGL((k1_scan<64, MC_SCAN_SUMMARY != 0>), dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
+    const dim3 grid((unsigned)T.n_tiles);
+    constexpr int CG_DENSE = TILE / 8 + NBR;
+    if (dense) {
+        if (plan.scan_mode == SCAN_VALIDATE) hipLaunchKernelGGL((k1_scan<CG_DENSE, SCAN_VALIDATE>), grid, dim3(64), 0, st, A);
+        else hipLaunchKernelGGL((k1_scan<CG_DENSE, SCAN_STREAM>), grid, dim3(64), 0, st, A);
+    } else {
+        if (plan.scan_mode == SCAN_VALIDATE) hipLaunchKernelGGL((k1_scan<64, SCAN_VALIDATE>), grid, dim3(64), 0, st, A);
+        else if (plan.scan_mode == SCAN_STREAM) hipLaunchKernelGGL((k1_scan<64, SCAN_STREAM>), grid, dim3(64), 0, st, A);
+        else hipLaunchKernelGGL((k1_scan<64, SCAN_SUMMARY>), grid, dim3(64), 0, st, A);
+    }
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
@@ -3854,11 +3887,12 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 // the synchronous pass: everything on the ctx stream, ev[0..3] around the stages (mc_last_times_ms)
 static int enqueue_fast_path(mc_ctx *c, const mc_params *prm, const DevRecords &O, hipEvent_t *ev, K1Args *out_args) {
     K0Set K;
-    K.desc = c->desc; K.tiles = c->tiles; K.nb_f0 = c->nb_f0;
+    K.desc = c->desc; K.nb_f0 = c->nb_f0;
+    const PassPlan plan = plan_pass(c, c->stream);            // (in front of ev[0]: a table's summaries are not part of a pass)
     HIP_TRY(hipEventRecord(ev[0], c->stream));
-    if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream, c->sync_pass_no, true)) return rc;
+    if (int rc = enqueue_k0(c, prm, K, c->cnt, c->stream, c->sync_pass_no, true, plan)) return rc;
     HIP_TRY(hipEventRecord(ev[1], c->stream));
-    if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args, c->payload_sorted, c->rare_list)) return rc;
+    if (int rc = enqueue_k1(c, prm, K, c->cnt, O, c->stream, ev[2], out_args, c->payload_sorted, c->rare_list, c->sync_pass_no, plan)) return rc;
     HIP_TRY(hipEventRecord(ev[3], c->stream));
     return 0;
 }
@@ -3913,7 +3947,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
 
     free_pool(c->lit_allocs);
     int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
         K1Args A;
         c->sync_pass_no = ++c->pass_counter;
@@ -3927,6 +3961,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
             cap = std::max<int64_t>(cap * 2, n + n / 4 + 4096);
             continue;
         }
+        // the table's first pass, and a row contradicts what a block was classified on (its first rows): the validation flags
+        // are complete now, the next attempt classifies on them
+        if (h.violation) continue;
         if (h.n_rare) {
             hipLaunchKernelGGL(k1_rare, dim3((h.n_rare + 63) / 64), dim3(64), 0, c->stream, A, (const Payload *)c->payload_sorted,
                                (const int64_t *)c->rare_list, (int64_t)h.n_rare);
@@ -3963,7 +4000,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         *n_records = n;
         return 0;
     }
-    mc_set_error("record buffer overflow after 3 attempts");
+    mc_set_error("record buffer overflow after 4 attempts");
     return -13;
 }
 
@@ -4042,8 +4079,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     const int64_t nb = std::max<int64_t>(T.n_nb, c->scratch_nb), nt = std::max<int64_t>(T.n_tiles, c->scratch_tiles);
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
-    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.tiles, (size_t)nt + 1) ||
-        dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1))
+    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1))
         return -10;
     if (cap >= (int64_t)1 << 31) {
         mc_set_error("mc_extract_features_async: %lld flush records per pass (call rows are 32 bits wide); use mc_extract_features",
@@ -4150,14 +4186,15 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // (a hipEventRecord between two kernels costs this queue ~9 us -- rocprofv3 timeline -- so the two events that only time
     // the pass, unlike ev_emit_end, which the side stream waits for, can be thinned out: mc_ctx_set_pass_timing)
     b.timed = c->timing_every > 0 && (c->pass_seq++ % c->timing_every) == 0;
+    const PassPlan plan = plan_pass(c, st);
     if (b.timed) HIP_TRY(hipEventRecord(b.ev_k0_start, st));
     b.pass_no = ++c->pass_counter;
-    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st, b.pass_no, false)) return rc;
+    if (int rc = enqueue_k0(c, prm, b.K, b.cnt, st, b.pass_no, false, plan)) return rc;
     if (b.timed) HIP_TRY(hipEventRecord(b.ev_scan_start, st));
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.ev_emit_end)) return rc;
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end)) return rc;
     if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b)) return rc;

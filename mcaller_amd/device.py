@@ -70,6 +70,11 @@ class Device(object):
     def current_slot(self):
         return int(lib().mc_ctx_current_slot(self._ctx))
 
+    def select_table(self, slot, as_new=False):
+        """Make the table resident in `slot` the current one again; as_new: the next pass does everything the first pass over a
+        table does (every row validated), whatever earlier passes learned about it."""
+        check(lib().mc_ctx_select_table(self._ctx, int(slot), 1 if as_new else 0))
+
     def reserve_tables(self, max_rows, max_segs, max_reads):
         """Size the table slots, the per-pass scratch and the record sets once for a stream of tables up to these sizes."""
         check(lib().mc_ctx_reserve_tables(self._ctx, int(max_rows), int(max_segs), int(max_reads)))
@@ -129,7 +134,7 @@ class Device(object):
         check(lib().mc_ctx_wait_upload(self._ctx, int(slot)))
 
     def upload_times_ms(self, slot):
-        """(H2D ms, k_validate ms) of the last upload into `slot`; waits for it."""
+        """(H2D ms, 0.0) of the last upload into `slot`; waits for it.  (Nothing runs at upload: the first pass validates.)"""
         a, b = C.c_float(0), C.c_float(0)
         check(lib().mc_ctx_upload_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
         return a.value, b.value

@@ -603,3 +603,42 @@ def test_dense_cluster_in_a_sparse_reference(dev):
             dev.run_async(6, skip, 0.0, score=True)
             H.assert_records_equal(dev.wait(), orc, 6)
         assert rec.n > 3000
+
+
+@pytest.mark.parametrize('motif,broken', [('GATC', False), ('GATC', True), ('A', False), ('A', True)])
+def test_first_second_and_later_passes_over_one_table(dev, motif, broken):
+    """What a pass does depends on what the passes before it left: the FIRST pass over a table classifies the reads on their
+    first rows and validates every row while it scans (k1_scan, SCAN_VALIDATE), the second classifies on the complete
+    validation flags and streams the positions, the third finds unit summaries (sparse motifs).  Every one of them, through
+    the synchronous and the pipelined interface, must hand out the oracle's records -- also when a read turns irregular far
+    from its first rows (the first pass notices while it scans and is repeated), and again after mc_ctx_select_table(as_new)."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    from tests.test_gpu_stream import _irregular
+    codes = synth.genome(length=500000, seed=41)
+    ref = synth.SynthRef(codes, motif=motif)
+    table, qual = synth.make_table(300000, seed=77, codes=codes)
+    if broken:
+        table = _irregular(table, 5)
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    orc = H.oracle_records(table, ref.device_arrays(), qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    for first_sync in (True, False):
+        slot = dev.upload_table_async(table, qual)
+        dev.wait_upload(slot)
+        for round_ in range(2):
+            for i in range(4):
+                if (i % 2 == 0) == first_sync:
+                    rec = dev.extract(6, 0, 0.0)
+                else:
+                    dev.run_async(6, 0, 0.0)
+                    rec = dev.wait()
+                H.assert_records_equal(rec, orc, 6)
+            dev.run_async(6, 0, 0.0)                   # two in flight over the same table
+            dev.run_async(6, 0, 0.0)
+            H.assert_records_equal(dev.wait(), orc, 6)
+            H.assert_records_equal(dev.wait(), orc, 6)
+            dev.select_table(slot, as_new=True)        # ... and everything again, as if the table had just arrived
+    dev.sync()
