@@ -680,9 +680,13 @@ __device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbit
 
 constexpr int PT = 16;              // payload slots reserved per tile; further chunks of 64 come from an atomic
 constexpr int NCHUNK = TILE / 64 + 1; // ... at most this many of them (one window per row, and one more per block start)
-constexpr int NQ = TILE / 512;      // k1_scan: stripes of 512 rows per tile -- every lane holds EIGHT consecutive rows of a stripe
-constexpr int NBR = 32;             // ... name blocks of a tile the register path handles (tiles of smaller reads: scan_tile_slowly)
-static_assert(TILE % 512 == 0, "whole stripes");
+#ifndef MC_CHUNK
+#define MC_CHUNK 1024
+#endif
+constexpr int CHUNK = MC_CHUNK;     // k1_scan: rows a wave holds in registers at a time; it takes its tile chunk after chunk
+constexpr int NCH = TILE / CHUNK;
+constexpr int NQ = CHUNK / 512;     // ... stripes of 512 rows per chunk -- every lane holds EIGHT consecutive rows of a stripe
+static_assert(CHUNK % 512 == 0 && TILE % CHUNK == 0, "whole stripes, whole chunks");
 
 struct __attribute__((aligned(16))) CandUnit {    // eight rows that may hold a site row, with the two rows behind them
     int32_t pos[10];
@@ -744,21 +748,19 @@ struct TileSlots {
     }
 };
 
-// A tile that holds more name blocks than the register path keeps track of (reads of a few dozen rows): every row of a regular
-// block is examined from global memory, 64 rows at a time.  Exact, slow, rare.
-__device__ __forceinline__ void scan_tile_slowly(const K1Args &A, int nb0, int nnb, int64_t tile, long long *s_chunk, int lane) {
+// The name blocks of a chunk beyond the two the register path keeps track of (reads of a few hundred rows or less): every row of
+// a regular block is examined from global memory, 64 rows at a time.  Exact, slow, rare.  Blocks nb0 .. nb0 + nnb - 1, rows [c0, c1).
+__device__ __forceinline__ void scan_blocks_slowly(const K1Args &A, int nb0, int nnb, int64_t c0, int64_t c1, TileSlots &S, int lane) {
     const DevTable &T = A.T;
     ScanGlobals G;
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = A.k; G.skip_thresh = A.skip_thresh;
-    const int64_t t0 = tile * TILE, t1 = min(t0 + (int64_t)TILE, T.n_rows);
-    TileSlots S{A, tile, s_chunk, 0, lane};
     for (int bi = 0; bi < nnb; ++bi) {
         const int nb_abs = nb0 + bi;
         const NbDesc d = A.desc[nb_abs];
         if (d.mode != MODE_REGULAR) continue;
         const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-        if (d.extra_row() >= t0 && d.extra_row() < t1) {
+        if (d.extra_row() >= c0 && d.extra_row() < c1) {
             const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
             Payload P;
             P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
@@ -766,7 +768,7 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, int nb0, int n
             P.nb = nb_abs;
             S.put(lane == 0 && xc.row >= 0, P);
         }
-        const int64_t lo = max(max(d.row_begin, d.first()), t0), hi = min(d.row_end, t1);
+        const int64_t lo = max(max(d.row_begin, d.first()), c0), hi = min(d.row_end, c1);
         for (int64_t base = lo; base < hi; base += 64) {
             const int64_t row = base + lane;
             RowRes fr;
@@ -779,12 +781,11 @@ __device__ __forceinline__ void scan_tile_slowly(const K1Args &A, int nb0, int n
             S.put(fr.closed != 0, P);
         }
     }
-    if (lane == 0) A.tile_cnt[tile] = S.total;
 }
 
 // ---- validation: what the rows of a name block look like when each is compared with the row before it (first pass over a
 // table; what makes a block "regular", see classify_block) ----
-// A name block's flags (V_*) that the classification of the pass did not rest on have come to light in a tile: they go into the
+// A name block's flags (V_*) that the classification of the pass did not rest on have come to light in a chunk: they go into the
 // table's flags, and if the block was taken for regular the pass cannot be finished by the fast path (mc_wait_records repeats
 // it on the table's flags, which are complete by then).  Called by one lane.
 __device__ __forceinline__ void note_validation(const K1Args &A, int nb_abs, uint32_t seen) {
@@ -806,13 +807,26 @@ __device__ __forceinline__ uint32_t row_vflags(int p, int x, int prev_p, int pre
     return f;
 }
 
-// ... of a tile with more name blocks than the register path handles: row by row from global memory (exact, slow, rare)
-__device__ __forceinline__ void validate_tile_slowly(const K1Args &A, int nb0, int64_t t0, int nrows, int lane) {
+// ... of the rows of one unit (r0 .. r0 + 7) that lie in [lo, hi); rows from pred_from on have their predecessor in the block
+__device__ __noinline__ uint32_t cut_unit_vflags(const int32_t *pos, const int32_t *idx, int64_t r0, int64_t lo, int64_t hi, int64_t pred_from) {
+    uint32_t f = 0;
+    for (int e = 0; e < 8; ++e) {
+        const int64_t r = r0 + e;
+        if (r < lo || r >= hi) continue;
+        const bool pred = r >= pred_from;
+        f |= row_vflags(pos[r], idx[r], pred ? pos[r - 1] : 0, pred ? idx[r - 1] : 0, pred);
+    }
+    return f;
+}
+
+// ... of the rows [r0, r1) of a chunk that lie in its third name block or beyond (nb_from: the block of r0): row by row from
+// global memory (exact, slow, rare)
+__device__ __forceinline__ void validate_rows_slowly(const K1Args &A, int nb_from, int64_t r0, int64_t r1, int lane) {
     const DevTable &T = A.T;
-    for (int base = 0; base < nrows; base += 64) {
-        const int64_t row = t0 + base + lane;
-        if (base + lane >= nrows) continue;
-        int b = nb0;
+    for (int64_t base = r0; base < r1; base += 64) {
+        const int64_t row = base + lane;
+        if (row >= r1) continue;
+        int b = nb_from;
         while (b + 1 < T.n_nb && T.nb_row_begin[b + 1] <= row) ++b;
         const bool has_pred = row > T.nb_row_begin[b];
         const uint32_t f = row_vflags(T.pos[row], T.idx[row], has_pred ? T.pos[row - 1] : 0, has_pred ? T.idx[row - 1] : 0, has_pred);
@@ -820,32 +834,84 @@ __device__ __forceinline__ void validate_tile_slowly(const K1Args &A, int nb0, i
     }
 }
 
-constexpr int SCAN_VALIDATE = 0;    // a table's first pass: positions and event indices streamed (8 B/row), every row validated
-constexpr int SCAN_STREAM = 1;      // a validated table, positions streamed (4 B/row): one-base motifs, where every unit is listed
+// A name-block descriptor through the scalar cache into SGPRs: b is wave-uniform, and nothing in the kernel that calls this writes
+// descriptors (K0 of the pass wrote them).  Spelled out as an instruction: a plain `dp->mode` is a VECTOR load of one byte --
+// there is no scalar byte load, and the compiler will not use scalar loads at all for memory that a store of the kernel might
+// alias -- and the wait for a vector load (vmcnt counts in order) is a wait for every column load in flight as well.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ NbDesc desc_uniform(const NbDesc *desc, int b) {
+    const NbDesc *p = desc + __builtin_amdgcn_readfirstlane(b);
+    union { u32x16 w; NbDesc d; } u;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u.w) : "s"(p));
+    return u.d;
+}
+__device__ __forceinline__ int64_t desc_row_end_uniform(const NbDesc *desc, int b) {
+    const int64_t *p = &(desc + __builtin_amdgcn_readfirstlane(b))->row_end;
+    int64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
+constexpr int SCAN_VALIDATE = 0;    // a table's first pass: positions, event indices and flag bytes streamed (9 B/row), every row validated
+constexpr int SCAN_STREAM = 1;      // a validated table, positions and flag bytes streamed (5 B/row): one-base motifs, where every unit is listed
 constexpr int SCAN_SUMMARY = 2;     // a validated table that has unit summaries (k_summarize): 1 B/row
 
-// k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier.
+// The columns of one chunk in registers: every lane holds eight consecutive rows (a unit) of each 512-row stripe.
+template <int MODE>
+struct ChunkCols {
+    int4 pa[NQ], pb[NQ];            // positions of rows i0 .. i0+3, i0+4 .. i0+7 of the lane's unit in stripe j (SCAN_SUMMARY: pa.x, pb.w only)
+    int4 xa[NQ], xb[NQ];            // ... their event indices (SCAN_VALIDATE)
+    uint2 fl[NQ];                   // ... their flag bytes (not SCAN_SUMMARY)
+    __device__ __forceinline__ void load(const DevTable &T, int64_t c0, int crows, int lane) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int i0 = (j * 64 + lane) * 8;
+            pa[j] = pb[j] = xa[j] = xb[j] = make_int4(0, 0, 0, 0);
+            fl[j] = make_uint2(0x02020202u, 0x02020202u);       // (rows past the table: MC_F_MODEL_N, never looked at anyway)
+            if (i0 < crows) {                       // (arrays are padded: whole units stay in bounds)
+                if (MODE == SCAN_SUMMARY) {
+                    const int2 pp = T.unit_pp[(c0 + i0) >> 3];
+                    pa[j].x = pp.x;
+                    pb[j].w = pp.y;
+                } else {
+                    pa[j] = *reinterpret_cast<const int4 *>(T.pos + c0 + i0);
+                    pb[j] = *reinterpret_cast<const int4 *>(T.pos + c0 + i0 + 4);
+                    fl[j] = *reinterpret_cast<const uint2 *>(T.flags + c0 + i0);
+                    if (MODE == SCAN_VALIDATE) {
+                        xa[j] = *reinterpret_cast<const int4 *>(T.idx + c0 + i0);
+                        xb[j] = *reinterpret_cast<const int4 *>(T.idx + c0 + i0 + 4);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier.  The wave takes its tile in chunks of
+// CHUNK rows and keeps the memory system busy throughout: the columns of the next chunk are requested as soon as the registers
+// of the current one are free, and travel while the current chunk's candidates are examined.
 //
-// The columns go from HBM into REGISTERS -- every lane holds eight consecutive rows (a unit) of each 512-row stripe, all loads of
-// the tile are issued before anything is used.  On a table's first pass (SCAN_VALIDATE) these are the positions and the event
-// indices, 8 B/row, and every row is compared with the row before it -- its neighbour in the lane, the previous lane's last row
-// (one shuffle), the row before the tile -- which gives the validation flags of the tile's name blocks: a tile inside one block
-// (eleven in twelve) ends with wave-wide flags that are held against what the block was classified on, and nothing is written
-// unless they say more.  The comparisons run while the mask words below are on their way.
+// The columns of a chunk go from HBM into REGISTERS -- every lane holds eight consecutive rows (a unit) of each 512-row stripe.
+// On a table's first pass (SCAN_VALIDATE) these are the positions, the event indices and the flag bytes, 9 B/row, and every row
+// is compared with the row before it -- its neighbour in the lane, the previous lane's last row (one shuffle), the last row of
+// the chunk before -- which gives the validation flags of the chunk's name blocks: a chunk inside one block (the usual case)
+// ends with wave-wide flags that are held against what the block was classified on, and nothing is written unless they say
+// more.  The comparisons run while the mask words below are on their way.
 //
 // 95 % of the units never leave the registers: one 32-bit extract from the strand bitmask (two words per unit, fetched
 // straight from L2 -- the masks of a bacterial genome are 0.6 MB per strand) tells whether any of the unit's k-mers holds an
-// 'M' at all.  Only the units that pass are written to an LDS list, with the two rows behind them and their mask words; one
-// lane per listed unit then fetches the unit's flag bytes (and, where the filter read unit summaries instead of the column,
-// its rows), and when all stripes are done -- the columns' registers are free again -- one lane per row of the listed units
-// decides whether the row is the LAST row of a window: its k-mer holds an 'M' (first one: the site m, :176) and the next
-// unfiltered row of the read lies beyond m, or there is none and another read (or the next shard) follows (:179).  Every
-// closed window leaves a 32-byte payload (last row, site, closing row); which of the rows before it belong to which slot is
-// worked out by k1_emit, eight lanes per window.  Whatever needs more than the list holds (a closing row beyond the tile or
-// behind two 'N' rows, mask words beyond the unit's two) is an out-of-line call that reads global memory.  Waves are short
-// and light, many are resident per SIMD, their loads overlap: the kernel streams.
-// CG: capacity of the candidate list.  The sparse instance (a GATC-like motif: one unit in 20 is listed) bails out to
-// scan_tile_slowly if a tile overflows it; the dense instance holds every unit of the tile.
+// 'M' at all.  Only the units that pass are written to an LDS list, with the two rows behind them, their flag bytes and their
+// mask words (where the filter read unit summaries instead of the columns, SCAN_SUMMARY, one lane per listed unit fetches its
+// rows and flag bytes now); then -- the columns' registers are free again, the next chunk's columns are on their way -- one lane
+// per row of the listed units decides whether the row is the LAST row of a window: its k-mer holds an 'M' (first one: the
+// site m, :176) and the next unfiltered row of the read lies beyond m, or there is none and another read (or the next shard)
+// follows (:179).  Every closed window leaves a 32-byte payload (last row, site, closing row); which of the rows before it
+// belong to which slot is worked out by k1_emit, eight lanes per window.  Whatever needs more than the list holds (a closing
+// row beyond the chunk or behind two 'N' rows, mask words beyond the unit's two) is an out-of-line call that reads global
+// memory.  The descriptors of the chunk's first two name blocks sit in SGPRs; a third block (reads of a few hundred rows) is
+// examined row by row from global memory.
+// CG: capacity of the candidate list (per chunk).  The sparse instance (a GATC-like motif: one unit in 20 is listed) bails out
+// to scan_blocks_slowly if a chunk overflows it; the dense instance holds every unit of a chunk.
 #ifdef MC_SCAN_WPE                  // (variant builds, tools/variants.sh)
 #define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MC_SCAN_WPE, MC_SCAN_WPE)))
 #else
@@ -853,293 +919,293 @@ constexpr int SCAN_SUMMARY = 2;     // a validated table that has unit summaries
 #endif
 template <int CG, int MODE>
 __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
-    static_assert(CG <= 64 || MODE != SCAN_SUMMARY, "one lane per listed unit fetches its rows: at most one round of 64");
     __shared__ __attribute__((aligned(16))) CandUnit s_cand[CG];
     __shared__ long long s_chunk[NCHUNK];           // first payload slot of the tile's 64-record chunks
-    __shared__ uint16_t s_seg_end[NBR];             // candidate units listed up to and including this name block
     const DevTable &T = A.T;
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int k = A.k;
     const int64_t t0 = tile * TILE;
     const int nrows = (int)(min(t0 + (int64_t)TILE, T.n_rows) - t0);
-
-    // ---- the columns: every load of the tile goes out before anything is used ----
-    // (SCAN_SUMMARY: only the unit summaries -- first and last position of the lane's unit in stripe j)
-    int4 pa[NQ], pb[NQ];                            // rows i0 .. i0+3, i0+4 .. i0+7 of the lane's unit in stripe j
-    int4 xa[NQ], xb[NQ];                            // ... their event indices (SCAN_VALIDATE)
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int i0 = (j * 64 + lane) * 8;
-        pa[j] = pb[j] = xa[j] = xb[j] = make_int4(0, 0, 0, 0);
-        if (i0 < nrows) {                           // (arrays are padded: whole units stay in bounds)
-            if (MODE == SCAN_SUMMARY) {
-                const int2 pp = T.unit_pp[(t0 + i0) >> 3];
-                pa[j].x = pp.x;
-                pb[j].w = pp.y;
-            } else {
-                pa[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0);
-                pb[j] = *reinterpret_cast<const int4 *>(T.pos + t0 + i0 + 4);
-                if (MODE == SCAN_VALIDATE) {
-                    xa[j] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0);
-                    xb[j] = *reinterpret_cast<const int4 *>(T.idx + t0 + i0 + 4);
-                }
-            }
-        }
-    }
-    int before_p = 0, before_x = 0;                 // the row before the tile (the first row's predecessor, if it is in its block)
-    if (MODE == SCAN_VALIDATE && t0 > 0) { before_p = T.pos[t0 - 1]; before_x = T.idx[t0 - 1]; }
-
-    // ---- the name blocks that overlap the tile: nb0 .. nb0 + nnb - 1 ----
-    const int nb0 = T.tile_nb[tile];
-    int nnb = 1;
-    while (nb0 + nnb < T.n_nb && A.desc[nb0 + nnb - 1].row_end < t0 + nrows) ++nnb;
-    if (nnb > NBR) {
-        if (MODE == SCAN_VALIDATE) validate_tile_slowly(A, nb0, t0, nrows, lane);
-        scan_tile_slowly(A, nb0, nnb, tile, s_chunk, lane);
-        return;
-    }
     const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t kmask = (1u << k) - 1u;
 
-    // ---- the mask words of the units: a unit that lies wholly inside one of the tile's first two blocks (from the block's first
-    // tested row on) spans positions [p0, p7]; its rows' k-mers cover mask bits [p0, p7 + k) of that block's strand.  If that is
-    // at most 32 bits, the two words from p0 >> 5 decide whether the unit can hold a site row; units cut by a block's ends,
-    // units of a third block, spans that do not fit are listed unconditionally ----
-    uint32_t mlo[NQ], mhi[NQ];
-    bool decidable[NQ];
-    {
-        const NbDesc *da = A.desc + nb0, *db = A.desc + nb0 + (nnb > 1 ? 1 : 0);
-        const bool rega = da->mode == MODE_REGULAR, regb = nnb > 1 && db->mode == MODE_REGULAR;
-        const int loa = (int)(max(max(da->row_begin, da->first()), t0) - t0), hia = (int)(min(da->row_end, t0 + (int64_t)nrows) - t0);
-        const int lob = (int)(max(max(db->row_begin, db->first()), t0) - t0), hib = (int)(min(db->row_end, t0 + (int64_t)nrows) - t0);
-        const uint32_t *ga = (da->rev ? A.R.mr : A.R.mf) + da->mask_off, *gb = (db->rev ? A.R.mr : A.R.mf) + db->mask_off;
-        const int nwa = ((da->contig_len + 31) >> 5) + 2, nwb = ((db->contig_len + 31) >> 5) + 2;     // (two zero words behind every contig's mask)
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int i0 = (j * 64 + lane) * 8;
-            const int p0 = pa[j].x, p7 = pb[j].w;
-            const bool ina = rega && i0 >= loa && i0 + 8 <= hia, inb = regb && i0 >= lob && i0 + 8 <= hib;
-            const uint32_t span = (uint32_t)p7 - (uint32_t)p0 + (uint32_t)k;
-            const int w = p0 >> 5;
-            decidable[j] = (ina || inb) && span - 1u < 32u && p0 >= 0 && w + 1 < (ina ? nwa : nwb);
-            mlo[j] = mhi[j] = 0u;
-            if (decidable[j]) {
-                const uint32_t *g = (ina ? ga : gb) + w;
-                mlo[j] = g[0];
-                mhi[j] = g[1];
-            }
-        }
-    }
-
-    // ---- first pass over the table: every row against the row before it (while the mask words are on their way) ----
-    if (MODE == SCAN_VALIDATE) {
-        for (int bi = 0; bi < nnb; ++bi) {
-            const NbDesc *dp = A.desc + nb0 + bi;
-            const int64_t rb = dp->row_begin;
-            const int vlo = (int)(max(rb, t0) - t0), vhi = (int)(min(dp->row_end, t0 + (int64_t)nrows) - t0);
-            const int pred_from = rb < t0 ? 0 : vlo + 1;      // rows from here on have their predecessor in the block
-            bool pos_dec = false, x_inc = false, x_dec = false, x_eq = false, pos0 = false;
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                if (j * 512 + 512 <= vlo || j * 512 >= vhi) continue;      // (wave-uniform)
-                const int i0 = (j * 64 + lane) * 8;
-                // the row before the unit: the previous lane's last row (lane 0: the previous stripe's, or the row before the tile)
-                int qp = __shfl_up(pb[j].w, 1), qx = __shfl_up(xb[j].w, 1);
-                {
-                    const int sp = j > 0 ? __shfl(pb[(j + NQ - 1) % NQ].w, 63) : before_p;
-                    const int sx = j > 0 ? __shfl(xb[(j + NQ - 1) % NQ].w, 63) : before_x;
-                    if (lane == 0) { qp = sp; qx = sx; }
-                }
-                const int ps[8] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w, pb[j].x, pb[j].y, pb[j].z, pb[j].w};
-                const int xs[8] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w, xb[j].x, xb[j].y, xb[j].z, xb[j].w};
-                if (i0 >= pred_from && i0 + 8 <= vhi) {     // the unit and the row before it inside the block: the usual case
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int pp = e ? ps[e - 1] : qp, px = e ? xs[e - 1] : qx;
-                        pos_dec |= ps[e] < pp;
-                        x_inc |= xs[e] > px;
-                        x_dec |= xs[e] < px;
-                        x_eq |= xs[e] == px;
-                    }
-                    const uint32_t m01 = min((uint32_t)ps[0], (uint32_t)ps[1]), m23 = min((uint32_t)ps[2], (uint32_t)ps[3]);
-                    const uint32_t m45 = min((uint32_t)ps[4], (uint32_t)ps[5]), m67 = min((uint32_t)ps[6], (uint32_t)ps[7]);
-                    pos0 |= min(min(m01, m23), min(m45, m67)) == 0u;
-                } else if (i0 + 8 > vlo && i0 < vhi) {      // a unit cut by the block's ends (or the block's very first rows)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int i = i0 + e;
-                        const bool in = i >= vlo && i < vhi, pred = in && i >= pred_from;
-                        const int pp = e ? ps[e - 1] : qp, px = e ? xs[e - 1] : qx;
-                        pos_dec |= pred && ps[e] < pp;
-                        x_inc |= pred && xs[e] > px;
-                        x_dec |= pred && xs[e] < px;
-                        x_eq |= pred && xs[e] == px;
-                        pos0 |= in && ps[e] == 0;
-                    }
-                }
-            }
-            const uint32_t seen = (__ballot(pos_dec) ? V_POS_DEC : 0u) | (__ballot(x_inc) ? V_IDX_INC : 0u) | (__ballot(x_dec) ? V_IDX_DEC : 0u) |
-                                  (__ballot(x_eq) ? V_IDX_EQ : 0u) | (__ballot(pos0) ? V_POS0 : 0u);
-            if (lane == 0) note_validation(A, nb0 + bi, seen);
-        }
-    }
-
-    // ---- all lanes, block by block and stripe by stripe: which units of eight rows can hold a site row at all? ----
-    int ncand = 0;
-    bool overflow = false;
-    for (int bi = 0; bi < nnb; ++bi) {
-        const NbDesc *dp = A.desc + nb0 + bi;
-        if (dp->mode == MODE_REGULAR) {
-            const int64_t lb_abs = max(dp->row_begin, dp->first());
-            const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(dp->row_end, t0 + (int64_t)nrows) - t0);
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                if (j * 512 + 512 <= lo || j * 512 >= hi) continue;      // (wave-uniform)
-                const int i0 = (j * 64 + lane) * 8;
-                const int p0 = pa[j].x, p7 = pb[j].w;
-                const bool touches = i0 + 8 > lo && i0 < hi;             // (a decidable unit touches its own block only)
-                const int span = p7 - p0 + k;
-                const uint32_t bits = bits_from(mlo[j], mhi[j], p0 & 31) & (0xFFFFFFFFu >> ((32 - span) & 31));
-                const bool cand = touches && (!decidable[j] || bits != 0u);
-                const unsigned long long bal = __ballot(cand);
-                if (!bal) continue;
-                if (ncand + __popcll(bal) > CG) { overflow = true; continue; }
-                // the two rows behind the unit: the next lane's first two rows (lane 63: the next stripe's)
-                int nx = 0, ny = 0;
-                if (MODE != SCAN_SUMMARY) {
-                    nx = __shfl_down(pa[j].x, 1);
-                    ny = __shfl_down(pa[j].y, 1);
-                    if (j + 1 < NQ) {
-                        const int sx = __shfl(pa[(j + 1) % NQ].x, 0), sy = __shfl(pa[(j + 1) % NQ].y, 0);
-                        if (lane == 63) { nx = sx; ny = sy; }
-                    }
-                }
-                if (cand) {
-                    CandUnit *g = s_cand + (ncand + __popcll(bal & below));
-                    int4 *gp = reinterpret_cast<int4 *>(g);
-                    if (MODE != SCAN_SUMMARY) {     // (the rows are in the registers; their flag bytes come later)
-                        gp[0] = pa[j];
-                        gp[1] = pb[j];
-                        reinterpret_cast<int2 *>(g)[4] = make_int2(nx, ny);
-                    }
-                    // the unit's first row | its two mask words and the word they start at (-1: none, every lookup out of line)
-                    gp[3] = make_int4((int)((uint32_t)i0 << 16), (int)mlo[j], (int)mhi[j], decidable[j] ? (p0 >> 5) : -1);
-                }
-                ncand += __popcll(bal);
-            }
-        }
-        if (lane == 0) s_seg_end[bi] = (uint16_t)ncand;
-    }
-    if (overflow) { scan_tile_slowly(A, nb0, nnb, tile, s_chunk, lane); return; }    // (nothing has been written yet)
-    __syncthreads();                                // (one wave: orders the list's words between the lanes)
-    for (int base = 0; base < ncand; base += 64) {
-        // the flag bytes of the listed units and of the two rows behind each (the columns are padded beyond the table's last
-        // row); SCAN_SUMMARY: their positions as well
-        const int gi = base + lane;
-        if (gi < ncand) {
-            CandUnit *g = s_cand + gi;
-            const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
-            const uint8_t *fr = T.flags + t0 + i0;
-            const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
-            const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
-            if (MODE == SCAN_SUMMARY) {
-                const int32_t *pr = T.pos + t0 + i0;
-                const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
-                const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
-                int4 *gp = reinterpret_cast<int4 *>(g);
-                gp[0] = a;
-                gp[1] = b4;
-                reinterpret_cast<int2 *>(g)[4] = nx;
-            }
-            reinterpret_cast<uint2 *>(g)[5] = f8;
-            reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
-        }
-    }
-    __syncthreads();
-
-    // ---- one lane per row of the listed units, block by block: is this row the last row of a window? ----
+    ChunkCols<MODE> C;
+    C.load(T, t0, min(nrows, CHUNK), lane);
+    int before_p = 0, before_x = 0;                 // the row before the chunk (its first row's predecessor, if that is in its block)
+    if (MODE == SCAN_VALIDATE && t0 > 0) { before_p = T.pos[t0 - 1]; before_x = T.idx[t0 - 1]; }
+    int nb0 = __builtin_amdgcn_readfirstlane(T.tile_nb[tile]);      // first name block that overlaps the chunk
     ScanGlobals G;
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
-    const uint32_t kmask = (1u << k) - 1u;
-    int seg_begin = 0;
-    for (int bi = 0; bi < nnb; ++bi) {
-        const int nb_abs = nb0 + bi;
-        const int seg_end = s_seg_end[bi];
-        const int first_g = seg_begin;
-        seg_begin = seg_end;
-        const NbDesc d = A.desc[nb_abs];
-        if (d.mode != MODE_REGULAR) continue;
-        const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-        // first 'M' in meth_ref[p:p+k] (:176,:270) from the unit's two mask words; ok = false when they do not hold all k bits
-        // (the row then takes the out-of-line path)
-        auto site_off = [&](const CandUnit *g, int p, bool &ok) -> int {
-            const int wb = (int)g->mw[2], wi = (p >> 5) - wb, sh = p & 31;
-            const uint32_t two = bits_from(g->mw[0], g->mw[1], sh), one = g->mw[1] >> sh;
-            ok = wb >= 0 && (wi == 0 || (wi == 1 && sh + k <= 32));
-            const uint32_t bits = (wi == 0 ? two : one) & kmask;
-            int o = bits ? (int)__builtin_ctz(bits) : -1;
-            if (p >= d.contig_len) { o = -1; ok = true; }
-            return o;
-        };
-        // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
-        if (d.extra_row() >= t0 && d.extra_row() < t0 + nrows) {
-            const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
-            Payload P;
-            P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
-            P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
-            P.nb = nb_abs;
-            S.put(lane == 0 && xc.row >= 0, P);
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int crows = min(nrows - ch * CHUNK, CHUNK);
+        if (crows <= 0) break;
+        const int64_t c0 = t0 + (int64_t)ch * CHUNK, c1 = c0 + crows;
+        const bool more = ch + 1 < NCH && nrows > (ch + 1) * CHUNK;
+        // ---- the name blocks that overlap the chunk: A = nb0, B = nb0 + 1 (if any), and whether there are more ----
+        while (nb0 + 1 < T.n_nb && desc_row_end_uniform(A.desc, nb0) <= c0) ++nb0;
+        const NbDesc da = desc_uniform(A.desc, nb0);
+        const bool has_b = nb0 + 1 < T.n_nb && da.row_end < c1;
+        const NbDesc db = desc_uniform(A.desc, nb0 + (has_b ? 1 : 0));
+        const bool has_c = has_b && nb0 + 2 < T.n_nb && db.row_end < c1;     // a third block: rows from db.row_end on take the slow path
+        const int nfast = has_b ? 2 : 1;
+
+        // ---- the mask words of the units: a unit that lies wholly inside block A or B (from the block's first tested row on) spans
+        // positions [p0, p7]; its rows' k-mers cover mask bits [p0, p7 + k) of that block's strand.  If that is at most 32 bits,
+        // the two words from p0 >> 5 decide whether the unit can hold a site row; units cut by a block's ends and spans that do
+        // not fit are listed unconditionally ----
+        uint32_t mlo[NQ], mhi[NQ];
+        bool decidable[NQ];
+        {
+            const bool rega = da.mode == MODE_REGULAR, regb = has_b && db.mode == MODE_REGULAR;
+            const int loa = (int)(max(max(da.row_begin, da.first()), c0) - c0), hia = (int)(min(da.row_end, c1) - c0);
+            const int lob = (int)(max(max(db.row_begin, db.first()), c0) - c0), hib = (int)(min(db.row_end, c1) - c0);
+            const uint32_t *ga = (da.rev ? A.R.mr : A.R.mf) + da.mask_off, *gb = (db.rev ? A.R.mr : A.R.mf) + db.mask_off;
+            const int nwa = ((da.contig_len + 31) >> 5) + 2, nwb = ((db.contig_len + 31) >> 5) + 2;     // (two zero words behind every contig's mask)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int i0 = (j * 64 + lane) * 8;
+                const int p0 = C.pa[j].x, p7 = C.pb[j].w;
+                const bool ina = rega && i0 >= loa && i0 + 8 <= hia, inb = regb && i0 >= lob && i0 + 8 <= hib;
+                const uint32_t span = (uint32_t)p7 - (uint32_t)p0 + (uint32_t)k;
+                const int w = p0 >> 5;
+                decidable[j] = (ina || inb) && span - 1u < 32u && p0 >= 0 && w + 1 < (ina ? nwa : nwb);
+                // (every lane loads, the undecidable ones the mask's first words: no branch, so all stripes' loads are in flight
+                // together and are waited for once)
+                const uint32_t *g = (inb ? gb : ga) + (decidable[j] ? w : 0);
+                mlo[j] = g[0];
+                mhi[j] = g[1];
+            }
         }
-        const int64_t lb_abs = max(d.row_begin, d.first());
-        const int lo = (int)(max(lb_abs, t0) - t0), hi = (int)(min(d.row_end, t0 + (int64_t)nrows) - t0);
-        for (int base = first_g * 8; base < seg_end * 8; base += 64) {
-            const int idx = base + lane;
-            const bool have = idx < seg_end * 8;
-            const CandUnit *g = s_cand + (have ? idx >> 3 : first_g);
-            const int e = idx & 7;
-            const int p = g->pos[e], p1 = g->pos[e + 1], p2 = g->pos[e + 2];
-            const uint32_t f = g->fl[e], f1 = g->fl[e + 1], f2 = g->fl[e + 2];
-            const int i = (int)g->i0 + e;
-            bool closed = false, far = false;
-            int m = 0, cp = 0;
-            int64_t cr = 0;
-            uint32_t pf = 0;
-            if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
-                bool ok;
-                const int o = site_off(g, p, ok);
-                if (!ok) far = true;
-                else if (o >= 0) {
-                    m = p + o;
-                    // the next unfiltered row of the read inside the tile: the row behind this one, or the one behind an 'N' row
-                    int c = -1;
-                    if (i + 1 < hi && !(f1 & MC_F_MODEL_N)) { c = i + 1; cp = p1; }
-                    else if (i + 2 < hi && (f1 & MC_F_MODEL_N) && !(f2 & MC_F_MODEL_N)) { c = i + 2; cp = p2; }
-                    if (c >= 0) {
-                        cr = t0 + c;
-                        closed = cp > m;
-                        if (closed && cp <= m + A.skip_thresh + 1) {
-                            bool ok2;
-                            const int o2 = site_off(g, cp, ok2);
-                            if (!ok2) far = true;
-                            else if (o2 > 0) pf |= PF_MULTI;
+
+        // ---- first pass over the table: every row against the row before it (while the mask words are on their way) ----
+        // (per-lane COUNTS of what the pairs of rows say -- a comparison and an add-with-carry each, two vector instructions and
+        // no scalar state; accumulating the lane masks of the comparisons themselves costs this kernel more scalar registers than
+        // it has)
+        if (MODE == SCAN_VALIDATE) {
+            for (int bi = 0; bi < nfast; ++bi) {
+                const int64_t rb = bi ? db.row_begin : da.row_begin, re = bi ? db.row_end : da.row_end;
+                const uint32_t vf_known = bi ? db.vf : da.vf;
+                const int vlo = (int)(max(rb, c0) - c0), vhi = (int)(min(re, c1) - c0);
+                const int pred_from = rb < c0 ? 0 : vlo + 1;      // rows from here on have their predecessor in the block
+                int n_pdec = 0, n_inc = 0, n_dec = 0, n_pairs = 0, n_pos0 = 0;
+                uint32_t f_cut = 0;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    if (j * 512 + 512 <= vlo || j * 512 >= vhi) continue;      // (wave-uniform)
+                    const int i0 = (j * 64 + lane) * 8;
+                    // the row before the unit: the previous lane's last row (lane 0: the previous stripe's, or the row before the chunk)
+                    int qp = __shfl_up(C.pb[j].w, 1), qx = __shfl_up(C.xb[j].w, 1);
+                    {
+                        const int sp = j > 0 ? __shfl(C.pb[(j + NQ - 1) % NQ].w, 63) : before_p;
+                        const int sx = j > 0 ? __shfl(C.xb[(j + NQ - 1) % NQ].w, 63) : before_x;
+                        if (lane == 0) { qp = sp; qx = sx; }
+                    }
+                    const int ps[8] = {C.pa[j].x, C.pa[j].y, C.pa[j].z, C.pa[j].w, C.pb[j].x, C.pb[j].y, C.pb[j].z, C.pb[j].w};
+                    const int xs[8] = {C.xa[j].x, C.xa[j].y, C.xa[j].z, C.xa[j].w, C.xb[j].x, C.xb[j].y, C.xb[j].z, C.xb[j].w};
+                    const bool whole = i0 >= pred_from && i0 + 8 <= vhi;
+                    const bool cut = !whole && i0 + 8 > vlo && i0 < vhi;
+                    if (whole) {                                // the unit and the row before it inside the block: the usual case
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int pp = e ? ps[e - 1] : qp, px = e ? xs[e - 1] : qx;
+                            n_pdec += ps[e] < pp;
+                            n_inc += xs[e] > px;
+                            n_dec += xs[e] < px;
                         }
-                    } else far = true;              // past the tile / the block, or behind two 'N' rows
+                        n_pairs += 8;
+                        const uint32_t m01 = min((uint32_t)ps[0], (uint32_t)ps[1]), m23 = min((uint32_t)ps[2], (uint32_t)ps[3]);
+                        const uint32_t m45 = min((uint32_t)ps[4], (uint32_t)ps[5]), m67 = min((uint32_t)ps[6], (uint32_t)ps[7]);
+                        n_pos0 += min(min(m01, m23), min(m45, m67)) == 0u;
+                    }
+                    // a unit cut by the block's ends (or the block's very first rows): its rows once more, from memory, out of line
+                    // (written here on the registers, the compiler shares the comparisons with the usual case above and keeps
+                    // their lane masks alive for every unit: 130 spilled scalar registers)
+                    if (__ballot(cut) != 0ull && cut) f_cut |= cut_unit_vflags(T.pos, T.idx, c0 + i0, c0 + vlo, c0 + vhi, c0 + pred_from);
                 }
+                const uint32_t seen = (__ballot(n_pdec != 0 || (f_cut & V_POS_DEC)) ? V_POS_DEC : 0u) | (__ballot(n_inc != 0 || (f_cut & V_IDX_INC)) ? V_IDX_INC : 0u) |
+                                      (__ballot(n_dec != 0 || (f_cut & V_IDX_DEC)) ? V_IDX_DEC : 0u) |
+                                      (__ballot(n_inc + n_dec != n_pairs || (f_cut & V_IDX_EQ)) ? V_IDX_EQ : 0u) |
+                                      (__ballot(n_pos0 != 0 || (f_cut & V_POS0)) ? V_POS0 : 0u);
+                if ((seen & ~vf_known) && lane == 0) note_validation(A, nb0 + bi, seen);
             }
-            if (__ballot(far)) {                       // rare
-                if (far) {
-                    const RowRes fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, t0 + i);
-                    closed = fr.closed; m = fr.m; cp = fr.cp; cr = fr.cr; pf = fr.pf;
-                }
+            if (has_c) validate_rows_slowly(A, nb0 + 2, db.row_end, c1, lane);
+            // the next chunk's "row before": this chunk's last row
+            if (more) {
+                before_p = __shfl(C.pb[NQ - 1].w, 63);
+                before_x = __shfl(C.xb[NQ - 1].w, 63);
             }
-            Payload P;
-            P.r = t0 + i; P.close_row = cr; P.m = m; P.close_pos = cp;
-            P.flags = pf | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
-            P.nb = nb_abs;
-            S.put(closed, P);
         }
+
+        // ---- all lanes, block by block and stripe by stripe: which units of eight rows can hold a site row at all? ----
+        int ncand = 0, seg_end_a = 0;
+        bool overflow = false;
+        for (int bi = 0; bi < nfast; ++bi) {
+            const bool reg = (bi ? db.mode : da.mode) == MODE_REGULAR;
+            if (reg) {
+                const int64_t lb_abs = bi ? max(db.row_begin, db.first()) : max(da.row_begin, da.first());
+                const int lo = (int)(max(lb_abs, c0) - c0), hi = (int)(min(bi ? db.row_end : da.row_end, c1) - c0);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    if (j * 512 + 512 <= lo || j * 512 >= hi) continue;      // (wave-uniform)
+                    const int i0 = (j * 64 + lane) * 8;
+                    const int p0 = C.pa[j].x, p7 = C.pb[j].w;
+                    const bool touches = i0 + 8 > lo && i0 < hi;             // (a decidable unit touches its own block only)
+                    const int span = p7 - p0 + k;
+                    const uint32_t bits = bits_from(mlo[j], mhi[j], p0 & 31) & (0xFFFFFFFFu >> ((32 - span) & 31));
+                    const bool cand = touches && (!decidable[j] || bits != 0u);
+                    const unsigned long long bal = __ballot(cand);
+                    if (!bal) continue;
+                    if (ncand + __popcll(bal) > CG) { overflow = true; continue; }
+                    // the two rows behind the unit: the next lane's first two rows (lane 63: the next stripe's)
+                    int nx = 0, ny = 0;
+                    uint32_t nf = 0x0202u;
+                    if (MODE != SCAN_SUMMARY) {
+                        nx = __shfl_down(C.pa[j].x, 1);
+                        ny = __shfl_down(C.pa[j].y, 1);
+                        nf = __shfl_down(C.fl[j].x, 1);
+                        if (j + 1 < NQ) {
+                            const int sx = __shfl(C.pa[(j + 1) % NQ].x, 0), sy = __shfl(C.pa[(j + 1) % NQ].y, 0);
+                            const uint32_t sf = __shfl(C.fl[(j + 1) % NQ].x, 0);
+                            if (lane == 63) { nx = sx; ny = sy; nf = sf; }
+                        }
+                    }
+                    if (cand) {
+                        CandUnit *g = s_cand + (ncand + __popcll(bal & below));
+                        int4 *gp = reinterpret_cast<int4 *>(g);
+                        if (MODE != SCAN_SUMMARY) {
+                            gp[0] = C.pa[j];
+                            gp[1] = C.pb[j];
+                            // pos[8], pos[9] | flag bytes 0..7
+                            gp[2] = make_int4(nx, ny, (int)C.fl[j].x, (int)C.fl[j].y);
+                        }
+                        // flag bytes 8, 9 and the unit's first row | its two mask words and the word they start at (-1: none, every
+                        // lookup out of line)
+                        gp[3] = make_int4((int)((nf & 0xFFFFu) | ((uint32_t)i0 << 16)), (int)mlo[j], (int)mhi[j], decidable[j] ? (p0 >> 5) : -1);
+                    }
+                    ncand += __popcll(bal);
+                }
+            }
+            if (bi == 0) seg_end_a = ncand;
+        }
+        // ---- the columns' registers are free: the next chunk's columns set out ----
+        if (more) C.load(T, c0 + CHUNK, min(nrows - (ch + 1) * CHUNK, CHUNK), lane);
+        if (overflow) {                                 // (nothing of the chunk has been written yet)
+            scan_blocks_slowly(A, nb0, nfast, c0, c1, S, lane);
+        } else {
+            __syncthreads();                            // (one wave: orders the list's words between the lanes)
+            if (MODE == SCAN_SUMMARY) {
+                // the rows of the listed units, the two rows behind each and their flag bytes (the columns are padded beyond the
+                // table's last row)
+                for (int base = 0; base < ncand; base += 64) {
+                    const int gi = base + lane;
+                    if (gi < ncand) {
+                        CandUnit *g = s_cand + gi;
+                        const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
+                        const int32_t *pr = T.pos + c0 + i0;
+                        const uint8_t *fr = T.flags + c0 + i0;
+                        const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
+                        const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
+                        const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
+                        const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
+                        int4 *gp = reinterpret_cast<int4 *>(g);
+                        gp[0] = a;
+                        gp[1] = b4;
+                        gp[2] = make_int4(nx.x, nx.y, (int)f8.x, (int)f8.y);
+                        reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
+                    }
+                }
+                __syncthreads();
+            }
+
+            // ---- one lane per row of the listed units, block by block: is this row the last row of a window? ----
+            for (int bi = 0; bi < nfast; ++bi) {
+                const int nb_abs = nb0 + bi;
+                const int first_g = bi ? seg_end_a : 0, seg_end = bi ? ncand : seg_end_a;
+                const NbDesc d = desc_uniform(A.desc, nb_abs);      // (again: the descriptors need not live in SGPRs through the phases)
+                if (d.mode != MODE_REGULAR) continue;
+                const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+                // first 'M' in meth_ref[p:p+k] (:176,:270) from the unit's two mask words; ok = false when they do not hold all k
+                // bits (the row then takes the out-of-line path)
+                auto site_off = [&](const CandUnit *g, int p, bool &ok) -> int {
+                    const int wb = (int)g->mw[2], wi = (p >> 5) - wb, sh = p & 31;
+                    const uint32_t two = bits_from(g->mw[0], g->mw[1], sh), one = g->mw[1] >> sh;
+                    ok = wb >= 0 && (wi == 0 || (wi == 1 && sh + k <= 32));
+                    const uint32_t bits = (wi == 0 ? two : one) & kmask;
+                    int o = bits ? (int)__builtin_ctz(bits) : -1;
+                    if (p >= d.contig_len) { o = -1; ok = true; }
+                    return o;
+                };
+                // -- the '+' window of a palindromic first site row (R5): one record, first of the block --
+                if (d.extra_row() >= c0 && d.extra_row() < c1) {
+                    const CloseRes xc = far_close(G, nb_abs, d.row_end, d.extra_row());
+                    Payload P;
+                    P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
+                    P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
+                    P.nb = nb_abs;
+                    S.put(lane == 0 && xc.row >= 0, P);
+                }
+                const int64_t lb_abs = max(d.row_begin, d.first());
+                const int lo = (int)(max(lb_abs, c0) - c0), hi = (int)(min(d.row_end, c1) - c0);
+                for (int base = first_g * 8; base < seg_end * 8; base += 64) {
+                    const int idx = base + lane;
+                    const bool have = idx < seg_end * 8;
+                    const CandUnit *g = s_cand + (have ? idx >> 3 : first_g);
+                    const int e = idx & 7;
+                    const int p = g->pos[e], p1 = g->pos[e + 1], p2 = g->pos[e + 2];
+                    const uint32_t f = g->fl[e], f1 = g->fl[e + 1], f2 = g->fl[e + 2];
+                    const int i = (int)g->i0 + e;
+                    bool closed = false, far = false;
+                    int m = 0, cp = 0;
+                    int64_t cr = 0;
+                    uint32_t pf = 0;
+                    if (have && i >= lo && i < hi && !(f & MC_F_MODEL_N)) {
+                        bool ok;
+                        const int o = site_off(g, p, ok);
+                        if (!ok) far = true;
+                        else if (o >= 0) {
+                            m = p + o;
+                            // the next unfiltered row of the read inside the chunk: the row behind this one, or the one behind an 'N' row
+                            int c = -1;
+                            if (i + 1 < hi && !(f1 & MC_F_MODEL_N)) { c = i + 1; cp = p1; }
+                            else if (i + 2 < hi && (f1 & MC_F_MODEL_N) && !(f2 & MC_F_MODEL_N)) { c = i + 2; cp = p2; }
+                            if (c >= 0) {
+                                cr = c0 + c;
+                                closed = cp > m;
+                                if (closed && cp <= m + A.skip_thresh + 1) {
+                                    bool ok2;
+                                    const int o2 = site_off(g, cp, ok2);
+                                    if (!ok2) far = true;
+                                    else if (o2 > 0) pf |= PF_MULTI;
+                                }
+                            } else far = true;              // past the chunk / the block, or behind two 'N' rows
+                        }
+                    }
+                    if (__ballot(far)) {                       // rare
+                        if (far) {
+                            const RowRes fr = far_row(G, gbits, d.contig_len, nb_abs, d.row_end, c0 + i);
+                            closed = fr.closed; m = fr.m; cp = fr.cp; cr = fr.cr; pf = fr.pf;
+                        }
+                    }
+                    Payload P;
+                    P.r = c0 + i; P.close_row = cr; P.m = m; P.close_pos = cp;
+                    P.flags = pf | (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
+                    P.nb = nb_abs;
+                    S.put(closed, P);
+                }
+            }
+        }
+        // ---- a third name block and beyond: row by row ----
+        if (has_c) {
+            int nslow = 1;
+            while (nb0 + 2 + nslow < T.n_nb && T.nb_row_begin[nb0 + 2 + nslow] < c1) ++nslow;
+            scan_blocks_slowly(A, nb0 + 2, nslow, c0, c1, S, lane);
+        }
+        if (more) __syncthreads();                      // (the list is rewritten by the next chunk)
     }
     if (lane == 0) A.tile_cnt[tile] = S.total;
 }
@@ -2076,6 +2142,7 @@ __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 #else
 #define K2_STAMP(i) do { } while (0)
 #endif
+
 
 #define MC_SCALAR_MEM __attribute__((address_space(4)))    // constant address space: uniform loads from it are s_load
 
@@ -3858,7 +3925,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.chunk_shift = dense ? 8 : 6;
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const dim3 grid((unsigned)T.n_tiles);
-    constexpr int CG_DENSE = TILE / 8 + NBR;
+    constexpr int CG_DENSE = CHUNK / 8 + 2;      // (every unit of a chunk; one cut by the boundary of its two blocks is listed twice)
     if (dense) {
         if (plan.scan_mode == SCAN_VALIDATE) hipLaunchKernelGGL((k1_scan<CG_DENSE, SCAN_VALIDATE>), grid, dim3(64), 0, st, A);
         else hipLaunchKernelGGL((k1_scan<CG_DENSE, SCAN_STREAM>), grid, dim3(64), 0, st, A);
