@@ -408,16 +408,27 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
 // first row's.  The pass's scan compares EVERY row with the row before it (k1_scan, validate_units) and marks the pass if a row of
 // a block classified regular says otherwise; whatever the first rows say is true of the block, so it is OR-ed into the
 // table's flags here and the scan adds the rest: after the pass the table's flags are complete.
-__global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
+// W: waves per name block.  The kernel's time is its slowest block -- a read that starts in a long stretch without a site needs
+// round after round of rows, each a dependent trip to memory: with W = 4 a round is 2048 rows (one block in seventy needs a
+// second one; with 512 rows one in three did, and the slowest of 4000 blocks needed eight).  Tables of short reads (more blocks
+// than there are rounds to save) take W = 1, four blocks per workgroup.
+#ifndef MC_K0_WAVES
+#define MC_K0_WAVES 1
+#endif
+template <int W>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, Counters *__restrict__ cnt, int classify,
                               int skip_thresh, unsigned long long pass_no, int hyp) {
+    static_assert(W == 1 || W == 2 || W == 4, "one wave per block, or a workgroup of two or four");
+    __shared__ long long s_f0[4];
+    __shared__ int s_rev[4];
     MC_FRONT_OF_THE_QUEUE;
     if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
         unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
         for (unsigned i = threadIdx.x; i < offsetof(Counters, irregular_pass) / 4; i += blockDim.x) w[i] = 0u;
     }
-    const int b = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
+    const int b = W == 1 ? (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     if (b >= T.n_nb) return;
     NbDesc d = T.nb_tmpl[b];
     const int n_seg = (int)d.vf;
@@ -450,25 +461,42 @@ __global__ __launch_bounds__(256) void k0_first_site(DevTable T, DevRef R, const
                 mf = R.mf + R.word_off[contig]; mr = R.mr + R.word_off[contig];
                 sb = T.seg_begin[seg]; se = T.seg_begin[seg + 1];
             }
-            // The kernel's time is its slowest wave (a read that starts in a long stretch without a site): rounds of 512
-            // rows, two blocks in three need one.  A round is two dependent loads (rows, then their mask words); the rows of
-            // the round after it are requested together with the mask words, so every further round costs ONE.
+            // A round is two dependent loads (rows, then their mask words); one wave per block: the rows of the round after it are
+            // requested together with the mask words, so every further round costs ONE.
             constexpr int FS = 8;
             uint32_t fl[FS], fl_next[FS];
             int ps[FS], ps_next[FS];
-            if (sb < se) first_site_rows<FS>(T, sb, se, lane, fl, ps);
-            for (int64_t base = sb; base < se && f0 < 0; base += 64 * FS) {
-                const bool more = base + 64 * FS < se;
-                f0 = first_site_among<FS>(mf, mr, L, base, k, fl, ps, f0rev,
-                                          [&]() { if (more) first_site_rows<FS>(T, base + 64 * FS, se, lane, fl_next, ps_next); });
+            if (W == 1) {
+                if (sb < se) first_site_rows<FS>(T, sb, se, lane, fl, ps);
+                for (int64_t base = sb; base < se && f0 < 0; base += 64 * FS) {
+                    const bool more = base + 64 * FS < se;
+                    f0 = first_site_among<FS>(mf, mr, L, base, k, fl, ps, f0rev,
+                                              [&]() { if (more) first_site_rows<FS>(T, base + 64 * FS, se, lane, fl_next, ps_next); });
 #pragma unroll
-                for (int u = 0; u < FS; ++u) { fl[u] = fl_next[u]; ps[u] = ps_next[u]; }
+                    for (int u = 0; u < FS; ++u) { fl[u] = fl_next[u]; ps[u] = ps_next[u]; }
+                }
+            } else {
+                for (int64_t base = sb; base < se && f0 < 0; base += 64 * FS * W) {        // (the same rounds for all four waves)
+                    const int64_t mine = base + (int64_t)wave * 64 * FS;
+                    long long f = -1;
+                    int frev = 0;
+                    if (mine < se) {
+                        first_site_rows<FS>(T, mine, se, lane, fl, ps);
+                        f = first_site_among<FS>(mf, mr, L, mine, k, fl, ps, frev, []() {});
+                    }
+                    if (lane == 0) { s_f0[wave] = f; s_rev[wave] = frev; }
+                    __syncthreads();
+#pragma unroll
+                    for (int w = W - 1; w >= 0; --w)
+                        if (s_f0[w] >= 0) { f0 = s_f0[w]; f0rev = s_rev[w]; }      // (the first in row order)
+                    __syncthreads();
+                }
             }
         }
     }
     const bool filtered = q_read < qual_thresh;
     if (filtered) { f0 = -1; f0rev = 0; }
-    if (lane == 0) {
+    if (lane == 0 && wave == 0) {
         d.first_delta = f0 >= 0 ? (int32_t)(f0 - d.row_begin) : -1;
         d.rev = (uint8_t)f0rev;
         d.filtered = filtered ? 1 : 0;
@@ -856,6 +884,11 @@ constexpr int SCAN_VALIDATE = 0;    // a table's first pass: positions, event in
 constexpr int SCAN_STREAM = 1;      // a validated table, positions and flag bytes streamed (5 B/row): one-base motifs, where every unit is listed
 constexpr int SCAN_SUMMARY = 2;     // a validated table that has unit summaries (k_summarize): 1 B/row
 
+#ifndef MC_STREAM_FLAGS
+#define MC_STREAM_FLAGS 1           // (variant builds: 0 = the flag bytes are not streamed, the listed units fetch theirs)
+#endif
+template <int MODE> constexpr bool flags_streamed() { return MODE != SCAN_SUMMARY && MC_STREAM_FLAGS != 0; }
+
 // The columns of one chunk in registers: every lane holds eight consecutive rows (a unit) of each 512-row stripe.
 template <int MODE>
 struct ChunkCols {
@@ -876,7 +909,7 @@ struct ChunkCols {
                 } else {
                     pa[j] = *reinterpret_cast<const int4 *>(T.pos + c0 + i0);
                     pb[j] = *reinterpret_cast<const int4 *>(T.pos + c0 + i0 + 4);
-                    fl[j] = *reinterpret_cast<const uint2 *>(T.flags + c0 + i0);
+                    if (flags_streamed<MODE>()) fl[j] = *reinterpret_cast<const uint2 *>(T.flags + c0 + i0);
                     if (MODE == SCAN_VALIDATE) {
                         xa[j] = *reinterpret_cast<const int4 *>(T.idx + c0 + i0);
                         xb[j] = *reinterpret_cast<const int4 *>(T.idx + c0 + i0 + 4);
@@ -1098,24 +1131,27 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             scan_blocks_slowly(A, nb0, nfast, c0, c1, S, lane);
         } else {
             __syncthreads();                            // (one wave: orders the list's words between the lanes)
-            if (MODE == SCAN_SUMMARY) {
-                // the rows of the listed units, the two rows behind each and their flag bytes (the columns are padded beyond the
-                // table's last row)
+            if (!flags_streamed<MODE>()) {
+                // the flag bytes of the listed units and of the two rows behind each (the columns are padded beyond the table's
+                // last row); SCAN_SUMMARY: their positions as well
                 for (int base = 0; base < ncand; base += 64) {
                     const int gi = base + lane;
                     if (gi < ncand) {
                         CandUnit *g = s_cand + gi;
                         const int i0 = (int)(reinterpret_cast<const uint32_t *>(g)[12] >> 16);
-                        const int32_t *pr = T.pos + c0 + i0;
                         const uint8_t *fr = T.flags + c0 + i0;
-                        const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
-                        const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
                         const uint2 f8 = *reinterpret_cast<const uint2 *>(fr);
                         const uint32_t nf = *reinterpret_cast<const uint16_t *>(fr + 8);
-                        int4 *gp = reinterpret_cast<int4 *>(g);
-                        gp[0] = a;
-                        gp[1] = b4;
-                        gp[2] = make_int4(nx.x, nx.y, (int)f8.x, (int)f8.y);
+                        if (MODE == SCAN_SUMMARY) {
+                            const int32_t *pr = T.pos + c0 + i0;
+                            const int4 a = *reinterpret_cast<const int4 *>(pr), b4 = *reinterpret_cast<const int4 *>(pr + 4);
+                            const int2 nx = *reinterpret_cast<const int2 *>(pr + 8);
+                            int4 *gp = reinterpret_cast<int4 *>(g);
+                            gp[0] = a;
+                            gp[1] = b4;
+                            reinterpret_cast<int2 *>(g)[4] = nx;
+                        }
+                        reinterpret_cast<uint2 *>(g)[5] = f8;
                         reinterpret_cast<uint32_t *>(g)[12] = nf | ((uint32_t)i0 << 16);
                     }
                 }
@@ -3897,10 +3933,15 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
         hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R);
         c->slots[c->cur].tmpl_ref = c->ref_version;
     }
-    const int64_t threads = (int64_t)T.n_nb * 64;
-    hipLaunchKernelGGL(k0_first_site, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, T, c->R,
-                       c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1,
-                       prm->skip_thresh, pass_no, plan.first ? 1 : 0);
+    // (four waves per name block unless the reads are short: see k0_first_site)
+    if (MC_K0_WAVES > 1 && T.n_rows >= (int64_t)T.n_nb * 2048)
+        hipLaunchKernelGGL(k0_first_site<MC_K0_WAVES>, dim3((unsigned)T.n_nb), dim3(64 * MC_K0_WAVES), 0, st, T, c->R,
+                           c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1,
+                           prm->skip_thresh, pass_no, plan.first ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k0_first_site<1>, dim3((unsigned)(((int64_t)T.n_nb * 64 + 255) / 256)), dim3(256), 0, st, T, c->R,
+                           c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1,
+                           prm->skip_thresh, pass_no, plan.first ? 1 : 0);
     if (lookback)
         hipLaunchKernelGGL(k0_classify, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, c->R,
                            K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt, pass_no);
