@@ -199,6 +199,8 @@ def main():
 
     rank, world, local, dist = dist_setup(args.gpus)
     if args.dry_ranks:
+        if os.environ.get('MCALLER_BENCH_FAIL_RANK') == str(rank) and world > 1:      # (tests: a rank that dies)
+            sys.exit(3)
         total = world
         if dist is not None:
             import torch

@@ -254,7 +254,8 @@ int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
  * most four passes are in flight (one being copied out, one computing, two queued).  mc_wait_records hands out the
  * OLDEST pass and returns a view of the context's pinned buffers (valid until four more passes have been enqueued).  A
  * pass that needs more than the fast path (irregular reads, record buffers too small) is re-run synchronously inside
- * mc_wait_records -- results are the same, only slower.  MLP classifier only (the forest runs in mc_extract_features). */
+ * mc_wait_records -- results are the same, only slower.  Either classifier (MLP: k2_mlp, forest: k3_forest) runs on the side
+ * stream behind the pass's emit. */
 int mc_extract_features_async(mc_ctx *ctx, const mc_params *prm);
 int mc_wait_records(mc_ctx *ctx, int64_t *n_records, mc_calls_view *out);
 /* Optional first half of mc_wait_records, for the oldest pass in flight whose copy-out has not been started: waits for
@@ -291,13 +292,22 @@ int64_t mc_site_count(mc_ctx *ctx);                       /* number of marked si
  * table, as in mc_params): make_bed keys such a row on the closing row's contig (R8, :216), which is no site of the
  * numbering -- the caller adds them to the BED as rows of their own. */
 int mc_site_counts(mc_ctx *ctx, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig);
+/* The same over the passes of a streamed file: mc_site_counts_reset zeroes the counts, mc_site_counts_accumulate adds the
+ * records of the pass handed out last (mc_wait_records) -- row_offset: the rows of the shards before it, so that the first-seen
+ * rows stay in file order.  mc_site_counts == reset + accumulate. */
+int mc_site_counts_reset(mc_ctx *ctx);
+int mc_site_counts_accumulate(mc_ctx *ctx, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig);
 int mc_site_counts_add(mc_ctx *ctx, const int64_t *site, const uint8_t *is_meth, const int64_t *first_row, int64_t n);
+int mc_comm_available(void);                              /* 0: librccl.so can be loaded in this process (nothing else is touched) */
 int mc_comm_unique_id(uint8_t *out128);                   /* rank 0: ncclGetUniqueId; ship the bytes to every rank */
 int mc_comm_init(mc_ctx *ctx, int32_t world, int32_t rank, const uint8_t *unique_id128);   /* ncclCommInitRank */
 int mc_comm_destroy(mc_ctx *ctx);
 /* all-reduce (if a communicator with world > 1 is set) + D2H: n_meth[n], n_total[n] int32, first_row[n] int64
  * (INT64_MAX: site not seen); *ms = time of the two collectives (hipEvents). */
 int mc_site_allreduce(mc_ctx *ctx, int32_t *n_meth, int32_t *n_total, int64_t *first_row, float *ms);
+/* This rank's own counts as they stand (D2H only, no collective): what a job adds up on the host when a rank could not
+ * take part in the all-reduce. */
+int mc_site_counts_fetch(mc_ctx *ctx, int32_t *n_meth, int32_t *n_total, int64_t *first_row);
 
 /* ===== the classifier fit behind --train (train_model.py:47,:62-65,:81-100): one-hidden-layer tanh/logistic perceptron, =====
  * Adam, binary log-loss + L2, scikit-learn's MLPClassifier recipe (batches of min(200, n) rows, tol / n_iter_no_change

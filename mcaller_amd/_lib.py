@@ -158,7 +158,11 @@ def lib():
         L.mc_site_count.restype = C.c_int64
         L.mc_site_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_site_counts_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.mc_site_counts_reset.argtypes = [C.c_void_p]
+        L.mc_site_counts_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_comm_unique_id.argtypes = [C.c_void_p]
+        L.mc_comm_available.argtypes = []
+        L.mc_site_counts_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mc_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.mc_comm_destroy.argtypes = [C.c_void_p]
         L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

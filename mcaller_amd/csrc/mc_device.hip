@@ -2379,8 +2379,11 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
                                                 const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                 const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                 const uint8_t *__restrict__ submodel_in, int64_t n,
-                                                double *__restrict__ prob) {
+                                                double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                const unsigned int *__restrict__ overflow) {
     __shared__ double s_x[64][MC_MAX_K + 2];
+    if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
+    if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n) return;
     double *x = s_x[threadIdx.x];
@@ -4089,7 +4092,8 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         if (prm->score && n > 0) {
             if (c->F.left)
                 hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, c->O.feats, k,
-                                   c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob);
+                                   c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob,
+                                   (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
             else
                 launch_k2(c, k2_grid(c, n), c->stream, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
                           (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
@@ -4221,7 +4225,11 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
-    if (b.prm.score)
+    if (b.prm.score && c->F.left)              // (the forest: one lane per record, the count read on the device; a workgroup beyond it ends at once)
+        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((b.cap + 63) / 64)), dim3(64), 0, st, c->F, b.O.feats, b.k, b.O.site_seg, T.seg_read,
+                           c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records,
+                           (const unsigned int *)&b.cnt->overflow);
+    else if (b.prm.score)
         launch_k2(c, k2_grid(c, b.cap), st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr,
                   b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_end, st));
@@ -4247,10 +4255,6 @@ static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
 extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = check_pass(c, prm)) return rc;
-    if (c->F.left && prm->score) {
-        mc_set_error("mc_extract_features_async: the forest classifier runs in mc_extract_features only");
-        return -12;
-    }
     if (c->ab_count >= MC_PASSES_IN_FLIGHT) {
         mc_set_error("mc_extract_features_async: %d passes are in flight; call mc_wait_records first", MC_PASSES_IN_FLIGHT);
         return -12;
@@ -4491,7 +4495,7 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
     if (forest)
         hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, dX, ni - 1,
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                           (const uint32_t *)nullptr, ds, n, dp);
+                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
     else
         launch_k2(c, k2_grid(c, n), c->stream, dX, ni - 1, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
                   (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
@@ -4591,18 +4595,34 @@ static int ensure_site_buffers(mc_ctx *c) {
 
 extern "C" int64_t mc_site_count(mc_ctx *c) { return c->R.n_sites; }
 
-extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig) {
+extern "C" int mc_site_counts_reset(mc_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
     if (!c->R.mf) {
-        mc_set_error("mc_site_counts: no reference set");
+        mc_set_error("mc_site_counts_reset: no reference set");
         return -12;
     }
     if (int rc = ensure_site_buffers(c)) return rc;
+    const int64_t ns = c->R.n_sites;
+    hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mc_site_counts(mc_ctx *c, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig) {
+    if (int rc = mc_site_counts_reset(c)) return rc;
+    return mc_site_counts_accumulate(c, row_offset, tail_contig, n_pending, n_cross_contig);
+}
+
+extern "C" int mc_site_counts_accumulate(mc_ctx *c, int64_t row_offset, int32_t tail_contig, int64_t *n_pending, int64_t *n_cross_contig) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->R.mf || !c->site_cnt || c->site_n != c->R.n_sites) {
+        mc_set_error("mc_site_counts_accumulate: call mc_site_counts_reset first (after the reference has been set)");
+        return -12;
+    }
     const int64_t ns = c->R.n_sites, n = c->last_n;
     unsigned long long *status = nullptr;
     HIP_TRY(hipMalloc((void **)&status, 24));
     HIP_TRY(hipMemsetAsync(status, 0, 24, c->stream));
-    hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
     if (n > 0)
         hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->R, c->O, n,
                            c->last_T.seg_contig ? c->last_T : c->T, (int)tail_contig, row_offset, c->site_cnt,
@@ -4698,6 +4718,8 @@ int rccl_load() {
 
 static_assert(sizeof(ncclUniqueId) == MC_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
+extern "C" int mc_comm_available(void) { return rccl_load(); }
+
 extern "C" int mc_comm_unique_id(uint8_t *out) {
     if (int rc = rccl_load()) return rc;
     ncclUniqueId id;
@@ -4730,6 +4752,22 @@ extern "C" int mc_comm_destroy(mc_ctx *c) {
         (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
     }
     if (c) c->comm = nullptr;
+    return 0;
+}
+
+extern "C" int mc_site_counts_fetch(mc_ctx *c, int32_t *n_meth, int32_t *n_total, int64_t *first_row) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->site_cnt) {
+        mc_set_error("mc_site_counts_fetch: call mc_site_counts first");
+        return -12;
+    }
+    const int64_t ns = c->site_n;
+    if (ns > 0) {
+        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -255,6 +255,19 @@ class Device(object):
         check(lib().mc_comm_unique_id(_ptr(buf)))
         return buf.tobytes()
 
+    @staticmethod
+    def comm_probe():
+        """Can librccl.so be loaded in this process?  Raises if not (nothing else is touched)."""
+        check(lib().mc_comm_available())
+
+    def site_counts_fetch(self):
+        """This rank's own per-site counts as they stand (no collective) -> (n_meth, n_total, first)."""
+        n = lib().mc_site_count(self._ctx)
+        n_meth, n_total = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+        check(lib().mc_site_counts_fetch(self._ctx, _ptr(n_meth), _ptr(n_total), _ptr(first)))
+        return n_meth, n_total, first
+
     def comm_init(self, world, rank, unique_id):
         """ncclCommInitRank on this GPU (RCCL over xGMI); collective over all ranks."""
         uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
@@ -270,6 +283,18 @@ class Device(object):
         their site's are left out too (self.n_cross_contig; make_bed.cross_contig_records lists them)."""
         pending, cross = C.c_int64(0), C.c_int64(0)
         check(lib().mc_site_counts(self._ctx, int(row_offset), int(tail_contig), C.byref(pending), C.byref(cross)))
+        self.n_cross_contig = cross.value
+        return pending.value
+
+    def site_counts_reset(self):
+        """Zero the device-side per-site counts (before the first shard of a streamed file)."""
+        check(lib().mc_site_counts_reset(self._ctx))
+
+    def site_counts_accumulate(self, row_offset=0, tail_contig=-1):
+        """Add the records of the pass handed out last to the per-site counts (a streamed file: shard after shard); returns
+        like site_counts."""
+        pending, cross = C.c_int64(0), C.c_int64(0)
+        check(lib().mc_site_counts_accumulate(self._ctx, int(row_offset), int(tail_contig), C.byref(pending), C.byref(cross)))
         self.n_cross_contig = cross.value
         return pending.value
 

@@ -329,35 +329,64 @@ class _Unstreamable(Exception):
     """The file needs the one-table path (an exit path of the reference, a read name in two shards, ...)."""
 
 
+class StreamResult(object):
+    """What stream_features hands back (the rows themselves went to the sink, shard after shard)."""
+
+    def __init__(self):
+        self.counters, self.messages, self.names = [], [], set()
+        self.n_rows = self.n_bytes = self.n_obs = self.n_multi = self.n_wskips = self.n_skipped = 0
+        self.positions = np.zeros(0, dtype=np.int32)
+        self.signals = self.contexts = None
+
+
 def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base, motif,
-                    positions_list, n_shards=None, device=None):
-    """Predict mode over a whole file, as the reference's batch loop (:140-148) streams it -- here in shards cut at read
-    starts (a window never spans two reads, :179,:242): two threads read the shards' text into pinned memory, the main
-    thread keeps the text of up to six shards on its way to the GPU, where it is parsed (mc_ctx_parse_begin / _end /
-    _finish; a shard the device parser declines, or every shard with MCALLER_HOST_PARSER, goes through the host parser and
-    mc_ctx_upload_table_async), two passes in flight (mc_extract_features_async), and formats the rows of the shards that
-    come back; reading, H2D, parsing, kernels, D2H and formatting overlap.
-    -> (text of all rows, counter lines, messages) or raises _Unstreamable: nothing has been written then."""
+                    positions_list, n_shards=None, device=None, sink=None, byte_range=None, tail_of_last=None, on_head=None,
+                    on_shard=None, mark_all=False, min_shards=2, train=False, pos_label=None):
+    """A whole file (or the byte range of one GPU of a sharded run), as the reference's batch loop (:140-148) streams it -- here
+    in shards cut at read starts (a window never spans two reads, :179,:242): two threads read the shards' text into pinned
+    memory, the main thread keeps the text of up to six shards on its way to the GPU, where it is parsed (mc_ctx_parse_begin /
+    _end / _finish; a shard the device parser declines, or every shard with MCALLER_HOST_PARSER, goes through the host parser
+    and mc_ctx_upload_table_async), two passes in flight (mc_extract_features_async), and formats the rows of the shards that
+    come back; reading, H2D, parsing, kernels, D2H and formatting overlap.  The rows of a shard go to `sink(bytes)` as soon as
+    they exist, in file order (the reference appends every 5000 observations, :230-232): memory is bounded by the shards in
+    flight, whatever the file's size.
+
+    byte_range: (lo, hi), both at first lines of reads, instead of what the reference's loop consumes of (0, endline);
+    tail_of_last(): called when the last shard is about to be enqueued -> name of the contig of the first unfiltered row
+    BEHIND the range (it closes the range's last window, R6/R8), None: end of file; on_head(name | None): called once, as soon as
+    the contig of the range's own first unfiltered row is known (what closes the range in front of it);
+    on_shard(P, rec, fin, tail name, rows of the shards before): every shard's records when they have been handed out (the
+    per-site reduction of a --bed run); mark_all: every contig is marked before the first pass (one site numbering for all the
+    GPUs of a run); train: features only, the reference's train dicts are collected (pos_label) and returned.
+    -> StreamResult, or raises _Unstreamable (an exit path of the reference, a read name in two shards: whoever called decides
+    what becomes of the rows the sink has seen)."""
     import os
     import time
     dev = device if device is not None else get_device()
-    lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
+    if byte_range is None:
+        lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
+    else:
+        lo, hi = byte_range
     if n_shards is None:
         n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or max(1, min(1 << 16, (hi - lo) // STREAM_SHARD_BYTES))
-    if n_shards < 2:
+    if n_shards < min_shards:
         raise _Unstreamable('one shard')
     cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
     pieces = [(cuts[i], cuts[i + 1]) for i in range(n_shards) if cuts[i + 1] > cuts[i]]
-    if len(pieces) < 2:
+    if len(pieces) < min_shards:
         raise _Unstreamable('one shard')
     import contextlib
     import io
     ref = MarkedReference(fasta_input, base, motif, positions_list)
     ref.quiet = True                   # (an exit path sends the file to the one-table path, which prints)
-    _, weights, _, soc = submodel_setup(modelset, base)
-    if weights[0].kind == 'forest':
-        raise _Unstreamable('the forest classifier runs one pass at a time')
-    dev.set_classifier(weights, soc)
+    if not train:
+        _, weights, _, soc = submodel_setup(modelset, base)
+        dev.set_classifier(weights, soc)               # (MLP or forest: either runs behind the emit of a pipelined pass)
+    out = StreamResult()
+    if train:
+        bm = base_models(base, False)                                             # :133
+        out.signals = {key: {} for key in bm.values()}
+        out.contexts = {key: {} for key in bm.values()}
 
     L = _lib.lib()
     L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
@@ -386,11 +415,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     def parse_shard(lo_i, hi_i):
         t_p = time.perf_counter()
         if on_device and hi_i - lo_i < (1 << 32) - 64:         # (mc_ctx_parse_begin: at most 4 GB of text per shard)
-            out = _lib.TextBlock(tsv_input, lo_i, hi_i)
+            res = _lib.TextBlock(tsv_input, lo_i, hi_i)
         else:
-            out = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
+            res = prepare(tsv_input, None, read2qual, lo_i, hi_i, base, motif, positions_list, exact_range=True, ref=ref, quiet=True)
         clock['parse'] += time.perf_counter() - t_p
-        return out
+        return res
 
     def mark_ahead():
         """The first contig of the file is marked while the first shards are read and sent (marking E. coli takes 14 ms; the main
@@ -456,7 +485,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             mark('text ready')
             parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
             mark('parse_begin done')
-            if not mark_thread and (len(parsing) >= 3 or next_piece[0] >= len(pieces)):
+            if not mark_thread and not mark_all and (len(parsing) >= 3 or next_piece[0] >= len(pieces)):
                 import threading
                 mark_thread.append(threading.Thread(target=mark_ahead, daemon=True))
                 mark_thread[0].start()
@@ -465,10 +494,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 next_piece[0] += 1
         return None
 
-    blobs, messages, names_seen = [], [], set()
-    totals = dict(obs=0, multi=0, wskips=0, skipped=0)
     positions = []
-    in_flight = []                  # (P, tail name) of the passes enqueued, oldest first
+    in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
     marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
     def hand_out():
@@ -479,23 +506,42 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             clock['hand_out'] += time.perf_counter() - t_h
 
     def _hand_out():
-        P, tail = in_flight.pop(0)
+        P, tail, rows_before = in_flight.pop(0)
         mark('wait ...')
         rec = dev.wait()
         mark('records here')
-        fin = Finisher(P, k, base, False, modelset=modelset, device=dev, tail_chrom=tail)
+        fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label, device=dev, tail_chrom=tail)
         with contextlib.redirect_stdout(io.StringIO()):        # (its exit paths print; the one-table path will)
             stop = fin.run(rec)
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
-        blobs.append(fin.text())
+        blob = fin.text()
+        if blob:
+            sink(blob)
+        out.n_bytes += len(blob)
         n = rec.n
         too = (rec.info[:n] & _I.I_TOO_MANY) != 0
         positions.append(np.unique(rec.site_pos[:n][~too]))
-        totals['obs'] += fin.num_observations
-        totals['multi'] += len(fin.multi) if fin._n_multi is None else fin._n_multi
-        totals['wskips'] += len(fin.w_skips) if fin._n_wskips is None else fin._n_wskips
-        totals['skipped'] += len(fin.skipped) if fin._n_skipped is None else fin._n_skipped
+        if len(positions) > 64:                                # (bounded: the union so far)
+            positions[:] = [np.unique(np.concatenate(positions))]
+        if train:                                              # (train mode goes record by record: its sets count)
+            out.n_obs += fin.num_observations
+            out.n_multi += len(fin.multi)
+            out.n_wskips += len(fin.w_skips)
+            out.n_skipped += len(fin.skipped)
+            for key, by_label in fin.signals.items():
+                for label, rows in by_label.items():
+                    out.signals[key].setdefault(label, []).extend(rows)
+            for key, by_label in fin.contexts.items():
+                for label, rows in by_label.items():
+                    out.contexts[key].setdefault(label, []).extend(rows)
+        else:
+            out.n_obs += fin.num_observations
+            out.n_multi += len(fin.multi) if fin._n_multi is None else fin._n_multi
+            out.n_wskips += len(fin.w_skips) if fin._n_wskips is None else fin._n_wskips
+            out.n_skipped += len(fin.skipped) if fin._n_skipped is None else fin._n_skipped
+        if on_shard is not None:
+            on_shard(P, rec, fin, tail, rows_before)
 
     def give_back(P_dropped):
         """A table the device parser has put into a slot and that no pass will scan: the slot is free again."""
@@ -522,7 +568,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             dev.set_reference(ref.device_arrays())
             marked[0] = n_marked
         dev.upload_table_async(P.table, P.qual)
-        dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=True)
+        dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=not train)
 
     while next_piece[0] < len(pieces) and len(ahead) < 3:      # (the first shards are read while the masks are made)
         ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
@@ -536,8 +582,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         dev.set_reference_motif(ref.raw_arrays(), *dev_motif)
         masks_on_device = True
     marked[0] = 0 if masks_on_device else -1
+    P = prev = None
     try:
-        prev = None
+        if mark_all:                                           # (one site numbering for every GPU of the run: all contigs, now)
+            for cid in range(len(ref.names)):
+                ref.mark(cid)
+        head_told = False
+        rows_seen, prev_rows_before = 0, 0
         while True:
             t_q = time.perf_counter()
             P = next_shard()
@@ -545,10 +596,12 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             if P is not None:
                 if P.fatal is not None:
                     raise _Unstreamable('an exit path of the reference')
-                if names_seen.intersection(P.table.read_names):
+                if out.names.intersection(P.table.read_names):
                     raise _Unstreamable('a read name in two shards')       # `last_read` would cross the cut (:161)
-                names_seen.update(P.table.read_names)
-                messages.extend(P.messages)
+                out.names.update(P.table.read_names)
+                out.messages.extend(P.messages)
+                rows_before = rows_seen
+                rows_seen += P.table.n_rows
                 if P.table.n_rows == 0:
                     give_back(P)
                     continue
@@ -556,8 +609,15 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 if head is None:
                     give_back(P)
                     continue                                   # no row passes the filters (:167-168): the loop never sees this shard
+                if not head_told and on_head is not None:
+                    on_head(ref.names[head])
+                head_told = True
             if prev is not None:
-                tail_id = head if P is not None else -1
+                if P is not None:
+                    tail_id = head
+                else:                                          # the range's last shard: what follows the range closes its last window
+                    tail_name = tail_of_last() if tail_of_last is not None else None
+                    tail_id = ref.names.index(tail_name) if tail_name is not None else -1
                 while len(in_flight) >= 2:
                     hand_out()
                 t_e = time.perf_counter()
@@ -565,10 +625,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 enqueue(prev, tail_id)
                 mark('enqueued')
                 clock['enqueue'] += time.perf_counter() - t_e
-                in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None))
+                in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None, prev_rows_before))
             prev = P
             if P is None:
                 break
+            prev_rows_before = rows_before
+        if not head_told and on_head is not None:
+            on_head(None)
         while in_flight:
             hand_out()
     except BaseException:
@@ -579,7 +642,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             dev.sync()
             for slot, _, _ in parsing:                         # tables the device parser was filling: their slots go back
                 dev.parse_abandon(slot)
-            for P_left in (locals().get('P'), locals().get('prev')):
+            for P_left in (P, prev):
                 if P_left is not None and getattr(P_left.table, 'device_slot', None) is not None:
                     dev.parse_abandon(P_left.table.device_slot)
                     P_left.table.device_slot = None
@@ -592,13 +655,15 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     finally:
         pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
-    n_pos = len(np.unique(np.concatenate(positions))) if positions else 0
-    counters = ['thread finished processing...:', '%d observations' % totals['obs'], '%d positions' % n_pos,
-                '%d regions with multiple methylated bases' % totals['multi'],
-                '%d observations with skips included' % totals['wskips'],
-                '%d observations with too many skips' % totals['skipped']]
+    out.n_rows = rows_seen
+    out.positions = np.unique(np.concatenate(positions)) if positions else np.zeros(0, dtype=np.int32)
+    out.counters = ['thread finished processing...:', '%d observations' % out.n_obs, '%d positions' % len(out.positions),
+                    '%d regions with multiple methylated bases' % out.n_multi,
+                    '%d observations with skips included' % out.n_wskips,
+                    '%d observations with too many skips' % out.n_skipped]
+    out.ref = ref
     stream_features.last_clock = clock
-    return b''.join(blobs), counters, messages
+    return out
 
 
 def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, classifier,
@@ -615,18 +680,24 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
     if not train:
         modelset = load_model_file(modelfile)                                     # :123-130
 
-    if not train and startline == 0 and endline is not None and os.environ.get('MCALLER_NO_STREAM') is None:
-        # a whole file in predict mode: streamed through the GPU in shards; whatever the shards cannot reproduce
-        # (the reference's exit paths, a read name that comes back later) takes the one-table path below from scratch
+    if startline == 0 and endline is not None and os.environ.get('MCALLER_NO_STREAM') is None:
+        # a whole file: streamed through the GPU in shards, every shard's rows appended as they come back (:230-232); whatever
+        # the shards cannot reproduce (the reference's exit paths, a read name that comes back later) takes the one-table path
+        # below from scratch -- the rows appended so far are taken back first, nothing is written or printed twice
+        size_before = os.path.getsize(tsv_output) if os.path.exists(tsv_output) else None
         try:
-            text, counters, messages = stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh,
-                                                       modelset, endline, base, motif, positions_list)
+            with open(tsv_output, 'ab') as out_fh:
+                res = stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base,
+                                      motif, positions_list, sink=out_fh.write, train=train, pos_label=pos_label)
         except _Unstreamable:
-            pass
+            if size_before is None:
+                os.remove(tsv_output)
+            else:
+                os.truncate(tsv_output, size_before)
         else:
-            for line in messages:
+            for line in res.messages:
                 print(line)
-            write_text(text, tsv_output)                                          # :293
+            counters = res.counters
             if timing:
                 ck = getattr(stream_features, 'last_clock', {})
                 print('[mcaller_amd timing] streamed in %s shards (%s parsed on the device): total %.3f s | reader / parser threads '
@@ -638,7 +709,7 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
                     print('[mcaller_amd timing] %8.2f ms %s' % (t_ev * 1e3, what), file=sys.stderr)
             for line in counters:                                                 # :295-301
                 print(line)
-            return None
+            return (res.signals, res.contexts) if train else None
 
     P = prepare(tsv_input, fasta_input, read2qual, startline, endline, base, motif, positions_list)
     t_prep = time.perf_counter()

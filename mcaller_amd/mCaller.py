@@ -82,7 +82,7 @@ class Run(object):
                 self.bed = dict(self.bed, path=self.output.split('.')[0] + '.methylation.summary.bed')   # make_bed.py:190
             self.sharded = extract_features_sharded(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh,
                                                     self.qual_thresh, self.modelfile, self.base, self.motif, self.positions,
-                                                    self.n_gpus, bed=self.bed)
+                                                    self.n_gpus, bed=self.bed, fastq=getattr(self, 'fastq', None))
             if self.sharded:
                 return None
         labels = pos2label(self.positions) if self.train else None
@@ -223,7 +223,7 @@ def main(argv=None):
         motif=args.motif, base=args.motif if (args.motif and len(args.motif) == 1) else args.base, k=args.num_variables,
         threads=args.threads, train=args.train, training_tsv=args.training_tsv or None, modelfile=modelfile,
         skip_thresh=args.skip_thresh, qual_thresh=args.qual_thresh, classifier=args.classifier,
-        plot_training=args.plot_training, n_gpus=max(1, n_gpus), bed=bed).go()
+        plot_training=args.plot_training, n_gpus=max(1, n_gpus), bed=bed, fastq=args.fastq).go()
 
 
 if __name__ == '__main__':

@@ -274,21 +274,6 @@ def add_pending_site_counts(dev, rec, table, index, row_offset=0, prob=None, ski
     return int(sel.sum())
 
 
-def allreduce_site_counts(n_meth, n_total, first, dist=None, backend_hint=None):
-    """Sum / min over ranks through torch.distributed: nccl (= RCCL over xGMI, GPU tensors) or gloo (CPU tensors).
-    Messages: 2 x 4 B + 8 B per site (~0.6 MB for E. coli GATC): latency-bound, no custom collective needed."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return n_meth, n_total, first
-    import torch
-    dev = 'cuda' if (backend_hint or dist.get_backend()) == 'nccl' else 'cpu'
-    packed = torch.from_numpy(np.stack([n_meth, n_total])).to(dev)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-    fmin = torch.from_numpy(first.copy()).to(dev)
-    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
-    packed = packed.cpu().numpy()
-    return packed[0], packed[1], fmin.cpu().numpy()
-
-
 def write_bed_from_counts(aggfi, n_meth, n_total, first, index, contig_names, meth_strings, k, depth_thresh, mod_thresh,
                           control=False, extras=()):
     """BED rows in first-occurrence order (make_bed.py:134,154-159) from reduced counts; `extras`: the rows of

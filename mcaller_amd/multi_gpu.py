@@ -1,23 +1,33 @@
 """One eventalign file on several GPUs of a node: reads shard embarrassingly.
 
 The byte range the reference's loop consumes (extract_contexts.py:141-148) is cut at the first lines of reads into one
-piece per GPU (`mc_eventalign_read_cuts_range`); one worker process per GPU parses its piece, runs the HIP path on it and
-writes its rows; the parent concatenates the pieces in file order, which is the reference's `-t 1` order
-(extract_contexts.py:179,242: a window never spans two reads).  Two things cross a cut and are exchanged through the parent
-before the kernels run: the first unfiltered row after a piece closes that piece's last window (R6) and supplies its `chrom`
-column (R8) -> `tail`; and `last_read`, which only matters when a read name occurs in two pieces -> then the file is not
-cut at all (the caller falls back to one GPU).  No collective is needed for the `.diffs` file; the per-site reduction
-feeding make_bed is the one exchange step (mc_site_allreduce, RCCL).
+piece per GPU (`mc_eventalign_read_cuts_range`); one worker process per GPU STREAMS its piece through its GPU exactly as the
+one-GPU path streams a whole file (`extract_contexts.stream_features`: the text read into pinned memory, parsed on the device,
+two passes in flight, every shard's rows appended to the worker's part file as they come back); the parent concatenates the
+parts in file order, which is the reference's `-t 1` order (extract_contexts.py:179,242: a window never spans two reads).
+Two things cross a cut: the first unfiltered row after a piece closes that piece's last window (R6) and supplies its `chrom`
+column (R8) -> `tail`, which a worker reports as soon as its first shard has been parsed and needs only when it enqueues its
+last; and `last_read`, which only matters when a read name occurs in two pieces -> the parent compares the pieces' names when
+the workers are done, and such a file is not cut at all (the caller falls back to one GPU).  No collective is needed for the
+`.diffs` file; the per-site reduction feeding make_bed is the one exchange step (mc_site_allreduce, RCCL).
 
-The protocol between the parent and its workers has three rounds, and every round is decided by the parent for ALL workers
-at once -- a worker never enters a collective (ncclCommInitRank, ncclAllReduce) that another worker may not reach:
+The protocol between the parent and its workers: every step that all workers take together is decided by the parent for ALL
+of them at once -- a worker never enters a collective (ncclCommInitRank, ncclAllReduce) that another worker may not reach.
 
-  1. worker -> parent: read names, head contig, rows, `fatal`            parent -> worker: go(tail, row offset) | abort
-  2. worker -> parent: rows written, or the reference's exit path        parent -> worker: reduce('rccl' | 'host') | abort
-  3. worker -> parent: per-site counts (rank 0 holds the all-reduced ones)
+  1. worker -> parent: the contig of its first unfiltered row ("head"), as soon as it is known
+     parent -> worker: go(tail) -- the head of the next piece that has one -- or abort
+  2. worker -> parent: done (counters, read names, rows) or the reference's exit path (`unstreamable`)
+     parent: a read name in two pieces, an exit path -> abort (the caller runs the one-GPU path)
+  with --bed, everything rank-local (the device-side counts, shard after shard) has happened inside step 2; then
+  3. parent -> worker: probe            worker -> parent: can RCCL be loaded here?  (rank 0: the unique id)
+  4. parent -> worker: init(uid) | host worker -> parent: communicator up / not
+  5. parent -> worker: rccl | host      worker -> parent: its own counts, and (rccl) the all-reduced ones
+     the parent uses rank 0's all-reduced counts only if EVERY worker reports the collective done; else it sums the workers'
+     own counts on the host.
 
-Every wait of the parent has a deadline (MCALLER_WORKER_TIMEOUT seconds, default 600); a worker that misses it, dies or
-reports an error makes the parent terminate all workers and return False: the caller runs the one-GPU path.
+Every wait of the parent has a deadline (MCALLER_WORKER_TIMEOUT seconds, default 600; the communicator steps 120); a worker
+that misses it, dies or reports an error makes the parent terminate all workers and return False: the caller runs the one-GPU
+path.
 
 Workers are spawned (never forked: the parent must not hold a HIP context), one per device in MCALLER_SHARD_DEVICES
 (default 0..n-1).
@@ -30,6 +40,8 @@ import time
 
 import numpy as np
 
+ROW_STRIDE = 1 << 40          # first-seen rows of the per-site reduction: piece number * ROW_STRIDE + row inside the piece
+
 
 def _devices(n_gpus):
     env = os.environ.get('MCALLER_SHARD_DEVICES', '')
@@ -41,6 +53,10 @@ def _devices(n_gpus):
     return list(range(n_gpus))
 
 
+class _Abort(Exception):
+    """The parent told the worker to stop."""
+
+
 def _worker(conn, device, job):
     import contextlib
     import io
@@ -48,99 +64,126 @@ def _worker(conn, device, job):
     try:
         from . import _lib
         if job['world'] > 1:
-            _lib.lib().mc_bind_to_device_numa_node(int(device))     # parser threads and pinned buffers next to this worker's GPU
+            _lib.lib().mc_bind_to_device_numa_node(int(device))     # reader threads and pinned buffers next to this worker's GPU
         from . import extract_contexts as ec
+        from . import make_bed
+        from .device import get_device
         from .model_io import load_model_file
-        # ---- round 1: parse, report what crosses the cuts ----
-        buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            P = ec.prepare(job['tsv'], job['fasta'], job['read2qual'], job['lo'], job['hi'], job['base'], job['motif'],
-                           job['positions_list'], exact_range=True)
-        t = P.table
-        if job['bed']:                       # the site numbering of the reduction must be the same on every worker:
-            for cid in range(len(P.ref.names)):   # mark every contig, not only the ones this piece touches
-                P.ref.mark(cid)
-        head = ec.head_contig(P, job['qual_thresh'])              # its first unfiltered row closes the previous piece's last window
-        uid = None
-        if job['bed'] and job['rank'] == 0 and job['world'] > 1:
-            try:
-                from .device import Device
-                uid = Device.comm_unique_id()                      # ncclGetUniqueId: shipped to the other workers by the parent
-            except Exception:
-                uid = None
-        conn.send(dict(names=list(t.read_names), head=None if head is None else P.ref.names[head], n_rows=t.n_rows,
-                       fatal=repr(P.fatal) if P.fatal is not None else None, stdout=buf.getvalue(), uid=uid))
-        go = conn.recv()
-        if go is None:
-            return
-        # ---- round 2: the kernels, the rows ----
-        tail = go['tail']
+        read2qual = job['read2qual']
+        if read2qual is None:                 # (every worker reads the FASTQ itself, natively: a pickled dict per worker costs more)
+            from .read_qual import extract_read_quality
+            read2qual = extract_read_quality(job['fastq'])
         modelset = load_model_file(job['modelfile'])
-        tail_id = P.ref.names.index(tail) if tail is not None else -1
-        rec = ec.compute(P, job['k'], job['skip_thresh'], job['qual_thresh'], modelset, job['base'], False, tail_contig=tail_id)
-        fin = ec.Finisher(P, job['k'], job['base'], False, modelset=modelset, tail_chrom=tail)
+        dev = get_device()
+        rank, k = job['rank'], job['k']
+        state = dict(head_sent=False, go_seen=False, index=None, extras=[])
+
+        def on_head(name):
+            state['head_sent'] = True
+            conn.send(dict(head=name))
+
+        def tail_of_last():
+            go = conn.recv()
+            state['go_seen'] = True
+            if go is None:
+                raise _Abort()
+            return go['tail']
+
+        def on_shard(P, rec, fin, tail, rows_before):
+            """The per-site reduction of one shard's records (make_bed.py:86-96), on the device, added to the worker's counts.
+            Records the host scored itself (NaN on the device) are folded in; records whose row names another contig than their
+            site (R8: closed by a row of the next contig) are not sites of the numbering: they travel as `extras`."""
+            if state['index'] is None:
+                state['index'] = make_bed.SiteIndex(P.ref.meth, len(P.ref.names))
+                dev.site_counts_reset()
+            offset = rank * ROW_STRIDE + rows_before
+            extras = make_bed.cross_contig_records(rec, P.table, P.ref, k, fin.host_scored, tail, row_offset=offset)
+            tail_id = P.ref.names.index(tail) if tail is not None else -1
+            if dev.site_counts_accumulate(row_offset=offset, tail_contig=tail_id):
+                make_bed.add_pending_site_counts(dev, rec, P.table, state['index'], row_offset=offset, prob=fin.host_prob(rec),
+                                                 skip=extras['records'])
+            state['extras'].extend(extras['rows'])
+
+        # ---- steps 1 and 2: the piece, streamed ----
         buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            stop = fin.run(rec)
-        if stop is None:
-            with open(job['part'], 'wb') as out:
-                out.write(fin.text())
-            info = rec.info[:rec.n]
-            too = (info & _lib.I_TOO_MANY) != 0
-            fin._count(rec.n)
-            conn.send(dict(stop=None, stdout=buf.getvalue(), n_obs=fin.num_observations,
-                           positions=np.unique(rec.site_pos[:rec.n][~too]), n_multi=fin._n_multi, n_wskips=fin._n_wskips,
-                           n_skipped=fin._n_skipped))
-        else:
-            conn.send(dict(stop=repr(stop), stdout=buf.getvalue()))
+        try:
+            with open(job['part'], 'wb') as out, contextlib.redirect_stdout(buf):
+                res = ec.stream_features(job['tsv'], job['fasta'], read2qual, k, job['skip_thresh'], job['qual_thresh'], modelset,
+                                         None, job['base'], job['motif'], job['positions_list'], byte_range=(job['lo'], job['hi']),
+                                         sink=out.write, tail_of_last=tail_of_last, on_head=on_head,
+                                         on_shard=on_shard if job['bed'] else None, mark_all=bool(job['bed']), min_shards=1)
+        except _Abort:
+            return
+        except ec._Unstreamable as e:
+            if not state['head_sent']:
+                conn.send(dict(head=None))
+            conn.send(dict(stop='unstreamable: %s' % e, stdout=buf.getvalue()))
+            conn.recv()
+            return
+        conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, names=list(res.names), n_rows=res.n_rows,
+                       n_obs=res.n_obs, positions=res.positions, n_multi=res.n_multi, n_wskips=res.n_wskips,
+                       n_skipped=res.n_skipped))
         if not job['bed']:
             return
+        # ---- steps 3-5: the per-site reduction; every step is the parent's decision for everybody ----
+        if not state['go_seen'] and conn.recv() is None:     # (a piece without a pass never asked for its tail: the answer is still there)
+            return
+        if conn.recv() is None:
+            return
+        if state['index'] is None:                # (a piece without a pass: counts of zero over the same site numbering)
+            from .refmark import MarkedReference
+            ref = MarkedReference(job['fasta'], job['base'], job['motif'], job['positions_list'])
+            ref.quiet = True
+            for cid in range(len(ref.names)):
+                ref.mark(cid)
+            dev.set_reference(ref.device_arrays())
+            dev.site_counts_reset()
+        uid, can = None, True
+        try:
+            from .device import Device
+            uid = Device.comm_unique_id() if rank == 0 else None   # (loads librccl.so; rank 0: ncclGetUniqueId)
+            if rank != 0:
+                Device.comm_probe()
+        except Exception as e:                                      # noqa
+            can, uid = False, None
+        conn.send(dict(can=can, uid=uid))
         how = conn.recv()
         if how is None:
             return
-        # ---- round 3: the per-site reduction; every worker is here, and every worker was told the same `how` ----
-        conn.send(dict(bed=_reduce_sites(job, go, how, P, rec, fin)))
+        up = False
+        if how.get('init'):
+            try:
+                dev.comm_init(job['world'], rank, how['uid'])      # (ncclCommInitRank: every worker was told to, every worker can)
+                up = True
+            except Exception:                                       # noqa
+                up = False
+        conn.send(dict(up=up))
+        how = conn.recv()
+        if how is None:
+            return
+        if not how.get('rccl') and up:
+            dev.comm_destroy()
+            up = False
+        own = dev.site_counts_fetch()         # this worker's own counts first: what the parent adds up if the collective fails anywhere
+        reduced, ms, err = None, 0.0, None
+        if up:
+            try:
+                reduced = dev.site_allreduce()
+                ms = reduced[3]
+            except Exception as e:                                  # noqa
+                err, reduced = str(e), None
+            dev.comm_destroy()
+        lead = rank == 0
+        conn.send(dict(bed=dict(own=own, reduced=reduced[:3] if (reduced is not None and lead) else None,
+                                collective_done=reduced is not None, ms=ms, err=err, extras=state['extras'])))
     except BaseException as e:                                   # noqa
         try:
-            conn.send(dict(error='%s: %s' % (type(e).__name__, e)))
+            import traceback
+            conn.send(dict(error='%s: %s\n%s' % (type(e).__name__, e, traceback.format_exc(limit=6))))
         except Exception:
             pass
     finally:
         conn.close()
-
-
-def _reduce_sites(job, go, how, P, rec, fin):
-    """The per-site reduction of this worker's records (make_bed.py:86-96): on the device, all-reduced over the workers
-    with RCCL (mc_site_allreduce) -- rank 0 then holds the node-wide counts.  Records the host scored itself (NaN on the
-    device) are folded into the device-side counts first.  If the communicator cannot be set up (e.g. several workers
-    sharing one GPU: RCCL refuses on every rank alike) the worker's own counts go to the parent, which adds them up.
-    Records whose row names another contig than their site (R8: closed by a row of the next contig) are not sites of the
-    numbering: they travel as `extras` and the parent adds them."""
-    from . import make_bed
-    from .device import get_device
-    index = make_bed.SiteIndex(P.ref.meth, len(P.ref.names))
-    dev = get_device()
-    offset = go['row_offset']
-    extras = make_bed.cross_contig_records(rec, P.table, P.ref, job['k'], fin.host_scored, fin.tail_chrom, row_offset=offset)
-    if how == 'rccl':
-        try:
-            if job['world'] > 1:
-                dev.comm_init(job['world'], job['rank'], go['uid'])
-            if dev.site_counts(row_offset=offset, tail_contig=go['tail_id']):
-                make_bed.add_pending_site_counts(dev, rec, P.table, index, row_offset=offset, prob=fin.host_prob(rec),
-                                                 skip=extras['records'])
-            n_meth, n_total, first, ms = dev.site_allreduce()
-            dev.comm_destroy()
-            lead = job['rank'] == 0
-            return dict(mode='rccl', n_meth=n_meth if lead else None, n_total=n_total if lead else None,
-                        first=first if lead else None, ms=ms, extras=extras['rows'])
-        except Exception as e:                                   # noqa
-            why = str(e)
-    else:
-        why = 'no RCCL communicator'
-    n_meth, n_total, first = make_bed.site_counts(rec, P.table, index, row_offset=offset, prob=fin.host_prob(rec),
-                                                  skip=extras['records'])
-    return dict(mode='host', why=why, n_meth=n_meth, n_total=n_total, first=first, extras=extras['rows'])
 
 
 class _Workers(object):
@@ -157,11 +200,12 @@ class _Workers(object):
             self.procs.append(p)
             self.conns.append(parent)
 
-    def gather(self):
-        """One message from every worker -> list, or None if a worker died, reported an error or missed the deadline."""
+    def gather(self, timeout=None, on_message=None):
+        """One message from every worker -> list, or None if a worker died, reported an error or missed the deadline.
+        on_message(i, msg): called as the messages arrive (the parent may have something to send meanwhile)."""
         out = [None] * len(self.conns)
         waiting = {c: i for i, c in enumerate(self.conns)}
-        deadline = time.monotonic() + self.timeout
+        deadline = time.monotonic() + (self.timeout if timeout is None else timeout)
         while waiting:
             ready = multiprocessing.connection.wait(list(waiting), timeout=max(0.0, deadline - time.monotonic()))
             if not ready:
@@ -174,7 +218,10 @@ class _Workers(object):
                 if 'error' in msg:
                     sys.stderr.write('mcaller_amd worker %d: %s\n' % (waiting[c], msg['error']))
                     return None
-                out[waiting.pop(c)] = msg
+                i = waiting.pop(c)
+                out[i] = msg
+                if on_message is not None:
+                    on_message(i, msg)
         return out
 
     def tell(self, messages):
@@ -208,11 +255,11 @@ class _Workers(object):
 
 
 def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, base, motif,
-                             positions_list, n_gpus, bed=None):
+                             positions_list, n_gpus, bed=None, fastq=None):
     """Predict mode on n_gpus GPUs.  Returns True when the `.diffs.<k>.tmp0` file has been written and the counter lines
     printed; False when the file cannot be cut (a read name in two pieces, an exit path of the reference, an error or a
     missed deadline in a worker): the caller then runs the one-GPU path, which reproduces the reference's behaviour in
-    those cases."""
+    those cases.  fastq: the workers read the qualities themselves (else `read2qual` is shipped to each)."""
     from . import _lib
     # the bytes the reference's loop reads for (0, file size): the last < 500 bytes of a file can stay unread (:141-148)
     lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, os.path.getsize(tsv_input))
@@ -221,41 +268,41 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     stem = '.'.join(tsv_input.split('.')[:-1])
     tsv_output = stem + '.diffs.' + str(k) + '.tmp0'
     ctx = multiprocessing.get_context('spawn')
-    jobs = [dict(tsv=tsv_input, fasta=fasta_input, read2qual=read2qual, lo=cuts[r], hi=cuts[r + 1], base=base, motif=motif,
-                 positions_list=positions_list, k=k, skip_thresh=skip_thresh, qual_thresh=qual_thresh, modelfile=modelfile,
-                 part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus) for r in range(n_gpus)]
+    jobs = [dict(tsv=tsv_input, fasta=fasta_input, read2qual=None if fastq else read2qual, fastq=fastq, lo=cuts[r], hi=cuts[r + 1],
+                 base=base, motif=motif, positions_list=positions_list, k=k, skip_thresh=skip_thresh, qual_thresh=qual_thresh,
+                 modelfile=modelfile, part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus)
+            for r in range(n_gpus)]
     W = _Workers(ctx, devices, jobs)
     try:
-        # ---- round 1 ----
+        # ---- step 1: the heads, as they come; go(tail) to everybody once all are known ----
         heads = W.gather()
-        if heads is None or any(h.get('fatal') for h in heads):
+        if heads is None:
             return W.stop()
-        seen = set()
-        for h in heads:
-            if seen.intersection(h['names']):
-                return W.stop()                                  # a read name in two pieces: `last_read` crosses the cut
-            seen.update(h['names'])
-        names = None
-        go = []
-        for r in range(n_gpus):
-            tail = next((h['head'] for h in heads[r + 1:] if h['head'] is not None), None)
-            go.append(dict(tail=tail, row_offset=sum(h['n_rows'] for h in heads[:r]), uid=heads[0].get('uid'), tail_id=-1))
-        if bed:                                                  # (contig ids for the device-side reduction)
-            from .refmark import read_fasta
-            names = [n for n, _ in read_fasta(fasta_input)]
-            for g in go:
-                g['tail_id'] = names.index(g['tail']) if g['tail'] is not None else -1
-        W.tell(go)
-        # ---- round 2 ----
+        W.tell([dict(tail=next((h['head'] for h in heads[r + 1:] if h['head'] is not None), None)) for r in range(n_gpus)])
+        # ---- step 2 ----
         results = W.gather()
         if results is None or any(x.get('stop') for x in results):
             return W.stop()
+        seen = set()
+        for x in results:
+            if seen.intersection(x['names']):
+                return W.stop()                                  # a read name in two pieces: `last_read` crosses the cut
+            seen.update(x['names'])
         beds = None
         if bed:
-            # ---- round 3: one decision for everybody ----
-            how = 'rccl' if (n_gpus == 1 or heads[0].get('uid') is not None) else 'host'
-            W.tell([how] * n_gpus)
-            third = W.gather()
+            # ---- steps 3-5: one decision for everybody, three times ----
+            quick = min(W.timeout, float(os.environ.get('MCALLER_COMM_TIMEOUT', '120')))
+            W.tell([dict(probe=True)] * n_gpus)
+            probes = W.gather(quick)
+            if probes is None:
+                return W.stop()
+            init = n_gpus > 1 and all(p['can'] for p in probes) and probes[0]['uid'] is not None
+            W.tell([dict(init=init, uid=probes[0]['uid'])] * n_gpus)
+            ups = W.gather(quick)
+            if ups is None:
+                return W.stop()
+            W.tell([dict(rccl=init and all(u['up'] for u in ups))] * n_gpus)
+            third = W.gather(quick)
             if third is None:
                 return W.stop()
             beds = [x['bed'] for x in third]
@@ -263,12 +310,17 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     except BaseException:
         W.stop()
         raise
-    for h in heads:
-        sys.stdout.write(h['stdout'])                             # 'could not find sequence' lines, in file order
+    for x in results:
+        for line in x['messages']:
+            print(line)                                           # 'could not find sequence' lines, in file order
     with open(tsv_output, 'ab') as out:
         for job in jobs:
             with open(job['part'], 'rb') as part:
-                out.write(part.read())
+                while True:
+                    block = part.read(64 << 20)
+                    if not block:
+                        break
+                    out.write(block)
             os.remove(job['part'])
     if bed:
         _write_bed(bed, beds, fasta_input, base, motif, positions_list, k)
@@ -282,8 +334,21 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     return True
 
 
+def combine_site_counts(beds):
+    """The node-wide per-site counts from what the workers report: rank 0's all-reduced counts if EVERY worker finished the
+    collective, else the sum (min for the first-seen rows) of the workers' own counts.  -> (n_meth, n_total, first, how)."""
+    if beds and all(b['collective_done'] for b in beds) and beds[0]['reduced'] is not None:
+        n_meth, n_total, first = beds[0]['reduced']
+        return n_meth, n_total, first, 'ncclAllReduce over %d GPUs' % len(beds)
+    n_meth = sum(np.asarray(b['own'][0], dtype=np.int64) for b in beds).astype(np.int32)
+    n_total = sum(np.asarray(b['own'][1], dtype=np.int64) for b in beds).astype(np.int32)
+    first = np.minimum.reduce([np.asarray(b['own'][2]) for b in beds])
+    why = next((b['err'] for b in beds if b.get('err')), None) or ('one worker' if len(beds) == 1 else 'no RCCL communicator')
+    return n_meth, n_total, first, 'summed on the host (%s)' % why
+
+
 def _write_bed(bed, beds, fasta_input, base, motif, positions_list, k):
-    """BED of the whole file from the workers' reductions: rank 0's all-reduced counts, or the sum of per-worker counts."""
+    """BED of the whole file from the workers' reductions."""
     from . import make_bed
     from .refmark import MarkedReference
     ref = MarkedReference(fasta_input, base, motif, positions_list)
@@ -293,17 +358,9 @@ def _write_bed(bed, beds, fasta_input, base, motif, positions_list, k):
         except SystemExit:
             pass
     index = make_bed.SiteIndex(ref.meth, len(ref.names))
-    if all(b['mode'] == 'rccl' for b in beds):
-        n_meth, n_total, first = beds[0]['n_meth'], beds[0]['n_total'], beds[0]['first']
-    elif all(b['mode'] == 'host' for b in beds):
-        n_meth = sum(b['n_meth'] for b in beds)
-        n_total = sum(b['n_total'] for b in beds)
-        first = np.minimum.reduce([b['first'] for b in beds])
-    else:
-        raise RuntimeError('workers disagree on how the per-site counts were reduced')
+    n_meth, n_total, first, how = combine_site_counts(beds)
     extras = [row for b in beds for row in b['extras']]
     count = make_bed.write_bed_from_counts(bed['path'], n_meth, n_total, first, index, ref.names, ref.meth, k,
                                            bed['min_depth'], bed['mod_threshold'], extras=extras)
     print(count, 'methylated loci found with min depth', bed['min_depth'], 'reads')
-    print('per-site reduction: %s' % ('ncclAllReduce over %d GPUs' % len(beds) if beds[0]['mode'] == 'rccl'
-                                      else 'summed on the host (%s)' % beds[0].get('why', '')))
+    print('per-site reduction: %s' % how)

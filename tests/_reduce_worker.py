@@ -9,6 +9,20 @@ from tests import helpers as H
 from tests.test_shards import make_workload
 
 
+def allreduce_site_counts(n_meth, n_total, first, dist=None):
+    """Sum / min over ranks through torch.distributed (gloo, CPU tensors) -- the reduction the product does with ncclAllReduce
+    through the C ABI (mc_site_allreduce); here only what it must equal.  Messages: 2 x 4 B + 8 B per site."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return n_meth, n_total, first
+    import torch
+    packed = torch.from_numpy(np.stack([n_meth, n_total]))
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    fmin = torch.from_numpy(first.copy())
+    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
+    packed = packed.numpy()
+    return packed[0], packed[1], fmin.numpy()
+
+
 def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -26,7 +40,7 @@ def main():
     H.oracle_score(rec, sub, qual, weights, soc, 6)
     index = make_bed.SiteIndex(ref.meth, 1)
     counts = make_bed.site_counts(rec, sub, index, row_offset=int(table.seg_row_begin[lo]))
-    n_meth, n_total, first = make_bed.allreduce_site_counts(*counts, dist=dist)
+    n_meth, n_total, first = allreduce_site_counts(*counts, dist=dist)
     if rank == 0:
         make_bed.write_bed_from_counts(out_path, n_meth, n_total, first, index, ref.names, ref.meth, 6, 1, 0.0)
     if dist is not None:

@@ -187,23 +187,28 @@ def test_cli_sharded_over_two_workers_equals_one_gpu(tmp_path):
         took.append(real(*a, **kw))
         return took[-1]
     multi_gpu.extract_features_sharded = spy
-    for extra in ([], ['--gpus', '2'], ['--gpus', '3']):
+    # (the last two: every worker streams its piece in four shards -- text parsed on the device, two passes in flight, the
+    # tail of a worker's last shard from the next worker's first)
+    for extra, shards in (([], None), (['--gpus', '2'], None), (['--gpus', '3'], None), (['--gpus', '2'], '4'), (['--gpus', '3'], '4')):
         out_path = tsv[:-4] + '.diffs.6'
         if os.path.exists(out_path):
             os.remove(out_path)
         os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * (int(extra[1]) if extra else 1))
+        if shards:
+            os.environ['MCALLER_STREAM_SHARDS'] = shards
         buf = io.StringIO()
         try:
             with contextlib.redirect_stdout(buf):
                 mCaller.main(common + extra)
         finally:
             del os.environ['MCALLER_SHARD_DEVICES']
+            os.environ.pop('MCALLER_STREAM_SHARDS', None)
         lines = [l for l in buf.getvalue().split('\n') if 'observations' in l or 'positions' in l or 'regions' in l]
         outs.append((open(out_path, 'rb').read(), lines))
     multi_gpu.extract_features_sharded = real
-    assert took == [True, True]                               # the sharded path ran (no fall-back to one GPU)
+    assert took == [True, True, True, True]                   # the sharded path ran (no fall-back to one GPU)
     assert outs[0][0].count(b'\n') > 200
-    assert outs[1] == outs[0] and outs[2] == outs[0]
+    assert all(o == outs[0] for o in outs[1:])
     assert not [f for f in os.listdir(d) if '.part' in f or '.tmp' in f]
 
 
@@ -228,25 +233,30 @@ def test_cli_bed_from_the_per_site_reduction(tmp_path):
     bed_path = os.path.join(d, 'syn.methylation.summary.bed')
     diffs = tsv[:-4] + '.diffs.6'
     results = []
-    for n in (1, 2):
+    # (one worker; two; one and three whose pieces are streamed in three shards each: the counts accumulate on the device
+    # shard after shard, mc_site_counts_accumulate)
+    for n, shards in ((1, None), (2, None), (1, '3'), (3, '3')):
         for f in (bed_path, diffs):
             if os.path.exists(f):
                 os.remove(f)
         os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * n)
+        if shards:
+            os.environ['MCALLER_STREAM_SHARDS'] = shards
         buf = io.StringIO()
         try:
             with contextlib.redirect_stdout(buf):
                 mCaller.main(common + ['--gpus', str(n)])
         finally:
             del os.environ['MCALLER_SHARD_DEVICES']
+            os.environ.pop('MCALLER_STREAM_SHARDS', None)
         results.append((open(bed_path).read(), buf.getvalue()))
-    assert 'per-site reduction: ncclAllReduce over 1 GPUs' in results[0][1] or 'per-site reduction' in results[0][1]
+    assert all('per-site reduction' in r[1] for r in results)
     assert 'summed on the host' in results[1][1]
     os.rename(bed_path, bed_path + '.reduced')
     with contextlib.redirect_stdout(io.StringIO()):
         make_bed.main(['-f', diffs, '-d', '3', '-t', '0.3'])
     want = open(bed_path).read()
-    assert results[0][0] == want and results[1][0] == want and want.count('\n') > 5
+    assert all(r[0] == want for r in results) and want.count('\n') > 5
     # --bed_vo: the same file with make_bed.py --vo's probability lists (two workers)
     os.remove(diffs)
     os.environ['MCALLER_SHARD_DEVICES'] = '0,0'

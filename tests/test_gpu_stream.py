@@ -273,7 +273,7 @@ def test_streamed_file_equals_the_one_table_path(tmp_path, monkeypatch, n_rows, 
 
     def spy(*a, **kw):
         out = real(*a, **kw)
-        streamed_calls.append(len(out[0]))
+        streamed_calls.append(out.n_bytes)
         return out
     monkeypatch.setattr(ec, 'stream_features', spy)
     got = _run_extract(paths, args, monkeypatch, shards=shards)

@@ -113,3 +113,49 @@ def test_bed_from_reduced_counts_equals_make_bed_on_the_diffs_text(tmp_path):
         out = tmp_path / 'reduced.bed'
         make_bed.write_bed_from_counts(str(out), counts[0], counts[1], counts[2], index, ref.names, ref.meth, 6, depth, thresh)
         assert out.read_text() == want and want.count('\n') >= (3 if depth == 1 else 0)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE in the environment) starts two rank processes
+    itself and rank 0 reports n_gpus = 2 (--dry-ranks: the rendezvous only, nothing touches a GPU); under a launcher's
+    environment it does not spawn."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--gpus', '2', '--dry-ranks'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'bench.py itself'
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--gpus', '1', '--dry-ranks'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])['n_gpus'] == 1
+
+
+def test_bench_rank_failure_is_the_exit_code():
+    """A rank that dies takes the others down and makes the launcher exit non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['MCALLER_BENCH_FAIL_RANK'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--gpus', '2', '--dry-ranks'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'rank 1 exited' in r.stderr
+
+
+def test_site_counts_of_the_workers_are_combined_on_the_host_when_the_collective_did_not_finish():
+    """multi_gpu.combine_site_counts: rank 0's all-reduced counts only if EVERY worker finished the collective; otherwise the
+    workers' own counts are added up (min of the first-seen rows) -- never an error after the rows have been written."""
+    from mcaller_amd.multi_gpu import combine_site_counts
+    big = np.iinfo(np.int64).max
+    own = [(np.array([1, 0, 2], np.int32), np.array([2, 0, 3], np.int32), np.array([7, big, 4], np.int64)),
+           (np.array([0, 1, 1], np.int32), np.array([1, 1, 1], np.int32), np.array([big, 9, 2], np.int64))]
+    summed = (np.array([1, 1, 3], np.int32), np.array([3, 1, 4], np.int32), np.array([7, 9, 2], np.int64))
+    reduced = tuple(a + 0 for a in summed)
+    ok = [dict(own=own[0], reduced=reduced, collective_done=True, err=None), dict(own=own[1], reduced=None, collective_done=True, err=None)]
+    got = combine_site_counts(ok)
+    assert all(np.array_equal(g, w) for g, w in zip(got[:3], reduced)) and 'ncclAllReduce' in got[3]
+    bad = [dict(own=own[0], reduced=reduced, collective_done=True, err=None),
+           dict(own=own[1], reduced=None, collective_done=False, err='ncclAllReduce failed: unhandled system error')]
+    got = combine_site_counts(bad)
+    assert all(np.array_equal(g, w) for g, w in zip(got[:3], summed)) and 'summed on the host' in got[3] and 'unhandled' in got[3]
+    host = [dict(own=o, reduced=None, collective_done=False, err=None) for o in own]
+    got = combine_site_counts(host)
+    assert all(np.array_equal(g, w) for g, w in zip(got[:3], summed))
