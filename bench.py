@@ -186,6 +186,8 @@ def main():
     ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
     ap.add_argument('--stream-shards', type=int, default=10, help='device end-to-end: distinct shards the rows arrive in (0: skip)')
     ap.add_argument('--f2f-events', type=float, default=1e7, help='file to file: rows of eventalign text (0: skip)')
+    ap.add_argument('--f2f-big-events', type=float, default=1e8,
+                    help='file to file at the headline size, in a process of its own: rows of eventalign text (0: skip)')
     ap.add_argument('--kernels-only', action='store_true', help='skip device end-to-end, file to file and the CPU legs (profiling runs)')
     ap.add_argument('--rescan-only', action='store_true',
                     help='profiling runs: the timed steps re-scan ONE validated table (config.resident_rescan) instead of full passes')
@@ -193,7 +195,7 @@ def main():
                     help='launch plumbing only (CPU test): the ranks rendezvous, rank 0 prints n_gpus, nothing touches a GPU')
     args = ap.parse_args()
     if args.kernels_only:
-        args.stream_shards, args.f2f_events, args.no_cpu_baseline = 0, 0, True
+        args.stream_shards, args.f2f_events, args.f2f_big_events, args.no_cpu_baseline = 0, 0, 0, True
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -527,16 +529,49 @@ def main():
                     mCaller.main(['-m', 'GATC', '-r', f2f_paths['fasta'], '-e', f2f_paths['tsv'], '-f', f2f_paths['fastq'], '-d', model_npz])
                 runs.append(time.perf_counter() - t_r)
             calls_f = sum(1 for _ in open(out_path, 'rb'))
-            best = min(runs[1:])
+            best, med = min(runs[1:]), float(np.median(runs[1:]))
             file_to_file = {'rows': f2f_rows, 'tsv_bytes': os.path.getsize(f2f_paths['tsv']), 'calls': calls_f,
-                            'seconds_first_run': runs[0], 'seconds_best': best, 'seconds_all': runs,
-                            'events_per_s': f2f_rows / best, 'calls_per_s': calls_f / best,
+                            'seconds_first_run': runs[0], 'seconds_best': best, 'seconds_median': med, 'seconds_all': runs,
+                            'events_per_s': f2f_rows / med, 'events_per_s_best': f2f_rows / best, 'calls_per_s': calls_f / med,
                             'host_cores': len(os.sched_getaffinity(0)), 'inputs_written_s': t_w,
                             'what': 'python -m mcaller_amd.mCaller -m GATC: FASTQ qualities, FASTA marking, the text read into pinned '
                                     'memory and parsed on the GPU (mc_ctx_parse_*), shards streamed through the table slots, native row '
                                     'formatter, .diffs.6 written (page cache warm)'}
         except Exception as e:                                  # noqa
             file_to_file = {'error': '%s: %s' % (type(e).__name__, e)}
+
+    # ---- file to file at the headline size (10^8 rows, 12.8 GB of text), in a process of its own: wall time per run, its peak RSS ----
+    file_to_file_big = None
+    if world == 1 and rank == 0 and args.f2f_big_events > 0 and file_to_file and 'error' not in file_to_file:
+        big_dir = None
+        try:
+            import subprocess
+            big_rows = int(args.f2f_big_events)
+            t_b, q_b = (table, qual) if big_rows == n_rows else synth.make_table(big_rows, seed=1000, codes=codes)
+            big_dir = tempfile.mkdtemp(prefix='mc_f2f_big_')
+            t_w = time.perf_counter()
+            synth.write_inputs(t_b, q_b, codes, big_dir)
+            t_w = time.perf_counter() - t_w
+            os.sync()
+            r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', big_dir, '--runs', '4', '--json'],
+                               capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-500:])
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            runs_b = res['seconds_all']
+            med_b = float(np.median(runs_b[1:]))
+            file_to_file_big = {'rows': big_rows, 'tsv_bytes': res['tsv_bytes'], 'diffs_bytes': res['diffs_bytes'], 'calls': res['calls'],
+                                'seconds_first_run': runs_b[0], 'seconds_best': min(runs_b[1:]), 'seconds_median': med_b,
+                                'seconds_all': runs_b, 'events_per_s': big_rows / med_b, 'calls_per_s': res['calls'] / med_b,
+                                'text_GBps': res['tsv_bytes'] / med_b / 1e9, 'peak_rss_mb': res['peak_rss_mb'], 'inputs_written_s': t_w,
+                                'what': 'python tools/file_to_file.py --inputs ... --runs 4 (the CLI, four times in one process of its '
+                                        'own; page cache warm): rows are appended to the output shard by shard, memory is bounded by '
+                                        'the shards in flight'}
+        except Exception as e:                                  # noqa
+            file_to_file_big = {'error': '%s: %s' % (type(e).__name__, e)}
+        finally:
+            if big_dir:
+                shutil.rmtree(big_dir, ignore_errors=True)
 
     # ---- text end to end: the same file, its text already in pinned host memory, parsed on the GPU shard after shard, a pass
     #      over every shard, records back in host memory (N = 1): what the link allows for eventalign TEXT ----
@@ -668,7 +703,7 @@ def main():
                        'calls_per_s_kernels_only': calls_per_step / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
                        'device_e2e': device_e2e,
                        'device_e2e_events_per_s': (device_e2e or {}).get('events_per_s'),
-                       'file_to_file': file_to_file, 'text_e2e': text_e2e},
+                       'file_to_file': file_to_file, 'file_to_file_1e8': file_to_file_big, 'text_e2e': text_e2e},
             'roofline': {'bound': 'hbm',
                          'kernel': 'every kernel that touches a table once: k0_first_site + k1_scan (validating) + k1_group_scan + '
                                    'k1_list + k1_emit',

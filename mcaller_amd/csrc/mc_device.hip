@@ -3607,7 +3607,7 @@ extern "C" int mc_ctx_parse_finish(mc_ctx *c, int32_t slot, const int32_t *seg_r
     }
     HIP_TRY(hipEventSynchronize(S.ev_uploaded));           // the stage is about to be rewritten (long done: the slot was idle)
     S.kp_state = 0;
-    S.refs -= 1;
+    S.refs = std::max(S.refs - 1, 0);
     if (int rc = fill_slot(c, slot, H.n_rows, H.n_seg, S.kp_seg_row.data(), seg_read, S.kp_seg_contig.data(), S.kp_seg_ns.data(), n_reads,
                            read_qual, nullptr))
         return rc;
@@ -3624,7 +3624,7 @@ extern "C" int mc_ctx_parse_abandon(mc_ctx *c, int32_t slot) {
     HIP_TRY(hipEventSynchronize(S.ev_parsed));
     // (ev_valid still stands for the slot's previous table, which is all a later upload waits for)
     S.kp_state = 0;
-    S.refs -= 1;
+    S.refs = std::max(S.refs - 1, 0);
     return 0;
 }
 
@@ -3697,7 +3697,7 @@ extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     if (int rc = sync_pass_streams(c)) return rc;
     if (c->ab_count == 0) {                                  // no pass to hand out any more: nothing is held
         c->held = -1;
-        for (TableSlot &S : c->slots) S.refs = 0;
+        for (TableSlot &S : c->slots) S.refs = S.kp_state != 0 ? 1 : 0;      // (but a slot the device parser is filling stays taken)
     }
     int32_t slot = -1;
     if (int rc = mc_ctx_upload_table_async(c, h, nullptr, &slot)) return rc;

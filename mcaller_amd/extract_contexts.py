@@ -183,16 +183,25 @@ class Finisher(object):
                 '%d observations with too many skips' % n_skipped]
 
     def _bind(self, rec):
-        P, k, t = self.P, self.k, self.P.table
         n = rec.n
         self._rec = rec
-        m = rec.n_calls                       # (a compacted view, mc_wait_records: rows of the calls only, see Records.call_row)
-        self._feats = rec.feats[:m * k].reshape(m, k)
-        self._row = rec.call_row[:n] if rec.call_row is not None else None
         self._info = rec.info[:n]
         self._site_pos = rec.site_pos[:n]
         self._seg_of = rec.site_seg[:n]
-        self._close_seg = np.searchsorted(t.seg_row_begin, rec.close_row[:n], side='right') - 1
+        self._lazy = None
+
+    def _per_record(self):
+        """(slot means [calls, k], row of every record in them or None, segment of every record's closing row): only the
+        per-record transcription (_one) needs these -- a streamed predict-mode shard whose rows all come from the native
+        formatter leaves the packed slot means (mc_calls_view.feats_lo32) as they arrived."""
+        if self._lazy is None:
+            rec, k, t, n = self._rec, self.k, self.P.table, self._rec.n
+            m = rec.n_calls                   # (a compacted view, mc_wait_records: rows of the calls only, see Records.call_row)
+            feats = rec.feats[:m * k].reshape(m, k)
+            row = rec.call_row[:n] if rec.call_row is not None else None
+            close_seg = np.searchsorted(t.seg_row_begin, rec.close_row[:n], side='right') - 1
+            self._lazy = (feats, row, close_seg)
+        return self._lazy
 
     def run(self, rec):
         """Returns None, or the exception (SystemExit / error) the reference would raise at that record."""
@@ -244,7 +253,8 @@ class Finisher(object):
 
     def _one(self, j):
         P, k, t = self.P, self.k, self.P.table
-        rec, feats = self._rec, self._feats
+        rec = self._rec
+        feats, rows_of, close_seg = self._per_record()
         names = t.read_names
         half = int((2 * k - 1) / 2)
         inf = int(self._info[j])
@@ -258,12 +268,12 @@ class Finisher(object):
             empty = inf & _I.I_EMPTY_MASK
             if empty:
                 self.w_skips.add((read, mpos))                                # :184-185
-            row = j if self._row is None else int(self._row[j])
+            row = j if rows_of is None else int(rows_of[j])
             diffs = [0 if (empty >> i) & 1 else float(feats[row, i]) for i in range(k)]
             qual = P.qual_obj[rid]
             diffs_txt = ','.join(['0' if (empty >> i) & 1 else fmt_float(feats[row, i]) for i in range(k)]
                                  + [str(qual)])
-            cseg = int(self._close_seg[j])
+            cseg = int(close_seg[j])
             chrom = self.tail_chrom if cseg >= t.n_seg else P.ref.names[int(t.seg_contig[cseg])]
             last_ref = P.ref.meth[int(t.seg_contig[seg])][1 if rev else 0]
             context = revcomp(last_ref[mpos - k + 1:mpos + k], rev)           # :194 (Python slicing rules)
@@ -310,6 +320,7 @@ class Finisher(object):
 
 
 STREAM_SHARD_BYTES = 128 << 20      # eventalign text per shard of a streamed file (~10^6 rows)
+STREAM_SHARD_MAX_BYTES = 2 << 30    # a shard beyond this (the cuts are at read starts: one giant read) sends the file to the one-table path
 
 
 def head_contig(P, qual_thresh):
@@ -403,8 +414,17 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     on_device = not os.environ.get('MCALLER_HOST_PARSER')
     if on_device:
         biggest = max(b - a for a, b in pieces)
-        rows_cap = min(biggest, (1 << 32) - 64) // 48 + 65536
-        dev.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
+        if biggest > STREAM_SHARD_MAX_BYTES:                   # (one giant read: twelve slots of that size are not worth reserving)
+            L.mc_host_pool_config(0, -1)
+            pool.shutdown(wait=False)
+            raise _Unstreamable('a shard of %d bytes' % biggest)
+        rows_cap = biggest // 48 + 65536
+        try:
+            dev.reserve_tables(rows_cap, rows_cap // 16, rows_cap // 16)
+        except _lib.McError as e:
+            L.mc_host_pool_config(0, -1)
+            pool.shutdown(wait=False)
+            raise _Unstreamable('the table slots cannot be reserved: %s' % e)
     clock['device_parsed'] = 0
     clock['events'] = []            # (MCALLER_TIMING=2: when the main thread did what)
     t_zero = time.perf_counter()
@@ -459,7 +479,10 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             return None
         slot, text, piece = parsing.pop(0)
         mark('parse_end ...')
-        table = dev.parse_end(slot, text)
+        try:
+            table = dev.parse_end(slot, text)
+        except _lib.McError as e:
+            raise _Unstreamable('the device parser failed: %s' % e)
         mark('parse_end done')
         if table is None:                                      # declined: the host parser takes the shard
             return prepare(tsv_input, None, read2qual, piece[0], piece[1], base, motif, positions_list, exact_range=True, ref=ref,
@@ -483,7 +506,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                     break
                 return text
             mark('text ready')
-            parsing.append((dev.parse_begin(text, ref.names, rows_cap), text, piece))
+            parsing.append((needs_a_slot(dev.parse_begin, text, ref.names, rows_cap), text, piece))
             mark('parse_begin done')
             if not mark_thread and not mark_all and (len(parsing) >= 3 or next_piece[0] >= len(pieces)):
                 import threading
@@ -493,6 +516,18 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 ahead.append((pool.submit(parse_shard, *pieces[next_piece[0]]), pieces[next_piece[0]]))
                 next_piece[0] += 1
         return None
+
+    def needs_a_slot(fn, *a):
+        """A call that takes a table slot (mc_ctx_parse_begin, mc_ctx_upload_table_async): with every slot taken the oldest pass is
+        handed out first; whatever else the streaming machinery declines sends the file to the one-table path."""
+        while True:
+            try:
+                return fn(*a)
+            except _lib.McError as e:
+                if 'table slots' in str(e) and in_flight:
+                    hand_out()
+                    continue
+                raise _Unstreamable('the streaming machinery declined: %s' % e)
 
     positions = []
     in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
@@ -567,7 +602,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 top_up_quietly()                               # (the link stays busy while the masks are made ready)
             dev.set_reference(ref.device_arrays())
             marked[0] = n_marked
-        dev.upload_table_async(P.table, P.qual)
+        needs_a_slot(dev.upload_table_async, P.table, P.qual)
         dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=not train)
 
     while next_piece[0] < len(pieces) and len(ahead) < 3:      # (the first shards are read while the masks are made)

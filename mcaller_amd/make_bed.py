@@ -243,6 +243,9 @@ def cross_contig_records(rec, table, ref, k, host_scored=None, tail_chrom=None, 
     tail_id = ref.names.index(tail_chrom) if tail_chrom is not None else -1
     close_contig = np.where(close_seg >= table.n_seg, tail_id,
                             table.seg_contig[np.minimum(close_seg, max(table.n_seg - 1, 0))].astype(np.int64))
+    # (closed by a row beyond the table with no contig behind it: the kernels emit no such record -- R6, the window is lost)
+    if ((close_contig < 0) & ((info & _lib.I_TOO_MANY) == 0)).any():
+        raise ValueError('a record is closed by a row beyond the table, but no contig follows the table')
     mask = ((info & _lib.I_TOO_MANY) == 0) & (close_contig != site_contig)
     for j in np.flatnonzero(mask):
         rev = bool(info[j] & _lib.I_REV)

@@ -1,5 +1,5 @@
 """One-off fuzz campaign on the GPU box: random micro-cases (oracle/casegen.py, seeds outside every committed fixture) through
-the HIP path -- synchronous and pipelined -- against the C oracle.  Prints the seeds that differ (none expected)."""
+the HIP path -- synchronous and pipelined, as a table's first, second and third pass -- against the C oracle.  Prints the seeds that differ (none expected)."""
 import contextlib, io, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -46,9 +46,18 @@ for fi, fl in enumerate(flavours):
                 H.oracle_score(orc, P.table, P.qual, w, soc, a['k'])
             rec = ec.compute(P, a['k'], a['skip_thresh'], a['qual_thresh'], modelset, a['base'], train, device=dev)
             H.assert_records_equal(rec, orc, a['k'])
-            dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'], score=not train)
-            rec2 = dev.wait()                         # (compacted view: the helper checks call_row, then compares by record)
-            H.assert_records_equal(rec2, orc, a['k'])
+            # the same table again through the pipelined interface: second pass (positions streamed), third (unit summaries), and
+            # -- declared new -- the validating first pass itself (two in flight)
+            slot = dev.current_slot()
+            for again in range(4):
+                if again == 2:
+                    dev.select_table(slot, as_new=True)
+                dev.run_async(a['k'], a['skip_thresh'], a['qual_thresh'], score=not train)
+                if again == 2:
+                    continue
+                for _ in range(2 if again == 3 else 1):
+                    rec2 = dev.wait()                 # (compacted view: the helper checks call_row, then compares by record)
+                    H.assert_records_equal(rec2, orc, a['k'])
             done += 1
         except AssertionError as e:
             bad.append((seed, fl, str(e)[:200]))

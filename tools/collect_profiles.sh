@@ -6,7 +6,9 @@ head=${2:-unknown}
 out=gpurun_out/$tag
 export TMPDIR=/tmp
 mkdir -p $out
-timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.err
+src=$(python3 -c "import bench; print(bench.kernel_source_hash())")
+echo "commit $head, kernel sources $src" > $out/HEAD.txt
+timeout 1200 python3 bench.py > $out/bench.json 2> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --kernels-only > $out/stats_bench.json 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
@@ -18,16 +20,28 @@ timeout 600 python3 bench.py --no-pipeline --kernels-only > $out/bench_sync.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 bench.py --kernels-only --no-pipeline --steps 50 > /dev/null 2>> $out/bench.err
 cp $out/stats1/*/*kernel_stats.csv $out/kernel_stats_one_pass_at_a_time.csv; rm -rf $out/stats1
 timeout 600 python3 bench.py --events 1e9 --steps 10 --warmup 3 --kernels-only > $out/bench_1e9.json 2>> $out/bench.err
+# dense (-m A): bench line, kernel averages one pass at a time, PMC passes
 timeout 600 python3 bench.py --motif A --events 1e8 --steps 5 --warmup 2 --kernels-only > $out/bench_dense_1e8.json 2>> $out/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/statsd -- python3 bench.py --motif A --events 1e8 --steps 5 --warmup 2 --kernels-only --no-pipeline > /dev/null 2>> $out/bench.err
+cp $out/statsd/*/*kernel_stats.csv $out/kernel_stats_dense_one_pass_at_a_time.csv; rm -rf $out/statsd
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetchd -- python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/writed -- python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
+python3 tools/pmc_summary.py $out/fetchd $out/writed $out/pmc_dense.json "python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only" $head
+rm -rf $out/fetchd $out/writed
 # the streamed file-to-file path: kernel averages of the device parser and of the per-shard passes
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 -- python3 tools/file_to_file.py 1e7 > $out/file_to_file.log 2>&1
 cp $out/stats2/*/*kernel_stats.csv $out/kernel_stats_file_to_file.csv; rm -rf $out/stats2
+# evidence on THIS code: fuzz campaign, pipelined soak, streamed-CLI soak (logs carry the commit and the kernel-source hash)
+( echo "commit $head, kernel sources $src"; timeout 1500 python3 tests/tools/fuzz_gpu.py ${FUZZ_PER_FLAVOUR:-600} ${FUZZ_SEED:-31000000} ) > $out/fuzz.log 2>&1
+( echo "commit $head, kernel sources $src"; timeout 600 python3 tools/pipeline_soak.py 1e8 ${SOAK_PASSES:-1500} ) > $out/pipeline_soak.log 2>&1
+( echo "commit $head, kernel sources $src"; timeout 900 python3 tools/stream_soak.py 3e6 ${SOAK_RUNS:-30} ) > $out/stream_soak.log 2>&1
 fi
 python3 - <<P
 import json
 for f in ("bench","bench_sync","bench_1e9","bench_dense_1e8"):
     try:
-        d=json.load(open("$out/%s.json"%f)); print(f, "%.4g"%d["value"], "%.4f"%d["ms_per_step"], {k:round(v,4) for k,v in d["config"]["kernel_ms"].items()}, d["roofline"]["frac"], d["roofline"]["per_table"]["frac"], (d["config"].get("device_e2e") or {}).get("events_per_s"), (d["config"].get("file_to_file") or {}).get("seconds_best"))
+        d=json.load(open("$out/%s.json"%f)); print(f, "%.4g"%d["value"], "%.4f"%d["ms_per_step"], {k:round(v,4) for k,v in d["config"]["kernel_ms"].items()}, round(d["roofline"]["frac"],4), d["roofline"]["kernels_ms"], (d["config"].get("device_e2e") or {}).get("events_per_s"), (d["config"].get("file_to_file") or {}).get("seconds_median"))
     except Exception as e: print(f, e)
 P
 tail -n 3 $out/bench.err
+tail -n 2 $out/fuzz.log $out/pipeline_soak.log $out/stream_soak.log 2>/dev/null

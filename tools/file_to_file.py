@@ -1,33 +1,46 @@
-"""File-to-file timing (third timing): synthetic eventalign TSV -> .diffs.6 through the CLI."""
-import os, sys, time, tempfile, contextlib, io
+"""File-to-file timing (third timing): synthetic eventalign TSV -> .diffs.6 through the CLI.
+
+  python tools/file_to_file.py [rows] [--runs N]            writes its own inputs (synthetic, `rows` rows)
+  python tools/file_to_file.py --inputs DIR [--runs N]      inputs already written (synth.write_inputs: syn.eventalign.tsv, ...)
+  --json: one JSON line (bench.py's 10^8-row leg runs this in a process of its own: wall time per run, peak RSS of the process)"""
+import contextlib, io, json, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from mcaller_amd import synth, mCaller
 
-n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
-d = tempfile.mkdtemp(prefix='mc_f2f_')
-codes = synth.genome()
-table, qual = synth.make_table(n, seed=5, codes=codes)
-t = time.time()
-tsv = os.path.join(d, 'syn.eventalign.tsv')
-synth.write_tsv(table, codes, tsv)
-with open(os.path.join(d, 'ref.fasta'), 'w') as fa:
-    s = synth.codes_to_str(codes)
-    fa.write('>ecoli_syn\n' + '\n'.join(s[i:i + 60] for i in range(0, len(s), 60)) + '\n')
-with open(os.path.join(d, 'reads.fastq'), 'w') as fq:
-    for i, name in enumerate(table.read_names):
-        q = int(round(qual[i]))
-        fq.write('@%s\nACGTACGTAC\n+\n%s\n' % (name, chr(33 + q) * 10))
-print('inputs written in %.1f s: %.1f MB of TSV, %d rows' % (time.time() - t, os.path.getsize(tsv) / 1e6, table.n_rows))
-os.environ['MCALLER_TIMING'] = os.environ.get('MCALLER_TIMING', '1')
+args = sys.argv[1:]
+as_json = '--json' in args
+runs = int(args[args.index('--runs') + 1]) if '--runs' in args else 6
+if '--inputs' in args:
+    d = args[args.index('--inputs') + 1]
+    paths = dict(tsv=os.path.join(d, 'syn.eventalign.tsv'), fasta=os.path.join(d, 'ref.fasta'), fastq=os.path.join(d, 'reads.fastq'))
+    n_rows = None
+else:
+    n_rows = int(float(args[0])) if args and not args[0].startswith('--') else 1000000
+    d = tempfile.mkdtemp(prefix='mc_f2f_')
+    codes = synth.genome()
+    table, qual = synth.make_table(n_rows, seed=5, codes=codes)
+    t = time.time()
+    paths = synth.write_inputs(table, qual, codes, d)
+    if not as_json:
+        print('inputs written in %.1f s: %.1f MB of TSV, %d rows' % (time.time() - t, os.path.getsize(paths['tsv']) / 1e6, table.n_rows))
+    del table
+if not as_json:
+    os.environ['MCALLER_TIMING'] = os.environ.get('MCALLER_TIMING', '1')
 model = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mcaller_amd', 'models', 'r95_twobase_model_NN_6_m6A.npz')
-for rep in range(6):
-    out = tsv[:-4] + '.diffs.6'
+out = paths['tsv'][:-4] + '.diffs.6'
+times, calls = [], 0
+for rep in range(runs):
     if os.path.exists(out):
         os.remove(out)
     t = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        mCaller.main(['-m', 'GATC', '-r', os.path.join(d, 'ref.fasta'), '-e', tsv, '-f', os.path.join(d, 'reads.fastq'), '-d', model])
+        mCaller.main(['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model])
     dt = time.perf_counter() - t
-    calls = sum(1 for _ in open(out))
-    print('run %d: %.3f s wall, %d calls -> %.3g events/s, %.3g calls/s (file to file)' % (rep, dt, calls, table.n_rows / dt, calls / dt))
+    times.append(dt)
+    calls = sum(1 for _ in open(out, 'rb'))
+    if not as_json:
+        print('run %d: %.3f s wall, %d calls%s' % (rep, dt, calls, '' if n_rows is None else ' -> %.3g events/s, %.3g calls/s (file to file)'
+                                                   % (n_rows / dt, calls / dt)))
+if as_json:
+    print(json.dumps({'seconds_all': times, 'calls': calls, 'tsv_bytes': os.path.getsize(paths['tsv']), 'diffs_bytes': os.path.getsize(out),
+                      'peak_rss_mb': resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}))
