@@ -2783,14 +2783,14 @@ struct mc_ctx {
         hipEvent_t ev_k0_start = nullptr, ev_k0_end = nullptr, ev_scan_start = nullptr, ev_scan_end = nullptr,
                    ev_emit_end = nullptr, ev_k2_start = nullptr, ev_k2_end = nullptr, ev_done = nullptr, ev_copied = nullptr;
         mc_params prm;
-        int64_t cap = 0, n_nb = 0, n_tiles = 0;
+        int64_t cap = 0, n_nb = 0;
         int k = 0;
         bool used = false, copying = false, timed = true;
         int slot = -1;             // table slot the pass scans
         unsigned long long pass_no = 0;   // what Counters.irregular_pass holds if the pass classified a block irregular
         const double *qual = nullptr;   // read qualities it was enqueued with
         int32_t n_qual = 0;
-        std::vector<void *> dev_allocs;
+        std::vector<void *> dev_allocs, k0_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
     hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
     int ab_head = 0, ab_tail = 0, ab_count = 0;
@@ -3206,8 +3206,9 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     if (int rc = sync_pass_streams(c)) return rc;
     free_pool(c->scratch_allocs);
     const int64_t res_tiles = c->res_rows ? (c->res_rows + TILE - 1) / TILE : 0;
-    const int64_t nb = std::max<int64_t>(std::max<int64_t>(n_nb, c->res_segs), c->scratch_nb);
-    const int64_t nt = std::max<int64_t>(std::max<int64_t>(n_tiles, res_tiles), c->scratch_tiles);
+    // (with head room: the tables of a stream differ by a few name blocks, and growing again means waiting for everything in flight)
+    const int64_t nb = std::max<int64_t>(std::max<int64_t>(n_nb + n_nb / 4 + 64, c->res_segs), c->scratch_nb);
+    const int64_t nt = std::max<int64_t>(std::max<int64_t>(n_tiles + n_tiles / 8 + 16, res_tiles), c->scratch_tiles);
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
@@ -4162,7 +4163,8 @@ static void free_async(mc_ctx *c) {
         b.st_host = nullptr; b.cnt = nullptr; b.pack = nullptr; b.pack_host = nullptr;
         b.O = DevRecords();
         b.K = K0Set();
-        b.cap = b.n_nb = b.n_tiles = 0; b.k = 0; b.used = false; b.copying = false;
+        free_pool(b.k0_allocs);
+        b.cap = b.n_nb = 0; b.k = 0; b.used = false; b.copying = false;
     }
     c->ab_head = c->ab_tail = c->ab_count = 0;
 }
@@ -4184,15 +4186,22 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
         for (hipEvent_t *e : {&b.ev_done, &b.ev_copied})
             HIP_TRY(hipEventCreate(e));
     }
-    if (b.cap >= cap && b.k == k && b.n_nb >= T.n_nb && b.n_tiles >= T.n_tiles) return 0;
+    // the strand-resolve output (64 B per name block) and the record set are sized apart: tables that come in turn differ by a few
+    // name blocks, and that must not cost a record set (for a one-base motif: gigabytes, pinned) -- with head room, so that it
+    // happens once
+    if (b.n_nb < T.n_nb) {
+        if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
+        free_pool(b.k0_allocs);
+        const int64_t nb = std::max<int64_t>(T.n_nb + T.n_nb / 4 + 64, c->scratch_nb);
+        if (dev_alloc(b.k0_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.k0_allocs, &b.K.nb_f0, (size_t)nb + 1)) return -10;
+        b.n_nb = nb;
+    }
+    if (b.cap >= cap && b.k == k) return 0;
     if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
     free_pool(b.dev_allocs);
     b.H = DevRecords();
-    const int64_t nb = std::max<int64_t>(T.n_nb, c->scratch_nb), nt = std::max<int64_t>(T.n_tiles, c->scratch_tiles);
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
-    if (dev_alloc(b.dev_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.dev_allocs, &b.K.nb_f0, (size_t)nb + 1))
-        return -10;
     if (cap >= (int64_t)1 << 31) {
         mc_set_error("mc_extract_features_async: %lld flush records per pass (call rows are 32 bits wide); use mc_extract_features",
                      (long long)cap);
@@ -4210,8 +4219,6 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     }
     b.cap = cap;
     b.k = k;
-    b.n_nb = nb;
-    b.n_tiles = nt;
     b.used = false;
     return 0;
 }
@@ -4278,7 +4285,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
-        if (!other.used && other.cap < cap) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
+        if (!other.used && (other.cap < cap || other.n_nb < T.n_nb)) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
     // K0 (strand resolve) and K1 (scan, ordering, emit) of a pass on the ctx stream, back to back with the next pass: nothing
     // on the scan's path waits for another queue.  K2 (classifier) and the packing on the side stream, behind the pass's
     // emit: they run beside K0 of the next pass (small latency-bound kernels) and the first microseconds of its scan.

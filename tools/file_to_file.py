@@ -7,6 +7,15 @@ import contextlib, io, json, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcaller_amd import synth, mCaller
 
+def peak_rss_mb():
+    """High-water mark of THIS program's resident memory (VmHWM: per address space -- ru_maxrss would carry over the size of the
+    process that started us, across fork and exec)."""
+    for line in open('/proc/self/status'):
+        if line.startswith('VmHWM:'):
+            return int(line.split()[1]) / 1024.0
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+
 args = sys.argv[1:]
 as_json = '--json' in args
 runs = int(args[args.index('--runs') + 1]) if '--runs' in args else 6
@@ -38,9 +47,13 @@ for rep in range(runs):
     dt = time.perf_counter() - t
     times.append(dt)
     calls = sum(1 for _ in open(out, 'rb'))
+    if os.environ.get('MCALLER_RSS'):                      # (what the process's resident memory is made of, run after run)
+        st = dict(l.split(':', 1) for l in open('/proc/self/status').read().splitlines() if ':' in l)
+        sys.stderr.write('run %d: VmRSS %s RssAnon %s RssFile %s RssShmem %s VmHWM %s\n' % (
+            rep, st['VmRSS'].strip(), st['RssAnon'].strip(), st['RssFile'].strip(), st['RssShmem'].strip(), st['VmHWM'].strip()))
     if not as_json:
         print('run %d: %.3f s wall, %d calls%s' % (rep, dt, calls, '' if n_rows is None else ' -> %.3g events/s, %.3g calls/s (file to file)'
                                                    % (n_rows / dt, calls / dt)))
 if as_json:
     print(json.dumps({'seconds_all': times, 'calls': calls, 'tsv_bytes': os.path.getsize(paths['tsv']), 'diffs_bytes': os.path.getsize(out),
-                      'peak_rss_mb': resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}))
+                      'peak_rss_mb': peak_rss_mb()}))
