@@ -1423,6 +1423,8 @@ static_assert(EG >= MC_MAX_K, "one lane per slot");
 
 // Windows longer than WROWS rows (a handful per 10^8 rows, if any): k1_emit lists them, k1_rare walks them row by row,
 // one thread each, after the host has seen the count.
+__device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j);
+
 __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int64_t *__restrict__ rare_list, int64_t n_rare) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_rare) return;
@@ -1431,6 +1433,7 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
     const NbDesc d = A.desc[P.nb];
     RowSrc S{A.T.pos, A.T.evmu, A.T.flags, false, 0.0};
     emit_record(A, S, d, P.nb, P.r, P.m, q);
+    bigfix_record(A, q);            // (a slot of more than 128 events: finished here, not by a pass of k1_bigfix over all records)
 }
 
 // (six waves per SIMD: the register allocator fits 80 VGPRs without scratch; the kernel's time is rounds x latency, so resident
@@ -1659,7 +1662,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // window that reaches behind the rows in front, a run of more than 128 events, the stray event of a palindromic first site
 // row, more name blocks than the table holds) goes to the row-by-row kernel like k1_emit's long windows.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ET = 1024;            // rows per piece
+#ifndef MC_ET
+#define MC_ET 1024
+#endif
+constexpr int ET = MC_ET;           // rows per piece
 constexpr int EH = 128;             // rows in front of the piece that are staged with it
 constexpr int ER = ET + EH;
 constexpr int E_THREADS = 256;
@@ -1668,234 +1674,268 @@ constexpr int E_MAXB = 16;          // name blocks per staged range
 constexpr uint8_t RUN_WIDE = 1, RUN_UNUSABLE = 2;
 static_assert(TILE % ET == 0, "whole pieces per tile");
 
+struct RunBlock {                   // a name block that overlaps the staged rows (staged indices), and what its windows need of it
+    int end, lb, id, seg;           // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
+    int contig_len, stray_q;
+    uint32_t xflags;
+    int64_t mask_off, seq_off;
+};
+
 __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payload *__restrict__ sorted) {
     __shared__ int32_t s_pos[ER], s_d[ER];
-    __shared__ uint8_t s_fl[ER];                // flag byte; later bit 7: the row is in a run (unfiltered, tested row of a regular block)
+    __shared__ uint8_t s_fl[ER];                // flag byte; bit 7: the row is in a run (unfiltered, tested row of a regular block)
     __shared__ uint16_t s_rid[ER];              // run of the row
     __shared__ double s_mean[ER];
     __shared__ int32_t s_rpos[ER];
     __shared__ uint16_t s_rrow[ER];             // first row of the run (staged index)
     __shared__ uint8_t s_rfl[ER];               // RUN_*
-    __shared__ int s_bbeg[E_MAXB], s_bend[E_MAXB], s_blb[E_MAXB], s_bid[E_MAXB];       // name blocks of the staged range (staged indices)
+    __shared__ RunBlock s_blk[E_MAXB];
     __shared__ int s_nblk, s_wsum[E_THREADS / 64];
     const DevTable &T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
-    const int64_t tile = blockIdx.x;
-    const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
-    const int64_t first_rec = tile_slot(A.tile_local, A.group_sum, tile, lane);
+    constexpr int PIECES = TILE / ET;
+    const int64_t tile = blockIdx.x / PIECES;
     const int n_win = A.tile_cnt[tile];
     if (n_win == 0) return;
+    const int64_t s0 = tile * TILE + (int64_t)(blockIdx.x % PIECES) * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
+    if (s0 >= T.n_rows) return;
+    const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
+    const int64_t first_rec = tile_slot(A.tile_local, A.group_sum, tile, lane);
     const int k = A.k;
-    const int64_t t0 = tile * TILE;
-    for (int sub = 0; sub < TILE / ET; ++sub) {
-        const int64_t s0 = t0 + (int64_t)sub * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
-        if (s0 >= T.n_rows) break;
-        const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
-        const int nst = (int)(s1 - h0);
-        __syncthreads();                            // (the previous piece's tables are rewritten)
-        // ---- the rows ----
+    const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
+    const int nst = (int)(s1 - h0);
+    // (the tile's payloads are in file order; this thread's first one sets out now and is long there when the run table stands)
+    Payload P0;
+    P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
+    if (tid < n_win && first_rec + tid < n_rec) P0 = sorted[first_rec + tid];
+    // ---- the rows ----
+    for (int i = tid; i < nst; i += E_THREADS) {
+        const int2 e = T.evmu[h0 + i];
+        s_pos[i] = T.pos[h0 + i];
+        s_d[i] = e.x - e.y;
+        s_fl[i] = T.flags[h0 + i] & 0x7Fu;
+    }
+    // ---- the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before
+    // began in (the staged rows begin at most EH rows in front of this tile), all at once ----
+    if (tid == 0) s_nblk = 0;
+    __syncthreads();
+    if (wave == 0) {
+        const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
+        const int b = bfrom + lane;
+        bool over = false, ends_early = false;
+        RunBlock rb;
+        if (b < T.n_nb) {
+            const NbDesc *dp = A.desc + b;
+            const int64_t rbeg = dp->row_begin, rend = dp->row_end;
+            over = rbeg < s1 && rend > h0;
+            ends_early = rend < s1 && b + 1 < T.n_nb;          // (the block behind this one begins before the piece ends)
+            if (over) {
+                rb.end = (int)min(rend - h0, (int64_t)nst);
+                // first row that belongs to a run: the block's first tested row (rows in front of it, and blocks that are not
+                // regular, are in no run)
+                rb.lb = dp->mode == MODE_REGULAR ? (int)max(max(rbeg, dp->first()) - h0, (int64_t)-1) : nst;
+                rb.id = b;
+                rb.seg = T.nb_seg_begin[b];
+                rb.contig_len = dp->contig_len;
+                rb.stray_q = dp->stray_q;
+                rb.xflags = dp->xflags;
+                rb.mask_off = dp->mask_off;
+                rb.seq_off = A.R.seq_off[dp->contig];
+            }
+        }
+        const unsigned long long bal = __ballot(over);
+        // (blocks are in row order: the overlapping ones are consecutive lanes; one behind the 64 looked at -- reads of a dozen
+        // rows -- makes the table unusable, like more than E_MAXB of them)
+        const int n = __popcll(bal), at = __popcll(bal & ((1ull << lane) - 1ull));
+        const bool more_behind = (__ballot(ends_early) >> 63) & 1ull;
+        if (over && at < E_MAXB) s_blk[at] = rb;
+        if (lane == 0) s_nblk = more_behind ? E_MAXB + 1 : n;
+    }
+    __syncthreads();
+    const int nblk = s_nblk;
+    const bool usable = nblk <= E_MAXB;
+    int n_runs = 0;
+    if (usable) {
+        // ---- which rows are in runs ----
         for (int i = tid; i < nst; i += E_THREADS) {
-            const int2 e = T.evmu[h0 + i];
-            s_pos[i] = T.pos[h0 + i];
-            s_d[i] = e.x - e.y;
-            s_fl[i] = T.flags[h0 + i] & 0x7Fu;
-        }
-        // ---- the name blocks that overlap the staged rows ----
-        if (tid == 0) {
-            int b = T.tile_nb[tile];
-            while (b > 0 && A.desc[b].row_begin > h0) --b;
-            int nb = 0;
-            for (; b < T.n_nb && nb <= E_MAXB; ++b) {
-                const NbDesc *dp = A.desc + b;
-                if (dp->row_begin >= s1) break;
-                if (dp->row_end <= h0) continue;
-                if (nb < E_MAXB) {
-                    s_bbeg[nb] = (int)max(dp->row_begin - h0, (int64_t)-1);          // (-1: the block began before the staged rows)
-                    s_bend[nb] = (int)min(dp->row_end - h0, (int64_t)nst);
-                    // first row that belongs to a run: the block's first tested row (rows in front of it, and blocks that are not
-                    // regular, are in no run)
-                    s_blb[nb] = dp->mode == MODE_REGULAR ? (int)max(max(dp->row_begin, dp->first()) - h0, (int64_t)-1) : nst;
-                    s_bid[nb] = b;
-                }
-                ++nb;
-            }
-            s_nblk = nb;
+            int j = 0;
+            while (j + 1 < nblk && i >= s_blk[j].end) ++j;
+            const bool in = i >= max(s_blk[j].lb, 0) && i < s_blk[j].end && !(s_fl[i] & MC_F_MODEL_N);
+            if (in) s_fl[i] |= 0x80u;
         }
         __syncthreads();
-        const int nblk = s_nblk;
-        const bool usable = nblk <= E_MAXB;
-        int n_runs = 0;
-        if (usable) {
-            // ---- which rows are in runs ----
-            for (int i = tid; i < nst; i += E_THREADS) {
-                int j = 0;
-                while (j + 1 < nblk && i >= s_bend[j]) ++j;
-                const bool in = i >= max(s_blb[j], 0) && i < s_bend[j] && !(s_fl[i] & MC_F_MODEL_N);
-                if (in) s_fl[i] |= 0x80u;
+        // ---- run heads (the row before it in its block that is in a run lies at another position, or there is none), numbered:
+        // every thread takes E_RPT consecutive rows ----
+        const int r_lo = tid * E_RPT, r_hi = min(r_lo + E_RPT, nst);
+        uint32_t heads = 0;
+        int blk = 0;
+        for (int i = r_lo; i < r_hi; ++i) {
+            if (!(s_fl[i] & 0x80u)) continue;
+            while (blk + 1 < nblk && i >= s_blk[blk].end) ++blk;
+            const int lb = max(s_blk[blk].lb, 0);
+            int j = i - 1;
+            while (j >= lb && !(s_fl[j] & 0x80u)) --j;
+            if (j < lb || s_pos[j] != s_pos[i]) heads |= 1u << (i - r_lo);
+        }
+        int mine = __popc(heads), incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int base = incl - mine;
+        for (int w = 0; w < E_THREADS / 64; ++w) { if (w < wave) base += s_wsum[w]; n_runs += s_wsum[w]; }
+        // (a row in a run that is no head belongs to the run of the last head before it: inside the thread's rows, or the
+        // last run of the rows before them)
+        int cur = base - 1;
+        for (int i = r_lo; i < r_hi; ++i) {
+            if (heads & (1u << (i - r_lo))) {
+                ++cur;
+                s_rrow[cur] = (uint16_t)i;
+                s_rpos[cur] = s_pos[i];
             }
-            __syncthreads();
-            // ---- run heads (the row before it in its block that is in a run lies at another position, or there is none), numbered:
-            // every thread takes E_RPT consecutive rows ----
-            const int r_lo = tid * E_RPT, r_hi = min(r_lo + E_RPT, nst);
-            uint32_t heads = 0;
-            int blk = 0;
-            for (int i = r_lo; i < r_hi; ++i) {
-                if (!(s_fl[i] & 0x80u)) continue;
-                while (blk + 1 < nblk && i >= s_bend[blk]) ++blk;
-                const int lb = max(s_blb[blk], 0);
-                int j = i - 1;
-                while (j >= lb && !(s_fl[j] & 0x80u)) --j;
-                if (j < lb || s_pos[j] != s_pos[i]) heads |= 1u << (i - r_lo);
+            s_rid[i] = (uint16_t)max(cur, 0);
+        }
+        __syncthreads();
+        // ---- the mean of every run: its rows in file order, NumPy's pairwise order (np.mean, :186; values fl(d / 1e4), :286) ----
+        for (int R = tid; R < n_runs; R += E_THREADS) {
+            const int i0 = s_rrow[R], p = s_rpos[R];
+            int bj = 0;
+            while (bj + 1 < nblk && i0 >= s_blk[bj].end) ++bj;
+            const int end = s_blk[bj].end;
+            int n = 0;
+            for (int j = i0; j < end; ++j) {
+                if (!(s_fl[j] & 0x80u)) continue;
+                if (s_pos[j] != p) break;
+                ++n;
             }
-            int mine = __popc(heads), incl = mine;
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            int base = incl - mine;
-            for (int w = 0; w < E_THREADS / 64; ++w) { if (w < wave) base += s_wsum[w]; n_runs += s_wsum[w]; }
-            // (a row in a run that is no head belongs to the run of the last head before it: inside the thread's rows, or the
-            // last run of the rows before them)
-            int cur = base - 1;
-            for (int i = r_lo; i < r_hi; ++i) {
-                if (heads & (1u << (i - r_lo))) {
-                    ++cur;
-                    s_rrow[cur] = (uint16_t)i;
-                    s_rpos[cur] = s_pos[i];
-                }
-                s_rid[i] = (uint16_t)max(cur, 0);
-            }
-            __syncthreads();
-            // ---- the mean of every run: its rows in file order, NumPy's pairwise order (np.mean, :186; values fl(d / 1e4), :286) ----
-            for (int R = tid; R < n_runs; R += E_THREADS) {
-                const int i0 = s_rrow[R], p = s_rpos[R];
-                int bj = 0;
-                while (bj + 1 < nblk && i0 >= s_bend[bj]) ++bj;
-                const int end = s_bend[bj];
-                int n = 0;
-                for (int j = i0; j < end; ++j) {
+            uint8_t rf = 0;
+            // (the staged rows begin inside the block and this run begins with them: rows of the same position may lie in front)
+            if (i0 == 0 && h0 > 0 && s_blk[bj].lb < 0) rf |= RUN_UNUSABLE;
+            double mean = 0.0;
+            if (n > 128) rf |= RUN_UNUSABLE;                  // NumPy's pairwise recursion proper: the row-by-row kernel
+            else {
+                const int n8 = n >= 8 ? n - (n % 8) : 0;
+                double acc = -0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
+                int idx = 0;
+                for (int j = i0; idx < n; ++j) {
                     if (!(s_fl[j] & 0x80u)) continue;
-                    if (s_pos[j] != p) break;
-                    ++n;
+                    const double v = div1e4(s_d[j]);
+                    if (idx < n8) {
+                        switch (idx & 7) {
+                            case 0: r0 += v; break;
+                            case 1: r1 += v; break;
+                            case 2: r2 += v; break;
+                            case 3: r3 += v; break;
+                            case 4: r4 += v; break;
+                            case 5: r5 += v; break;
+                            case 6: r6 += v; break;
+                            default: r7 += v; break;
+                        }
+                        if (idx + 1 == n8) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                    } else acc += v;
+                    ++idx;
                 }
-                uint8_t rf = 0;
-                // (the staged rows begin inside the block and this run begins with them: rows of the same position may lie in front)
-                if (i0 == 0 && h0 > 0 && s_blb[bj] < 0) rf |= RUN_UNUSABLE;
-                double mean = 0.0;
-                if (n > 128) rf |= RUN_UNUSABLE;                  // NumPy's pairwise recursion proper: the row-by-row kernel
-                else {
-                    const int n8 = n >= 8 ? n - (n % 8) : 0;
-                    double acc = -0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
-                    int idx = 0;
-                    for (int j = i0; idx < n; ++j) {
-                        if (!(s_fl[j] & 0x80u)) continue;
-                        const double v = div1e4(s_d[j]);
-                        if (idx < n8) {
-                            switch (idx & 7) {
-                                case 0: r0 += v; break;
-                                case 1: r1 += v; break;
-                                case 2: r2 += v; break;
-                                case 3: r3 += v; break;
-                                case 4: r4 += v; break;
-                                case 5: r5 += v; break;
-                                case 6: r6 += v; break;
-                                default: r7 += v; break;
-                            }
-                            if (idx + 1 == n8) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                        } else acc += v;
-                        ++idx;
-                    }
-                    mean = (0.0 + acc) / (double)n;
-                    int32_t as_int;
-                    if (!slot_is_narrow(mean, &as_int)) rf |= RUN_WIDE;
-                }
-                s_mean[R] = mean;
-                s_rfl[R] = rf;
+                mean = (0.0 + acc) / (double)n;
+                int32_t as_int;
+                if (!slot_is_narrow(mean, &as_int)) rf |= RUN_WIDE;
+            }
+            s_mean[R] = mean;
+            s_rfl[R] = rf;
+        }
+    }
+    __syncthreads();
+    // ---- the windows whose last row lies in the piece (the tile's payloads are in file order: a contiguous stretch) ----
+    for (int w = tid; w < n_win; w += E_THREADS) {
+        const int64_t q = first_rec + w;
+        if (q >= n_rec) break;
+        const Payload P = w == tid ? P0 : sorted[q];
+        if (P.r < s0 || P.r >= s1) continue;
+        const int m = P.m;
+        int bj = 0;
+        if (usable) while (bj + 1 < nblk && s_blk[bj].id != P.nb) ++bj;
+        // (what the info word needs from the reference -- the character after the 'M' -- requested before the runs are looked up)
+        const bool rev = P.flags & PF_REV;
+        bool edge = true;
+        uint32_t ctx_word = 0;
+        unsigned char ctx_base = 0;
+        if (usable && !(P.flags & PF_EXTRA)) {
+            const RunBlock &B0 = s_blk[bj];
+            const int64_t L = B0.contig_len;
+            edge = m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L;
+            if (!edge) {
+                const int at = rev ? m - 1 : m + 1;
+                ctx_word = ((rev ? A.R.mr : A.R.mf) + B0.mask_off)[at >> 5];
+                ctx_base = (A.R.seq + B0.seq_off)[at];
             }
         }
-        __syncthreads();
-        // ---- the windows whose last row lies in the piece (the tile's payloads are in file order: a contiguous stretch) ----
-        for (int w = tid; w < n_win; w += E_THREADS) {
-            const int64_t q = first_rec + w;
-            if (q >= n_rec) break;
-            const Payload P = sorted[q];
-            if (P.r < s0 || P.r >= s1) continue;
-            const int m = P.m;
-            if (P.flags & PF_EXTRA) {                   // the one-event '+' window of a palindromic first site row (R5)
-                for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
-                A.O.wmask[q] = 0;
-                A.O.site_pos[q] = m;
-                A.O.site_seg[q] = T.nb_seg_begin[P.nb];
-                A.O.close_row[q] = P.close_row;
-                A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
-                A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
-                continue;
-            }
-            const NbDesc *dp = A.desc + P.nb;
-            bool rare = !usable;
-            double f[MC_MAX_K];
-            uint32_t have = 0, wide = 0;
-#pragma unroll
-            for (int s = 0; s < MC_MAX_K; ++s) f[s] = 0.0;
-            if (!rare) {
-                if ((P.flags & PF_STRAY) && m - dp->stray_q >= 0 && m - dp->stray_q < k) rare = true;     // (the stray event is first in its slot)
-                int bj = 0;
-                while (bj + 1 < nblk && s_bid[bj] != P.nb) ++bj;
-                const int lb = s_blb[bj];                      // (< 0: the block's tested rows begin before the staged rows)
-                const int R = s_rid[(int)(P.r - h0)];
-                for (int t = 0; t < k && !rare; ++t) {
-                    const int Rt = R - t;
-                    if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
-                    if ((int)s_rrow[Rt] < max(lb, 0)) break;           // a run of the block before
-                    const int qpos = s_rpos[Rt];
-                    if (qpos < m - k + 1) break;
-                    const uint8_t rf = s_rfl[Rt];
-                    if (rf & RUN_UNUSABLE) { rare = true; break; }
-                    const int slot = m - qpos;
-#pragma unroll
-                    for (int s = 0; s < MC_MAX_K; ++s)
-                        if (s == slot) f[s] = s_mean[Rt];
-                    have |= 1u << slot;
-                    if (rf & RUN_WIDE) wide |= 1u << slot;
-                }
-            }
-            if (rare) { A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q; continue; }
-            const uint32_t kbits = (1u << k) - 1u, empties = ~have & kbits;
-            const bool too_many = __popc(empties) > A.skip_thresh;
-            const bool rev = P.flags & PF_REV;
-            uint32_t info = rev ? MC_I_REV : 0u, wmask = 0;
-            if (too_many) {
-                info |= MC_I_TOO_MANY;
-                for (int s = 0; s < k; ++s) A.O.feats[q * k + s] = 0.0;
-            } else {
-#pragma unroll
-                for (int s = 0; s < MC_MAX_K; ++s) {
-                    if (s >= k) continue;
-                    const int dst = rev ? s : k - 1 - s;               // :187-188
-                    A.O.feats[q * k + dst] = f[s];
-                    if ((wide >> s) & 1u) wmask |= 1u << dst;
-                    if ((empties >> s) & 1u) info |= 1u << dst;        // feature dst came from an empty slot (:186)
-                }
-                // context[k], the character after the 'M', picks the sub-model (:197)
-                const int64_t L = dp->contig_len;
-                if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) info |= MC_I_EDGE;     // Python slicing decides
-                else {
-                    const uint32_t *bits = (rev ? A.R.mr : A.R.mf) + dp->mask_off;
-                    const uint8_t *seq = A.R.seq + A.R.seq_off[dp->contig];
-                    unsigned char ch;
-                    if (!rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-                    else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-                    info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-                }
-            }
-            if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
-            A.O.wmask[q] = (uint8_t)wmask;
+        if (P.flags & PF_EXTRA) {                   // the one-event '+' window of a palindromic first site row (R5)
+            for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
+            A.O.wmask[q] = 0;
             A.O.site_pos[q] = m;
             A.O.site_seg[q] = T.nb_seg_begin[P.nb];
             A.O.close_row[q] = P.close_row;
-            A.O.info[q] = info;
+            A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
             A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+            continue;
         }
+        bool rare = !usable;
+        double f[MC_MAX_K];
+        uint32_t have = 0, wide = 0;
+#pragma unroll
+        for (int s = 0; s < MC_MAX_K; ++s) f[s] = 0.0;
+        if (!rare) {
+            const RunBlock &B = s_blk[bj];
+            if ((P.flags & PF_STRAY) && m - B.stray_q >= 0 && m - B.stray_q < k) rare = true;     // (the stray event is first in its slot)
+            const int lb = B.lb;                           // (< 0: the block's tested rows begin before the staged rows)
+            const int R = s_rid[(int)(P.r - h0)];
+            for (int t = 0; t < k && !rare; ++t) {
+                const int Rt = R - t;
+                if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
+                if ((int)s_rrow[Rt] < max(lb, 0)) break;           // a run of the block before
+                const int qpos = s_rpos[Rt];
+                if (qpos < m - k + 1) break;
+                const uint8_t rf = s_rfl[Rt];
+                if (rf & RUN_UNUSABLE) { rare = true; break; }
+                const int slot = m - qpos;
+#pragma unroll
+                for (int s = 0; s < MC_MAX_K; ++s)
+                    if (s == slot) f[s] = s_mean[Rt];
+                have |= 1u << slot;
+                if (rf & RUN_WIDE) wide |= 1u << slot;
+            }
+        }
+        if (rare) { A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q; continue; }
+        const RunBlock &B = s_blk[bj];
+        const uint32_t kbits = (1u << k) - 1u, empties = ~have & kbits;
+        const bool too_many = __popc(empties) > A.skip_thresh;
+        uint32_t info = rev ? MC_I_REV : 0u, wmask = 0;
+        if (too_many) {
+            info |= MC_I_TOO_MANY;
+            for (int s = 0; s < k; ++s) A.O.feats[q * k + s] = 0.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < MC_MAX_K; ++s) {
+                if (s >= k) continue;
+                const int dst = rev ? s : k - 1 - s;               // :187-188
+                A.O.feats[q * k + dst] = f[s];
+                if ((wide >> s) & 1u) wmask |= 1u << dst;
+                if ((empties >> s) & 1u) info |= 1u << dst;        // feature dst came from an empty slot (:186)
+            }
+            // context[k], the character after the 'M', picks the sub-model (:197)
+            if (edge) info |= MC_I_EDGE;                            // the 2k-1 context leaves the contig: Python slicing decides
+            else {
+                const int at = rev ? m - 1 : m + 1;
+                const unsigned char ch = ((ctx_word >> (at & 31)) & 1u) ? 'M' : (rev ? comp_char(ctx_base) : ctx_base);
+                info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+            }
+        }
+        if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
+        A.O.wmask[q] = (uint8_t)wmask;
+        A.O.site_pos[q] = m;
+        A.O.site_seg[q] = B.seg;
+        A.O.close_row[q] = P.close_row;
+        A.O.info[q] = info;
+        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
 }
 
@@ -4242,10 +4282,10 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
     const bool runs = dense && !no_runs;
     if (ev_emit_end && MC_EVENTS_ON_KERNELS) {
-        if (runs) hipExtLaunchKernelGGL(k1_emit_runs, dim3((unsigned)T.n_tiles), dim3(E_THREADS), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
+        if (runs) hipExtLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
         else hipExtLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
     } else {
-        if (runs) hipLaunchKernelGGL(k1_emit_runs, dim3((unsigned)T.n_tiles), dim3(E_THREADS), 0, st, A, (const Payload *)sorted);
+        if (runs) hipLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, A, (const Payload *)sorted);
         else hipLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, A, (const Payload *)sorted);
         if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
     }
@@ -4336,7 +4376,6 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         if (h.n_rare) {
             hipLaunchKernelGGL(k1_rare, dim3((h.n_rare + 63) / 64), dim3(64), 0, c->stream, A, (const Payload *)c->payload_sorted,
                                (const int64_t *)c->rare_list, (int64_t)h.n_rare);
-            h.n_big = 1;                      // such a window may hold a slot of > 128 events: let k1_bigfix look
         }
         if (h.n_big && n > 0) hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, A, n);
         const bool irregular = h.irregular_pass == c->sync_pass_no;
@@ -4345,7 +4384,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         }
         // records -> pinned host memory; the slot means and indices travel while the classifier runs
         if (int rc = ensure_pinned(c, n, k)) return rc;
-        const bool early = n > 0 && !h.n_big && !irregular;
+        const bool early = n > 0 && !h.n_big && !h.n_rare && !irregular;      // (nothing on the ctx stream still writes records)
         if (early) { if (int rc = copy_out_features(c, n, k, c->copy_stream)) return rc; }
         if (prm->score && n > 0) {
             if (c->F.left)
@@ -4459,6 +4498,8 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     b.H = DevRecords();
     if (alloc_records(b.dev_allocs, b.O, cap, k)) return -10;
     if (dev_alloc(b.dev_allocs, &b.cnt, 1)) return -10;
+    // (the pass mark is only ever written by the kernels: whatever fresh device memory holds must not look like a pass number)
+    HIP_TRY(hipMemsetAsync(b.cnt, 0, sizeof(Counters), c->stream));
     if (cap >= (int64_t)1 << 31) {
         mc_set_error("mc_extract_features_async: %lld flush records per pass (call rows are 32 bits wide); use mc_extract_features",
                      (long long)cap);
