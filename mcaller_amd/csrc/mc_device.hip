@@ -1674,6 +1674,13 @@ constexpr int E_MAXB = 16;          // name blocks per staged range
 constexpr uint8_t RUN_WIDE = 1, RUN_UNUSABLE = 2;
 static_assert(TILE % ET == 0, "whole pieces per tile");
 
+#ifdef MC_ER_TRACE      // (variant build: 100 MHz time stamps of the phases of 1024 workgroups in the middle of the grid)
+__device__ unsigned long long g_er_trace[1024 * 8];
+#define ER_STAMP(i) do { if (tid == 0 && blockIdx.x >= 40000 && blockIdx.x < 41024) g_er_trace[(blockIdx.x - 40000) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ER_STAMP(i) do { } while (0)
+#endif
+
 struct RunBlock {                   // a name block that overlaps the staged rows (staged indices), and what its windows need of it
     int end, lb, id, seg;           // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
     int contig_len, stray_q;
@@ -1706,6 +1713,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
     const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
     const int nst = (int)(s1 - h0);
     // (the tile's payloads are in file order; this thread's first one sets out now and is long there when the run table stands)
+    ER_STAMP(0);
     Payload P0;
     P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
     if (tid < n_win && first_rec + tid < n_rec) P0 = sorted[first_rec + tid];
@@ -1753,6 +1761,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
         if (lane == 0) s_nblk = more_behind ? E_MAXB + 1 : n;
     }
     __syncthreads();
+    ER_STAMP(1);
     const int nblk = s_nblk;
     const bool usable = nblk <= E_MAXB;
     int n_runs = 0;
@@ -1765,6 +1774,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
             if (in) s_fl[i] |= 0x80u;
         }
         __syncthreads();
+        ER_STAMP(2);
         // ---- run heads (the row before it in its block that is in a run lies at another position, or there is none), numbered:
         // every thread takes E_RPT consecutive rows ----
         const int r_lo = tid * E_RPT, r_hi = min(r_lo + E_RPT, nst);
@@ -1796,6 +1806,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
             s_rid[i] = (uint16_t)max(cur, 0);
         }
         __syncthreads();
+        ER_STAMP(3);
         // ---- the mean of every run: its rows in file order, NumPy's pairwise order (np.mean, :186; values fl(d / 1e4), :286) ----
         for (int R = tid; R < n_runs; R += E_THREADS) {
             const int i0 = s_rrow[R], p = s_rpos[R];
@@ -1813,6 +1824,8 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
             if (i0 == 0 && h0 > 0 && s_blk[bj].lb < 0) rf |= RUN_UNUSABLE;
             double mean = 0.0;
             if (n > 128) rf |= RUN_UNUSABLE;                  // NumPy's pairwise recursion proper: the row-by-row kernel
+            else if (n == 1) mean = 0.0 + (-0.0 + div1e4(s_d[i0]));      // (every second run: one event, fl(d / 1e4) over 1 -- no sum, no
+                                                              // division, and narrow by construction; i0 is in the run: it is its head)
             else {
                 const int n8 = n >= 8 ? n - (n % 8) : 0;
                 double acc = -0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
@@ -1844,6 +1857,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
         }
     }
     __syncthreads();
+    ER_STAMP(4);
     // ---- the windows whose last row lies in the piece (the tile's payloads are in file order: a contiguous stretch) ----
     for (int w = tid; w < n_win; w += E_THREADS) {
         const int64_t q = first_rec + w;
@@ -1937,6 +1951,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
         A.O.info[q] = info;
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
+    ER_STAMP(5);
 }
 
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
@@ -4812,6 +4827,14 @@ static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uin
     (void)hipFree(ds);
     return 0;
 }
+
+#ifdef MC_ER_TRACE
+extern "C" int mc_debug_er_trace(unsigned long long *out, int64_t n_words) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_er_trace), (size_t)n_words * 8));
+    return 0;
+}
+#endif
 
 #ifdef MC_K2_TRACE
 extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
