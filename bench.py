@@ -61,7 +61,16 @@ def dist_setup(n_gpus):
     dist = None
     if world > 1:
         import torch.distributed as dist_mod      # plumbing only: rendezvous, barrier, max-over-ranks
-        dist_mod.init_process_group(backend='gloo', init_method='env://')
+        # (gloo announces its connections on STDOUT: the one JSON line is the only thing this program writes there)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist_mod.init_process_group(backend='gloo', init_method='env://')
+            dist_mod.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         dist = dist_mod
     return rank, world, local, dist
 
