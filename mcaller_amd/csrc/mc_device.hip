@@ -1382,7 +1382,9 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
 // Eight lanes per tile: the tile's payloads (arrival order) are gathered into file order, so that k1_emit reads them
 // with unit stride.  The first record slot of the tile = the windows of all earlier groups of 1024 tiles (summed by the
 // eight lanes) + the tile's offset inside its group.
-__global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ sorted) {
+// gather == 0 (dense references: k1_emit_runs takes a tile's payloads where the scan left them, a tile at a time): only the
+// total, and the checks.
+__global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ sorted, int gather) {
     MC_FRONT_OF_THE_QUEUE;
     const DevTable &T = A.T;
     constexpr int LG = 8;
@@ -1401,6 +1403,11 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     if (tile == T.n_tiles - 1 && l == 0) A.cnt->n_records = (unsigned long long)(first + c);   // the total
     if (c == 0) return;
     if (first + c > A.O.capacity) { if (l == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    if (!gather) {                                  // (a chunk the scan could not get: the pass is repeated with more room)
+        for (int ci = l; PT + (ci << A.chunk_shift) < c; ci += LG)
+            if (A.tile_chunk[tile * NCHUNK + ci] < 0) atomicOr(&A.cnt->overflow, 1u);
+        return;
+    }
     for (int j = l; j < c; j += LG) {
         long long slot = tile * PT + j;
         if (j >= PT) {
@@ -1410,6 +1417,13 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
         }
         sorted[first + j] = A.payload[slot];
     }
+}
+
+// the j-th payload of a tile, where the scan left it (arrival order inside a tile is file order)
+__device__ __forceinline__ Payload tile_payload(const K1Args &A, int64_t tile, int j) {
+    long long slot = tile * PT + j;
+    if (j >= PT) slot = A.tile_chunk[tile * NCHUNK + ((j - PT) >> A.chunk_shift)] + ((j - PT) & ((1 << A.chunk_shift) - 1));
+    return A.payload[slot];
 }
 
 // Eight lanes per closed window, lane s = slot s of the window (k <= 8).  First the eight lanes together look at the 64 rows
@@ -1688,7 +1702,7 @@ struct RunBlock {                   // a name block that overlaps the staged row
     int64_t mask_off, seq_off;
 };
 
-__global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payload *__restrict__ sorted) {
+__global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__restrict__ sorted) {
     __shared__ int32_t s_pos[ER], s_d[ER];
     __shared__ uint8_t s_fl[ER];                // flag byte; bit 7: the row is in a run (unfiltered, tested row of a regular block)
     __shared__ uint16_t s_rid[ER];              // run of the row
@@ -1716,7 +1730,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
     ER_STAMP(0);
     Payload P0;
     P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
-    if (tid < n_win && first_rec + tid < n_rec) P0 = sorted[first_rec + tid];
+    if (tid < n_win && first_rec + tid < n_rec) P0 = tile_payload(A, tile, tid);
     // ---- the rows ----
     for (int i = tid; i < nst; i += E_THREADS) {
         const int2 e = T.evmu[h0 + i];
@@ -1862,7 +1876,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
     for (int w = tid; w < n_win; w += E_THREADS) {
         const int64_t q = first_rec + w;
         if (q >= n_rec) break;
-        const Payload P = w == tid ? P0 : sorted[q];
+        const Payload P = w == tid ? P0 : tile_payload(A, tile, w);
         if (P.r < s0 || P.r >= s1) continue;
         const int m = P.m;
         int bj = 0;
@@ -1918,7 +1932,11 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, const Payloa
                 if (rf & RUN_WIDE) wide |= 1u << slot;
             }
         }
-        if (rare) { A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q; continue; }
+        if (rare) {                                 // (the row-by-row kernel looks its windows up in the ordered list)
+            sorted[q] = P;
+            A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
+            continue;
+        }
         const RunBlock &B = s_blk[bj];
         const uint32_t kbits = (1u << k) - 1u, empties = ~have & kbits;
         const bool too_many = __popc(empties) > A.skip_thresh;
@@ -4289,18 +4307,19 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted);
+    // (dense references: a workgroup per tile, the mean of every position once, see k1_emit_runs -- which takes the payloads where
+    // the scan left them: no gather)
+    static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
+    const bool runs = dense && !no_runs;
+    hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted, runs ? 0 : 1);
     // (ev_emit_end rides on the emit's own dispatch packet: a hipEventRecord behind it is a barrier packet of its own and
     // costs the queue 5-9 us)
     const dim3 emit_grid((unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs));
-    // (dense references: a workgroup per tile, the mean of every position once, see k1_emit_runs)
-    static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
-    const bool runs = dense && !no_runs;
     if (ev_emit_end && MC_EVENTS_ON_KERNELS) {
-        if (runs) hipExtLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
+        if (runs) hipExtLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, nullptr, ev_emit_end, 0, A, sorted);
         else hipExtLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, nullptr, ev_emit_end, 0, A, (const Payload *)sorted);
     } else {
-        if (runs) hipLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, A, (const Payload *)sorted);
+        if (runs) hipLaunchKernelGGL(k1_emit_runs, dim3((unsigned)(T.n_tiles * (TILE / ET))), dim3(E_THREADS), 0, st, A, sorted);
         else hipLaunchKernelGGL(k1_emit, emit_grid, dim3(256), 0, st, A, (const Payload *)sorted);
         if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
     }
