@@ -1679,11 +1679,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #ifndef MC_ET
 #define MC_ET 1024
 #endif
+#ifndef MC_ER_WAVES
+#define MC_ER_WAVES 6
+#endif
 constexpr int ET = MC_ET;           // rows per piece
-constexpr int EH = 128;             // rows in front of the piece that are staged with it
+#ifndef MC_EH
+#define MC_EH 128
+#endif
+constexpr int EH = MC_EH;           // rows in front of the piece that are staged with it
 constexpr int ER = ET + EH;
 constexpr int E_THREADS = 256;
-constexpr int E_RPT = (ER + E_THREADS - 1) / E_THREADS;     // staged rows per thread (contiguous)
 constexpr int E_MAXB = 16;          // name blocks per staged range
 constexpr uint8_t RUN_WIDE = 1, RUN_UNUSABLE = 2;
 static_assert(TILE % ET == 0, "whole pieces per tile");
@@ -1696,24 +1701,33 @@ __device__ unsigned long long g_er_trace[1024 * 8];
 #endif
 
 struct RunBlock {                   // a name block that overlaps the staged rows (staged indices), and what its windows need of it
-    int end, lb, id, seg;           // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
+    int end, lb, id, contig;        // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
     int contig_len, stray_q;
     uint32_t xflags;
-    int64_t mask_off, seq_off;
+    int64_t mask_off;
 };
 
-__global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__restrict__ sorted) {
-    __shared__ int32_t s_pos[ER], s_d[ER];
-    __shared__ uint8_t s_fl[ER];                // flag byte; bit 7: the row is in a run (unfiltered, tested row of a regular block)
-    __shared__ uint16_t s_rid[ER];              // run of the row
+// (the barriers of k1_emit_runs order LDS traffic only: __syncthreads() would also wait for every global load in flight -- the
+// rows a wave keeps in registers, what a window needs from the reference -- although nobody shares those)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int E_CHUNKS = ER / 64;                          // the staged rows in chunks of 64: a wave owns 5 or 4 consecutive ones
+constexpr int E_CPW = 5;
+static_assert(ER % 64 == 0 && E_THREADS == 256 && (E_CHUNKS + 3) / 4 <= E_CPW, "the chunks are split over 4 waves, at most E_CPW each");
+static_assert(ER < (1 << 12), "s_rrow keeps RUN_* above the row");
+constexpr int E_RF_SHIFT = 12;
+
+__global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER_WAVES, MC_ER_WAVES))) void k1_emit_runs(K1Args A, Payload *__restrict__ sorted) {
+    __shared__ uint16_t s_rid[ER];              // run at or before the row
+    __shared__ int32_t s_dc[ER + 8];            // (event - model) of the rows in runs, run after run
     __shared__ double s_mean[ER];
     __shared__ int32_t s_rpos[ER];
-    __shared__ uint16_t s_rrow[ER];             // first row of the run (staged index)
-    __shared__ uint8_t s_rfl[ER];               // RUN_*
+    __shared__ uint16_t s_rrow[ER];             // first row of the run (staged index) | RUN_* << 12
+    __shared__ uint16_t s_rc0[ER + 2];          // where the run's rows begin in s_dc; one more: where the last run's end
     __shared__ RunBlock s_blk[E_MAXB];
-    __shared__ int s_nblk, s_wsum[E_THREADS / 64];
+    __shared__ int s_nblk, s_wheads[E_THREADS / 64], s_wins[E_THREADS / 64];
     const DevTable &T = A.T;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     constexpr int PIECES = TILE / ET;
     const int64_t tile = blockIdx.x / PIECES;
@@ -1731,17 +1745,27 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
     Payload P0;
     P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
     if (tid < n_win && first_rec + tid < n_rec) P0 = tile_payload(A, tile, tid);
-    // ---- the rows ----
-    for (int i = tid; i < nst; i += E_THREADS) {
-        const int2 e = T.evmu[h0 + i];
-        s_pos[i] = T.pos[h0 + i];
-        s_d[i] = e.x - e.y;
-        s_fl[i] = T.flags[h0 + i] & 0x7Fu;
+    // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
+    // chunk in front of its first one (which row in a run came last before the wave's rows) ----
+    const int c_lo = (wave * E_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * E_CHUNKS + 3) >> 2;
+    int32_t rp[E_CPW], rd[E_CPW];
+    uint32_t rfl[E_CPW];
+#pragma unroll
+    for (int c = 0; c < E_CPW; ++c) {
+        const int i = (c_lo + c) * 64 + lane;
+        rp[c] = 0; rd[c] = 0; rfl[c] = MC_F_MODEL_N;
+        if (c_lo + c < c_hi && i < nst) {
+            const int2 e = T.evmu[h0 + i];
+            rp[c] = T.pos[h0 + i];
+            rd[c] = e.x - e.y;
+            rfl[c] = T.flags[h0 + i];
+        }
     }
+    int32_t pre_p = 0;
+    uint32_t pre_f = MC_F_MODEL_N;
+    if (c_lo > 0 && (c_lo - 1) * 64 + lane < nst) { pre_p = T.pos[h0 + (c_lo - 1) * 64 + lane]; pre_f = T.flags[h0 + (c_lo - 1) * 64 + lane]; }
     // ---- the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before
     // began in (the staged rows begin at most EH rows in front of this tile), all at once ----
-    if (tid == 0) s_nblk = 0;
-    __syncthreads();
     if (wave == 0) {
         const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
         const int b = bfrom + lane;
@@ -1758,12 +1782,11 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
                 // regular, are in no run)
                 rb.lb = dp->mode == MODE_REGULAR ? (int)max(max(rbeg, dp->first()) - h0, (int64_t)-1) : nst;
                 rb.id = b;
-                rb.seg = T.nb_seg_begin[b];
+                rb.contig = dp->contig;
                 rb.contig_len = dp->contig_len;
                 rb.stray_q = dp->stray_q;
                 rb.xflags = dp->xflags;
                 rb.mask_off = dp->mask_off;
-                rb.seq_off = A.R.seq_off[dp->contig];
             }
         }
         const unsigned long long bal = __ballot(over);
@@ -1774,103 +1797,150 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
         if (over && at < E_MAXB) s_blk[at] = rb;
         if (lane == 0) s_nblk = more_behind ? E_MAXB + 1 : n;
     }
-    __syncthreads();
+    lds_barrier();
     ER_STAMP(1);
     const int nblk = s_nblk;
     const bool usable = nblk <= E_MAXB;
+    // ---- what the info word of a window needs from the reference (the character after the 'M', the segment of its block):
+    // two trips, the first sets out now for this thread's first window, the second when the runs are numbered ----
+    struct WinCtx { int bj, seg, at; bool edge; uint32_t word; int64_t soff; unsigned char base; };
+    auto ctx_begin = [&](const Payload &P, WinCtx &X) {
+        X.bj = 0; X.seg = 0; X.at = 0; X.edge = true; X.word = 0; X.soff = 0; X.base = 0;
+        if (!usable || (P.flags & PF_EXTRA)) return;
+        while (X.bj + 1 < nblk && s_blk[X.bj].id != P.nb) ++X.bj;
+        const RunBlock &B0 = s_blk[X.bj];
+        const int m = P.m;
+        const int64_t L = B0.contig_len;
+        X.seg = T.nb_seg_begin[P.nb];
+        X.edge = m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L;
+        if (!X.edge) {
+            const bool rev = P.flags & PF_REV;
+            X.at = rev ? m - 1 : m + 1;
+            X.word = ((rev ? A.R.mr : A.R.mf) + B0.mask_off)[X.at >> 5];
+            X.soff = A.R.seq_off[B0.contig];
+        }
+    };
+    auto ctx_end = [&](WinCtx &X) { if (!X.edge) X.base = (A.R.seq + X.soff)[X.at]; };
+    const bool w0_mine = P0.r >= s0 && P0.r < s1;           // (no payload: r = -1)
+    WinCtx X0;
+    X0.bj = 0; X0.seg = 0; X0.at = 0; X0.edge = true; X0.word = 0; X0.soff = 0; X0.base = 0;
+    if (w0_mine) ctx_begin(P0, X0);
     int n_runs = 0;
     if (usable) {
-        // ---- which rows are in runs ----
-        for (int i = tid; i < nst; i += E_THREADS) {
-            int j = 0;
-            while (j + 1 < nblk && i >= s_blk[j].end) ++j;
-            const bool in = i >= max(s_blk[j].lb, 0) && i < s_blk[j].end && !(s_fl[i] & MC_F_MODEL_N);
-            if (in) s_fl[i] |= 0x80u;
-        }
-        __syncthreads();
-        ER_STAMP(2);
-        // ---- run heads (the row before it in its block that is in a run lies at another position, or there is none), numbered:
-        // every thread takes E_RPT consecutive rows ----
-        const int r_lo = tid * E_RPT, r_hi = min(r_lo + E_RPT, nst);
-        uint32_t heads = 0;
-        int blk = 0;
-        for (int i = r_lo; i < r_hi; ++i) {
-            if (!(s_fl[i] & 0x80u)) continue;
-            while (blk + 1 < nblk && i >= s_blk[blk].end) ++blk;
-            const int lb = max(s_blk[blk].lb, 0);
-            int j = i - 1;
-            while (j >= lb && !(s_fl[j] & 0x80u)) --j;
-            if (j < lb || s_pos[j] != s_pos[i]) heads |= 1u << (i - r_lo);
-        }
-        int mine = __popc(heads), incl = mine;
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int base = incl - mine;
-        for (int w = 0; w < E_THREADS / 64; ++w) { if (w < wave) base += s_wsum[w]; n_runs += s_wsum[w]; }
-        // (a row in a run that is no head belongs to the run of the last head before it: inside the thread's rows, or the
-        // last run of the rows before them)
-        int cur = base - 1;
-        for (int i = r_lo; i < r_hi; ++i) {
-            if (heads & (1u << (i - r_lo))) {
-                ++cur;
-                s_rrow[cur] = (uint16_t)i;
-                s_rpos[cur] = s_pos[i];
+        const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+        // ---- which row in a run came last before the wave's rows (none: row -1) ----
+        int carry_row = -1, carry_pos = 0;
+        for (int cc = c_lo - 1; cc >= 0; --cc) {
+            const int i = cc * 64 + lane;
+            int32_t p = pre_p;
+            uint32_t f = pre_f;
+            if (cc != c_lo - 1 && i < nst) { p = T.pos[h0 + i]; f = T.flags[h0 + i]; }
+            int bj = 0;
+            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+            const bool in = i >= max(s_blk[bj].lb, 0) && i < s_blk[bj].end && !(f & MC_F_MODEL_N);
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                const int top = 63 - __clzll(m);
+                carry_row = cc * 64 + top;
+                carry_pos = __shfl(p, top);
+                break;
             }
-            s_rid[i] = (uint16_t)max(cur, 0);
         }
-        __syncthreads();
+        // ---- the wave's rows: which are in runs, which begin one (the row before it in its block that is in a run lies at
+        // another position, or there is none) ----
+        unsigned long long inm[E_CPW], headm[E_CPW];
+        uint32_t cutm = 0;              // bit c: the lane's row of chunk c begins a run whose first rows may lie in front of the staged ones
+        int nh = 0, ni = 0, bj = 0;
+#pragma unroll
+        for (int c = 0; c < E_CPW; ++c) {
+            inm[c] = 0; headm[c] = 0;
+            if (c_lo + c >= c_hi) continue;
+            const int base = (c_lo + c) * 64, i = base + lane;
+            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+            const int lb = s_blk[bj].lb, lbm = max(lb, 0);
+            const bool in = i < nst && i >= lbm && i < s_blk[bj].end && !(rfl[c] & MC_F_MODEL_N);
+            const unsigned long long m = __ballot(in), below = m & lt;
+            const int pl = 63 - __clzll(below | 1ull);
+            int prow = base + pl, ppos = __shfl(rp[c], pl);
+            if (!below) { prow = carry_row; ppos = carry_pos; }
+            const bool alone = prow < lbm, head = in && (alone || ppos != rp[c]);
+            if (head && alone && lb < 0) cutm |= 1u << c;
+            const unsigned long long hm = __ballot(head);
+            inm[c] = m; headm[c] = hm;
+            nh += __popcll(hm); ni += __popcll(m);
+            if (m) {
+                const int top = 63 - __clzll(m);
+                carry_row = base + top;
+                carry_pos = __shfl(rp[c], top);
+            }
+        }
+        if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
+        lds_barrier();
+        ER_STAMP(2);
+        int hbase = 0, ibase = 0, n_in = 0;
+#pragma unroll
+        for (int w = 0; w < E_THREADS / 64; ++w) {
+            const int a = s_wheads[w], b2 = s_wins[w];
+            if (w < wave) { hbase += a; ibase += b2; }
+            n_runs += a; n_in += b2;
+        }
+        // ---- runs numbered in row order; the rows in runs packed run after run ----
+#pragma unroll
+        for (int c = 0; c < E_CPW; ++c) {
+            if (c_lo + c >= c_hi) continue;
+            const int i = (c_lo + c) * 64 + lane;
+            const int rid = hbase + __popcll(headm[c] & le) - 1, at = ibase + __popcll(inm[c] & lt);
+            if (i < nst) s_rid[i] = (uint16_t)max(rid, 0);
+            if ((inm[c] >> lane) & 1ull) s_dc[at] = rd[c];
+            if ((headm[c] >> lane) & 1ull) {
+                s_rrow[rid] = (uint16_t)(i | (((cutm >> c) & 1u) ? (RUN_UNUSABLE << E_RF_SHIFT) : 0));
+                s_rpos[rid] = rp[c];
+                s_rc0[rid] = (uint16_t)at;
+            }
+            hbase += __popcll(headm[c]); ibase += __popcll(inm[c]);
+        }
+        if (tid == 0) s_rc0[n_runs] = (uint16_t)n_in;
+        lds_barrier();
         ER_STAMP(3);
+        if (w0_mine) ctx_end(X0);
         // ---- the mean of every run: its rows in file order, NumPy's pairwise order (np.mean, :186; values fl(d / 1e4), :286) ----
         for (int R = tid; R < n_runs; R += E_THREADS) {
-            const int i0 = s_rrow[R], p = s_rpos[R];
-            int bj = 0;
-            while (bj + 1 < nblk && i0 >= s_blk[bj].end) ++bj;
-            const int end = s_blk[bj].end;
-            int n = 0;
-            for (int j = i0; j < end; ++j) {
-                if (!(s_fl[j] & 0x80u)) continue;
-                if (s_pos[j] != p) break;
-                ++n;
-            }
-            uint8_t rf = 0;
-            // (the staged rows begin inside the block and this run begins with them: rows of the same position may lie in front)
-            if (i0 == 0 && h0 > 0 && s_blk[bj].lb < 0) rf |= RUN_UNUSABLE;
             double mean = 0.0;
-            if (n > 128) rf |= RUN_UNUSABLE;                  // NumPy's pairwise recursion proper: the row-by-row kernel
-            else if (n == 1) mean = 0.0 + (-0.0 + div1e4(s_d[i0]));      // (every second run: one event, fl(d / 1e4) over 1 -- no sum, no
-                                                              // division, and narrow by construction; i0 is in the run: it is its head)
-            else {
-                const int n8 = n >= 8 ? n - (n % 8) : 0;
-                double acc = -0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0, r5 = 0.0, r6 = 0.0, r7 = 0.0;
-                int idx = 0;
-                for (int j = i0; idx < n; ++j) {
-                    if (!(s_fl[j] & 0x80u)) continue;
-                    const double v = div1e4(s_d[j]);
-                    if (idx < n8) {
-                        switch (idx & 7) {
-                            case 0: r0 += v; break;
-                            case 1: r1 += v; break;
-                            case 2: r2 += v; break;
-                            case 3: r3 += v; break;
-                            case 4: r4 += v; break;
-                            case 5: r5 += v; break;
-                            case 6: r6 += v; break;
-                            default: r7 += v; break;
-                        }
-                        if (idx + 1 == n8) acc = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                    } else acc += v;
-                    ++idx;
+            uint32_t rf = 0;
+            const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
+            const int d0 = s_dc[c0], d1 = s_dc[c0 + 1], d2 = s_dc[c0 + 2], d3 = s_dc[c0 + 3];     // (there is room behind the last row)
+            if (n > 128) { rf = RUN_UNUSABLE; mean = 0.0; }          // NumPy's pairwise recursion proper: the row-by-row kernel
+            else if (n >= 8) {
+                const int n8 = n - (n % 8);
+                double r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = 0.0;
+                for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) r[u] += div1e4(s_dc[c0 + j + u]);
                 }
+                double acc = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (int j = n8; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
                 mean = (0.0 + acc) / (double)n;
+            } else {
+                // (every second run is one event: fl(d / 1e4) over 1 -- no division, and narrow by construction)
+                double acc = -0.0 + div1e4(d0);
+                if (n > 1) acc += div1e4(d1);
+                if (n > 2) acc += div1e4(d2);
+                if (n > 3) acc += div1e4(d3);
+                for (int j = 4; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
+                mean = 0.0 + acc;
+                if (n > 1) mean = mean / (double)n;
+            }
+            if (n > 1 && n <= 128) {
                 int32_t as_int;
                 if (!slot_is_narrow(mean, &as_int)) rf |= RUN_WIDE;
             }
             s_mean[R] = mean;
-            s_rfl[R] = rf;
+            if (rf) s_rrow[R] |= (uint16_t)(rf << E_RF_SHIFT);
         }
     }
-    __syncthreads();
+    lds_barrier();
     ER_STAMP(4);
     // ---- the windows whose last row lies in the piece (the tile's payloads are in file order: a contiguous stretch) ----
     for (int w = tid; w < n_win; w += E_THREADS) {
@@ -1879,23 +1949,10 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
         const Payload P = w == tid ? P0 : tile_payload(A, tile, w);
         if (P.r < s0 || P.r >= s1) continue;
         const int m = P.m;
-        int bj = 0;
-        if (usable) while (bj + 1 < nblk && s_blk[bj].id != P.nb) ++bj;
-        // (what the info word needs from the reference -- the character after the 'M' -- requested before the runs are looked up)
         const bool rev = P.flags & PF_REV;
-        bool edge = true;
-        uint32_t ctx_word = 0;
-        unsigned char ctx_base = 0;
-        if (usable && !(P.flags & PF_EXTRA)) {
-            const RunBlock &B0 = s_blk[bj];
-            const int64_t L = B0.contig_len;
-            edge = m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L;
-            if (!edge) {
-                const int at = rev ? m - 1 : m + 1;
-                ctx_word = ((rev ? A.R.mr : A.R.mf) + B0.mask_off)[at >> 5];
-                ctx_base = (A.R.seq + B0.seq_off)[at];
-            }
-        }
+        WinCtx X = X0;
+        if (w != tid) { ctx_begin(P, X); ctx_end(X); }      // (a tile with more windows than the workgroup has threads)
+        const int bj = X.bj;
         if (P.flags & PF_EXTRA) {                   // the one-event '+' window of a palindromic first site row (R5)
             for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
             A.O.wmask[q] = 0;
@@ -1907,10 +1964,7 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
             continue;
         }
         bool rare = !usable;
-        double f[MC_MAX_K];
         uint32_t have = 0, wide = 0;
-#pragma unroll
-        for (int s = 0; s < MC_MAX_K; ++s) f[s] = 0.0;
         if (!rare) {
             const RunBlock &B = s_blk[bj];
             if ((P.flags & PF_STRAY) && m - B.stray_q >= 0 && m - B.stray_q < k) rare = true;     // (the stray event is first in its slot)
@@ -1919,15 +1973,15 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
             for (int t = 0; t < k && !rare; ++t) {
                 const int Rt = R - t;
                 if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
-                if ((int)s_rrow[Rt] < max(lb, 0)) break;           // a run of the block before
+                const int rr = s_rrow[Rt];
+                if ((rr & ((1 << E_RF_SHIFT) - 1)) < max(lb, 0)) break;           // a run of the block before
                 const int qpos = s_rpos[Rt];
                 if (qpos < m - k + 1) break;
-                const uint8_t rf = s_rfl[Rt];
+                const int rf = rr >> E_RF_SHIFT;
                 if (rf & RUN_UNUSABLE) { rare = true; break; }
                 const int slot = m - qpos;
-#pragma unroll
-                for (int s = 0; s < MC_MAX_K; ++s)
-                    if (s == slot) f[s] = s_mean[Rt];
+                if (slot < 0) continue;                    // (the run of the closing row itself, behind the site)
+                A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];         // :187-188 (a window that turns out rare is written again)
                 have |= 1u << slot;
                 if (rf & RUN_WIDE) wide |= 1u << slot;
             }
@@ -1937,34 +1991,29 @@ __global__ __launch_bounds__(E_THREADS) void k1_emit_runs(K1Args A, Payload *__r
             A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
             continue;
         }
-        const RunBlock &B = s_blk[bj];
         const uint32_t kbits = (1u << k) - 1u, empties = ~have & kbits;
         const bool too_many = __popc(empties) > A.skip_thresh;
         uint32_t info = rev ? MC_I_REV : 0u, wmask = 0;
-        if (too_many) {
-            info |= MC_I_TOO_MANY;
-            for (int s = 0; s < k; ++s) A.O.feats[q * k + s] = 0.0;
-        } else {
-#pragma unroll
-            for (int s = 0; s < MC_MAX_K; ++s) {
-                if (s >= k) continue;
-                const int dst = rev ? s : k - 1 - s;               // :187-188
-                A.O.feats[q * k + dst] = f[s];
-                if ((wide >> s) & 1u) wmask |= 1u << dst;
-                if ((empties >> s) & 1u) info |= 1u << dst;        // feature dst came from an empty slot (:186)
-            }
+        for (uint32_t z = too_many ? kbits : empties; z; z &= z - 1u) {
+            const int s = __ffs(z) - 1;
+            A.O.feats[q * k + (rev ? s : k - 1 - s)] = 0.0;
+        }
+        if (too_many) info |= MC_I_TOO_MANY;
+        else {
+            // (slot s is feature s on the reverse strand, k - 1 - s on the forward one)
+            wmask = rev ? wide : __brev(wide) >> (32 - k);
+            info |= rev ? empties : __brev(empties) >> (32 - k);   // feature dst came from an empty slot (:186)
             // context[k], the character after the 'M', picks the sub-model (:197)
-            if (edge) info |= MC_I_EDGE;                            // the 2k-1 context leaves the contig: Python slicing decides
+            if (X.edge) info |= MC_I_EDGE;                          // the 2k-1 context leaves the contig: Python slicing decides
             else {
-                const int at = rev ? m - 1 : m + 1;
-                const unsigned char ch = ((ctx_word >> (at & 31)) & 1u) ? 'M' : (rev ? comp_char(ctx_base) : ctx_base);
+                const unsigned char ch = ((X.word >> (X.at & 31)) & 1u) ? 'M' : (rev ? comp_char(X.base) : X.base);
                 info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
             }
         }
         if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
         A.O.wmask[q] = (uint8_t)wmask;
         A.O.site_pos[q] = m;
-        A.O.site_seg[q] = B.seg;
+        A.O.site_seg[q] = X.seg;
         A.O.close_row[q] = P.close_row;
         A.O.info[q] = info;
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);

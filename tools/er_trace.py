@@ -23,7 +23,7 @@ L.mc_debug_er_trace.argtypes = [C.c_void_p, C.c_int64]
 assert L.mc_debug_er_trace(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(1024, 8).astype(np.int64)
 ok = t[:, 5] > 0
-names = ['rows + table (barrier)', 'rows marked', 'heads numbered', 'means', 'windows']
+names = ['rows + table (barrier)', 'heads found', 'runs numbered', 'means', 'windows']
 for i, nm in enumerate(names):
     d = (t[ok, i + 1] - t[ok, i]) * 10
     print('%-24s mean %7.0f ns  p90 %7.0f  max %7.0f' % (nm, d.mean(), np.percentile(d, 90), d.max()))
