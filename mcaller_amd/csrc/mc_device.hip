@@ -165,11 +165,14 @@ struct DevForest {
     uint8_t *sub_of_char = nullptr;
 };
 
-constexpr int NSHARD = 8;  // record-slot counters, one per blockIdx & 7 (= XCD): no single hot atomic
+// Payload-slot counters (k1_scan's TileSlots::reserve), one per tile & (NSHARD - 1), every one in a cache line of its own: a
+// one-base motif has every tile fetch a chunk of slots, and 6*10^4 atomics on the eight counters of ONE line took 0.4 ms of the
+// scan's 0.76 -- they are served one after the other, ~7 ns each, wherever in the line they land.  (Tables of fewer than 1024
+// tiles use eight of them: every counter owns an equal share of the payload slots.)
+constexpr int NSHARD = 64, SHARD_PAD = 16;
 
 struct Counters {          // device-side status block
     unsigned long long n_records;
-    unsigned long long shard[NSHARD];
     unsigned int overflow;
     unsigned int violation;    // first pass over a table: a row contradicts what a regular block was classified on (the pass is
                                // repeated on the table's complete validation flags)
@@ -182,6 +185,8 @@ struct Counters {          // device-side status block
     // special iff this equals its own number
     unsigned long long irregular_pass;
     unsigned long long end_of_head;   // (k_pack copies everything before this field to the host)
+    unsigned long long pad_to_line[SHARD_PAD];
+    unsigned long long shard[NSHARD * SHARD_PAD];
 };
 
 // The small kernels on the ctx stream's critical path (strand resolve, tile descriptors, the ordering of the payloads) run
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable 
     if (blockIdx.x == 0) {             // (everything but the pass mark, which is only ever written)
         unsigned int *w = reinterpret_cast<unsigned int *>(cnt);
         for (unsigned i = threadIdx.x; i < offsetof(Counters, irregular_pass) / 4; i += blockDim.x) w[i] = 0u;
+        for (unsigned i = threadIdx.x; i < NSHARD; i += blockDim.x) cnt->shard[i * SHARD_PAD] = 0ull;
     }
     const int b = W == 1 ? (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -619,6 +625,8 @@ struct K1Args {
     long long payload_cap;
     long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of (1 << chunk_shift) behind its own PT slots
     int chunk_shift;              // 6: chunks of 64 (sparse motifs); 8: chunks of 256 (a one-base motif: ~270 windows per tile)
+    int shard_shift;              // the chunk counters in use: 1 << shard_shift
+    int shard_mask;               // ... less one
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
@@ -666,7 +674,7 @@ struct ScanGlobals {
 struct CloseRes { int64_t row; int pos; int ns; };
 struct RowRes { int64_t cr; int m, cp, closed; uint32_t pf; };
 
-__device__ __noinline__ CloseRes far_close(const ScanGlobals G, int nb_abs, int64_t my_end, int64_t r) {
+__device__ __forceinline__ CloseRes far_close_body(const ScanGlobals &G, int nb_abs, int64_t my_end, int64_t r) {
     DevTable T;
     T.n_rows = G.n_rows; T.flags = const_cast<uint8_t *>(G.flags); T.pos = const_cast<int32_t *>(G.pos);
     T.nb_row_begin = const_cast<int64_t *>(G.nb_row_begin); T.n_nb = G.n_nb;
@@ -676,6 +684,7 @@ __device__ __noinline__ CloseRes far_close(const ScanGlobals G, int nb_abs, int6
     c.ns = ns ? 1 : 0;
     return c;
 }
+__device__ __noinline__ CloseRes far_close(const ScanGlobals G, int nb_abs, int64_t my_end, int64_t r) { return far_close_body(G, nb_abs, my_end, r); }
 
 // word w of a strand mask of n_words words (0 outside)
 __device__ __forceinline__ uint32_t mask_word_global(const uint32_t *__restrict__ gbits, int64_t n_words, int64_t w) {
@@ -690,20 +699,25 @@ __device__ __forceinline__ int site_off_global(const uint32_t *__restrict__ gbit
 }
 
 // Is `row` (unfiltered, inside its regular name block) the last row of a window?  Everything from global memory.
-__device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbits, int contig_len, int nb_abs, int64_t my_end,
-                                       int64_t row) {
+// (_body: inlined where the caller has many values alive -- they would all have to sit in the callee-saved half of the
+// registers across a call: the one-base-motif scan went from 120 to 180 registers with the call in its row loop)
+__device__ __forceinline__ RowRes far_row_body(const ScanGlobals &G, const uint32_t *gbits, int contig_len, int nb_abs, int64_t my_end,
+                                               int64_t row) {
     RowRes res;
     res.cr = 0; res.m = 0; res.cp = 0; res.closed = 0; res.pf = 0;
     const int p = G.pos[row];
     const int o = site_off_global(gbits, contig_len, G.k, p);
     if (o < 0) return res;
     res.m = p + o;
-    const CloseRes c = far_close(G, nb_abs, my_end, row);
+    const CloseRes c = far_close_body(G, nb_abs, my_end, row);
     res.cr = c.row; res.cp = c.pos;
     res.closed = (c.row >= 0 && (c.ns || c.pos > res.m)) ? 1 : 0;
     if (c.ns) res.pf |= PF_CLOSE_NS;
     if (!c.ns && c.pos <= res.m + G.skip_thresh + 1 && site_off_global(gbits, contig_len, G.k, c.pos) > 0) res.pf |= PF_MULTI;
     return res;
+}
+__device__ __noinline__ RowRes far_row(const ScanGlobals G, const uint32_t *gbits, int contig_len, int nb_abs, int64_t my_end, int64_t row) {
+    return far_row_body(G, gbits, contig_len, nb_abs, my_end, row);
 }
 
 constexpr int PT = 16;              // payload slots reserved per tile; further chunks of 64 come from an atomic
@@ -736,6 +750,13 @@ struct TileSlots {
     long long *s_chunk;           // [NCHUNK] first slot of the tile's chunks (LDS)
     int total;                    // windows closed so far
     int lane;
+    long long ahead = -1;         // (lane 0) the shard counter's value before a chunk fetched ahead of need (take_ahead), -1: none
+    // A one-base motif: every tile needs a chunk, and the wave would wait 3 us for the counter's answer when it gets there -- it
+    // asks at once and looks at the answer when the first chunk is due.  (A tile that closes fewer than PT windows leaves the
+    // chunk unused: the payload array has a chunk to spare for every tile.)
+    __device__ __forceinline__ void take_ahead() {
+        if (lane == 0) ahead = (long long)atomicAdd(&A.cnt->shard[(int)(tile & A.shard_mask) * SHARD_PAD], 1ull << A.chunk_shift);
+    }
     __device__ __forceinline__ long long slot_of(int rank) const {
         const int cs = A.chunk_shift;
         return rank < PT ? tile * PT + rank : s_chunk[(rank - PT) >> cs] + ((rank - PT) & ((1 << cs) - 1));
@@ -745,15 +766,26 @@ struct TileSlots {
         const int c0 = total <= PT ? 0 : (total - PT + cm) >> cs, c1 = new_total <= PT ? 0 : (new_total - PT + cm) >> cs;
         if (c1 > c0) {
             if (lane == 0) {
-                const int n = c1 - c0;
-                const int sh = (int)(tile & (NSHARD - 1));
-                const long long per = (A.payload_cap - A.T.n_tiles * PT) / NSHARD;
-                const long long off = (long long)atomicAdd(&A.cnt->shard[sh], (unsigned long long)n << cs);
-                long long base = A.T.n_tiles * PT + sh * per + off;
-                if (off + ((long long)n << cs) > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
-                for (int c = c0; c < c1; ++c) {
-                    s_chunk[c] = base < 0 ? -1 : base + ((long long)(c - c0) << cs);
-                    A.tile_chunk[tile * NCHUNK + c] = s_chunk[c];
+                const int sh = (int)(tile & A.shard_mask);
+                const long long per = (A.payload_cap - A.T.n_tiles * PT) >> A.shard_shift;      // (a shift: a 64-bit division is a hundred instructions)
+                int cf = c0;
+                if (ahead >= 0) {                   // the chunk fetched ahead is the first of these
+                    const long long base = ahead + (1ll << cs) > per ? -1 : A.T.n_tiles * PT + sh * per + ahead;
+                    if (base < 0) atomicOr(&A.cnt->overflow, 1u);
+                    s_chunk[cf] = base;
+                    A.tile_chunk[tile * NCHUNK + cf] = base;
+                    ahead = -1;
+                    ++cf;
+                }
+                if (cf < c1) {
+                    const int n = c1 - cf;
+                    const long long off = (long long)atomicAdd(&A.cnt->shard[sh * SHARD_PAD], (unsigned long long)n << cs);
+                    long long base = A.T.n_tiles * PT + sh * per + off;
+                    if (off + ((long long)n << cs) > per) { atomicOr(&A.cnt->overflow, 1u); base = -1; }
+                    for (int c = cf; c < c1; ++c) {
+                        s_chunk[c] = base < 0 ? -1 : base + ((long long)(c - cf) << cs);
+                        A.tile_chunk[tile * NCHUNK + c] = s_chunk[c];
+                    }
                 }
             }
             // lane 0's s_chunk entries, before any lane reads them: LDS operations of one wave execute in order, so this only
@@ -867,14 +899,20 @@ __device__ __forceinline__ void validate_rows_slowly(const K1Args &A, int nb_fro
 // there is no scalar byte load, and the compiler will not use scalar loads at all for memory that a store of the kernel might
 // alias -- and the wait for a vector load (vmcnt counts in order) is a wait for every column load in flight as well.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <typename T_>
+__device__ __forceinline__ const T_ *uniform_ptr(const T_ *p) {       // (a pointer that is the same in all lanes, said so to the compiler:
+    const uint64_t v = reinterpret_cast<uint64_t>(p);                  // out-of-line callers get theirs through a vector register)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const T_ *>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ NbDesc desc_uniform(const NbDesc *desc, int b) {
-    const NbDesc *p = desc + __builtin_amdgcn_readfirstlane(b);
+    const NbDesc *p = uniform_ptr(desc) + __builtin_amdgcn_readfirstlane(b);
     union { u32x16 w; NbDesc d; } u;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u.w) : "s"(p));
     return u.d;
 }
 __device__ __forceinline__ int64_t desc_row_end_uniform(const NbDesc *desc, int b) {
-    const int64_t *p = &(desc + __builtin_amdgcn_readfirstlane(b))->row_end;
+    const int64_t *p = &(uniform_ptr(desc) + __builtin_amdgcn_readfirstlane(b))->row_end;
     int64_t v;
     asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
     return v;
@@ -919,6 +957,156 @@ struct ChunkCols {
         }
     }
 };
+
+// The rows of one regular name block inside a chunk, for a one-base motif (k1_scan<CG_DENSE>): four rows in five are site rows
+// there and every unit would be listed -- so no list: the chunk's columns are in LDS, every lane its own units (k1_scan put
+// them there: the registers carry the next chunk's columns meanwhile), and every lane examines the eight rows of its unit of
+// each stripe with the two rows behind them (the next lane's): first which of them are last rows of windows, then -- the
+// lanes' counts added up -- the payloads, in row order.
+struct DenseStash { const int4 *pa, *pb, *fw; const int *dec; };      // [NQ * 64]: positions 0..3, 4..7 | flag bytes 0..7, the unit's two mask words | decidable
+__device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, DenseStash L, int nb_abs, int64_t c0, int64_t c1,
+                                              int2 tail_p, uint32_t tail_f) {
+    const DevTable &T = A.T;
+    const int lane = threadIdx.x, k = A.k;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t kmask = (1u << k) - 1u;
+    ScanGlobals G;
+    G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
+    G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
+    const NbDesc d = desc_uniform(A.desc, nb_abs);      // (again: the descriptors need not live in SGPRs through the phases)
+    if (d.mode != MODE_REGULAR) return;
+    const uint32_t *gbits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+    if (d.extra_row() >= c0 && d.extra_row() < c1) {     // the '+' window of a palindromic first site row (R5): first of the block
+        const CloseRes xc = far_close_body(G, nb_abs, d.row_end, d.extra_row());
+        Payload P;
+        P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
+        P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
+        P.nb = nb_abs;
+        S.put(lane == 0 && xc.row >= 0, P);
+    }
+    const int64_t lb_abs = max(d.row_begin, d.first());
+    const int lo = (int)(max(lb_abs, c0) - c0), hi = (int)(min(d.row_end, c1) - c0);
+    const int hi_close = (int)(min(d.row_end, c1 + 2) - c0);        // (rows that can close a window: the two behind the chunk too)
+    const uint32_t base_flags = (d.stray_q != NO_STRAY ? PF_STRAY : 0u) | (d.rev ? PF_REV : 0u);
+#pragma unroll 1
+    for (int j = 0; j < NQ; ++j) {
+        if (j * 512 + 512 <= lo || j * 512 >= hi) continue;      // (wave-uniform)
+        const int i0 = (j * 64 + lane) * 8;
+        const int4 qa = L.pa[j * 64 + lane], qb = L.pb[j * 64 + lane], qw = L.fw[j * 64 + lane];
+        const uint2 qf = make_uint2((uint32_t)qw.x, (uint32_t)qw.y);
+        // the two rows behind the unit: the next lane's first two (lane 63: the next stripe's, or the rows behind the chunk)
+        const int un = j * 64 + lane + 1;           // (unit behind this one, < NQ * 64 unless this is the chunk's last)
+        const bool last = un >= NQ * 64;
+        const int4 na = L.pa[last ? 0 : un], nw = L.fw[last ? 0 : un];
+        const int nx = last ? tail_p.x : na.x, ny = last ? tail_p.y : na.y;
+        const uint32_t nf = last ? tail_f : (uint32_t)nw.x;
+        const int ps[10] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, nx, ny};
+        // bit e: row e of the ten has an 'N' model k-mer (MC_F_MODEL_N is bit 1 of the flag byte)
+        static_assert(MC_F_MODEL_N == 2, "the bit picked out of the flag bytes below");
+        uint32_t nbits = 0;
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+            const uint32_t wd = e < 4 ? qf.x : e < 8 ? qf.y : nf;
+            nbits |= ((wd >> (8 * (e & 3) + 1)) & 1u) << e;
+        }
+        // ... is a row of the block that is tested (>= lo) / lies in front of the block's (the chunk's) end: all ten at once
+        const uint32_t below_hi = (1u << min(max(hi - i0, 0), 10)) - 1u, from_lo = ~((1u << min(max(lo - i0, 0), 10)) - 1u);
+        const uint32_t act = below_hi & from_lo & ~nbits & 0xFFu;
+        // the next unfiltered row of the read inside the chunk: the row behind this one (bit e of dc1), or the one behind an
+        // 'N' row (dc2)
+        const uint32_t free_rows = ((1u << min(max(hi_close - i0, 0), 10)) - 1u) & ~nbits;
+        const uint32_t dc1 = free_rows >> 1, dc2 = ~dc1 & (nbits >> 1) & (free_rows >> 2);
+        // first 'M' in meth_ref[p:p+k] (:176,:270) from the unit's two mask words W (bit 0 = position w_base); ok = false
+        // when they do not hold all k bits (the row is then looked at out of line)
+        const bool w_any = L.dec[j * 64 + lane] != 0;
+        const int w_base = ps[0] & ~31;
+        const uint64_t W = ((uint64_t)(uint32_t)qw.w << 32) | (uint32_t)qw.z;
+        auto site_off = [&](int p, bool &ok) -> int {
+            const uint32_t q = (uint32_t)(p - w_base);
+            const bool beyond = p >= d.contig_len;
+            ok = beyond | (w_any & (q <= (uint32_t)(64 - k)));
+            const uint32_t bits = beyond ? 0u : (uint32_t)(W >> (q & 63u)) & kmask;
+            return __ffs(bits) - 1;
+        };
+        uint32_t cbits = 0, farbits = 0, multibits = 0, how = 0;    // how: four bits per row, m - pos | (closing row is two behind) << 3
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = ps[e];
+            bool ok, ok2;
+            const int o = site_off(p, ok);
+            const int m = p + o;
+            const bool a = (act >> e) & 1u, has_dc = ((dc1 | dc2) >> e) & 1u, two = (dc2 >> e) & 1u;
+            const int cp = two ? ps[e + 2] : ps[e + 1];
+            const int o2 = site_off(cp, ok2);
+            const bool site = a & ok & (o >= 0);
+            const bool near = cp <= m + A.skip_thresh + 1;
+            const bool shut = site & has_dc & (cp > m);
+            // out of line: mask bits beyond the unit's two words; a closing row past the chunk / the block or behind two 'N' rows
+            const bool far = (a & !ok) | (site & !has_dc) | (shut & near & !ok2);
+            const bool closed = shut & !(near & !ok2);
+            farbits |= (far ? 1u : 0u) << e;
+            cbits |= (closed ? 1u : 0u) << e;
+            multibits |= ((closed & near & (o2 > 0)) ? 1u : 0u) << e;
+            how |= (closed ? (uint32_t)(o | (two ? 8 : 0)) : 0u) << (4 * e);
+            // (the rows one after the other, their results gathered as they come: the compiler would keep the 32 of them apart until
+        // the end of the loop, and their lane masks side by side do not fit the scalar registers)
+        asm volatile("" : "+v"(cbits), "+v"(farbits), "+v"(multibits), "+v"(how));
+        __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__ballot(farbits != 0u)) {              // rare
+            for (uint32_t fb = farbits; fb; fb &= fb - 1u) {
+                const int e = __ffs(fb) - 1;
+                const RowRes fr = far_row_body(G, gbits, d.contig_len, nb_abs, d.row_end, c0 + i0 + e);
+                if (fr.closed) cbits |= 1u << e;
+            }
+        }
+        const unsigned long long any = __ballot(cbits != 0u);
+        if (!any) continue;
+        // the lanes' counts (0 .. 8) added up bit by bit: four ballots, no trip through the LDS crossbar
+        const int mine = __popc(cbits);
+        int before = 0, n_new = 0;
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+            const unsigned long long mb = __ballot((mine >> bt) & 1);
+            before += __popcll(mb & below) << bt;
+            n_new += __popcll(mb) << bt;
+        }
+        S.reserve(S.total + n_new);
+        const int rank0 = S.total + before;
+        // (a lane's payloads lie side by side unless a chunk ends between them: one look at the chunk table per lane)
+        const int cs = A.chunk_shift;
+        const long long slot0 = S.slot_of(rank0);
+        const int room = rank0 < PT ? PT - rank0 : (1 << cs) - ((rank0 - PT) & ((1 << cs) - 1));    // slots from slot0 to the end of its strip
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!((cbits >> e) & 1u) || ((farbits >> e) & 1u)) continue;
+            const uint32_t h = (how >> (4 * e)) & 15u;
+            const int dc = 1 + (int)(h >> 3);
+            Payload P;
+            P.r = c0 + i0 + e; P.close_row = c0 + i0 + e + dc; P.m = ps[e] + (int)(h & 7u);
+            P.close_pos = dc == 1 ? ps[e + 1] : ps[e + 2];
+            P.flags = base_flags | (((multibits >> e) & 1u) ? PF_MULTI : 0u);
+            P.nb = nb_abs;
+            const int t = __popc(cbits & ((1u << e) - 1u));
+            const long long slot = t < room ? (slot0 < 0 ? -1 : slot0 + t) : S.slot_of(rank0 + t);
+            if (slot >= 0) A.payload[slot] = P;
+            __builtin_amdgcn_sched_barrier(0);      // (one payload at a time: eight side by side are eighty registers)
+        }
+        if (__ballot((cbits & farbits) != 0u)) {    // rare: once more, for what the payload holds
+            for (uint32_t fb = cbits & farbits; fb; fb &= fb - 1u) {
+                const int e = __ffs(fb) - 1;
+                const RowRes fr = far_row_body(G, gbits, d.contig_len, nb_abs, d.row_end, c0 + i0 + e);
+                Payload P;
+                P.r = c0 + i0 + e; P.close_row = fr.cr; P.m = fr.m; P.close_pos = fr.cp;
+                P.flags = fr.pf | base_flags;
+                P.nb = nb_abs;
+                const long long slot = S.slot_of(rank0 + __popc(cbits & ((1u << e) - 1u)));
+                if (slot >= 0) A.payload[slot] = P;
+            }
+        }
+        S.total += n_new;
+    }
+}
 
 // k1_scan: THE SCAN.  One wave per tile of TILE rows, nothing persistent, no barrier.  The wave takes its tile in chunks of
 // CHUNK rows and keeps the memory system busy throughout: the columns of the next chunk are requested as soon as the registers
@@ -965,6 +1153,16 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
 
     ChunkCols<MODE> C;
     C.load(T, t0, min(nrows, CHUNK), lane);
+    // (a one-base motif: the two rows behind the chunk -- the columns are padded by a tile -- so that the windows of the chunk's
+    // last rows are closed like all others: one in eight chunks ends on a site row, and a row that is looked at out of line costs
+    // the wave a chain of five loads)
+    int2 tail_p = make_int2(0, 0);
+    uint32_t tail_f = 0;
+    auto load_tail = [&](int64_t c1) {
+        tail_p = make_int2(T.pos[c1], T.pos[c1 + 1]);
+        tail_f = (uint32_t)T.flags[c1] | ((uint32_t)T.flags[c1 + 1] << 8);
+    };
+    if constexpr (CG > 64) load_tail(t0 + min(nrows, CHUNK));
     int before_p = 0, before_x = 0;                 // the row before the chunk (its first row's predecessor, if that is in its block)
     if (MODE == SCAN_VALIDATE && t0 > 0) { before_p = T.pos[t0 - 1]; before_x = T.idx[t0 - 1]; }
     int nb0 = __builtin_amdgcn_readfirstlane(T.tile_nb[tile]);      // first name block that overlaps the chunk
@@ -972,6 +1170,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
+    if constexpr (CG > 64) S.take_ahead();
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
@@ -993,7 +1192,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
         // not fit are listed unconditionally ----
         uint32_t mlo[NQ], mhi[NQ];
         bool decidable[NQ];
-        {
+        auto fetch_mask_words = [&]() {
             const bool rega = da.mode == MODE_REGULAR, regb = has_b && db.mode == MODE_REGULAR;
             const int loa = (int)(max(max(da.row_begin, da.first()), c0) - c0), hia = (int)(min(da.row_end, c1) - c0);
             const int lob = (int)(max(max(db.row_begin, db.first()), c0) - c0), hib = (int)(min(db.row_end, c1) - c0);
@@ -1013,7 +1212,10 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
                 mlo[j] = g[0];
                 mhi[j] = g[1];
             }
-        }
+        };
+        // (the one-base-motif instance fetches them behind the validation: what is alive across the validation's out-of-line
+        // calls has to sit in the callee-saved half of the registers, and six values more there are a wave per SIMD less)
+        if (CG <= 64 || MODE != SCAN_VALIDATE) fetch_mask_words();
 
         // ---- first pass over the table: every row against the row before it (while the mask words are on their way) ----
         // (per-lane COUNTS of what the pairs of rows say -- a comparison and an add-with-carry each, two vector instructions and
@@ -1074,6 +1276,47 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             }
         }
 
+        if (CG > 64 && MODE == SCAN_VALIDATE) fetch_mask_words();
+        // ---- a one-base motif: four rows in five are site rows and every unit would be listed -- the rows are examined where they
+        // are, in the registers: every lane its eight rows of a stripe (with the two behind them from the next lane), first
+        // which of them are last rows of windows, then -- the lanes' counts added up -- the payloads, in row order ----
+        if constexpr (CG > 64) {
+            // (the chunk out of the registers into LDS, every lane its own units: the loop below is one copy of the code for both
+            // stripes, the rows behind a unit are the next lane's without a shuffle, and the registers are free for the next
+            // chunk's columns, which set out now)
+            __shared__ int4 s_pa[NQ][64], s_pb[NQ][64], s_fw[NQ][64];      // positions 0..3, 4..7 | flag bytes 0..7, the unit's two mask words
+            __shared__ int s_dec[NQ][64];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                s_pa[j][lane] = C.pa[j];
+                s_pb[j][lane] = C.pb[j];
+                s_fw[j][lane] = make_int4((int)C.fl[j].x, (int)C.fl[j].y, (int)mlo[j], (int)mhi[j]);
+                s_dec[j][lane] = decidable[j] ? 1 : 0;
+            }
+            const int2 tail_p_now = tail_p;
+            const uint32_t tail_f_now = tail_f;
+#if defined(MC_DENSE_PREFETCH) && MC_DENSE_PREFETCH          // (variant build: the next chunk's columns under way while this one's rows are examined -- no gain, 16 registers more)
+            if (more) {
+                C.load(T, c0 + CHUNK, min(nrows - (ch + 1) * CHUNK, CHUNK), lane);
+                load_tail(c0 + CHUNK + min(nrows - (ch + 1) * CHUNK, CHUNK));
+            }
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (one wave: its LDS operations execute in order)
+            const DenseStash stash{&s_pa[0][0], &s_pb[0][0], &s_fw[0][0], &s_dec[0][0]};
+            // (a third name block and beyond -- reads of a few hundred rows -- the same way: their units have no mask words here,
+            // every row of theirs is looked at out of line.  No call in this instance of the kernel: whatever is alive across a
+            // call has to sit in the callee-saved half of the registers, and the chunk under way alone is twenty of them)
+            int nblk = nfast;
+            if (has_c) while (nb0 + nblk < T.n_nb && T.nb_row_begin[nb0 + nblk] < c1) ++nblk;
+#pragma unroll 1
+            for (int bi = 0; bi < nblk; ++bi) dense_block_rows(A, S, stash, nb0 + bi, c0, c1, tail_p_now, tail_f_now);
+#if !defined(MC_DENSE_PREFETCH) || !MC_DENSE_PREFETCH
+            if (more) {
+                C.load(T, c0 + CHUNK, min(nrows - (ch + 1) * CHUNK, CHUNK), lane);
+                load_tail(c0 + CHUNK + min(nrows - (ch + 1) * CHUNK, CHUNK));
+            }
+#endif
+        } else {
         // ---- all lanes, block by block and stripe by stripe: which units of eight rows can hold a site row at all? ----
         int ncand = 0, seg_end_a = 0;
         bool overflow = false;
@@ -1235,13 +1478,14 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
                 }
             }
         }
+        }
         // ---- a third name block and beyond: row by row ----
-        if (has_c) {
+        if (CG <= 64 && has_c) {
             int nslow = 1;
             while (nb0 + 2 + nslow < T.n_nb && T.nb_row_begin[nb0 + 2 + nslow] < c1) ++nslow;
             scan_blocks_slowly(A, nb0 + 2, nslow, c0, c1, S, lane);
         }
-        if (more) __syncthreads();                      // (the list is rewritten by the next chunk)
+        if (CG <= 64 && more) __syncthreads();          // (the list is rewritten by the next chunk)
     }
     if (lane == 0) A.tile_cnt[tile] = S.total;
 }
@@ -4342,6 +4586,9 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.pass_no = pass_no;
     const bool dense = dense_reference(c);
     A.chunk_shift = dense ? 8 : 6;
+    A.shard_shift = T.n_tiles >= 1024 ? 6 : 3;
+    A.shard_mask = (1 << A.shard_shift) - 1;
+    static_assert(NSHARD == 64, "shard_shift");
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const dim3 grid((unsigned)T.n_tiles);
     constexpr int CG_DENSE = CHUNK / 8 + 2;      // (every unit of a chunk; one cut by the boundary of its two blocks is listed twice)
