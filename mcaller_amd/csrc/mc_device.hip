@@ -628,6 +628,7 @@ struct K1Args {
     int shard_shift;              // the chunk counters in use: 1 << shard_shift
     int shard_mask;               // ... less one
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
+    int32_t *tile_half;           // [n_tiles] ... in its first chunk (the one-base-motif scan: k1_emit_runs' pieces are the scan's chunks)
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
     DevRecords O;                 // records, file order
@@ -1171,6 +1172,8 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
     if constexpr (CG > 64) S.take_ahead();
+    int half = 0;                                   // windows closed in the first chunk
+    static_assert(CG <= 64 || NCH == 2, "tile_half: two chunks per tile");
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1486,8 +1489,10 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             scan_blocks_slowly(A, nb0 + 2, nslow, c0, c1, S, lane);
         }
         if (CG <= 64 && more) __syncthreads();          // (the list is rewritten by the next chunk)
+        if (CG > 64 && ch == 0) half = S.total;
     }
     if (lane == 0) A.tile_cnt[tile] = S.total;
+    if (CG > 64 && lane == 0) A.tile_half[tile] = half;
 }
 
 // Tile counts -> first record slot of every tile, two levels: groups of 1024 tiles are scanned here (coalesced),
@@ -1975,9 +1980,11 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     constexpr int PIECES = TILE / ET;
     const int64_t tile = blockIdx.x / PIECES;
-    const int n_win = A.tile_cnt[tile];
-    if (n_win == 0) return;
-    const int64_t s0 = tile * TILE + (int64_t)(blockIdx.x % PIECES) * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
+    static_assert(ET == CHUNK && PIECES == 2, "a piece is a chunk of the scan: its windows are the tile's first tile_half, or the rest");
+    const int piece = blockIdx.x % PIECES;
+    const int w_lo = piece ? A.tile_half[tile] : 0, w_hi = piece ? A.tile_cnt[tile] : A.tile_half[tile];
+    if (w_lo >= w_hi) return;
+    const int64_t s0 = tile * TILE + (int64_t)piece * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
     if (s0 >= T.n_rows) return;
     const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
     const int64_t first_rec = tile_slot(A.tile_local, A.group_sum, tile, lane);
@@ -1988,7 +1995,7 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     ER_STAMP(0);
     Payload P0;
     P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
-    if (tid < n_win && first_rec + tid < n_rec) P0 = tile_payload(A, tile, tid);
+    if (w_lo + tid < w_hi && first_rec + w_lo + tid < n_rec) P0 = tile_payload(A, tile, w_lo + tid);
     // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
     // chunk in front of its first one (which row in a run came last before the wave's rows) ----
     const int c_lo = (wave * E_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * E_CHUNKS + 3) >> 2;
@@ -2187,15 +2194,15 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     lds_barrier();
     ER_STAMP(4);
     // ---- the windows whose last row lies in the piece (the tile's payloads are in file order: a contiguous stretch) ----
-    for (int w = tid; w < n_win; w += E_THREADS) {
+    for (int w = w_lo + tid; w < w_hi; w += E_THREADS) {
         const int64_t q = first_rec + w;
         if (q >= n_rec) break;
-        const Payload P = w == tid ? P0 : tile_payload(A, tile, w);
+        const Payload P = w == w_lo + tid ? P0 : tile_payload(A, tile, w);
         if (P.r < s0 || P.r >= s1) continue;
         const int m = P.m;
         const bool rev = P.flags & PF_REV;
         WinCtx X = X0;
-        if (w != tid) { ctx_begin(P, X); ctx_end(X); }      // (a tile with more windows than the workgroup has threads)
+        if (w != w_lo + tid) { ctx_begin(P, X); ctx_end(X); }      // (a piece with more windows than the workgroup has threads)
         const int bj = X.bj;
         if (P.flags & PF_EXTRA) {                   // the one-event '+' window of a palindromic first site row (R5)
             for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
@@ -3362,7 +3369,7 @@ struct mc_ctx {
     std::vector<void *> lit_allocs;
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
-    int32_t *tile_cnt = nullptr;
+    int32_t *tile_cnt = nullptr, *tile_half = nullptr;
     long long *tile_chunk = nullptr;
     Payload *payload_sorted = nullptr;   // payloads in file order (k1_list)
     int64_t *rare_list = nullptr;
@@ -3830,7 +3837,7 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
-        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1))
+        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1) || dev_alloc(P, &c->tile_half, (size_t)nt + 1))
         return -10;
     c->scratch_nb = nb;
     c->scratch_tiles = nt;
@@ -4580,7 +4587,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
-    A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt;
+    A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt; A.tile_half = c->tile_half;
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
