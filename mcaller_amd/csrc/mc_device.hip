@@ -751,18 +751,18 @@ struct TileSlots {
     long long *s_chunk;           // [NCHUNK] first slot of the tile's chunks (LDS)
     int total;                    // windows closed so far
     int lane;
-    long long ahead = -1;         // (lane 0) the shard counter's value before a chunk fetched ahead of need (take_ahead), -1: none
     // A one-base motif: every tile needs a chunk, and the wave would wait 3 us for the counter's answer when it gets there -- it
-    // asks at once and looks at the answer when the first chunk is due.  (A tile that closes fewer than PT windows leaves the
-    // chunk unused: the payload array has a chunk to spare for every tile.)
-    __device__ __forceinline__ void take_ahead() {
-        if (lane == 0) ahead = (long long)atomicAdd(&A.cnt->shard[(int)(tile & A.shard_mask) * SHARD_PAD], 1ull << A.chunk_shift);
+    // asks at once (-> ahead, lane 0: the shard counter's value before the chunk; -1: none) and looks at the answer when the
+    // first chunk is due: reserve() and put() with that variable.  (A tile that closes fewer than PT windows leaves the chunk
+    // unused: the payload array has a chunk to spare for every tile.)
+    __device__ __forceinline__ long long take_ahead() const {
+        return lane == 0 ? (long long)atomicAdd(&A.cnt->shard[(int)(tile & A.shard_mask) * SHARD_PAD], 1ull << A.chunk_shift) : -1;
     }
     __device__ __forceinline__ long long slot_of(int rank) const {
         const int cs = A.chunk_shift;
         return rank < PT ? tile * PT + rank : s_chunk[(rank - PT) >> cs] + ((rank - PT) & ((1 << cs) - 1));
     }
-    __device__ __forceinline__ void reserve(int new_total) {   // chunks for ranks < new_total (wave-uniform call)
+    __device__ __forceinline__ void reserve(int new_total, long long *ahead = nullptr) {   // chunks for ranks < new_total (wave-uniform call)
         const int cs = A.chunk_shift, cm = (1 << cs) - 1;
         const int c0 = total <= PT ? 0 : (total - PT + cm) >> cs, c1 = new_total <= PT ? 0 : (new_total - PT + cm) >> cs;
         if (c1 > c0) {
@@ -770,12 +770,12 @@ struct TileSlots {
                 const int sh = (int)(tile & A.shard_mask);
                 const long long per = (A.payload_cap - A.T.n_tiles * PT) >> A.shard_shift;      // (a shift: a 64-bit division is a hundred instructions)
                 int cf = c0;
-                if (ahead >= 0) {                   // the chunk fetched ahead is the first of these
-                    const long long base = ahead + (1ll << cs) > per ? -1 : A.T.n_tiles * PT + sh * per + ahead;
+                if (ahead && *ahead >= 0) {         // the chunk fetched ahead is the first of these
+                    const long long base = *ahead + (1ll << cs) > per ? -1 : A.T.n_tiles * PT + sh * per + *ahead;
                     if (base < 0) atomicOr(&A.cnt->overflow, 1u);
                     s_chunk[cf] = base;
                     A.tile_chunk[tile * NCHUNK + cf] = base;
-                    ahead = -1;
+                    *ahead = -1;
                     ++cf;
                 }
                 if (cf < c1) {
@@ -796,11 +796,11 @@ struct TileSlots {
         }
     }
     // the lanes with `closed` write their payloads, in lane order
-    __device__ __forceinline__ void put(bool closed, const Payload &P) {
+    __device__ __forceinline__ void put(bool closed, const Payload &P, long long *ahead = nullptr) {
         const unsigned long long bal = __ballot(closed);
         if (!bal) return;
         const int n_new = __popcll(bal);
-        reserve(total + n_new);
+        reserve(total + n_new, ahead);
         if (closed) {
             const long long slot = slot_of(total + __popcll(bal & ((1ull << lane) - 1ull)));
             if (slot >= 0) A.payload[slot] = P;
@@ -965,8 +965,8 @@ struct ChunkCols {
 // each stripe with the two rows behind them (the next lane's): first which of them are last rows of windows, then -- the
 // lanes' counts added up -- the payloads, in row order.
 struct DenseStash { const int4 *pa, *pb, *fw; const int *dec; };      // [NQ * 64]: positions 0..3, 4..7 | flag bytes 0..7, the unit's two mask words | decidable
-__device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, DenseStash L, int nb_abs, int64_t c0, int64_t c1,
-                                              int2 tail_p, uint32_t tail_f) {
+__device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, long long &ahead, DenseStash L, int nb_abs, int64_t c0,
+                                                 int64_t c1, int2 tail_p, uint32_t tail_f) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x, k = A.k;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -983,7 +983,7 @@ __device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, 
         P.r = d.extra_row(); P.close_row = xc.row; P.m = d.extra_mpos; P.close_pos = xc.pos;
         P.flags = PF_EXTRA | (xc.ns ? PF_CLOSE_NS : 0u);
         P.nb = nb_abs;
-        S.put(lane == 0 && xc.row >= 0, P);
+        S.put(lane == 0 && xc.row >= 0, P, &ahead);
     }
     const int64_t lb_abs = max(d.row_begin, d.first());
     const int lo = (int)(max(lb_abs, c0) - c0), hi = (int)(min(d.row_end, c1) - c0);
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, 
             before += __popcll(mb & below) << bt;
             n_new += __popcll(mb) << bt;
         }
-        S.reserve(S.total + n_new);
+        S.reserve(S.total + n_new, &ahead);
         const int rank0 = S.total + before;
         // (a lane's payloads lie side by side unless a chunk ends between them: one look at the chunk table per lane)
         const int cs = A.chunk_shift;
@@ -1137,7 +1137,8 @@ __device__ __forceinline__ void dense_block_rows(const K1Args &A, TileSlots &S, 
 #ifdef MC_SCAN_WPE                  // (variant builds, tools/variants.sh)
 #define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MC_SCAN_WPE, MC_SCAN_WPE)))
 #else
-#define MC_SCAN_ATTR
+// (the instance that reads unit summaries fits 80 registers -- six waves per SIMD -- give or take one: said to the compiler)
+#define MC_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(MODE == SCAN_SUMMARY ? 6 : 1)))
 #endif
 template <int CG, int MODE>
 __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
@@ -1171,7 +1172,8 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
-    if constexpr (CG > 64) S.take_ahead();
+    long long ahead = -1;
+    if constexpr (CG > 64) ahead = S.take_ahead();
     int half = 0;                                   // windows closed in the first chunk
     static_assert(CG <= 64 || NCH == 2, "tile_half: two chunks per tile");
 
@@ -1312,7 +1314,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             int nblk = nfast;
             if (has_c) while (nb0 + nblk < T.n_nb && T.nb_row_begin[nb0 + nblk] < c1) ++nblk;
 #pragma unroll 1
-            for (int bi = 0; bi < nblk; ++bi) dense_block_rows(A, S, stash, nb0 + bi, c0, c1, tail_p_now, tail_f_now);
+            for (int bi = 0; bi < nblk; ++bi) dense_block_rows(A, S, ahead, stash, nb0 + bi, c0, c1, tail_p_now, tail_f_now);
 #if !defined(MC_DENSE_PREFETCH) || !MC_DENSE_PREFETCH
             if (more) {
                 C.load(T, c0 + CHUNK, min(nrows - (ch + 1) * CHUNK, CHUNK), lane);

@@ -419,6 +419,38 @@ def test_other_window_lengths(dev, k):
         assert rec.n > 50
 
 
+@pytest.mark.parametrize('read_len', [(40, 300), (300, 1500)])
+def test_one_base_motif_with_short_reads(dev, read_len):
+    """A one-base motif over reads of a few hundred events: a 1024-row chunk of the scan holds three and more name blocks (their
+    units have no mask words there: every row of theirs is looked at out of line), the emit's pieces more blocks than their
+    table holds.  First pass (validating), second, third, and the validating pass again with two in flight: the oracle's
+    records every time."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=120000, seed=41)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(400000, seed=4100 + read_len[0], codes=codes, read_len=read_len)
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    assert orc.n > 30000
+    dev.set_reference(arrays)
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    rec = dev.extract(6, 0, 0.0, score=False)
+    rec.prob[:rec.n] = np.nan
+    H.assert_records_equal(rec, orc, 6)
+    slot = dev.current_slot()
+    for again in range(4):
+        if again == 2:
+            dev.select_table(slot, as_new=True)
+        dev.run_async(6, 0, 0.0, score=False)
+        if again == 2:
+            continue
+        for _ in range(2 if again == 3 else 1):
+            rec2 = dev.wait()
+            rec2.prob[:rec2.n] = np.nan
+            H.assert_records_equal(rec2, orc, 6)
+
+
 def test_empty_and_tiny_tables(dev):
     """No rows, one row, fewer rows than a window: no records, no crash, both paths."""
     from mcaller_amd import synth, _lib
