@@ -1,0 +1,60 @@
+"""One-off campaign on the GPU box for the one-base-motif kernels (k1_scan<CG_DENSE>, k1_emit_runs): random synthetic TABLES --
+sizes around the multiples of a chunk / a piece (1024 rows) and a tile (2048), reads from a dozen to thousands of events, every k
+and skip_thresh, a quality threshold that filters reads -- each as a table's first pass (synchronous, validating), second, third
+and, declared new, the validating pass again with two in flight, against the C oracle.  (The micro-cases of fuzz_gpu.py are a
+few hundred rows: they never cross a chunk.)  usage: fuzz_dense_tables.py [n_tables] [first seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mcaller_amd import synth
+from mcaller_amd.device import Device
+from tests import helpers as H
+
+n_tables = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 9000000
+dev = Device(0)
+bad, done, rows, t0 = [], 0, 0, time.time()
+for i in range(n_tables):
+    seed = seed0 + i
+    rng = np.random.default_rng(seed)
+    codes = synth.genome(length=int(rng.integers(30000, 400000)), seed=seed)
+    motif = ['A', 'A', 'A', 'C', 'AT', 'GA'][int(rng.integers(0, 6))]          # one-base motifs, and two-base ones that are dense too
+    base = 'C' if motif == 'C' else 'A'
+    lo = int(rng.choice([8, 30, 120, 600, 3000]))
+    read_len = (lo, lo * int(rng.integers(2, 12)))
+    around = int(rng.choice([1024, 2048, 3072, 4096, 10240, 50000, 200000]))
+    n = max(50, around + int(rng.integers(-40, 41)) if rng.random() < 0.7 else int(rng.integers(100, 300000)))
+    k = int(rng.choice([6, 6, 6, 4, 5, 7, 8]))
+    skip = int(rng.integers(0, min(3, (k - 1) // 2 + 1)))
+    qthr = float(rng.choice([0.0, 0.0, 8.0, 10.5]))
+    try:
+        ref = synth.SynthRef(codes, base=base, motif=motif)
+        table, qual = synth.make_table(n, seed=seed, codes=codes, read_len=read_len)
+        arrays = ref.device_arrays()
+        orc = H.oracle_records(table, arrays, qual, k, skip, qthr)
+        dev.set_reference(arrays)
+        dev.upload_table(table)
+        dev.set_read_quality(qual)
+        rec = dev.extract(k, skip, qthr, score=False)
+        rec.prob[:rec.n] = np.nan
+        H.assert_records_equal(rec, orc, k)
+        slot = dev.current_slot()
+        for again in range(4):
+            if again == 2:
+                dev.select_table(slot, as_new=True)
+            dev.run_async(k, skip, qthr, score=False)
+            if again == 2:
+                continue
+            for _ in range(2 if again == 3 else 1):
+                rec2 = dev.wait()
+                rec2.prob[:rec2.n] = np.nan
+                H.assert_records_equal(rec2, orc, k)
+        done += 1
+        rows += table.n_rows
+    except AssertionError as e:
+        bad.append((seed, motif, read_len, n, k, skip, qthr, str(e)[:160]))
+    except Exception as e:
+        bad.append((seed, motif, read_len, n, k, skip, qthr, 'ERROR %s: %s' % (type(e).__name__, str(e)[:160])))
+print('%d tables (%d rows) compared in %.0f s, %d differ' % (done, rows, time.time() - t0, len(bad)))
+for b in bad[:20]:
+    print(b)
