@@ -178,8 +178,6 @@ struct Counters {          // device-side status block
                                // repeated on the table's complete validation flags)
     unsigned int n_big;
     unsigned int n_rare;       // windows left to k1_rare
-    unsigned int giveup;       // k1_dense met a piece it cannot answer (more name blocks than its table holds, ...): the pass is
-    unsigned int pad0;         // repeated with the scan + emit pair (it marks the pass like an irregular read does)
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
     unsigned long long n_wide; // slot means of those records that travel as 64 bits (k_pack: the others as 32-bit integers)
     // the pass in which a name block was last classified irregular (mc_params-independent pass number, never 0).  Written,
@@ -627,8 +625,6 @@ struct K1Args {
     long long payload_cap;
     long long *tile_chunk;        // [n_tiles * NCHUNK] first payload slot of the tile's chunks of (1 << chunk_shift) behind its own PT slots
     int chunk_shift;              // 6: chunks of 64 (sparse motifs); 8: chunks of 256 (a one-base motif: ~270 windows per tile)
-    int validate_only;            // k1_scan<CG_DENSE>: no windows, no payloads (k1_dense follows)
-    unsigned long long *look;     // [pieces] k1_dense: windows of the piece / of all pieces up to it, tagged with the pass (decoupled look-back)
     int shard_shift;              // the chunk counters in use: 1 << shard_shift
     int shard_mask;               // ... less one
     int32_t *tile_cnt;            // [n_tiles] windows closed in the tile
@@ -1177,7 +1173,7 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
     G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
     TileSlots S{A, tile, s_chunk, 0, lane};
     long long ahead = -1;
-    if constexpr (CG > 64) { if (!A.validate_only) ahead = S.take_ahead(); }
+    if constexpr (CG > 64) ahead = S.take_ahead();
     int half = 0;                                   // windows closed in the first chunk
     static_assert(CG <= 64 || NCH == 2, "tile_half: two chunks per tile");
 
@@ -1317,7 +1313,6 @@ __global__ __launch_bounds__(64) MC_SCAN_ATTR void k1_scan(K1Args A) {
             // call has to sit in the callee-saved half of the registers, and the chunk under way alone is twenty of them)
             int nblk = nfast;
             if (has_c) while (nb0 + nblk < T.n_nb && T.nb_row_begin[nb0 + nblk] < c1) ++nblk;
-            if (A.validate_only) nblk = 0;      // (k1_dense finds the windows itself: this kernel only validates the table's first pass)
 #pragma unroll 1
             for (int bi = 0; bi < nblk; ++bi) dense_block_rows(A, S, ahead, stash, nb0 + bi, c0, c1, tail_p_now, tail_f_now);
 #if !defined(MC_DENSE_PREFETCH) || !MC_DENSE_PREFETCH
@@ -2277,437 +2272,6 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
     ER_STAMP(5);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k1_dense: scan, ordering and emit of a one-base motif in ONE kernel (regular name blocks only; anything it cannot answer
-// makes it give the pass up -- Counters.giveup -- and the pass is repeated with k1_scan + k1_emit_runs).
-//
-// The run table of k1_emit_runs knows where the windows are: the rows of a run share a position p, so they share the site
-// m = p + (first 'M' of meth_ref[p:p+k], :176), and only the run's LAST row can be the last row of a window -- the row behind
-// any other row of the run lies at p <= m.  The window of run R is closed (:179) iff the next run of the block lies beyond m
-// (its head is the closing row), or R is the block's last run and another read (or the next shard) follows.  So no payloads:
-// a workgroup stages a piece of the table like k1_emit_runs, numbers the runs, tests every run -- the windows whose CLOSING ROW
-// lies in the piece are the piece's (for a block's last window: whose block ends in the piece; the '+' window of R5: whose
-// row lies in the piece; the run itself may lie in the rows in front) -- counts them, learns its first record slot from the
-// pieces before it (decoupled look-back over A.look, in blockIdx order: workgroups are dispatched in index order on every XCD
-// and XCDs take them round-robin, so the lowest index not yet resident never waits for a higher one), and writes the records.
-// ---------------------------------------------------------------------------------------------------
-struct DenseBlock {
-    int end, lb, id, contig;        // (as RunBlock)
-    int contig_len, stray_q;
-    uint32_t xflags;
-    int rev;
-    int64_t mask_off;
-    int64_t end_abs;                // one past the block's last row (table index)
-    int64_t ns_close;               // the block's last window, if it is this piece's: the row that closes it (find_close), -1: none
-    int64_t extra_close;            // the '+' window of a palindromic first site row (R5), if its row lies in this piece: its closing row; -1: none
-    int extra_mpos, extra_ns;
-    int n_wins;                     // windows of the block's runs that are this piece's
-};
-constexpr unsigned long long LOOK_AGG = 1ull << 46, LOOK_INC = 2ull << 46, LOOK_VAL = (1ull << 46) - 1ull;
-
-__global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER_WAVES, MC_ER_WAVES))) void k1_dense(K1Args A, Payload *__restrict__ sorted) {
-    __shared__ int32_t s_dc[ER + 8];            // (event - model) of the rows in runs, run after run; then: the piece's windows
-    __shared__ double s_mean[ER];
-    __shared__ int32_t s_rpos[ER];
-    __shared__ uint16_t s_rrow[ER + 2];         // first row of the run (staged index) | RUN_* << 12
-    __shared__ uint16_t s_rc0[ER + 2];          // where the run's rows begin in s_dc; one more: where the last run's end
-    __shared__ uint8_t s_rw[ER];                // the run's window: 1 this piece's | o << 1 | 16 PF_MULTI | 32 closed by the next read
-    __shared__ DenseBlock s_blk[E_MAXB];
-    __shared__ int s_nblk, s_wheads[E_THREADS / 64], s_wins[E_THREADS / 64], s_wcnt[E_THREADS / 64];
-    __shared__ long long s_first, s_look_sum[E_THREADS / 64];
-    __shared__ int s_look_inc[E_THREADS / 64];
-    const DevTable &T = A.T;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t piece_no = blockIdx.x;
-    const unsigned long long tag = (A.pass_no & 0xFFFFull) << 48;
-    const int64_t s0 = piece_no * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
-    const int64_t tile = s0 / TILE;
-    const int k = A.k;
-    const uint32_t kmask = (1u << k) - 1u;
-    const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
-    const int nst = (int)(s1 - h0);
-    const int own0 = (int)(s0 - h0);            // staged rows from here on are the piece's own
-    // ---- the rows (as in k1_emit_runs) ----
-    const int c_lo = (wave * E_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * E_CHUNKS + 3) >> 2;
-    int32_t rp[E_CPW], rd[E_CPW];
-    uint32_t rfl[E_CPW];
-#pragma unroll
-    for (int c = 0; c < E_CPW; ++c) {
-        const int i = (c_lo + c) * 64 + lane;
-        rp[c] = 0; rd[c] = 0; rfl[c] = MC_F_MODEL_N;
-        if (c_lo + c < c_hi && i < nst) {
-            const int2 e = T.evmu[h0 + i];
-            rp[c] = T.pos[h0 + i];
-            rd[c] = e.x - e.y;
-            rfl[c] = T.flags[h0 + i];
-        }
-    }
-    int32_t pre_p = 0;
-    uint32_t pre_f = MC_F_MODEL_N;
-    if (c_lo > 0 && (c_lo - 1) * 64 + lane < nst) { pre_p = T.pos[h0 + (c_lo - 1) * 64 + lane]; pre_f = T.flags[h0 + (c_lo - 1) * 64 + lane]; }
-    ScanGlobals G;
-    G.pos = T.pos; G.flags = T.flags; G.nb_row_begin = T.nb_row_begin; G.desc = A.desc; G.n_rows = T.n_rows;
-    G.n_nb = T.n_nb; G.tail_contig = A.tail_contig; G.k = k; G.skip_thresh = A.skip_thresh;
-    // ---- the name blocks that overlap the staged rows; with them what closes a block's last window and its '+' window ----
-    if (wave == 0) {
-        const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
-        const int b = bfrom + lane;
-        bool over = false, ends_early = false;
-        DenseBlock rb;
-        if (b < T.n_nb) {
-            const NbDesc *dp = A.desc + b;
-            const int64_t rbeg = dp->row_begin, rend = dp->row_end;
-            over = rbeg < s1 && rend > h0;
-            ends_early = rend < s1 && b + 1 < T.n_nb;
-            if (over) {
-                const bool reg = dp->mode == MODE_REGULAR;
-                rb.end = (int)min(rend - h0, (int64_t)nst);
-                rb.lb = reg ? (int)max(max(rbeg, dp->first()) - h0, (int64_t)-1) : nst;
-                rb.id = b;
-                rb.contig = dp->contig;
-                rb.contig_len = dp->contig_len;
-                rb.stray_q = dp->stray_q;
-                rb.xflags = dp->xflags;
-                rb.rev = dp->rev;
-                rb.mask_off = dp->mask_off;
-                rb.end_abs = rend;
-                rb.ns_close = -1; rb.extra_close = -1; rb.extra_mpos = dp->extra_mpos; rb.extra_ns = 0; rb.n_wins = 0;
-                // (the rows behind the block's last row, and behind the '+' window's row: out of line, once per read)
-                if (reg && rend - 1 >= s0 && rend - 1 < s1) {
-                    const CloseRes xc = far_close_body(G, b, rend, rend - 1);
-                    rb.ns_close = xc.row;           // (closed by another read: whatever its position; -1: lost at the end of the file)
-                }
-                if (reg && dp->extra_row() >= s0 && dp->extra_row() < s1) {
-                    const CloseRes xc = far_close_body(G, b, rend, dp->extra_row());
-                    rb.extra_close = xc.row;
-                    rb.extra_ns = xc.ns;
-                }
-            }
-        }
-        const unsigned long long bal = __ballot(over);
-        const int n = __popcll(bal), at = __popcll(bal & ((1ull << lane) - 1ull));
-        const bool more_behind = (__ballot(ends_early) >> 63) & 1ull;
-        if (over && at < E_MAXB) s_blk[at] = rb;
-        if (lane == 0) s_nblk = more_behind ? E_MAXB + 1 : n;
-    }
-    lds_barrier();
-    const int nblk = s_nblk;
-    const bool usable = nblk <= E_MAXB;
-    bool giveup = !usable;
-    int n_runs = 0;
-    if (usable) {
-        const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-        int carry_row = -1, carry_pos = 0;
-        for (int cc = c_lo - 1; cc >= 0; --cc) {
-            const int i = cc * 64 + lane;
-            int32_t p = pre_p;
-            uint32_t f = pre_f;
-            if (cc != c_lo - 1 && i < nst) { p = T.pos[h0 + i]; f = T.flags[h0 + i]; }
-            int bj = 0;
-            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
-            const bool in = i >= max(s_blk[bj].lb, 0) && i < s_blk[bj].end && !(f & MC_F_MODEL_N);
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                const int top = 63 - __clzll(m);
-                carry_row = cc * 64 + top;
-                carry_pos = __shfl(p, top);
-                break;
-            }
-        }
-        unsigned long long inm[E_CPW], headm[E_CPW];
-        uint32_t cutm = 0;
-        int nh = 0, ni = 0, bj = 0;
-        bool blind = false;         // a block that began before the staged rows has its first staged row in a run among the piece's own
-#pragma unroll
-        for (int c = 0; c < E_CPW; ++c) {
-            inm[c] = 0; headm[c] = 0;
-            if (c_lo + c >= c_hi) continue;
-            const int base = (c_lo + c) * 64, i = base + lane;
-            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
-            const int lb = s_blk[bj].lb, lbm = max(lb, 0);
-            const bool in = i < nst && i >= lbm && i < s_blk[bj].end && !(rfl[c] & MC_F_MODEL_N);
-            const unsigned long long m = __ballot(in), below = m & lt;
-            const int pl = 63 - __clzll(below | 1ull);
-            int prow = base + pl, ppos = __shfl(rp[c], pl);
-            if (!below) { prow = carry_row; ppos = carry_pos; }
-            const bool alone = prow < lbm, head = in && (alone || ppos != rp[c]);
-            if (head && alone && lb < 0) { cutm |= 1u << c; if (i >= own0 && h0 > 0) blind = true; }
-            const unsigned long long hm = __ballot(head);
-            inm[c] = m; headm[c] = hm;
-            nh += __popcll(hm); ni += __popcll(m);
-            if (m) {
-                const int top = 63 - __clzll(m);
-                carry_row = base + top;
-                carry_pos = __shfl(rp[c], top);
-            }
-        }
-        // (more than EH filtered rows in a row inside a read: the run in front of them, whose window this piece's first row
-        // closes, is not among the staged rows)
-        if (__ballot(blind)) giveup = true;
-        if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
-        lds_barrier();
-        int hbase = 0, ibase = 0, n_in = 0;
-#pragma unroll
-        for (int w = 0; w < E_THREADS / 64; ++w) {
-            const int a = s_wheads[w], b2 = s_wins[w];
-            if (w < wave) { hbase += a; ibase += b2; }
-            n_runs += a; n_in += b2;
-        }
-#pragma unroll
-        for (int c = 0; c < E_CPW; ++c) {
-            if (c_lo + c >= c_hi) continue;
-            const int i = (c_lo + c) * 64 + lane;
-            const int rid = hbase + __popcll(headm[c] & le) - 1, at = ibase + __popcll(inm[c] & lt);
-            if ((inm[c] >> lane) & 1ull) s_dc[at] = rd[c];
-            if ((headm[c] >> lane) & 1ull) {
-                s_rrow[rid] = (uint16_t)(i | (((cutm >> c) & 1u) ? (RUN_UNUSABLE << E_RF_SHIFT) : 0));
-                s_rpos[rid] = rp[c];
-                s_rc0[rid] = (uint16_t)at;
-            }
-            hbase += __popcll(headm[c]); ibase += __popcll(inm[c]);
-        }
-        if (tid == 0) { s_rc0[n_runs] = (uint16_t)n_in; s_rrow[n_runs] = (uint16_t)nst; }
-        lds_barrier();
-        // ---- every run: its mean (as in k1_emit_runs), and its window ----
-        for (int R = tid; R < n_runs; R += E_THREADS) {
-            double mean = 0.0;
-            uint32_t rf = 0;
-            const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
-            const int d0 = s_dc[c0], d1 = s_dc[c0 + 1], d2 = s_dc[c0 + 2], d3 = s_dc[c0 + 3];
-            const int i0 = s_rrow[R] & ((1 << E_RF_SHIFT) - 1), p = s_rpos[R];
-            const int nx = s_rrow[R + 1] & ((1 << E_RF_SHIFT) - 1);       // head of the next run (nst behind the last one)
-            const int pn = R + 1 < n_runs ? s_rpos[R + 1] : 0;
-            int bjr = 0;
-            while (bjr + 1 < nblk && i0 >= s_blk[bjr].end) ++bjr;
-            const DenseBlock &B = s_blk[bjr];
-            // the site of the run's rows: first 'M' of meth_ref[p:p+k] on the block's strand (:176, :270)
-            const uint32_t *gbits = (B.rev ? A.R.mr : A.R.mf) + B.mask_off;
-#if defined(MC_XD) && MC_XD == 1
-            const int o = (p & 3) == 0 ? 0 : -1; (void)gbits;
-#else
-            const int o = site_off_global(gbits, B.contig_len, k, p);
-#endif
-            if (n > 128) { rf = RUN_UNUSABLE; mean = 0.0; }
-            else if (n >= 8) {
-                const int n8 = n - (n % 8);
-                double r[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) r[u] = 0.0;
-                for (int j = 0; j < n8; j += 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) r[u] += div1e4(s_dc[c0 + j + u]);
-                }
-                double acc = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-                for (int j = n8; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
-                mean = (0.0 + acc) / (double)n;
-            } else {
-                double acc = -0.0 + div1e4(d0);
-                if (n > 1) acc += div1e4(d1);
-                if (n > 2) acc += div1e4(d2);
-                if (n > 3) acc += div1e4(d3);
-                for (int j = 4; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
-                mean = 0.0 + acc;
-                if (n > 1) mean = mean / (double)n;
-            }
-            if (n > 1 && n <= 128) {
-                int32_t as_int;
-                if (!slot_is_narrow(mean, &as_int)) rf |= RUN_WIDE;
-            }
-            s_mean[R] = mean;
-            if (rf) s_rrow[R] |= (uint16_t)(rf << E_RF_SHIFT);
-            // the window whose last row is the run's last: closed by the head of the next run of the block if that lies beyond
-            // the site (:179) -- this piece's if that head is among its own rows --, or, the block's last run, by the next read
-            uint32_t wbits = 0;
-            if (o >= 0) {
-                const int m = p + o;
-                if (nx < B.end) {                   // (the next run is the block's: runs are in row order)
-                    if (nx >= own0 && pn > m) {
-                        wbits = 1u | ((uint32_t)o << 1);
-                        if (pn <= m + A.skip_thresh + 1 && site_off_global(gbits, B.contig_len, k, pn) > 0) wbits |= 16u;
-                    }
-                } else if (B.end_abs <= h0 + nst) { // the block's last run (the block ends among the staged rows)
-                    if (B.end_abs - 1 >= s0 && B.ns_close >= 0) wbits = 1u | ((uint32_t)o << 1) | 32u;
-                }
-            }
-            s_rw[R] = (uint8_t)wbits;
-        }
-    }
-    lds_barrier();
-    // ---- the piece's windows, in file order: the runs' in run order, a block's '+' window in front of the block's runs ----
-    int n_win = 0;
-    uint32_t *const s_list = reinterpret_cast<uint32_t *>(s_dc);        // run | o << 11 | flags << 14 (1 multi, 2 closed by the next read) ; '+' window: 1 << 31 | block
-    if (usable) {
-        constexpr int RPT = (ER + E_THREADS - 1) / E_THREADS;           // runs per thread, consecutive
-        const int r_lo = tid * RPT, r_hi = min(r_lo + RPT, n_runs);
-        int mine = 0;
-        for (int R = r_lo; R < r_hi; ++R) mine += s_rw[R] & 1u;
-        // '+' windows in front of my first run's block ... counted with the first run of their block (or, a block without runs
-        // here, with the first run behind it); thread 0 counts the ones in front of run 0, the last thread's count is closed below
-        int incl = mine;
-        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2); if (lane >= o2) incl += v; }
-        if (lane == 63) s_wcnt[wave] = incl;
-        lds_barrier();
-        int base = incl - mine, total_runs_w = 0;
-        for (int w = 0; w < E_THREADS / 64; ++w) { if (w < wave) base += s_wcnt[w]; total_runs_w += s_wcnt[w]; }
-        // the '+' windows: block j's lies in front of every run of block j and behind every run of the blocks before it
-        int n_extra = 0;
-        for (int j = 0; j < nblk; ++j) n_extra += s_blk[j].extra_close >= 0 ? 1 : 0;
-        n_win = total_runs_w + n_extra;
-        lds_barrier();                  // (s_dc's rows are read no more: the list takes their place)
-        int cur = base;
-        for (int R = r_lo; R < r_hi; ++R) {
-            const uint32_t wb = s_rw[R];
-            if (!(wb & 1u)) continue;
-            const int i0 = s_rrow[R] & ((1 << E_RF_SHIFT) - 1);
-            int bjr = 0, ex = 0;
-            while (bjr + 1 < nblk && i0 >= s_blk[bjr].end) ++bjr;
-            for (int j = 0; j <= bjr; ++j) ex += s_blk[j].extra_close >= 0 ? 1 : 0;    // '+' windows in front of this run
-            s_list[cur + ex] = (uint32_t)R | (((wb >> 1) & 7u) << 11) | (((wb >> 4) & 3u) << 14);
-            ++cur;
-        }
-        if (tid < nblk && s_blk[tid].extra_close >= 0) {
-            // (in front of it: the windows of the runs of the blocks before -- the runs whose head lies in front of this block's rows)
-            int ex = 0, before = 0;
-            for (int j = 0; j < tid; ++j) ex += s_blk[j].extra_close >= 0 ? 1 : 0;
-            const int my_begin = tid == 0 ? 0 : s_blk[tid - 1].end;
-            for (int R = 0; R < n_runs; ++R) {
-                if ((s_rrow[R] & ((1 << E_RF_SHIFT) - 1)) >= my_begin) break;
-                before += s_rw[R] & 1u;
-            }
-            s_list[before + ex] = (1u << 31) | (uint32_t)tid;
-        }
-    }
-    // ---- the first record slot: the pieces before this one.  All 256 threads look at one piece each: with one lane the inclusive
-    // values would travel from piece to piece, a memory round trip each, through the 1 500 pieces in flight (measured: 0.9 ms of
-    // 2.4); with one wave, 64 pieces per round trip, still 0.76 ----
-    if (tid == 0) {
-        if (giveup) {
-            atomicOr(&A.cnt->giveup, 1u);
-            *reinterpret_cast<volatile unsigned long long *>(&A.cnt->irregular_pass) = A.pass_no;
-        }
-        __hip_atomic_store(&A.look[piece_no], tag | LOOK_AGG | (unsigned long long)n_win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    long long excl = 0;
-#if defined(MC_XD) && MC_XD == 2
-    excl = piece_no * 130;
-    for (int64_t j0 = -1; j0 >= 0; j0 -= E_THREADS) {
-#else
-    for (int64_t j0 = piece_no - 1; j0 >= 0; j0 -= E_THREADS) {
-#endif
-        const int64_t j = j0 - tid;
-        unsigned long long v = LOOK_INC;                            // (in front of the first piece: nothing)
-        if (j >= 0)
-            do { v = __hip_atomic_load(&A.look[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 48) != (tag >> 48) || !(v & (LOOK_AGG | LOOK_INC)));
-        const unsigned long long incm = __ballot((v & LOOK_INC) != 0ull);
-        const int first = incm ? __ffsll((unsigned long long)incm) - 1 : 64;         // the nearest piece of the wave's 64 that knows its inclusive value
-        long long val = lane <= first ? (long long)(v & LOOK_VAL) : 0;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) val += __shfl_xor(val, o2);
-        if (lane == 0) { s_look_sum[wave] = val; s_look_inc[wave] = incm ? 1 : 0; }
-        lds_barrier();
-        bool found = false;
-        for (int w = 0; w < E_THREADS / 64 && !found; ++w) { excl += s_look_sum[w]; found = s_look_inc[w] != 0; }
-        lds_barrier();
-        if (found) break;
-    }
-    if (tid == 0) {
-        __hip_atomic_store(&A.look[piece_no], tag | LOOK_INC | (unsigned long long)(excl + n_win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (piece_no == (int64_t)gridDim.x - 1) A.cnt->n_records = (unsigned long long)(excl + n_win);
-        if (excl + n_win > A.O.capacity) atomicOr(&A.cnt->overflow, 1u);
-    }
-    if (excl + n_win > A.O.capacity) excl = -1;
-    if (tid == 0) s_first = excl;
-    lds_barrier();
-    const long long first_rec = s_first;
-    if (first_rec < 0 || giveup) return;
-#if defined(MC_XD) && MC_XD == 3
-    if (n_win >= 0) return;
-#endif
-    // ---- the records ----
-    for (int w = tid; w < n_win; w += E_THREADS) {
-        const int64_t q = first_rec + w;
-        const uint32_t e = s_list[w];
-        if (e >> 31) {                              // the one-event '+' window of a palindromic first site row (R5)
-            const DenseBlock &B = s_blk[e & 0xFFu];
-            for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
-            A.O.wmask[q] = 0;
-            A.O.site_pos[q] = B.extra_mpos;
-            A.O.site_seg[q] = T.nb_seg_begin[B.id];
-            A.O.close_row[q] = B.extra_close;
-            A.O.info[q] = MC_I_TOO_MANY | ((!B.extra_ns && (B.xflags & 1)) ? MC_I_MULTI : 0u);
-            A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
-            continue;
-        }
-        const int R = (int)(e & 0x7FFu), o = (int)((e >> 11) & 7u);
-        const bool multi = (e >> 14) & 1u, by_ns = (e >> 15) & 1u;
-        const int i0 = s_rrow[R] & ((1 << E_RF_SHIFT) - 1);
-        int bjr = 0;
-        while (bjr + 1 < nblk && i0 >= s_blk[bjr].end) ++bjr;
-        const DenseBlock &B = s_blk[bjr];
-        const int m = s_rpos[R] + o;
-        const bool rev = B.rev;
-        const int lb = B.lb;
-        const int64_t close_row = by_ns ? B.ns_close : h0 + (int64_t)(s_rrow[R + 1] & ((1 << E_RF_SHIFT) - 1));
-        bool rare = B.stray_q != NO_STRAY && m - B.stray_q >= 0 && m - B.stray_q < k;     // (the stray event is first in its slot)
-        uint32_t have = 0, wide = 0;
-        for (int t = 0; t < k && !rare; ++t) {
-            const int Rt = R - t;
-            if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
-            const int rr = s_rrow[Rt];
-            if ((rr & ((1 << E_RF_SHIFT) - 1)) < max(lb, 0)) break;           // a run of the block before
-            const int qpos = s_rpos[Rt];
-            if (qpos < m - k + 1) break;
-            const int rf = rr >> E_RF_SHIFT;
-            if (rf & RUN_UNUSABLE) { rare = true; break; }
-            const int slot = m - qpos;
-            if (slot < 0) continue;
-            A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];
-            have |= 1u << slot;
-            if (rf & RUN_WIDE) wide |= 1u << slot;
-        }
-        if (rare) {                                 // (the row-by-row kernel: it wants the window's last row -- the last unfiltered row in front of the closing one)
-            Payload P;
-            int64_t r = (by_ns ? B.end_abs : close_row) - 1;
-            while (r > 0 && (T.flags[r] & MC_F_MODEL_N)) --r;
-            P.r = r; P.close_row = close_row; P.m = m; P.close_pos = 0;
-            P.flags = (rev ? PF_REV : 0u) | (B.stray_q != NO_STRAY ? PF_STRAY : 0u) | (multi ? PF_MULTI : 0u) | (by_ns ? PF_CLOSE_NS : 0u);
-            P.nb = B.id;
-            sorted[q] = P;
-            A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
-            continue;
-        }
-        const uint32_t kbits = (1u << k) - 1u, empties = ~have & kbits;
-        const bool too_many = __popc(empties) > A.skip_thresh;
-        uint32_t info = rev ? MC_I_REV : 0u, wmask = 0;
-        for (uint32_t z = too_many ? kbits : empties; z; z &= z - 1u) {
-            const int s = __ffs(z) - 1;
-            A.O.feats[q * k + (rev ? s : k - 1 - s)] = 0.0;
-        }
-        if (too_many) info |= MC_I_TOO_MANY;
-        else {
-            wmask = rev ? wide : __brev(wide) >> (32 - k);
-            info |= rev ? empties : __brev(empties) >> (32 - k);   // feature dst came from an empty slot (:186)
-            // context[k], the character after the 'M', picks the sub-model (:197)
-            const int64_t L = B.contig_len;
-            if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) info |= MC_I_EDGE;
-            else {
-                const int at = rev ? m - 1 : m + 1;
-                const uint32_t word = ((rev ? A.R.mr : A.R.mf) + B.mask_off)[at >> 5];
-                const unsigned char base = (A.R.seq + A.R.seq_off[B.contig])[at];
-                const unsigned char ch = ((word >> (at & 31)) & 1u) ? 'M' : (rev ? comp_char(base) : base);
-                info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-            }
-        }
-        if (multi) info |= MC_I_MULTI;              // the closing row shifted the window (:242-248)
-        A.O.wmask[q] = (uint8_t)wmask;
-        A.O.site_pos[q] = m;
-        A.O.site_seg[q] = T.nb_seg_begin[B.id];
-        A.O.close_row[q] = close_row;
-        A.O.info[q] = info;
-        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
-    }
 }
 
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
@@ -3808,9 +3372,6 @@ struct mc_ctx {
     int32_t *tile_local = nullptr;
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr, *tile_half = nullptr;
-    unsigned long long *look = nullptr;   // k1_dense's look-back words, one per piece of ET rows
-    bool no_fused = false;                // this call's pass was given up by k1_dense: scan + emit pair
-    bool last_fused = false;              // the pass enqueued last went through k1_dense
     long long *tile_chunk = nullptr;
     Payload *payload_sorted = nullptr;   // payloads in file order (k1_list)
     int64_t *rare_list = nullptr;
@@ -4278,10 +3839,8 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
-        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1) || dev_alloc(P, &c->tile_half, (size_t)nt + 1) ||
-        dev_alloc(P, &c->look, (size_t)nt * (TILE / ET) + 2))
+        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1) || dev_alloc(P, &c->tile_half, (size_t)nt + 1))
         return -10;
-    HIP_TRY(hipMemset(c->look, 0, ((size_t)nt * (TILE / ET) + 2) * 8));     // (the words carry the pass they were written in)
     c->scratch_nb = nb;
     c->scratch_tiles = nt;
     return 0;
@@ -5036,33 +4595,9 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.pass_no = pass_no;
     const bool dense = dense_reference(c);
     A.chunk_shift = dense ? 8 : 6;
-    A.look = c->look;
-    A.validate_only = 0;
     A.shard_shift = T.n_tiles >= 1024 ? 6 : 3;
     A.shard_mask = (1 << A.shard_shift) - 1;
     static_assert(NSHARD == 64, "shard_shift");
-    // one-base motifs, every name block regular (as far as this pass knows): ONE kernel finds the windows, orders them and writes
-    // the records (k1_dense); on the table's first pass the scan runs in front of it for the validation alone.  A pass it gives
-    // up (Counters.giveup: marked like a pass with irregular reads) is repeated with the scan + emit pair.
-    static const bool fused_env = getenv("MCALLER_DENSE_FUSED") != nullptr;
-    static const bool no_runs_env = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;
-    c->last_fused = dense && fused_env && !no_runs_env && !c->no_fused;
-    if (c->last_fused) {
-        constexpr int CGD = CHUNK / 8 + 2;
-        if (plan.scan_mode == SCAN_VALIDATE) {
-            A.validate_only = 1;
-            hipLaunchKernelGGL((k1_scan<CGD, SCAN_VALIDATE>), dim3((unsigned)T.n_tiles), dim3(64), 0, st, A);
-        }
-        if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
-        const dim3 pieces((unsigned)((T.n_rows + ET - 1) / ET));
-        if (ev_emit_end && MC_EVENTS_ON_KERNELS) hipExtLaunchKernelGGL(k1_dense, pieces, dim3(E_THREADS), 0, st, nullptr, ev_emit_end, 0, A, sorted);
-        else {
-            hipLaunchKernelGGL(k1_dense, pieces, dim3(E_THREADS), 0, st, A, sorted);
-            if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
-        }
-        *out_args = A;
-        return 0;
-    }
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const dim3 grid((unsigned)T.n_tiles);
     constexpr int CG_DENSE = CHUNK / 8 + 2;      // (every unit of a chunk; one cut by the boundary of its two blocks is listed twice)
@@ -5160,8 +4695,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
 
     free_pool(c->lit_allocs);
     int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
-    c->no_fused = false;
-    for (int attempt = 0; attempt < 5; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         if (int rc = ensure_records(c, cap, k)) return rc;
         K1Args A;
         c->sync_pass_no = ++c->pass_counter;
@@ -5178,12 +4712,6 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         // the table's first pass, and a row contradicts what a block was classified on (its first rows): the validation flags
         // are complete now, the next attempt classifies on them
         if (h.violation) continue;
-        // k1_dense gave the pass up, or met irregular reads (the literal path goes with the scan's records): the scan + emit pair
-        if (c->last_fused && (h.giveup || h.irregular_pass == c->sync_pass_no)) {
-            if (getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: k1_dense gave the pass up (giveup %u, irregular %u): scan + emit\n", h.giveup, (unsigned)(h.irregular_pass == c->sync_pass_no));
-            c->no_fused = true;
-            continue;
-        }
         if (h.n_rare) {
             hipLaunchKernelGGL(k1_rare, dim3((h.n_rare + 63) / 64), dim3(64), 0, c->stream, A, (const Payload *)c->payload_sorted,
                                (const int64_t *)c->rare_list, (int64_t)h.n_rare);
@@ -5377,7 +4905,6 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     }
     const DevTable &T = c->T;
     const int k = prm->k;
-    c->no_fused = false;
     mc_ctx::AsyncBuf &b = c->ab[c->ab_head];
     b.prm = *prm;
     if (T.n_rows == 0 || T.n_nb == 0) {            // nothing to scan: an empty pass
