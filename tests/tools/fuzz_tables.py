@@ -2,7 +2,8 @@
 sizes around the multiples of a chunk / a piece (1024 rows) and a tile (2048), reads from a dozen to thousands of events, every k
 and skip_thresh, a quality threshold that filters reads -- each as a table's first pass (synchronous, validating), second, third
 and, declared new, the validating pass again with two in flight, against the C oracle.  (The micro-cases of fuzz_gpu.py are a
-few hundred rows: they never cross a chunk.)  usage: fuzz_dense_tables.py [n_tables] [first seed]"""
+few hundred rows: they never cross a chunk.)  usage: fuzz_tables.py [n_tables] [first seed] [dense|sparse]
+("sparse": the same tables under motifs of three to five bases -- k1_scan<64>'s candidate lists, k1_emit)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,14 +13,17 @@ from tests import helpers as H
 
 n_tables = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 9000000
+kind = sys.argv[3] if len(sys.argv) > 3 else 'dense'
+MOTIFS = {'dense': ['A', 'A', 'A', 'C', 'AT', 'GA'],                                   # one-base motifs, and two-base ones that are dense too
+          'sparse': ['GATC', 'GATC', 'CAG', 'TAC', 'GCAGC', 'ACGT', 'CCG']}[kind]
 dev = Device(0)
 bad, done, rows, t0 = [], 0, 0, time.time()
 for i in range(n_tables):
     seed = seed0 + i
     rng = np.random.default_rng(seed)
     codes = synth.genome(length=int(rng.integers(30000, 400000)), seed=seed)
-    motif = ['A', 'A', 'A', 'C', 'AT', 'GA'][int(rng.integers(0, 6))]          # one-base motifs, and two-base ones that are dense too
-    base = 'C' if motif == 'C' else 'A'
+    motif = MOTIFS[int(rng.integers(0, len(MOTIFS)))]
+    base = 'A' if 'A' in motif else 'C'
     lo = int(rng.choice([8, 30, 120, 600, 3000]))
     read_len = (lo, lo * int(rng.integers(2, 12)))
     around = int(rng.choice([1024, 2048, 3072, 4096, 10240, 50000, 200000]))

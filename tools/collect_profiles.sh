@@ -37,7 +37,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats2 
 cp $out/stats2/*/*kernel_stats.csv $out/kernel_stats_file_to_file.csv; rm -rf $out/stats2
 # evidence on THIS code: fuzz campaign, pipelined soak, streamed-CLI soak (logs carry the commit and the kernel-source hash)
 ( echo "commit $head, kernel sources $src"; timeout 1500 python3 tests/tools/fuzz_gpu.py ${FUZZ_PER_FLAVOUR:-600} ${FUZZ_SEED:-31000000} ) > $out/fuzz.log 2>&1
-( echo "commit $head, kernel sources $src"; timeout 900 python3 tests/tools/fuzz_dense_tables.py ${FUZZ_DENSE_TABLES:-2000} ${FUZZ_SEED:-31000000} ) > $out/fuzz_dense_tables.log 2>&1
+( echo "commit $head, kernel sources $src"; timeout 900 python3 tests/tools/fuzz_tables.py ${FUZZ_DENSE_TABLES:-2000} ${FUZZ_SEED:-31000000} dense; timeout 900 python3 tests/tools/fuzz_tables.py ${FUZZ_SPARSE_TABLES:-2000} ${FUZZ_SEED:-31000000} sparse ) > $out/fuzz_tables.log 2>&1
 ( echo "commit $head, kernel sources $src"; timeout 600 python3 tools/pipeline_soak.py 1e8 ${SOAK_PASSES:-1500} ) > $out/pipeline_soak.log 2>&1
 ( echo "commit $head, kernel sources $src"; timeout 900 python3 tools/stream_soak.py 3e6 ${SOAK_RUNS:-30} ) > $out/stream_soak.log 2>&1
 fi
@@ -49,4 +49,4 @@ for f in ("bench","bench_sync","bench_1e9","bench_dense_1e8"):
     except Exception as e: print(f, e)
 P
 tail -n 3 $out/bench.err
-tail -n 2 $out/fuzz.log $out/fuzz_dense_tables.log $out/pipeline_soak.log $out/stream_soak.log 2>/dev/null
+tail -n 2 $out/fuzz.log $out/fuzz_tables.log $out/pipeline_soak.log $out/stream_soak.log 2>/dev/null
