@@ -9,6 +9,9 @@ from column 3 of the test TSV; (2) runs the reference's own C
 its testdata and on random micro-cases from oracle/casegen.py; (3) compares every output with
 oracle/py_oracle.py (the pin) and writes the captured reference outputs under tests/golden/.
 
+usage: make_golden.py [n_micro_cases=2000] [--out DIR] [--rf-only]
+(--out DIR: write the fixtures under DIR/tests/golden and DIR/mcaller_amd/models instead of into the repository.)
+
 Outputs (all DATA: inputs + expected outputs + exported weight arrays, no reference source):
   tests/golden/testdata/          the reference's test inputs (TSV gz, FASTQ, position lists, the
                                   rebuilt span of the FASTA) and its own golden outputs
@@ -33,6 +36,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
 sys.path.insert(0, REPO)
+# where the fixtures go: the repository, or a copy of its layout under --out DIR (tests/test_pin_recipe.py regenerates them
+# into a scratch directory and compares with the committed bytes)
+OUT_GOLDEN = HERE                                          # tests/golden/
+OUT_PKG_MODELS = os.path.join(REPO, 'mcaller_amd', 'models')   # the weight exports ship with the package
+
+
+def golden_models_dir():
+    """models_meta.json, the RF fixture and its meta (the .npz weight exports live in OUT_PKG_MODELS)."""
+    return os.path.join(OUT_GOLDEN, 'models')
 
 SEQIO_STANDIN = '''
 """Minimal stand-in for Bio.SeqIO.parse (FASTA / FASTQ) -- ours, for running the reference here."""
@@ -137,10 +149,12 @@ def run_cli(script, argv):
     return buf.getvalue(), code
 
 
-def export_models(outdir):
+def export_models():
     import pickle
     import numpy as np
+    outdir = golden_models_dir()
     os.makedirs(outdir, exist_ok=True)
+    os.makedirs(OUT_PKG_MODELS, exist_ok=True)
     meta = {}
     for fn in ['r95_twobase_model_NN_6_m6A.pkl', 'r94_model_NN_6_m6A.pkl',
                'CAAYNNNNNRTAC_model_6_m6A.pkl', 'CRAANNNNNNNTGC_model_6_m6A.pkl']:
@@ -159,9 +173,7 @@ def export_models(outdir):
         if is_dict:
             arrays['__is_dict__'] = np.array([1], dtype=np.uint8)     # (a dict with the single key 'general' stays a dict)
         stem = fn[:-4]
-        pkg_models = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'mcaller_amd', 'models')   # shipped with the package
-        os.makedirs(pkg_models, exist_ok=True)
-        np.savez(os.path.join(pkg_models, stem + '.npz'), **arrays)
+        np.savez(os.path.join(OUT_PKG_MODELS, stem + '.npz'), **arrays)
         # known answers: predict_proba on fixed probe vectors, per sub-model
         rng = np.random.default_rng(7)
         probes = np.concatenate([rng.normal(0, 2.5, size=(64, 6)), rng.uniform(6, 12, size=(64, 1))], axis=1)
@@ -177,7 +189,7 @@ def export_models(outdir):
     return meta
 
 
-def export_rf_fixture(outdir):
+def export_rf_fixture():
     """BASELINE config 5's alternative classifier: a scikit-learn RandomForestClassifier with the reference's
     hyper-parameters (train_model.py:40-45; `min_impurity_split` dropped, scikit-learn >= 1.0 rejects it) and a fixed
     random_state, fitted HERE on seeded synthetic vectors labelled by the shipped r95 MLP.  The pickle (data, written by
@@ -185,6 +197,8 @@ def export_rf_fixture(outdir):
     import pickle
     import numpy as np
     from sklearn.ensemble import RandomForestClassifier
+    outdir = golden_models_dir()
+    os.makedirs(outdir, exist_ok=True)
     rng = np.random.default_rng(11)
     ref = pickle.loads(open(os.path.join(REF, 'r95_twobase_model_NN_6_m6A.pkl'), 'rb').read(), encoding='latin')
     models, ka = {}, {}
@@ -206,10 +220,11 @@ def export_rf_fixture(outdir):
               open(os.path.join(outdir, 'rf_meta.json'), 'w'))
 
 
-def load_weights(models_dir, stem):
+def load_weights(stem):
+    """The arrays export_models() wrote: weights from OUT_PKG_MODELS, the sub-model list from models_meta.json."""
     import numpy as np
-    z = np.load(os.path.join(models_dir, stem + '.npz'))
-    meta = json.load(open(os.path.join(models_dir, 'models_meta.json')))[stem]
+    z = np.load(os.path.join(OUT_PKG_MODELS, stem + '.npz'))
+    meta = json.load(open(os.path.join(golden_models_dir(), 'models_meta.json')))[stem]
     out = {'__twobase__': meta['is_dict']}
     for key in meta['submodels']:
         out[key] = (z[key + '.W1'], z[key + '.b1'], z[key + '.W2'], z[key + '.b2'])
@@ -257,7 +272,7 @@ def run_reference_case(ec, rq, pos2label, case, d):
     return dict(outcome=outcome, text=text, stdout=buf.getvalue().split('\n'), ret=ret)
 
 
-def run_oracle_case(case, d, models_dir):
+def run_oracle_case(case, d):
     from oracle import py_oracle as po
     a = case['args']
     tsv = os.path.join(d, 'case.eventalign.tsv')
@@ -272,7 +287,7 @@ def run_oracle_case(case, d, models_dir):
             t = line.split()
             if len(t) > 1:
                 pos_label[(t[0], int(t[1]), t[2])] = t[3]
-    models = None if a['train'] else load_weights(models_dir, MODEL_FILES[a['model']])
+    models = None if a['train'] else load_weights(MODEL_FILES[a['model']])
     outcome, res = 'ok', None
     try:
         res = po.extract_features_oracle(tsv, fasta, read2qual, a['k'], a['skip_thresh'], a['qual_thresh'],
@@ -327,7 +342,13 @@ def _plain(sig):
 
 
 def main():
+    global OUT_GOLDEN, OUT_PKG_MODELS
     n_micro = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2000
+    if '--out' in sys.argv:                                  # a scratch copy of the repository's layout
+        root = os.path.abspath(sys.argv[sys.argv.index('--out') + 1])
+        OUT_GOLDEN = os.path.join(root, 'tests', 'golden')
+        OUT_PKG_MODELS = os.path.join(root, 'mcaller_amd', 'models')
+        os.makedirs(OUT_GOLDEN, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='mcaller_golden_')
     install_shims(scratch)
     import extract_contexts as ec
@@ -335,12 +356,11 @@ def main():
     from train_model import pos2label
     from oracle import casegen
 
-    models_dir = os.path.join(HERE, 'models')
     if '--rf-only' in sys.argv:
-        export_rf_fixture(models_dir)
+        export_rf_fixture()
         return
-    meta = export_models(models_dir)
-    export_rf_fixture(models_dir)
+    meta = export_models()
+    export_rf_fixture()
     report = {'models': {k: v['sha256'] for k, v in meta.items()}}
 
     # ------------------------------------------------------------------ testdata ------------
@@ -351,7 +371,7 @@ def main():
     os.chmod(td, 0o755)
     genome = rebuild_fasta(os.path.join(td, 'masonread1.eventalign.tsv'),
                            os.path.join(td, 'pb_ecoli_polished_assembly.fasta'), False)
-    fix_td = os.path.join(HERE, 'testdata')
+    fix_td = os.path.join(OUT_GOLDEN, 'testdata')
     os.makedirs(fix_td, exist_ok=True)
     with open(os.path.join(td, 'masonread1.eventalign.tsv'), 'rb') as src, \
             gzip.GzipFile(os.path.join(fix_td, 'masonread1.eventalign.tsv.gz'), 'wb', mtime=0) as dst:
@@ -364,7 +384,7 @@ def main():
     json.dump({'contig': 'ecoli', 'length': 4734145, 'span_start': 13100, 'span': genome[13100:26500]},
               open(os.path.join(fix_td, 'rebuilt_fasta_span.json'), 'w'))
 
-    ref_out = os.path.join(HERE, 'ref_outputs')
+    ref_out = os.path.join(OUT_GOLDEN, 'ref_outputs')
     os.makedirs(ref_out, exist_ok=True)
     model = os.path.join(REF, 'r95_twobase_model_NN_6_m6A.pkl')
     common = ['-r', os.path.join(td, 'pb_ecoli_polished_assembly.fasta'),
@@ -424,8 +444,8 @@ def main():
     tsvp = os.path.join(td, 'masonread1.eventalign.tsv')
     fap = os.path.join(td, 'pb_ecoli_polished_assembly.fasta')
     r2q = po.read_fastq_quality(os.path.join(td, 'masonread1.fastq'))
-    w95 = load_weights(models_dir, MODEL_FILES['r95'])
-    w94 = load_weights(models_dir, MODEL_FILES['r94'])
+    w95 = load_weights(MODEL_FILES['r95'])
+    w94 = load_weights(MODEL_FILES['r94'])
     specs = [('config1_positions_m6A', dict(positions_list=os.path.join(td, 'test_positions_m6A.txt')), w95, 0),
              ('motif_GATC', dict(motif='GATC'), w95, 0), ('motif_A', dict(motif='A'), w95, 0),
              ('positions_all', dict(positions_list=posf), w95, 0),
@@ -447,7 +467,7 @@ def main():
     for seed in range(n_micro):
         case = casegen.gen_case(seed)
         ref = run_reference_case(ec, rq, pos2label, case, d)
-        orc = run_oracle_case(case, d, models_dir)
+        orc = run_oracle_case(case, d)
         df = compare_case(ref, orc)
         fl = case['flavour']
         by_flavour.setdefault(fl, [0, 0])
@@ -468,9 +488,9 @@ def main():
             kept.append(case)
     report['micro'] = dict(cases=n_micro, different=n_diff, by_flavour=by_flavour, outcomes=outcomes,
                            first_differences=first_diffs, kept=len(kept))
-    with gzip.GzipFile(os.path.join(HERE, 'micro_cases.json.gz'), 'wb', mtime=0) as fh:
+    with gzip.GzipFile(os.path.join(OUT_GOLDEN, 'micro_cases.json.gz'), 'wb', mtime=0) as fh:
         fh.write(json.dumps(kept).encode())
-    json.dump(report, open(os.path.join(HERE, 'PIN_REPORT.json'), 'w'), indent=1, sort_keys=True)
+    json.dump(report, open(os.path.join(OUT_GOLDEN, 'PIN_REPORT.json'), 'w'), indent=1, sort_keys=True)
     print(json.dumps({k: report[k] for k in ('testdata_pin',)}, indent=1))
     print(json.dumps({k: v for k, v in report['micro'].items() if k != 'by_flavour'}, indent=1))
     print(json.dumps(report['micro']['by_flavour']))

@@ -36,7 +36,9 @@ def build_input(path):
 def main():
     scratch = tempfile.mkdtemp(prefix='mcaller_golden_bed_')
     mg.install_shims(scratch)
-    out_dir = os.path.join(HERE, 'bed_cases')
+    # --out DIR: write under DIR/tests/golden/bed_cases instead of into the repository (tests/test_pin_recipe.py)
+    out_root = os.path.join(os.path.abspath(sys.argv[sys.argv.index('--out') + 1]), 'tests', 'golden') if '--out' in sys.argv else HERE
+    out_dir = os.path.join(out_root, 'bed_cases')
     os.makedirs(out_dir, exist_ok=True)
     work = os.path.join(scratch, 'w')
     os.makedirs(work)

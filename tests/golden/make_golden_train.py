@@ -52,7 +52,9 @@ def sklearn_fit(X, y, init, max_iter):
 
 
 def main():
-    out = os.path.join(HERE, 'train')
+    # --out DIR: write under DIR/tests/golden/train instead of into the repository (tests/test_pin_recipe.py)
+    out_root = os.path.join(os.path.abspath(sys.argv[sys.argv.index('--out') + 1]), 'tests', 'golden') if '--out' in sys.argv else HERE
+    out = os.path.join(out_root, 'train')
     os.makedirs(out, exist_ok=True)
     cases = [('n1000_h100', 1000, 100, 2.0, 200), ('n450_h100', 450, 100, 1.2, 60), ('n150_h100', 150, 100, 3.0, 200),
              ('n333_h16', 333, 16, 2.5, 40), ('n3000_h16_noise_stops', 3000, 16, 0.0, 200), ('n1000_h4_noise_stops', 1000, 4, 0.0, 200)]
