@@ -11,7 +11,13 @@ Workload at N=1: BASELINE.json configs[2] -- synthetic 10^8 events, -m GATC, NN 
 skip_thresh 0.  N>1: every rank scans its own 10^8-row shards of reads (weak scaling, no data-path collective).
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts the N ranks itself.
 
-Prints ONE JSON line on rank 0.  Beside the contract's keys it carries, at N=1:
+After the timed steps the ranks > 0 are done; rank 0 goes on alone (at every N) with the product-shaped legs, among them
+  strong_scaling             BASELINE.json configs[3] through the product path: ONE 10^8-row eventalign file ->
+                             `python -m mcaller_amd.mCaller --gpus N --bed` (mcaller_amd/multi_gpu.py: N byte ranges cut at read
+                             starts, one worker process per GPU streaming its range over its own PCIe link, the per-site
+                             ncclAllReduce, .diffs.6 and BED written), wall time of the whole run; "scaling": "strong"
+
+Prints ONE JSON line on rank 0.  Beside the contract's keys it carries:
   config.device_e2e          distinct shards (10^8 rows in total) streamed from pinned host memory through the table slots:
                              H2D + per-table kernel + pass + D2H of the records, next to the measured H2D-only rate
   config.file_to_file        eventalign TSV -> .diffs.6 through the CLI (parser and row formatter included)
@@ -181,6 +187,70 @@ def python_twin_baseline(paths, model_npz, n_rows_file):
                       % (n_jobs, sample / 1e6, rows, dt)}
 
 
+REAL_STDOUT = None
+
+
+def print_line(obj):
+    out = REAL_STDOUT if REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(obj) + '\n')
+    out.flush()
+
+
+METRIC = 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)'
+STRONG_KEYS = ('scaling', 'n_gpus', 'rows', 'tsv_bytes', 'calls', 'calls_per_s', 'events_per_s', 'text_GBps', 'seconds_median',
+               'seconds_best', 'seconds_first_run', 'seconds_all', 'site_reduction', 'workers', 'phases_s', 'bed_rows',
+               'diffs_equal_the_one_gpu_run', 'peak_rss_mb', 'what')
+
+
+def strong_scaling_leg(inputs_dir, n_gpus, dry=False, rows=None, one_gpu_sha=None, one_device=False, runs=4):
+    """BASELINE.json configs[3] as it is stated, through the product: one eventalign file of `rows` rows ->
+    `mCaller --gpus N --bed` (tools/file_to_file.py runs the CLI `runs` times in a process of its own; the workers of the first
+    run stay for the later ones).  Total work is fixed as N grows: "scaling": "strong".  The timed span of a run is the CLI's
+    main(): FASTQ qualities, FASTA, the cut into N byte ranges, N workers streaming (read, H2D, parse, passes, rows), the
+    per-site reduction (ncclAllReduce when N > 1 communicators come up, the host's sum otherwise), parts joined, BED written."""
+    out = dict.fromkeys(STRONG_KEYS)
+    out['scaling'], out['n_gpus'] = 'strong', n_gpus
+    if dry:
+        return out
+    import subprocess
+    env = dict(os.environ, MCALLER_KEEP_WORKERS='1')
+    if one_device:
+        env['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * n_gpus)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', inputs_dir, '--runs', str(runs),
+                        '--json', '--gpus', str(n_gpus), '--bed'], capture_output=True, text=True, timeout=1200, env=env)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-800:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    secs = res['seconds_all']
+    warm = secs[1:] if len(secs) > 1 else secs
+    med = float(np.median(warm))
+    stats = [x for x in res.get('sharded_runs', []) if x]
+    last = stats[-1] if stats else None
+    if last is None:
+        raise RuntimeError('the sharded path declined the file (one-GPU fall-back ran): %s | stderr: %s'
+                           % (res.get('stdout_tail', '')[-300:], r.stderr[-600:]))
+    red = dict(last['site_reduction'] or {})
+    if len(stats) > 1:           # (the collective's milliseconds: median over the warm runs)
+        ms_all = [x['site_reduction']['ms'] for x in stats[1:] if x['site_reduction'] and x['site_reduction'].get('ms') is not None]
+        red['ms_all_runs'] = [x['site_reduction'].get('ms') if x['site_reduction'] else None for x in stats]
+        if ms_all:
+            red['ms'] = float(np.median(ms_all))
+    out.update(rows=rows if rows is not None else last['rows'], tsv_bytes=res['tsv_bytes'], calls=res['calls'],
+               calls_per_s=res['calls'] / med, events_per_s=last['rows'] / med, text_GBps=res['tsv_bytes'] / med / 1e9,
+               seconds_median=med, seconds_best=min(warm), seconds_first_run=secs[0], seconds_all=secs, site_reduction=red,
+               workers=[dict(rank=w['rank'], device=w['device'], rows=w['rows'], text_bytes=w['text_bytes'], shards=w['shards'],
+                             seconds=w['seconds']['total'], seconds_setup=w['seconds']['setup'],
+                             seconds_site_counts=w['seconds']['site_counts'], peak_rss_mb=w['peak_rss_mb']) for w in last['workers']],
+               phases_s=last['seconds'], bed_rows=res.get('bed_rows'),
+               diffs_equal_the_one_gpu_run=(res['diffs_sha256'] == one_gpu_sha) if one_gpu_sha else None,
+               peak_rss_mb=res['peak_rss_mb'],
+               what='python tools/file_to_file.py --inputs ... --runs %d --gpus %d --bed: the CLI (mcaller_amd.mCaller --gpus N --bed) '
+                    '%d times in one process of its own, page cache warm; seconds_first_run includes starting the %d worker '
+                    'processes (interpreter, HIP context, pinned buffers), the later runs find them waiting; median / best over the '
+                    'later runs; workers / phases_s / site_reduction: the last run' % (runs, n_gpus, runs, n_gpus))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -197,14 +267,23 @@ def main():
     ap.add_argument('--f2f-events', type=float, default=1e7, help='file to file: rows of eventalign text (0: skip)')
     ap.add_argument('--f2f-big-events', type=float, default=1e8,
                     help='file to file at the headline size, in a process of its own: rows of eventalign text (0: skip)')
+    ap.add_argument('--strong-events', type=float, default=1e8,
+                    help='strong-scaling leg (one file through mCaller --gpus N --bed): rows of eventalign text (0: skip)')
     ap.add_argument('--kernels-only', action='store_true', help='skip device end-to-end, file to file and the CPU legs (profiling runs)')
     ap.add_argument('--rescan-only', action='store_true',
                     help='profiling runs: the timed steps re-scan ONE validated table (config.resident_rescan) instead of full passes')
     ap.add_argument('--dry-ranks', action='store_true',
                     help='launch plumbing only (CPU test): the ranks rendezvous, rank 0 prints n_gpus, nothing touches a GPU')
     args = ap.parse_args()
+    # The one JSON line is the only thing this program writes to its stdout: from here on file descriptor 1 is stderr (RCCL and
+    # gloo announce themselves on the C library's stdout, buffered until exit), the line goes to a private copy of the real one.
+    global REAL_STDOUT
+    if REAL_STDOUT is None and not (args.gpus > 1 and 'WORLD_SIZE' not in os.environ):
+        sys.stdout.flush()
+        REAL_STDOUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
     if args.kernels_only:
-        args.stream_shards, args.f2f_events, args.f2f_big_events, args.no_cpu_baseline = 0, 0, 0, True
+        args.stream_shards, args.f2f_events, args.f2f_big_events, args.strong_events, args.no_cpu_baseline = 0, 0, 0, 0, True
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -221,8 +300,12 @@ def main():
             total = int(t[0])
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({'dry_ranks': True, 'n_gpus': world, 'ranks_seen': total, 'launcher': 'bench.py itself'
-                              if os.environ.get('MCALLER_BENCH_SPAWNED') else 'environment'}))
+            # (the schema of the real line's two legs, values empty: the weak leg = the contract's keys, the strong leg below)
+            print_line({'dry_ranks': True, 'n_gpus': world, 'ranks_seen': total, 'launcher': 'bench.py itself'
+                              if os.environ.get('MCALLER_BENCH_SPAWNED') else 'environment',
+                              'metric': METRIC, 'value': None, 'unit': 'calls/s', 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': None, 'ms_per_step_steady': None, 'scaling': 'weak',
+                              'strong_scaling': strong_scaling_leg(None, world, dry=True)})
         return
     from mcaller_amd import synth, _lib
     from mcaller_amd.device import Device
@@ -243,6 +326,7 @@ def main():
     _, weights, _, soc = submodel_setup(modelset, 'A')
 
     dev_index = 0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local      # (one-GPU boxes: test the N>1 plumbing)
+    affinity_at_start = os.sched_getaffinity(0)
     numa_node = Device.bind_host_to_numa_node(dev_index) if (world > 1 or os.environ.get('MCALLER_BENCH_BIND')) else None  # pinned buffers next to the rank's GPU
     dev = Device(dev_index)
     dev.set_reference(ref.device_arrays())
@@ -306,7 +390,10 @@ def main():
     time_every = 1 if args.no_pipeline else max(1, min(args.time_every, max(1, args.steps // 2)))
     dev.set_pass_timing(time_every)
 
+    done_at = []
+
     def on_done(rec):
+        done_at.append(time.perf_counter())
         last[0] = rec
         calls_seen[0] += int(rec.n_calls) if getattr(rec, '_compacted', False) else int(((rec.info[:rec.n] & _lib.I_TOO_MANY) == 0).sum())
         calls_seen[1] += 1
@@ -322,11 +409,16 @@ def main():
     calls_seen[:] = [0, 0]
     barrier()
     dev.sync()                              # nothing of the warm-up is left on any stream
+    del done_at[:]
     t0 = time.perf_counter()
     run_steps(args.steps, on_done, full)    # the last wait() returns when the last pass's records are in host memory
     dev.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the step time without the pipeline's fill and drain: the median interval between the completions of consecutive passes
+    # (a 20-step run pays one fill and one drain in 20 steps, a 200-step run in 200: this figure is the same for both)
+    gaps = np.diff(np.array(done_at[:args.steps]))
+    steady_ms = float(np.median(gaps)) * 1e3 if len(gaps) >= 3 else None
     calls_in_region = calls_seen[0]         # calls of all timed steps of this rank (the two tables differ by a few)
     rec = last[0]
     info = rec.info[:rec.n]
@@ -376,7 +468,7 @@ def main():
     # the one exchange step of the multi-GPU job: per-site counts summed over ranks (feeds make_bed).  Outside the timed
     # steps.  Counted on the device from the records of the last step and all-reduced with RCCL through the C ABI
     # (mc_site_counts / mc_site_allreduce); if that fails (e.g. a plumbing test with two ranks on one GPU) the same
-    # reduction goes through torch.distributed (nccl, then gloo) from the host copy of the records.
+    # reduction goes through torch.distributed's gloo group from the host copy of the records.
     reduction = None
     reduction_hung = False
     if dist is not None:
@@ -414,26 +506,14 @@ def main():
                     import torch
                     counts = make_bed.site_counts(rec_red, table_red, index, row_offset=rank * n_rows)
 
-                    def reduce_with(backend):
-                        group = dist.new_group(backend=backend) if backend == 'nccl' else None
-                        packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
-                        fmin = torch.from_numpy(counts[2].copy())
-                        if backend == 'nccl':
-                            torch.cuda.set_device(0 if os.environ.get('MCALLER_BENCH_ONE_DEVICE') else local)
-                            packed, fmin = packed.cuda(), fmin.cuda()
-                        t_r = time.perf_counter()
-                        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-                        dist.all_reduce(fmin, op=dist.ReduceOp.MIN, group=group)
-                        if backend == 'nccl':
-                            torch.cuda.synchronize()
-                        return packed.cpu(), fmin.cpu(), (time.perf_counter() - t_r) * 1e3
-
-                    backend = 'torch nccl (native RCCL path failed: %s)' % e_native
-                    try:
-                        packed, fmin, ms = reduce_with('nccl')
-                    except Exception as e_nccl:                    # noqa
-                        backend = 'gloo (native: %s; torch nccl: %s)' % (e_native, type(e_nccl).__name__)
-                        packed, fmin, ms = reduce_with('gloo')
+                    # (the same reduction through torch.distributed's gloo group, from the host copy of the records)
+                    packed = torch.from_numpy(np.stack([counts[0], counts[1]]))
+                    fmin = torch.from_numpy(counts[2].copy())
+                    t_r = time.perf_counter()
+                    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
+                    ms = (time.perf_counter() - t_r) * 1e3
+                    backend = 'gloo (native RCCL path: %s)' % e_native
                     reduction = {'backend': backend, 'ms': ms, 'observations': int(packed[1].sum().item()),
                                  'observations_expected': expected,
                                  'bytes': int(packed.numel() * packed.element_size() + fmin.numel() * 8)}
@@ -453,6 +533,27 @@ def main():
         else:
             reduction = box.get('reduction')
 
+    # ---- the ranks > 0 are done.  Rank 0 goes on alone with the product-shaped legs -- at every N -- once the others have let
+    #      go of their GPUs (the workers of the strong-scaling leg take all N) ----
+    if dist is not None:
+        if rank != 0:
+            dev.close()
+            dev = None
+        if reduction_hung:               # (a thread is stuck inside a collective: no orderly shutdown, no barrier to trust)
+            if rank != 0:
+                sys.stdout.flush()
+                os._exit(0)
+        else:
+            barrier()
+            dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            return
+        try:                             # (rank 0 is alone now: its solo legs and the workers it starts may use every core again;
+            os.sched_setaffinity(0, affinity_at_start)          # a worker binds itself to its own GPU's node)
+        except OSError:
+            pass
+
     # ---- the kernels one at a time (outside the timed region): hipEvents around every stage of a synchronous FULL pass ----
     sync_ms = []
     for _ in range(7):
@@ -460,9 +561,9 @@ def main():
         sync_ms.append(dev.times_ms())
     sync_ms = {k: float(np.median([t[k] for t in sync_ms[1:]])) for k in sync_ms[0]}
 
-    # ---- device end to end: distinct shards from pinned host memory through the table slots (N = 1) ----
+    # ---- device end to end: distinct shards from pinned host memory through the table slots (one GPU: rank 0's) ----
     device_e2e, shards = None, []
-    if world == 1 and args.stream_shards > 0:
+    if args.stream_shards > 0:
         try:
             S = args.stream_shards
             per = n_rows // S
@@ -509,9 +610,9 @@ def main():
         except Exception as e:                                  # noqa
             device_e2e = {'error': '%s: %s' % (type(e).__name__, e)}
 
-    # ---- file to file: eventalign TSV -> .diffs.6 through the CLI (N = 1) ----
+    # ---- file to file: eventalign TSV -> .diffs.6 through the CLI (one GPU: rank 0's) ----
     file_to_file, f2f_dir, f2f_paths, f2f_rows = None, None, None, 0
-    if world == 1 and rank == 0 and args.f2f_events > 0:
+    if args.f2f_events > 0:
         try:
             import contextlib
             import io
@@ -526,8 +627,9 @@ def main():
             f2f_paths = synth.write_inputs(t_f, q_f, codes, f2f_dir)
             t_w = time.perf_counter() - t_w
             os.sync()                                            # (the runs below read the page cache, not a file still being written back)
-            dev.close()                                          # the CLI makes its own context
-            dev = None
+            if dev is not None:
+                dev.close()                                      # the CLI makes its own context
+                dev = None
             runs = []
             out_path = f2f_paths['tsv'][:-4] + '.diffs.6'
             for _ in range(10):                                  # (the first runs still pin memory and warm the page cache)
@@ -549,35 +651,51 @@ def main():
         except Exception as e:                                  # noqa
             file_to_file = {'error': '%s: %s' % (type(e).__name__, e)}
 
-    # ---- file to file at the headline size (10^8 rows, 12.8 GB of text), in a process of its own: wall time per run, its peak RSS ----
-    file_to_file_big = None
-    if world == 1 and rank == 0 and args.f2f_big_events > 0 and file_to_file and 'error' not in file_to_file:
+    # ---- the headline size (10^8 rows, 11.7 GB of text), in processes of their own: file to file on one GPU (wall time per run,
+    #      peak RSS), then BASELINE.json configs[3] -- the same file through `mCaller --gpus N --bed` on all N GPUs (strong scaling) ----
+    file_to_file_big, strong = None, None
+    big_rows = int(max(args.f2f_big_events, args.strong_events))
+    if big_rows > 0:
         big_dir = None
         try:
             import subprocess
-            big_rows = int(args.f2f_big_events)
+            if dev is not None:
+                dev.close()                                      # (the legs below run in processes of their own)
+                dev = None
             t_b, q_b = (table, qual) if big_rows == n_rows else synth.make_table(big_rows, seed=1000, codes=codes)
             big_dir = tempfile.mkdtemp(prefix='mc_f2f_big_')
             t_w = time.perf_counter()
             synth.write_inputs(t_b, q_b, codes, big_dir)
             t_w = time.perf_counter() - t_w
             os.sync()
-            r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', big_dir, '--runs', '4', '--json'],
-                               capture_output=True, text=True, timeout=900)
-            if r.returncode != 0:
-                raise RuntimeError(r.stderr[-500:])
-            res = json.loads(r.stdout.strip().splitlines()[-1])
-            runs_b = res['seconds_all']
-            med_b = float(np.median(runs_b[1:]))
-            file_to_file_big = {'rows': big_rows, 'tsv_bytes': res['tsv_bytes'], 'diffs_bytes': res['diffs_bytes'], 'calls': res['calls'],
-                                'seconds_first_run': runs_b[0], 'seconds_best': min(runs_b[1:]), 'seconds_median': med_b,
-                                'seconds_all': runs_b, 'events_per_s': big_rows / med_b, 'calls_per_s': res['calls'] / med_b,
-                                'text_GBps': res['tsv_bytes'] / med_b / 1e9, 'peak_rss_mb': res['peak_rss_mb'], 'inputs_written_s': t_w,
-                                'what': 'python tools/file_to_file.py --inputs ... --runs 4 (the CLI, four times in one process of its '
-                                        'own; page cache warm): rows are appended to the output shard by shard, memory is bounded by '
-                                        'the shards in flight'}
+            one_gpu_sha = None
+            if args.f2f_big_events > 0:
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', big_dir, '--runs', '4',
+                                        '--json'], capture_output=True, text=True, timeout=900)
+                    if r.returncode != 0:
+                        raise RuntimeError(r.stderr[-500:])
+                    res = json.loads(r.stdout.strip().splitlines()[-1])
+                    runs_b = res['seconds_all']
+                    med_b = float(np.median(runs_b[1:]))
+                    one_gpu_sha = res['diffs_sha256']
+                    file_to_file_big = {'rows': big_rows, 'tsv_bytes': res['tsv_bytes'], 'diffs_bytes': res['diffs_bytes'], 'calls': res['calls'],
+                                        'seconds_first_run': runs_b[0], 'seconds_best': min(runs_b[1:]), 'seconds_median': med_b,
+                                        'seconds_all': runs_b, 'events_per_s': big_rows / med_b, 'calls_per_s': res['calls'] / med_b,
+                                        'text_GBps': res['tsv_bytes'] / med_b / 1e9, 'peak_rss_mb': res['peak_rss_mb'], 'inputs_written_s': t_w,
+                                        'what': 'python tools/file_to_file.py --inputs ... --runs 4 (the CLI, four times in one process of its '
+                                                'own; page cache warm): rows are appended to the output shard by shard, memory is bounded by '
+                                                'the shards in flight'}
+                except Exception as e:                          # noqa
+                    file_to_file_big = {'error': '%s: %s' % (type(e).__name__, e)}
+            if args.strong_events > 0:
+                try:
+                    strong = strong_scaling_leg(big_dir, world, rows=big_rows, one_gpu_sha=one_gpu_sha,
+                                                one_device=bool(os.environ.get('MCALLER_BENCH_ONE_DEVICE')))
+                except Exception as e:                          # noqa
+                    strong = dict(strong_scaling_leg(None, world, dry=True), error='%s: %s' % (type(e).__name__, e))
         except Exception as e:                                  # noqa
-            file_to_file_big = {'error': '%s: %s' % (type(e).__name__, e)}
+            file_to_file_big = file_to_file_big or {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             if big_dir:
                 shutil.rmtree(big_dir, ignore_errors=True)
@@ -680,13 +798,16 @@ def main():
                 traffic_source = ('%s was collected on other kernel sources (%s, running %s): no traffic figure'
                                   % (os.path.relpath(PMC_FILE, REPO), pmc.get('kernel_source_sha16'), src_hash))
         out = {
-            'metric': 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)',
+            'metric': METRIC,
             'value': calls_region_total / elapsed_max,
             'unit': 'calls/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed_max / args.steps * 1e3,
+            'ms_per_step_steady': steady_ms,
+            'ms_per_step_steady_what': 'median interval between the completions of consecutive passes of the timed region on rank 0 '
+                                       '(the pipeline\'s fill and drain, which a short run pays inside ms_per_step, left out)',
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -712,6 +833,7 @@ def main():
                        'calls_per_s_kernels_only': calls_per_step / (float(np.mean([t['total'] for t in tot_ms])) * 1e-3),
                        'device_e2e': device_e2e,
                        'device_e2e_events_per_s': (device_e2e or {}).get('events_per_s'),
+                       'strong_scaling': 'see the top-level key (BASELINE.json configs[3]: one file, mCaller --gpus N --bed)',
                        'file_to_file': file_to_file, 'file_to_file_1e8': file_to_file_big, 'text_e2e': text_e2e},
             'roofline': {'bound': 'hbm',
                          'kernel': 'every kernel that touches a table once: k0_first_site + k1_scan (validating) + k1_group_scan + '
@@ -737,7 +859,17 @@ def main():
                                  'bytes only for the listed units, so the kernels move about half the algorithmic bytes: a frac '
                                  'near 1 would not mean 8 TB/s of traffic'},
         }
-        if not args.no_cpu_baseline and world == 1:          # the CPU legs: rank 0 at N=1 only
+        # the story in the order a user meets it: a FILE goes through at file_to_file_calls_per_s (parser, link and row formatter
+        # included), columns that are already parsed at device_e2e_calls_per_s (the link is the bound), and `value` is the rate
+        # of the resident-table passes the roofline is quoted on; each with the CPU leg that does the same work
+        out['file_to_file_calls_per_s'] = (file_to_file_big or {}).get('calls_per_s')
+        out['file_to_file_what'] = ('config.file_to_file_1e8: 10^8 rows of eventalign text -> .diffs.6 through the CLI on one GPU, median '
+                                    'of the warm runs; like-for-like CPU leg: cpu_baseline_reference_like')
+        out['device_e2e_calls_per_s'] = (device_e2e or {}).get('calls_per_s')
+        out['device_e2e_what'] = ('config.device_e2e: parsed columns from pinned host memory, records back in host memory; like-for-like '
+                                  'CPU leg: cpu_baseline_all_cores')
+        out['strong_scaling'] = strong
+        if not args.no_cpu_baseline:                         # the CPU legs: on rank 0, at every N
             from tests import helpers as H                   # the checker (oracle/), timed as the CPU baseline
             n_cpu = min(n_rows, int(args.cpu_events))
             sub = table if n_cpu == n_rows else table.slice_segments(
@@ -780,7 +912,7 @@ def main():
                     out['cpu_baseline_reference_like'] = python_twin_baseline(f2f_paths, model_npz, f2f_rows)
                 except Exception as e:                          # noqa
                     out['cpu_baseline_reference_like'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        print(json.dumps(out))
+        print_line(out)
     if f2f_dir:
         shutil.rmtree(f2f_dir, ignore_errors=True)
     if reduction_hung:                   # (a thread is stuck inside a collective: no orderly shutdown)
@@ -788,8 +920,6 @@ def main():
         os._exit(0)
     if dev is not None:
         dev.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

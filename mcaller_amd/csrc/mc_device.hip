@@ -3429,6 +3429,9 @@ struct mc_ctx {
     int32_t *site_cnt = nullptr;      // [2 * n_sites]: n_meth | n_total
     int64_t *site_first = nullptr;    // [n_sites]
     int64_t site_n = 0;
+    hipStream_t site_stream = nullptr;                  // the reduction's own queue: a shard's records are reduced beside the passes in flight
+    unsigned long long *site_status = nullptr;          // [4] device: pending, not-a-site, cross-contig (k_site_counts)
+    unsigned long long *site_status_host = nullptr, *site_status_host_dev = nullptr;   // pinned copy the host reads (written by a kernel: no DMA)
     void *comm = nullptr;             // ncclComm_t
     int comm_world = 1, comm_rank = 0;
 };
@@ -3591,6 +3594,9 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->cnt) (void)hipFree(c->cnt);
     if (c->site_cnt) (void)hipFree(c->site_cnt);
     if (c->site_first) (void)hipFree(c->site_first);
+    if (c->site_status) (void)hipFree(c->site_status);
+    if (c->site_status_host) (void)hipHostFree(c->site_status_host);
+    if (c->site_stream) { (void)hipStreamSynchronize(c->site_stream); (void)hipStreamDestroy(c->site_stream); }
     (void)sync_pass_streams(c);
     free_async(c);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
@@ -3678,6 +3684,7 @@ extern "C" int mc_ctx_set_reference(mc_ctx *c, const mc_ref_view *h) {
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { mc_set_error("mc_ctx_set_reference: the upload failed"); rc = -11; }
     (void)hipHostFree(stage);
     if (rc) return rc;
+    if (c->site_stream) (void)hipStreamSynchronize(c->site_stream);
     if (c->site_cnt) { (void)hipFree(c->site_cnt); c->site_cnt = nullptr; }
     if (c->site_first) { (void)hipFree(c->site_first); c->site_first = nullptr; }
     c->site_n = 0;
@@ -3749,6 +3756,7 @@ extern "C" int mc_ctx_set_reference_motif(mc_ctx *c, const mc_ref_view *h, const
     (void)hipHostFree(stage);
     free_pool(tmp);
     if (rc) return rc;
+    if (c->site_stream) (void)hipStreamSynchronize(c->site_stream);
     if (c->site_cnt) { (void)hipFree(c->site_cnt); c->site_cnt = nullptr; }
     if (c->site_first) { (void)hipFree(c->site_first); c->site_first = nullptr; }
     c->site_n = 0;
@@ -5231,11 +5239,34 @@ __global__ void k_site_counts(DevRef R, DevRecords O, int64_t n, DevTable T, int
     atomicMin(reinterpret_cast<long long *>(&first[s]), (long long)(O.close_row[j] + row_offset));
 }
 
+// the status words of one accumulation to where the host reads them; zeroed for the next
+__global__ void k_site_status_out(unsigned long long *__restrict__ status, unsigned long long *__restrict__ host) {
+    if (threadIdx.x < 4) {
+        host[threadIdx.x] = status[threadIdx.x];
+        status[threadIdx.x] = 0;
+    }
+}
+
 }  // namespace
 
+// The reduction has a queue of its own (site_stream): the records it reads are those of the pass handed out last -- complete
+// since mc_wait_records returned --, so nothing of it has to wait for, or hold up, the passes in flight on the ctx stream
+// (a shard's reduction used to drain that stream, allocate and free a status block, and fetch 24 bytes through the DMA
+// engines, behind every shard of text on its way: 2 ms per shard).  What the host reads comes back through pinned memory
+// written by a kernel.
 static int ensure_site_buffers(mc_ctx *c) {
     const int64_t n = c->R.n_sites;
+    if (!c->site_stream) HIP_TRY(hipStreamCreateWithFlags(&c->site_stream, hipStreamNonBlocking));
+    if (!c->site_status) {
+        HIP_TRY(hipMalloc((void **)&c->site_status, 256));
+        HIP_TRY(hipMemset(c->site_status, 0, 256));
+    }
+    if (!c->site_status_host) {
+        HIP_TRY(hipHostMalloc((void **)&c->site_status_host, 256, hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&c->site_status_host_dev, c->site_status_host, 0));
+    }
     if (c->site_cnt && c->site_n == n) return 0;
+    HIP_TRY(hipStreamSynchronize(c->site_stream));
     if (c->site_cnt) (void)hipFree(c->site_cnt);
     if (c->site_first) (void)hipFree(c->site_first);
     c->site_cnt = nullptr; c->site_first = nullptr;
@@ -5255,7 +5286,7 @@ extern "C" int mc_site_counts_reset(mc_ctx *c) {
     }
     if (int rc = ensure_site_buffers(c)) return rc;
     const int64_t ns = c->R.n_sites;
-    hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->stream, c->site_cnt, c->site_first, ns);
+    hipLaunchKernelGGL(k_site_fill, dim3((unsigned)((2 * ns + 255) / 256 + 1)), dim3(256), 0, c->site_stream, c->site_cnt, c->site_first, ns);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -5272,18 +5303,14 @@ extern "C" int mc_site_counts_accumulate(mc_ctx *c, int64_t row_offset, int32_t 
         return -12;
     }
     const int64_t ns = c->R.n_sites, n = c->last_n;
-    unsigned long long *status = nullptr;
-    HIP_TRY(hipMalloc((void **)&status, 24));
-    HIP_TRY(hipMemsetAsync(status, 0, 24, c->stream));
     if (n > 0)
-        hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->R, c->O, n,
+        hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->site_stream, c->R, c->O, n,
                            c->last_T.seg_contig ? c->last_T : c->T, (int)tail_contig, row_offset, c->site_cnt,
-                           c->site_first, ns, status);
-    unsigned long long h[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, status, 24, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+                           c->site_first, ns, c->site_status);
+    hipLaunchKernelGGL(k_site_status_out, dim3(1), dim3(64), 0, c->site_stream, c->site_status, c->site_status_host_dev);
     HIP_TRY(hipGetLastError());
-    (void)hipFree(status);
+    HIP_TRY(hipStreamSynchronize(c->site_stream));       // (this queue only: the passes in flight go on)
+    const unsigned long long h[3] = {c->site_status_host[0], c->site_status_host[1], c->site_status_host[2]};
     if (h[1]) {
         mc_set_error("mc_site_counts: %llu records name a position that is not a marked site", h[1]);
         return -14;
@@ -5415,11 +5442,11 @@ extern "C" int mc_site_counts_fetch(mc_ctx *c, int32_t *n_meth, int32_t *n_total
     }
     const int64_t ns = c->site_n;
     if (ns > 0) {
-        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->site_stream));
+        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->site_stream));
+        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->site_stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->site_stream));
     return 0;
 }
 
@@ -5432,18 +5459,18 @@ extern "C" int mc_site_allreduce(mc_ctx *c, int32_t *n_meth, int32_t *n_total, i
     const int64_t ns = c->site_n;
     if (ms) *ms = 0.f;
     if (c->comm && c->comm_world > 1 && ns > 0) {
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        RCCL_TRY(g_rccl.AllReduce(c->site_cnt, c->site_cnt, (size_t)ns * 2, ncclInt32, ncclSum, (ncclComm_t)c->comm, c->stream));
-        RCCL_TRY(g_rccl.AllReduce(c->site_first, c->site_first, (size_t)ns, ncclInt64, ncclMin, (ncclComm_t)c->comm, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->site_stream));
+        RCCL_TRY(g_rccl.AllReduce(c->site_cnt, c->site_cnt, (size_t)ns * 2, ncclInt32, ncclSum, (ncclComm_t)c->comm, c->site_stream));
+        RCCL_TRY(g_rccl.AllReduce(c->site_first, c->site_first, (size_t)ns, ncclInt64, ncclMin, (ncclComm_t)c->comm, c->site_stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->site_stream));
+        HIP_TRY(hipStreamSynchronize(c->site_stream));
         if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
     }
     if (ns > 0) {
-        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_meth, c->site_cnt, (size_t)ns * 4, hipMemcpyDeviceToHost, c->site_stream));
+        HIP_TRY(hipMemcpyAsync(n_total, c->site_cnt + ns, (size_t)ns * 4, hipMemcpyDeviceToHost, c->site_stream));
+        HIP_TRY(hipMemcpyAsync(first_row, c->site_first, (size_t)ns * 8, hipMemcpyDeviceToHost, c->site_stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->site_stream));
     return 0;
 }

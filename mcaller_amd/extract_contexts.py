@@ -384,6 +384,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         raise _Unstreamable('one shard')
     cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
     pieces = [(cuts[i], cuts[i + 1]) for i in range(n_shards) if cuts[i + 1] > cuts[i]]
+    if byte_range is not None and not pieces:
+        # the range of a GPU of a sharded run that holds no read (fewer reads than GPUs): a finished piece, not a reason to
+        # send the whole file to one GPU
+        if on_head is not None:
+            on_head(None)
+        stream_features.last_clock = dict(shards=0)
+        return StreamResult()
     if len(pieces) < min_shards:
         raise _Unstreamable('one shard')
     import contextlib
@@ -724,11 +731,15 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
             with open(tsv_output, 'ab') as out_fh:
                 res = stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base,
                                       motif, positions_list, sink=out_fh.write, train=train, pos_label=pos_label)
-        except _Unstreamable:
+        except BaseException as e:
+            # the rows appended so far are taken back whatever stopped the stream (a device error, MemoryError, ^C: a re-run
+            # must not find half a file to append to); only _Unstreamable goes on to the one-table path
             if size_before is None:
                 os.remove(tsv_output)
             else:
                 os.truncate(tsv_output, size_before)
+            if not isinstance(e, _Unstreamable):
+                raise
         else:
             for line in res.messages:
                 print(line)

@@ -83,6 +83,12 @@ class Run(object):
             self.sharded = extract_features_sharded(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh,
                                                     self.qual_thresh, self.modelfile, self.base, self.motif, self.positions,
                                                     self.n_gpus, bed=self.bed, fastq=getattr(self, 'fastq', None))
+            stats_path = os.environ.get('MCALLER_STATS_JSON')
+            if stats_path:                                  # what the run measured (per worker: rows, seconds; the reduction)
+                import json
+                from . import multi_gpu
+                with open(stats_path, 'w') as fh:
+                    json.dump(multi_gpu.last_run, fh)
             if self.sharded:
                 return None
         labels = pos2label(self.positions) if self.train else None

@@ -282,7 +282,13 @@ def write_bed_from_counts(aggfi, n_meth, n_total, first, index, contig_names, me
     """BED rows in first-occurrence order (make_bed.py:134,154-159) from reduced counts; `extras`: the rows of
     cross_contig_records (all ranks), which are entries of their own."""
     entries = []                                        # (first row, chrom, pos, context, strand, meth, depth)
-    for key in np.nonzero(n_total > 0)[0]:
+    # (the selection of :143-154 on the count arrays first: only the sites that will be written get a context string)
+    n_meth, n_total = np.asarray(n_meth), np.asarray(n_total)
+    seen = n_total > 0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        frac_all = n_meth.astype(np.float64) / n_total.astype(np.float64)
+    keep = seen & (n_total >= depth_thresh) & ((frac_all >= mod_thresh) != bool(control))
+    for key in np.nonzero(keep)[0]:
         c, rev, pos = index.locate(int(key))
         context = revcomp(meth_strings[c][rev][pos - k + 1:pos + k], bool(rev))
         entries.append([int(first[key]), contig_names[c], pos, context, '-' if rev else '+', int(n_meth[key]), int(n_total[key])])

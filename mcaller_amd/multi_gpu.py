@@ -29,8 +29,11 @@ Every wait of the parent has a deadline (MCALLER_WORKER_TIMEOUT seconds, default
 that misses it, dies or reports an error makes the parent terminate all workers and return False: the caller runs the one-GPU
 path.
 
-Workers are spawned (never forked: the parent must not hold a HIP context), one per device in MCALLER_SHARD_DEVICES
-(default 0..n-1).
+Workers are spawned (never forked: the parent must not hand a HIP context down), one per device in MCALLER_SHARD_DEVICES
+(default 0..n-1).  A worker takes jobs until it is told to end: with MCALLER_KEEP_WORKERS set the workers of one file stay for
+the next (their HIP contexts, pinned buffers and table slots with them) -- what a caller that runs file after file wants, and
+what bench.py's strong-scaling leg times as the warm runs.  `last_run` holds what the last run measured (per worker: rows,
+seconds; the reduction: backend, milliseconds, bytes); mCaller.py writes it to $MCALLER_STATS_JSON.
 """
 import multiprocessing
 import multiprocessing.connection
@@ -53,129 +56,34 @@ def _devices(n_gpus):
     return list(range(n_gpus))
 
 
+def _peak_rss_mb():
+    try:
+        for line in open('/proc/self/status'):
+            if line.startswith('VmHWM:'):
+                return int(line.split()[1]) / 1024.0
+    except OSError:
+        pass
+    return None
+
+
 class _Abort(Exception):
     """The parent told the worker to stop."""
 
 
-def _worker(conn, device, job):
-    import contextlib
-    import io
+def _worker(conn, device):
+    """A worker process: one GPU, jobs from the parent until it says None (or its end of the pipe closes).  A plain run sends
+    one job; a caller that runs file after file (MCALLER_KEEP_WORKERS: bench.py's strong-scaling leg) finds the worker, its HIP
+    context, its pinned buffers and its table slots where the last file left them."""
     os.environ['MCALLER_DEVICE'] = str(device)
+    cache = {}
     try:
-        from . import _lib
-        if job['world'] > 1:
-            _lib.lib().mc_bind_to_device_numa_node(int(device))     # reader threads and pinned buffers next to this worker's GPU
-        from . import extract_contexts as ec
-        from . import make_bed
-        from .device import get_device
-        from .model_io import load_model_file
-        read2qual = job['read2qual']
-        if read2qual is None:                 # (every worker reads the FASTQ itself, natively: a pickled dict per worker costs more)
-            from .read_qual import extract_read_quality
-            read2qual = extract_read_quality(job['fastq'])
-        modelset = load_model_file(job['modelfile'])
-        dev = get_device()
-        rank, k = job['rank'], job['k']
-        state = dict(head_sent=False, go_seen=False, index=None, extras=[])
-
-        def on_head(name):
-            state['head_sent'] = True
-            conn.send(dict(head=name))
-
-        def tail_of_last():
-            go = conn.recv()
-            state['go_seen'] = True
-            if go is None:
-                raise _Abort()
-            return go['tail']
-
-        def on_shard(P, rec, fin, tail, rows_before):
-            """The per-site reduction of one shard's records (make_bed.py:86-96), on the device, added to the worker's counts.
-            Records the host scored itself (NaN on the device) are folded in; records whose row names another contig than their
-            site (R8: closed by a row of the next contig) are not sites of the numbering: they travel as `extras`."""
-            if state['index'] is None:
-                state['index'] = make_bed.SiteIndex(P.ref.meth, len(P.ref.names))
-                dev.site_counts_reset()
-            offset = rank * ROW_STRIDE + rows_before
-            extras = make_bed.cross_contig_records(rec, P.table, P.ref, k, fin.host_scored, tail, row_offset=offset)
-            tail_id = P.ref.names.index(tail) if tail is not None else -1
-            if dev.site_counts_accumulate(row_offset=offset, tail_contig=tail_id):
-                make_bed.add_pending_site_counts(dev, rec, P.table, state['index'], row_offset=offset, prob=fin.host_prob(rec),
-                                                 skip=extras['records'])
-            state['extras'].extend(extras['rows'])
-
-        # ---- steps 1 and 2: the piece, streamed ----
-        buf = io.StringIO()
-        try:
-            with open(job['part'], 'wb') as out, contextlib.redirect_stdout(buf):
-                res = ec.stream_features(job['tsv'], job['fasta'], read2qual, k, job['skip_thresh'], job['qual_thresh'], modelset,
-                                         None, job['base'], job['motif'], job['positions_list'], byte_range=(job['lo'], job['hi']),
-                                         sink=out.write, tail_of_last=tail_of_last, on_head=on_head,
-                                         on_shard=on_shard if job['bed'] else None, mark_all=bool(job['bed']), min_shards=1)
-        except _Abort:
-            return
-        except ec._Unstreamable as e:
-            if not state['head_sent']:
-                conn.send(dict(head=None))
-            conn.send(dict(stop='unstreamable: %s' % e, stdout=buf.getvalue()))
-            conn.recv()
-            return
-        conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, names=list(res.names), n_rows=res.n_rows,
-                       n_obs=res.n_obs, positions=res.positions, n_multi=res.n_multi, n_wskips=res.n_wskips,
-                       n_skipped=res.n_skipped))
-        if not job['bed']:
-            return
-        # ---- steps 3-5: the per-site reduction; every step is the parent's decision for everybody ----
-        if not state['go_seen'] and conn.recv() is None:     # (a piece without a pass never asked for its tail: the answer is still there)
-            return
-        if conn.recv() is None:
-            return
-        if state['index'] is None:                # (a piece without a pass: counts of zero over the same site numbering)
-            from .refmark import MarkedReference
-            ref = MarkedReference(job['fasta'], job['base'], job['motif'], job['positions_list'])
-            ref.quiet = True
-            for cid in range(len(ref.names)):
-                ref.mark(cid)
-            dev.set_reference(ref.device_arrays())
-            dev.site_counts_reset()
-        uid, can = None, True
-        try:
-            from .device import Device
-            uid = Device.comm_unique_id() if rank == 0 else None   # (loads librccl.so; rank 0: ncclGetUniqueId)
-            if rank != 0:
-                Device.comm_probe()
-        except Exception as e:                                      # noqa
-            can, uid = False, None
-        conn.send(dict(can=can, uid=uid))
-        how = conn.recv()
-        if how is None:
-            return
-        up = False
-        if how.get('init'):
+        while True:
             try:
-                dev.comm_init(job['world'], rank, how['uid'])      # (ncclCommInitRank: every worker was told to, every worker can)
-                up = True
-            except Exception:                                       # noqa
-                up = False
-        conn.send(dict(up=up))
-        how = conn.recv()
-        if how is None:
-            return
-        if not how.get('rccl') and up:
-            dev.comm_destroy()
-            up = False
-        own = dev.site_counts_fetch()         # this worker's own counts first: what the parent adds up if the collective fails anywhere
-        reduced, ms, err = None, 0.0, None
-        if up:
-            try:
-                reduced = dev.site_allreduce()
-                ms = reduced[3]
-            except Exception as e:                                  # noqa
-                err, reduced = str(e), None
-            dev.comm_destroy()
-        lead = rank == 0
-        conn.send(dict(bed=dict(own=own, reduced=reduced[:3] if (reduced is not None and lead) else None,
-                                collective_done=reduced is not None, ms=ms, err=err, extras=state['extras'])))
+                job = conn.recv()
+            except (EOFError, OSError):
+                return
+            if job is None or not _job(conn, device, job, cache):
+                return
     except BaseException as e:                                   # noqa
         try:
             import traceback
@@ -186,19 +94,179 @@ def _worker(conn, device, job):
         conn.close()
 
 
+def _job(conn, device, job, cache):
+    """One piece of one file.  -> True: done, the next job may come; False: the parent said stop."""
+    import contextlib
+    import io
+    t_job = time.perf_counter()
+    from . import _lib
+    if job['world'] > 1 and not cache.get('bound'):
+        _lib.lib().mc_bind_to_device_numa_node(int(device))     # reader threads and pinned buffers next to this worker's GPU
+        cache['bound'] = True
+    from . import extract_contexts as ec
+    from . import make_bed
+    from .device import get_device
+    from .model_io import load_model_file
+    read2qual = job['read2qual']
+    if read2qual is None:                 # (every worker reads the FASTQ itself, natively: a pickled dict per worker costs more)
+        key = ('fastq', job['fastq'], os.path.getmtime(job['fastq']), os.path.getsize(job['fastq']))
+        if cache.get('fastq_key') != key:
+            from .read_qual import extract_read_quality
+            cache['fastq_key'], cache['read2qual'] = key, extract_read_quality(job['fastq'])
+        read2qual = cache['read2qual']
+    modelset = load_model_file(job['modelfile'])
+    dev = get_device()
+    rank, k = job['rank'], job['k']
+    state = dict(head_sent=False, go_seen=False, index=None, extras=[], t_reduce=0.0)
+    t_ready = time.perf_counter()
+
+    def on_head(name):
+        state['head_sent'] = True
+        conn.send(dict(head=name))
+
+    def tail_of_last():
+        go = conn.recv()
+        state['go_seen'] = True
+        if go is None:
+            raise _Abort()
+        return go['tail']
+
+    def on_shard(P, rec, fin, tail, rows_before):
+        """The per-site reduction of one shard's records (make_bed.py:86-96), on the device, added to the worker's counts.
+        Records the host scored itself (NaN on the device) are folded in; records whose row names another contig than their
+        site (R8: closed by a row of the next contig) are not sites of the numbering: they travel as `extras`."""
+        t_r = time.perf_counter()
+        if state['index'] is None:
+            state['index'] = make_bed.SiteIndex(P.ref.meth, len(P.ref.names))
+            dev.site_counts_reset()
+        offset = rank * ROW_STRIDE + rows_before
+        extras = make_bed.cross_contig_records(rec, P.table, P.ref, k, fin.host_scored, tail, row_offset=offset)
+        tail_id = P.ref.names.index(tail) if tail is not None else -1
+        if dev.site_counts_accumulate(row_offset=offset, tail_contig=tail_id):
+            make_bed.add_pending_site_counts(dev, rec, P.table, state['index'], row_offset=offset, prob=fin.host_prob(rec),
+                                             skip=extras['records'])
+        state['extras'].extend(extras['rows'])
+        state['t_reduce'] += time.perf_counter() - t_r
+
+    # ---- steps 1 and 2: the piece, streamed ----
+    buf = io.StringIO()
+    try:
+        with open(job['part'], 'wb') as out, contextlib.redirect_stdout(buf):
+            res = ec.stream_features(job['tsv'], job['fasta'], read2qual, k, job['skip_thresh'], job['qual_thresh'], modelset,
+                                     None, job['base'], job['motif'], job['positions_list'], byte_range=(job['lo'], job['hi']),
+                                     sink=out.write, tail_of_last=tail_of_last, on_head=on_head,
+                                     on_shard=on_shard if job['bed'] else None, mark_all=bool(job['bed']), min_shards=1)
+    except _Abort:
+        return False
+    except ec._Unstreamable as e:
+        if not state['head_sent']:
+            conn.send(dict(head=None))
+        conn.send(dict(stop='unstreamable: %s' % e, stdout=buf.getvalue()))
+        conn.recv()
+        return False
+    t_done = time.perf_counter()
+    clock = getattr(ec.stream_features, 'last_clock', None) or {}
+    conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, names=list(res.names), n_rows=res.n_rows,
+                   n_obs=res.n_obs, positions=res.positions, n_multi=res.n_multi, n_wskips=res.n_wskips,
+                   n_skipped=res.n_skipped, n_bytes_out=res.n_bytes,
+                   seconds=dict(total=t_done - t_job, setup=t_ready - t_job, stream=t_done - t_ready,
+                                site_counts=state['t_reduce'], reader_threads=clock.get('parse', 0.0),
+                                wait_for_table=clock.get('wait_parser', 0.0), enqueue=clock.get('enqueue', 0.0),
+                                hand_out=clock.get('hand_out', 0.0)),
+                   shards=clock.get('shards', 0), text_bytes=job['hi'] - job['lo'], peak_rss_mb=_peak_rss_mb()))
+    if not state['go_seen'] and conn.recv() is None:     # (a piece without a pass never asked for its tail: the answer is still there)
+        return False
+    if not job['bed']:
+        return True
+    # ---- steps 3-5: the per-site reduction; every step is the parent's decision for everybody ----
+    if conn.recv() is None:
+        return False
+    if state['index'] is None:                # (a piece without a pass: counts of zero over the same site numbering)
+        from .refmark import MarkedReference
+        ref = MarkedReference(job['fasta'], job['base'], job['motif'], job['positions_list'])
+        ref.quiet = True
+        for cid in range(len(ref.names)):
+            ref.mark(cid)
+        dev.set_reference(ref.device_arrays())
+        dev.site_counts_reset()
+    # (kept workers keep their communicator: ncclCommInitRank is paid by the first file only)
+    keep = bool(os.environ.get('MCALLER_KEEP_WORKERS'))
+    have = cache.get('comm') == (job['world'], rank)
+    uid, can = None, True
+    try:
+        from .device import Device
+        uid = Device.comm_unique_id() if rank == 0 else None   # (loads librccl.so; rank 0: ncclGetUniqueId)
+        if rank != 0:
+            Device.comm_probe()
+    except Exception as e:                                      # noqa
+        can, uid = False, None
+    conn.send(dict(can=can, uid=uid, have=have))
+    how = conn.recv()
+    if how is None:
+        return False
+    up = False
+    t_init = time.perf_counter()
+    if how.get('reuse') and have:
+        up = True
+    elif how.get('init'):
+        cache.pop('comm', None)
+        try:
+            dev.comm_init(job['world'], rank, how['uid'])      # (ncclCommInitRank: every worker was told to, every worker can)
+            up = True
+        except Exception:                                       # noqa
+            up = False
+    t_init = time.perf_counter() - t_init
+    conn.send(dict(up=up))
+    how = conn.recv()
+    if how is None:
+        return False
+    if not how.get('rccl') and up:
+        dev.comm_destroy()
+        cache.pop('comm', None)
+        up = False
+    own = dev.site_counts_fetch()         # this worker's own counts first: what the parent adds up if the collective fails anywhere
+    reduced, ms, err = None, 0.0, None
+    if up:
+        try:
+            reduced = dev.site_allreduce()
+            ms = reduced[3]
+        except Exception as e:                                  # noqa
+            err, reduced = str(e), None
+        if keep and reduced is not None:
+            cache['comm'] = (job['world'], rank)
+        else:
+            dev.comm_destroy()
+            cache.pop('comm', None)
+    lead = rank == 0
+    conn.send(dict(bed=dict(own=own, reduced=reduced[:3] if (reduced is not None and lead) else None,
+                            collective_done=reduced is not None, ms=ms, comm_init_ms=t_init * 1e3,
+                            comm_reused=bool(how.get('rccl')) and have, err=err,
+                            extras=state['extras'])))
+    return True
+
+
 class _Workers(object):
     """The worker processes and the parent's ends of their pipes; every wait has a deadline."""
 
-    def __init__(self, ctx, devices, jobs):
-        self.procs, self.conns, self.jobs = [], [], jobs
+    def __init__(self, ctx, devices):
+        self.procs, self.conns, self.jobs, self.devices = [], [], [], list(devices)
         self.timeout = float(os.environ.get('MCALLER_WORKER_TIMEOUT', '600'))
-        for dev, job in zip(devices, jobs):
+        self.files = 0
+        for dev in devices:
             parent, child = ctx.Pipe()
-            p = ctx.Process(target=_worker, args=(child, dev, job))
+            p = ctx.Process(target=_worker, args=(child, dev))
             p.start()
             child.close()
             self.procs.append(p)
             self.conns.append(parent)
+
+    def alive(self):
+        return all(p.is_alive() for p in self.procs)
+
+    def start(self, jobs):
+        self.jobs = jobs
+        self.files += 1
+        self.tell(jobs)
 
     def gather(self, timeout=None, on_message=None):
         """One message from every worker -> list, or None if a worker died, reported an error or missed the deadline.
@@ -233,6 +301,9 @@ class _Workers(object):
 
     def stop(self, remove_parts=True):
         """Abort: workers that wait for the parent get `None`, everything still alive after a moment is terminated."""
+        global _kept
+        if _kept is self:
+            _kept = None
         self.tell([None] * len(self.conns))
         t_end = time.monotonic() + 5.0
         for p in self.procs:
@@ -241,17 +312,53 @@ class _Workers(object):
             if p.is_alive():
                 p.terminate()
                 p.join(5.0)
+        for c in self.conns:
+            c.close()
         if remove_parts:
             for job in self.jobs:
                 if os.path.exists(job['part']):
                     os.remove(job['part'])
         return False
 
-    def join(self):
+    def release(self):
+        """The file is done: the workers end (told so: a worker waits for its next job), or stay for the next file."""
+        global _kept
+        if os.environ.get('MCALLER_KEEP_WORKERS'):
+            if _kept is None:
+                import atexit
+                atexit.register(_stop_kept)
+            _kept = self
+            return
+        self.tell([None] * len(self.conns))
         for p in self.procs:
             p.join(self.timeout)
             if p.is_alive():
                 p.terminate()
+        for c in self.conns:
+            c.close()
+
+
+_kept = None          # the workers of the last file, with MCALLER_KEEP_WORKERS
+
+
+def _stop_kept():
+    if _kept is not None:
+        _kept.stop(remove_parts=False)
+
+
+def _workers_for(devices):
+    """Workers for these devices: the ones kept from the last file (same devices, all alive) or new ones (spawned, never
+    forked: the parent may hold a HIP context of its own and must not hand it down)."""
+    global _kept
+    if _kept is not None:
+        W, _kept = _kept, None
+        if W.devices == list(devices) and W.alive():
+            return W
+        W.stop(remove_parts=False)
+    return _Workers(multiprocessing.get_context('spawn'), devices)
+
+
+last_run = None       # what the last sharded run measured (mCaller.py writes it to $MCALLER_STATS_JSON)
 
 
 def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, base, motif,
@@ -260,20 +367,31 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     printed; False when the file cannot be cut (a read name in two pieces, an exit path of the reference, an error or a
     missed deadline in a worker): the caller then runs the one-GPU path, which reproduces the reference's behaviour in
     those cases.  fastq: the workers read the qualities themselves (else `read2qual` is shipped to each)."""
+    global last_run
     from . import _lib
+    t_start = time.perf_counter()
+    last_run = None
     # the bytes the reference's loop reads for (0, file size): the last < 500 bytes of a file can stay unread (:141-148)
     lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, os.path.getsize(tsv_input))
     cuts = _lib.eventalign_read_cuts(tsv_input, n_gpus, lo, hi)
     devices = _devices(n_gpus)
     stem = '.'.join(tsv_input.split('.')[:-1])
     tsv_output = stem + '.diffs.' + str(k) + '.tmp0'
-    ctx = multiprocessing.get_context('spawn')
     jobs = [dict(tsv=tsv_input, fasta=fasta_input, read2qual=None if fastq else read2qual, fastq=fastq, lo=cuts[r], hi=cuts[r + 1],
                  base=base, motif=motif, positions_list=positions_list, k=k, skip_thresh=skip_thresh, qual_thresh=qual_thresh,
                  modelfile=modelfile, part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus)
             for r in range(n_gpus)]
-    W = _Workers(ctx, devices, jobs)
+    W = _workers_for(devices)
+    reused = W.files > 0
+    t_cut = time.perf_counter()
+    marking = None
     try:
+        W.start(jobs)
+        if bed:                               # (the site numbering of the BED, made while the workers stream)
+            import threading
+            marking = {}
+            marking['thread'] = threading.Thread(target=_mark_for_bed, args=(marking, fasta_input, base, motif, positions_list), daemon=True)
+            marking['thread'].start()
         # ---- step 1: the heads, as they come; go(tail) to everybody once all are known ----
         heads = W.gather()
         if heads is None:
@@ -288,6 +406,7 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
             if seen.intersection(x['names']):
                 return W.stop()                                  # a read name in two pieces: `last_read` crosses the cut
             seen.update(x['names'])
+        t_streamed = time.perf_counter()
         beds = None
         if bed:
             # ---- steps 3-5: one decision for everybody, three times ----
@@ -296,8 +415,9 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
             probes = W.gather(quick)
             if probes is None:
                 return W.stop()
-            init = n_gpus > 1 and all(p['can'] for p in probes) and probes[0]['uid'] is not None
-            W.tell([dict(init=init, uid=probes[0]['uid'])] * n_gpus)
+            reuse = n_gpus > 1 and all(p.get('have') for p in probes)       # (kept workers whose communicator is still up)
+            init = reuse or (n_gpus > 1 and all(p['can'] for p in probes) and probes[0]['uid'] is not None)
+            W.tell([dict(init=init and not reuse, reuse=reuse, uid=probes[0]['uid'])] * n_gpus)
             ups = W.gather(quick)
             if ups is None:
                 return W.stop()
@@ -306,7 +426,8 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
             if third is None:
                 return W.stop()
             beds = [x['bed'] for x in third]
-        W.join()
+        t_reduced = time.perf_counter()
+        W.release()
     except BaseException:
         W.stop()
         raise
@@ -322,8 +443,11 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
                         break
                     out.write(block)
             os.remove(job['part'])
+    t_joined = time.perf_counter()
+    reduction = None
     if bed:
-        _write_bed(bed, beds, fasta_input, base, motif, positions_list, k)
+        reduction = _write_bed(bed, beds, fasta_input, base, motif, positions_list, k, marking)
+        reduction['seconds_steps_3_to_5'] = t_reduced - t_streamed
     positions = np.unique(np.concatenate([x['positions'] for x in results])) if results else np.zeros(0)
     print('thread finished processing...:')
     print('%d observations' % sum(x['n_obs'] for x in results))
@@ -331,6 +455,15 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     print('%d regions with multiple methylated bases' % sum(x['n_multi'] for x in results))
     print('%d observations with skips included' % sum(x['n_wskips'] for x in results))
     print('%d observations with too many skips' % sum(x['n_skipped'] for x in results))
+    last_run = dict(n_gpus=n_gpus, devices=devices, workers_reused=reused, rows=sum(x['n_rows'] for x in results),
+                    observations=sum(x['n_obs'] for x in results), text_bytes=hi - lo,
+                    seconds=dict(total=time.perf_counter() - t_start, cut_and_start=t_cut - t_start, streamed=t_streamed - t_cut,
+                                 reduction=t_reduced - t_streamed, parts_joined=t_joined - t_reduced,
+                                 bed_written=time.perf_counter() - t_joined),
+                    workers=[dict(rank=r, device=devices[r], rows=x['n_rows'], text_bytes=x['text_bytes'], shards=x['shards'],
+                                  bytes_out=x['n_bytes_out'], peak_rss_mb=x['peak_rss_mb'], seconds=x['seconds'])
+                             for r, x in enumerate(results)],
+                    site_reduction=reduction)
     return True
 
 
@@ -347,20 +480,43 @@ def combine_site_counts(beds):
     return n_meth, n_total, first, 'summed on the host (%s)' % why
 
 
-def _write_bed(bed, beds, fasta_input, base, motif, positions_list, k):
+def _mark_for_bed(box, fasta_input, base, motif, positions_list):
+    """Every contig marked and the sites numbered (the key space of the reduction): what the BED writer needs of the reference."""
+    try:
+        from . import make_bed
+        from .refmark import MarkedReference
+        ref = MarkedReference(fasta_input, base, motif, positions_list)
+        ref.quiet = True
+        for cid in range(len(ref.names)):
+            try:
+                ref.mark(cid)
+            except SystemExit:
+                pass
+        box['ref'], box['index'] = ref, make_bed.SiteIndex(ref.meth, len(ref.names))
+    except BaseException as e:                                   # noqa
+        box['error'] = e
+
+
+def _write_bed(bed, beds, fasta_input, base, motif, positions_list, k, marking=None):
     """BED of the whole file from the workers' reductions."""
     from . import make_bed
-    from .refmark import MarkedReference
-    ref = MarkedReference(fasta_input, base, motif, positions_list)
-    for cid in range(len(ref.names)):
-        try:
-            ref.mark(cid)
-        except SystemExit:
-            pass
-    index = make_bed.SiteIndex(ref.meth, len(ref.names))
+    if marking is None:
+        marking = {}
+        _mark_for_bed(marking, fasta_input, base, motif, positions_list)
+    else:
+        marking['thread'].join()
+    if 'error' in marking:
+        raise marking['error']
+    ref, index = marking['ref'], marking['index']
     n_meth, n_total, first, how = combine_site_counts(beds)
     extras = [row for b in beds for row in b['extras']]
     count = make_bed.write_bed_from_counts(bed['path'], n_meth, n_total, first, index, ref.names, ref.meth, k,
                                            bed['min_depth'], bed['mod_threshold'], extras=extras)
     print(count, 'methylated loci found with min depth', bed['min_depth'], 'reads')
     print('per-site reduction: %s' % how)
+    rccl = how.startswith('ncclAllReduce')
+    return dict(backend=how, ms=max(b['ms'] for b in beds) if rccl else None,
+                comm_init_ms=max(b.get('comm_init_ms', 0.0) for b in beds) if rccl else None,
+                comm_reused=all(b.get('comm_reused') for b in beds) if rccl else None,
+                bytes=int(index.n) * 16, sites=int(index.n), observations=int(np.asarray(n_total, dtype=np.int64).sum()),
+                loci_written=int(count), cross_contig_rows=len(extras))

@@ -3,6 +3,7 @@ import contextlib
 import io
 import os
 import shutil
+import sys
 
 import numpy as np
 import pytest
@@ -306,3 +307,70 @@ def test_cli_bed_over_several_contigs_equals_make_bed(tmp_path):
         assert got == open(bed).read(), case['seed']
         n_done += 1
     assert n_done >= 10
+
+
+def test_strong_scaling_leg_of_the_bench_equals_the_one_gpu_run(tmp_path):
+    """bench.py's strong-scaling leg (BASELINE.json configs[3]): one file -> `mCaller --gpus N --bed` in a process of its own,
+    the CLI several times, the workers of the first run kept for the later ones (MCALLER_KEEP_WORKERS).  With 1, 2 and 3 workers
+    sharing GPU 0 (RCCL refuses a communicator of one device twice: the host-sum branch) the `.diffs.6` bytes equal the plain
+    one-GPU run's, every run; the leg reports per-worker seconds, the reduction's backend and bytes, and the BED's rows."""
+    import bench
+    from mcaller_amd import synth
+    codes = synth.genome(length=300000, seed=23)
+    table, qual = synth.make_table(600000, seed=9, codes=codes, read_len=(1500, 6000))
+    d = str(tmp_path)
+    synth.write_inputs(table, qual, codes, d)
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, 'tools', 'file_to_file.py'), '--inputs', d, '--runs', '2', '--json'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = json.loads(r.stdout.strip().splitlines()[-1])
+    assert one['calls'] > 100
+    beds = []
+    for n in (1, 2, 3):
+        leg = bench.strong_scaling_leg(d, n, rows=table.n_rows, one_gpu_sha=one['diffs_sha256'], one_device=True, runs=3)
+        assert leg['scaling'] == 'strong' and leg['n_gpus'] == n and leg['diffs_equal_the_one_gpu_run'] is True
+        assert leg['calls'] == one['calls'] and leg['rows'] == table.n_rows and len(leg['seconds_all']) == 3
+        assert len(leg['workers']) == n and sum(w['rows'] for w in leg['workers']) == table.n_rows
+        assert all(w['seconds'] > 0 for w in leg['workers'])
+        red = leg['site_reduction']
+        assert red['bytes'] == red['sites'] * 16 and red['sites'] > 100 and red['observations'] == one['calls']
+        assert ('summed on the host' in red['backend']) and leg['bed_rows'] > 50
+        assert leg['calls_per_s'] > 0 and leg['events_per_s'] > 0 and set(bench.STRONG_KEYS) <= set(leg)
+        beds.append(leg['bed_rows'])
+    assert len(set(beds)) == 1
+
+
+def test_workers_are_kept_between_files_and_replaced_when_the_devices_change(tmp_path):
+    """MCALLER_KEEP_WORKERS: the workers of one sharded run take the next file (same processes); another device list, or a
+    worker that died, starts new ones; a piece without a read (more GPUs than reads) is a finished piece, not a fall-back."""
+    from mcaller_amd import synth, mCaller, multi_gpu
+    codes = synth.genome(length=200000, seed=25)
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
+    outs, pids, reused = {}, [], []
+    os.environ['MCALLER_KEEP_WORKERS'] = '1'
+    try:
+        for tag, rows, seed, devs, read_len in (('a', 200000, 3, '0,0', (1500, 6000)), ('b', 150000, 4, '0,0', (1500, 6000)),
+                                                ('a', 200000, 3, '0,0,0', (1500, 6000)), ('c', 30000, 5, '0,0,0', (14000, 15000))):
+            d = str(tmp_path / (tag + devs.replace(',', '')))
+            os.makedirs(d)
+            table, qual = synth.make_table(rows, seed=seed, codes=codes, read_len=read_len)
+            paths = synth.write_inputs(table, qual, codes, d)
+            os.environ['MCALLER_SHARD_DEVICES'] = devs
+            with contextlib.redirect_stdout(io.StringIO()):
+                mCaller.main(['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model,
+                              '--gpus', str(devs.count(',') + 1), '--bed', '--bed_min_depth', '1'])
+            assert multi_gpu.last_run is not None, 'the sharded path declined'
+            assert multi_gpu.last_run['rows'] == table.n_rows
+            pids.append([p.pid for p in multi_gpu._kept.procs])
+            reused.append(multi_gpu.last_run['workers_reused'])
+            outs.setdefault(tag, []).append(open(paths['tsv'][:-4] + '.diffs.6', 'rb').read())
+            if tag == 'c':          # two reads, three workers: one range is empty
+                assert table.n_reads < 3 and min(w['rows'] for w in multi_gpu.last_run['workers']) == 0
+        assert pids[0] == pids[1] and len(pids[2]) == 3 and pids[2] == pids[3] and reused == [False, True, False, True]
+        assert outs['a'][0] == outs['a'][1] and outs['a'][0].count(b'\n') > 50
+    finally:
+        del os.environ['MCALLER_KEEP_WORKERS']
+        os.environ.pop('MCALLER_SHARD_DEVICES', None)
+        multi_gpu._stop_kept()

@@ -126,6 +126,13 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'bench.py itself'
+    # both legs' schema: the weak leg is the contract's keys, the strong leg (BASELINE.json configs[3]: ONE file through
+    # `mCaller --gpus N --bed`) a top-level object of its own
+    assert line['scaling'] == 'weak' and {'value', 'ms_per_step', 'ms_per_step_steady', 'metric', 'unit'} <= set(line)
+    strong = line['strong_scaling']
+    assert strong['scaling'] == 'strong' and strong['n_gpus'] == 2
+    assert {'calls_per_s', 'events_per_s', 'seconds_median', 'seconds_first_run', 'site_reduction', 'workers', 'rows', 'phases_s',
+            'diffs_equal_the_one_gpu_run', 'bed_rows'} <= set(strong)
     r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--gpus', '1', '--dry-ranks'], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])['n_gpus'] == 1
