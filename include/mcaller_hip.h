@@ -14,12 +14,16 @@
  * binding, with the reference's signature.
  *
  * Conventions: every function returns 0 on success, <0 on error (text via mc_last_error(), thread
- * local).  Plain pointers and sizes only; no exceptions or callbacks cross the ABI.  Host buffers are
+ * local; MC_E_NO_FREE_SLOT is the one code a caller acts on: hand out the oldest pass and try again).  Plain pointers and sizes only; no exceptions or callbacks cross the ABI.  Host buffers are
  * caller-allocated and never retained after the call returns.  One mc_ctx per GPU; calls on a ctx
  * are serialised by the caller (one process per GPU).
  */
 #ifndef MCALLER_HIP_H
 #define MCALLER_HIP_H
+
+/* mc_ctx_upload_table_async / mc_ctx_parse_begin: every table slot is taken by a pass in flight (or by the records handed out
+ * last).  Not a failure of the stream: mc_wait_records frees a slot. */
+#define MC_E_NO_FREE_SLOT (-16)
 
 #include <stdint.h>
 
@@ -199,7 +203,7 @@ int mc_ctx_set_read_quality(mc_ctx *ctx, const double *qual, int32_t n_reads);/*
  * mc_ctx_wait_upload(slot) returns.  (A table can also arrive as TEXT and be parsed on the device: mc_ctx_parse_begin below.)
  * A slot is free again when every pass that scanned its table has been handed out by
  * mc_wait_records (and the next pass after it: the last records handed out may still be reduced by mc_site_counts); with
- * no free slot the call fails (-12): wait for a pass first. */
+ * no free slot the call fails with MC_E_NO_FREE_SLOT: wait for a pass first. */
 #define MC_TABLE_SLOTS 12
 int mc_ctx_reserve_tables(mc_ctx *ctx, int64_t max_rows, int32_t max_segs, int32_t max_reads);
 int mc_ctx_upload_table_async(mc_ctx *ctx, const mc_table_view *host_table, const double *read_qual, int32_t *slot);
@@ -207,7 +211,9 @@ int mc_ctx_wait_upload(mc_ctx *ctx, int32_t slot);
 int mc_ctx_current_slot(mc_ctx *ctx);                       /* slot of the current table, -1: none */
 /* Makes the table resident in `slot` the current one again.  as_new != 0: the next pass treats it like a table it has never
  * seen -- it does everything the first pass over a table does (positions and event indices streamed, every row validated),
- * whatever earlier passes learned (measurement: the cost of a table that is scanned once, without the upload). */
+ * whatever earlier passes learned (measurement: the cost of a table that is scanned once, without the upload).  Fails for a
+ * slot that holds no COMPLETE table (never filled; a parse abandoned or never finished).  Passes over the slot that are in
+ * flight keep the plan they were enqueued with: declare a table new beside them only if they are first passes too. */
 int mc_ctx_select_table(mc_ctx *ctx, int32_t slot, int32_t as_new);
 /* hipEvent time of the last upload into `slot` (waits for it): the H2D transfers, in ms.  *validate_ms is 0: nothing runs at
  * upload any more (the validation is part of the first pass's scan). */
@@ -226,6 +232,17 @@ int mc_ctx_set_mlp(mc_ctx *ctx, int32_t n_models, int32_t n_in, int32_t n_hidden
 int mc_ctx_set_forest(mc_ctx *ctx, int32_t n_models, int32_t n_in, const int32_t *model_tree_off,
                       const int32_t *tree_node_off, const int32_t *left, const int32_t *right, const int32_t *feature,
                       const double *threshold, const double *value, const uint8_t *submodel_of_char);
+
+/* The closed-form classifiers of `-c LR` / `-c NBC` (train_model.py:55-60: LogisticRegression, GaussianNB; scored at the same
+ * call site, :199).  params: n_models * stride doubles --
+ *   MC_CLF_LOGISTIC, stride n_in + 1:   coef_[0][0..n_in), intercept_[0]              p = expit(x . coef + intercept)
+ *   MC_CLF_GNB,      stride 4 n_in + 2: theta_[0], var_[0], theta_[1], var_[1] (n_in each), log(class_prior_[0]), log(class_prior_[1])
+ *                                       p = exp(jll_1 - logsumexp(jll)), jll_c = log prior_c - 0.5 sum log(2 pi var_c) - 0.5 sum (x - theta_c)^2 / var_c
+ * fp64, sums in index order.  Replaces the MLP / forest of the context. */
+#define MC_CLF_LOGISTIC 1
+#define MC_CLF_GNB 2
+int mc_ctx_set_simple_classifier(mc_ctx *ctx, int32_t kind, int32_t n_models, int32_t n_in, const double *params, int32_t stride,
+                                 const uint8_t *submodel_of_char);
 
 typedef struct mc_params {
     int32_t k;             /* -n   (:110 `k`)            */
@@ -277,6 +294,7 @@ int mc_ctx_sync(mc_ctx *ctx);
 /* Batched classifier alone (B2, extract_contexts.py:199): X[n*n_in] -> p[n]; host buffers. */
 int mc_mlp_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
 int mc_forest_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);
+int mc_simple_forward(mc_ctx *ctx, const double *X, const uint8_t *submodel, int64_t n, double *p);     /* LR / NBC */
 
 /* ===== per-site reduction feeding make_bed (make_bed.py:86-96,:134,:143,:154), the one exchange step of a multi-GPU job =====
  * Sites = every 'M' of the marked strands, numbered per contig: '+' sites by position, then '-' sites by position

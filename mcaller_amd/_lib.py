@@ -16,8 +16,12 @@ F_KMER_EQ, F_MODEL_N, F_SEG_START, F_NAME_START = 1, 2, 4, 8
 I_EMPTY_MASK, I_REV, I_TOO_MANY, I_MULTI, I_EDGE, I_NEXT_SHIFT = 0xFF, 0x100, 0x200, 0x400, 0x800, 16
 
 
+E_NO_FREE_SLOT = -16      # include/mcaller_hip.h: MC_E_NO_FREE_SLOT
+
+
 class McError(RuntimeError):
-    pass
+    """An error of the library; `code`: what the call returned."""
+    code = None
 
 
 class TableView(C.Structure):
@@ -154,6 +158,8 @@ def lib():
         L.mc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_forest_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mc_ctx_set_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.mc_simple_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mc_ctx_set_simple_classifier.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.mc_site_count.argtypes = [C.c_void_p]
         L.mc_site_count.restype = C.c_int64
         L.mc_site_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -179,7 +185,9 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise McError(lib().mc_last_error().decode('utf-8', 'replace') or 'libmcaller_hip error %d' % rc)
+        e = McError(lib().mc_last_error().decode('utf-8', 'replace') or 'libmcaller_hip error %d' % rc)
+        e.code = rc
+        raise e
 
 
 def _ptr(a):

@@ -165,6 +165,16 @@ struct DevForest {
     uint8_t *sub_of_char = nullptr;
 };
 
+// Closed-form classifiers (-c LR, -c NBC; train_model.py:55-60, scored at the same call site :199): per sub-model `stride`
+// doubles.  MC_CLF_LOGISTIC: w[n_in], b -- p = expit(x . w + b) (scikit-learn's LogisticRegression, binary);
+// MC_CLF_GNB: theta0[n_in], var0[n_in], theta1[n_in], var1[n_in], log prior0, log prior1 -- GaussianNB's joint log
+// likelihoods, p = exp(jll1 - logsumexp(jll)).
+struct DevSimple {
+    int32_t kind = 0, n_models = 0, n_in = 0, stride = 0;
+    double *params = nullptr;
+    uint8_t *sub_of_char = nullptr;
+};
+
 // Payload-slot counters (k1_scan's TileSlots::reserve), one per tile & (NSHARD - 1), every one in a cache line of its own: a
 // one-base motif has every tile fetch a chunk of slots, and 6*10^4 atomics on the eight counters of ONE line took 0.4 ms of the
 // scan's 0.76 -- they are served one after the other, ~7 ns each, wherever in the line they land.  (Tables of fewer than 1024
@@ -3041,6 +3051,64 @@ __global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__res
     prob[r] = sum / (double)(t1 - t0);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K3': the closed-form classifiers -- logistic regression (-c LR) and Gaussian naive Bayes (-c NBC), train_model.py:55-60;
+// call site :199.  One lane per record, fp64, the sums in index order (scikit-learn: a BLAS dot / numpy sums over seven
+// terms: agreement to ~1e-16 relative, pinned at 1e-12 against captured predict_proba).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k3_simple(DevSimple S, const double *__restrict__ feats, int k,
+                                                const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                const unsigned int *__restrict__ overflow) {
+    if (overflow && *overflow) return;
+    if (n_dev) n = min(n, (int64_t)*n_dev);
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double x[MC_MAX_K + 1];
+    const int NI = S.n_in;
+    int mi;
+    if (submodel_in) {
+        mi = submodel_in[r];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+    } else {
+        const uint32_t inf = info[r];
+        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
+        mi = S.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) x[i] = i < k ? feats[r * k + i] : 0.0;
+        const double q = qual[seg_read[site_seg[r]]];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) if (i == k) x[i] = q;
+    }
+    if (mi >= S.n_models) return;
+    const double *P = S.params + (size_t)mi * S.stride;
+    if (S.kind == MC_CLF_LOGISTIC) {
+        double d = 0.0;
+        for (int i = 0; i < MC_MAX_K + 1; ++i) if (i < NI) d += x[i] * P[i];
+        d += P[NI];
+        // scipy.special.expit: 1 / (1 + exp(-d)), the large-|d| ends as it writes them
+        prob[r] = d >= 0.0 ? 1.0 / (1.0 + exp(-d)) : exp(d) / (1.0 + exp(d));
+    } else {
+        // GaussianNB._joint_log_likelihood: log prior - 0.5 * sum(log(2 pi var)) - 0.5 * sum((x - theta)^2 / var)
+        double jll[2];
+        for (int cls = 0; cls < 2; ++cls) {
+            const double *theta = P + (size_t)cls * 2 * NI, *var = theta + NI;
+            double a = 0.0, b2 = 0.0;
+            for (int i = 0; i < MC_MAX_K + 1; ++i)
+                if (i < NI) {
+                    a += log(2.0 * 3.14159265358979323846 * var[i]);
+                    const double t = x[i] - theta[i];
+                    b2 += (t * t) / var[i];
+                }
+            jll[cls] = P[4 * (size_t)NI + cls] + (-0.5 * a) - 0.5 * b2;
+        }
+        // exp(jll1 - logsumexp(jll0, jll1))
+        const double mx = fmax(jll[0], jll[1]);
+        const double lse = mx + log(exp(jll[0] - mx) + exp(jll[1] - mx));
+        prob[r] = exp(jll[1] - lse);
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -3308,6 +3376,8 @@ struct TableSlot {
     hipEvent_t ev_uploaded = nullptr;  // the H2D transfers of the slot's table are done
     hipEvent_t ev_up_start = nullptr, ev_val_start = nullptr, ev_valid = nullptr;   // ... begin; the small arrays are in place (ctx stream)
     int refs = 0;                      // passes in flight that scan this table (+1 while the device parser fills the slot)
+    bool holds_table = false;          // S.T describes the columns in the slot (set by fill_slot; cleared when a parse begins to
+                                       // overwrite them or is abandoned): what mc_ctx_select_table may make current again
     // What the passes enqueued so far leave behind for the next one (host-side notes; the work is ordered by the ctx stream):
     int passes = 0;                    // passes enqueued over this table.  The first streams positions and event indices and
                                        // completes the validation flags (k1_scan, SCAN_VALIDATE); later ones classify on the flags.
@@ -3357,7 +3427,8 @@ struct mc_ctx {
     DevRef R;
     DevMlp M;
     DevForest F;
-    std::vector<void *> forest_allocs;
+    DevSimple Sc;                      // -c LR / -c NBC
+    std::vector<void *> forest_allocs, simple_allocs;
     double *qual = nullptr;
     int32_t n_qual = 0;
     NbDesc *desc = nullptr;
@@ -3588,6 +3659,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     free_pool(c->ref_allocs);
     free_pool(c->mlp_allocs);
     free_pool(c->forest_allocs);
+    free_pool(c->simple_allocs);
     free_pool(c->rec_allocs);
     free_pool(c->lit_allocs);
     if (c->qual_own) (void)hipFree(c->qual_own);
@@ -3979,6 +4051,7 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
     HIP_TRY(hipGetLastError());
     c->T = T;
     c->cur = at;
+    S.holds_table = true;
     if (read_qual) { c->qual = S.qual; c->n_qual = S.n_qual; }
     else { c->qual = c->qual_own; c->n_qual = c->n_qual_own; }       // mc_ctx_set_read_quality's table applies
     return 0;
@@ -3993,7 +4066,7 @@ extern "C" int mc_ctx_upload_table_async(mc_ctx *c, const mc_table_view *h, cons
         return -12;
     }
     const int at = free_slot(c, "mc_ctx_upload_table_async");
-    if (at < 0) return -12;
+    if (at < 0) return MC_E_NO_FREE_SLOT;
     TableSlot &S = c->slots[at];
     if (int rc = slot_ensure(c, S, n, h->n_seg, h->n_reads)) return rc;
     HIP_TRY(hipEventSynchronize(S.ev_uploaded));          // the stage is about to be rewritten (long done: the slot was idle)
@@ -4100,7 +4173,7 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
         return -12;
     }
     const int at = free_slot(c, "mc_ctx_parse_begin");
-    if (at < 0) return -12;
+    if (at < 0) return MC_E_NO_FREE_SLOT;
     TableSlot &S = c->slots[at];
     // rows: what the caller expects (the slots were sized by mc_ctx_reserve_tables, or grow here); a shard with more rows or
     // segments than the slot holds comes back from mc_ctx_parse_end as "needs the host parser"
@@ -4172,6 +4245,7 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
 #undef KP_STEP
     HIP_TRY(hipGetLastError());
     S.refs += 1;                                            // the slot is taken until mc_ctx_parse_finish / _abandon
+    S.holds_table = false;                                  // (the columns are being overwritten: S.T describes them no more)
     S.kp_state = 1;
     S.kp_bytes = n_bytes;
     if (slot_out) *slot_out = at;
@@ -4300,8 +4374,10 @@ extern "C" int mc_ctx_current_slot(mc_ctx *c) { return c->cur; }
 // the blocks' first rows, positions and event indices streamed, every row validated).
 extern "C" int mc_ctx_select_table(mc_ctx *c, int32_t slot, int32_t as_new) {
     HIP_TRY(hipSetDevice(c->device));
-    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].T.pos || c->slots[slot].kp_state != 0) {
-        mc_set_error("mc_ctx_select_table: slot %d holds no table", slot);
+    // (holds_table: set when a table's small arrays went in, fill_slot; cleared when a parse began to overwrite the columns -- a
+    // parse that was abandoned, or handed out and never finished, leaves columns that S.T does not describe)
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || !c->slots[slot].T.pos || c->slots[slot].kp_state != 0 || !c->slots[slot].holds_table) {
+        mc_set_error("mc_ctx_select_table: slot %d holds no complete table", slot);
         return -12;
     }
     TableSlot &S = c->slots[slot];
@@ -4309,6 +4385,9 @@ extern "C" int mc_ctx_select_table(mc_ctx *c, int32_t slot, int32_t as_new) {
     c->cur = slot;
     if (S.qual) { c->qual = S.qual; c->n_qual = S.n_qual; }
     else { c->qual = c->qual_own; c->n_qual = c->n_qual_own; }
+    // (passes over the slot that are still in flight keep the plan they were enqueued with; a first pass only ORs what it sees
+    // into the table's validation flags, so declaring the table new beside them is safe as long as they are first passes too --
+    // bench.py's steps -- and a caller that mixes pass kinds waits for them first)
     if (as_new) S.passes = 0;
     return 0;
 }
@@ -4367,7 +4446,9 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
     }
     free_pool(c->mlp_allocs);
     free_pool(c->forest_allocs);
+    free_pool(c->simple_allocs);
     c->F = DevForest();
+    c->Sc = DevSimple();
     DevMlp &M = c->M;
     M.n_models = n_models;
     M.n_in = n_in;
@@ -4411,7 +4492,9 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
         }
     free_pool(c->forest_allocs);
     free_pool(c->mlp_allocs);
+    free_pool(c->simple_allocs);
     c->M = DevMlp();
+    c->Sc = DevSimple();
     DevForest &F = c->F;
     F.n_models = n_models;
     F.n_in = n_in;
@@ -4425,6 +4508,60 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
     UP(F.sub_of_char, sub_of_char, 256, c->forest_allocs);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+extern "C" int mc_ctx_set_simple_classifier(mc_ctx *c, int32_t kind, int32_t n_models, int32_t n_in, const double *params,
+                                            int32_t stride, const uint8_t *sub_of_char) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int want = kind == MC_CLF_LOGISTIC ? n_in + 1 : (kind == MC_CLF_GNB ? 4 * n_in + 2 : -1);
+    if (n_models < 1 || n_in < 1 || n_in > MC_MAX_K + 1 || stride != want) {
+        mc_set_error("unsupported classifier: kind %d, %d models, %d inputs, %d parameters each", kind, n_models, n_in, stride);
+        return -12;
+    }
+    if (kind == MC_CLF_GNB)
+        for (int m = 0; m < n_models; ++m)
+            for (int cls = 0; cls < 2; ++cls)
+                for (int i = 0; i < n_in; ++i)
+                    if (!(params[(size_t)m * stride + (size_t)cls * 2 * n_in + n_in + i] > 0.0)) {
+                        mc_set_error("naive Bayes model %d: variance %d of class %d is not positive", m, i, cls);
+                        return -12;
+                    }
+    free_pool(c->forest_allocs);
+    free_pool(c->mlp_allocs);
+    free_pool(c->simple_allocs);
+    c->M = DevMlp();
+    c->F = DevForest();
+    DevSimple &S = c->Sc;
+    S = DevSimple();
+    UP(S.params, params, (size_t)n_models * stride, c->simple_allocs);
+    UP(S.sub_of_char, sub_of_char, 256, c->simple_allocs);
+    S.kind = kind; S.n_models = n_models; S.n_in = n_in; S.stride = stride;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the classifier of the context -- MLP (k2_mlp), forest (k3_forest) or one of the closed forms (k3_simple) -- over n records
+// (n_dev: the count is on the device, n is the capacity)
+static void launch_k2(mc_ctx *c, unsigned grid, hipStream_t st, const double *feats, int k, const int32_t *site_seg,
+                      const int32_t *seg_read, const double *qual, const uint32_t *info, const uint8_t *submodel_in, int64_t n,
+                      double *prob, const unsigned long long *n_dev, const unsigned int *overflow);
+static unsigned k2_grid(const mc_ctx *c, int64_t n);
+static int classifier_inputs(const mc_ctx *c) {
+    return c->F.left ? c->F.n_in : (c->Sc.params ? c->Sc.n_in : (c->M.W1 ? c->M.n_in : 0));
+}
+static void launch_classifier(mc_ctx *c, hipStream_t st, const double *feats, int k, const int32_t *site_seg, const int32_t *seg_read,
+                              const double *qual, const uint32_t *info, const uint8_t *submodel_in, int64_t n, double *prob,
+                              const unsigned long long *n_dev, const unsigned int *overflow) {
+    if (n <= 0) return;
+    if (c->F.left)             // (one lane per record; with the count on the device a workgroup beyond it ends at once)
+        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->F, feats, k, site_seg, seg_read, qual, info,
+                           submodel_in, n, prob, n_dev, overflow);
+    else if (c->Sc.params)
+        hipLaunchKernelGGL(k3_simple, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->Sc, feats, k, site_seg, seg_read, qual, info,
+                           submodel_in, n, prob, n_dev, overflow);
+    else
+        launch_k2(c, k2_grid(c, n), st, feats, k, site_seg, seg_read, qual, info, submodel_in, n, prob, n_dev, overflow);
 }
 
 // marked positions are dense (a one-base motif): the scan instance that lists every unit of a tile, bigger payload chunks
@@ -4680,7 +4817,7 @@ static int check_pass(mc_ctx *c, const mc_params *prm) {
         mc_set_error("read quality table has %d entries, table names %d reads", c->n_qual, T.n_reads);
         return -12;
     }
-    const int clf_in = c->F.left ? c->F.n_in : (c->M.W1 ? c->M.n_in : 0);
+    const int clf_in = classifier_inputs(c);
     if (prm->score && clf_in != k + 1) {
         mc_set_error("classifier expects %d inputs but num_variables+1 = %d", clf_in, k + 1);
         return -12;
@@ -4733,15 +4870,9 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         if (int rc = ensure_pinned(c, n, k)) return rc;
         const bool early = n > 0 && !h.n_big && !h.n_rare && !irregular;      // (nothing on the ctx stream still writes records)
         if (early) { if (int rc = copy_out_features(c, n, k, c->copy_stream)) return rc; }
-        if (prm->score && n > 0) {
-            if (c->F.left)
-                hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, c->O.feats, k,
-                                   c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n, c->O.prob,
-                                   (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
-            else
-                launch_k2(c, k2_grid(c, n), c->stream, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info,
-                          (const uint8_t *)nullptr, n, c->O.prob, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
-        }
+        if (prm->score && n > 0)
+            launch_classifier(c, c->stream, c->O.feats, k, c->O.site_seg, T.seg_read, c->qual, c->O.info, (const uint8_t *)nullptr, n,
+                              c->O.prob, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         if (n > 0) {
             if (!early) { if (int rc = copy_out_features(c, n, k, c->stream)) return rc; }
@@ -4877,13 +5008,9 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
-    if (b.prm.score && c->F.left)              // (the forest: one lane per record, the count read on the device; a workgroup beyond it ends at once)
-        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((b.cap + 63) / 64)), dim3(64), 0, st, c->F, b.O.feats, b.k, b.O.site_seg, T.seg_read,
-                           c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records,
-                           (const unsigned int *)&b.cnt->overflow);
-    else if (b.prm.score)
-        launch_k2(c, k2_grid(c, b.cap), st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr,
-                  b.cap, b.O.prob, (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
+    if (b.prm.score)
+        launch_classifier(c, st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob,
+                          (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_end, st));
     return 0;
 }
@@ -5128,29 +5255,26 @@ extern "C" int mc_last_times_ms(mc_ctx *c, float *out5) {
     return 0;
 }
 
-static int classifier_forward(mc_ctx *c, bool forest, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+// predict_proba of the context's classifier on n input rows from the host (what the reference's call site :199 does, batched)
+static int classifier_forward(mc_ctx *c, int which, const double *X, const uint8_t *submodel, int64_t n, double *p) {
     HIP_TRY(hipSetDevice(c->device));
-    if (forest ? !c->F.left : !c->M.W1) {
-        mc_set_error("classifier forward: no %s set", forest ? "forest" : "MLP");
+    const bool have = which == 1 ? c->F.left != nullptr : (which == 2 ? c->Sc.params != nullptr : c->M.W1 != nullptr);
+    if (!have) {
+        mc_set_error("classifier forward: no %s set", which == 1 ? "forest" : (which == 2 ? "logistic / naive Bayes model" : "MLP"));
         return -12;
     }
     if (n <= 0) return 0;
     double *dX = nullptr, *dp = nullptr;
     uint8_t *ds = nullptr;
-    const int ni = forest ? c->F.n_in : c->M.n_in;
+    const int ni = classifier_inputs(c);
     HIP_TRY(hipMalloc((void **)&dX, (size_t)n * ni * 8));
     HIP_TRY(hipMalloc((void **)&dp, (size_t)n * 8));
     HIP_TRY(hipMalloc((void **)&ds, (size_t)n));
     HIP_TRY(hipMemcpyAsync(dX, X, (size_t)n * ni * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(ds, submodel, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dp, 0xFF, (size_t)n * 8, c->stream));   // NaN
-    if (forest)
-        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, c->F, dX, ni - 1,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                           (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
-    else
-        launch_k2(c, k2_grid(c, n), c->stream, dX, ni - 1, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
-                  (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
+    launch_classifier(c, c->stream, dX, ni - 1, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                      (const uint32_t *)nullptr, ds, n, dp, (const unsigned long long *)nullptr, (const unsigned int *)nullptr);
     HIP_TRY(hipMemcpyAsync(p, dp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
@@ -5177,11 +5301,15 @@ extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
 #endif
 
 extern "C" int mc_mlp_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
-    return classifier_forward(c, false, X, submodel, n, p);
+    return classifier_forward(c, 0, X, submodel, n, p);
 }
 
 extern "C" int mc_forest_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
-    return classifier_forward(c, true, X, submodel, n, p);
+    return classifier_forward(c, 1, X, submodel, n, p);
+}
+
+extern "C" int mc_simple_forward(mc_ctx *c, const double *X, const uint8_t *submodel, int64_t n, double *p) {
+    return classifier_forward(c, 2, X, submodel, n, p);
 }
 
 // ===================================================================================================

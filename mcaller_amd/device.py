@@ -167,10 +167,23 @@ class Device(object):
                                       _ptr(arr['feature']), _ptr(arr['threshold']), _ptr(arr['value']), _ptr(soc)))
         self._clf = 'forest'
 
+    def set_simple(self, models, submodel_of_char):
+        """models: list of LogisticWeights or of GaussianNBWeights (one per sub-model) -- `-c LR` / `-c NBC`."""
+        kind = {'logistic': 1, 'gnb': 2}[models[0].kind]
+        if any(m.kind != models[0].kind or m.n_in != models[0].n_in for m in models):
+            raise NotImplementedError('sub-models of different kinds or shapes')
+        params = np.ascontiguousarray(np.stack([m.params() for m in models]), dtype=np.float64)
+        soc = np.ascontiguousarray(submodel_of_char, dtype=np.uint8)
+        check(lib().mc_ctx_set_simple_classifier(self._ctx, kind, len(models), models[0].n_in, _ptr(params), params.shape[1], _ptr(soc)))
+        self._clf = 'simple'
+
     def set_classifier(self, weights, submodel_of_char):
-        """MLP or forest, whatever the model file held (extract_contexts.py:199 calls either the same way)."""
+        """MLP, forest, logistic regression or naive Bayes, whatever the model file held (extract_contexts.py:199 calls any
+        of them the same way)."""
         if weights[0].kind == 'forest':
             self.set_forest(weights, submodel_of_char)
+        elif weights[0].kind in ('logistic', 'gnb'):
+            self.set_simple(weights, submodel_of_char)
         else:
             self.set_mlp(weights, submodel_of_char)
             self._clf = 'mlp'
@@ -179,7 +192,7 @@ class Device(object):
         X = np.ascontiguousarray(X, dtype=np.float64)
         sm = np.ascontiguousarray(submodel, dtype=np.uint8)
         p = np.empty(len(X), dtype=np.float64)
-        fn = lib().mc_forest_forward if getattr(self, '_clf', 'mlp') == 'forest' else lib().mc_mlp_forward
+        fn = {'forest': lib().mc_forest_forward, 'simple': lib().mc_simple_forward}.get(getattr(self, '_clf', 'mlp'), lib().mc_mlp_forward)
         check(fn(self._ctx, _ptr(X), _ptr(sm), len(X), _ptr(p)))
         return p
 
@@ -346,7 +359,7 @@ class Device(object):
                      n_iter=int(n_iter[j]), val_correct=int(correct[j]), n_val=len(va[j])) for j in range(nj)]
 
     def mlp_forward(self, X, submodel):
-        if getattr(self, '_clf', 'mlp') == 'forest':
+        if getattr(self, '_clf', 'mlp') != 'mlp':
             return self.classifier_forward(X, submodel)
         X = np.ascontiguousarray(X, dtype=np.float64)
         sm = np.ascontiguousarray(submodel, dtype=np.uint8)

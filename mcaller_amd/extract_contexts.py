@@ -531,7 +531,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             try:
                 return fn(*a)
             except _lib.McError as e:
-                if 'table slots' in str(e) and in_flight:
+                if e.code == _lib.E_NO_FREE_SLOT and in_flight:
                     hand_out()
                     continue
                 raise _Unstreamable('the streaming machinery declined: %s' % e)

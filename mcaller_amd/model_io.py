@@ -103,6 +103,38 @@ class ForestWeights(object):
         self.classes = classes
 
 
+class LogisticWeights(object):
+    """scikit-learn LogisticRegression, two classes (train_model.py:55-57, `-c LR`): p = expit(x . coef_ + intercept_)."""
+    kind = 'logistic'
+
+    def __init__(self, coef, intercept, classes=None):
+        self.coef = np.ascontiguousarray(coef, dtype=np.float64).reshape(-1)
+        self.intercept = float(np.asarray(intercept, dtype=np.float64).reshape(-1)[0])
+        self.n_in = len(self.coef)
+        self.classes = classes
+
+    def params(self):
+        return np.concatenate([self.coef, [self.intercept]])
+
+
+class GaussianNBWeights(object):
+    """scikit-learn GaussianNB, two classes (train_model.py:59-60, `-c NBC`): per class the feature means and variances (the
+    variances as the estimator stores them, smoothing included) and the class prior."""
+    kind = 'gnb'
+
+    def __init__(self, theta, var, prior, classes=None):
+        self.theta = np.ascontiguousarray(theta, dtype=np.float64)
+        self.var = np.ascontiguousarray(var, dtype=np.float64)
+        self.prior = np.ascontiguousarray(prior, dtype=np.float64).reshape(-1)
+        if self.theta.shape != self.var.shape or self.theta.shape[0] != 2 or len(self.prior) != 2:
+            raise NotImplementedError('naive Bayes models with %d classes' % self.theta.shape[0])
+        self.n_in = self.theta.shape[1]
+        self.classes = classes
+
+    def params(self):
+        return np.concatenate([self.theta[0], self.var[0], self.theta[1], self.var[1], np.log(self.prior)])
+
+
 def _as_text(x):
     return x.decode('latin1') if isinstance(x, bytes) else str(x)
 
@@ -113,9 +145,19 @@ def _estimator_weights(est, where):
         trees = [(t.tree_.nodes, t.tree_.values) for t in est.estimators_]
         n_feat = int(getattr(est, 'n_features_in_', getattr(est, 'n_features_', 0)) or 0)
         return ForestWeights(trees, n_feat, [_as_text(c) for c in getattr(est, 'classes_', [])])
+    if cls == 'LogisticRegression':
+        coef = np.asarray(est.coef_, dtype=np.float64)
+        if coef.ndim != 2 or coef.shape[0] != 1:
+            raise NotImplementedError('%s: logistic regression with %s coefficients (two classes are supported)' % (where, coef.shape))
+        return LogisticWeights(coef[0], est.intercept_, [_as_text(c) for c in getattr(est, 'classes_', [])])
+    if cls == 'GaussianNB':
+        var = getattr(est, 'var_', None)
+        if var is None:
+            var = est.sigma_                                # (scikit-learn < 1.0)
+        return GaussianNBWeights(est.theta_, var, est.class_prior_, [_as_text(c) for c in getattr(est, 'classes_', [])])
     if cls != 'MLPClassifier':
-        raise NotImplementedError('%s: classifier %s is not supported by the HIP path '
-                                  '(MLPClassifier and RandomForestClassifier are)' % (where, cls))
+        raise NotImplementedError('%s: classifier %s is not supported by the HIP path (MLPClassifier, RandomForestClassifier, '
+                                  'LogisticRegression and GaussianNB are)' % (where, cls))
     coefs, inter = est.coefs_, est.intercepts_
     act = _as_text(getattr(est, 'activation', 'tanh'))
     out_act = _as_text(getattr(est, 'out_activation_', 'logistic'))

@@ -9,7 +9,7 @@ from column 3 of the test TSV; (2) runs the reference's own C
 its testdata and on random micro-cases from oracle/casegen.py; (3) compares every output with
 oracle/py_oracle.py (the pin) and writes the captured reference outputs under tests/golden/.
 
-usage: make_golden.py [n_micro_cases=2000] [--out DIR] [--rf-only]
+usage: make_golden.py [n_micro_cases=2000] [--out DIR] [--rf-only | --simple-only]
 (--out DIR: write the fixtures under DIR/tests/golden and DIR/mcaller_amd/models instead of into the repository.)
 
 Outputs (all DATA: inputs + expected outputs + exported weight arrays, no reference source):
@@ -220,6 +220,42 @@ def export_rf_fixture():
               open(os.path.join(outdir, 'rf_meta.json'), 'w'))
 
 
+def export_simple_fixture():
+    """The reference's other two closed-form classifiers (`-c LR`, `-c NBC`; train_model.py:55-60): scikit-learn
+    LogisticRegression(solver='liblinear', penalty='l1') -- `multi_class='ovr'` is what that solver does for two classes anyway,
+    and scikit-learn >= 1.5 warns about the argument; a fixed random_state so that the fixture can be regenerated byte for byte -- and
+    GaussianNB(), fitted HERE on seeded synthetic vectors labelled by the
+    shipped r95 MLP (as the RF fixture).  The pickles (dicts keyed by sub-model, the reference's format) and predict_proba on
+    probe vectors are the fixture for the device's closed-form classifiers."""
+    import pickle
+    import numpy as np
+    import sklearn
+    from sklearn.linear_model import LogisticRegression
+    from sklearn.naive_bayes import GaussianNB
+    outdir = golden_models_dir()
+    os.makedirs(outdir, exist_ok=True)
+    ref = pickle.loads(open(os.path.join(REF, 'r95_twobase_model_NN_6_m6A.pkl'), 'rb').read(), encoding='latin')
+    meta = {'sklearn': sklearn.__version__}
+    for tag, make in (('LR', lambda: LogisticRegression(solver='liblinear', penalty='l1', random_state=5)), ('NBC', lambda: GaussianNB())):
+        rng = np.random.default_rng(13)
+        probes = np.round(np.concatenate([rng.normal(0, 2.5, size=(256, 6)), rng.uniform(6, 12, size=(256, 1))], axis=1), 4)
+        probes[0, :6] = 40.0                               # (far out: the ends of expit / logsumexp)
+        probes[1, :6] = -40.0
+        models, ka = {}, {}
+        for key in ('MG', 'MH'):
+            X = np.concatenate([rng.normal(0, 2.5, size=(400, 6)), rng.uniform(6, 12, size=(400, 1))], axis=1)
+            y = np.where(ref[key].predict_proba(X)[:, 1] + rng.normal(0, 0.15, size=400) >= 0.5, 'm6A', 'A')
+            est = make()
+            est.fit(X, y)
+            assert list(est.classes_) == ['A', 'm6A']
+            models[key] = est
+            ka[key] = [float(v) for v in est.predict_proba(probes)[:, 1]]
+        with open(os.path.join(outdir, 'simple_twobase_model_%s_6_m6A.pkl' % tag), 'wb') as fh:
+            pickle.dump(models, fh, protocol=4)
+        meta[tag] = dict(probes=[[float(v) for v in r] for r in probes], known_answers=ka, classes=[str(c) for c in models['MG'].classes_])
+    json.dump(meta, open(os.path.join(outdir, 'simple_meta.json'), 'w'))
+
+
 def load_weights(stem):
     """The arrays export_models() wrote: weights from OUT_PKG_MODELS, the sub-model list from models_meta.json."""
     import numpy as np
@@ -359,8 +395,12 @@ def main():
     if '--rf-only' in sys.argv:
         export_rf_fixture()
         return
+    if '--simple-only' in sys.argv:
+        export_simple_fixture()
+        return
     meta = export_models()
     export_rf_fixture()
+    export_simple_fixture()
     report = {'models': {k: v['sha256'] for k, v in meta.items()}}
 
     # ------------------------------------------------------------------ testdata ------------

@@ -100,6 +100,10 @@ def oracle_score(rec, table, qual, weights, soc, k):
     if weights[0].kind == 'forest':
         rec.prob[:n] = oracle_forest_forward(weights, X, sub)
         return
+    if weights[0].kind in ('logistic', 'gnb'):
+        from oracle import clf_oracle
+        rec.prob[:n] = clf_oracle.forward(weights, X, sub)
+        return
     W1 = np.ascontiguousarray(np.stack([w.W1 for w in weights]))
     b1 = np.ascontiguousarray(np.stack([w.b1 for w in weights]))
     W2 = np.ascontiguousarray(np.stack([w.W2 for w in weights]))
