@@ -46,8 +46,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(REPO, 'profiles', 'r03_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc']
+PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc.json')
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc', 'mcaller_amd/csrc/mc_dense.inc']
 
 
 def kernel_source_hash():
@@ -260,6 +260,7 @@ def main():
     ap.add_argument('--motif', default='GATC')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='one pass at a time (mc_extract_features) instead of the pipelined passes')
+    ap.add_argument('--depth', type=int, default=3, help='pipelined passes in flight (1: one pass at a time through the pipelined interface)')
     ap.add_argument('--time-every', type=int, default=8,
                     help='pipelined passes: hipEvents that time a pass go with every n-th pass (one costs the queue ~9 us)')
     ap.add_argument('--cpu-events', type=float, default=1e8, help='rows of the same workload timed on the CPU oracle')
@@ -363,11 +364,16 @@ def main():
             for _ in range(n_steps):
                 on_done(step_sync(full))
             return
-        depth = min(3, n_steps)                                  # passes in flight (the library allows four)
+        depth = max(1, min(args.depth, 3, n_steps))              # passes in flight (the library allows four)
 
         def enqueue():
             next_table(full)
             dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+        if depth == 1:                                           # (one pass at a time through the pipelined interface: profiling)
+            for _ in range(n_steps):
+                enqueue()
+                on_done(dev.wait())
+            return
         for _ in range(depth):
             enqueue()
         dev.wait_begin()                                         # copy-out of the oldest pass started
@@ -819,7 +825,7 @@ def main():
                                                           'declared new: positions + event indices streamed, every row validated)'
                                                           if full else 'ONE validated resident table re-scanned (--rescan-only)'),
                        'step': 'full pass' if full else 'resident rescan',
-                       'passes_in_flight': 1 if args.no_pipeline else min(3, args.steps),
+                       'passes_in_flight': 1 if args.no_pipeline else max(1, min(args.depth, 3, args.steps)),
                        'events_per_gpu': n_rows, 'calls_per_gpu': calls_per_step, 'flush_records_per_gpu': n_records,
                        'copy_out_bytes_per_pass': copy_out_bytes,
                        'events_per_s': n_rows * world * args.steps / elapsed_max,

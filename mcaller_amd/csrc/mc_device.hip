@@ -612,6 +612,53 @@ __device__ __forceinline__ double leaf_sum(RowSrc &S, int64_t &cur, int n) {
     return res;
 }
 
+// The copy-out's packing (k_pack, below) takes the records in PACK_WGS chunks; the kept records and wide slots of every chunk
+// are counted where the records are written (count_for_packing): no pass over the records for the counts alone.
+#ifndef MC_PACK_WGS
+#define MC_PACK_WGS 512
+#endif
+#ifndef MC_PACK_THREADS
+#define MC_PACK_THREADS 512
+#endif
+constexpr int PACK_WGS = MC_PACK_WGS, PACK_THREADS = MC_PACK_THREADS;
+
+// chunk_cnt[PACK_PAD * b], chunk_cnt[PACK_PAD * b + 1]: kept records of chunk b (calls: no MC_I_TOO_MANY) and their slot means
+// that are not fl(d / 1e4) -- every chunk's pair in a cache line of its own: the emit's waves work on neighbouring records, and
+// atomics on one line are served one after the other (all 418 records of a chunk, sixteen chunks to a line: k1_emit 40 -> 139 us).
+constexpr int PACK_PAD = 16;
+
+// One record (q of n_rec) for the packing's counts.  Called by one lane per record (the rare paths).
+__device__ __forceinline__ void count_for_packing(unsigned long long *chunk_cnt, int64_t q, int64_t n_rec, bool kept, int n_wide) {
+    if (!chunk_cnt || !kept) return;
+    const uint32_t per = (uint32_t)((n_rec + PACK_WGS - 1) / PACK_WGS);
+    const uint32_t b = (uint32_t)q / per;
+    atomicAdd(&chunk_cnt[PACK_PAD * b], 1ull);
+    if (n_wide) atomicAdd(&chunk_cnt[PACK_PAD * b + 1], (unsigned long long)n_wide);
+}
+
+// ... the records of a wave, all lanes calling: kept (one lane per record), q, wmask (bit f: slot mean f is wide) of the lane's
+// record.  One pair of atomics for the wave unless its records straddle a chunk boundary.
+__device__ __forceinline__ void count_wave_for_packing(unsigned long long *chunk_cnt, int64_t n_rec, bool kept, int64_t q, uint32_t wmask, int k) {
+    if (!chunk_cnt) return;
+    const unsigned long long km = __ballot(kept);
+    if (!km) return;
+    const uint32_t per = (uint32_t)((n_rec + PACK_WGS - 1) / PACK_WGS);
+    const uint32_t bq = kept ? (uint32_t)q / per : 0u;
+    const int first = __ffsll((unsigned long long)km) - 1;
+    const uint32_t b0 = (uint32_t)__shfl((int)bq, first);
+    if (!__ballot(kept && bq != b0)) {
+        int nw = 0;
+        for (int f = 0; f < k; ++f) nw += __popcll(__ballot(kept && ((wmask >> f) & 1u)));
+        if ((int)(threadIdx.x & 63) == first) {
+            atomicAdd(&chunk_cnt[PACK_PAD * b0], (unsigned long long)__popcll(km));
+            if (nw) atomicAdd(&chunk_cnt[PACK_PAD * b0 + 1], (unsigned long long)nw);
+        }
+    } else if (kept) {
+        atomicAdd(&chunk_cnt[PACK_PAD * bq], 1ull);
+        if (wmask) atomicAdd(&chunk_cnt[PACK_PAD * bq + 1], (unsigned long long)__popc(wmask));
+    }
+}
+
 // What k1_scan hands to k1_emit per closed window (arrival order; k1_list maps file order onto it)
 constexpr uint32_t PF_EXTRA = 1, PF_CLOSE_NS = 2, PF_MULTI = 8, PF_REV = 16, PF_STRAY = 32;
 constexpr int WROWS = 64;   // rows before a window's last row that k1_emit looks at (longer windows: k1_rare)
@@ -646,6 +693,9 @@ struct K1Args {
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
+    int needs_ctx;                // (host side) the records' info words lack context[k]: k_ctx_fill goes behind the emit (k1_dense)
+    unsigned long long *chunk_cnt;  // pipelined passes: [PACK_PAD * PACK_WGS] kept records / their wide slots per chunk of the copy-out's packing
+                                  // (k_pack), counted by the emit itself as it writes the records; nullptr: nobody packs (or k_pack_count counts)
 };
 
 // The row that closes a window whose last row is r (in name block nb_abs, which ends at my_end): the next
@@ -1648,6 +1698,8 @@ __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int
 __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ sorted, int gather) {
     MC_FRONT_OF_THE_QUEUE;
     const DevTable &T = A.T;
+    if (A.chunk_cnt && blockIdx.x == 0)              // (the packing's counts: the emit behind this kernel adds them up)
+        for (int i = threadIdx.x; i < PACK_WGS; i += blockDim.x) { A.chunk_cnt[PACK_PAD * i] = 0ull; A.chunk_cnt[PACK_PAD * i + 1] = 0ull; }
     constexpr int LG = 8;
     const int64_t tile = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LG;
     const int l = threadIdx.x & (LG - 1);
@@ -1664,6 +1716,7 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     if (tile == T.n_tiles - 1 && l == 0) A.cnt->n_records = (unsigned long long)(first + c);   // the total
     if (c == 0) return;
     if (first + c > A.O.capacity) { if (l == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    if (gather == 2) return;                        // (k1_dense: no payloads at all -- only the total, and the room)
     if (!gather) {                                  // (a chunk the scan could not get: the pass is repeated with more room)
         for (int ci = l; PT + (ci << A.chunk_shift) < c; ci += LG)
             if (A.tile_chunk[tile * NCHUNK + ci] < 0) atomicOr(&A.cnt->overflow, 1u);
@@ -1846,10 +1899,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     const int n = __popcll(ms) + (has_stray ? 1 : 0);
     const uint32_t empties = (uint32_t)(__ballot(fast && s < k && n == 0) >> gsh) & 0xFFu;    // bit s: slot s is empty
-    if (!fast) continue;
+    bool kept_rec = false;                  // (lane 0 of a group: its record is a call; wide_bit: which of its slot means are wide)
+    unsigned wide_bit = 0u;
+    if (fast) {
     const bool too_many = __popc(empties) > A.skip_thresh;
     const bool rev = P.flags & PF_REV;
-    unsigned wide_bit = 0u;
     if (s < k) {
         double f = 0.0;
         if (!too_many && n > 0) {
@@ -1921,7 +1975,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         A.O.close_row[q] = P.close_row;
         A.O.info[q] = info;
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+        kept_rec = !too_many;
     }
+    }
+    count_wave_for_packing(A.chunk_cnt, n_rec, kept_rec, q, wide_bit, k);       // (the packing's counts, k_pack)
     }
 }
 
@@ -2284,6 +2341,8 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     ER_STAMP(5);
 }
 
+#include "mc_dense.inc"
+
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
 // thread per such record, so that k1_emit carries neither the stack nor the registers for it.
 __device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
@@ -2384,6 +2443,14 @@ __global__ void k1_rare_dev(K1Args A, const Payload *__restrict__ sorted, const 
         RowSrc S{A.T.pos, A.T.evmu, A.T.flags, false, 0.0};
         emit_record(A, S, d, P.nb, P.r, P.m, q);
         bigfix_record(A, q);
+        if (A.chunk_cnt && !(A.O.info[q] & MC_I_TOO_MANY)) {       // (the packing's counts: k1_emit left this record out)
+            int n_wide = 0;
+            for (int f = 0; f < A.k; ++f) {
+                int32_t d32;
+                n_wide += slot_is_narrow(A.O.feats[q * A.k + f], &d32) ? 0 : 1;
+            }
+            count_for_packing(A.chunk_cnt, q, min((int64_t)A.cnt->n_records, A.O.capacity), true, n_wide);
+        }
     }
 }
 
@@ -3132,13 +3199,7 @@ __global__ __launch_bounds__(64) void k3_simple(DevSimple S, const double *__res
 // (512 x 512: beside the next pass's scan the two kernels wait for memory most of the time, and twice the lanes have twice the
 // loads in flight -- k_pack 96 -> 46 us there, and the scan it runs beside 106 -> 96 us; pipelined pass with 256 x 256: 0.2013 ms,
 // 448 or 512: 0.193-0.195, 576: 0.203, 640: 0.207, 768: 0.215, 1024: 0.231; 256 x 512, 384 x 384: 0.195-0.197)
-#ifndef MC_PACK_WGS
-#define MC_PACK_WGS 512
-#endif
-#ifndef MC_PACK_THREADS
-#define MC_PACK_THREADS 512
-#endif
-constexpr int PACK_WGS = MC_PACK_WGS, PACK_THREADS = MC_PACK_THREADS;
+// (PACK_WGS, PACK_THREADS: defined with the emit kernels, which count per packing chunk)
 
 struct PackLayout { size_t pos, seg, info, feats; };       // byte offsets in the block (the closing rows come first)
 __host__ __device__ inline PackLayout pack_layout(int64_t n, int close32) {
@@ -3166,7 +3227,7 @@ __host__ __device__ inline PackTail pack_tail(size_t feats_off, size_t m, int k,
     return T;
 }
 
-// chunk_cnt[b] = kept records of chunk b, chunk_cnt[PACK_WGS + b] = their wide slots
+// chunk_cnt[PACK_PAD * b] = kept records of chunk b, chunk_cnt[PACK_PAD * b + 1] = their wide slots
 __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt, int k,
                                                              unsigned long long *__restrict__ chunk_cnt) {
     __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
@@ -3191,8 +3252,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const
     if (threadIdx.x == 0) {
         unsigned long long t = 0, w = 0;
         for (int j = 0; j < PACK_THREADS / 64; ++j) { t += s_wave[0][j]; w += s_wave[1][j]; }
-        chunk_cnt[blockIdx.x] = t;
-        chunk_cnt[PACK_WGS + blockIdx.x] = w;
+        chunk_cnt[PACK_PAD * blockIdx.x] = t;
+        chunk_cnt[PACK_PAD * blockIdx.x + 1] = w;
     }
 }
 
@@ -3206,8 +3267,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     __shared__ double s_feats[PACK_THREADS * MC_MAX_K];     // the strip's slot means, loaded with consecutive lanes on consecutive words
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // kept records (and their wide slots) before this chunk, and in all chunks
-    unsigned long long v = tid < PACK_WGS ? chunk_cnt[tid] : 0ull, before = tid < (int)blockIdx.x ? v : 0ull;
-    unsigned long long w = tid < PACK_WGS ? chunk_cnt[PACK_WGS + tid] : 0ull, wbefore = tid < (int)blockIdx.x ? w : 0ull;
+    unsigned long long v = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid] : 0ull, before = tid < (int)blockIdx.x ? v : 0ull;
+    unsigned long long w = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid + 1] : 0ull, wbefore = tid < (int)blockIdx.x ? w : 0ull;
     for (int o = 32; o > 0; o >>= 1) {
         v += __shfl_xor(v, o); before += __shfl_xor(before, o);
         w += __shfl_xor(w, o); wbefore += __shfl_xor(wbefore, o);
@@ -4730,7 +4791,7 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
                       hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
-                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr) {
+                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
@@ -4739,10 +4800,39 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
     const bool dense = dense_reference(c);
+    static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
+    const bool runs = dense && !no_runs;
+    // (k1_emit and the row-by-row kernel count the packing's chunks as they write the records; the run-table emit of a dense
+    // reference does not: k_pack_count goes over its records)
+    A.chunk_cnt = runs ? nullptr : chunk_cnt;
+    A.needs_ctx = 0;
     A.chunk_shift = dense ? 8 : 6;
     A.shard_shift = T.n_tiles >= 1024 ? 6 : 3;
     A.shard_mask = (1 << A.shard_shift) - 1;
     static_assert(NSHARD == 64, "shard_shift");
+    // Dense references, pipelined passes: ONE streaming kernel, run twice (mc_dense.inc) -- the windows of every tile counted (and
+    // the table validated, if this is its first pass), the counts turned into first record slots, the same walk again writing
+    // the records in file order; no payloads.  (The synchronous pass, and the re-run of a pass this kernel gives up, take the
+    // scan + run-table emit below.)
+    static const bool stream_env = getenv("MCALLER_DENSE_STREAM") != nullptr;     // (opt-in: measured slower than the pair below, see the next commit)
+    if (runs && chunk_cnt && stream_env) {
+        const dim3 tiles((unsigned)T.n_tiles);
+        A.chunk_cnt = chunk_cnt;
+        A.needs_ctx = 1;
+        if (plan.scan_mode == SCAN_VALIDATE) hipLaunchKernelGGL((k1_dense<false, true>), tiles, dim3(64), 0, st, A, sorted);
+        else hipLaunchKernelGGL((k1_dense<false, false>), tiles, dim3(64), 0, st, A, sorted);
+        if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
+        hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
+                           (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
+        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted, 2);
+        if (ev_emit_end && MC_EVENTS_ON_KERNELS) hipExtLaunchKernelGGL((k1_dense<true, false>), tiles, dim3(64), 0, st, nullptr, ev_emit_end, 0, A, sorted);
+        else {
+            hipLaunchKernelGGL((k1_dense<true, false>), tiles, dim3(64), 0, st, A, sorted);
+            if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
+        }
+        *out_args = A;
+        return 0;
+    }
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const dim3 grid((unsigned)T.n_tiles);
     constexpr int CG_DENSE = CHUNK / 8 + 2;      // (every unit of a chunk; one cut by the boundary of its two blocks is listed twice)
@@ -4759,8 +4849,6 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
                        (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
     // (dense references: a workgroup per tile, the mean of every position once, see k1_emit_runs -- which takes the payloads where
     // the scan left them: no gather)
-    static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
-    const bool runs = dense && !no_runs;
     hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted, runs ? 0 : 1);
     // (ev_emit_end rides on the emit's own dispatch packet: a hipEventRecord behind it is a barrier packet of its own and
     // costs the queue 5-9 us)
@@ -4984,7 +5072,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
         return -12;
     }
     const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8 + 1) + 128;       // (every slot mean 64 bits wide at worst, a mask byte per call)
-    if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)2 * PACK_WGS)) return -10;
+    if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_PAD * PACK_WGS)) return -10;
     if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
@@ -5007,6 +5095,8 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     hipStream_t st = c->side_stream;
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
+    if (A.needs_ctx)               // (k1_dense's records: the character after the 'M', per record from the reference)
+        hipLaunchKernelGGL(k_ctx_fill, dim3((unsigned)((b.cap + 255) / 256)), dim3(256), 0, st, A);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
     if (b.prm.score)
         launch_classifier(c, st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob,
@@ -5016,9 +5106,10 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
 }
 
 // Packing of a pass whose classifier has been enqueued (ev_k2_end recorded): what mc_wait_records_begin copies out.
-static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b) {
+// count: the chunk counts are not there yet (the emit counts them as it writes the records, except k1_emit_runs)
+static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b, bool count) {
     hipStream_t s2 = c->side_stream;
-    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.k, b.chunk_cnt);
+    if (count) hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, b.O, (const Counters *)b.cnt, b.k, b.chunk_cnt);
     if (MC_EVENTS_ON_KERNELS)
         hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, s2, nullptr, b.ev_done, 0, b.O, (const Counters *)b.cnt,
                               (const unsigned long long *)b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev);
@@ -5085,10 +5176,10 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end)) return rc;
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt)) return rc;
     if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
-    if (int rc = enqueue_pack(c, b)) return rc;
+    if (int rc = enqueue_pack(c, b, A.chunk_cnt == nullptr)) return rc;
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
     // copy-out of the previous pass, which mc_wait_records enqueues later)
     HIP_TRY(hipGetLastError());

@@ -4,7 +4,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob('gpurun_out/sq/p*/**/*counter_collection.csv', recursive=True):
     per = collections.defaultdict(float)
     for row in csv.DictReader(open(path)):
-        k = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0]
+        k = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].replace('k1_dense<true, false>', 'k1_dense_emit').replace('k1_dense<false, false>', 'k1_dense_count').replace('k1_dense<false, true>', 'k1_dense_countv').split('<')[0]
         per[(k, row['Dispatch_Id'], row['Counter_Name'])] += float(row['Counter_Value'])
     for (k, d, c), v in per.items():
         agg[k][c].append(v)
