@@ -47,7 +47,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc', 'mcaller_amd/csrc/mc_dense.inc']
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc']
 
 
 def kernel_source_hash():
@@ -842,8 +842,8 @@ def main():
                        'strong_scaling': 'see the top-level key (BASELINE.json configs[3]: one file, mCaller --gpus N --bed)',
                        'file_to_file': file_to_file, 'file_to_file_1e8': file_to_file_big, 'text_e2e': text_e2e},
             'roofline': {'bound': 'hbm',
-                         'kernel': 'every kernel that touches a table once: k0_first_site + k1_scan (validating) + k1_group_scan + '
-                                   'k1_list + k1_emit',
+                         'kernel': 'every kernel that touches a table once: k_nb_template + k0_first_site + k1_scan (validating) + '
+                                   'k1_group_scan + k1_list + k1_emit',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_source, 'traffic_per_kernel': per_kernel_traffic,

@@ -25,9 +25,13 @@ void mc_set_error(const char *fmt, ...) {
 extern "C" const char *mc_last_error(void) { return g_err; }
 extern "C" const char *mc_version(void) { return "mcaller_hip 0.2 (gfx950)"; }
 
-// Cores this process may run on (sched_getaffinity), not the cores of the machine: a worker that bound itself to the NUMA
-// node of its GPU (mc_bind_to_device_numa_node), or a job inside a cpuset, starts that many parser / formatter threads.
-extern "C" int mc_host_cores(void) {
+// Cores this process may USE: the CPUs of its affinity mask (a worker that bound itself to the NUMA node of its GPU,
+// mc_bind_to_device_numa_node, or a job inside a cpuset), capped by the CPU-time quota of its control group (cpu.max: a
+// container that is granted 16 CPUs' worth of time per 100 ms on a 256-CPU host) -- and by $MCALLER_HOST_CORES (the workers of a
+// multi-GPU run share one quota).  Parser, reader, formatter and FASTQ threads are that many: with 64 threads runnable under a
+// quota of 16 the group burns its period's allowance in 25 ms and EVERY thread of the process -- the one that feeds the GPU
+// included -- is stopped for the other 75 (file to file at 10^8 rows: 0.5 s on a busy box instead of 0.3).
+static int affinity_cpus(void) {
     const int max_cpus = 8192;
     cpu_set_t *set = CPU_ALLOC(max_cpus);
     int n = 0;
@@ -37,8 +41,43 @@ extern "C" int mc_host_cores(void) {
         if (sched_getaffinity(0, bytes, set) == 0) n = CPU_COUNT_S(bytes, set);
         CPU_FREE(set);
     }
-    if (n < 1) n = 1;
-    return n;
+    return n < 1 ? 1 : n;
+}
+
+static int cgroup_quota_cpus(void) {           // -> CPUs' worth of time the control group grants, 0: unlimited / unknown
+    // cgroup v2: "<quota> <period>" or "max <period>"; the process's own group, or the root the container sees
+    char path[512] = "/sys/fs/cgroup/cpu.max";
+    if (FILE *f = fopen("/proc/self/cgroup", "r")) {
+        char line[512];
+        while (fgets(line, sizeof(line), f))
+            if (strncmp(line, "0::", 3) == 0) {
+                char *nl = strchr(line, '\n');
+                if (nl) *nl = 0;
+                char own[512];
+                snprintf(own, sizeof(own), "/sys/fs/cgroup%s/cpu.max", line + 3);
+                if (FILE *g = fopen(own, "r")) { fclose(g); snprintf(path, sizeof(path), "%s", own); }
+            }
+        fclose(f);
+    }
+    long long quota = 0, period = 0;
+    if (FILE *f = fopen(path, "r")) {
+        char q[64] = "";
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {                                     // cgroup v1
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = 0; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)std::max<long long>(1, (quota + period - 1) / period);
+}
+
+extern "C" int mc_host_cores(void) {
+    int n = affinity_cpus();
+    static const int quota = cgroup_quota_cpus();
+    if (quota > 0) n = std::min(n, quota);
+    if (const char *e = getenv("MCALLER_HOST_CORES")) { if (atoi(e) > 0) n = std::min(n, atoi(e)); }
+    return n < 1 ? 1 : n;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -225,6 +264,15 @@ struct Workers {
             CPU_FREE(set);
         }
         // (Linux numbers the second hardware thread of every core after all first ones: ascending order = cores first)
+        // Fewer workers than CPUs (a CPU-time quota, mc_host_cores): spread over the physical cores -- the first half of the list
+        // on a machine with two hardware threads a core -- so that they sit on both sockets and share no core
+        const int use = mc_host_cores();
+        if (use < (int)cpus.size()) {
+            const size_t pool = cpus.size() >= (size_t)use * 2 ? cpus.size() / 2 : cpus.size();
+            std::vector<int> pick;
+            for (int i = 0; i < use; ++i) pick.push_back(cpus[(size_t)i * pool / (size_t)use]);
+            cpus.swap(pick);
+        }
     }
 
     // run tasks of job j until it has none left to hand out; returns the number this thread ran
@@ -283,7 +331,10 @@ void mc_parallel_for(int n, const std::function<void(int)> &f) {
         }
         W.jobs.push_back(&job);
     }
-    W.wake.notify_all();
+    // (as many workers as the job has tasks for: waking them all -- a few hundred threads on a big host, each to find the tasks
+    // gone -- costs the process CPU time it may not have)
+    if (n - 1 >= W.n_threads) W.wake.notify_all();
+    else for (int i = 0; i < n - 1; ++i) W.wake.notify_one();
     Workers::run_tasks(&job);                                  // the caller takes tasks as well
     {
         std::unique_lock<std::mutex> lk(W.mu);

@@ -693,7 +693,6 @@ struct K1Args {
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
-    int needs_ctx;                // (host side) the records' info words lack context[k]: k_ctx_fill goes behind the emit (k1_dense)
     unsigned long long *chunk_cnt;  // pipelined passes: [PACK_PAD * PACK_WGS] kept records / their wide slots per chunk of the copy-out's packing
                                   // (k_pack), counted by the emit itself as it writes the records; nullptr: nobody packs (or k_pack_count counts)
 };
@@ -1716,7 +1715,6 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     if (tile == T.n_tiles - 1 && l == 0) A.cnt->n_records = (unsigned long long)(first + c);   // the total
     if (c == 0) return;
     if (first + c > A.O.capacity) { if (l == 0) atomicOr(&A.cnt->overflow, 1u); return; }
-    if (gather == 2) return;                        // (k1_dense: no payloads at all -- only the total, and the room)
     if (!gather) {                                  // (a chunk the scan could not get: the pass is repeated with more room)
         for (int ci = l; PT + (ci << A.chunk_shift) < c; ci += LG)
             if (A.tile_chunk[tile * NCHUNK + ci] < 0) atomicOr(&A.cnt->overflow, 1u);
@@ -2340,8 +2338,6 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     }
     ER_STAMP(5);
 }
-
-#include "mc_dense.inc"
 
 // Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
 // thread per such record, so that k1_emit carries neither the stack nor the registers for it.
@@ -4449,7 +4445,10 @@ extern "C" int mc_ctx_select_table(mc_ctx *c, int32_t slot, int32_t as_new) {
     // (passes over the slot that are still in flight keep the plan they were enqueued with; a first pass only ORs what it sees
     // into the table's validation flags, so declaring the table new beside them is safe as long as they are first passes too --
     // bench.py's steps -- and a caller that mixes pass kinds waits for them first)
-    if (as_new) S.passes = 0;
+    if (as_new) {
+        S.passes = 0;
+        S.tmpl_ref = -1;          // (the name-block templates too: k_nb_template is part of what a table costs when it is scanned once)
+    }
     return 0;
 }
 
@@ -4805,34 +4804,10 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     // (k1_emit and the row-by-row kernel count the packing's chunks as they write the records; the run-table emit of a dense
     // reference does not: k_pack_count goes over its records)
     A.chunk_cnt = runs ? nullptr : chunk_cnt;
-    A.needs_ctx = 0;
     A.chunk_shift = dense ? 8 : 6;
     A.shard_shift = T.n_tiles >= 1024 ? 6 : 3;
     A.shard_mask = (1 << A.shard_shift) - 1;
     static_assert(NSHARD == 64, "shard_shift");
-    // Dense references, pipelined passes: ONE streaming kernel, run twice (mc_dense.inc) -- the windows of every tile counted (and
-    // the table validated, if this is its first pass), the counts turned into first record slots, the same walk again writing
-    // the records in file order; no payloads.  (The synchronous pass, and the re-run of a pass this kernel gives up, take the
-    // scan + run-table emit below.)
-    static const bool stream_env = getenv("MCALLER_DENSE_STREAM") != nullptr;     // (opt-in: measured slower than the pair below, see the next commit)
-    if (runs && chunk_cnt && stream_env) {
-        const dim3 tiles((unsigned)T.n_tiles);
-        A.chunk_cnt = chunk_cnt;
-        A.needs_ctx = 1;
-        if (plan.scan_mode == SCAN_VALIDATE) hipLaunchKernelGGL((k1_dense<false, true>), tiles, dim3(64), 0, st, A, sorted);
-        else hipLaunchKernelGGL((k1_dense<false, false>), tiles, dim3(64), 0, st, A, sorted);
-        if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
-        hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((T.n_tiles + GROUP - 1) / GROUP)), dim3(GROUP), 0, st,
-                           (const int32_t *)c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum);
-        hipLaunchKernelGGL(k1_list, dim3((unsigned)((T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted, 2);
-        if (ev_emit_end && MC_EVENTS_ON_KERNELS) hipExtLaunchKernelGGL((k1_dense<true, false>), tiles, dim3(64), 0, st, nullptr, ev_emit_end, 0, A, sorted);
-        else {
-            hipLaunchKernelGGL((k1_dense<true, false>), tiles, dim3(64), 0, st, A, sorted);
-            if (ev_emit_end) HIP_TRY(hipEventRecord(ev_emit_end, st));
-        }
-        *out_args = A;
-        return 0;
-    }
     // one wave per tile; the instance with the small candidate list unless marked positions are dense (a one-base motif)
     const dim3 grid((unsigned)T.n_tiles);
     constexpr int CG_DENSE = CHUNK / 8 + 2;      // (every unit of a chunk; one cut by the boundary of its two blocks is listed twice)
@@ -5095,8 +5070,6 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     hipStream_t st = c->side_stream;
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     hipLaunchKernelGGL(k1_rare_dev, dim3(64), dim3(64), 0, st, A, (const Payload *)b.sorted, (const int64_t *)b.rare);
-    if (A.needs_ctx)               // (k1_dense's records: the character after the 'M', per record from the reference)
-        hipLaunchKernelGGL(k_ctx_fill, dim3((unsigned)((b.cap + 255) / 256)), dim3(256), 0, st, A);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
     if (b.prm.score)
         launch_classifier(c, st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob,

@@ -70,13 +70,17 @@ class _Abort(Exception):
     """The parent told the worker to stop."""
 
 
-def _worker(conn, device):
+def _worker(conn, device, n_workers=1):
     """A worker process: one GPU, jobs from the parent until it says None (or its end of the pipe closes).  A plain run sends
     one job; a caller that runs file after file (MCALLER_KEEP_WORKERS: bench.py's strong-scaling leg) finds the worker, its HIP
     context, its pinned buffers and its table slots where the last file left them."""
     os.environ['MCALLER_DEVICE'] = str(device)
     cache = {}
     try:
+        if n_workers > 1:                       # (the workers of a run share the host's cores -- and its CPU-time quota, if it has one)
+            from . import _lib
+            share = max(2, int(_lib.lib().mc_host_cores()) // n_workers)
+            os.environ['MCALLER_HOST_CORES'] = str(min(share, int(os.environ.get('MCALLER_HOST_CORES', share))))
         while True:
             try:
                 job = conn.recv()
@@ -254,7 +258,7 @@ class _Workers(object):
         self.files = 0
         for dev in devices:
             parent, child = ctx.Pipe()
-            p = ctx.Process(target=_worker, args=(child, dev))
+            p = ctx.Process(target=_worker, args=(child, dev, len(self.devices)))
             p.start()
             child.close()
             self.procs.append(p)
