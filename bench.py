@@ -889,7 +889,7 @@ def main():
             # the same port on all host cores: shards by read (what the reference's -t does with processes), one thread each
             try:
                 from concurrent.futures import ThreadPoolExecutor
-                from mcaller_amd import shard
+                from tests import shard                    # (the checker side: shards of a table for the CPU legs)
                 cores = min(len(os.sched_getaffinity(0)), 64)
                 bounds = [b for b in shard.shard_bounds(sub, cores) if b[1] > b[0]]
                 subs = [(sub.slice_segments(lo, hi), shard.tail_contig(sub, qual, 0.0, hi)) for lo, hi in bounds]

@@ -30,7 +30,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend='gloo', init_method='env://')
-    from mcaller_amd import shard, make_bed
+    from mcaller_amd import make_bed
+    from tests import shard
     from mcaller_amd.extract_contexts import submodel_setup
     codes, ref, table, qual = make_workload(n_rows=120000, seed=33, genome_len=40000)
     _, weights, _, soc = submodel_setup(H.load_modelset('r95'), 'A')

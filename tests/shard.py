@@ -1,11 +1,12 @@
-"""Sharding by read: a window never spans two name blocks (flush on read change,
+"""Test / bench helper (not part of the product: the product shards FILES by byte range, mcaller_amd/multi_gpu.py).
+Sharding a TABLE by read: a window never spans two name blocks (flush on read change,
 extract_contexts.py:179,242), so a table can be cut at name-block boundaries and the shards scanned independently, one
 GPU each.  Two things cross a cut: the first unfiltered row after a shard closes the shard's last window (R6) and gives
 that record its `chrom` (R8) -> `tail_contig`; and `last_read`, which only matters when a read name occurs in more than
 one name block -> such tables are not cut."""
 import numpy as np
 
-from . import _lib
+from mcaller_amd import _lib
 
 
 def name_block_starts(table):

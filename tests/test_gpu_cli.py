@@ -72,7 +72,8 @@ def test_train_mode_feature_matrix(td, tmp_path):
 
 def test_sharded_run_on_one_gpu_equals_the_whole():
     """Shards scanned one after the other on the same GPU (tail_contig path of the kernels) == the whole table."""
-    from mcaller_amd import shard, synth
+    from mcaller_amd import synth
+    from tests import shard
     from mcaller_amd.device import Device
     from mcaller_amd.extract_contexts import submodel_setup
     codes = synth.genome(length=500000, seed=9)

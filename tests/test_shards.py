@@ -20,7 +20,7 @@ def make_workload(n_rows=150000, seed=21, motif='GATC', genome_len=300000):
 
 
 def sharded_records(table, ref, qual, n_shards, k=6, skip=0, qthresh=0.0):
-    from mcaller_amd import shard
+    from tests import shard
     bounds = shard.shard_bounds(table, n_shards)
     parts, ro, so, nr, tr = [], [], [], [], []
     for lo, hi in bounds:
@@ -53,7 +53,8 @@ def test_shards_with_quality_filter_and_skips():
 
 
 def test_repeated_read_names_are_not_cut():
-    from mcaller_amd import shard, _lib
+    from mcaller_amd import _lib
+    from tests import shard
     codes, ref, table, qual = make_workload(n_rows=30000)
     table.seg_read[-1] = table.seg_read[0]                        # the last read reuses the first read's name
     assert shard.has_repeated_names(table)

@@ -8,14 +8,18 @@ export TMPDIR=/tmp
 mkdir -p $out
 src=$(python3 -c "import bench; print(bench.kernel_source_hash())")
 echo "commit $head, kernel sources $src" > $out/HEAD.txt
-# the PMC passes first: bench.py quotes roofline.traffic from profiles/r03_pmc.json if that file was collected on the kernel
+# the PMC passes first: bench.py quotes roofline.traffic from profiles/r04_pmc.json if that file was collected on the kernel
 # sources the library was built from -- on the box's copy of the repository it is, from here on
 : > $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 python3 tools/pmc_summary.py $out/fetch $out/write $out/pmc.json "python3 bench.py --steps 4 --warmup 0 --kernels-only" $head
-cp $out/pmc.json profiles/r03_pmc.json
+cp $out/pmc.json profiles/r04_pmc.json
 timeout 1200 python3 bench.py > $out/bench.json 2>> $out/bench.err
+# the driver's own command line (20 steps: the pipeline's fill and drain inside the timed region; ms_per_step_steady beside it)
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmdline.json 2>> $out/bench.err
+# two ranks on the one GPU of this box (plumbing of the N > 1 line: both legs, the reduction's host-sum branch), at 2*10^7 rows
+MCALLER_BENCH_ONE_DEVICE=1 timeout 900 python3 bench.py --gpus 2 --steps 20 --warmup 5 --events 2e7 --strong-events 2e7 --f2f-big-events 2e7 --f2f-events 1e6 > $out/bench_2ranks_on_one_gpu_plumbing.json 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --kernels-only > $out/stats_bench.json 2>> $out/bench.err
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 rm -rf $out/fetch $out/write $out/stats
@@ -43,9 +47,9 @@ cp $out/stats2/*/*kernel_stats.csv $out/kernel_stats_file_to_file.csv; rm -rf $o
 fi
 python3 - <<P
 import json
-for f in ("bench","bench_sync","bench_1e9","bench_dense_1e8"):
+for f in ("bench","bench_driver_cmdline","bench_sync","bench_1e9","bench_dense_1e8"):
     try:
-        d=json.load(open("$out/%s.json"%f)); print(f, "%.4g"%d["value"], "%.4f"%d["ms_per_step"], {k:round(v,4) for k,v in d["config"]["kernel_ms"].items()}, round(d["roofline"]["frac"],4), d["roofline"]["kernels_ms"], (d["config"].get("device_e2e") or {}).get("events_per_s"), (d["config"].get("file_to_file") or {}).get("seconds_median"))
+        d=json.load(open("$out/%s.json"%f)); print(f, "%.4g"%d["value"], "%.4f"%d["ms_per_step"], {k:round(v,4) for k,v in d["config"]["kernel_ms"].items()}, round(d["roofline"]["frac"],4), d["roofline"]["kernels_ms"], (d["config"].get("device_e2e") or {}).get("events_per_s"), (d["config"].get("file_to_file") or {}).get("seconds_median"), (d["config"].get("file_to_file_1e8") or {}).get("seconds_median"), (d.get("strong_scaling") or {}).get("seconds_median"), d.get("ms_per_step_steady"))
     except Exception as e: print(f, e)
 P
 tail -n 3 $out/bench.err
