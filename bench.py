@@ -47,7 +47,8 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_device.hip', 'mcaller_amd/csrc/mc_devparse.inc']
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_literal.hip',
+                  'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip', 'mcaller_amd/csrc/mc_devparse.inc']
 
 
 def kernel_source_hash():

@@ -1,0 +1,665 @@
+// mc_classify.hip: predict_proba (k2_mlp, k3_forest, k3_simple) and the packing of a pass's records for the copy-out (k_pack) -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers: mc_dev.h; the map of the
+// kernels: mc_stream.hip.
+#include "mc_dev.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// K2: batched MLP forward, fp64 (predict_proba, :199).  One lane per record; the weights are scalar operands.
+// ---------------------------------------------------------------------------------------------------
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)) and 1 / (1 + e^{-z}) = 1 - 1 / (e^{z} + 1) from one exponential each and a
+// reciprocal that FOUR of them share, written out: the library's exp and the IEEE division cost ~100 instructions per tanh,
+// and the classifier is 100 tanh per call -- this is 25.  Absolute error < 1e-15, far inside the 1e-9 the probabilities are
+// held to.
+//
+// e^{2t} + 1 for t >= 0:  t = n ln2/2 + r, |r| <= ln2/4;  e^{2r} = 1 + 2r + r^2 G(r) with G of degree 9 -- the interpolant of
+// (e^x - 1 - x) / x^2 at the Chebyshev nodes of [-ln2/2, ln2/2] (computed with 80 digits; relative error of e^x with the
+// coefficients rounded to double: 1.6e-17; the Taylor polynomial needs two more terms), its coefficients scaled by powers
+// of two for the argument x = 2r -- and e^{2t} = 2^n e^{2r}.  n = rint(2t / ln2) without v_rndne / v_cvt / v_ldexp
+// (quarter-rate fp64 instructions): adding 1.5 * 2^52 leaves the integer in the low mantissa bits, and 2^n is built from it
+// with one integer instruction.  e^0 = 1 exactly (tanh(0) = 0).
+//
+// The constants live in VGPRs on purpose (VgprConst): k2_mlp keeps the weights of four hidden units in SGPRs (72 of the
+// ~100 there are), and constants the compiler put there as well were spilled to VGPR lanes and read back inside the loop.
+struct VgprConst {
+    double v;
+    __device__ __forceinline__ explicit VgprConst(double x) : v(x) { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ operator double() const { return v; }
+};
+struct ExpConsts {
+    VgprConst two_log2e{2.8853900817779268}, magic{6755399441055744.0}, half_ln2_hi{-0.3465735901845619},
+        half_ln2_lo{-9.541074646352939e-11};
+    VgprConst t_max4{87.5};        // e^{2t} <= e^175: the product of four such (e^{2t} + 1) stays finite; tanh(87.5) = 1 in double
+    VgprConst g9{5.1405589494805136e-05}, g8{0.0002828297056809958}, g7{0.0014109321451518497}, g6{0.00634918945176432},
+        g5{0.02539682542470863}, g4{0.08888888907016779}, g3{0.26666666666656197}, g2{0.6666666666659861},
+        g1{1.3333333333333335}, g0{2.0000000000000004};
+};
+
+__device__ __forceinline__ double exp2t_plus1(double t, const ExpConsts &C) {      // (0 <= t <= 350)
+    const double tt = fma(t, C.two_log2e, C.magic);
+    const double n = tt - C.magic;
+    double r = fma(n, C.half_ln2_hi, t);                    // ln2/2 in two pieces
+    r = fma(n, C.half_ln2_lo, r);
+    double p = C.g9;
+    p = fma(p, r, C.g8);
+    p = fma(p, r, C.g7);
+    p = fma(p, r, C.g6);
+    p = fma(p, r, C.g5);
+    p = fma(p, r, C.g4);
+    p = fma(p, r, C.g3);
+    p = fma(p, r, C.g2);
+    p = fma(p, r, C.g1);
+    p = fma(p, r, C.g0);
+    p = fma(p, r, 2.0);
+    p = fma(p, r, 1.0);
+    const int ni = __double2loint(tt);                      // n: 0 .. 1010
+    return fma(p, __hiloint2double((ni + 1023) << 20, 0), 1.0);     // p 2^n + 1
+}
+
+// 1 / d for d >= 1: the hardware's reciprocal estimate and two Newton steps (relative error ~1e-16; no scaling needed, d is
+// never small, huge d gives 0)
+__device__ __forceinline__ double recip_ge1(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double tanh_1exp(double x, const ExpConsts &C) {
+    const double q = recip_ge1(exp2t_plus1(fmin(fabs(x), C.t_max4), C));
+    return copysign(fma(-2.0, q, 1.0), x);
+}
+
+// four at a time, step by step side by side (four independent chains in flight: the Horner scheme alone is a dependent
+// sequence of twelve), and one reciprocal, of the product of the four denominators (each <= e^175 + 1)
+__device__ __forceinline__ void tanh_4(double &x0, double &x1, double &x2, double &x3, const ExpConsts &C) {
+    double t[4] = {fmin(fabs(x0), C.t_max4), fmin(fabs(x1), C.t_max4), fmin(fabs(x2), C.t_max4), fmin(fabs(x3), C.t_max4)};
+    double tt[4], r[4], p[4], d[4];
+#define MC_EACH for (int c = 0; c < 4; ++c)
+#pragma unroll
+    MC_EACH tt[c] = fma(t[c], C.two_log2e, C.magic);
+#pragma unroll
+    MC_EACH r[c] = fma(tt[c] - C.magic, C.half_ln2_hi, t[c]);
+#pragma unroll
+    MC_EACH r[c] = fma(tt[c] - C.magic, C.half_ln2_lo, r[c]);
+#pragma unroll
+    MC_EACH p[c] = fma(C.g9, r[c], C.g8);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g7);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g6);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g5);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g4);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g3);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g2);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g1);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], C.g0);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], 2.0);
+#pragma unroll
+    MC_EACH p[c] = fma(p[c], r[c], 1.0);
+#pragma unroll
+    MC_EACH d[c] = fma(p[c], __hiloint2double((__double2loint(tt[c]) + 1023) << 20, 0), 1.0);
+#undef MC_EACH
+    const double p01 = d[0] * d[1], p23 = d[2] * d[3];
+    const double rall = recip_ge1(p01 * p23);
+    const double r01 = rall * p23, r23 = rall * p01;        // 1 / (d0 d1), 1 / (d2 d3)
+    x0 = copysign(fma(-2.0, r01 * d[1], 1.0), x0);
+    x1 = copysign(fma(-2.0, r01 * d[0], 1.0), x1);
+    x2 = copysign(fma(-2.0, r23 * d[3], 1.0), x2);
+    x3 = copysign(fma(-2.0, r23 * d[2], 1.0), x3);
+}
+
+// 1 / (1 + e^{-z}) = (1 + tanh(z / 2)) / 2
+__device__ __forceinline__ double logistic(double z, const ExpConsts &C) {
+    const double q = recip_ge1(exp2t_plus1(fmin(0.5 * fabs(z), 350.0), C));   // 1 / (e^{|z|} + 1)
+    return z >= 0.0 ? 1.0 - q : q;
+}
+
+// One lane per record, one hidden unit after the other inside the lane, the weights as SCALAR operands: the records a wave
+// takes belong to one sub-model, so W1[:, j], b1[j], W2[j] are the same for its 64 lanes -- they come through the scalar
+// cache into SGPRs (nine s_load'ed doubles per hidden unit) and the vector pipe issues nothing but the arithmetic:
+// 7 + ~30 + 1 fp64 instructions per hidden unit and record, no LDS reads, no address arithmetic, no butterfly.
+//
+// A workgroup takes a contiguous stretch of the records (the pass's records divided evenly over the workgroups, K2B at a
+// time) and
+//   A. finds the records that are scored at all (skipped records and records whose context leaves the contig are not) and
+//      lists them sub-model by sub-model in LDS, every sub-model's list padded to whole groups of 64; the read quality
+//      (a chain of three dependent loads per record) is fetched here, for all records at once;
+//   B. wave w computes quarter (w & 3) of the hidden units for groups (w >> 2), (w >> 2) + n_waves / 4, ...: the four
+//      SIMDs of the CU carry the same load whatever the number of groups, and a workgroup of 1024 records (~11 groups of
+//      the headline workload) keeps all of them busy.  Partial sums go to LDS;
+//   C. the quarters are added in a fixed order (the result does not depend on which wave ran when) and the logistic
+//      function gives the probability.
+// The earlier version (eight lanes per record, pairs of records per lane group, weights in LDS: 126 LDS reads and ~1200
+// VALU instructions per step of 16 records, 3.1 uneven waves per SIMD) took 53 us for the headline pass.
+constexpr int K2B = 1024;                       // records per workgroup iteration
+#ifndef MC_K2_THREADS
+#define MC_K2_THREADS 1024
+#endif
+constexpr int K2_THREADS = MC_K2_THREADS;
+constexpr int K2_WAVES = K2_THREADS / 64;
+constexpr int K2_SLOTS = K2B + K2_MAXM * 64;    // list entries: every sub-model's part is padded to a multiple of 64
+constexpr int K2_SUB = K2B / 64;                // 64-record pieces of a stretch: the unit of the list's prefix sums
+static_assert(K2_WAVES >= 4 && K2_WAVES % 4 == 0 && K2B % K2_THREADS == 0, "four unit quarters; whole records per thread");
+static_assert(K2_SUB * K2_MAXM <= K2_THREADS && K2_MAXM * 64 <= K2_THREADS, "one thread per (piece, sub-model) / per pad entry");
+
+#ifdef MC_K2_TRACE      // (variant build for tools/k2_trace.py: 100 MHz time stamps of every wave's phases)
+__device__ unsigned long long g_k2_trace[1024 * 16 * 16];
+#define K2_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024) g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + (i)] = wall_clock64(); g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 8 + (i)] = clock64(); } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
+
+
+#define MC_SCALAR_MEM __attribute__((address_space(4)))    // constant address space: uniform loads from it are s_load
+
+// NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
+// unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
+// are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
+template <int NI_T>
+__global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+                                                     const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                     const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                     const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                     double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                     const unsigned int *__restrict__ overflow) {
+    if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
+    if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
+    constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
+    const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
+    __shared__ uint16_t s_list[K2_SLOTS];       // record (offset in the stretch) of every list entry; 0xFFFF: padding
+    __shared__ double s_q[K2B];                 // read quality of the stretch's records
+    __shared__ double s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
+    __shared__ int s_cnt[K2_SUB][K2_MAXM], s_before[K2_SUB][K2_MAXM], s_tot[K2_MAXM], s_gmodel[K2_SLOTS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const ExpConsts C;
+    K2_STAMP(0);
+    // Which quarter of the hidden units a wave takes: the one of the SIMD it runs on, so that the four SIMDs of the CU carry
+    // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  The waves
+    // register before the first barrier of the first stretch.  (If the workgroup's waves did not land on all four SIMDs:
+    // by wave number.)
+    __shared__ uint32_t s_simd_of_wave[K2_WAVES / 4];       // a byte per wave
+    const int simd = (int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3;      // HW_ID[5:4]
+    int quarter = 0, g_first = 0, g_step = 1;
+    bool placed = false;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    K2_STAMP(1);
+    for (int64_t base = lo; base < hi; base += K2B) {
+        // ---- A: the lists
+        // (the read quality is a chain of three dependent loads -- segment, read, quality: it starts with the first load of
+        // the stretch and is only waited for when the lists are done)
+        int mi[K2B / K2_THREADS], rank[K2B / K2_THREADS];
+        double qv[K2B / K2_THREADS];
+#pragma unroll
+        for (int i = 0; i < K2B / K2_THREADS; ++i) {
+            const int off = i * K2_THREADS + tid;
+            const int64_t r = base + off;
+            mi[i] = 255;                            // sub-model of record r (255: not scored here)
+            qv[i] = 0.0;
+            if (r < hi) {
+                if (submodel_in) mi[i] = submodel_in[r];
+                else {
+                    const uint32_t inf = info[r];
+                    const int32_t seg = site_seg[r];
+                    if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) {
+                        mi[i] = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+                        qv[i] = qual[seg_read[seg]];
+                    }
+                }
+            }
+            rank[i] = 0;
+            for (int m = 0; m < NM; ++m) {          // (a key outside the models is the KeyError path, :218: the host decides)
+                const unsigned long long bal = __ballot(mi[i] == m);
+                if (mi[i] == m) rank[i] = __popcll(bal & below);
+                if (lane == 0) s_cnt[off >> 6][m] = __popcll(bal);
+            }
+        }
+        if (!placed && lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
+        K2_STAMP(2);
+        __syncthreads();
+        if (!placed) {
+            uint32_t per_simd = 0;                  // a byte per SIMD: its waves
+            int slot = 0;                           // waves of this wave's SIMD with a smaller number
+            for (int w4 = 0; w4 < K2_WAVES / 4; ++w4) {
+                const uint32_t four = __builtin_amdgcn_readfirstlane(s_simd_of_wave[w4]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int sd = (four >> (8 * b)) & 3;
+                    per_simd += 1u << (8 * sd);
+                    slot += (w4 * 4 + b < wave && sd == simd) ? 1 : 0;
+                }
+            }
+            const bool by_simd = (per_simd & 0xFFu) && (per_simd & 0xFF00u) && (per_simd & 0xFF0000u) && (per_simd & 0xFF000000u);
+            quarter = by_simd ? simd : wave & 3;
+            g_first = by_simd ? slot : wave >> 2;
+            g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : K2_WAVES / 4;
+            placed = true;
+        }
+        if (tid < K2_SUB * K2_MAXM) {               // thread (piece c, sub-model m): the sub-model's records in pieces before c
+            const int c = tid / K2_MAXM, m = tid % K2_MAXM;
+            int all = 0, before = 0;
+            if (m < NM)
+                for (int c2 = 0; c2 < K2_SUB; ++c2) { const int v = s_cnt[c2][m]; all += v; before += c2 < c ? v : 0; }
+            s_before[c][m] = before;
+            if (c == 0) s_tot[m] = all;
+        }
+        __syncthreads();
+        int n_groups = 0;
+        {
+            int start[K2_MAXM];                     // first list entry of every sub-model
+#pragma unroll
+            for (int m = 0; m < K2_MAXM; ++m) { start[m] = n_groups * 64; n_groups += (s_tot[m] + 63) >> 6; }
+#pragma unroll
+            for (int i = 0; i < K2B / K2_THREADS; ++i) {
+                const int off = i * K2_THREADS + tid;
+                if (mi[i] < NM) {
+                    int st = 0;
+#pragma unroll
+                    for (int m = 0; m < K2_MAXM; ++m) st = mi[i] == m ? start[m] : st;
+                    s_list[st + s_before[off >> 6][mi[i]] + rank[i]] = (uint16_t)off;
+                }
+            }
+            if (tid < K2_MAXM * 64) {               // padding of sub-model tid / 64, and the sub-model of its groups
+                const int m = tid >> 6;
+                int st = 0;
+#pragma unroll
+                for (int m2 = 0; m2 < K2_MAXM; ++m2) st = m == m2 ? start[m2] : st;
+                const int tot = s_tot[m], g = (tot + 63) >> 6;
+                if (tot + lane < g * 64) s_list[st + tot + lane] = 0xFFFF;
+                if (lane < g) s_gmodel[(st >> 6) + lane] = m;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K2B / K2_THREADS; ++i) s_q[i * K2_THREADS + tid] = qv[i];
+        __syncthreads();
+        K2_STAMP(3);
+        // ---- B: a quarter of the hidden units for every fourth (eighth ...) group
+        const int u0 = quarter * H / 4, u1 = (quarter + 1) * H / 4;
+        for (int g = g_first; g < n_groups; g += g_step) {
+            const int mdl = __builtin_amdgcn_readfirstlane(s_gmodel[g]);
+            const int e = s_list[g * 64 + lane];
+            const int off = e == 0xFFFF ? s_list[g * 64] : e;       // (padding lanes compute the group's first record again)
+            const int64_t r = base + off;
+            double x[NX];
+            if (submodel_in) {                       // plain batched call: X rows of n_in values
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+            } else {                                 // flush records: k slot means + read quality (:189-193)
+                const double q = s_q[off];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+            }
+            const MC_SCALAR_MEM double *wu = (const MC_SCALAR_MEM double *)M.wu + ((size_t)mdl * H + u0) * S;
+            double z = 0.0;
+            int u = u0;
+            for (; u + 4 <= u1; u += 4, wu += 4 * S) {          // four independent chains: the fp64 tanh is a long dependent sequence
+                double a0 = x[0] * wu[0], a1 = x[0] * wu[S], a2 = x[0] * wu[2 * S], a3 = x[0] * wu[3 * S];
+#pragma unroll
+                for (int i = 1; i < NX; ++i)
+                    if (i < NI) {
+                        a0 = fma(x[i], wu[i], a0);
+                        a1 = fma(x[i], wu[S + i], a1);
+                        a2 = fma(x[i], wu[2 * S + i], a2);
+                        a3 = fma(x[i], wu[3 * S + i], a3);
+                    }
+                a0 += wu[NI]; a1 += wu[S + NI]; a2 += wu[2 * S + NI]; a3 += wu[3 * S + NI];     // (a second scalar operand in the first fma would cost two moves)
+                tanh_4(a0, a1, a2, a3, C);
+                z = fma(a0, wu[NI + 1], z);
+                z = fma(a1, wu[S + NI + 1], z);
+                z = fma(a2, wu[2 * S + NI + 1], z);
+                z = fma(a3, wu[3 * S + NI + 1], z);
+            }
+            for (; u < u1; ++u, wu += S) {
+                double a0 = x[0] * wu[0];
+#pragma unroll
+                for (int i = 1; i < NX; ++i)
+                    if (i < NI) a0 = fma(x[i], wu[i], a0);
+                z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
+            }
+            s_part[quarter][g * 64 + lane] = z;
+        }
+        K2_STAMP(4);
+        __syncthreads();
+        K2_STAMP(5);
+        // ---- C: the output unit
+        for (int t = tid; t < n_groups * 64; t += K2_THREADS) {
+            const int e = s_list[t];
+            if (e == 0xFFFF) continue;
+            const double z = ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t];
+            prob[base + e] = logistic(z + M.b2[s_gmodel[t >> 6]], C);
+        }
+        // (no barrier here: what the next stretch writes before its first barrier -- s_q, s_cnt -- was last read before the
+        // barrier above)
+        K2_STAMP(6);
+#ifdef MC_K2_TRACE
+        if (lane == 0 && blockIdx.x < 1024)
+            g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 7] = (unsigned)simd | (unsigned)quarter << 4 | (unsigned)g_first << 8 | (unsigned)g_step << 16 | (unsigned long long)n_groups << 24;
+#endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: random-forest predict_proba (classifier RF, train_model.py:39-45; call site :199).  One lane per record: inputs cast
+// to float32 (scikit-learn's DTYPE), each tree walked with `x[feature] <= threshold` to a leaf, p1 = v1/(v0+v1) per tree
+// (predict_proba normalises the leaf values), summed over the trees in order and divided by their number.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__restrict__ feats, int k,
+                                                const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                const unsigned int *__restrict__ overflow) {
+    __shared__ double s_x[64][MC_MAX_K + 2];
+    if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
+    if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double *x = s_x[threadIdx.x];
+    const int NI = F.n_in;
+    int mi;
+    if (submodel_in) {
+        mi = submodel_in[r];
+        for (int i = 0; i < NI; ++i) x[i] = (double)(float)feats[r * NI + i];
+    } else {
+        const uint32_t inf = info[r];
+        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
+        mi = F.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+        for (int i = 0; i < k; ++i) x[i] = (double)(float)feats[r * k + i];
+        x[k] = (double)(float)qual[seg_read[site_seg[r]]];
+    }
+    if (mi >= F.n_models) return;
+    const int t0 = F.model_tree_off[mi], t1 = F.model_tree_off[mi + 1];
+    double sum = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        int node = F.tree_node_off[t];
+        int l;
+        while ((l = F.left[node]) >= 0) node = (x[F.feature[node]] <= F.threshold[node]) ? l : F.right[node];
+        const double v0 = F.value[2 * (size_t)node], v1 = F.value[2 * (size_t)node + 1];
+        double norm = (-0.0 + v0) + v1;
+        if (norm == 0.0) norm = 1.0;
+        sum += v1 / norm;
+    }
+    prob[r] = sum / (double)(t1 - t0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3': the closed-form classifiers -- logistic regression (-c LR) and Gaussian naive Bayes (-c NBC), train_model.py:55-60;
+// call site :199.  One lane per record, fp64, the sums in index order (scikit-learn: a BLAS dot / numpy sums over seven
+// terms: agreement to ~1e-16 relative, pinned at 1e-12 against captured predict_proba).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k3_simple(DevSimple S, const double *__restrict__ feats, int k,
+                                                const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                const unsigned int *__restrict__ overflow) {
+    if (overflow && *overflow) return;
+    if (n_dev) n = min(n, (int64_t)*n_dev);
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double x[MC_MAX_K + 1];
+    const int NI = S.n_in;
+    int mi;
+    if (submodel_in) {
+        mi = submodel_in[r];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+    } else {
+        const uint32_t inf = info[r];
+        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
+        mi = S.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) x[i] = i < k ? feats[r * k + i] : 0.0;
+        const double q = qual[seg_read[site_seg[r]]];
+        for (int i = 0; i < MC_MAX_K + 1; ++i) if (i == k) x[i] = q;
+    }
+    if (mi >= S.n_models) return;
+    const double *P = S.params + (size_t)mi * S.stride;
+    if (S.kind == MC_CLF_LOGISTIC) {
+        double d = 0.0;
+        for (int i = 0; i < MC_MAX_K + 1; ++i) if (i < NI) d += x[i] * P[i];
+        d += P[NI];
+        // scipy.special.expit: 1 / (1 + exp(-d)), the large-|d| ends as it writes them
+        prob[r] = d >= 0.0 ? 1.0 / (1.0 + exp(-d)) : exp(d) / (1.0 + exp(d));
+    } else {
+        // GaussianNB._joint_log_likelihood: log prior - 0.5 * sum(log(2 pi var)) - 0.5 * sum((x - theta)^2 / var)
+        double jll[2];
+        for (int cls = 0; cls < 2; ++cls) {
+            const double *theta = P + (size_t)cls * 2 * NI, *var = theta + NI;
+            double a = 0.0, b2 = 0.0;
+            for (int i = 0; i < MC_MAX_K + 1; ++i)
+                if (i < NI) {
+                    a += log(2.0 * 3.14159265358979323846 * var[i]);
+                    const double t = x[i] - theta[i];
+                    b2 += (t * t) / var[i];
+                }
+            jll[cls] = P[4 * (size_t)NI + cls] + (-0.5 * a) - 0.5 * b2;
+        }
+        // exp(jll1 - logsumexp(jll0, jll1))
+        const double mx = fmax(jll[0], jll[1]);
+        const double lse = mx + log(exp(jll[0] - mx) + exp(jll[1] - mx));
+        prob[r] = exp(jll[1] - lse);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Pipelined passes: every pass in flight has its own counters, strand-resolve output and record set; the host reads
+// the counters on the copy stream and then moves exactly n records with the DMA engines while the next pass computes.
+// (A kernel that stores the records straight into pinned host memory reaches the same 54 GB/s, but every kernel of the
+// next pass that ENDS while it runs waits for it: the end-of-kernel cache write-back queues behind its PCIe writes --
+// measured with rocprofv3, see DESIGN.md.  DMA copies do not go through the shader caches.)
+// ---------------------------------------------------------------------------------------------------
+// What a pipelined pass hands to the DMA engine is ONE block: four narrow columns of all n flush records (closing row --
+// 32 bits wide for tables below 2^31 - 1 rows --, site, segment, info) and, behind them, the slot means and the probability
+// of the records that are calls -- compacted: a record with MC_I_TOO_MANY is only counted by the host (:239), nothing reads
+// its means, and at 6 % skips it is every third record.  The row of record j in the compacted part is the number of
+// records before it without MC_I_TOO_MANY: the host derives it where it needs it (mc_calls_view) -- the copy-out was what
+// bounded a pass (PCIe, 55 GB/s), so bytes dropped here were time (16 instead of 24 narrow bytes per record: 12.8 -> 11.2 MB
+// per pass of the headline workload; the slot means as 32-bit integers where they can be, see pack_tail: 8.75 MB, and the
+// kernels of the ctx stream are the bound).  Two small kernels: per-chunk counts of kept records, then every
+// workgroup sums the counts before its chunk and packs the chunk.  The pass's counters go to pinned host memory from here
+// as well (a 96-byte store over PCIe): the host reads them after hipEventSynchronize(ev_done) and enqueues the transfer
+// at once, without a read-back on the copy stream in between.
+// (512 x 512: beside the next pass's scan the two kernels wait for memory most of the time, and twice the lanes have twice the
+// loads in flight -- k_pack 96 -> 46 us there, and the scan it runs beside 106 -> 96 us; pipelined pass with 256 x 256: 0.2013 ms,
+// 448 or 512: 0.193-0.195, 576: 0.203, 640: 0.207, 768: 0.215, 1024: 0.231; 256 x 512, 384 x 384: 0.195-0.197)
+// (PACK_WGS, PACK_THREADS: defined with the emit kernels, which count per packing chunk)
+
+// chunk_cnt[PACK_PAD * b] = kept records of chunk b, chunk_cnt[PACK_PAD * b + 1] = their wide slots
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt, int k,
+                                                             unsigned long long *__restrict__ chunk_cnt) {
+    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
+    const int64_t n = cnt->overflow ? 0 : min((int64_t)cnt->n_records, O.capacity);
+    const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    unsigned int kept = 0, wide = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) {
+        if (O.info[i] & MC_I_TOO_MANY) continue;
+        kept += 1u;
+        const unsigned wm = O.wmask[i];                      // (k1_emit's note; 0xFF: a record of the rare paths, looked at here)
+        if (wm != 0xFFu) wide += (unsigned)__popc(wm);
+        else
+            for (int f = 0; f < k; ++f) {
+                int32_t d;
+                wide += slot_is_narrow(O.feats[i * k + f], &d) ? 0u : 1u;
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_xor(kept, o); wide += __shfl_xor(wide, o); }
+    if ((threadIdx.x & 63) == 0) { s_wave[0][threadIdx.x >> 6] = kept; s_wave[1][threadIdx.x >> 6] = wide; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0, w = 0;
+        for (int j = 0; j < PACK_THREADS / 64; ++j) { t += s_wave[0][j]; w += s_wave[1][j]; }
+        chunk_cnt[PACK_PAD * blockIdx.x] = t;
+        chunk_cnt[PACK_PAD * blockIdx.x + 1] = w;
+    }
+}
+
+__global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
+                                                       const unsigned long long *__restrict__ chunk_cnt,
+                                                       unsigned char *__restrict__ out, int k, int close32,
+                                                       Counters *__restrict__ host_status) {
+    static_assert(PACK_WGS <= PACK_THREADS && PACK_THREADS % 64 == 0, "one chunk count per thread");
+    __shared__ unsigned long long s_sum[4][PACK_THREADS / 64];
+    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
+    __shared__ double s_feats[PACK_THREADS * MC_MAX_K];     // the strip's slot means, loaded with consecutive lanes on consecutive words
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // kept records (and their wide slots) before this chunk, and in all chunks
+    unsigned long long v = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid] : 0ull, before = tid < (int)blockIdx.x ? v : 0ull;
+    unsigned long long w = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid + 1] : 0ull, wbefore = tid < (int)blockIdx.x ? w : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o); before += __shfl_xor(before, o);
+        w += __shfl_xor(w, o); wbefore += __shfl_xor(wbefore, o);
+    }
+    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; s_sum[2][wave] = w; s_sum[3][wave] = wbefore; }
+    __syncthreads();
+    unsigned long long total = 0, base = 0, total_wide = 0, wbase = 0;
+    for (int j = 0; j < PACK_THREADS / 64; ++j) { total += s_sum[0][j]; base += s_sum[1][j]; total_wide += s_sum[2][j]; wbase += s_sum[3][j]; }
+    constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;      // everything the host looks at
+    constexpr int kept_word = (int)(offsetof(Counters, n_kept) / 4);          // (n_kept and n_wide: two words each, set below)
+    static_assert(offsetof(Counters, n_wide) == offsetof(Counters, n_kept) + 8, "n_kept, n_wide side by side");
+    if (blockIdx.x == 0) {
+        if (tid < (int)head_words && (tid < kept_word || tid >= kept_word + 4))
+            reinterpret_cast<volatile unsigned int *>(host_status)[tid] = reinterpret_cast<const unsigned int *>(cnt)[tid];
+        if (tid == 0) {
+            *reinterpret_cast<volatile unsigned long long *>(&host_status->n_kept) = total;
+            *reinterpret_cast<volatile unsigned long long *>(&host_status->n_wide) = total_wide;
+        }
+    }
+    if (cnt->overflow) return;                                           // (the host runs such a pass again, synchronously)
+    const int64_t n = min((int64_t)cnt->n_records, O.capacity);
+    const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
+    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    const PackLayout L = pack_layout(n, close32);
+    const PackTail T = pack_tail(L.feats, (size_t)total, k, (size_t)total_wide);
+    int64_t *o_close = reinterpret_cast<int64_t *>(out);
+    int32_t *o_close32 = reinterpret_cast<int32_t *>(out);
+    int32_t *o_pos = reinterpret_cast<int32_t *>(out + L.pos);
+    int32_t *o_seg = reinterpret_cast<int32_t *>(out + L.seg);
+    uint32_t *o_info = reinterpret_cast<uint32_t *>(out + L.info);
+    int32_t *o_lo = reinterpret_cast<int32_t *>(out + T.lo32);
+    double *o_prob = reinterpret_cast<double *>(out + T.prob);
+    uint8_t *o_mask = out + T.wmask;
+    uint32_t *o_hi = reinterpret_cast<uint32_t *>(out + T.hi32);
+    for (int64_t s = lo; s < hi; s += PACK_THREADS) {
+        const int64_t i = s + tid;
+        const bool valid = i < hi;
+        const uint32_t info = valid ? O.info[i] : MC_I_TOO_MANY;
+        const bool keep = !(info & MC_I_TOO_MANY);
+        {
+            const int64_t n_here = min((int64_t)PACK_THREADS, hi - s) * k;
+            for (int64_t j = tid; j < n_here; j += PACK_THREADS) s_feats[j] = O.feats[s * k + j];
+        }
+        __syncthreads();
+        // the record's slot means: 32-bit integers where they are fl(d / 1e4), both halves where they are not
+        int32_t lo32[MC_MAX_K];
+        uint32_t hi32[MC_MAX_K];
+        unsigned int wmask = 0, n_w = 0;
+        if (keep) {
+            const unsigned noted = O.wmask[i];
+            for (int f = 0; f < k; ++f) {
+                const double x = s_feats[tid * k + f];
+                int32_t d = 0;
+                const bool narrow = noted != 0xFFu ? !((noted >> f) & 1u) : slot_is_narrow(x, &d);
+                if (narrow) lo32[f] = noted != 0xFFu ? (int32_t)rint(x * 1e4) : d;
+                else {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+                    lo32[f] = (int32_t)(uint32_t)bits;
+                    hi32[n_w++] = (uint32_t)(bits >> 32);
+                    wmask |= 1u << f;
+                }
+            }
+        }
+        // places: rank among the strip's kept records; wide slots before this record's
+        const unsigned long long kmask = __ballot(keep);
+        unsigned int w_incl = n_w;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int y = __shfl_up(w_incl, o);
+            if (lane >= o) w_incl += y;
+        }
+        if (lane == 63) s_wave[1][wave] = w_incl;
+        if (lane == 0) s_wave[0][wave] = (unsigned int)__popcll(kmask);
+        __syncthreads();
+        unsigned int in_strip = (unsigned int)__popcll(kmask & ((1ull << lane) - 1ull)), strip = 0, w_off = w_incl - n_w, w_strip = 0;
+        for (int j = 0; j < PACK_THREADS / 64; ++j) {
+            if (j < wave) { in_strip += s_wave[0][j]; w_off += s_wave[1][j]; }
+            strip += s_wave[0][j];
+            w_strip += s_wave[1][j];
+        }
+        if (valid) {
+            if (close32) o_close32[i] = (int32_t)O.close_row[i];
+            else o_close[i] = O.close_row[i];
+            o_pos[i] = O.site_pos[i];
+            o_seg[i] = O.site_seg[i];
+            o_info[i] = info;
+            if (keep) {
+                const unsigned long long row = base + in_strip;
+                o_prob[row] = O.prob[i];
+                o_mask[row] = (uint8_t)wmask;
+                for (int f = 0; f < k; ++f) o_lo[row * k + f] = lo32[f];
+                for (unsigned int j = 0; j < n_w; ++j) o_hi[wbase + w_off + j] = hi32[j];
+            }
+        }
+        __syncthreads();
+        base += strip;
+        wbase += w_strip;
+    }
+}
+
+
+}  // namespace
+
+// k2_mlp workgroups: the records are divided evenly over them (the kernel does that with the count on the device); one
+// per CU, fewer for a handful of records
+#ifndef MC_K2_WG_PER_CU
+#define MC_K2_WG_PER_CU 1
+#endif
+
+// the classifier of a context -- MLP (k2_mlp: the 7-input instance for k = 6, the reference's models, or the general one), forest
+// (k3_forest) or one of the closed forms (k3_simple) -- over n records (n_dev: the count is on the device, n is the capacity)
+void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &S, int n_cu, hipStream_t st, const double *feats, int k,
+                          const int32_t *site_seg, const int32_t *seg_read, const double *qual, const uint32_t *info,
+                          const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow) {
+    if (n <= 0) return;
+    if (F.left)                // (one lane per record; with the count on the device a workgroup beyond it ends at once)
+        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, F, feats, k, site_seg, seg_read, qual, info,
+                           submodel_in, n, prob, n_dev, overflow);
+    else if (S.params)
+        hipLaunchKernelGGL(k3_simple, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S, feats, k, site_seg, seg_read, qual, info,
+                           submodel_in, n, prob, n_dev, overflow);
+    else {
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * MC_K2_WG_PER_CU));
+        if (M.n_in == 7)
+            hipLaunchKernelGGL(k2_mlp<7>, dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+                               prob, n_dev, overflow);
+        else
+            hipLaunchKernelGGL(k2_mlp<0>, dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+                               prob, n_dev, overflow);
+    }
+}
+
+void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, k, chunk_cnt);
+}
+
+void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
+                    Counters *host_status, hipStream_t st, hipEvent_t stop) {
+    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status);
+    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status);
+}
+
+#ifdef MC_K2_TRACE
+extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
+    if (n_words > 1024 * 16 * 16) n_words = 1024 * 16 * 16;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
+}
+#endif
