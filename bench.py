@@ -215,6 +215,8 @@ def strong_scaling_leg(inputs_dir, n_gpus, dry=False, rows=None, one_gpu_sha=Non
         return out
     import subprocess
     env = dict(os.environ, MCALLER_KEEP_WORKERS='1')
+    env.setdefault('MCALLER_COMM_TIMEOUT', '60')        # (a communicator that does not come up: the parent sums on the host after this)
+    env.setdefault('MCALLER_WORKER_TIMEOUT', '300')
     if one_device:
         env['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * n_gpus)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', inputs_dir, '--runs', str(runs),

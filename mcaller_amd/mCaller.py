@@ -76,13 +76,15 @@ class Run(object):
         if self.training_tsv:                               # mCaller.py:35-36: the matrix comes from an earlier run
             from .load_mCaller_data import tsv2matrix
             return tsv2matrix(self.training_tsv, self.base)
-        if not self.train and (self.n_gpus > 1 or self.bed):     # reads shard over the GPUs of the node (multi_gpu.py)
+        labels = pos2label(self.positions) if self.train else None
+        if (self.n_gpus > 1 and self.train) or (not self.train and (self.n_gpus > 1 or self.bed)):     # reads shard over the GPUs of the node (multi_gpu.py)
             from .multi_gpu import extract_features_sharded
             if self.bed:
                 self.bed = dict(self.bed, path=self.output.split('.')[0] + '.methylation.summary.bed')   # make_bed.py:190
             self.sharded = extract_features_sharded(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh,
                                                     self.qual_thresh, self.modelfile, self.base, self.motif, self.positions,
-                                                    self.n_gpus, bed=self.bed, fastq=getattr(self, 'fastq', None))
+                                                    self.n_gpus, bed=None if self.train else self.bed, fastq=getattr(self, 'fastq', None),
+                                                    train=self.train, pos_label=labels)
             stats_path = os.environ.get('MCALLER_STATS_JSON')
             if stats_path:                                  # what the run measured (per worker: rows, seconds; the reduction)
                 import json
@@ -90,8 +92,10 @@ class Run(object):
                 with open(stats_path, 'w') as fh:
                     json.dump(multi_gpu.last_run, fh)
             if self.sharded:
+                if self.train:
+                    from . import multi_gpu
+                    return multi_gpu.train_dicts
                 return None
-        labels = pos2label(self.positions) if self.train else None
         return extract_features(self.tsv, self.reference, self.read2qual, self.k, self.skip_thresh, self.qual_thresh,
                                 self.modelfile, self.classifier, 0, endline=os.path.getsize(self.tsv), train=self.train,
                                 pos_label=labels, base=self.base, motif=self.motif, positions_list=self.positions)
@@ -113,7 +117,8 @@ class Run(object):
         if not self.bed or self.train or self.training_tsv:
             return
         from . import make_bed
-        if not self.sharded:
+        from . import multi_gpu
+        if not self.sharded or not multi_gpu.bed_written:       # (the sharded run declined, or its reduction did not finish)
             make_bed.summarise_diffs(self.output, self.bed['path'], self.bed['min_depth'], self.bed['mod_threshold'])
         if self.bed.get('vo'):
             # make_bed.py --vo's per-read probability lists (:114-115); the columns before them must be the reduced ones

@@ -118,7 +118,8 @@ def _job(conn, device, job, cache):
             from .read_qual import extract_read_quality
             cache['fastq_key'], cache['read2qual'] = key, extract_read_quality(job['fastq'])
         read2qual = cache['read2qual']
-    modelset = load_model_file(job['modelfile'])
+    train = bool(job.get('train'))
+    modelset = None if train else load_model_file(job['modelfile'])      # (train mode: features only, :131-134)
     dev = get_device()
     rank, k = job['rank'], job['k']
     state = dict(head_sent=False, go_seen=False, index=None, extras=[], t_reduce=0.0)
@@ -159,7 +160,8 @@ def _job(conn, device, job, cache):
             res = ec.stream_features(job['tsv'], job['fasta'], read2qual, k, job['skip_thresh'], job['qual_thresh'], modelset,
                                      None, job['base'], job['motif'], job['positions_list'], byte_range=(job['lo'], job['hi']),
                                      sink=out.write, tail_of_last=tail_of_last, on_head=on_head,
-                                     on_shard=on_shard if job['bed'] else None, mark_all=bool(job['bed']), min_shards=1)
+                                     on_shard=on_shard if job['bed'] else None, mark_all=bool(job['bed']), min_shards=1,
+                                     train=train, pos_label=job.get('pos_label'))
     except _Abort:
         return False
     except ec._Unstreamable as e:
@@ -172,7 +174,7 @@ def _job(conn, device, job, cache):
     clock = getattr(ec.stream_features, 'last_clock', None) or {}
     conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, names=list(res.names), n_rows=res.n_rows,
                    n_obs=res.n_obs, positions=res.positions, n_multi=res.n_multi, n_wskips=res.n_wskips,
-                   n_skipped=res.n_skipped, n_bytes_out=res.n_bytes,
+                   n_skipped=res.n_skipped, n_bytes_out=res.n_bytes, signals=res.signals, contexts=res.contexts,
                    seconds=dict(total=t_done - t_job, setup=t_ready - t_job, stream=t_done - t_ready,
                                 site_counts=state['t_reduce'], reader_threads=clock.get('parse', 0.0),
                                 wait_for_table=clock.get('wait_parser', 0.0), enqueue=clock.get('enqueue', 0.0),
@@ -363,14 +365,18 @@ def _workers_for(devices):
 
 
 last_run = None       # what the last sharded run measured (mCaller.py writes it to $MCALLER_STATS_JSON)
+train_dicts = None    # train mode: the (signals, contexts) the last sharded run collected
+bed_written = False   # the last sharded run wrote the BED from the workers' reduction (else: the caller makes it from the rows)
 
 
 def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelfile, base, motif,
-                             positions_list, n_gpus, bed=None, fastq=None):
-    """Predict mode on n_gpus GPUs.  Returns True when the `.diffs.<k>.tmp0` file has been written and the counter lines
+                             positions_list, n_gpus, bed=None, fastq=None, train=False, pos_label=None):
+    """One file on n_gpus GPUs.  Returns True when the `.diffs.<k>[.train].tmp0` file has been written and the counter lines
     printed; False when the file cannot be cut (a read name in two pieces, an exit path of the reference, an error or a
     missed deadline in a worker): the caller then runs the one-GPU path, which reproduces the reference's behaviour in
-    those cases.  fastq: the workers read the qualities themselves (else `read2qual` is shipped to each)."""
+    those cases.  fastq: the workers read the qualities themselves (else `read2qual` is shipped to each).  train (the reference
+    fans train-mode extraction out over its `-t` processes too, mCaller.py:72-87): the workers return their pieces of the
+    (signals, contexts) dicts, merged here in file order -> `train_dicts`."""
     global last_run
     from . import _lib
     t_start = time.perf_counter()
@@ -380,10 +386,11 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     cuts = _lib.eventalign_read_cuts(tsv_input, n_gpus, lo, hi)
     devices = _devices(n_gpus)
     stem = '.'.join(tsv_input.split('.')[:-1])
-    tsv_output = stem + '.diffs.' + str(k) + '.tmp0'
+    tsv_output = stem + '.diffs.' + str(k) + ('.train' if train else '') + '.tmp0'
     jobs = [dict(tsv=tsv_input, fasta=fasta_input, read2qual=None if fastq else read2qual, fastq=fastq, lo=cuts[r], hi=cuts[r + 1],
                  base=base, motif=motif, positions_list=positions_list, k=k, skip_thresh=skip_thresh, qual_thresh=qual_thresh,
-                 modelfile=modelfile, part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus)
+                 modelfile=modelfile, part='%s.diffs.%d.part%d' % (stem, k, r), bed=bool(bed), rank=r, world=n_gpus, train=bool(train),
+                 pos_label=pos_label if train else None)
             for r in range(n_gpus)]
     W = _workers_for(devices)
     reused = W.files > 0
@@ -411,27 +418,35 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
                 return W.stop()                                  # a read name in two pieces: `last_read` crosses the cut
             seen.update(x['names'])
         t_streamed = time.perf_counter()
-        beds = None
+        beds, reduction_failed = None, None
         if bed:
-            # ---- steps 3-5: one decision for everybody, three times ----
+            # ---- steps 3-5: one decision for everybody, three times.  The rows are done by now: if a step of the reduction does not
+            # finish (a communicator that never comes up, a worker that dies in it) the workers are stopped, the parts are kept, and
+            # the caller makes the BED from the rows -- what make_bed.py does ----
             quick = min(W.timeout, float(os.environ.get('MCALLER_COMM_TIMEOUT', '120')))
-            W.tell([dict(probe=True)] * n_gpus)
-            probes = W.gather(quick)
-            if probes is None:
-                return W.stop()
-            reuse = n_gpus > 1 and all(p.get('have') for p in probes)       # (kept workers whose communicator is still up)
-            init = reuse or (n_gpus > 1 and all(p['can'] for p in probes) and probes[0]['uid'] is not None)
-            W.tell([dict(init=init and not reuse, reuse=reuse, uid=probes[0]['uid'])] * n_gpus)
-            ups = W.gather(quick)
-            if ups is None:
-                return W.stop()
-            W.tell([dict(rccl=init and all(u['up'] for u in ups))] * n_gpus)
-            third = W.gather(quick)
-            if third is None:
-                return W.stop()
-            beds = [x['bed'] for x in third]
+
+            def reduction_steps():
+                W.tell([dict(probe=True)] * n_gpus)
+                probes = W.gather(quick)
+                if probes is None:
+                    return None, 'a worker did not answer the probe'
+                reuse = n_gpus > 1 and all(p.get('have') for p in probes)       # (kept workers whose communicator is still up)
+                init = reuse or (n_gpus > 1 and all(p['can'] for p in probes) and probes[0]['uid'] is not None)
+                W.tell([dict(init=init and not reuse, reuse=reuse, uid=probes[0]['uid'])] * n_gpus)
+                ups = W.gather(quick)
+                if ups is None:
+                    return None, 'the communicator did not come up within %.0f s' % quick
+                W.tell([dict(rccl=init and all(u['up'] for u in ups))] * n_gpus)
+                third = W.gather(quick)
+                if third is None:
+                    return None, 'the all-reduce did not finish within %.0f s' % quick
+                return [x['bed'] for x in third], None
+            beds, reduction_failed = reduction_steps()
         t_reduced = time.perf_counter()
-        W.release()
+        if reduction_failed:
+            W.stop(remove_parts=False)
+        else:
+            W.release()
     except BaseException:
         W.stop()
         raise
@@ -448,10 +463,16 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
                     out.write(block)
             os.remove(job['part'])
     t_joined = time.perf_counter()
-    reduction = None
-    if bed:
+    global bed_written
+    reduction, bed_written = None, False
+    if bed and beds is not None:
         reduction = _write_bed(bed, beds, fasta_input, base, motif, positions_list, k, marking)
         reduction['seconds_steps_3_to_5'] = t_reduced - t_streamed
+        bed_written = True
+    elif bed:
+        sys.stderr.write('mcaller_amd: the per-site reduction did not finish (%s): the BED is made from the rows\n' % reduction_failed)
+        reduction = dict(backend='rows (%s)' % reduction_failed, ms=None, comm_init_ms=None, comm_reused=None, bytes=0, sites=None,
+                         observations=None, loci_written=None, cross_contig_rows=None, seconds_steps_3_to_5=t_reduced - t_streamed)
     positions = np.unique(np.concatenate([x['positions'] for x in results])) if results else np.zeros(0)
     print('thread finished processing...:')
     print('%d observations' % sum(x['n_obs'] for x in results))
@@ -459,6 +480,17 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
     print('%d regions with multiple methylated bases' % sum(x['n_multi'] for x in results))
     print('%d observations with skips included' % sum(x['n_wskips'] for x in results))
     print('%d observations with too many skips' % sum(x['n_skipped'] for x in results))
+    global train_dicts
+    train_dicts = None
+    if train:                                  # the pieces' dicts, in file order (:133-134: one entry per sub-model key, lists per label)
+        signals, contexts = {}, {}
+        for x in results:
+            for merged, piece in ((signals, x['signals'] or {}), (contexts, x['contexts'] or {})):
+                for key, by_label in piece.items():
+                    into = merged.setdefault(key, {})
+                    for label, rows in by_label.items():
+                        into.setdefault(label, []).extend(rows)
+        train_dicts = (signals, contexts)
     last_run = dict(n_gpus=n_gpus, devices=devices, workers_reused=reused, rows=sum(x['n_rows'] for x in results),
                     observations=sum(x['n_obs'] for x in results), text_bytes=hi - lo,
                     seconds=dict(total=time.perf_counter() - t_start, cut_and_start=t_cut - t_start, streamed=t_streamed - t_cut,

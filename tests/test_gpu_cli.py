@@ -375,3 +375,81 @@ def test_workers_are_kept_between_files_and_replaced_when_the_devices_change(tmp
         del os.environ['MCALLER_KEEP_WORKERS']
         os.environ.pop('MCALLER_SHARD_DEVICES', None)
         multi_gpu._stop_kept()
+
+
+def test_cli_bed_when_the_reduction_does_not_finish(tmp_path):
+    """A step of the per-site reduction that does not finish in time (here: a deadline nobody can meet) must not cost the
+    sharded run: the workers are stopped, their rows are kept, the BED is made from the rows -- `.diffs` and BED as ever."""
+    from mcaller_amd import synth, mCaller, make_bed, multi_gpu
+    codes = synth.genome(length=40000, seed=33)
+    table, qual = synth.make_table(200000, seed=7, codes=codes, read_len=(1500, 6000))
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
+    argv = ['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model, '--bed', '--bed_min_depth', '2']
+    bed_path = os.path.join(str(tmp_path), 'syn.methylation.summary.bed')
+    diffs = paths['tsv'][:-4] + '.diffs.6'
+    outs = []
+    for timeout in (None, '0.000001'):
+        for f in (bed_path, diffs):
+            if os.path.exists(f):
+                os.remove(f)
+        os.environ['MCALLER_SHARD_DEVICES'] = '0,0'
+        if timeout:
+            os.environ['MCALLER_COMM_TIMEOUT'] = timeout
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                mCaller.main(argv + ['--gpus', '2'])
+        finally:
+            del os.environ['MCALLER_SHARD_DEVICES']
+            os.environ.pop('MCALLER_COMM_TIMEOUT', None)
+        assert multi_gpu.last_run is not None                       # the sharded path ran both times
+        outs.append((open(diffs, 'rb').read(), open(bed_path).read(), multi_gpu.bed_written, multi_gpu.last_run['site_reduction']['backend']))
+    assert outs[0][2] is True and outs[1][2] is False and outs[1][3].startswith('rows (')
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][1].count('\n') > 5
+    assert not [f for f in os.listdir(str(tmp_path)) if '.part' in f or '.tmp' in f]
+
+
+def test_train_mode_over_two_and_three_workers_equals_one_gpu(tmp_path):
+    """The reference fans train-mode extraction out over its `-t` processes too (mCaller.py:72-87): `extract_features_sharded(...,
+    train=True)` -- every worker streams its byte range with features only, the parent merges the pieces' dicts in file order --
+    returns the dicts and writes the `.train` rows the one-GPU run does."""
+    from mcaller_amd import synth, multi_gpu
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    codes = synth.genome(length=150000, seed=35)
+    table, qual = synth.make_table(500000, seed=12, codes=codes, read_len=(1500, 6000))
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    seq = np.frombuffer(synth.codes_to_str(codes).encode('ascii'), dtype=np.uint8)
+    hit = np.flatnonzero((seq[:-3] == ord('G')) & (seq[1:-2] == ord('A')) & (seq[2:-1] == ord('T')) & (seq[3:] == ord('C')))
+    posfile = str(tmp_path / 'positions.txt')
+    with open(posfile, 'w') as fh:
+        for p in hit:
+            fh.write('ecoli_syn\t%d\t+\t%s\n' % (p + 1, 'm6A' if (p + 1) % 3 == 0 else 'A'))
+            fh.write('ecoli_syn\t%d\t-\t%s\n' % (p + 2, 'm6A' if (p + 2) % 3 == 0 else 'A'))
+    pos_label = H.pos2label(posfile)
+    r2q = extract_read_quality(paths['fastq'])
+    size = os.path.getsize(paths['tsv'])
+    tmp = paths['tsv'][:-4] + '.diffs.6.train.tmp0'
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sig, ctx = ec.extract_features(paths['tsv'], paths['fasta'], r2q, 6, 0, 0.0, None, 'NN', 0, endline=size, train=True,
+                                       pos_label=pos_label, base='A', motif=None, positions_list=posfile)
+    want_rows, want_lines = open(tmp, 'rb').read(), [l for l in buf.getvalue().splitlines() if 'observations' in l or 'regions' in l]
+    assert want_rows.count(b'\n') > 300 and sum(len(v) for v in sig['general'].values()) == want_rows.count(b'\n')
+    for n in (2, 3):
+        os.remove(tmp)
+        os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * n)
+        os.environ['MCALLER_STREAM_SHARDS'] = '3'
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                ok = multi_gpu.extract_features_sharded(paths['tsv'], paths['fasta'], r2q, 6, 0, 0.0, None, 'A', None, posfile, n,
+                                                        fastq=paths['fastq'], train=True, pos_label=pos_label)
+        finally:
+            del os.environ['MCALLER_SHARD_DEVICES']
+            del os.environ['MCALLER_STREAM_SHARDS']
+        assert ok is True
+        assert open(tmp, 'rb').read() == want_rows
+        assert multi_gpu.train_dicts[0] == sig and multi_gpu.train_dicts[1] == ctx
+        assert [l for l in buf.getvalue().splitlines() if 'observations' in l or 'regions' in l] == want_lines

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs every probe under tools/ (and tests/tools/) once, small, against the library at HEAD; one line per tool: ok / FAILED.
+# On the GPU box, through gpurun; the variant builds k2_trace and er_trace must exist (tools/variants.sh k2_trace "MC_K2_TRACE=1"
+# er_trace "MC_ER_TRACE=1").  The log of the round's run: profiles/r04_tools_check.log.
+export TMPDIR=/tmp
+out=gpurun_out/tools_check; mkdir -p $out
+run() { name=$1; shift; if timeout 300 "$@" > $out/$name.log 2>&1; then echo "ok      $name"; else echo "FAILED  $name (exit $?): $(tail -n 1 $out/$name.log | cut -c1-120)"; fi; }
+run file_to_file        python3 tools/file_to_file.py 2e6 --runs 2
+run file_to_file_gpus2  env MCALLER_SHARD_DEVICES=0,0 python3 tools/file_to_file.py 2e6 --runs 2 --gpus 2 --bed
+run f2f_cprofile        python3 tools/f2f_cprofile.py 2e6
+run f2f_profile         tools/f2f_profile.sh 2e6
+run kstats              tools/kstats.sh tools_check/kstats --events 2e7 --steps 6
+run sparse_stats        tools/sparse_stats.sh tools_check/sparse --events 2e7 --steps 6
+run dense_stats         tools/dense_stats.sh tools_check/dense --events 2e7
+run timeline            tools/timeline.sh
+run pipeline_probe      python3 tools/pipeline_probe.py 2e7
+run pipeline_soak       python3 tools/pipeline_soak.py 2e7 40
+run stream_soak         python3 tools/stream_soak.py 1e6 3
+run shard_probe         python3 tools/shard_probe.py
+run parse_threads_probe python3 tools/parse_threads_probe.py
+run pread_probe         python3 tools/pread_probe.py
+run read_probe          python3 tools/read_probe.py
+run dma_probe           python3 tools/dma_probe.py
+run forest_probe        python3 tools/forest_probe.py 2e7
+run variant_probe       python3 tools/variant_probe.py
+run k2_trace            env MCALLER_LIB=mcaller_amd/variants/k2_trace.so python3 tools/k2_trace.py 2e7
+run er_trace            env MCALLER_LIB=mcaller_amd/variants/er_trace.so python3 tools/er_trace.py 2e7
+run fuzz_gpu            python3 tests/tools/fuzz_gpu.py 5 71000000
+run fuzz_tables_dense   python3 tests/tools/fuzz_tables.py 20 72000000 dense
+run fuzz_tables_sparse  python3 tests/tools/fuzz_tables.py 20 72000000 sparse
+run train_probe         python3 tests/tools/train_probe.py
+for m in tools/micro/*.hip; do b=$(basename $m .hip); if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mc_micro_$b $m > $out/micro_$b.log 2>&1 && timeout 120 /tmp/mc_micro_$b >> $out/micro_$b.log 2>&1; then echo "ok      micro/$b"; else echo "FAILED  micro/$b: $(tail -n 1 $out/micro_$b.log | cut -c1-120)"; fi; done

@@ -83,6 +83,8 @@ def main():
         calls = sum(1 for _ in open(out, 'rb'))
         if stats_path:
             stats_all.append(json.load(open(stats_path)) if os.path.exists(stats_path) else None)
+            if stats_all[-1] is None:                      # (the sharded path declined and the one-GPU path ran: the later runs would too)
+                break
         if os.environ.get('MCALLER_RSS'):                      # (what the process's resident memory is made of, run after run)
             st = dict(l.split(':', 1) for l in open('/proc/self/status').read().splitlines() if ':' in l)
             sys.stderr.write('run %d: VmRSS %s RssAnon %s RssFile %s RssShmem %s VmHWM %s\n' % (
@@ -94,7 +96,7 @@ def main():
                 s = stats_all[-1]
                 print('       sharded: %s | workers %s | reduction %s' % (
                     {k: round(v, 3) for k, v in s['seconds'].items()},
-                    [(w['rows'], round(w['seconds']['total'], 3), round(w['seconds']['setup'], 3)) for w in s['workers']],
+                    [(w['rows'], round(w['seconds']['total'], 3), round(w['seconds']['setup'], 3), 'rss %.0f MB' % (w['peak_rss_mb'] or 0)) for w in s['workers']],
                     s['site_reduction'] and {k: s['site_reduction'][k] for k in ('backend', 'ms', 'bytes')}))
     if as_json:
         res = {'seconds_all': times, 'calls': calls, 'tsv_bytes': os.path.getsize(paths['tsv']), 'diffs_bytes': os.path.getsize(out),
