@@ -56,14 +56,17 @@ def _devices(n_gpus):
     return list(range(n_gpus))
 
 
-def _peak_rss_mb():
+def _peak_rss_mb(breakdown=False):
+    """High-water mark of this process's resident memory in MB (breakdown: what it is made of right now -- pinned host memory
+    counts as RssShmem)."""
     try:
-        for line in open('/proc/self/status'):
-            if line.startswith('VmHWM:'):
-                return int(line.split()[1]) / 1024.0
-    except OSError:
-        pass
-    return None
+        st = dict(l.split(':', 1) for l in open('/proc/self/status').read().splitlines() if ':' in l)
+        mb = lambda key: int(st[key].split()[0]) / 1024.0 if key in st else None
+        if breakdown:
+            return {k: mb(k) for k in ('VmHWM', 'VmRSS', 'RssAnon', 'RssFile', 'RssShmem')}
+        return mb('VmHWM')
+    except (OSError, ValueError):
+        return None
 
 
 class _Abort(Exception):
@@ -179,7 +182,7 @@ def _job(conn, device, job, cache):
                                 site_counts=state['t_reduce'], reader_threads=clock.get('parse', 0.0),
                                 wait_for_table=clock.get('wait_parser', 0.0), enqueue=clock.get('enqueue', 0.0),
                                 hand_out=clock.get('hand_out', 0.0)),
-                   shards=clock.get('shards', 0), text_bytes=job['hi'] - job['lo'], peak_rss_mb=_peak_rss_mb()))
+                   shards=clock.get('shards', 0), text_bytes=job['hi'] - job['lo'], peak_rss_mb=_peak_rss_mb(), rss_mb=_peak_rss_mb(True)))
     if not state['go_seen'] and conn.recv() is None:     # (a piece without a pass never asked for its tail: the answer is still there)
         return False
     if not job['bed']:
@@ -198,12 +201,13 @@ def _job(conn, device, job, cache):
     # (kept workers keep their communicator: ncclCommInitRank is paid by the first file only)
     keep = bool(os.environ.get('MCALLER_KEEP_WORKERS'))
     have = cache.get('comm') == (job['world'], rank)
-    uid, can = None, True
-    try:
-        from .device import Device
-        uid = Device.comm_unique_id() if rank == 0 else None   # (loads librccl.so; rank 0: ncclGetUniqueId)
-        if rank != 0:
-            Device.comm_probe()
+    uid, can = None, job['world'] > 1      # (one worker: nothing to exchange, and loading librccl.so costs seconds and ~11 GB of
+    try:                                   #  transient host memory while the HIP runtime unpacks its code objects)
+        if can:
+            from .device import Device
+            uid = Device.comm_unique_id() if rank == 0 else None   # (loads librccl.so; rank 0: ncclGetUniqueId)
+            if rank != 0:
+                Device.comm_probe()
     except Exception as e:                                      # noqa
         can, uid = False, None
     conn.send(dict(can=can, uid=uid, have=have))
@@ -497,7 +501,7 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
                                  reduction=t_reduced - t_streamed, parts_joined=t_joined - t_reduced,
                                  bed_written=time.perf_counter() - t_joined),
                     workers=[dict(rank=r, device=devices[r], rows=x['n_rows'], text_bytes=x['text_bytes'], shards=x['shards'],
-                                  bytes_out=x['n_bytes_out'], peak_rss_mb=x['peak_rss_mb'], seconds=x['seconds'])
+                                  bytes_out=x['n_bytes_out'], peak_rss_mb=x['peak_rss_mb'], rss_mb=x.get('rss_mb'), seconds=x['seconds'])
                              for r, x in enumerate(results)],
                     site_reduction=reduction)
     return True

@@ -24,7 +24,7 @@ run dma_probe           python3 tools/dma_probe.py
 run forest_probe        python3 tools/forest_probe.py 2e7
 run variant_probe       python3 tools/variant_probe.py
 run k2_trace            env MCALLER_LIB=mcaller_amd/variants/k2_trace.so python3 tools/k2_trace.py 2e7
-run er_trace            env MCALLER_LIB=mcaller_amd/variants/er_trace.so python3 tools/er_trace.py 2e7
+run er_trace            env MCALLER_LIB=mcaller_amd/variants/er_trace.so python3 tools/er_trace.py 1e8     # (its trace window is workgroups 40000-41023: 10^8 rows)
 run fuzz_gpu            python3 tests/tools/fuzz_gpu.py 5 71000000
 run fuzz_tables_dense   python3 tests/tools/fuzz_tables.py 20 72000000 dense
 run fuzz_tables_sparse  python3 tests/tools/fuzz_tables.py 20 72000000 sparse

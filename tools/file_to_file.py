@@ -96,7 +96,7 @@ def main():
                 s = stats_all[-1]
                 print('       sharded: %s | workers %s | reduction %s' % (
                     {k: round(v, 3) for k, v in s['seconds'].items()},
-                    [(w['rows'], round(w['seconds']['total'], 3), round(w['seconds']['setup'], 3), 'rss %.0f MB' % (w['peak_rss_mb'] or 0)) for w in s['workers']],
+                    [(w['rows'], round(w['seconds']['total'], 3), round(w['seconds']['setup'], 3), 'rss %.0f MB' % (w['peak_rss_mb'] or 0), {k: round(v) for k, v in (w.get('rss_mb') or {}).items() if v is not None}) for w in s['workers']],
                     s['site_reduction'] and {k: s['site_reduction'][k] for k in ('backend', 'ms', 'bytes')}))
     if as_json:
         res = {'seconds_all': times, 'calls': calls, 'tsv_bytes': os.path.getsize(paths['tsv']), 'diffs_bytes': os.path.getsize(out),
