@@ -351,6 +351,7 @@ struct K1Args {
     int32_t *tile_half;           // [n_tiles] ... in its first chunk (the one-base-motif scan: k1_emit_runs' pieces are the scan's chunks)
     const int32_t *tile_local;    // [n_tiles] exclusive scan of tile_cnt inside its group of 1024 tiles
     const int64_t *group_sum;     // [n_groups] windows per group
+    int64_t *tile_first;          // [n_tiles] first record of the tile (k1_list writes it for k1_emit_runs: group prefix + tile_local)
     DevRecords O;                 // records, file order
     Counters *cnt;
     int k, skip_thresh, tail_contig;

@@ -412,53 +412,64 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     __shared__ int s_nblk, s_wheads[E_THREADS / 64], s_wins[E_THREADS / 64];
     const DevTable &T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     constexpr int PIECES = TILE / ET;
     const int64_t tile = blockIdx.x / PIECES;
     static_assert(ET == CHUNK && PIECES == 2, "a piece is a chunk of the scan: its windows are the tile's first tile_half, or the rest");
     const int piece = blockIdx.x % PIECES;
-    const int w_lo = piece ? A.tile_half[tile] : 0, w_hi = piece ? A.tile_cnt[tile] : A.tile_half[tile];
-    if (w_lo >= w_hi) return;
     const int64_t s0 = tile * TILE + (int64_t)piece * ET, s1 = min(s0 + (int64_t)ET, T.n_rows);
     if (s0 >= T.n_rows) return;
-    const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
-    const int64_t first_rec = tile_slot(A.tile_local, A.group_sum, tile, lane);
     const int k = A.k;
     const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
     const int nst = (int)(s1 - h0);
-    // (the tile's payloads are in file order; this thread's first one sets out now and is long there when the run table stands)
     ER_STAMP(0);
-    Payload P0;
-    P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0;
-    if (w_lo + tid < w_hi && first_rec + w_lo + tid < n_rec) P0 = tile_payload(A, tile, w_lo + tid);
     // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
-    // chunk in front of its first one (which row in a run came last before the wave's rows) ----
+    // chunk in front of its first one (which row in a run came last before the wave's rows).  Their addresses need nothing but
+    // the block index, so they set out FIRST and all at once, whatever the piece turns out to hold: a lane beyond the staged rows
+    // reads the last staged row and drops it (a load behind a test is waited for before the next one is sent) ----
     const int c_lo = (wave * E_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * E_CHUNKS + 3) >> 2;
     int32_t rp[E_CPW], rd[E_CPW];
     uint32_t rfl[E_CPW];
+    int2 re[E_CPW];
 #pragma unroll
     for (int c = 0; c < E_CPW; ++c) {
-        const int i = (c_lo + c) * 64 + lane;
-        rp[c] = 0; rd[c] = 0; rfl[c] = MC_F_MODEL_N;
-        if (c_lo + c < c_hi && i < nst) {
-            const int2 e = T.evmu[h0 + i];
-            rp[c] = T.pos[h0 + i];
-            rd[c] = e.x - e.y;
-            rfl[c] = T.flags[h0 + i];
-        }
+        const int64_t j = h0 + min((c_lo + c) * 64 + lane, nst - 1);
+        re[c] = T.evmu[j];
+        rp[c] = T.pos[j];
+        rfl[c] = T.flags[j];
     }
-    int32_t pre_p = 0;
-    uint32_t pre_f = MC_F_MODEL_N;
-    if (c_lo > 0 && (c_lo - 1) * 64 + lane < nst) { pre_p = T.pos[h0 + (c_lo - 1) * 64 + lane]; pre_f = T.flags[h0 + (c_lo - 1) * 64 + lane]; }
-    // ---- the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before
-    // began in (the staged rows begin at most EH rows in front of this tile), all at once ----
+    const int64_t jpre = h0 + min(max((c_lo - 1) * 64 + lane, 0), nst - 1);
+    int32_t pre_p = T.pos[jpre];
+    uint32_t pre_f = T.flags[jpre];
+    // ---- what the piece holds (scalars, one trip), then the name blocks and where this thread's first window lies (one more,
+    // beside the rows).  No test stands between the loads and KEEP_TOGETHER: the compiler moves a load behind a branch that can
+    // leave (one round trip each, then), and splits a descriptor into the part the first test needs and the rest ----
+    const unsigned overflow = A.cnt->overflow;   // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
+    const int t_half = A.tile_half[tile], t_cnt = A.tile_cnt[tile];
+    const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
+    const int64_t first_rec = A.tile_first[tile];
+    const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
+    const int w_lo = piece ? t_half : 0, w_hi = piece ? t_cnt : t_half;
+    const bool live = !overflow && w_lo < w_hi;
+    // (the tile's payloads are in file order, where the scan left them: the first PT in the tile's own slots, the rest in chunks)
+    const int w0 = w_lo + tid;
+    const bool have_p0 = live && w0 < w_hi && first_rec + w0 < n_rec;
+    const int j0 = have_p0 ? w0 : 0, jc0 = max(j0 - PT, 0);
+    long long cb0 = A.tile_chunk[tile * NCHUNK + (jc0 >> A.chunk_shift)];
+    // the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before began in
+    // (the staged rows begin at most EH rows in front of this tile), all at once; the whole descriptor, 64 bytes in four loads (a
+    // lane behind the last block reads the last one and drops it)
+    const int b = bfrom + lane;
     if (wave == 0) {
-        const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
-        const int b = bfrom + lane;
+        const int4 *dq = (const int4 *)(A.desc + min(b, T.n_nb - 1));
+        int4 q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                          "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
         bool over = false, ends_early = false;
         RunBlock rb;
+        NbDesc D;
+        ((int4 *)&D)[0] = q0; ((int4 *)&D)[1] = q1; ((int4 *)&D)[2] = q2; ((int4 *)&D)[3] = q3;
         if (b < T.n_nb) {
-            const NbDesc *dp = A.desc + b;
+            const NbDesc *dp = &D;
             const int64_t rbeg = dp->row_begin, rend = dp->row_end;
             over = rbeg < s1 && rend > h0;
             ends_early = rend < s1 && b + 1 < T.n_nb;          // (the block behind this one begins before the piece ends)
@@ -483,6 +494,22 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
         if (over && at < E_MAXB) s_blk[at] = rb;
         if (lane == 0) s_nblk = more_behind ? E_MAXB + 1 : n;
     }
+    asm volatile("" : "+v"(re[0].x), "+v"(re[0].y), "+v"(rp[0]), "+v"(rfl[0]), "+v"(re[1].x), "+v"(re[1].y), "+v"(rp[1]), "+v"(rfl[1]),
+                      "+v"(re[2].x), "+v"(re[2].y), "+v"(rp[2]), "+v"(rfl[2]), "+v"(re[3].x), "+v"(re[3].y), "+v"(rp[3]), "+v"(rfl[3]),
+                      "+v"(re[4].x), "+v"(re[4].y), "+v"(rp[4]), "+v"(rfl[4]), "+v"(pre_p), "+v"(pre_f), "+v"(cb0));
+    static_assert(E_CPW == 5, "KEEP_TOGETHER lists the rows of five chunks");
+    // this thread's first window sets out now and is long there when the run table stands
+    Payload P0 = A.payload[j0 >= PT ? cb0 + (jc0 & ((1 << A.chunk_shift) - 1)) : tile * PT + j0];
+    if (!live) return;                  // (nothing closes in the piece, or the pass is repeated with more room)
+    if (!have_p0) { P0.r = -1; P0.m = 0; P0.flags = 0; P0.nb = 0; P0.close_row = 0; P0.close_pos = 0; }
+#pragma unroll
+    for (int c = 0; c < E_CPW; ++c) {
+        const bool staged = c_lo + c < c_hi && (c_lo + c) * 64 + lane < nst;
+        rd[c] = staged ? re[c].x - re[c].y : 0;
+        rp[c] = staged ? rp[c] : 0;
+        rfl[c] = staged ? rfl[c] : (uint32_t)MC_F_MODEL_N;
+    }
+    if (!(c_lo > 0 && (c_lo - 1) * 64 + lane < nst)) { pre_p = 0; pre_f = MC_F_MODEL_N; }
     lds_barrier();
     ER_STAMP(1);
     const int nblk = s_nblk;

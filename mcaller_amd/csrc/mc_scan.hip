@@ -899,6 +899,7 @@ __global__ __launch_bounds__(256) void k1_list(K1Args A, Payload *__restrict__ s
     const int c = A.tile_cnt[tile];
     const int64_t first = part + A.tile_local[tile];
     if (tile == T.n_tiles - 1 && l == 0) A.cnt->n_records = (unsigned long long)(first + c);   // the total
+    if (!gather && l == 0) A.tile_first[tile] = first;
     if (c == 0) return;
     if (first + c > A.O.capacity) { if (l == 0) atomicOr(&A.cnt->overflow, 1u); return; }
     if (!gather) {                                  // (a chunk the scan could not get: the pass is repeated with more room)

@@ -176,6 +176,7 @@ struct mc_ctx {
     hipStream_t copy_stream2 = nullptr;     // pipelined passes alternate between the two: no turnaround gap between transfers
     std::vector<void *> lit_allocs;
     int32_t *tile_local = nullptr;
+    int64_t *tile_first = nullptr;
     int64_t *group_sum = nullptr;
     int32_t *tile_cnt = nullptr, *tile_half = nullptr;
     long long *tile_chunk = nullptr;
@@ -655,7 +656,8 @@ static int ensure_scratch(mc_ctx *c, int64_t n_nb, int64_t n_tiles) {
     std::vector<void *> &P = c->scratch_allocs;
     if (dev_alloc(P, &c->desc, (size_t)nb + 1) || dev_alloc(P, &c->nb_f0, (size_t)nb + 1) ||
         dev_alloc(P, &c->tile_chunk, ((size_t)nt + 1) * NCHUNK) || dev_alloc(P, &c->tile_local, (size_t)nt + 1) ||
-        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1) || dev_alloc(P, &c->tile_half, (size_t)nt + 1))
+        dev_alloc(P, &c->group_sum, (size_t)(nt / GROUP + 2)) || dev_alloc(P, &c->tile_cnt, (size_t)nt + 1) || dev_alloc(P, &c->tile_half, (size_t)nt + 1) ||
+        dev_alloc(P, &c->tile_first, (size_t)nt + 1))
         return -10;
     c->scratch_nb = nb;
     c->scratch_tiles = nt;
@@ -1427,7 +1429,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt; A.tile_half = c->tile_half;
-    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.O = O; A.cnt = cnt; A.k = prm->k;
+    A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.tile_first = c->tile_first; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
     const bool dense = dense_reference(c);
