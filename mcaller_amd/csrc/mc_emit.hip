@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #define MC_ET 1024
 #endif
 #ifndef MC_ER_WAVES
-#define MC_ER_WAVES 6
+#define MC_ER_WAVES 7
 #endif
 constexpr int ET = MC_ET;           // rows per piece
 #ifndef MC_EH
@@ -385,11 +385,12 @@ __device__ unsigned long long g_er_trace[1024 * 8];
 #endif
 
 struct RunBlock {                   // a name block that overlaps the staged rows (staged indices), and what its windows need of it
-    int end, lb, id, contig;        // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
-    int contig_len, stray_q;
+    int16_t end, lb;                // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
+    int id, contig, contig_len, stray_q;
     uint32_t xflags;
     int64_t mask_off;
 };
+static_assert(sizeof(RunBlock) == 32, "RunBlock layout");
 
 // (the barriers of k1_emit_runs order LDS traffic only: __syncthreads() would also wait for every global load in flight -- the
 // rows a wave keeps in registers, what a window needs from the reference -- although nobody shares those)
@@ -402,10 +403,11 @@ static_assert(ER < (1 << 12), "s_rrow keeps RUN_* above the row");
 constexpr int E_RF_SHIFT = 12;
 
 __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER_WAVES, MC_ER_WAVES))) void k1_emit_runs(K1Args A, Payload *__restrict__ sorted) {
-    __shared__ uint16_t s_rid[ER];              // run at or before the row
+    __shared__ uint8_t s_rid[ET];               // run at or before the row (the piece's rows: where windows end), counted from ...
+    __shared__ int16_t s_cb[E_CHUNKS];          // ... the last run that begins before the row's chunk of 64 (-1: none)
     __shared__ int32_t s_dc[ER + 8];            // (event - model) of the rows in runs, run after run
     __shared__ double s_mean[ER];
-    __shared__ int32_t s_rpos[ER];
+    __shared__ uint16_t s_rpos[ER];             // the run's position, its low 16 bits: windows look at differences between neighbours (RUN_UNUSABLE: a jump they cannot tell)
     __shared__ uint16_t s_rrow[ER];             // first row of the run (staged index) | RUN_* << 12
     __shared__ uint16_t s_rc0[ER + 2];          // where the run's rows begin in s_dc; one more: where the last run's end
     __shared__ RunBlock s_blk[E_MAXB];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     if (s0 >= T.n_rows) return;
     const int k = A.k;
     const int64_t h0 = max(s0 - (int64_t)EH, (int64_t)0);
-    const int nst = (int)(s1 - h0);
+    const int nst = (int)(s1 - h0), i_piece = (int)(s0 - h0);
     ER_STAMP(0);
     // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
     // chunk in front of its first one (which row in a run came last before the wave's rows).  Their addresses need nothing but
@@ -474,10 +476,10 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
             over = rbeg < s1 && rend > h0;
             ends_early = rend < s1 && b + 1 < T.n_nb;          // (the block behind this one begins before the piece ends)
             if (over) {
-                rb.end = (int)min(rend - h0, (int64_t)nst);
+                rb.end = (int16_t)min(rend - h0, (int64_t)nst);
                 // first row that belongs to a run: the block's first tested row (rows in front of it, and blocks that are not
                 // regular, are in no run)
-                rb.lb = dp->mode == MODE_REGULAR ? (int)max(max(rbeg, dp->first()) - h0, (int64_t)-1) : nst;
+                rb.lb = (int16_t)(dp->mode == MODE_REGULAR ? min(max(max(rbeg, dp->first()) - h0, (int64_t)-1), (int64_t)nst) : (int64_t)nst);
                 rb.id = b;
                 rb.contig = dp->contig;
                 rb.contig_len = dp->contig_len;
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
         // ---- the wave's rows: which are in runs, which begin one (the row before it in its block that is in a run lies at
         // another position, or there is none) ----
         unsigned long long inm[E_CPW], headm[E_CPW];
-        uint32_t cutm = 0;              // bit c: the lane's row of chunk c begins a run whose first rows may lie in front of the staged ones
+        uint32_t cutm = 0;              // bit c: the lane's row of chunk c begins a run that windows cannot use: its first rows may lie in front of the staged ones
         int nh = 0, ni = 0, bj = 0;
 #pragma unroll
         for (int c = 0; c < E_CPW; ++c) {
@@ -577,7 +579,12 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
             int prow = base + pl, ppos = __shfl(rp[c], pl);
             if (!below) { prow = carry_row; ppos = carry_pos; }
             const bool alone = prow < lbm, head = in && (alone || ppos != rp[c]);
+            // (... or that lies too far from the run before it for sixteen bits of position)
+#ifdef MC_ER_NO_JUMP_CHECK      // (variant build: the mutant tests/test_gpu_parity.py::test_one_base_motif_with_jumps_in_the_positions must catch)
             if (head && alone && lb < 0) cutm |= 1u << c;
+#else
+            if (head && (alone ? lb < 0 : (uint32_t)(rp[c] - ppos) >= 30000u)) cutm |= 1u << c;
+#endif
             const unsigned long long hm = __ballot(head);
             inm[c] = m; headm[c] = hm;
             nh += __popcll(hm); ni += __popcll(m);
@@ -603,11 +610,12 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
             if (c_lo + c >= c_hi) continue;
             const int i = (c_lo + c) * 64 + lane;
             const int rid = hbase + __popcll(headm[c] & le) - 1, at = ibase + __popcll(inm[c] & lt);
-            if (i < nst) s_rid[i] = (uint16_t)max(rid, 0);
+            if (i < nst && i >= i_piece) s_rid[i - i_piece] = (uint8_t)__popcll(headm[c] & le);
+            if (lane == 0) s_cb[c_lo + c] = (int16_t)(hbase - 1);
             if ((inm[c] >> lane) & 1ull) s_dc[at] = rd[c];
             if ((headm[c] >> lane) & 1ull) {
                 s_rrow[rid] = (uint16_t)(i | (((cutm >> c) & 1u) ? (RUN_UNUSABLE << E_RF_SHIFT) : 0));
-                s_rpos[rid] = rp[c];
+                s_rpos[rid] = (uint16_t)rp[c];
                 s_rc0[rid] = (uint16_t)at;
             }
             hbase += __popcll(headm[c]); ibase += __popcll(inm[c]);
@@ -682,17 +690,16 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
             const RunBlock &B = s_blk[bj];
             if ((P.flags & PF_STRAY) && m - B.stray_q >= 0 && m - B.stray_q < k) rare = true;     // (the stray event is first in its slot)
             const int lb = B.lb;                           // (< 0: the block's tested rows begin before the staged rows)
-            const int R = s_rid[(int)(P.r - h0)];
+            const int R = max((int)s_cb[(int)(P.r - h0) >> 6] + (int)s_rid[(int)(P.r - s0)], 0);
             for (int t = 0; t < k && !rare; ++t) {
                 const int Rt = R - t;
                 if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
                 const int rr = s_rrow[Rt];
                 if ((rr & ((1 << E_RF_SHIFT) - 1)) < max(lb, 0)) break;           // a run of the block before
-                const int qpos = s_rpos[Rt];
-                if (qpos < m - k + 1) break;
+                const int slot = (int16_t)((uint16_t)m - s_rpos[Rt]);       // m - (the run's position): neighbours lie < 30000 apart
+                if (slot > k - 1) break;
                 const int rf = rr >> E_RF_SHIFT;
                 if (rf & RUN_UNUSABLE) { rare = true; break; }
-                const int slot = m - qpos;
                 if (slot < 0) continue;                    // (the run of the closing row itself, behind the site)
                 A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];         // :187-188 (a window that turns out rare is written again)
                 have |= 1u << slot;

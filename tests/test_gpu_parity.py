@@ -637,6 +637,44 @@ def test_dense_cluster_in_a_sparse_reference(dev):
         assert rec.n > 3000
 
 
+def test_one_base_motif_with_jumps_in_the_positions(dev):
+    """k1_emit_runs keeps the position of a run in sixteen bits and tells the slots of a window from differences between
+    neighbouring runs; a read whose positions jump by 30000 or more between two rows (an alignment across a large deletion) takes
+    the row-by-row path for the windows at the jump -- also when the jump is a multiple of 65536.  Records == oracle."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=1000000, seed=43)
+    ref = synth.SynthRef(codes, motif='A')
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    table, qual = synth.make_table(300000, seed=91, codes=codes, read_len=(600, 2500))
+    rng = np.random.default_rng(17)
+    jumps = [29990, 29999, 30000, 30001, 40000, 65530, 65536, 65538, 70000, 131072, 196608 + 3]
+    n_jumped = 0
+    for s in range(table.n_seg):
+        a, b = int(table.seg_row_begin[s]), int(table.seg_row_begin[s + 1])
+        if b - a < 400:
+            continue
+        for _ in range(4):                       # up to four jumps per read, somewhere inside it
+            at = int(rng.integers(a + 50, b - 50))
+            d = jumps[int(rng.integers(0, len(jumps)))]
+            if int(table.pos[b - 1]) + d < len(codes) - 8 and table.pos[at] != table.pos[at - 1]:
+                table.pos[at:b] += d
+                n_jumped += 1
+    assert n_jumped > 50
+    dev.set_reference(ref.device_arrays())
+    dev.set_mlp(weights, soc)
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    for skip in (0, 2):
+        orc = H.oracle_records(table, ref.device_arrays(), qual, 6, skip, 0.0)
+        H.oracle_score(orc, table, qual, weights, soc, 6)
+        rec = dev.extract(6, skip, 0.0, score=True)
+        H.assert_records_equal(rec, orc, 6)
+        dev.run_async(6, skip, 0.0, score=True)
+        H.assert_records_equal(dev.wait(), orc, 6)
+    assert rec.n > 10000
+
+
 @pytest.mark.parametrize('motif,broken', [('GATC', False), ('GATC', True), ('A', False), ('A', True)])
 def test_first_second_and_later_passes_over_one_table(dev, motif, broken):
     """What a pass does depends on what the passes before it left: the FIRST pass over a table classifies the reads on their
