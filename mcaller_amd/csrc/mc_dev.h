@@ -50,6 +50,7 @@ enum : uint8_t { MODE_NONE = 0, MODE_REGULAR = 1, MODE_IRREGULAR = 2 };
 constexpr uint32_t V_POS_DEC = 1, V_IDX_INC = 2, V_IDX_DEC = 4, V_IDX_EQ = 8, V_POS0 = 16, V_MULTI_SEG = 32;
 
 constexpr int32_t NO_STRAY = INT32_MIN;
+constexpr int32_t NO_SEQ_DELTA = INT32_MIN;
 
 struct __attribute__((aligned(16))) NbDesc {
     int64_t row_begin;
@@ -67,6 +68,9 @@ struct __attribute__((aligned(16))) NbDesc {
     uint32_t vf;        // the validation flags (V_*) the classification rests on: the table's (validated tables), or what the
                         // block's first rows say (first pass: the scan marks the pass if a later row says otherwise).
                         // In the template (k_nb_template): the number of segments of the block
+    int32_t seq_delta;  // byte offset of the contig's sequence less 32 * mask_off (the reference's two layouts run side by side: a few
+                        // bytes per contig), so that the base at a position is one load behind the descriptor, not two (R.seq_off[contig]
+                        // first); NO_SEQ_DELTA: it does not fit, R.seq_off has to be asked
     __host__ __device__ int64_t first() const { return first_delta < 0 ? -1 : row_begin + first_delta; }
     __host__ __device__ int64_t extra_row() const { return (xflags & 2) ? row_begin + first_delta - 1 : -1; }
     __host__ __device__ bool extra_multi() const { return xflags & 1; }
@@ -305,7 +309,10 @@ __device__ __forceinline__ void count_wave_for_packing(unsigned long long *chunk
     if (!chunk_cnt) return;
     const unsigned long long km = __ballot(kept);
     if (!km) return;
-    const uint32_t per = (uint32_t)((n_rec + PACK_WGS - 1) / PACK_WGS);
+    uint32_t per = (uint32_t)((n_rec + PACK_WGS - 1) / PACK_WGS);
+    // (the division is made here, every time: its reciprocal, worked out once in front of the caller's loop, is one more value the
+    // caller's registers do not hold -- it is spilled, and the reload waits for every store of the round)
+    asm volatile("" : "+s"(per));
     const uint32_t bq = kept ? (uint32_t)q / per : 0u;
     const int first = __ffsll((unsigned long long)km) - 1;
     const uint32_t b0 = (uint32_t)__shfl((int)bq, first);

@@ -134,13 +134,22 @@ __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int6
 // waves count -- four: 76 us for ordering + emit, five: 59, six: 55, seven (72 VGPRs, 20 bytes of scratch): 57.  Six lanes per
 // window for k <= 6, ten windows per wave instead of eight: 66 us -- six loads per lane and step instead of four, the lane
 // arithmetic of groups that are not a power of two, and 20 bytes of scratch eat more than the fifth fewer waves give)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
+#ifdef MC_EM_TRACE      // (variant build: 100 MHz time stamps of the first two rounds of the first wave of 1024 workgroups)
+__device__ unsigned long long g_em_trace[1024 * 2 * 8];
+#define EM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && em_round < 2) g_em_trace[(blockIdx.x * 2 + em_round) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define EM_STAMP(i) do { } while (0)
+#endif
+#ifndef MC_EMIT_WAVES
+#define MC_EMIT_WAVES 6             // (80 registers, nothing spilled: a reload from scratch waits for every load in flight)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC_EMIT_WAVES, MC_EMIT_WAVES))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
+    int em_round = 0;
+    EM_STAMP(7);
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);
-    const int s = lane & (EG - 1);
-    const int gsh = lane & ~(EG - 1);                        // first lane of my group
     const int k = A.k;
     // grid-stride over groups of 64/EG windows per wave (the record count is only known on the device)
     // (the payload of the wave's next round is fetched while the current one is worked on)
@@ -151,7 +160,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int64_t q0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / EG;
         if (q0 < n_rec) Pn = sorted[q0];
     }
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; (t - lane) / EG < n_rec; t += stride) {
+    // (tw: the wave's first lane, the same in all lanes -- scalar registers)
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int64_t tw = blockIdx.x * (int64_t)blockDim.x + wave_in_wg * 64; tw / EG < n_rec; tw += stride) {
+    // (what a round can work out again in an instruction is worked out again: kept across the loop these values -- and the
+    // constant of the probability column -- are what the compiler spills, and a reload from scratch waits for every load in flight)
+    int lane_now = lane;
+    uint32_t nan_hi = 0x7ff80000u;
+    asm volatile("" : "+v"(lane_now), "+v"(nan_hi));
+    const int64_t t = tw + lane_now;
+    EM_STAMP(0);
+    const int s = lane_now & (EG - 1);
+    const int gsh = lane_now & ~(EG - 1);                    // first lane of my group
+    const double no_prob = __longlong_as_double((long long)((unsigned long long)nan_hi << 32));
     const int64_t q = t / EG;
     const bool live = q < n_rec;
     const Payload P = Pn;
@@ -163,38 +184,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int64_t r = P.r;
     const int m = P.m;
     const bool window = live && !(P.flags & PF_EXTRA);
+    // ---- everything the payload addresses, in ONE round trip: what every window needs of the name block's descriptor (28 of its
+    // 64 bytes, the eight lanes of a group the same ones), the segment of the block, and the rows before the window's last row -- lane l of the group looks
+    // at rows r-l, r-l-8, r-l-16, r-l-24: four independent loads of the position and of the flag byte, eight consecutive rows
+    // per load instruction and group (the columns have FRONT rows of padding in front: no clamping).  No test between the loads
+    // and the line that keeps them together: a load behind a test is waited for before the next one is sent (a lane without a
+    // window reads what its stand-in payload points at: block 0, row 0) ----
+    const NbDesc *dp = A.desc + P.nb;
+    static_assert(offsetof(NbDesc, row_begin) == 0 && offsetof(NbDesc, mask_off) == 16 && offsetof(NbDesc, first_delta) == 24 && offsetof(NbDesc, contig_len) == 28,
+                  "the descriptor's second 16 bytes: mask_off, first_delta, contig_len");
+    int2 d_rb = *reinterpret_cast<const int2 *>(&dp->row_begin);
+    int4 d_1 = reinterpret_cast<const int4 *>(dp)[1];
+    int32_t d_sdel = dp->seq_delta;
+    int32_t seg_of = T.nb_seg_begin[P.nb];
+    int pj[4];
+    uint32_t fj[4];
+    {
+        const int32_t *pp = T.pos + (r - s);
+        const uint8_t *fp = T.flags + (r - s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pj[e] = pp[-8 * e];
+            fj[e] = fp[-8 * e];
+        }
+    }
+    asm volatile("" : "+v"(d_rb.x), "+v"(d_rb.y), "+v"(d_1.x), "+v"(d_1.y), "+v"(d_1.z), "+v"(d_1.w), "+v"(d_sdel),
+                      "+v"(seg_of), "+v"(pj[0]), "+v"(pj[1]), "+v"(pj[2]), "+v"(pj[3]), "+v"(fj[0]), "+v"(fj[1]), "+v"(fj[2]), "+v"(fj[3]));
+    EM_STAMP(1);
+    const int64_t d_row_begin = ((int64_t)(uint32_t)d_rb.x) | ((int64_t)d_rb.y << 32), d_mask_off = ((int64_t)(uint32_t)d_1.x) | ((int64_t)d_1.y << 32);
+    const int64_t d_first = d_1.z < 0 ? -1 : d_row_begin + d_1.z;         // (NbDesc::first())
+    const int64_t Lc = d_1.w;
     if (live && !window && s == 0) {            // the one-event '+' window of a palindromic first site row (R5)
         for (int s2 = 0; s2 < k; ++s2) A.O.feats[q * k + s2] = 0.0;
         A.O.wmask[q] = 0;
         A.O.site_pos[q] = m;
-        A.O.site_seg[q] = T.nb_seg_begin[P.nb];
+        A.O.site_seg[q] = seg_of;
         A.O.close_row[q] = P.close_row;
-        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (A.desc[P.nb].xflags & 1)) ? MC_I_MULTI : 0u);
-        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+        A.O.info[q] = MC_I_TOO_MANY | ((!(P.flags & PF_CLOSE_NS) && (dp->xflags & 1)) ? MC_I_MULTI : 0u);
+        A.O.prob[q] = no_prob;
     }
-    // ---- which of the rows before the window's last row belong to which slot?  Lane l of the group looks at rows r-l,
-    // r-l-8, r-l-16, r-l-24: four independent loads of the position and of the flag byte, eight consecutive rows per load
-    // instruction and group (the columns have FRONT rows of padding in front: no clamping).  A row is in the window iff it
-    // is unfiltered, not before the block's first tested row, and its k-mer offset m - pos is one of 0..k-1; positions are
-    // non-decreasing in a regular block, so the first unfiltered row with pos < m-k+1 (or the block's start) ends the window.
-    // One window in a hundred is longer than 32 rows: the groups that saw no end look at rows 32..63 in a second step; a
-    // window longer than 64 rows goes to the row-by-row kernel (k1_rare).  (Fewer rows looked at = fewer DRAM lines per
-    // window: the kernel's time is the number of scattered lines it touches.) ----
-    const NbDesc *dp = A.desc + P.nb;
+    // ---- which of those rows belong to which slot?  A row is in the window iff it is unfiltered, not before the block's first
+    // tested row, and its k-mer offset m - pos is one of 0..k-1; positions are non-decreasing in a regular block, so the first
+    // unfiltered row with pos < m-k+1 (or the block's start) ends the window.  One window in a hundred is longer than 32 rows:
+    // the groups that saw no end look at rows 32..63 in a second step; a window longer than 64 rows goes to the row-by-row kernel
+    // (k1_rare).  (Fewer rows looked at = fewer DRAM lines per window: the kernel's time is the number of scattered lines it
+    // touches.) ----
     uint32_t W = 0xFFFFFFFFu;                   // my eight rows' slots, four bits each (15: not in the window)
     bool stop_any = false;
     int back = 0;
     // rows r-l-8e, e = E0 .. E0+3 -> their nibbles of W
-    auto look = [&](const int E0) {
-        const int32_t *pp = T.pos + (r - s);
-        const uint8_t *fp = T.flags + (r - s);
-        int pj[4];
-        uint32_t fj[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pj[e] = pp[-8 * (E0 + e)];
-            fj[e] = fp[-8 * (E0 + e)];
-        }
+    auto sort_rows = [&](const int E0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool inb = 8 * (E0 + e) <= back;          // not before the block's first tested row
@@ -206,37 +245,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
     };
     if (window) {
-        back = (int)min(r - max(dp->row_begin, dp->first()), (int64_t)1 << 20) - s;
-        look(0);
+        back = (int)min(r - max(d_row_begin, d_first), (int64_t)1 << 20) - s;
+        sort_rows(0);
     }
     bool covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
     if (__ballot(window && !covered)) {             // (one round in twelve)
-        if (window && !covered) look(4);
+        if (window && !covered) {
+            const int32_t *pp = T.pos + (r - s);
+            const uint8_t *fp = T.flags + (r - s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pj[e] = pp[-8 * (4 + e)];
+                fj[e] = fp[-8 * (4 + e)];
+            }
+            sort_rows(4);
+        }
         covered = ((__ballot(stop_any) >> gsh) & 0xFFull) != 0ull;
     }
     const bool fast = window && covered;
     if (window && !covered && s == 0) A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
-    // ---- lane 0 of the group: what the info word and the segment column need from the descriptor and the reference.  These
-    // are three dependent loads (descriptor -> sequence offset -> base / mask word); issued here they are in flight beside
-    // the (event, model) loads below instead of behind them ----
-    uint32_t ctx_bits = 0u;               // MC_I_EDGE, or context[k] in its place
-    int32_t seg_of = 0;
-    if (fast && s == 0) {
-        const int64_t L = dp->contig_len;
-        const bool rev0 = P.flags & PF_REV;
-        seg_of = T.nb_seg_begin[P.nb];
-        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
-            ctx_bits = MC_I_EDGE;                // the 2k-1 context leaves the contig: Python slicing decides
-        } else {
-            // context[k], the character after the 'M', picks the sub-model (:197)
-            const uint32_t *bits = (rev0 ? A.R.mr : A.R.mf) + dp->mask_off;
-            const uint8_t *seq = A.R.seq + A.R.seq_off[dp->contig];
-            unsigned char ch;
-            if (!rev0) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-            ctx_bits = ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-        }
-    }
+    EM_STAMP(2);
+    // ---- what the info word needs from the reference: context[k], the character after the 'M', picks the sub-model (:197) --
+    // the mask word and the base at m + 1 (m - 1 on the reverse strand), one load each behind the descriptor; they travel beside
+    // the (event, model) loads below and are looked at when the slot means are done.  All lanes ask (the eight of a group the
+    // same addresses); a context that leaves the contig is Python slicing's business (MC_I_EDGE): its lanes ask for position 0 ----
+    const bool rev0 = P.flags & PF_REV;
+    const bool edge = m - k + 1 < 0 || (int64_t)m + k > Lc || m < 1 || m + 1 >= Lc;
+    const int at = edge ? 0 : (rev0 ? m - 1 : m + 1);
+    uint32_t ctx_word = ((rev0 ? A.R.mr : A.R.mf) + d_mask_off)[at >> 5];
+    // (a reference whose two layouts lie too far apart for the descriptor's 32 bits: the base is fetched at the end, two loads)
+    const bool seq_near = d_sdel != NO_SEQ_DELTA;
+    uint32_t ctx_base = A.R.seq[(seq_near ? 32 * d_mask_off + d_sdel : (int64_t)0) + at];
+    uint32_t info_out = 0u;
+    bool info_ctx = false;
     // ---- my slot's rows: bit j of ms <=> row r-j belongs to slot s.  Every lane fetches the eight slot words of its group and
     // picks the nibbles that equal its slot: bit 4e of Z <=> row r-l-8e is mine ----
     uint32_t lo4 = 0u, hi4 = 0u;                // nibble e: rows of lanes 0..3 / 4..7 at distance 8e
@@ -333,18 +374,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             uint32_t em = empties;
             if (!rev) em = (__brev(empties) >> 24) >> (8 - k);
             info |= em & MC_I_EMPTY_MASK;
-            info |= ctx_bits;
+            info_ctx = true;
         }
         if (P.flags & PF_MULTI) info |= MC_I_MULTI;         // the closing row shifted the window (:242-248)
         A.O.site_pos[q] = m;
         A.O.site_seg[q] = seg_of;
         A.O.close_row[q] = P.close_row;
-        A.O.info[q] = info;
-        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+        A.O.prob[q] = no_prob;
+        info_out = info;
         kept_rec = !too_many;
     }
     }
+    EM_STAMP(3);
+    // (the mask word and the base are waited for HERE, by everybody: a use behind a test, and the compiler moves their loads
+    // behind the test as well -- behind the slot means instead of beside them)
+    asm volatile("" : "+v"(ctx_word), "+v"(ctx_base));
+    EM_STAMP(4);
+    if (fast && s == 0) {
+        if (info_ctx) {
+            if (edge) info_out |= MC_I_EDGE;             // the 2k-1 context leaves the contig: Python slicing decides
+            else {
+                if (!seq_near) ctx_base = A.R.seq[A.R.seq_off[dp->contig] + at];
+                const unsigned char ch = ((ctx_word >> (at & 31)) & 1u) ? 'M' : (rev0 ? comp_char((unsigned char)ctx_base) : (unsigned char)ctx_base);
+                info_out |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+            }
+        }
+        A.O.info[q] = info_out;
+    }
     count_wave_for_packing(A.chunk_cnt, n_rec, kept_rec, q, wide_bit, k);       // (the packing's counts, k_pack)
+    EM_STAMP(5);
+    ++em_round;
     }
 }
 
@@ -888,6 +947,12 @@ void mc_launch_bigfix(const K1Args &A, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(k1_bigfix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, n);
 }
 
+#ifdef MC_EM_TRACE
+extern "C" int mc_debug_em_trace(unsigned long long *out, int64_t n_words) {
+    if (n_words > 1024 * 2 * 8) return -12;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_em_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
+}
+#endif
 #ifdef MC_ER_TRACE
 extern "C" int mc_debug_er_trace(unsigned long long *out, int64_t n_words) {
     if (n_words > 1024 * 8) n_words = 1024 * 8;

@@ -31,6 +31,8 @@ __global__ void k_nb_template(DevTable T, DevRef R) {
     d.filtered = 0;
     d.xflags = 0;
     d.vf = (uint32_t)(T.nb_seg_begin[b + 1] - T.nb_seg_begin[b]);      // segments (contigs) of the block
+    const int64_t sd = R.seq_off[d.contig] - 32 * d.mask_off;
+    d.seq_delta = (sd > (int64_t)INT32_MIN && sd <= (int64_t)INT32_MAX) ? (int32_t)sd : NO_SEQ_DELTA;
     T.nb_tmpl[b] = d;
 }
 

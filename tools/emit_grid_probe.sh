@@ -1,0 +1,4 @@
+for w in 1 2 3 4 5 8; do
+  echo "== EMIT_WGS $w"
+  MCALLER_EMIT_WGS=$w tools/sparse_stats.sh eg$w --events 1e8 2>&1 | grep "k1_emit" | tail -1
+done
