@@ -146,7 +146,7 @@ __device__ unsigned long long g_em_trace[1024 * 2 * 8];
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC_EMIT_WAVES, MC_EMIT_WAVES))) void k1_emit(K1Args A, const Payload *__restrict__ sorted) {
     const DevTable &T = A.T;
     const int lane = threadIdx.x & 63;
-    int em_round = 0;
+    [[maybe_unused]] int em_round = 0;
     EM_STAMP(7);
     if (A.cnt->overflow) return;       // the record buffers were too small: k1_list left payloads unwritten, the pass is repeated
     const int64_t n_rec = min((int64_t)A.cnt->n_records, A.O.capacity);

@@ -37,6 +37,10 @@ for rnd in (0, 1):
 ok = (t[:, 0, 5] > 0) & (t[:, 0, 7] > 0)
 d = (t[ok, 0, 0] - t[ok, 0, 7]) * 10
 print('kernel start -> first round     mean %7.0f ns  p90 %7.0f' % (d.mean(), np.percentile(d, 90)))
+st = (t[ok, 0, 7] - t[ok, 0, 7].min()) / 100.0
+print('workgroup start after the first one (us): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f' % tuple(np.percentile(st, [10, 50, 90, 100])))
+en = (np.maximum(t[ok, 0, 5], t[ok, 1, 5]) - t[ok, 0, 7].min()) / 100.0
+print('end of the second round after the first start (us): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f' % tuple(np.percentile(en, [10, 50, 90, 100])))
 start = t[ok, 0, 7].min()
 last = np.maximum(t[:, 0, 5], t[:, 1, 5]).max()
 print('first stamp -> last stamp of the traced waves: %.1f us' % ((last - start) / 100.0))
