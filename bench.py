@@ -845,7 +845,7 @@ def main():
                        'strong_scaling': 'see the top-level key (BASELINE.json configs[3]: one file, mCaller --gpus N --bed)',
                        'file_to_file': file_to_file, 'file_to_file_1e8': file_to_file_big, 'text_e2e': text_e2e},
             'roofline': {'bound': 'hbm',
-                         'kernel': 'every kernel that touches a table once: k_nb_template + k0_first_site + k1_scan (validating) + '
+                         'kernel': 'every kernel that touches a table once: k0_first_site (makes the name-block templates too) + k1_scan (validating) + '
                                    'k1_group_scan + k1_list + k1_emit',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,

@@ -67,7 +67,7 @@ struct __attribute__((aligned(16))) NbDesc {
     uint8_t mode, rev, filtered, xflags;   // xflags: bit0 extra_multi, bit1 has the '+' window (its row = first - 1)
     uint32_t vf;        // the validation flags (V_*) the classification rests on: the table's (validated tables), or what the
                         // block's first rows say (first pass: the scan marks the pass if a later row says otherwise).
-                        // In the template (k_nb_template): the number of segments of the block
+                        // In the template (nb_template(), mc_k0.hip): the number of segments of the block
     int32_t seq_delta;  // byte offset of the contig's sequence less 32 * mask_off (the reference's two layouts run side by side: a few
                         // bytes per contig), so that the base at a position is one load behind the descriptor, not two (R.seq_off[contig]
                         // first); NO_SEQ_DELTA: it does not fit, R.seq_off has to be asked
@@ -94,7 +94,7 @@ struct DevTable {
     int32_t *nb_read = nullptr;       // [n_nb]
     uint8_t *nb_repeat = nullptr;     // [n_nb] read id seen in an earlier name block
     uint32_t *nb_vflags = nullptr;    // [n_nb]
-    NbDesc *nb_tmpl = nullptr;        // [n_nb] the pass-independent fields of the name-block descriptors (k_nb_template)
+    NbDesc *nb_tmpl = nullptr;        // [n_nb] the pass-independent fields of the name-block descriptors (nb_template(), made by the first k0_first_site over the table)
     int64_t n_tiles = 0;
     int32_t *tile_nb = nullptr;       // [n_tiles] name block of the first row of every tile of the scan
     int has_repeats = 0;
@@ -472,9 +472,8 @@ constexpr int SCAN_SUMMARY = 2;     // a validated table that has unit summaries
 
 // ---- what the kernel units hand to the host side (mc_stream.hip): every kernel with its launch geometry, on stream st; `stop`:
 //      an event that rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL), or nullptr ----
-void mc_launch_nb_template(const DevTable &T, const DevRef &R, hipStream_t st);
 void mc_launch_first_site(const DevTable &T, const DevRef &R, const double *qual, double qual_thresh, int k, NbDesc *desc, int64_t *nb_f0,
-                          Counters *cnt, int classify, int skip_thresh, unsigned long long pass_no, int hyp, hipStream_t st);
+                          Counters *cnt, int classify, int skip_thresh, unsigned long long pass_no, int hyp, int make_tmpl, hipStream_t st);
 void mc_launch_classify(const DevTable &T, const DevRef &R, NbDesc *desc, const int64_t *nb_f0, int entry_read, int k, int skip_thresh,
                         Counters *cnt, unsigned long long pass_no, hipStream_t st);
 void mc_launch_extend(const DevTable &T, NbDesc *desc, const int64_t *nb_f0, int entry_read, Counters *cnt, unsigned long long pass_no,

@@ -1,4 +1,4 @@
-// mc_k0.hip: strand resolve (k_nb_template, k0_first_site, k0_classify, k0_extend) -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers: mc_dev.h; the map of the
+// mc_k0.hip: strand resolve (k0_first_site with the name-block templates, k0_classify, k0_extend) -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers: mc_dev.h; the map of the
 // kernels: mc_stream.hip.
 #include "mc_dev.h"
 
@@ -11,10 +11,9 @@ namespace {
 // (`read_name != last_read`, :161-174) each unfiltered row is tested on the strand `rev = (col3 != col10)`;
 // the first row that holds an 'M' in its k-mer becomes the block's first site row f0.
 // (the fields of a descriptor that do not depend on the pass -- rows, contig, mask offset, read -- are prepared once per
-// table/reference by k_nb_template, so that a pass reads one 64-byte line per block instead of walking five tables)
-__global__ void k_nb_template(DevTable T, DevRef R) {
-    const int b = (int)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
-    if (b >= T.n_nb) return;
+// table/reference by nb_template(), so that a pass reads one 64-byte line per block instead of walking five tables)
+// The pass-independent fields of block b's descriptor (three dependent loads: block -> segment's contig -> the contig's offsets)
+__device__ __forceinline__ NbDesc nb_template(const DevTable &T, const DevRef &R, int b) {
     NbDesc d;
     d.row_begin = T.nb_row_begin[b];
     d.row_end = T.nb_row_begin[b + 1];
@@ -33,7 +32,7 @@ __global__ void k_nb_template(DevTable T, DevRef R) {
     d.vf = (uint32_t)(T.nb_seg_begin[b + 1] - T.nb_seg_begin[b]);      // segments (contigs) of the block
     const int64_t sd = R.seq_off[d.contig] - 32 * d.mask_off;
     d.seq_delta = (sd > (int64_t)INT32_MIN && sd <= (int64_t)INT32_MAX) ? (int32_t)sd : NO_SEQ_DELTA;
-    T.nb_tmpl[b] = d;
+    return d;
 }
 
 // NS stripes of 64 rows from `base`: all loads of the round are issued before any is used.  -> first site row or -1
@@ -167,7 +166,7 @@ __device__ __forceinline__ void classify_block(const DevTable &T, const DevRef &
 template <int W>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable T, DevRef R, const double *__restrict__ qual, double qual_thresh, int k,
                               NbDesc *__restrict__ desc, int64_t *__restrict__ nb_f0, Counters *__restrict__ cnt, int classify,
-                              int skip_thresh, unsigned long long pass_no, int hyp) {
+                              int skip_thresh, unsigned long long pass_no, int hyp, int make_tmpl) {
     static_assert(W == 1 || W == 2 || W == 4, "one wave per block, or a workgroup of two or four");
     __shared__ long long s_f0[4];
     __shared__ int s_rev[4];
@@ -180,7 +179,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable 
     const int b = W == 1 ? (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     if (b >= T.n_nb) return;
-    NbDesc d = T.nb_tmpl[b];
+    // make_tmpl: the table (or the reference) is new -- the block's template is made here and kept for the passes to come: a
+    // launch of its own costs the queue 5 us, here it is two loads in front of the mask words, beside the block's first rows
+    NbDesc d;
+    if (make_tmpl) {
+        d = nb_template(T, R, b);
+        if (lane == 0 && wave == 0) T.nb_tmpl[b] = d;
+    } else d = T.nb_tmpl[b];
     const int n_seg = (int)d.vf;
     // (the quality decides whether the rows are looked at at all, but its load is not waited for before theirs go out: the
     // block's latency is a chain of dependent loads, and this removes one link)
@@ -316,19 +321,15 @@ __global__ void k0_extend(DevTable T, NbDesc *__restrict__ desc, const int64_t *
 
 }  // namespace
 
-void mc_launch_nb_template(const DevTable &T, const DevRef &R, hipStream_t st) {
-    hipLaunchKernelGGL(k_nb_template, dim3((unsigned)((T.n_nb + 255) / 256)), dim3(256), 0, st, T, R);
-}
-
 // (four waves per name block unless the reads are short: see k0_first_site)
 void mc_launch_first_site(const DevTable &T, const DevRef &R, const double *qual, double qual_thresh, int k, NbDesc *desc, int64_t *nb_f0,
-                          Counters *cnt, int classify, int skip_thresh, unsigned long long pass_no, int hyp, hipStream_t st) {
+                          Counters *cnt, int classify, int skip_thresh, unsigned long long pass_no, int hyp, int make_tmpl, hipStream_t st) {
     if (MC_K0_WAVES > 1 && T.n_rows >= (int64_t)T.n_nb * 2048)
         hipLaunchKernelGGL(k0_first_site<MC_K0_WAVES>, dim3((unsigned)T.n_nb), dim3(64 * MC_K0_WAVES), 0, st, T, R, qual, qual_thresh, k,
-                           desc, nb_f0, cnt, classify, skip_thresh, pass_no, hyp);
+                           desc, nb_f0, cnt, classify, skip_thresh, pass_no, hyp, make_tmpl);
     else
         hipLaunchKernelGGL(k0_first_site<1>, dim3((unsigned)(((int64_t)T.n_nb * 64 + 255) / 256)), dim3(256), 0, st, T, R, qual, qual_thresh,
-                           k, desc, nb_f0, cnt, classify, skip_thresh, pass_no, hyp);
+                           k, desc, nb_f0, cnt, classify, skip_thresh, pass_no, hyp, make_tmpl);
 }
 
 void mc_launch_classify(const DevTable &T, const DevRef &R, NbDesc *desc, const int64_t *nb_f0, int entry_read, int k, int skip_thresh,

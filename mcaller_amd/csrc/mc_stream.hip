@@ -9,7 +9,7 @@
 //                                parsed on the device (mc_devparse.inc): line starts, tokens, numbers, name blocks and segments,
 //                                the columns written straight into a table slot
 //   per table     (nothing runs at upload: the first pass over a table validates it while it scans)
-//                k_nb_template   the pass-independent fields of the name-block descriptors
+//                (nb_template     the pass-independent fields of the name-block descriptors: inside the first k0_first_site over a table)
 //                k_summarize     a table that is scanned a second time gets unit summaries (first / last position of every
 //                                eight rows): every further scan reads 1 B/row instead of streaming the columns
 //   per pass     k0_first_site   first site row of every name block under the "new read" strand rule (:161-174) -> strand of
@@ -1128,7 +1128,7 @@ extern "C" int mc_ctx_select_table(mc_ctx *c, int32_t slot, int32_t as_new) {
     // bench.py's steps -- and a caller that mixes pass kinds waits for them first)
     if (as_new) {
         S.passes = 0;
-        S.tmpl_ref = -1;          // (the name-block templates too: k_nb_template is part of what a table costs when it is scanned once)
+        S.tmpl_ref = -1;          // (the name-block templates too: they are part of what a table costs when it is scanned once)
     }
     return 0;
 }
@@ -1176,7 +1176,7 @@ extern "C" int mc_ctx_set_read_quality(mc_ctx *c, const double *qual, int32_t n_
 extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t n_hidden, const double *W1,
                               const double *b1, const double *W2, const double *b2, const uint8_t *sub_of_char) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_pass_streams(c)) return rc;            // (passes in flight score with the old one, on the side stream)
     if (n_in < 1 || n_in > MC_MAX_K + 1 || n_models < 1 || n_hidden < 1) {
         mc_set_error("unsupported MLP shape: %d models, %d inputs, %d hidden", n_models, n_in, n_hidden);
         return -12;
@@ -1219,7 +1219,7 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
                                  const int32_t *feature, const double *threshold, const double *value,
                                  const uint8_t *sub_of_char) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_pass_streams(c)) return rc;            // (passes in flight score with the old one, on the side stream)
     if (n_models < 1 || n_in < 1 || n_in > MC_MAX_K + 1) {
         mc_set_error("unsupported forest shape: %d models, %d inputs", n_models, n_in);
         return -12;
@@ -1254,7 +1254,7 @@ extern "C" int mc_ctx_set_forest(mc_ctx *c, int32_t n_models, int32_t n_in, cons
 extern "C" int mc_ctx_set_simple_classifier(mc_ctx *c, int32_t kind, int32_t n_models, int32_t n_in, const double *params,
                                             int32_t stride, const uint8_t *sub_of_char) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = sync_pass_streams(c)) return rc;            // (passes in flight score with the old one, on the side stream)
     const int want = kind == MC_CLF_LOGISTIC ? n_in + 1 : (kind == MC_CLF_GNB ? 4 * n_in + 2 : -1);
     if (n_models < 1 || n_in < 1 || n_in > MC_MAX_K + 1 || stride != want) {
         mc_set_error("unsupported classifier: kind %d, %d models, %d inputs, %d parameters each", kind, n_models, n_in, stride);
@@ -1410,12 +1410,11 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     const DevTable &T = c->T;
     const int k = prm->k;
     const bool lookback = T.has_repeats || prm->entry_read >= 0;      // a block may see name == last_read (:161)
-    if (c->cur >= 0 && c->slots[c->cur].tmpl_ref != c->ref_version) {      // once per (table, reference)
-        mc_launch_nb_template(T, c->R, st);
-        c->slots[c->cur].tmpl_ref = c->ref_version;
-    }
+    // (the name-block templates: once per (table, reference), made by the first pass's k0_first_site itself)
+    const bool make_tmpl = c->cur >= 0 && c->slots[c->cur].tmpl_ref != c->ref_version;
+    if (c->cur >= 0) c->slots[c->cur].tmpl_ref = c->ref_version;
     mc_launch_first_site(T, c->R, c->qual, prm->qual_thresh, k, K.desc, K.nb_f0, cnt, lookback ? 0 : 1, prm->skip_thresh, pass_no,
-                         plan.first ? 1 : 0, st);
+                         plan.first ? 1 : 0, make_tmpl ? 1 : 0, st);
     if (lookback) mc_launch_classify(T, c->R, K.desc, K.nb_f0, prm->entry_read, k, prm->skip_thresh, cnt, pass_no, st);
     if (extend) mc_launch_extend(T, K.desc, K.nb_f0, prm->entry_read, cnt, pass_no, st);
     return 0;

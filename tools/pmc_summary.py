@@ -26,8 +26,8 @@ def short(name):
     return name.split('<')[0]
 
 
-PER_TABLE_KERNELS = ['k_nb_template', 'k0_first_site', 'k1_scan<64,0>', 'k1_group_scan', 'k1_list', 'k1_emit']     # every kernel that touches a table once
-DENSE_PER_TABLE_KERNELS = ['k_nb_template', 'k0_first_site', 'k1_scan<130,0>', 'k1_group_scan', 'k1_list', 'k1_emit_runs']
+PER_TABLE_KERNELS = ['k0_first_site', 'k1_scan<64,0>', 'k1_group_scan', 'k1_list', 'k1_emit']     # every kernel that touches a table once
+DENSE_PER_TABLE_KERNELS = ['k0_first_site', 'k1_scan<130,0>', 'k1_group_scan', 'k1_list', 'k1_emit_runs']
 
 
 def kernel_source_hash():
