@@ -637,6 +637,34 @@ def test_dense_cluster_in_a_sparse_reference(dev):
         assert rec.n > 3000
 
 
+def test_reference_layouts_far_apart(dev):
+    """The character after the 'M' (it picks the sub-model) is read from the sequence at 32 * (the contig's mask offset) + a
+    32-bit difference the name-block descriptor carries (NbDesc.seq_delta); a caller's reference whose mask words and bases lie
+    further apart than 32 bits hold takes the two dependent loads through seq_off.  Records and probabilities == oracle."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=300000, seed=52)
+    ref = synth.SynthRef(codes, motif='GATC')
+    arrays = dict(ref.device_arrays())
+    shift = (1 << 26) + 5                       # words in front of the contig's masks: 32 * shift > 2^31
+    for name in ('mbits_fwd', 'mbits_rev'):
+        arrays[name] = np.ascontiguousarray(np.concatenate([np.zeros(shift, dtype=arrays[name].dtype), arrays[name]]))
+    arrays['word_off'] = np.array([shift], dtype=np.int64)
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    table, qual = synth.make_table(300000, seed=93, codes=codes, read_len=(800, 5000))
+    dev.set_reference(arrays)
+    dev.set_mlp(weights, soc)
+    dev.upload_table(table)
+    dev.set_read_quality(qual)
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    rec = dev.extract(6, 0, 0.0, score=True)
+    H.assert_records_equal(rec, orc, 6)
+    dev.run_async(6, 0, 0.0, score=True)
+    H.assert_records_equal(dev.wait(), orc, 6)
+    assert rec.n > 300
+
+
 def test_one_base_motif_with_jumps_in_the_positions(dev):
     """k1_emit_runs keeps the position of a run in sixteen bits and tells the slots of a window from differences between
     neighbouring runs; a read whose positions jump by 30000 or more between two rows (an alignment across a large deletion) takes
