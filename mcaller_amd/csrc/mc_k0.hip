@@ -12,16 +12,16 @@ namespace {
 // the first row that holds an 'M' in its k-mer becomes the block's first site row f0.
 // (the fields of a descriptor that do not depend on the pass -- rows, contig, mask offset, read -- are prepared once per
 // table/reference by nb_template(), so that a pass reads one 64-byte line per block instead of walking five tables)
-// The pass-independent fields of block b's descriptor (three dependent loads: block -> segment's contig -> the contig's offsets)
-__device__ __forceinline__ NbDesc nb_template(const DevTable &T, const DevRef &R, int b) {
-    NbDesc d;
+// The pass-independent fields of block b's descriptor, in two steps: what the block's own tables say (rows, read, segments: one
+// load each), then what hangs on its first segment's contig (two more dependent loads) -- the caller sends the block's first
+// rows on their way in between
+__device__ __forceinline__ void nb_template_rows(const DevTable &T, int b, NbDesc &d, int &seg0) {
     d.row_begin = T.nb_row_begin[b];
     d.row_end = T.nb_row_begin[b + 1];
-    d.contig = T.seg_contig[T.nb_seg_begin[b]];
-    d.mask_off = R.word_off[d.contig];
-    d.first_delta = -1;
-    d.contig_len = (int32_t)R.contig_len[d.contig];
     d.read = T.nb_read[b];
+    seg0 = T.nb_seg_begin[b];
+    d.vf = (uint32_t)(T.nb_seg_begin[b + 1] - seg0);       // segments (contigs) of the block
+    d.first_delta = -1;
     d.stray_q = NO_STRAY;
     d.stray_d = 0;
     d.extra_mpos = 0;
@@ -29,10 +29,13 @@ __device__ __forceinline__ NbDesc nb_template(const DevTable &T, const DevRef &R
     d.rev = 0;
     d.filtered = 0;
     d.xflags = 0;
-    d.vf = (uint32_t)(T.nb_seg_begin[b + 1] - T.nb_seg_begin[b]);      // segments (contigs) of the block
+}
+__device__ __forceinline__ void nb_template_contig(const DevTable &T, const DevRef &R, int seg0, NbDesc &d) {
+    d.contig = T.seg_contig[seg0];
+    d.mask_off = R.word_off[d.contig];
+    d.contig_len = (int32_t)R.contig_len[d.contig];
     const int64_t sd = R.seq_off[d.contig] - 32 * d.mask_off;
     d.seq_delta = (sd > (int64_t)INT32_MIN && sd <= (int64_t)INT32_MAX) ? (int32_t)sd : NO_SEQ_DELTA;
-    return d;
 }
 
 // NS stripes of 64 rows from `base`: all loads of the round are issued before any is used.  -> first site row or -1
@@ -182,10 +185,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable 
     // make_tmpl: the table (or the reference) is new -- the block's template is made here and kept for the passes to come: a
     // launch of its own costs the queue 5 us, here it is two loads in front of the mask words, beside the block's first rows
     NbDesc d;
-    if (make_tmpl) {
-        d = nb_template(T, R, b);
-        if (lane == 0 && wave == 0) T.nb_tmpl[b] = d;
-    } else d = T.nb_tmpl[b];
+    int tm_seg0 = 0;
+    if (make_tmpl) nb_template_rows(T, b, d, tm_seg0);
+    else d = T.nb_tmpl[b];
     const int n_seg = (int)d.vf;
     // (the quality decides whether the rows are looked at at all, but its load is not waited for before theirs go out: the
     // block's latency is a chain of dependent loads, and this removes one link)
@@ -199,6 +201,19 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable 
         if (r1 != d.row_begin) vf |= i_second > i_first ? V_IDX_INC : (i_second < i_first ? V_IDX_DEC : V_IDX_EQ);
         if (p_first == 0) vf |= V_POS0;
     } else vf = T.nb_vflags[b];
+    // (the usual block -- one segment, one wave: the first round's rows set out now, in front of the template's two loads)
+#ifndef MC_K0_FS
+#define MC_K0_FS 8
+#endif
+    constexpr int FS = MC_K0_FS;         // stripes of 64 rows per round
+    uint32_t fl[FS], fl_next[FS];
+    int ps[FS], ps_next[FS];
+    const bool rows_out = W == 1 && n_seg == 1 && d.row_begin < d.row_end;
+    if (rows_out) first_site_rows<FS>(T, d.row_begin, d.row_end, lane, fl, ps);
+    if (make_tmpl) {
+        nb_template_contig(T, R, tm_seg0, d);
+        if (lane == 0 && wave == 0) T.nb_tmpl[b] = d;
+    }
     int64_t f0 = -1;
     int f0rev = 0;
     {
@@ -218,11 +233,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k0_first_site(DevTable 
             }
             // A round is two dependent loads (rows, then their mask words); one wave per block: the rows of the round after it are
             // requested together with the mask words, so every further round costs ONE.
-            constexpr int FS = 8;
-            uint32_t fl[FS], fl_next[FS];
-            int ps[FS], ps_next[FS];
             if (W == 1) {
-                if (sb < se) first_site_rows<FS>(T, sb, se, lane, fl, ps);
+                if (sb < se && !rows_out) first_site_rows<FS>(T, sb, se, lane, fl, ps);
                 for (int64_t base = sb; base < se && f0 < 0; base += 64 * FS) {
                     const bool more = base + 64 * FS < se;
                     f0 = first_site_among<FS>(mf, mr, L, base, k, fl, ps, f0rev,
