@@ -151,20 +151,21 @@ def _twin_ready(_):
 
 
 def _twin_job(job):
-    tsv, fasta, lo, hi = job
-    res = _twin['fn'](tsv, fasta, _twin['r2q'], 6, 0, 0.0, _twin['models'], lo, hi, base='A', motif='GATC')
+    tsv, fasta, lo, hi, motif = job
+    res = _twin['fn'](tsv, fasta, _twin['r2q'], 6, 0, 0.0, _twin['models'], lo, hi, base='A', motif=motif)
     return len(res['rows'])
 
 
-def python_twin_baseline(paths, model_npz, n_rows_file):
+def python_twin_baseline(paths, model_npz, n_rows_file, motif='GATC', fraction=1.0):
     import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     size = os.path.getsize(paths['tsv'])
     cores = len(os.sched_getaffinity(0))
     sample = size if cores >= 64 else min(size, cores * (16 << 20))
+    sample = max(1 << 20, int(sample * fraction))       # (a one-base motif: a call every eleven rows, one MLP forward each -- a bounded sample)
     n_jobs = cores
     step = sample // n_jobs
-    jobs = [(paths['tsv'], paths['fasta'], i * step, (i + 1) * step if i + 1 < n_jobs else sample) for i in range(n_jobs)]
+    jobs = [(paths['tsv'], paths['fasta'], i * step, (i + 1) * step if i + 1 < n_jobs else sample, motif) for i in range(n_jobs)]
     ctx = multiprocessing.get_context('spawn')           # never fork a process that holds a HIP context
     # (an executor, not a Pool: a worker that dies in its initializer breaks it with an exception instead of being respawned for ever)
     ex = ProcessPoolExecutor(max_workers=cores, mp_context=ctx, initializer=_twin_init, initargs=(paths['fastq'], model_npz))
@@ -183,9 +184,9 @@ def python_twin_baseline(paths, model_npz, n_rows_file):
     rows = n_rows_file * sample / float(size)
     return {'value': calls / dt, 'unit': 'calls/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
             'events_per_s': rows / dt,
-            'sample': 'pure-Python twin of extract_features (oracle/py_oracle.py: per-row window machine, one MLP forward per '
+            'sample': 'pure-Python twin of extract_features -m %s (oracle/py_oracle.py: per-row window machine, one MLP forward per '
                       'observation), multiprocessing over %d byte ranges of %.0f MB of eventalign text (~%.3g rows), %.2f s'
-                      % (n_jobs, sample / 1e6, rows, dt)}
+                      % (motif, n_jobs, sample / 1e6, rows, dt)}
 
 
 REAL_STDOUT = None
@@ -198,7 +199,7 @@ def print_line(obj):
 
 
 METRIC = 'm6A calls/sec (GATC motif, E. coli-like synthetic eventalign)'
-STRONG_KEYS = ('scaling', 'n_gpus', 'rows', 'tsv_bytes', 'calls', 'calls_per_s', 'events_per_s', 'text_GBps', 'seconds_median',
+STRONG_KEYS = ('scaling', 'n_gpus', 'projected', 'rows', 'tsv_bytes', 'calls', 'calls_per_s', 'events_per_s', 'text_GBps', 'seconds_median',
                'seconds_best', 'seconds_first_run', 'seconds_all', 'site_reduction', 'workers', 'phases_s', 'bed_rows',
                'diffs_equal_the_one_gpu_run', 'peak_rss_mb', 'what')
 
@@ -254,6 +255,96 @@ def strong_scaling_leg(inputs_dir, n_gpus, dry=False, rows=None, one_gpu_sha=Non
     return out
 
 
+def dense_file_to_file_leg(inputs_dir, rows, runs):
+    """`mCaller -m A` (every A of both strands is a site: a call every eleven rows -- the mode BASELINE.md's per-phase profile of the
+    reference is quoted on, extract_contexts.py:186,199,207,216) file to file through the CLI on one GPU, in a process of its own,
+    with the phase split the stream measures of itself."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'file_to_file.py'), '--inputs', inputs_dir, '--runs', str(runs),
+                        '--json', '--motif', 'A'], capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-500:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    secs = res['seconds_all']
+    warm = secs[1:] if len(secs) > 1 else secs
+    med = float(np.median(warm))
+    ph = [p for p in res.get('phases_all', [])[1:] if p] or [p for p in res.get('phases_all', []) if p]
+    phases = {k: float(np.median([p[k] for p in ph])) for k in ('parse', 'wait_parser', 'enqueue', 'hand_out', 'wait_records', 'format', 'write')
+              if ph and all(k in p for p in ph)}
+    bound = None
+    if phases:
+        main = {'formatter (mc_format_diffs: shortest round-trip doubles, rows of text)': phases.get('format', 0.0),
+                'write (the rows appended to the output file)': phases.get('write', 0.0),
+                'GPU + copy-out (records waited for)': phases.get('wait_records', 0.0),
+                'reader + link + device parser (next table waited for)': phases.get('wait_parser', 0.0)}
+        bound = max(main, key=main.get)
+    return {'rows': rows, 'motif': 'A', 'tsv_bytes': res['tsv_bytes'], 'diffs_bytes': res['diffs_bytes'], 'calls': res['calls'],
+            'seconds_first_run': secs[0], 'seconds_median': med, 'seconds_best': min(warm), 'seconds_all': secs,
+            'events_per_s': rows / med, 'calls_per_s': res['calls'] / med, 'text_in_GBps': res['tsv_bytes'] / med / 1e9,
+            'text_out_GBps': res['diffs_bytes'] / med / 1e9, 'peak_rss_mb': res['peak_rss_mb'],
+            'phases_s': phases, 'bound': bound,
+            'phases_what': 'seconds of the MAIN thread per run, median of the warm runs (they add up to the run; the reader threads and '
+                           'the GPU work beside it): wait_parser = the next shard\'s table waited for (read, H2D, device parser), enqueue '
+                           '= upload + passes enqueued, hand_out = wait_records (kernels + copy-out of the oldest pass) + format (native '
+                           'row formatter on all host cores) + write (rows appended to the file)',
+            'what': 'python tools/file_to_file.py --inputs ... --motif A --runs %d --json: the CLI in a process of its own, page cache warm' % runs}
+
+
+def config5_leg(keep_dir, rows):
+    """BASELINE.json configs[4] -- `--train` on labelled positions + the RF classifier, 10^7 rows -- through the CLI on one GPU
+    (tools/config5.py, a process of its own; the inputs stay in keep_dir for the CPU leg)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'config5.py'), str(int(rows)), '--runs', '3', '--json', '--keep', keep_dir],
+                       capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-600:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def config5_cpu_leg(paths):
+    """The CPU leg of config 5: the C oracle's window machine + forest forward over the same 10^7-row table, on one core and
+    sharded by read over all cores (the checker, timed as the baseline -- never part of the product path)."""
+    import contextlib
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import helpers as H
+    from tests import shard
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    r2q = extract_read_quality(paths['fastq'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        P = ec.prepare(paths['tsv'], paths['fasta'], r2q, 0, os.path.getsize(paths['tsv']), 'A', None, paths['positions'])
+    arrays = P.ref.device_arrays()
+    ms = H.load_rf_modelset()
+    _, forests, _, soc = ec.submodel_setup(ms, 'A')
+    t1 = time.perf_counter()
+    orc = H.oracle_records(P.table, arrays, P.qual, 6, 0, 0.0)
+    t2 = time.perf_counter()
+    H.oracle_score(orc, P.table, P.qual, forests, soc, 6)
+    t3 = time.perf_counter()
+    scored = int(np.isfinite(orc.prob[:orc.n]).sum())
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    bounds = [b for b in shard.shard_bounds(P.table, cores) if b[1] > b[0]]
+    subs = [(P.table.slice_segments(lo, hi), shard.tail_contig(P.table, P.qual, 0.0, hi)) for lo, hi in bounds]
+
+    def one(job):
+        st, tail = job
+        o = H.oracle_records(st, arrays, P.qual, 6, 0, 0.0, tail_contig=tail)
+        H.oracle_score(o, st, P.qual, forests, soc, 6)
+        return int(np.isfinite(o.prob[:o.n]).sum())
+    t4 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=len(subs)) as ex:
+        mt = sum(ex.map(one, subs))
+    t5 = time.perf_counter()
+    return {'kind': 'port', 'cpu_model': cpu_model(), 'rows': int(P.table.n_rows), 'scored_records': scored,
+            'one_core': {'window_machine_s': t2 - t1, 'forest_forward_s': t3 - t2, 'forest_ns_per_record': (t3 - t2) * 1e9 / max(scored, 1),
+                         'calls_per_s': scored / (t3 - t1), 'events_per_s': P.table.n_rows / (t3 - t1)},
+            'all_cores': {'threads': len(subs), 'seconds': t5 - t4, 'scored_records': mt, 'calls_per_s': mt / (t5 - t4),
+                          'events_per_s': P.table.n_rows / (t5 - t4)},
+            'sample': 'the parsed 10^7-row table of the config-5 file (columns in host memory): C oracle window machine + forest '
+                      'forward (50 trees), one core %.2f s; sharded by read over %d threads %.2f s' % (t3 - t1, len(subs), t5 - t4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -273,6 +364,10 @@ def main():
                     help='file to file at the headline size, in a process of its own: rows of eventalign text (0: skip)')
     ap.add_argument('--strong-events', type=float, default=1e8,
                     help='strong-scaling leg (one file through mCaller --gpus N --bed): rows of eventalign text (0: skip)')
+    ap.add_argument('--dense-events', type=float, default=1e8,
+                    help='file to file with -m A (dense mode), at the 10^7-row and at this size: rows of eventalign text (0: skip both)')
+    ap.add_argument('--config5-events', type=float, default=1e7,
+                    help='BASELINE.json configs[4] (--train on labelled positions + RF): rows of eventalign text (0: skip)')
     ap.add_argument('--kernels-only', action='store_true', help='skip device end-to-end, file to file and the CPU legs (profiling runs)')
     ap.add_argument('--rescan-only', action='store_true',
                     help='profiling runs: the timed steps re-scan ONE validated table (config.resident_rescan) instead of full passes')
@@ -288,6 +383,7 @@ def main():
         os.dup2(2, 1)
     if args.kernels_only:
         args.stream_shards, args.f2f_events, args.f2f_big_events, args.strong_events, args.no_cpu_baseline = 0, 0, 0, 0, True
+        args.dense_events = args.config5_events = 0
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -659,11 +755,17 @@ def main():
                                     'formatter, .diffs.6 written (page cache warm)'}
         except Exception as e:                                  # noqa
             file_to_file = {'error': '%s: %s' % (type(e).__name__, e)}
+    file_to_file_dense = {}
+    if args.dense_events > 0 and f2f_paths is not None:
+        try:
+            file_to_file_dense['1e7'] = dense_file_to_file_leg(f2f_dir, f2f_rows, 4)
+        except Exception as e:                                  # noqa
+            file_to_file_dense['1e7'] = {'error': '%s: %s' % (type(e).__name__, e)}
 
     # ---- the headline size (10^8 rows, 11.7 GB of text), in processes of their own: file to file on one GPU (wall time per run,
     #      peak RSS), then BASELINE.json configs[3] -- the same file through `mCaller --gpus N --bed` on all N GPUs (strong scaling) ----
     file_to_file_big, strong = None, None
-    big_rows = int(max(args.f2f_big_events, args.strong_events))
+    big_rows = int(max(args.f2f_big_events, args.strong_events, args.dense_events))
     if big_rows > 0:
         big_dir = None
         try:
@@ -697,21 +799,60 @@ def main():
                                                 'the shards in flight'}
                 except Exception as e:                          # noqa
                     file_to_file_big = {'error': '%s: %s' % (type(e).__name__, e)}
+            if args.dense_events > 0:
+                try:
+                    file_to_file_dense['big'] = dense_file_to_file_leg(big_dir, big_rows, 3)
+                except Exception as e:                          # noqa
+                    file_to_file_dense['big'] = {'error': '%s: %s' % (type(e).__name__, e)}
             if args.strong_events > 0:
                 try:
                     strong = strong_scaling_leg(big_dir, world, rows=big_rows, one_gpu_sha=one_gpu_sha,
                                                 one_device=bool(os.environ.get('MCALLER_BENCH_ONE_DEVICE')))
                 except Exception as e:                          # noqa
                     strong = dict(strong_scaling_leg(None, world, dry=True), error='%s: %s' % (type(e).__name__, e))
+                if world == 1:
+                    # a PROJECTION of the curve: one worker, its 1/N piece of the file, 1/N of the host threads, on this GPU
+                    try:
+                        r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'project_scaling.py'), '--inputs', big_dir,
+                                            '--parts', '2,4,8', '--runs', '3', '--json'], capture_output=True, text=True, timeout=900)
+                        if r.returncode != 0:
+                            raise RuntimeError(r.stderr[-500:])
+                        proj = json.loads(r.stdout.strip().splitlines()[-1])
+                        t1 = strong.get('seconds_median') if strong else None
+                        rows_p = [dict(n_gpus=1, seconds=t1, measured=True)]
+                        for w in proj['per_n']:
+                            if 'error' in w:
+                                rows_p.append(dict(n_gpus=w['n_parts'], error=w['error']))
+                                continue
+                            rows_p.append(dict(n_gpus=w['n_parts'], seconds=w['seconds_median'], measured=False, host_threads_per_worker=w['host_threads'],
+                                               worker_text_GBps=w['text_GBps'], rows=w['rows'], speedup_over_one_gpu=(t1 / w['seconds_median']) if t1 else None,
+                                               efficiency=(t1 / w['seconds_median'] / w['n_parts']) if t1 else None,
+                                               main_thread_s={k: w['stream_last_run'].get(k) for k in ('wait_parser', 'enqueue', 'hand_out', 'parse')}))
+                        strong['projected'] = {'label': 'PROJECTION, not a measurement of N GPUs', 'per_n': rows_p, 'what': proj['what'],
+                                               'host_threads_total': proj['per_n'][0].get('host_threads_of') if proj['per_n'] and 'error' not in proj['per_n'][0] else None}
+                    except Exception as e:                      # noqa
+                        strong['projected'] = {'error': '%s: %s' % (type(e).__name__, e)}
         except Exception as e:                                  # noqa
             file_to_file_big = file_to_file_big or {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             if big_dir:
                 shutil.rmtree(big_dir, ignore_errors=True)
 
+    # ---- BASELINE.json configs[4]: --train on labelled positions + the RF classifier, in a process of its own ----
+    config5, config5_dir = None, None
+    if args.config5_events > 0:
+        try:
+            if dev is not None:
+                dev.close()
+                dev = None
+            config5_dir = tempfile.mkdtemp(prefix='mc_config5_')
+            config5 = config5_leg(config5_dir, args.config5_events)
+        except Exception as e:                                  # noqa
+            config5 = {'error': '%s: %s' % (type(e).__name__, e)}
+
     # ---- text end to end: the same file, its text already in pinned host memory, parsed on the GPU shard after shard, a pass
     #      over every shard, records back in host memory (N = 1): what the link allows for eventalign TEXT ----
-    text_e2e = None
+    text_e2e, roofline_parser = None, None
     if file_to_file and 'error' not in file_to_file:
         try:
             from mcaller_amd import _lib
@@ -770,6 +911,35 @@ def main():
                         if device_e2e and 'h2d_only_GBps' in device_e2e else None,
                         'what': 'eventalign text in pinned host memory -> mc_ctx_parse_begin/_end/_finish (line starts, tokens, '
                                 'numbers, segments on the GPU) -> K0-K2 -> records in host memory; three shards of text ahead'}
+            # ---- the device parser alone (roofline_parser): ONE shard's text parsed with nothing else in flight, hipEvents
+            #      around the parser's kernels (mc_ctx_parse_times_ms) ----
+            try:
+                text0 = max(texts, key=lambda t: t.n_bytes)
+                pm, hm, rows0 = [], [], 0
+                for _ in range(6):
+                    slot = d2.parse_begin(text0, ref2.names, rows_cap)
+                    h2d_ms, parse_ms = d2.parse_times_ms(slot)
+                    tab = d2.parse_end(slot, text0)
+                    if tab is None:
+                        raise RuntimeError('the device parser declined the shard')
+                    rows0 = tab.n_rows
+                    d2.parse_abandon(slot)
+                    pm.append(parse_ms)
+                    hm.append(h2d_ms)
+                p_ms, alg = float(np.median(pm[1:])), float(text0.n_bytes + 17.0 * rows0)
+                roofline_parser = {'bound': 'hbm', 'kernel': 'kp_count + kp_scan + kp_starts + kp_parse + kp_count_rows + kp_scan + kp_place (+ the '
+                                   'small copies that hand the result out), one shard of text, nothing else in flight',
+                                   'achieved': alg / (p_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': alg / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                   'algorithmic_bytes': alg, 'algorithmic_bytes_what': 'the shard\'s text read once (%d B) + 17 B/row of columns '
+                                   'written (%d rows)' % (text0.n_bytes, rows0),
+                                   'kernel_ms': p_ms, 'text_h2d_ms': float(np.median(hm[1:])),
+                                   'text_GBps_parser': text0.n_bytes / (p_ms * 1e-3) / 1e9,
+                                   'text_GBps_link': text0.n_bytes / (float(np.median(hm[1:])) * 1e-3) / 1e9,
+                                   'note': 'one PCIe link feeds one GPU: the parser is hidden behind the text\'s transfer as long as '
+                                           'kernel_ms < text_h2d_ms; low priority while that holds (DESIGN.md section 9)'}
+            except Exception as e:                              # noqa
+                roofline_parser = {'error': '%s: %s' % (type(e).__name__, e)}
             del texts
         except Exception as e:                                  # noqa
             text_e2e = {'error': '%s: %s' % (type(e).__name__, e)}
@@ -878,6 +1048,18 @@ def main():
         out['device_e2e_what'] = ('config.device_e2e: parsed columns from pinned host memory, records back in host memory; like-for-like '
                                   'CPU leg: cpu_baseline_all_cores')
         out['strong_scaling'] = strong
+        out['file_to_file_dense'] = file_to_file_dense or None
+        out['file_to_file_dense_what'] = ('`mCaller -m A` file to file through the CLI on one GPU at 10^7 rows ("1e7") and at the headline size '
+                                          '("big"): seconds, phase split of the main thread, which phase bounds the mode')
+        out['config5'] = config5
+        out['roofline_parser'] = roofline_parser
+        if world > 1 and strong and strong.get('calls_per_s'):
+            out['strong_value'] = strong['calls_per_s']
+        out['scaling_note'] = ('`value` is the weak leg: every rank passes over its own resident tables, nothing crosses GPUs inside the timed '
+                               'region, so it grows N-fold by construction.  What BASELINE.json configs[3] asks -- ONE 10^8-row file over N '
+                               'GPUs, per-site reduction included -- is strong_scaling.calls_per_s (top-level strong_value at N > 1); on one '
+                               'GPU strong_scaling.projected carries measured per-worker seconds at 1/2, 1/4, 1/8 of the file and of the '
+                               'host threads')
         if not args.no_cpu_baseline:                         # the CPU legs: on rank 0, at every N
             from tests import helpers as H                   # the checker (oracle/), timed as the CPU baseline
             n_cpu = min(n_rows, int(args.cpu_events))
@@ -921,9 +1103,24 @@ def main():
                     out['cpu_baseline_reference_like'] = python_twin_baseline(f2f_paths, model_npz, f2f_rows)
                 except Exception as e:                          # noqa
                     out['cpu_baseline_reference_like'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                if file_to_file_dense:                           # the dense mode's like-for-like CPU leg, on the same 10^7-row file
+                    try:
+                        file_to_file_dense['cpu_baseline_reference_like'] = python_twin_baseline(f2f_paths, model_npz, f2f_rows, motif='A',
+                                                                                                 fraction=0.25)
+                    except Exception as e:                      # noqa
+                        file_to_file_dense['cpu_baseline_reference_like'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            if config5 and 'error' not in config5 and config5.get('inputs'):
+                try:
+                    config5['cpu_baseline'] = config5_cpu_leg(config5['inputs'])
+                except Exception as e:                          # noqa
+                    config5['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if config5:
+            config5.pop('inputs', None)
         print_line(out)
     if f2f_dir:
         shutil.rmtree(f2f_dir, ignore_errors=True)
+    if config5_dir:
+        shutil.rmtree(config5_dir, ignore_errors=True)
     if reduction_hung:                   # (a thread is stuck inside a collective: no orderly shutdown)
         sys.stdout.flush()
         os._exit(0)

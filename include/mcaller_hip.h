@@ -218,6 +218,11 @@ int mc_ctx_select_table(mc_ctx *ctx, int32_t slot, int32_t as_new);
 /* hipEvent time of the last upload into `slot` (waits for it): the H2D transfers, in ms.  *validate_ms is 0: nothing runs at
  * upload any more (the validation is part of the first pass's scan). */
 int mc_ctx_upload_times_ms(mc_ctx *ctx, int32_t slot, float *h2d_ms, float *validate_ms);
+/* hipEvent times of the last mc_ctx_parse_begin into `slot` (waits for it; call between mc_ctx_parse_begin and
+ * mc_ctx_parse_finish / _abandon): *text_h2d_ms the transfer of the shard's text, *parse_ms the device parser's kernels behind
+ * it (kp_count .. kp_place and the small copies that hand the result out) -- what replaces the reference's `line.split()` loop
+ * (extract_contexts.py:146-152).  Meaningful when nothing else was in flight on the parse stream (bench.py's roofline_parser). */
+int mc_ctx_parse_times_ms(mc_ctx *ctx, int32_t slot, float *text_h2d_ms, float *parse_ms);
 /* MLP weights, row-major float64: W1[n_in*n_hidden], b1[n_hidden], W2[n_hidden], b2[1] per sub-model (at most 8 sub-models:
  * the reference's models have two, 'MG' and 'MH', or one); submodel_of_char[256]: context[k] (ASCII) -> sub-model index,
  * 255 = KeyError path (:197,:218). */

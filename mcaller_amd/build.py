@@ -35,6 +35,15 @@ def build_lib(force=False, verbose=True, out=None, defines=()):
     common = shared_deps()
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (several workers of a sharded run, or pytest-xdist processes, may all find the library stale at the
+    # same moment); objects and the library are written beside their place and renamed into it
+    import fcntl
+    with open(os.path.join(objdir, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(hipcc, srcs, macros, common, objdir, force, verbose)
+
+
+def _build_locked(hipcc, srcs, macros, common, objdir, force, verbose):
     stamp = os.path.join(objdir, 'macros.txt')           # (objects built with other macros are stale)
     if not os.path.exists(stamp) or open(stamp).read() != ' '.join(macros):
         force = True
@@ -44,22 +53,38 @@ def build_lib(force=False, verbose=True, out=None, defines=()):
         objs.append(obj)
         newest = max(os.path.getmtime(d) for d in [src] + common)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            jobs.append([hipcc] + FLAGS + WARN + macros + ['-c', src, '-o', obj])
+            tmp = '%s.tmp.%d' % (obj, os.getpid())
+            jobs.append(([hipcc] + FLAGS + WARN + macros + ['-c', src, '-o', tmp], tmp, obj))
     if not jobs and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(o) for o in objs):
         return OUT
-    running = []
-    for cmd in jobs:                          # the units side by side (a handful of compilers; each is one thread)
-        if verbose:
-            print(' '.join(cmd), file=sys.stderr)
-        running.append((cmd, subprocess.Popen(cmd)))
-    failed = [cmd for cmd, p in running if p.wait() != 0]
+    # the units side by side, at most eight compilers at a time and never more than the host has CPUs (each is one thread, ~1.5 GB)
+    width = max(1, min(len(jobs), len(os.sched_getaffinity(0)), int(os.environ.get('MCALLER_BUILD_JOBS', '8'))))
+    failed, running, todo = [], [], list(jobs)
+    while todo or running:
+        while todo and len(running) < width:
+            cmd, tmp, obj = todo.pop(0)
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            running.append((cmd, tmp, obj, subprocess.Popen(cmd)))
+        cmd, tmp, obj, proc = running.pop(0)
+        rc = proc.wait()
+        if rc != 0:
+            failed.append((rc, cmd))
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        else:
+            os.replace(tmp, obj)
     if failed:
-        raise subprocess.CalledProcessError(1, failed[0])
+        for rc, cmd in failed[1:]:
+            print('build failed (%d): %s' % (rc, ' '.join(cmd)), file=sys.stderr)
+        raise subprocess.CalledProcessError(failed[0][0], failed[0][1])
     open(stamp, 'w').write(' '.join(macros))
-    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', OUT] + objs + ['-ldl']
+    out_tmp = '%s.tmp.%d' % (OUT, os.getpid())
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', out_tmp] + objs + ['-ldl']
     if verbose:
         print(' '.join(link), file=sys.stderr)
     subprocess.check_call(link)
+    os.replace(out_tmp, OUT)
     return OUT
 
 

@@ -353,43 +353,93 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
 // to float32 (scikit-learn's DTYPE), each tree walked with `x[feature] <= threshold` to a leaf, p1 = v1/(v0+v1) per tree
 // (predict_proba normalises the leaf values), summed over the trees in order and divided by their number.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k3_forest(DevForest F, const double *__restrict__ feats, int k,
-                                                const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
-                                                const double *__restrict__ qual, const uint32_t *__restrict__ info,
-                                                const uint8_t *__restrict__ submodel_in, int64_t n,
-                                                double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
-                                                const unsigned int *__restrict__ overflow) {
-    __shared__ double s_x[64][MC_MAX_K + 2];
+// Two shapes, picked by the number of records the pass really has (on the device for pipelined passes):
+//   few records (a shard of a streamed file in positions mode: a few thousand) -- a WAVE per record, a lane per tree: one lane
+//   walking 50 trees one after the other is ~1100 dependent loads, 200 us for 14 000 records however few they are; side by side the
+//   trees of a record are ~22 dependent loads.  The per-tree fractions are then added in tree order by every lane (v_readlane
+//   with the tree as a scalar): the sum is the one the sequential walk gives, bit for bit;
+//   many records (a one-base motif: millions) -- a lane per record as before: the loads in flight are what counts there.
+constexpr int K3_THREADS = 256;
+__global__ __launch_bounds__(K3_THREADS) void k3_forest(DevForest F, const double *__restrict__ feats, int k,
+                                                        const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
+                                                        const double *__restrict__ qual, const uint32_t *__restrict__ info,
+                                                        const uint8_t *__restrict__ submodel_in, int64_t n,
+                                                        double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
+                                                        const unsigned int *__restrict__ overflow) {
+    __shared__ double s_x[K3_THREADS][MC_MAX_K + 2];
     if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    double *x = s_x[threadIdx.x];
     const int NI = F.n_in;
-    int mi;
-    if (submodel_in) {
-        mi = submodel_in[r];
-        for (int i = 0; i < NI; ++i) x[i] = (double)(float)feats[r * NI + i];
-    } else {
-        const uint32_t inf = info[r];
-        if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) return;
-        mi = F.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
-        for (int i = 0; i < k; ++i) x[i] = (double)(float)feats[r * k + i];
-        x[k] = (double)(float)qual[seg_read[site_seg[r]]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (K3_THREADS / 64);
+    if (n <= n_waves * 16) {
+        // ---- a wave per record, a lane per tree ----
+        double *x = s_x[wave * 64];
+        for (int64_t r = (int64_t)blockIdx.x * (K3_THREADS / 64) + wave; r < n; r += n_waves) {
+            int mi;
+            if (submodel_in) {
+                mi = submodel_in[r];
+                if (lane < NI) x[lane] = (double)(float)feats[r * NI + lane];
+            } else {
+                const uint32_t inf = info[r];
+                if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) continue;            // (the same for all lanes)
+                mi = F.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+                if (lane < k) x[lane] = (double)(float)feats[r * k + lane];
+                if (lane == k) x[k] = (double)(float)qual[seg_read[site_seg[r]]];
+            }
+            if (mi >= F.n_models) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (one wave: its LDS operations execute in order)
+            const int t0 = F.model_tree_off[mi], t1 = F.model_tree_off[mi + 1];
+            double sum = 0.0;
+            for (int tb = t0; tb < t1; tb += 64) {
+                const int t = tb + lane;
+                double q = 0.0;
+                if (t < t1) {
+                    int node = F.tree_node_off[t];
+                    int l;
+                    while ((l = F.left[node]) >= 0) node = (x[F.feature[node]] <= F.threshold[node]) ? l : F.right[node];
+                    const double v0 = F.value[2 * (size_t)node], v1 = F.value[2 * (size_t)node + 1];
+                    double norm = (-0.0 + v0) + v1;
+                    if (norm == 0.0) norm = 1.0;
+                    q = v1 / norm;
+                }
+                const int here = min(64, t1 - tb);
+                for (int j = 0; j < here; ++j)                              // in tree order, as the sequential walk adds them
+                    sum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), j), __builtin_amdgcn_readlane(__double2loint(q), j));
+            }
+            if (lane == 0) prob[r] = sum / (double)(t1 - t0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (x is rewritten by the next record)
+        }
+        return;
     }
-    if (mi >= F.n_models) return;
-    const int t0 = F.model_tree_off[mi], t1 = F.model_tree_off[mi + 1];
-    double sum = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        int node = F.tree_node_off[t];
-        int l;
-        while ((l = F.left[node]) >= 0) node = (x[F.feature[node]] <= F.threshold[node]) ? l : F.right[node];
-        const double v0 = F.value[2 * (size_t)node], v1 = F.value[2 * (size_t)node + 1];
-        double norm = (-0.0 + v0) + v1;
-        if (norm == 0.0) norm = 1.0;
-        sum += v1 / norm;
+    // ---- a lane per record ----
+    double *x = s_x[tid];
+    for (int64_t r = (int64_t)blockIdx.x * K3_THREADS + tid; r < n; r += (int64_t)gridDim.x * K3_THREADS) {
+        int mi;
+        if (submodel_in) {
+            mi = submodel_in[r];
+            for (int i = 0; i < NI; ++i) x[i] = (double)(float)feats[r * NI + i];
+        } else {
+            const uint32_t inf = info[r];
+            if (inf & (MC_I_TOO_MANY | MC_I_EDGE)) continue;
+            mi = F.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+            for (int i = 0; i < k; ++i) x[i] = (double)(float)feats[r * k + i];
+            x[k] = (double)(float)qual[seg_read[site_seg[r]]];
+        }
+        if (mi >= F.n_models) continue;
+        const int t0 = F.model_tree_off[mi], t1 = F.model_tree_off[mi + 1];
+        double sum = 0.0;
+        for (int t = t0; t < t1; ++t) {
+            int node = F.tree_node_off[t];
+            int l;
+            while ((l = F.left[node]) >= 0) node = (x[F.feature[node]] <= F.threshold[node]) ? l : F.right[node];
+            const double v0 = F.value[2 * (size_t)node], v1 = F.value[2 * (size_t)node + 1];
+            double norm = (-0.0 + v0) + v1;
+            if (norm == 0.0) norm = 1.0;
+            sum += v1 / norm;
+        }
+        prob[r] = sum / (double)(t1 - t0);
     }
-    prob[r] = sum / (double)(t1 - t0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -630,9 +680,9 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
                           const int32_t *site_seg, const int32_t *seg_read, const double *qual, const uint32_t *info,
                           const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow) {
     if (n <= 0) return;
-    if (F.left)                // (one lane per record; with the count on the device a workgroup beyond it ends at once)
-        hipLaunchKernelGGL(k3_forest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, F, feats, k, site_seg, seg_read, qual, info,
-                           submodel_in, n, prob, n_dev, overflow);
+    if (F.left)                // (a wave per record or a lane per record: the kernel looks at the count, which may be on the device only)
+        hipLaunchKernelGGL(k3_forest, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)n_cu * 8))), dim3(K3_THREADS), 0, st,
+                           F, feats, k, site_seg, seg_read, qual, info, submodel_in, n, prob, n_dev, overflow);
     else if (S.params)
         hipLaunchKernelGGL(k3_simple, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S, feats, k, site_seg, seg_read, qual, info,
                            submodel_in, n, prob, n_dev, overflow);

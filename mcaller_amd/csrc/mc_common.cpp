@@ -44,32 +44,50 @@ static int affinity_cpus(void) {
     return n < 1 ? 1 : n;
 }
 
-static int cgroup_quota_cpus(void) {           // -> CPUs' worth of time the control group grants, 0: unlimited / unknown
-    // cgroup v2: "<quota> <period>" or "max <period>"; the process's own group, or the root the container sees
-    char path[512] = "/sys/fs/cgroup/cpu.max";
+static int quota_of(const char *path) {          // CPUs' worth of time in one cpu.max ("<quota> <period>" | "max <period>"), 0: none
+    long long quota = 0, period = 0;
+    if (FILE *f = fopen(path, "r")) {
+        char q[64] = "";
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)std::max<long long>(1, (quota + period - 1) / period);
+}
+
+static int cgroup_quota_cpus(void) {           // -> CPUs' worth of time the control groups grant, 0: unlimited / unknown
+    // cgroup v2: the process's own group and every ancestor up to the root the container sees (a quota set on a systemd slice
+    // or on a pod applies to everything below it): the smallest one counts
+    int best = 0;
+    auto take = [&](int q) { if (q > 0 && (best == 0 || q < best)) best = q; };
+    char own[512] = "";
     if (FILE *f = fopen("/proc/self/cgroup", "r")) {
         char line[512];
         while (fgets(line, sizeof(line), f))
             if (strncmp(line, "0::", 3) == 0) {
                 char *nl = strchr(line, '\n');
                 if (nl) *nl = 0;
-                char own[512];
-                snprintf(own, sizeof(own), "/sys/fs/cgroup%s/cpu.max", line + 3);
-                if (FILE *g = fopen(own, "r")) { fclose(g); snprintf(path, sizeof(path), "%s", own); }
+                snprintf(own, sizeof(own), "%s", line + 3);
             }
         fclose(f);
     }
-    long long quota = 0, period = 0;
-    if (FILE *f = fopen(path, "r")) {
-        char q[64] = "";
-        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else {                                     // cgroup v1
+    bool v2 = false;
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu.max", "r")) { fclose(g); v2 = true; }
+    for (;;) {                                   // "/a/b/c" -> "/a/b" -> "/a" -> ""
+        char path[1100];
+        snprintf(path, sizeof(path), "/sys/fs/cgroup%s/cpu.max", own);
+        if (FILE *g = fopen(path, "r")) { fclose(g); v2 = true; take(quota_of(path)); }
+        char *slash = strrchr(own, '/');
+        if (!slash) break;
+        *slash = 0;
+    }
+    if (!v2) {                                   // cgroup v1
+        long long quota = 0, period = 0;
         if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = 0; fclose(g); }
         if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0) take((int)std::max<long long>(1, (quota + period - 1) / period));
     }
-    if (quota <= 0 || period <= 0) return 0;
-    return (int)std::max<long long>(1, (quota + period - 1) / period);
+    return best;
 }
 
 extern "C" int mc_host_cores(void) {
@@ -249,7 +267,8 @@ struct Workers {
     std::mutex mu;                          // guards jobs, n_threads; the condition variables
     std::condition_variable wake, done;
     std::vector<Job *> jobs;                // jobs that may still have tasks to hand out
-    std::vector<int> cpus;                  // the CPUs of the process's affinity mask, physical cores first
+    std::vector<int> cpus;                  // the CPUs the workers are bound to: of the process's affinity mask, physical cores first
+    int n_first = 0;                        // ... how many of the mask's CPUs are the first hardware thread of their core
     int n_threads = 0;
 
     Workers() {
@@ -263,14 +282,46 @@ struct Workers {
                     if (CPU_ISSET_S(c, bytes, set)) cpus.push_back(c);
             CPU_FREE(set);
         }
-        // (Linux numbers the second hardware thread of every core after all first ones: ascending order = cores first)
-        // Fewer workers than CPUs (a CPU-time quota, mc_host_cores): spread over the physical cores -- the first half of the list
-        // on a machine with two hardware threads a core -- so that they sit on both sockets and share no core
+        // The first hardware thread of every core in front, the other threads of the cores behind them (from the kernel's
+        // topology files: a host without SMT, or a mask that holds first threads only, has nothing in the second part).
+        // Fewer workers than CPUs (a CPU-time quota, a share of a multi-GPU run: mc_host_cores): spread over the physical cores,
+        // so that they sit on both sockets and share no core -- and ROTATED by $MCALLER_HOST_CORE_OFFSET: the workers of a sharded
+        // run whose GPUs hang off the same NUMA node are bound to the same CPUs and would all pick the same few of them
+        // (multi_gpu._worker gives worker r the offset r x its share)
+        std::vector<int> first, rest;
+        for (int c : cpus) {
+            char path[128];
+            snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            int lowest = c;
+            if (FILE *f = fopen(path, "r")) {
+                char list[256] = "";
+                if (fgets(list, (int)sizeof(list), f)) {
+                    for (char *q = list; *q;) {                 // "3,131" or "6-7": the smallest sibling that is in our mask
+                        char *end = nullptr;
+                        const long a = strtol(q, &end, 10);
+                        if (end == q) break;
+                        long b = a;
+                        q = end;
+                        if (*q == '-') { b = strtol(q + 1, &end, 10); q = end; }
+                        for (long x = a; x <= b; ++x)
+                            if (x < lowest && std::find(cpus.begin(), cpus.end(), (int)x) != cpus.end()) lowest = (int)x;
+                        while (*q == ',' || *q == '\n' || *q == ' ') ++q;
+                    }
+                }
+                fclose(f);
+            }
+            (lowest == c ? first : rest).push_back(c);
+        }
+        n_first = (int)first.size();
+        cpus = first;
+        cpus.insert(cpus.end(), rest.begin(), rest.end());
         const int use = mc_host_cores();
         if (use < (int)cpus.size()) {
-            const size_t pool = cpus.size() >= (size_t)use * 2 ? cpus.size() / 2 : cpus.size();
+            const size_t pool = (size_t)n_first >= (size_t)use ? (size_t)n_first : cpus.size();
+            size_t off = 0;
+            if (const char *e = getenv("MCALLER_HOST_CORE_OFFSET")) { if (atoll(e) > 0) off = (size_t)atoll(e); }
             std::vector<int> pick;
-            for (int i = 0; i < use; ++i) pick.push_back(cpus[(size_t)i * pool / (size_t)use]);
+            for (int i = 0; i < use; ++i) pick.push_back(cpus[(off + (size_t)i * pool / (size_t)use) % pool]);
             cpus.swap(pick);
         }
     }
@@ -321,6 +372,7 @@ void mc_parallel_for(int n, const std::function<void(int)> &f) {
     Job job;
     job.fn = &f;
     job.n = n;
+    int n_threads_now;
     {
         std::lock_guard<std::mutex> lk(W.mu);
         const int want = std::min(n - 1, std::max((int)W.cpus.size() - 1, 0));
@@ -330,10 +382,11 @@ void mc_parallel_for(int n, const std::function<void(int)> &f) {
             ++W.n_threads;
         }
         W.jobs.push_back(&job);
+        n_threads_now = W.n_threads;
     }
     // (as many workers as the job has tasks for: waking them all -- a few hundred threads on a big host, each to find the tasks
     // gone -- costs the process CPU time it may not have)
-    if (n - 1 >= W.n_threads) W.wake.notify_all();
+    if (n - 1 >= n_threads_now) W.wake.notify_all();
     else for (int i = 0; i < n - 1; ++i) W.wake.notify_one();
     Workers::run_tasks(&job);                                  // the caller takes tasks as well
     {

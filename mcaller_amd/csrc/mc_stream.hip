@@ -1146,6 +1146,19 @@ extern "C" int mc_ctx_upload_times_ms(mc_ctx *c, int32_t slot, float *h2d_ms, fl
     return 0;
 }
 
+extern "C" int mc_ctx_parse_times_ms(mc_ctx *c, int32_t slot, float *text_h2d_ms, float *parse_ms) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (slot < 0 || slot >= MC_TABLE_SLOTS || c->slots[slot].kp_state == 0 || !c->slots[slot].ev_parsed) {
+        mc_set_error("mc_ctx_parse_times_ms: slot %d holds no parse", slot);
+        return -12;
+    }
+    TableSlot &S = c->slots[slot];
+    HIP_TRY(hipEventSynchronize(S.ev_parsed));
+    if (text_h2d_ms) HIP_TRY(hipEventElapsedTime(text_h2d_ms, S.ev_up_start, S.ev_text_up));
+    if (parse_ms) HIP_TRY(hipEventElapsedTime(parse_ms, S.ev_text_up, S.ev_parsed));
+    return 0;
+}
+
 extern "C" int mc_ctx_upload_table(mc_ctx *c, const mc_table_view *h) {
     HIP_TRY(hipSetDevice(c->device));
     // the one-table interface: whatever is in flight finishes first, so the caller's buffers are free on return and the

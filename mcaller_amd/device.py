@@ -139,6 +139,12 @@ class Device(object):
         check(lib().mc_ctx_upload_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def parse_times_ms(self, slot):
+        """(text H2D ms, device parser ms) of the parse begun into `slot` (between parse_begin and parse_end / parse_abandon)."""
+        a, b = C.c_float(0), C.c_float(0)
+        check(lib().mc_ctx_parse_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_read_quality(self, qual):
         q = np.ascontiguousarray(qual, dtype=np.float64)
         check(lib().mc_ctx_set_read_quality(self._ctx, _ptr(q), len(q)))

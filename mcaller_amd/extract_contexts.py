@@ -409,7 +409,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     L = _lib.lib()
     L.mc_host_pool_config(1, -1)                           # the parser's tables live in pinned memory, recycled
     masks_on_device = False            # (decided below, once the first shards are being read)
-    clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces))     # MCALLER_TIMING
+    clock = dict(wait_parser=0.0, hand_out=0.0, enqueue=0.0, parse=0.0, shards=len(pieces),     # MCALLER_TIMING
+                 wait_records=0.0, format=0.0, write=0.0, out_bytes=0, records=0)        # (hand_out, split: GPU + copy-out waited for | rows formatted | sink)
     # two reader / parser threads take the shards in turn (the native calls spread a shard over all cores, but opening,
     # cutting and stitching are serial: two shards in the works hide that); at most three shards ahead of the GPU
     from concurrent.futures import ThreadPoolExecutor
@@ -550,7 +551,10 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     def _hand_out():
         P, tail, rows_before = in_flight.pop(0)
         mark('wait ...')
+        t_w = time.perf_counter()
         rec = dev.wait()
+        t_f = time.perf_counter()
+        clock['wait_records'] += t_f - t_w
         mark('records here')
         fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label, device=dev, tail_chrom=tail)
         with contextlib.redirect_stdout(io.StringIO()):        # (its exit paths print; the one-table path will)
@@ -558,8 +562,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
         blob = fin.text()
+        t_s = time.perf_counter()
+        clock['format'] += t_s - t_f
         if blob:
             sink(blob)
+        clock['write'] += time.perf_counter() - t_s
+        clock['out_bytes'] += len(blob)
+        clock['records'] += int(rec.n)
         out.n_bytes += len(blob)
         n = rec.n
         too = (rec.info[:n] & _I.I_TOO_MANY) != 0
@@ -734,10 +743,13 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
         except BaseException as e:
             # the rows appended so far are taken back whatever stopped the stream (a device error, MemoryError, ^C: a re-run
             # must not find half a file to append to); only _Unstreamable goes on to the one-table path
-            if size_before is None:
-                os.remove(tsv_output)
-            else:
-                os.truncate(tsv_output, size_before)
+            try:                           # (the cleanup must not replace what stopped the stream: the file may never have been opened)
+                if size_before is None:
+                    os.remove(tsv_output)
+                else:
+                    os.truncate(tsv_output, size_before)
+            except OSError:
+                pass
             if not isinstance(e, _Unstreamable):
                 raise
         else:
@@ -747,9 +759,11 @@ def extract_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thr
             if timing:
                 ck = getattr(stream_features, 'last_clock', {})
                 print('[mcaller_amd timing] streamed in %s shards (%s parsed on the device): total %.3f s | reader / parser threads '
-                      '%.3f s | main thread: waiting for the next table %.3f, upload + enqueue %.3f, wait + format %.3f' % (
+                      '%.3f s | main thread: waiting for the next table %.3f, upload + enqueue %.3f, wait + format %.3f (records '
+                      'waited for %.3f, %d records formatted %.3f, %d bytes written %.3f)' % (
                           ck.get('shards'), ck.get('device_parsed'), time.perf_counter() - t_start, ck.get('parse', 0),
-                          ck.get('wait_parser', 0), ck.get('enqueue', 0), ck.get('hand_out', 0)), file=sys.stderr)
+                          ck.get('wait_parser', 0), ck.get('enqueue', 0), ck.get('hand_out', 0), ck.get('wait_records', 0),
+                          ck.get('records', 0), ck.get('format', 0), ck.get('out_bytes', 0), ck.get('write', 0)), file=sys.stderr)
             if timing == '2':
                 for t_ev, what in getattr(stream_features, 'last_clock', {}).get('events', []):
                     print('[mcaller_amd timing] %8.2f ms %s' % (t_ev * 1e3, what), file=sys.stderr)

@@ -149,7 +149,12 @@ def _estimator_weights(est, where):
         coef = np.asarray(est.coef_, dtype=np.float64)
         if coef.ndim != 2 or coef.shape[0] != 1:
             raise NotImplementedError('%s: logistic regression with %s coefficients (two classes are supported)' % (where, coef.shape))
-        return LogisticWeights(coef[0], est.intercept_, [_as_text(c) for c in getattr(est, 'classes_', [])])
+        # predict_proba of a binary model fitted with multi_class='multinomial' is softmax([-d, d])[1] = expit(2 d), not
+        # expit(d) (scikit-learn < 1.7 keeps the attribute; the reference's own fit is 'ovr', train_model.py:56): twice the
+        # coefficients give the same numbers through the one formula the kernel has
+        scale = 2.0 if _as_text(getattr(est, 'multi_class', 'auto')) == 'multinomial' else 1.0
+        return LogisticWeights(scale * coef[0], scale * np.asarray(est.intercept_, dtype=np.float64),
+                               [_as_text(c) for c in getattr(est, 'classes_', [])])
     if cls == 'GaussianNB':
         var = getattr(est, 'var_', None)
         if var is None:

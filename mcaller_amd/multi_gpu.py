@@ -73,7 +73,7 @@ class _Abort(Exception):
     """The parent told the worker to stop."""
 
 
-def _worker(conn, device, n_workers=1):
+def _worker(conn, device, n_workers=1, index=0):
     """A worker process: one GPU, jobs from the parent until it says None (or its end of the pipe closes).  A plain run sends
     one job; a caller that runs file after file (MCALLER_KEEP_WORKERS: bench.py's strong-scaling leg) finds the worker, its HIP
     context, its pinned buffers and its table slots where the last file left them."""
@@ -83,7 +83,10 @@ def _worker(conn, device, n_workers=1):
         if n_workers > 1:                       # (the workers of a run share the host's cores -- and its CPU-time quota, if it has one)
             from . import _lib
             share = max(2, int(_lib.lib().mc_host_cores()) // n_workers)
-            os.environ['MCALLER_HOST_CORES'] = str(min(share, int(os.environ.get('MCALLER_HOST_CORES', share))))
+            share = min(share, int(os.environ.get('MCALLER_HOST_CORES', share)))
+            os.environ['MCALLER_HOST_CORES'] = str(share)
+            # (workers whose GPUs hang off one NUMA node are bound to the same CPUs: each takes its own stretch of them)
+            os.environ['MCALLER_HOST_CORE_OFFSET'] = str(index * share)
         while True:
             try:
                 job = conn.recv()
@@ -264,7 +267,7 @@ class _Workers(object):
         self.files = 0
         for dev in devices:
             parent, child = ctx.Pipe()
-            p = ctx.Process(target=_worker, args=(child, dev, len(self.devices)))
+            p = ctx.Process(target=_worker, args=(child, dev, len(self.devices), len(self.procs)))
             p.start()
             child.close()
             self.procs.append(p)

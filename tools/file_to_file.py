@@ -6,6 +6,7 @@
                      streaming its range, with --bed the per-site reduction (ncclAllReduce) and the BED file -- BASELINE.json
                      configs[3].  The workers of one run stay for the next (MCALLER_KEEP_WORKERS): the first run pays for N
                      interpreters and HIP contexts, the later ones are what a file costs
+  --motif M          the CLI's -m (default GATC; `A`: every A of both strands is a site -- the dense mode, BASELINE.md's per-phase profile)
   --json: one JSON line (bench.py's 10^8-row legs run this in a process of its own: wall time per run, peak RSS of the process,
           sha-256 of the output, and for the sharded path what multi_gpu.last_run measured in every run)"""
 import contextlib, hashlib, io, json, os, resource, sys, tempfile, time
@@ -42,6 +43,7 @@ def main():
     runs = int(args[args.index('--runs') + 1]) if '--runs' in args else 6
     n_gpus = int(args[args.index('--gpus') + 1]) if '--gpus' in args else 0
     with_bed = '--bed' in args
+    motif = args[args.index('--motif') + 1] if '--motif' in args else 'GATC'
     if '--inputs' in args:
         d = args[args.index('--inputs') + 1]
         paths = dict(tsv=os.path.join(d, 'syn.eventalign.tsv'), fasta=os.path.join(d, 'ref.fasta'), fastq=os.path.join(d, 'reads.fastq'))
@@ -61,14 +63,15 @@ def main():
     model = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mcaller_amd', 'models', 'r95_twobase_model_NN_6_m6A.npz')
     out = paths['tsv'][:-4] + '.diffs.6'
     bed = os.path.join(os.path.dirname(paths['tsv']), 'syn.methylation.summary.bed')
-    argv = ['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model]
+    argv = ['-m', motif, '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model]
     stats_path = None
     if n_gpus or with_bed:
         argv += ['--gpus', str(max(1, n_gpus))] + (['--bed', '--bed_min_depth', '1'] if with_bed else [])
         os.environ['MCALLER_KEEP_WORKERS'] = '1'
         stats_path = os.path.join(d, 'sharded_run_stats.json')
         os.environ['MCALLER_STATS_JSON'] = stats_path
-    times, calls, stats_all, stdout_tail = [], 0, [], ''
+    times, calls, stats_all, stdout_tail, phases = [], 0, [], '', []
+    from mcaller_amd import extract_contexts as ec
     for rep in range(runs):
         for f in (out, bed, stats_path):
             if f and os.path.exists(f):
@@ -80,6 +83,10 @@ def main():
         dt = time.perf_counter() - t
         times.append(dt)
         stdout_tail = buf.getvalue()[-600:]
+        # what the one-GPU stream measured of itself (extract_contexts.stream_features: seconds of the main thread's phases)
+        ck = dict(getattr(ec.stream_features, 'last_clock', None) or {})
+        ck.pop('events', None)
+        phases.append(ck if not (n_gpus or with_bed) else None)
         calls = sum(1 for _ in open(out, 'rb'))
         if stats_path:
             stats_all.append(json.load(open(stats_path)) if os.path.exists(stats_path) else None)
@@ -100,7 +107,7 @@ def main():
                     s['site_reduction'] and {k: s['site_reduction'][k] for k in ('backend', 'ms', 'bytes')}))
     if as_json:
         res = {'seconds_all': times, 'calls': calls, 'tsv_bytes': os.path.getsize(paths['tsv']), 'diffs_bytes': os.path.getsize(out),
-               'diffs_sha256': sha256_of(out), 'peak_rss_mb': peak_rss_mb(), 'argv': argv[8:]}
+               'diffs_sha256': sha256_of(out), 'peak_rss_mb': peak_rss_mb(), 'argv': argv[8:], 'motif': motif, 'phases_all': phases}
         if stats_path:
             res['sharded_runs'] = stats_all
             res['stdout_tail'] = stdout_tail
