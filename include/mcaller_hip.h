@@ -260,6 +260,11 @@ typedef struct mc_params {
     int32_t entry_first_idx; /* the matching first_read_ind (:161-162); shards > 0 of one file      */
 } mc_params;
 
+/* How the pass handed out last by mc_wait_records ran: *fused_room > 0 -- scan, ordering and emit as ONE kernel with that many
+ * record slots per 1024-row piece (dense references: k1_fused; the slots a piece does not fill never reach the host);
+ * *rerun != 0 -- the pipelined pass could not be finished as enqueued (record room too small, an irregular read, a row that
+ * contradicts what a block was classified on) and was repeated synchronously inside mc_wait_records. */
+int mc_last_pass_info(mc_ctx *ctx, int32_t *fused_room, int32_t *rerun);
 /* The hot path on the GPU: strand resolve + window scan + classifier.  Leaves the flush records on the
  * device, in file order; *n_records = how many. */
 int mc_extract_features(mc_ctx *ctx, const mc_params *prm, int64_t *n_records);

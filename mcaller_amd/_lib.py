@@ -136,6 +136,7 @@ def lib():
         L.mc_ctx_current_slot.argtypes = [C.c_void_p]
         L.mc_ctx_select_table.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.mc_ctx_upload_times_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mc_last_pass_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mc_ctx_parse_times_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mc_ctx_destroy.argtypes = [C.c_void_p]

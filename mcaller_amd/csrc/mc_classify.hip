@@ -524,16 +524,19 @@ __global__ __launch_bounds__(64) void k3_simple(DevSimple S, const double *__res
 // 448 or 512: 0.193-0.195, 576: 0.203, 640: 0.207, 768: 0.215, 1024: 0.231; 256 x 512, 384 x 384: 0.195-0.197)
 // (PACK_WGS, PACK_THREADS: defined with the emit kernels, which count per packing chunk)
 
-// chunk_cnt[PACK_PAD * b] = kept records of chunk b, chunk_cnt[PACK_PAD * b + 1] = their wide slots
+// chunk_cnt[PACK_PAD * b] = kept records of chunk b, chunk_cnt[PACK_PAD * b + 1] = their wide slots; holes != 0 (the fused pass
+// of a dense reference, k1_fused: fixed room per piece): chunk_cnt[PACK_PAD * b + 2] = the chunk's records that are not holes
 __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const Counters *__restrict__ cnt, int k,
-                                                             unsigned long long *__restrict__ chunk_cnt) {
-    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
+                                                             unsigned long long *__restrict__ chunk_cnt, int holes) {
+    __shared__ unsigned int s_wave[3][PACK_THREADS / 64];
     const int64_t n = cnt->overflow ? 0 : min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
-    unsigned int kept = 0, wide = 0;
+    unsigned int kept = 0, wide = 0, real = 0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) {
-        if (O.info[i] & MC_I_TOO_MANY) continue;
+        const uint32_t info = O.info[i];
+        if (!(info & MC_I_HOLE)) real += 1u;
+        if (info & MC_I_TOO_MANY) continue;
         kept += 1u;
         const unsigned wm = O.wmask[i];                      // (k1_emit's note; 0xFF: a record of the rare paths, looked at here)
         if (wm != 0xFFu) wide += (unsigned)__popc(wm);
@@ -543,42 +546,49 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const
                 wide += slot_is_narrow(O.feats[i * k + f], &d) ? 0u : 1u;
             }
     }
-    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_xor(kept, o); wide += __shfl_xor(wide, o); }
-    if ((threadIdx.x & 63) == 0) { s_wave[0][threadIdx.x >> 6] = kept; s_wave[1][threadIdx.x >> 6] = wide; }
+    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_xor(kept, o); wide += __shfl_xor(wide, o); real += __shfl_xor(real, o); }
+    if ((threadIdx.x & 63) == 0) { s_wave[0][threadIdx.x >> 6] = kept; s_wave[1][threadIdx.x >> 6] = wide; s_wave[2][threadIdx.x >> 6] = real; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = 0, w = 0;
-        for (int j = 0; j < PACK_THREADS / 64; ++j) { t += s_wave[0][j]; w += s_wave[1][j]; }
+        unsigned long long t = 0, w = 0, r = 0;
+        for (int j = 0; j < PACK_THREADS / 64; ++j) { t += s_wave[0][j]; w += s_wave[1][j]; r += s_wave[2][j]; }
         chunk_cnt[PACK_PAD * blockIdx.x] = t;
         chunk_cnt[PACK_PAD * blockIdx.x + 1] = w;
+        if (holes) chunk_cnt[PACK_PAD * blockIdx.x + 2] = r;
     }
 }
 
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ chunk_cnt,
                                                        unsigned char *__restrict__ out, int k, int close32,
-                                                       Counters *__restrict__ host_status) {
+                                                       Counters *__restrict__ host_status, int holes) {
     static_assert(PACK_WGS <= PACK_THREADS && PACK_THREADS % 64 == 0, "one chunk count per thread");
-    __shared__ unsigned long long s_sum[4][PACK_THREADS / 64];
-    __shared__ unsigned int s_wave[2][PACK_THREADS / 64];
+    __shared__ unsigned long long s_sum[6][PACK_THREADS / 64];
+    __shared__ unsigned int s_wave[3][PACK_THREADS / 64];
     __shared__ double s_feats[PACK_THREADS * MC_MAX_K];     // the strip's slot means, loaded with consecutive lanes on consecutive words
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // kept records (and their wide slots) before this chunk, and in all chunks
     unsigned long long v = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid] : 0ull, before = tid < (int)blockIdx.x ? v : 0ull;
     unsigned long long w = tid < PACK_WGS ? chunk_cnt[PACK_PAD * tid + 1] : 0ull, wbefore = tid < (int)blockIdx.x ? w : 0ull;
+    // (a pass with holes: the records that are not holes, before this chunk and in all -- what the narrow columns are indexed by)
+    unsigned long long r = (holes && tid < PACK_WGS) ? chunk_cnt[PACK_PAD * tid + 2] : 0ull, rbefore = tid < (int)blockIdx.x ? r : 0ull;
     for (int o = 32; o > 0; o >>= 1) {
         v += __shfl_xor(v, o); before += __shfl_xor(before, o);
         w += __shfl_xor(w, o); wbefore += __shfl_xor(wbefore, o);
+        r += __shfl_xor(r, o); rbefore += __shfl_xor(rbefore, o);
     }
-    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; s_sum[2][wave] = w; s_sum[3][wave] = wbefore; }
+    if (lane == 0) { s_sum[0][wave] = v; s_sum[1][wave] = before; s_sum[2][wave] = w; s_sum[3][wave] = wbefore; s_sum[4][wave] = r; s_sum[5][wave] = rbefore; }
     __syncthreads();
-    unsigned long long total = 0, base = 0, total_wide = 0, wbase = 0;
-    for (int j = 0; j < PACK_THREADS / 64; ++j) { total += s_sum[0][j]; base += s_sum[1][j]; total_wide += s_sum[2][j]; wbase += s_sum[3][j]; }
+    unsigned long long total = 0, base = 0, total_wide = 0, wbase = 0, total_real = 0, rbase = 0;
+    for (int j = 0; j < PACK_THREADS / 64; ++j) {
+        total += s_sum[0][j]; base += s_sum[1][j]; total_wide += s_sum[2][j]; wbase += s_sum[3][j]; total_real += s_sum[4][j]; rbase += s_sum[5][j];
+    }
     constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;      // everything the host looks at
     constexpr int kept_word = (int)(offsetof(Counters, n_kept) / 4);          // (n_kept and n_wide: two words each, set below)
     static_assert(offsetof(Counters, n_wide) == offsetof(Counters, n_kept) + 8, "n_kept, n_wide side by side");
     if (blockIdx.x == 0) {
-        if (tid < (int)head_words && (tid < kept_word || tid >= kept_word + 4))
+        static_assert(offsetof(Counters, n_records) == 0, "the record count: the block's first two words");
+        if (tid < (int)head_words && (tid < kept_word || tid >= kept_word + 4) && !(holes && tid < 2 && !cnt->overflow))     // (holes: the count that goes out is set below)
             reinterpret_cast<volatile unsigned int *>(host_status)[tid] = reinterpret_cast<const unsigned int *>(cnt)[tid];
         if (tid == 0) {
             *reinterpret_cast<volatile unsigned long long *>(&host_status->n_kept) = total;
@@ -589,7 +599,11 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     const int64_t n = min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
-    const PackLayout L = pack_layout(n, close32);
+    // (holes: the host is told the number of records that are not holes -- written behind the copy of the counters above by the
+    // same thread, so it stands)
+    const int64_t n_out = holes ? (int64_t)total_real : n;
+    if (holes && blockIdx.x == 0 && tid == 0) *reinterpret_cast<volatile unsigned long long *>(&host_status->n_records) = (unsigned long long)n_out;
+    const PackLayout L = pack_layout(n_out, close32);
     const PackTail T = pack_tail(L.feats, (size_t)total, k, (size_t)total_wide);
     int64_t *o_close = reinterpret_cast<int64_t *>(out);
     int32_t *o_close32 = reinterpret_cast<int32_t *>(out);
@@ -602,8 +616,8 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
     uint32_t *o_hi = reinterpret_cast<uint32_t *>(out + T.hi32);
     for (int64_t s = lo; s < hi; s += PACK_THREADS) {
         const int64_t i = s + tid;
-        const bool valid = i < hi;
-        const uint32_t info = valid ? O.info[i] : MC_I_TOO_MANY;
+        const uint32_t info = i < hi ? O.info[i] : (MC_I_TOO_MANY | MC_I_HOLE);
+        const bool valid = i < hi && !(info & MC_I_HOLE);
         const bool keep = !(info & MC_I_TOO_MANY);
         {
             const int64_t n_here = min((int64_t)PACK_THREADS, hi - s) * k;
@@ -636,21 +650,25 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
             const unsigned int y = __shfl_up(w_incl, o);
             if (lane >= o) w_incl += y;
         }
+        const unsigned long long vmask = __ballot(valid);
         if (lane == 63) s_wave[1][wave] = w_incl;
-        if (lane == 0) s_wave[0][wave] = (unsigned int)__popcll(kmask);
+        if (lane == 0) { s_wave[0][wave] = (unsigned int)__popcll(kmask); s_wave[2][wave] = (unsigned int)__popcll(vmask); }
         __syncthreads();
         unsigned int in_strip = (unsigned int)__popcll(kmask & ((1ull << lane) - 1ull)), strip = 0, w_off = w_incl - n_w, w_strip = 0;
+        unsigned int r_in_strip = (unsigned int)__popcll(vmask & ((1ull << lane) - 1ull)), r_strip = 0;
         for (int j = 0; j < PACK_THREADS / 64; ++j) {
-            if (j < wave) { in_strip += s_wave[0][j]; w_off += s_wave[1][j]; }
+            if (j < wave) { in_strip += s_wave[0][j]; w_off += s_wave[1][j]; r_in_strip += s_wave[2][j]; }
             strip += s_wave[0][j];
             w_strip += s_wave[1][j];
+            r_strip += s_wave[2][j];
         }
         if (valid) {
-            if (close32) o_close32[i] = (int32_t)O.close_row[i];
-            else o_close[i] = O.close_row[i];
-            o_pos[i] = O.site_pos[i];
-            o_seg[i] = O.site_seg[i];
-            o_info[i] = info;
+            const int64_t io = holes ? (int64_t)(rbase + r_in_strip) : i;        // (holes are compacted away: the host never sees one)
+            if (close32) o_close32[io] = (int32_t)O.close_row[i];
+            else o_close[io] = O.close_row[i];
+            o_pos[io] = O.site_pos[i];
+            o_seg[io] = O.site_seg[i];
+            o_info[io] = info;
             if (keep) {
                 const unsigned long long row = base + in_strip;
                 o_prob[row] = O.prob[i];
@@ -662,6 +680,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
         __syncthreads();
         base += strip;
         wbase += w_strip;
+        rbase += r_strip;
     }
 }
 
@@ -697,14 +716,14 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
     }
 }
 
-void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, k, chunk_cnt);
+void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, int holes, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, k, chunk_cnt, holes);
 }
 
 void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, hipStream_t st, hipEvent_t stop) {
-    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status);
-    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status);
+                    Counters *host_status, int holes, hipStream_t st, hipEvent_t stop) {
+    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
+    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
 }
 
 #ifdef MC_K2_TRACE

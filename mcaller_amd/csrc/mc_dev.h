@@ -229,6 +229,8 @@ __device__ __forceinline__ unsigned char comp_char(unsigned char c) {
 }
 
 constexpr uint32_t MC_I_BIG = 0x1000u;   // internal: a slot holds > 128 events, finished by k1_bigfix
+constexpr uint32_t MC_I_HOLE = 0x2000u;  // internal: a record slot a piece of the fused dense pass (k1_fused) did not fill -- always with MC_I_TOO_MANY;
+                                         // k_pack compacts the holes away, the host never sees one
 constexpr int O_EXTRA = 14;              // meta nibble: the one-event '+' window of a palindromic f0 (R5)
 
 struct RowSrc {   // the columns, for window walks
@@ -485,6 +487,11 @@ void mc_launch_list(const K1Args &A, Payload *sorted, int gather, hipStream_t st
 int mc_emit_occupancy(void);            // resident k1_emit workgroups per CU (occupancy query)
 void mc_launch_emit(const K1Args &A, const Payload *sorted, unsigned grid, hipStream_t st, hipEvent_t stop);
 void mc_launch_emit_runs(const K1Args &A, Payload *sorted, hipStream_t st, hipEvent_t stop);
+// the fused pass of a dense reference (mc_fused.hip): room per piece, pieces of a table, the launch
+int mc_fused_room(double density);
+int mc_fused_room_max(void);
+int64_t mc_fused_pieces(const DevTable &T);
+void mc_launch_fused(const K1Args &A, Payload *sorted, int cap, bool validate, hipStream_t st, hipEvent_t stop);
 void mc_launch_rare(const K1Args &A, const Payload *sorted, const int64_t *rare_list, int64_t n_rare, hipStream_t st);
 void mc_launch_rare_dev(const K1Args &A, const Payload *sorted, const int64_t *rare_list, hipStream_t st);
 void mc_launch_bigfix(const K1Args &A, int64_t n, hipStream_t st);
@@ -493,8 +500,8 @@ void mc_launch_merge(const DevRecords &O, int64_t n_o, const DevRecords &L, int6
 void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &S, int n_cu, hipStream_t st, const double *feats, int k,
                           const int32_t *site_seg, const int32_t *seg_read, const double *qual, const uint32_t *info,
                           const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow);
-void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, hipStream_t st);
+void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, int holes, hipStream_t st);
 void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, hipStream_t st, hipEvent_t stop);
+                    Counters *host_status, int holes, hipStream_t st, hipEvent_t stop);
 
 #endif  // MC_DEV_H

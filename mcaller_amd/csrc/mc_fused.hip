@@ -1,0 +1,671 @@
+// mc_fused.hip: k1_fused -- scan, ordering and emit of a pass over a DENSE reference (a one-base motif: a window closes every
+// eleven rows) in ONE kernel -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers:
+// mc_dev.h; the map of the kernels: mc_stream.hip.  Replaces, for pipelined passes, k1_scan<130> + k1_group_scan + k1_list +
+// k1_emit_runs (mc_scan.hip, mc_emit.hip): the reference's flush / shift path, extract_contexts.py:179-256.
+//
+// Where the pair spends its instructions is the scan's question "is this row the last row of a window?", asked of every ROW
+// (57 vector instructions a row) -- but the rows of one position share their site, so only the last row of a RUN of one position can
+// be a window's last row, and the run table is what k1_emit_runs builds anyway.  Here the question is asked per run, by the
+// workgroup that holds the run table:
+//   * a workgroup takes a PIECE of FT rows with FH rows in front, stages positions, flag bytes and (event - model), cuts the
+//     unfiltered rows of every regular name block into runs, gives every run its mean (NumPy's pairwise order) -- as
+//     k1_emit_runs does -- and, new, its SITE: the first marked position of the run's k-mer (two words of the block's strand
+//     mask, one batched trip per thread);
+//   * the window of run R is closed by the HEAD of the next run of its block iff that head lies beyond R's site (:179): closing
+//     run R + 1 = "closer".  A piece owns the windows whose CLOSING row lies in it -- everything a closer needs lies behind it,
+//     in the rows in front, so nothing is looked at beyond the piece, and the order of the closing rows is the order in which the
+//     reference flushes (:179-239 run at the closing row);
+//   * the closers of a piece are counted per thread over consecutive runs, numbered by one scan across the workgroup, listed in
+//     LDS, and handed out one window per thread: record = piece x cap + rank.  FIXED ROOM per piece instead of an ordering across
+//     pieces (a look-back serialised on the slowest workgroup, a count pass costs what the scan costs: NOTES.md sections 10, 12):
+//     the slots a piece does not fill are HOLES (MC_I_HOLE | MC_I_TOO_MANY), which the classifier kernels, k_site_counts and
+//     k_pack_count skip like any record that is not a call, and k_pack compacts away: the host never sees one.  A piece with more
+//     windows than room marks the pass (Counters.overflow): it is repeated by the pair, with twice the room next time;
+//   * what is not the head of a run closing the run before it -- the first unfiltered row of a name block (it closes the last
+//     window of the read before, whatever its position), the head of a block's first run (it closes the one-event '+' window of
+//     a palindromic first site row, R5), the end of the shard -- is a handful of SPECIAL closers per table: one thread each,
+//     from global memory (closed_by), their windows finished by the row-by-row kernel (k1_rare_dev) like k1_emit's long windows;
+//     so is everything the run table cannot answer (a run that begins in front of the staged rows, more than 128 events in a
+//     run, the stray event of R5); a piece with more name blocks than the table holds is walked a row per lane;
+//   * on a table's first pass the piece's rows are validated as the scan validates them (every row against the row before it
+//     in its name block: note_validation), event indices staged with the rows.
+#include "mc_dev.h"
+
+namespace {
+
+#ifndef MC_FT
+#define MC_FT 1024
+#endif
+#ifndef MC_FH
+#define MC_FH 128
+#endif
+#ifndef MC_FD_WAVES
+#define MC_FD_WAVES 6
+#endif
+constexpr int FT = MC_FT;           // rows per piece
+constexpr int FH = MC_FH;           // rows in front of the piece that are staged with it
+constexpr int FR = FT + FH;
+constexpr int F_THREADS = 256;
+constexpr int F_MAXB = 16;          // name blocks per staged range
+constexpr int F_CHUNKS = FR / 64;   // the staged rows in chunks of 64: a wave owns 5 or 4 consecutive ones
+constexpr int F_CPW = 5;
+constexpr int F_ROW_BITS = 11;
+constexpr uint32_t RF_WIDE = 1, RF_UNUSABLE = 2, RF_ALONE = 4;      // flags of a run, above its first row in s_rrow
+constexpr int F_MAXSPEC = 2 * F_MAXB + 1;
+static_assert(TILE % FT == 0, "whole pieces per tile");
+static_assert(FR % 64 == 0 && F_THREADS == 256 && (F_CHUNKS + 3) / 4 <= F_CPW, "the chunks are split over 4 waves, at most F_CPW each");
+static_assert(FR < (1 << F_ROW_BITS), "s_rrow keeps the run's flags above its row");
+
+struct FBlock {                     // a name block that overlaps the staged rows (staged indices), and what its windows need of it
+    int16_t end, lb;                // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
+    int16_t begin;                  // the block's first row (-1: before the staged rows)
+    uint8_t rev, xflags;
+    int id, contig, contig_len, stray_q, seq_delta, seg, extra_mpos;
+    uint32_t vf;
+    int64_t mask_off;
+};
+static_assert(sizeof(FBlock) == 48, "FBlock layout");
+
+struct FSpec {                      // a special closer's window: finished by k1_rare_dev (kind 1) or written as it is (kind 2: R5)
+    int64_t r, cr;                  // last row of the window, closing row
+    int32_t m, nb;
+    uint8_t kind, ns;               // (the record goes in front of the window its block's first run closes: s_bfirst)
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The validation of a first pass (mc_scan.hip has the same two for the scan): flags a row shows that the classification of the
+// pass did not rest on go into the table's flags; a block taken for regular marks the pass.
+__device__ __forceinline__ void f_note_validation(const K1Args &A, int nb_abs, uint32_t seen) {
+    const NbDesc *dp = A.desc + nb_abs;
+    if (!(seen & ~dp->vf)) return;
+    atomicOr(&A.T.nb_vflags[nb_abs], seen);
+    if (dp->mode == MODE_REGULAR) {
+        *reinterpret_cast<volatile unsigned int *>(&A.cnt->violation) = 1u;
+        *reinterpret_cast<volatile unsigned long long *>(&A.cnt->irregular_pass) = A.pass_no;
+    }
+}
+__device__ __forceinline__ uint32_t f_row_vflags(int p, int x, int prev_p, int prev_x, bool has_pred) {
+    uint32_t f = p == 0 ? V_POS0 : 0u;
+    if (has_pred) {
+        if (p < prev_p) f |= V_POS_DEC;
+        f |= x > prev_x ? V_IDX_INC : (x < prev_x ? V_IDX_DEC : V_IDX_EQ);
+    }
+    return f;
+}
+
+// Which window does the unfiltered row c (in name block bc; c == n_rows, bc == n_nb: the first row of the next shard) close?
+// The one of the unfiltered row before it (:179): everything from global memory, one thread, rare.  c_pos: the row's position
+// (looked at only when the two rows share their block).  kind 0: none; 1: the window of site m whose last row is r (block nb);
+// 2: the one-event '+' window of nb's palindromic first site row (R5).
+struct Closed { int kind; int64_t r; int m, nb; bool ns; };
+__device__ __noinline__ Closed closed_by(const K1Args &A, int64_t c, int bc, int c_pos) {
+    const DevTable &T = A.T;
+    Closed out;
+    out.kind = 0; out.r = 0; out.m = 0; out.nb = 0; out.ns = false;
+    int bb = min(bc, T.n_nb - 1);
+    int64_t rr = c - 1;
+    while (rr >= 0) {                               // the unfiltered row before c
+        while (bb > 0 && T.nb_row_begin[bb] > rr) --bb;
+        if (A.desc[bb].filtered) { rr = T.nb_row_begin[bb] - 1; continue; }     // (the read whole)
+        if (!(T.flags[rr] & MC_F_MODEL_N)) break;
+        --rr;
+    }
+    if (rr < 0) return out;
+    const NbDesc d = A.desc[bb];
+    if (d.mode != MODE_REGULAR) return out;         // (an irregular block: the pass is finished by the literal path anyway)
+    out.ns = bb != bc;
+    out.r = rr; out.nb = bb;
+    if (rr == d.extra_row()) {                      // R5: closed by whatever unfiltered row comes next
+        out.kind = 2; out.m = d.extra_mpos;
+        return out;
+    }
+    if (rr < max(d.row_begin, d.first())) return out;
+    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
+    const int o = first_m(bits, d.contig_len, T.pos[rr], A.k);
+    if (o < 0) return out;
+    out.m = T.pos[rr] + o;
+    if (!out.ns && c_pos <= out.m) return out;
+    out.kind = 1;
+    return out;
+}
+
+__device__ __forceinline__ void write_extra(const K1Args &A, int64_t q, int m, int seg, int64_t cr, bool multi) {
+    for (int s2 = 0; s2 < A.k; ++s2) A.O.feats[q * A.k + s2] = 0.0;
+    A.O.wmask[q] = 0;
+    A.O.site_pos[q] = m;
+    A.O.site_seg[q] = seg;
+    A.O.close_row[q] = cr;
+    A.O.info[q] = MC_I_TOO_MANY | (multi ? MC_I_MULTI : 0u);
+    A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// a window left to the row-by-row kernel: it looks its payload up in the ordered list (k1_rare_dev: nb, r, m)
+__device__ __forceinline__ void leave_to_rare(const K1Args &A, Payload *__restrict__ sorted, int64_t q, int64_t r, int m, int nb, int64_t cr) {
+    Payload P;
+    P.r = r; P.close_row = cr; P.m = m; P.close_pos = 0; P.flags = 0; P.nb = nb;
+    sorted[q] = P;
+    A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
+}
+
+// exclusive prefix of `mine` over the workgroup's threads (and the total); s_w: F_THREADS / 64 words of LDS
+__device__ __forceinline__ int wg_exclusive_scan(int mine, int lane, int wave, int *s_w, int &total) {
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    lds_barrier();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < F_THREADS / 64; ++w) {
+        const int v = s_w[w];
+        if (w < wave) off += v;
+        total += v;
+    }
+    return off + incl - mine;
+}
+
+template <bool VALIDATE>
+__global__ __launch_bounds__(F_THREADS) __attribute__((amdgpu_waves_per_eu(MC_FD_WAVES, MC_FD_WAVES)))
+void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
+    __shared__ int32_t s_dc[FR + 8];            // (event - model) of the rows in runs, run after run; later: the list of closers
+    __shared__ double s_mean[FR];
+    __shared__ int32_t s_rpos[FR];              // the run's position
+    __shared__ uint16_t s_rrow[FR + 1];         // first row of the run (staged index) | RF_* << F_ROW_BITS
+    __shared__ uint16_t s_rc0[FR + 2];          // where the run's rows begin in s_dc; one more: where the last run's end
+    __shared__ uint8_t s_ro[FR + 1];            // the run's site: offset of the first 'M' of its k-mer + 1 (0: none) | bit 7: the position behind the site is marked too
+    __shared__ FBlock s_blk[F_MAXB];
+    __shared__ int16_t s_bfirst[F_MAXB + 1];    // first run of the block (the runs of later blocks behind it); -1 until known
+    __shared__ FSpec s_spec[F_MAXSPEC];
+    __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
+    const DevTable &T = A.T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PIECES = TILE / FT;
+    const int64_t piece_no = blockIdx.x;
+    const int64_t tile = piece_no / PIECES;
+    const int64_t s0 = piece_no * (int64_t)FT, s1 = min(s0 + (int64_t)FT, T.n_rows);
+    if (piece_no == 0 && tid == 0) A.cnt->n_records = (unsigned long long)gridDim.x * (unsigned long long)cap;      // every slot of every piece: holes are records that are not calls
+    const int k = A.k;
+    const int64_t q0 = piece_no * (int64_t)cap;
+    if (s0 >= T.n_rows) {                        // (a piece behind the table: all holes)
+        for (int w = tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+        return;
+    }
+    const int64_t h0 = max(s0 - (int64_t)FH, (int64_t)0);
+    const int nst = (int)(s1 - h0), i_piece = (int)(s0 - h0);
+    // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
+    // chunk in front of its first one.  Their addresses need nothing but the block index, so they set out FIRST and all at once
+    // (a lane beyond the staged rows reads the last staged row and drops it: a load behind a test is a round trip of its own) ----
+    const int c_lo = (wave * F_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * F_CHUNKS + 3) >> 2;
+    int32_t rp[F_CPW], rd[F_CPW], rx[F_CPW];
+    uint32_t rfl[F_CPW];
+    int2 re[F_CPW];
+#pragma unroll
+    for (int c = 0; c < F_CPW; ++c) {
+        const int64_t j = h0 + min((c_lo + c) * 64 + lane, nst - 1);
+        re[c] = T.evmu[j];
+        rp[c] = T.pos[j];
+        rfl[c] = T.flags[j];
+        rx[c] = VALIDATE ? T.idx[j] : 0;
+    }
+    const int64_t jpre = h0 + min(max((c_lo - 1) * 64 + lane, 0), nst - 1);
+    int32_t pre_p = T.pos[jpre], pre_x = VALIDATE ? T.idx[jpre] : 0;
+    uint32_t pre_f = T.flags[jpre];
+    const unsigned overflow = A.cnt->overflow;   // (a piece ran out of room: the pass is repeated, nobody reads what the others write)
+    const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
+    // the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before began in,
+    // all at once; the whole descriptor, 64 bytes in four loads, and the block's segment
+    const int b = bfrom + lane;
+    if (wave == 0) {
+        const int bc = min(b, T.n_nb - 1);
+        const int4 *dq = (const int4 *)(A.desc + bc);
+        int4 d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+        int seg = T.nb_seg_begin[bc];
+        asm volatile("" : "+v"(d0.x), "+v"(d0.y), "+v"(d0.z), "+v"(d0.w), "+v"(d1.x), "+v"(d1.y), "+v"(d1.z), "+v"(d1.w),
+                          "+v"(d2.x), "+v"(d2.y), "+v"(d2.z), "+v"(d2.w), "+v"(d3.x), "+v"(d3.y), "+v"(d3.z), "+v"(d3.w), "+v"(seg));
+        bool over = false, ends_early = false;
+        FBlock fb;
+        NbDesc D;
+        ((int4 *)&D)[0] = d0; ((int4 *)&D)[1] = d1; ((int4 *)&D)[2] = d2; ((int4 *)&D)[3] = d3;
+        if (b < T.n_nb) {
+            const int64_t rbeg = D.row_begin, rend = D.row_end;
+            over = rbeg < s1 && rend > h0;
+            ends_early = rend < s1 && b + 1 < T.n_nb;           // (the block behind this one begins before the piece ends)
+            if (over) {
+                fb.end = (int16_t)min(rend - h0, (int64_t)nst);
+                fb.begin = (int16_t)max(rbeg - h0, (int64_t)-1);
+                // first row that belongs to a run: the block's first tested row (rows in front of it, and blocks that are not
+                // regular, are in no run)
+                fb.lb = (int16_t)(D.mode == MODE_REGULAR ? min(max(max(rbeg, D.first()) - h0, (int64_t)-1), (int64_t)nst) : (int64_t)nst);
+                fb.rev = D.rev;
+                fb.xflags = (uint8_t)(D.xflags | (D.filtered ? 0x80u : 0u) | (D.mode == MODE_REGULAR ? 0x40u : 0u));
+                fb.id = b;
+                fb.contig = D.contig;
+                fb.contig_len = D.contig_len;
+                fb.stray_q = D.stray_q;
+                fb.seq_delta = D.seq_delta;
+                fb.seg = seg;
+                fb.extra_mpos = D.extra_mpos;
+                fb.vf = D.vf;
+                fb.mask_off = D.mask_off;
+            }
+        }
+        const unsigned long long bal = __ballot(over);
+        const int n = __popcll(bal), at = __popcll(bal & ((1ull << lane) - 1ull));
+        const bool more_behind = (__ballot(ends_early) >> 63) & 1ull;
+        if (over && at < F_MAXB) s_blk[at] = fb;
+        if (lane <= F_MAXB) s_bfirst[lane] = -1;
+        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; }
+    }
+    asm volatile("" : "+v"(re[0].x), "+v"(re[0].y), "+v"(rp[0]), "+v"(rfl[0]), "+v"(rx[0]), "+v"(re[1].x), "+v"(re[1].y), "+v"(rp[1]), "+v"(rfl[1]), "+v"(rx[1]),
+                      "+v"(re[2].x), "+v"(re[2].y), "+v"(rp[2]), "+v"(rfl[2]), "+v"(rx[2]), "+v"(re[3].x), "+v"(re[3].y), "+v"(rp[3]), "+v"(rfl[3]), "+v"(rx[3]),
+                      "+v"(re[4].x), "+v"(re[4].y), "+v"(rp[4]), "+v"(rfl[4]), "+v"(rx[4]), "+v"(pre_p), "+v"(pre_f), "+v"(pre_x));
+    static_assert(F_CPW == 5, "the line above lists the rows of five chunks");
+    if (overflow) return;
+#pragma unroll
+    for (int c = 0; c < F_CPW; ++c) {
+        const bool staged = c_lo + c < c_hi && (c_lo + c) * 64 + lane < nst;
+        rd[c] = staged ? re[c].x - re[c].y : 0;
+        rp[c] = staged ? rp[c] : 0;
+        rfl[c] = staged ? rfl[c] : (uint32_t)MC_F_MODEL_N;
+    }
+    if (!(c_lo > 0 && (c_lo - 1) * 64 + lane < nst)) { pre_p = 0; pre_f = MC_F_MODEL_N; }
+    lds_barrier();
+    const int nblk = s_nblk;
+    const bool usable = nblk <= F_MAXB;
+    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    const bool at_eof = s1 == T.n_rows && A.tail_contig >= 0;      // the first row of the next shard closes this shard's last window (R6, R8)
+
+    if (!usable) {
+        // ---- more name blocks than the table holds (reads of a few dozen rows): every row of the piece is looked at as a closer,
+        // from global memory; a thread takes four consecutive rows.  Exact, slow, rare ----
+        Closed cl[5];
+        int mine = 0;
+        int bc = bfrom;
+#pragma unroll 1
+        for (int e = 0; e < 5; ++e) {
+            cl[e].kind = 0;
+            int64_t c = s0 + 4 * tid + e;
+            if (e == 4) { if (!(tid == F_THREADS - 1 && at_eof)) continue; c = T.n_rows; }
+            else if (c >= s1) continue;
+            int cpos = 0;
+            if (c < T.n_rows) {
+                while (bc + 1 < T.n_nb && T.nb_row_begin[bc + 1] <= c) ++bc;
+                if (VALIDATE) {
+                    const bool has_pred = c > T.nb_row_begin[bc];
+                    const uint32_t f = f_row_vflags(T.pos[c], T.idx[c], has_pred ? T.pos[c - 1] : 0, has_pred ? T.idx[c - 1] : 0, has_pred);
+                    f_note_validation(A, bc, f);
+                }
+                if (A.desc[bc].filtered || (T.flags[c] & MC_F_MODEL_N)) continue;
+                cpos = T.pos[c];
+            }
+            cl[e] = closed_by(A, c, c < T.n_rows ? bc : T.n_nb, cpos);
+            mine += cl[e].kind != 0;
+        }
+        int n_win;
+        int rank = wg_exclusive_scan(mine, lane, wave, s_scan, n_win);
+        if (n_win > cap) { if (tid == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+#pragma unroll 1
+        for (int e = 0; e < 5; ++e) {
+            if (!cl[e].kind) continue;
+            const int64_t q = q0 + rank++;
+            const int64_t c = e == 4 ? T.n_rows : s0 + 4 * tid + e;
+            if (cl[e].kind == 2) write_extra(A, q, cl[e].m, T.nb_seg_begin[cl[e].nb], c, !cl[e].ns && A.desc[cl[e].nb].extra_multi());
+            else leave_to_rare(A, sorted, q, cl[e].r, cl[e].m, cl[e].nb, c);
+        }
+        for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+        return;
+    }
+
+    int n_runs = 0;
+    {
+        // ---- which row in a run came last before the wave's rows (none: row -1) ----
+        int carry_row = -1, carry_pos = 0;
+        for (int cc = c_lo - 1; cc >= 0; --cc) {
+            const int i = cc * 64 + lane;
+            int32_t p = pre_p;
+            uint32_t f = pre_f;
+            if (cc != c_lo - 1 && i < nst) { p = T.pos[h0 + i]; f = T.flags[h0 + i]; }
+            int bj = 0;
+            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+            const bool in = i >= max((int)s_blk[bj].lb, 0) && i < s_blk[bj].end && !(f & MC_F_MODEL_N);
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                const int top = 63 - __clzll(m);
+                carry_row = cc * 64 + top;
+                carry_pos = __shfl(p, top);
+                break;
+            }
+        }
+        // ---- the wave's rows: which are in runs, which begin one (the row before it in its block that is in a run lies at
+        // another position, or there is none); a first pass: every row of the piece against the row before it ----
+        unsigned long long inm[F_CPW], headm[F_CPW];
+        uint32_t cutm = 0, alonem = 0;  // bit c: the lane's row of chunk c begins its block's first staged run / one whose first rows may lie in front of the staged ones
+        int nh = 0, ni = 0, bj = 0;
+#pragma unroll
+        for (int c = 0; c < F_CPW; ++c) {
+            inm[c] = 0; headm[c] = 0;
+            if (c_lo + c >= c_hi) continue;
+            const int base = (c_lo + c) * 64, i = base + lane;
+            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+            const int lb = s_blk[bj].lb, lbm = max(lb, 0);
+            if (VALIDATE) {
+                // the row before: the previous lane's, lane 0: the last row of the chunk before (the wave's, or the one loaded in front)
+                int qp = __shfl_up(rp[c], 1), qx = __shfl_up(rx[c], 1);
+                const int sp = __shfl(c > 0 ? rp[c > 0 ? c - 1 : 0] : pre_p, 63), sx = __shfl(c > 0 ? rx[c > 0 ? c - 1 : 0] : pre_x, 63);
+                if (lane == 0) { qp = sp; qx = sx; }
+                const bool mine = i >= i_piece && i < nst && i < s_blk[bj].end && i >= (int)s_blk[bj].begin;
+                const bool has_pred = i > (int)s_blk[bj].begin;
+                const uint32_t f = mine ? f_row_vflags(rp[c], rx[c], qp, qx, has_pred) : 0u;
+                if (f & ~s_blk[bj].vf) f_note_validation(A, s_blk[bj].id, f);
+            }
+            const bool in = i < nst && i >= lbm && i < s_blk[bj].end && !(rfl[c] & MC_F_MODEL_N);
+            const unsigned long long m = __ballot(in), below = m & lt;
+            const int pl = 63 - __clzll(below | 1ull);
+            int prow = base + pl, ppos = __shfl(rp[c], pl);
+            if (!below) { prow = carry_row; ppos = carry_pos; }
+            const bool alone = prow < lbm, head = in && (alone || ppos != rp[c]);
+            if (head && alone) { alonem |= 1u << c; if (lb < 0) cutm |= 1u << c; }
+            const unsigned long long hm = __ballot(head);
+            inm[c] = m; headm[c] = hm;
+            nh += __popcll(hm); ni += __popcll(m);
+            if (m) {
+                const int top = 63 - __clzll(m);
+                carry_row = base + top;
+                carry_pos = __shfl(rp[c], top);
+            }
+        }
+        if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
+        lds_barrier();
+        int hbase = 0, ibase = 0, n_in = 0;
+#pragma unroll
+        for (int w = 0; w < F_THREADS / 64; ++w) {
+            const int a = s_wheads[w], b2 = s_wins[w];
+            if (w < wave) { hbase += a; ibase += b2; }
+            n_runs += a; n_in += b2;
+        }
+        // ---- runs numbered in row order; the rows in runs packed run after run ----
+        bj = 0;
+#pragma unroll
+        for (int c = 0; c < F_CPW; ++c) {
+            if (c_lo + c >= c_hi) continue;
+            const int i = (c_lo + c) * 64 + lane;
+            const int rid = hbase + __popcll(headm[c] & le) - 1, at = ibase + __popcll(inm[c] & lt);
+            if ((inm[c] >> lane) & 1ull) s_dc[at] = rd[c];
+            if ((headm[c] >> lane) & 1ull) {
+                const uint32_t fl = (((cutm >> c) & 1u) ? RF_UNUSABLE : 0u) | (((alonem >> c) & 1u) ? RF_ALONE : 0u);
+                s_rrow[rid] = (uint16_t)(i | (fl << F_ROW_BITS));
+                s_rpos[rid] = rp[c];
+                s_rc0[rid] = (uint16_t)at;
+                if ((alonem >> c) & 1u) {           // (the block's first run)
+                    while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+                    s_bfirst[bj] = (int16_t)rid;
+                }
+            }
+            hbase += __popcll(headm[c]); ibase += __popcll(inm[c]);
+        }
+        if (tid == 0) { s_rc0[n_runs] = (uint16_t)n_in; s_rrow[n_runs] = (uint16_t)nst; s_ro[n_runs] = 0; }
+        lds_barrier();
+    }
+    // ---- the mean of every run (its rows in file order, NumPy's pairwise order: np.mean, :186; values fl(d / 1e4), :286) and its
+    // site: the first 'M' of meth_ref[p : p + k] (:176, :270) from two words of the block's strand mask -- the words of all runs
+    // of a thread set out before the first mean is begun ----
+    constexpr int RPT = (FR + F_THREADS - 1) / F_THREADS;       // runs per thread (strided), at most
+    uint32_t wlo[RPT], whi[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int R = tid + u * F_THREADS;
+        wlo[u] = whi[u] = 0u;
+        if (R < n_runs) {
+            const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
+            int bj = 0;
+            while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
+            const FBlock &B = s_blk[bj];
+            const int p = s_rpos[R];
+            const int pw = ((p >= 0 && p < B.contig_len) ? max(p - 1, 0) : 0) >> 5;     // (two zero words lie behind every contig's mask)
+            const uint32_t *g = (B.rev ? A.R.mr : A.R.mf) + B.mask_off + pw;
+            wlo[u] = g[0];
+            whi[u] = g[1];
+        }
+    }
+    // the special closers of the piece: what the first unfiltered row of a name block, the head of its first run, and the end
+    // of the shard close -- one thread per block, beside the means of the others
+    if (tid <= nblk) {
+        const int j = tid;
+        FSpec e1, e2;
+        e1.kind = e2.kind = 0;
+        e1.ns = e2.ns = 0; e1.r = e2.r = e1.cr = e2.cr = 0; e1.m = e2.m = e1.nb = e2.nb = 0;
+        if (j < nblk) {
+            const FBlock &B = s_blk[j];
+            if (!(B.xflags & 0x80u) && B.end > i_piece) {            // (not filtered; overlaps the piece)
+                const int fr = s_bfirst[j];
+                const int frow = fr >= 0 ? (int)(s_rrow[fr] & ((1 << F_ROW_BITS) - 1)) : nst;
+                // the block's first unfiltered row.  (A run of the block that begins in front of the piece: the row lies in front
+                // of the piece too, and belongs to the piece before -- the usual case, nothing is loaded for it)
+                if (!(frow < i_piece)) {
+                    int64_t c = T.nb_row_begin[B.id];
+                    const int64_t cend = h0 + B.end;
+                    while (c < cend && (T.flags[c] & MC_F_MODEL_N)) ++c;
+                    if (c >= s0 && c < cend && c < s1) {
+                        const Closed cl = closed_by(A, c, B.id, 0);
+                        if (cl.kind) { e1.kind = (uint8_t)cl.kind; e1.r = cl.r; e1.cr = c; e1.m = cl.m; e1.nb = cl.nb; e1.ns = 1; }
+                    }
+                }
+                // the head of its first run closes the '+' window of a palindromic first site row (R5; that row is first - 1):
+                // if nothing but 'N' rows lies between the two
+                if ((B.xflags & 2u) && (B.xflags & 0x40u) && fr >= 0 && frow >= i_piece) {
+                    const NbDesc *dp = A.desc + B.id;
+                    const int64_t xr = dp->row_begin + dp->first_delta - 1;
+                    int64_t r = h0 + frow - 1;
+                    while (r > xr && (T.flags[r] & MC_F_MODEL_N)) --r;
+                    if (r == xr) { e2.kind = 2; e2.r = xr; e2.cr = h0 + frow; e2.m = B.extra_mpos; e2.nb = B.id; e2.ns = 0; }
+                }
+            }
+        } else if (at_eof) {
+            const Closed cl = closed_by(A, T.n_rows, T.n_nb, 0);
+            if (cl.kind) { e1.kind = (uint8_t)cl.kind; e1.r = cl.r; e1.cr = T.n_rows; e1.m = cl.m; e1.nb = cl.nb; e1.ns = 1; }
+        }
+        s_spec[2 * j] = e1;
+        if (j < nblk) s_spec[2 * j + 1] = e2;
+        if (e1.kind | e2.kind) s_anyspec = 1;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int R = tid + u * F_THREADS;
+        if (R >= n_runs) continue;
+        double mean = 0.0;
+        uint32_t rf = 0;
+        const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
+        const int d0 = s_dc[c0], d1 = s_dc[c0 + 1], d2 = s_dc[c0 + 2], d3 = s_dc[c0 + 3];     // (there is room behind the last row)
+        if (n > 128) { rf = RF_UNUSABLE; mean = 0.0; }          // NumPy's pairwise recursion proper: the row-by-row kernel
+        else if (n >= 8) {
+            const int n8 = n - (n % 8);
+            double r[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) r[v] = 0.0;
+            for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) r[v] += div1e4(s_dc[c0 + j + v]);
+            }
+            double acc = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (int j = n8; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
+            mean = (0.0 + acc) / (double)n;
+        } else {
+            // (every second run is one event: fl(d / 1e4) over 1 -- no division, and narrow by construction)
+            double acc = -0.0 + div1e4(d0);
+            if (n > 1) acc += div1e4(d1);
+            if (n > 2) acc += div1e4(d2);
+            if (n > 3) acc += div1e4(d3);
+            for (int j = 4; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
+            mean = 0.0 + acc;
+            if (n > 1) mean = mean / (double)n;
+        }
+        if (n > 1 && n <= 128) {
+            int32_t as_int;
+            if (!slot_is_narrow(mean, &as_int)) rf |= RF_WIDE;
+        }
+        s_mean[R] = mean;
+        if (rf) s_rrow[R] |= (uint16_t)(rf << F_ROW_BITS);
+        // the site
+        const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
+        int bj = 0;
+        while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
+        const int p = s_rpos[R], L = s_blk[bj].contig_len;
+        uint32_t code = 0;
+        if (p >= 0 && p < L) {
+            const int sh = p - ((max(p - 1, 0) >> 5) << 5);                 // bit of position p in whi:wlo (0 .. 32)
+            const uint64_t W = (((uint64_t)whi[u] << 32) | wlo[u]) >> sh;
+            const uint32_t bits = (uint32_t)W & ((1u << k) - 1u);
+            if (bits) {
+                const int o = __ffs(bits) - 1;
+                // the position behind the site in the read's direction: m + 1, on the reverse strand m - 1 (context[k], :197)
+                const int at_bit = s_blk[bj].rev ? sh + o - 1 : sh + o + 1;
+                const uint32_t next = at_bit >= 0 ? (uint32_t)(((((uint64_t)whi[u] << 32) | wlo[u]) >> at_bit) & 1ull) : 0u;
+                code = (uint32_t)(o + 1) | (next << 7);
+            }
+        }
+        s_ro[R] = (uint8_t)code;
+    }
+    lds_barrier();
+    // ---- the closers of the piece, in row order: run R' closes the window of run R' - 1 of its block iff its head lies beyond that
+    // run's site (:179); in front of a block's first run what the special closers of the block close.  Counted per thread over
+    // consecutive runs, numbered across the workgroup, listed (the events' room is free now) ----
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_dc);
+    const int rpt = (n_runs + 1 + F_THREADS - 1) / F_THREADS;   // (n_runs itself: where the specials behind the last run go)
+    const int R_lo = tid * rpt, R_hi = min(R_lo + rpt, n_runs + 1);
+    // a block without a run of its own: its specials go in front of the next block's first run
+    if (tid == 0) {
+        int next = n_runs;
+        s_bfirst[nblk] = (int16_t)n_runs;
+        for (int j = nblk - 1; j >= 0; --j) {
+            if (s_bfirst[j] < 0) s_bfirst[j] = (int16_t)next;
+            next = s_bfirst[j];
+        }
+    }
+    lds_barrier();
+    const int n_spec = s_anyspec ? 2 * nblk + 1 : 0;       // (one piece in twenty has a special closer)
+    auto closes = [&](int Rc) -> bool {           // run Rc (0 < Rc < n_runs) closes the window of the run before it
+        const uint32_t rr = s_rrow[Rc];
+        if ((rr >> F_ROW_BITS) & RF_ALONE) return false;
+        if ((int)(rr & ((1 << F_ROW_BITS) - 1)) < i_piece) return false;
+        const int o1 = (int)(s_ro[Rc - 1] & 15u);
+        return o1 != 0 && s_rpos[Rc] - s_rpos[Rc - 1] > o1 - 1;
+    };
+    int mine = 0;
+    for (int Rc = R_lo; Rc < R_hi; ++Rc) {
+        for (int e = 0; e < n_spec; ++e)
+            if (s_spec[e].kind && (int)s_bfirst[e >> 1] == Rc) ++mine;
+        if (Rc > 0 && Rc < n_runs && closes(Rc)) ++mine;
+    }
+    int n_win;
+    int rank = wg_exclusive_scan(mine, lane, wave, s_scan, n_win);
+    if (n_win > cap) { if (tid == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+    for (int Rc = R_lo; Rc < R_hi; ++Rc) {
+        for (int e = 0; e < n_spec; ++e)
+            if (s_spec[e].kind && (int)s_bfirst[e >> 1] == Rc) s_list[rank++] = (uint16_t)(0x8000u | (unsigned)e);
+        if (Rc > 0 && Rc < n_runs && closes(Rc)) s_list[rank++] = (uint16_t)Rc;
+    }
+    lds_barrier();
+    // ---- a window per thread ----
+    const uint32_t kbits = (1u << k) - 1u;
+    for (int w = tid; w < n_win; w += F_THREADS) {
+        const int64_t q = q0 + w;
+        const unsigned ent = s_list[w];
+        if (ent & 0x8000u) {
+            const FSpec &S = s_spec[ent & 0x7FFFu];
+            if (S.kind == 2) write_extra(A, q, S.m, T.nb_seg_begin[S.nb], S.cr, !S.ns && A.desc[S.nb].extra_multi());
+            else leave_to_rare(A, sorted, q, S.r, S.m, S.nb, S.cr);
+            continue;
+        }
+        const int Rc = (int)ent, R = Rc - 1;
+        const int hrow = s_rrow[Rc] & ((1 << F_ROW_BITS) - 1);
+        int bj = 0;
+        while (bj + 1 < nblk && hrow >= s_blk[bj].end) ++bj;
+        const FBlock &B = s_blk[bj];
+        const uint32_t code = s_ro[R];
+        const int o = (int)(code & 15u) - 1, m = s_rpos[R] + o;
+        const bool rev = B.rev;
+        // context[k], the character behind the 'M' (:197): marked too, or the base (complemented on the reverse strand)
+        const int64_t L = B.contig_len;
+        const bool edge = m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L;
+        const int at = edge ? 0 : (rev ? m - 1 : m + 1);
+        const int64_t seq_base = B.seq_delta != NO_SEQ_DELTA ? 32 * B.mask_off + B.seq_delta : A.R.seq_off[B.contig];
+        uint32_t base_ch = A.R.seq[seq_base + at];
+        bool rare = (B.stray_q != NO_STRAY) && m - B.stray_q >= 0 && m - B.stray_q < k;        // (the stray event of R5 is first in its slot)
+        uint32_t have = 0, wide = 0;
+        const int lb = B.lb;
+        for (int t = 0; t < k && !rare; ++t) {
+            const int Rt = R - t;
+            if (Rt < 0) { if (lb < 0) rare = true; break; }         // (the window reaches behind the rows in front)
+            const uint32_t rr = s_rrow[Rt];
+            if ((int)(rr & ((1 << F_ROW_BITS) - 1)) < max(lb, 0)) break;            // a run of the block before
+            const int slot = m - s_rpos[Rt];
+            if (slot > k - 1) break;
+            const uint32_t rf = rr >> F_ROW_BITS;
+            if (rf & RF_UNUSABLE) { rare = true; break; }
+            if (slot < 0) continue;
+            A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];            // :187-188 (a window that turns out rare is written again)
+            have |= 1u << slot;
+            if (rf & RF_WIDE) wide |= 1u << slot;
+        }
+        const int64_t cr = h0 + hrow;
+        if (rare) {                                 // (the row-by-row kernel: the window's last row is the unfiltered row before the closer)
+            int64_t r = cr - 1;
+            while (r > 0 && (T.flags[r] & MC_F_MODEL_N)) --r;
+            leave_to_rare(A, sorted, q, r, m, B.id, cr);
+            continue;
+        }
+        const uint32_t empties = ~have & kbits;
+        const bool too_many = __popc(empties) > A.skip_thresh;
+        uint32_t info = rev ? MC_I_REV : 0u, wmask = 0;
+        for (uint32_t z = too_many ? kbits : empties; z; z &= z - 1u) {
+            const int s = __ffs(z) - 1;
+            A.O.feats[q * k + (rev ? s : k - 1 - s)] = 0.0;
+        }
+        if (too_many) info |= MC_I_TOO_MANY;
+        else {
+            wmask = rev ? wide : __brev(wide) >> (32 - k);
+            info |= rev ? empties : __brev(empties) >> (32 - k);   // feature dst came from an empty slot (:186)
+            if (edge) info |= MC_I_EDGE;                           // the 2k-1 context leaves the contig: Python slicing decides
+            else {
+                const unsigned char ch = (code & 0x80u) ? 'M' : (rev ? comp_char((unsigned char)base_ch) : (unsigned char)base_ch);
+                info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
+            }
+        }
+        // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
+        if (s_rpos[Rc] <= m + A.skip_thresh + 1 && (s_ro[Rc] & 15u) > 1u) info |= MC_I_MULTI;
+        A.O.wmask[q] = (uint8_t)wmask;
+        A.O.site_pos[q] = m;
+        A.O.site_seg[q] = B.seg;
+        A.O.close_row[q] = cr;
+        A.O.info[q] = info;
+        A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+}
+
+}  // namespace
+
+// room per piece for a reference with `density` marked positions per position and strand: what guess_capacity() assumes per
+// row (a window closes about once per marked site a read covers, ~0.52 positions per row), twice over, in whole sixteens
+int mc_fused_room(double density) {
+    const int want = (int)(FT * density * 0.52 * 2.0) + 48;
+    return std::min(FT + 2 * F_MAXB + 2, (want + 15) & ~15);
+}
+int mc_fused_room_max(void) { return FT + 2 * F_MAXB + 2; }
+int64_t mc_fused_pieces(const DevTable &T) { return T.n_tiles * (TILE / FT); }
+
+void mc_launch_fused(const K1Args &A, Payload *sorted, int cap, bool validate, hipStream_t st, hipEvent_t stop) {
+    const dim3 grid((unsigned)mc_fused_pieces(A.T));
+    if (validate) {
+        if (stop) hipExtLaunchKernelGGL(k1_fused<true>, grid, dim3(F_THREADS), 0, st, nullptr, stop, 0, A, sorted, cap);
+        else hipLaunchKernelGGL(k1_fused<true>, grid, dim3(F_THREADS), 0, st, A, sorted, cap);
+    } else {
+        if (stop) hipExtLaunchKernelGGL(k1_fused<false>, grid, dim3(F_THREADS), 0, st, nullptr, stop, 0, A, sorted, cap);
+        else hipLaunchKernelGGL(k1_fused<false>, grid, dim3(F_THREADS), 0, st, A, sorted, cap);
+    }
+}

@@ -189,6 +189,9 @@ struct mc_ctx {
     Counters *cnt = nullptr;
     int last_k = 0;
     int64_t last_n = 0;
+    int64_t last_slots = 0;        // record slots the records handed out last occupy on the device (a fused dense pass: with holes in between)
+    int last_fused_room = 0, last_rerun = 0;   // how the pass handed out last ran (mc_last_pass_info)
+    int fused_scale = 1;           // the fused dense pass (k1_fused): room per piece x this (doubled when a piece ran out of room)
     int64_t ref_total_len = 0;    // bases of the marked reference (record capacity guess)
     float times[5] = {0, 0, 0, 0, 0};
     std::vector<void *> ref_allocs, mlp_allocs, rec_allocs;
@@ -220,6 +223,8 @@ struct mc_ctx {
         int64_t cap = 0, n_nb = 0;
         int k = 0;
         bool used = false, copying = false, timed = true;
+        int fused_room = 0;        // > 0: the pass ran as ONE kernel (k1_fused) with this many record slots per piece -- holes in between
+        int64_t slots = 0;         // ... record slots in all
         int slot = -1;             // table slot the pass scans
         unsigned long long pass_no = 0;   // what Counters.irregular_pass holds if the pass classified a block irregular
         const double *qual = nullptr;   // read qualities it was enqueued with
@@ -1436,7 +1441,7 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
                       hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
-                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr) {
+                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr, int fused_room = 0) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
@@ -1454,6 +1459,16 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.shard_shift = T.n_tiles >= 1024 ? 6 : 3;
     A.shard_mask = (1 << A.shard_shift) - 1;
     static_assert(NSHARD == 64, "shard_shift");
+    if (fused_room > 0) {
+        // a dense reference, a pipelined pass: scan, ordering and emit as ONE kernel with fixed room per piece (k1_fused,
+        // mc_fused.hip); the pass's event rides on its dispatch packet
+        hipEvent_t on_packet = (ev_emit_end && MC_EVENTS_ON_KERNELS) ? ev_emit_end : nullptr;
+        mc_launch_fused(A, sorted, fused_room, plan.scan_mode == SCAN_VALIDATE, st, on_packet);
+        if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
+        if (ev_emit_end && !on_packet) HIP_TRY(hipEventRecord(ev_emit_end, st));
+        *out_args = A;
+        return 0;
+    }
     mc_launch_scan(A, dense, plan.scan_mode, st);
     if (ev_scan_end) HIP_TRY(hipEventRecord(ev_scan_end, st));
     mc_launch_group_scan(c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum, st);
@@ -1526,6 +1541,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
     const int k = prm->k;
     if (int rc = check_pass(c, prm)) return rc;
     c->last_n = 0;
+    c->last_slots = 0;
     if (T.n_rows == 0 || T.n_nb == 0) return 0;
     if (c->ab_count) { if (int rc = sync_pass_streams(c)) return rc; }   // pipelined passes share the scratch: let them finish
     if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
@@ -1577,6 +1593,7 @@ extern "C" int mc_extract_features(mc_ctx *c, const mc_params *prm, int64_t *n_r
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
         HIP_TRY(hipEventElapsedTime(&c->times[4], c->ev[0], c->ev[4]));
         c->last_n = n;
+        c->last_slots = n;
         *n_records = n;
         return 0;
     }
@@ -1712,8 +1729,9 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
 // count: the chunk counts are not there yet (the emit counts them as it writes the records, except k1_emit_runs)
 static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b, bool count) {
     hipStream_t s2 = c->side_stream;
-    if (count) mc_launch_pack_count(b.O, b.cnt, b.k, b.chunk_cnt, s2);
-    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
+    const int holes = b.fused_room > 0 ? 1 : 0;
+    if (count) mc_launch_pack_count(b.O, b.cnt, b.k, b.chunk_cnt, holes, s2);
+    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev, holes, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
     if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_done, s2));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1735,12 +1753,25 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
         memset(b.st_host, 0, sizeof(Counters));
         b.pass_no = ++c->pass_counter;
         b.used = false;
+        b.fused_room = 0; b.slots = 0;
         b.slot = -1;
         c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
         c->ab_count += 1;
         return 0;
     }
-    const int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
+    int64_t cap = std::max<int64_t>(guess_capacity(c), c->Omain.capacity);
+    // A dense reference (a one-base motif): the pass as ONE kernel with fixed room per piece of the table, holes in between
+    // (k1_fused; MCALLER_DENSE_FUSED=0: the scan + emit pair, which the synchronous interface and every repeated pass keep)
+    const bool fused_wanted = !(getenv("MCALLER_DENSE_FUSED") && atoi(getenv("MCALLER_DENSE_FUSED")) == 0) && !getenv("MCALLER_NO_EMIT_RUNS");
+    int fused_room = 0;
+    if (fused_wanted && dense_reference(c)) {
+        const double density = (double)c->R.n_sites / (2.0 * (double)c->ref_total_len);
+        if (const char *e = getenv("MCALLER_FUSED_ROOM")) fused_room = std::max(1, atoi(e));        // (tests: force the overflow path)
+        else fused_room = (int)std::min<int64_t>(mc_fused_room_max(), (int64_t)mc_fused_room(density) * c->fused_scale);
+        cap = std::max<int64_t>(cap, mc_fused_pieces(T) * fused_room);
+    }
+    b.fused_room = fused_room;
+    b.slots = fused_room > 0 ? mc_fused_pieces(T) * fused_room : 0;
     if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
@@ -1773,7 +1804,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt)) return rc;
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room)) return rc;
     if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b, A.chunk_cnt == nullptr)) return rc;
@@ -1882,6 +1913,10 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     if (special && getenv("MCALLER_VERBOSE"))
         fprintf(stderr, "mcaller_hip: pass re-run synchronously (overflow %u, irregular %u, big %u, rare %u, records %llu)\n",
                 st.overflow, (unsigned)(st.irregular_pass == b.pass_no), st.n_big, st.n_rare, st.n_records);
+    c->last_fused_room = b.used ? b.fused_room : 0;
+    c->last_rerun = special ? 1 : 0;
+    if (special && st.overflow && b.fused_room > 0 && b.fused_room < mc_fused_room_max())
+        c->fused_scale = std::min(c->fused_scale * 2, 64);       // (a piece ran out of room: twice the room from the next pass on)
     if (special) {
         // a pass the fast path alone cannot finish (record buffers too small, irregular reads):
         // run it again through mc_extract_features, which handles all of that, and hand out its buffers
@@ -1913,6 +1948,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     }
     c->O = b.O;                    // what mc_site_counts reduces: the records of the pass just handed out
     c->last_n = n;
+    c->last_slots = b.fused_room > 0 ? std::min<int64_t>(b.slots, b.cap) : n;
     c->last_k = b.k ? b.k : c->last_k;
     *n_records = n;
     out->capacity = n;
@@ -1927,6 +1963,12 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->feats_wide = packed ? b.h_wmask : nullptr;
     out->n_wide = packed ? b.h_n_wide : 0;
     out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
+    return 0;
+}
+
+extern "C" int mc_last_pass_info(mc_ctx *c, int32_t *fused_room, int32_t *rerun) {
+    if (fused_room) *fused_room = c->last_fused_room;
+    if (rerun) *rerun = c->last_rerun;
     return 0;
 }
 
@@ -2102,7 +2144,7 @@ extern "C" int mc_site_counts_accumulate(mc_ctx *c, int64_t row_offset, int32_t 
         mc_set_error("mc_site_counts_accumulate: call mc_site_counts_reset first (after the reference has been set)");
         return -12;
     }
-    const int64_t ns = c->R.n_sites, n = c->last_n;
+    const int64_t ns = c->R.n_sites, n = c->last_slots;      // (every slot: a hole is a record that is not a call)
     if (n > 0)
         hipLaunchKernelGGL(k_site_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->site_stream, c->R, c->O, n,
                            c->last_T.seg_contig ? c->last_T : c->T, (int)tail_contig, row_offset, c->site_cnt,

@@ -260,6 +260,13 @@ class Device(object):
     def last_pass_timed(self):
         return bool(lib().mc_last_pass_timed(self._ctx))
 
+    def last_pass_info(self):
+        """(record slots per piece if the pass handed out last ran as the fused dense kernel, else 0; whether it was repeated
+        synchronously inside wait())."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        check(lib().mc_last_pass_info(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, bool(b.value)
+
     def times_ms(self):
         t = np.zeros(5, dtype=np.float32)
         check(lib().mc_last_times_ms(self._ctx, _ptr(t)))

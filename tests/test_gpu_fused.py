@@ -1,0 +1,166 @@
+"""The fused pass of a dense reference (k1_fused, mcaller_amd/csrc/mc_fused.hip): scan, ordering and emit of a pipelined pass over
+a one-base motif as ONE kernel with fixed room per 1024-row piece -- against the C oracle (the literal sequential machine,
+extract_contexts.py:147-291), through the C ABI.  Every comparison also asks the library HOW the pass ran (mc_last_pass_info):
+a pass that fell back to the scan + emit pair would pass these tests without testing anything.  Runs on a real MI355X only."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dev():
+    from mcaller_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def wait_fused(dev, orc, k, expect_fused=True, prob_tol=None):
+    rec = dev.wait()
+    room, rerun = dev.last_pass_info()
+    if expect_fused:
+        assert room > 0 and not rerun, (room, rerun)
+    if prob_tol is None:
+        rec.prob[:rec.n] = np.nan
+        orc.prob[:orc.n] = np.nan
+        H.assert_records_equal(rec, orc, k)
+    else:
+        H.assert_records_equal(rec, orc, k, prob_tol=prob_tol)
+    return rec
+
+
+@pytest.mark.parametrize('read_len,n_rows,skip,k', [((3000, 20000), 300000, 0, 6), ((40, 300), 200000, 0, 6), ((300, 1500), 150000, 1, 6),
+                                                    ((8, 60), 60000, 0, 6), ((1000, 5000), 120000, 2, 7), ((500, 4000), 100000, 0, 4),
+                                                    ((2000, 9000), 131072 + 17, 0, 8), ((600, 2500), 4096, 1, 5), ((100, 900), 1025, 0, 1)])
+def test_fused_pass_equals_the_oracle(dev, read_len, n_rows, skip, k):
+    """Long reads (one name block per piece), short reads (three and more per piece, pieces with more blocks than the table holds:
+    the row-per-lane walk), every window length, skips allowed; as a table's first pass (validating), as a later pass, and the
+    validating pass again with two in flight."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=150000, seed=61 + k)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(n_rows, seed=6100 + read_len[0] + skip, codes=codes, read_len=read_len)
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, k, skip, 0.0)
+    assert orc.n > n_rows // 40
+    dev.set_reference(arrays)
+    slot = dev.upload_table_async(table, qual)
+    dev.run_async(k, skip, 0.0, score=False)                     # the table's first pass: k1_fused<validating>
+    wait_fused(dev, orc, k)
+    dev.run_async(k, skip, 0.0, score=False)                     # a validated table: k1_fused<false>
+    wait_fused(dev, orc, k)
+    dev.select_table(slot, as_new=True)
+    dev.run_async(k, skip, 0.0, score=False)
+    dev.run_async(k, skip, 0.0, score=False)
+    wait_fused(dev, orc, k)
+    wait_fused(dev, orc, k)
+
+
+def test_fused_pass_with_quality_filter_and_tail(dev):
+    """Reads dropped by the quality threshold (their rows are nobody's closers), and the first row of the next shard closing
+    the table's last window (tail_contig >= 0: R6, R8)."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=100000, seed=77)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(90000, seed=771, codes=codes, read_len=(200, 2500))
+    arrays = ref.device_arrays()
+    dev.set_reference(arrays)
+    dev.upload_table_async(table, qual)
+    for qthr, tail in ((9.0, -1), (0.0, 0), (10.5, 0)):
+        orc = H.oracle_records(table, arrays, qual, 6, 0, qthr, tail_contig=tail)
+        dev.run_async(6, 0, qthr, tail_contig=tail, score=False)
+        wait_fused(dev, orc, 6)
+
+
+def test_fused_pass_scored_and_site_counts(dev):
+    """The classifier and the per-site reduction behind a fused pass: holes are skipped like any record that is not a call, the
+    host never sees one (record count, probabilities, per-site counts as from the oracle's records)."""
+    from mcaller_amd import synth, make_bed
+    from mcaller_amd.extract_contexts import submodel_setup
+    from mcaller_amd.model_io import load_model_file, shipped_model
+    codes = synth.genome(length=80000, seed=5)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(120000, seed=51, codes=codes, read_len=(1500, 6000))
+    arrays = ref.device_arrays()
+    _, weights, _, soc = submodel_setup(load_model_file(shipped_model('r95_twobase_model_NN_6_m6A')), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    dev.set_reference(arrays)
+    dev.set_mlp(weights, soc)
+    dev.upload_table_async(table, qual)
+    dev.run_async(6, 0, 0.0, score=True)
+    rec = wait_fused(dev, orc, 6, prob_tol=1e-9)
+    assert rec.n == orc.n
+    index = make_bed.SiteIndex(ref.meth, 1)
+    want = make_bed.site_counts(orc, table, index)
+    dev.site_counts()
+    n_meth, n_total, first = dev.site_counts_fetch()
+    assert np.array_equal(n_total, want[1]) and np.array_equal(n_meth, want[0])
+    seen = n_total > 0
+    assert np.array_equal(first[seen], want[2][seen])
+
+
+def test_a_piece_out_of_room_repeats_the_pass(dev, monkeypatch):
+    """Fixed room per piece that is too small (forced): the pass is marked, repeated by the scan + emit pair inside wait(), and
+    the records are the oracle's; the next pass gets twice the room."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=60000, seed=9)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(50000, seed=91, codes=codes, read_len=(1000, 4000))
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    dev.set_reference(arrays)
+    dev.upload_table_async(table, qual)
+    monkeypatch.setenv('MCALLER_FUSED_ROOM', '16')
+    dev.run_async(6, 0, 0.0, score=False)
+    rec = wait_fused(dev, orc, 6, expect_fused=False)
+    assert dev.last_pass_info() == (16, True)
+    monkeypatch.delenv('MCALLER_FUSED_ROOM')
+    dev.run_async(6, 0, 0.0, score=False)
+    wait_fused(dev, orc, 6)
+
+
+def test_the_pair_behind_a_knob(dev, monkeypatch):
+    """MCALLER_DENSE_FUSED=0: the scan + emit pair for pipelined passes too (what the synchronous interface always runs)."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=60000, seed=10)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(40000, seed=92, codes=codes, read_len=(1000, 4000))
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    dev.set_reference(arrays)
+    dev.upload_table_async(table, qual)
+    monkeypatch.setenv('MCALLER_DENSE_FUSED', '0')
+    dev.run_async(6, 0, 0.0, score=False)
+    wait_fused(dev, orc, 6, expect_fused=False)
+    assert dev.last_pass_info() == (0, False)
+
+
+def test_fused_pass_at_full_size_dense():
+    """10^7 rows, -m A, scored: the records of the fused pass (the product's streaming interface) equal the oracle's."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    from mcaller_amd.model_io import load_model_file, shipped_model
+    codes = synth.genome()
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(10000000, seed=1234, codes=codes)
+    arrays = ref.device_arrays()
+    _, weights, _, soc = submodel_setup(load_model_file(shipped_model('r95_twobase_model_NN_6_m6A')), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    assert orc.n > 800000
+    d = Device(0)
+    try:
+        d.set_reference(arrays)
+        d.set_mlp(weights, soc)
+        d.upload_table_async(table, qual)
+        d.run_async(6, 0, 0.0, score=True)
+        d.run_async(6, 0, 0.0, score=True)
+        wait_fused(d, orc, 6, prob_tol=1e-9)
+        wait_fused(d, orc, 6, prob_tol=1e-9)
+    finally:
+        d.close()
