@@ -419,6 +419,9 @@ int mc_calls_expand(const mc_calls_view *rec, int64_t n_records, int32_t k, int3
 void mc_free(void *p);
 /* repr(float) == str(np.float64) of one value into out32 (NUL-terminated); returns its length. */
 int mc_repr_double(double v, char *out32);
+/* ... of d / 1e4 for a 32-bit integer d, from the integer alone (how the formatter prints the slot means that travel as
+ * integers, mc_calls_view.feats_lo32): the same characters as mc_repr_double((double)d / 1e4). */
+int mc_repr_fixed4(int32_t d, char *out32);
 
 /* ===== measurement plumbing: a table as nanopolish-eventalign text (13 columns), written by all host cores =====
  * For file-to-file timing on synthetic workloads (bench.py); seq = the contig's bases (k-mers of columns 3 and 10). */

@@ -454,20 +454,47 @@ class DiffsFormatter(object):
         self._args = a
 
     def rows(self, first, n_threads=0):
-        """-> (bytes, number of rows, stop): stop < n means record `stop` needs the host's own handling."""
+        """-> (rows as a bytes-like object, number of rows, stop): stop < n means record `stop` needs the host's own handling.
+        The rows stay in the buffer the library made (a one-base motif writes a gigabyte of them per 10^8 events: no copy into a
+        bytes object here, none when they are joined -- whoever writes them hands the buffer to write())."""
         text, nb, nr, stop = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(lib().mc_format_diffs(C.byref(self._args), int(first), int(n_threads), C.byref(text), C.byref(nb),
                                     C.byref(nr), C.byref(stop)))
+        return LibBuffer(text, nb.value), nr.value, stop.value
+
+
+class LibBuffer(object):
+    """Bytes the library allocated (mc_free releases them when this object goes): `view` is a memoryview over them."""
+
+    def __init__(self, ptr, n):
+        self._ptr, self.n = ptr, int(n)
+        self.view = memoryview((C.c_char * self.n).from_address(ptr.value)).cast('B') if self.n else memoryview(b'')
+
+    def __len__(self):
+        return self.n
+
+    def __bytes__(self):
+        return self.view.tobytes()
+
+    def __del__(self):
         try:
-            blob = C.string_at(text, nb.value)
-        finally:
-            lib().mc_free(text)
-        return blob, nr.value, stop.value
+            if self._ptr is not None and self._ptr.value:
+                self.view.release()
+                lib().mc_free(self._ptr)
+        except Exception:       # noqa (interpreter shutdown)
+            pass
+        self._ptr = None
 
 
 def repr_double(x):
     buf = C.create_string_buffer(40)
     lib().mc_repr_double(float(x), buf)
+    return buf.value.decode()
+
+
+def repr_fixed4(d):
+    buf = C.create_string_buffer(40)
+    lib().mc_repr_fixed4(int(d), buf)
     return buf.value.decode()
 
 

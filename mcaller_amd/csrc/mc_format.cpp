@@ -72,6 +72,29 @@ inline char *put_repr(char *o, double v) {
     return o;
 }
 
+// repr(d / 1e4) for a 32-bit integer d without a floating-point conversion: a decimal of at most ten significant digits IS the
+// shortest string that round-trips to its double (two decimals of up to 15 digits never share a double), so the digits of d with
+// the point four places from the right, trailing zeros dropped, ".0" for an integer -- |d / 1e4| < 214748.4 and >= 0.0001 keep
+// Python out of the exponent form.  53 % of the slot means of the headline workload and every one-event slot travel as such a d
+// (k_pack, mc_calls_view.feats_lo32): six of these per row were half of the formatter's time.
+inline char *put_fixed4(char *o, int32_t d) {
+    uint32_t a = d < 0 ? (uint32_t)(-(int64_t)d) : (uint32_t)d;
+    if (d < 0) *o++ = '-';
+    const uint32_t ip = a / 10000u, fp = a % 10000u;
+    char tmp[12];
+    int n = 0;
+    uint32_t v = ip;
+    do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (n) *o++ = tmp[--n];
+    *o++ = '.';
+    if (fp == 0) { *o++ = '0'; return o; }
+    char f4[4] = {(char)('0' + fp / 1000u), (char)('0' + fp / 100u % 10u), (char)('0' + fp / 10u % 10u), (char)('0' + fp % 10u)};
+    int nf = 4;
+    while (f4[nf - 1] == '0') --nf;
+    memcpy(o, f4, (size_t)nf);
+    return o + nf;
+}
+
 inline char *put_int(char *o, long long v) {
     const auto r = std::to_chars(o, o + 24, v);
     return r.ptr;
@@ -174,6 +197,23 @@ struct RowCursor {
         if (rec->call_row) return rec->call_row[j];
         return (info & MC_I_TOO_MANY) ? -1 : kept++;
     }
+    // the k slot means of call row `row` (rows in ascending order) for printing: bit s of the result set <=> slot s travels as the
+    // integer d[s] = value x 1e4 (printed by put_fixed4), else f[s] holds the double
+    unsigned feats_for_print(int64_t row, int k, double *f, int32_t *d) {
+        if (rec->feats) { memcpy(f, rec->feats + row * k, (size_t)k * sizeof(double)); return 0u; }
+        if (!wide_known) { wide = wide_before(rec, row); wide_known = true; }
+        const unsigned mask = rec->feats_wide[row];
+        const int32_t *lo = rec->feats_lo32 + row * k;
+        for (int s = 0; s < k; ++s) {
+            if ((mask >> s) & 1u) {
+                const uint64_t bits = ((uint64_t)rec->feats_hi32[wide++] << 32) | (uint32_t)lo[s];
+                memcpy(&f[s], &bits, 8);
+            } else {
+                d[s] = lo[s];
+            }
+        }
+        return ~mask & ((1u << k) - 1u);
+    }
     // the k slot means of call row `row` (rows must come in ascending order) into f[]
     void feats(int64_t row, int k, double *f) {
         if (rec->feats) { memcpy(f, rec->feats + row * k, (size_t)k * sizeof(double)); return; }
@@ -191,16 +231,9 @@ struct RowCursor {
     }
 };
 
-inline bool native_ok(const mc_format_args *a, int64_t j, RowCursor &cur) {
-    const uint32_t info = a->rec->info[j];
-    const int64_t row = cur.row(j, info);
-    if (info & MC_I_TOO_MANY) return true;               // no text
-    if (std::isnan(a->rec->prob[row])) return false;
-    char ctx[2 * MC_MAX_K];
-    return build_context(a, j, ctx);
-}
-
-void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_t &n_rows) {
+// rows of records [j0, j1) into `out`; -> the first record the host must handle itself (a context that leaves the contig, an
+// unscored record, ...: the rows before it are in `out`), or j1
+int64_t format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_t &n_rows) {
     const mc_format_args *a = J.a;
     const mc_calls_view *rec = a->rec;
     const mc_table_view *t = a->table;
@@ -209,13 +242,20 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
     size_t used = 0;
     n_rows = 0;
     RowCursor cur(rec, j0);
-    for (int64_t j = j0; j < j1; ++j) {
+    int32_t cseg = -1;                  // (the closing rows of consecutive records ascend: the segment is carried along)
+    int64_t j = j0;
+    for (; j < j1; ++j) {
         const uint32_t info = rec->info[j];
         const int64_t row = cur.row(j, info);                                      // (compacted views: mc_wait_records)
         if (info & MC_I_TOO_MANY) continue;
+        if (std::isnan(rec->prob[row])) break;                                     // (scored by the host)
         const int32_t seg = rec->site_seg[j];
         const int32_t rid = t->seg_read[seg];
-        const int32_t cseg = seg_of_row(t, close_row_of(rec, j));
+        const int64_t crow = close_row_of(rec, j);
+        if (cseg < 0 || crow < t->seg_row_begin[cseg] || (cseg < t->n_seg && crow >= t->seg_row_begin[cseg + 1])) {
+            if (cseg >= 0 && cseg + 1 < t->n_seg && crow >= t->seg_row_begin[cseg + 1] && crow < t->seg_row_begin[cseg + 2]) ++cseg;
+            else cseg = seg_of_row(t, crow);
+        }
         const char *chrom;
         size_t chrom_len;
         if (cseg >= t->n_seg) { chrom = a->tail_chrom; chrom_len = J.tail_len; }     // R8: the closing row's contig
@@ -230,14 +270,16 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         o = put_str(o, chrom, chrom_len); *o++ = '\t';
         o = put_str(o, a->read_names[rid], J.name_len[(size_t)rid]); *o++ = '\t';
         o = put_int(o, rec->site_pos[j]); *o++ = '\t';
-        build_context(a, j, o);
+        if (!build_context(a, j, o)) break;                                        // (the host's own handling: nothing of this row is kept)
         o += 2 * k - 1;
         *o++ = '\t';
         const uint32_t empty = info & MC_I_EMPTY_MASK;
         double f[MC_MAX_K];
-        cur.feats(row, k, f);
+        int32_t d[MC_MAX_K];
+        const unsigned as_int = cur.feats_for_print(row, k, f, d);
         for (int i = 0; i < k; ++i) {
             if ((empty >> i) & 1u) *o++ = '0';                                     // literal int 0  (:186)
+            else if ((as_int >> i) & 1u) o = put_fixed4(o, d[i]);
             else o = put_repr(o, f[i]);
             *o++ = ',';
         }
@@ -247,12 +289,19 @@ void format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_
         if (p1 >= 0.5) o = put_str(o, a->label_meth, J.lab_pos_len);               // :200-206
         else o = put_str(o, a->label_unmeth, J.lab_neg_len);
         *o++ = '\t';
-        o = put_repr(o, std::nearbyint(p1 * 100.0) / 100.0);                       // np.round(p, 2)  (:207)
+        // np.round(p, 2) (:207): an integer number of hundredths, printed as such
+        const double h = std::nearbyint(p1 * 100.0);
+        if (h >= 0.0 && h <= 100.0) {
+            const int hi = (int)h;
+            if (hi == 100) { memcpy(o, "1.0", 3); o += 3; }
+            else { *o++ = '0'; *o++ = '.'; *o++ = (char)('0' + hi / 10); if (hi % 10) *o++ = (char)('0' + hi % 10); }
+        } else o = put_repr(o, h / 100.0);
         *o++ = '\n';
         used = (size_t)(o - buf.data());
         ++n_rows;
     }
     out.append(buf.data(), used);
+    return j;
 }
 
 }  // namespace
@@ -271,20 +320,8 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     int nt = n_threads > 0 ? n_threads : mc_host_cores();                 // the cores this process may use
     nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (n - first) / 4096));
 
-    // pass 1: the first record the host must handle itself
-    std::vector<int64_t> stops((size_t)nt, n);
-    auto scan = [&](int w) {
-        const int64_t lo = first + (n - first) * w / nt, hi = first + (n - first) * (w + 1) / nt;
-        RowCursor cur(a->rec, lo);
-        for (int64_t j = lo; j < hi; ++j)
-            if (!native_ok(a, j, cur)) { stops[(size_t)w] = j; return; }
-    };
-    mc_parallel_for(nt, scan);
-    int64_t stop = n;
-    for (int64_t s : stops) stop = std::min(stop, s);
-    *stop_at = stop;
-
-    // pass 2: the rows of [first, stop), pieces in record order
+    // every thread formats its piece of [first, n) and stops at the first record the host must handle itself; the rows before
+    // the first such record of all count, what later pieces formatted is dropped (a handful of records per file end a run)
     Job J;
     J.a = a;
     const mc_table_view *t = a->table;
@@ -300,25 +337,29 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     J.lab_pos_len = strlen(a->label_meth);
     J.lab_neg_len = strlen(a->label_unmeth);
     std::vector<std::string> parts((size_t)nt);
-    std::vector<int64_t> rows((size_t)nt, 0);
+    std::vector<int64_t> rows((size_t)nt, 0), stops((size_t)nt, n);
+    auto piece_lo = [&](int w) { return first + (n - first) * w / nt; };
     auto work = [&](int w) {
-        const int64_t lo = first + (stop - first) * w / nt, hi = first + (stop - first) * (w + 1) / nt;
-        format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w]);
+        const int64_t lo = piece_lo(w), hi = piece_lo(w + 1);
+        parts[(size_t)w].reserve((size_t)(hi - lo) * 96 + 4096);
+        stops[(size_t)w] = format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w]);
     };
     mc_parallel_for(nt, work);
+    int64_t stop = n;
+    int last = nt;                        // pieces [0, last) count
+    for (int w = 0; w < nt; ++w)
+        if (stops[(size_t)w] < piece_lo(w + 1)) { stop = stops[(size_t)w]; last = w + 1; break; }
+    *stop_at = stop;
     size_t total = 0;
-    for (auto &p : parts) total += p.size();
+    std::vector<size_t> at((size_t)last + 1, 0);
+    for (int w = 0; w < last; ++w) { at[(size_t)w] = total; total += parts[(size_t)w].size(); }
     char *outp = (char *)malloc(std::max<size_t>(total, 1));
     if (!outp) {
         mc_set_error("mc_format_diffs: out of memory (%zu bytes)", total);
         return -10;
     }
-    size_t off = 0;
-    for (int w = 0; w < nt; ++w) {
-        memcpy(outp + off, parts[(size_t)w].data(), parts[(size_t)w].size());
-        off += parts[(size_t)w].size();
-        *n_rows += rows[(size_t)w];
-    }
+    mc_parallel_for(last, [&](int w) { memcpy(outp + at[(size_t)w], parts[(size_t)w].data(), parts[(size_t)w].size()); });
+    for (int w = 0; w < last; ++w) *n_rows += rows[(size_t)w];
     *text = outp;
     *n_bytes = (int64_t)total;
     return 0;
@@ -387,6 +428,13 @@ extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t k, i
 }
 
 extern "C" void mc_free(void *p) { free(p); }
+
+// repr(d / 1e4) from the integer alone (tests pin it against Python's)
+extern "C" int mc_repr_fixed4(int32_t d, char *out32) {
+    char *e = put_fixed4(out32, d);
+    *e = 0;
+    return (int)(e - out32);
+}
 
 // repr(float) alone (tests pin it against Python's)
 extern "C" int mc_repr_double(double v, char *out32) {

@@ -99,7 +99,9 @@ __device__ __forceinline__ uint32_t f_row_vflags(int p, int x, int prev_p, int p
 // (looked at only when the two rows share their block).  kind 0: none; 1: the window of site m whose last row is r (block nb);
 // 2: the one-event '+' window of nb's palindromic first site row (R5).
 struct Closed { int kind; int64_t r; int m, nb; bool ns; };
-__device__ __noinline__ Closed closed_by(const K1Args &A, int64_t c, int bc, int c_pos) {
+// (inlined at its three call sites: a call would take the kernel's arguments by reference -- they would be copied to scratch at
+// the kernel's entry and every A.x afterwards would be a scratch load)
+__device__ __forceinline__ Closed closed_by(const K1Args &A, int64_t c, int bc, int c_pos) {
     const DevTable &T = A.T;
     Closed out;
     out.kind = 0; out.r = 0; out.m = 0; out.nb = 0; out.ns = false;
@@ -414,12 +416,11 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     // ---- the mean of every run (its rows in file order, NumPy's pairwise order: np.mean, :186; values fl(d / 1e4), :286) and its
     // site: the first 'M' of meth_ref[p : p + k] (:176, :270) from two words of the block's strand mask -- the words of all runs
     // of a thread set out before the first mean is begun ----
-    constexpr int RPT = (FR + F_THREADS - 1) / F_THREADS;       // runs per thread (strided), at most
-    uint32_t wlo[RPT], whi[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const int R = tid + u * F_THREADS;
-        wlo[u] = whi[u] = 0u;
+    // (a thread's runs are R = tid, tid + 256, ...: the words of the run after the current one are on their way while its mean
+    // is added up -- a loop, not five copies of it: the instruction cache holds the kernel)
+    uint32_t wlo = 0u, whi = 0u;
+    auto site_words = [&](int R, uint32_t &lo, uint32_t &hi) {
+        lo = hi = 0u;
         if (R < n_runs) {
             const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
             int bj = 0;
@@ -428,10 +429,11 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             const int p = s_rpos[R];
             const int pw = ((p >= 0 && p < B.contig_len) ? max(p - 1, 0) : 0) >> 5;     // (two zero words lie behind every contig's mask)
             const uint32_t *g = (B.rev ? A.R.mr : A.R.mf) + B.mask_off + pw;
-            wlo[u] = g[0];
-            whi[u] = g[1];
+            lo = g[0];
+            hi = g[1];
         }
-    }
+    };
+    site_words(tid, wlo, whi);
     // the special closers of the piece: what the first unfiltered row of a name block, the head of its first run, and the end
     // of the shard close -- one thread per block, beside the means of the others
     if (tid <= nblk) {
@@ -473,10 +475,10 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (j < nblk) s_spec[2 * j + 1] = e2;
         if (e1.kind | e2.kind) s_anyspec = 1;
     }
-#pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const int R = tid + u * F_THREADS;
-        if (R >= n_runs) continue;
+#pragma unroll 1
+    for (int R = tid; R < n_runs; R += F_THREADS) {
+        uint32_t nlo, nhi;
+        site_words(R + F_THREADS, nlo, nhi);
         double mean = 0.0;
         uint32_t rf = 0;
         const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
@@ -518,17 +520,18 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         uint32_t code = 0;
         if (p >= 0 && p < L) {
             const int sh = p - ((max(p - 1, 0) >> 5) << 5);                 // bit of position p in whi:wlo (0 .. 32)
-            const uint64_t W = (((uint64_t)whi[u] << 32) | wlo[u]) >> sh;
+            const uint64_t W = (((uint64_t)whi << 32) | wlo) >> sh;
             const uint32_t bits = (uint32_t)W & ((1u << k) - 1u);
             if (bits) {
                 const int o = __ffs(bits) - 1;
                 // the position behind the site in the read's direction: m + 1, on the reverse strand m - 1 (context[k], :197)
                 const int at_bit = s_blk[bj].rev ? sh + o - 1 : sh + o + 1;
-                const uint32_t next = at_bit >= 0 ? (uint32_t)(((((uint64_t)whi[u] << 32) | wlo[u]) >> at_bit) & 1ull) : 0u;
+                const uint32_t next = at_bit >= 0 ? (uint32_t)(((((uint64_t)whi << 32) | wlo) >> at_bit) & 1ull) : 0u;
                 code = (uint32_t)(o + 1) | (next << 7);
             }
         }
         s_ro[R] = (uint8_t)code;
+        wlo = nlo; whi = nhi;
     }
     lds_barrier();
     // ---- the closers of the piece, in row order: run R' closes the window of run R' - 1 of its block iff its head lies beyond that

@@ -161,9 +161,18 @@ class Finisher(object):
         self._n_pos = self._n_multi = self._n_wskips = self._n_skipped = None    # set by the vectorised counters
 
     # ---- output ----
+    def write_to(self, sink):
+        """The rows to sink(bytes-like), piece by piece as they were made (no joined copy) -> bytes written."""
+        n = 0
+        for b in self.blobs:
+            if len(b):
+                sink(b.view if isinstance(b, _lib.LibBuffer) else b)
+                n += len(b)
+        return n
+
     def text(self, max_rows=None):
         """The rows as bytes; max_rows: only the first that many (the reference's 5000-row batches on an exit)."""
-        blob = b''.join(self.blobs)
+        blob = b''.join(b.view if isinstance(b, _lib.LibBuffer) else b for b in self.blobs)
         if max_rows is None:
             return blob
         return b''.join(blob.splitlines(True)[:max_rows])
@@ -561,15 +570,13 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             stop = fin.run(rec)
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
-        blob = fin.text()
         t_s = time.perf_counter()
         clock['format'] += t_s - t_f
-        if blob:
-            sink(blob)
+        n_out = fin.write_to(sink)
         clock['write'] += time.perf_counter() - t_s
-        clock['out_bytes'] += len(blob)
+        clock['out_bytes'] += n_out
         clock['records'] += int(rec.n)
-        out.n_bytes += len(blob)
+        out.n_bytes += n_out
         n = rec.n
         too = (rec.info[:n] & _I.I_TOO_MANY) != 0
         positions.append(np.unique(rec.site_pos[:n][~too]))

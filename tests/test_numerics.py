@@ -77,3 +77,19 @@ def test_division_by_1e4_without_dividing(tmp_path):
     subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-mfma', '-o', exe, src, '-lm', '-lpthread'])
     out = subprocess.check_output([exe], timeout=600).decode()
     assert 'mismatches over all int32: 0' in out, out
+
+
+def test_fixed_point_repr_matches_python():
+    """mc_repr_fixed4(d) (how the formatter prints the slot means that travel as integers: no floating-point conversion) ==
+    repr(d / 1e4) == str(np.float64(d / 1e4)): the edges of the 32-bit range, every trailing-zero pattern, 200 000 random d."""
+    from mcaller_amd._lib import repr_fixed4
+    rng = random.Random(13)
+    ds = [0, 1, -1, 9, 10, 99, 100, 999, 1000, 9999, 10000, -10000, 10001, 12300, 120000, 1234567, -7055, 2147483647, -2147483648,
+          -2147483647, 2147480000, 100000000, 99999999, 50000, 5]
+    ds += [rng.randrange(-400000, 400000) for _ in range(100000)]             # what (event - model) x 1e4 looks like
+    ds += [rng.randrange(-2 ** 31, 2 ** 31) for _ in range(100000)]
+    ds += [rng.randrange(-3000, 3000) * 100 for _ in range(5000)] + [rng.randrange(-300, 300) * 10000 for _ in range(2000)]
+    for d in ds:
+        assert repr_fixed4(d) == repr(d / 1e4), d
+    for d in ds[:2000]:
+        assert repr_fixed4(d) == str(np.float64(d) / 1e4)
