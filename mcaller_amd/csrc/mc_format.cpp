@@ -11,10 +11,13 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -117,6 +120,49 @@ inline int comp_of(int c) {          // base_comps, extract_contexts.py:11; -1: 
     }
 }
 
+// Memory that is written once per call and thrown away -- the pieces the threads format into, the block the rows leave in -- is
+// KEPT between calls: a shard of a one-base motif is 16 MB of rows, and fresh memory of that size comes from mmap, every page of
+// it a fault taken under the process's one address-space lock by sixteen threads at once (the formatter scaled 3.9x on 8
+// threads; per row and thread it took twice as long on 16 as on one).
+struct PartBuf {                        // a growable piece of text that keeps its memory
+    char *p = nullptr;
+    size_t cap = 0, used = 0;
+    void need(size_t more) {
+        if (used + more <= cap) return;
+        const size_t ncap = std::max(cap * 2, used + more + (1u << 20));
+        char *q = (char *)realloc(p, ncap);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = ncap;
+    }
+};
+std::mutex g_fmt_mu;                    // one formatting call at a time owns the pieces below
+std::vector<PartBuf> g_parts;
+struct OutBlock { char *p; size_t cap; bool busy; };
+std::mutex g_out_mu;
+std::vector<OutBlock> g_out;            // blocks handed out by mc_format_diffs, kept when mc_free gets them back (at most four)
+
+char *out_alloc(size_t n) {
+    std::lock_guard<std::mutex> lk(g_out_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_out.size(); ++i)
+        if (!g_out[i].busy && g_out[i].cap >= n && (best < 0 || g_out[i].cap < g_out[(size_t)best].cap)) best = (int)i;
+    if (best >= 0) { g_out[(size_t)best].busy = true; return g_out[(size_t)best].p; }
+    const size_t cap = std::max<size_t>(n + n / 4, 1u << 20);
+    char *p = (char *)malloc(cap);
+    if (!p) return nullptr;
+    for (size_t i = 0; i < g_out.size(); ++i)          // (a block that is too small makes room for this one)
+        if (!g_out[i].busy) { free(g_out[i].p); g_out[i] = OutBlock{p, cap, true}; return p; }
+    if (g_out.size() < 4) { g_out.push_back(OutBlock{p, cap, true}); return p; }
+    return p;                                           // (more than four in use at once: a plain block, freed as such)
+}
+
+bool out_release(void *p) {
+    std::lock_guard<std::mutex> lk(g_out_mu);
+    for (auto &b : g_out)
+        if (b.p == p) { b.busy = false; return true; }
+    return false;
+}
+
 struct Job {
     const mc_format_args *a;
     std::vector<size_t> name_len, qual_len, contig_len_txt;
@@ -191,6 +237,9 @@ struct RowCursor {
     bool wide_known;
     RowCursor(const mc_calls_view *r, int64_t first)
         : rec(r), kept(r->compacted && !r->call_row ? kept_in(r, 0, first) : 0), wide(0), wide_known(false) {}
+    // (the caller has counted: kept records before `first`, wide slots of the call rows before the first one of this walk)
+    RowCursor(const mc_calls_view *r, int64_t kept_before, int64_t wide_before_)
+        : rec(r), kept(kept_before), wide(wide_before_), wide_known(true) {}
     // (call for every record in order; info = rec->info[j])
     int64_t row(int64_t j, uint32_t info) {
         if (!rec->compacted) return j;
@@ -233,15 +282,22 @@ struct RowCursor {
 
 // rows of records [j0, j1) into `out`; -> the first record the host must handle itself (a context that leaves the contig, an
 // unscored record, ...: the rows before it are in `out`), or j1
-int64_t format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int64_t &n_rows) {
+// (what a thread writes per row lives in ITS locals: the pieces' buffers and row counts sit side by side in memory, and sixteen
+// threads updating neighbouring words per row pass the cache line around -- the formatter took the same 20 ms on 1, 4 and 8 threads)
+int64_t format_range(const Job &J, int64_t j0, int64_t j1, PartBuf &out_shared, int64_t &n_rows_shared, const RowCursor &start) {
+    PartBuf out = out_shared;
+    int64_t n_rows = 0;
+    struct WriteBack {                  // (also when a piece runs out of memory: the shared entry must not keep a pointer realloc gave up)
+        PartBuf &shared, &mine;
+        int64_t &rows_shared, &rows_mine;
+        ~WriteBack() { shared = mine; rows_shared = rows_mine; }
+    } write_back{out_shared, out, n_rows_shared, n_rows};
     const mc_format_args *a = J.a;
     const mc_calls_view *rec = a->rec;
     const mc_table_view *t = a->table;
     const int k = a->k;
-    std::vector<char> buf(1 << 16);
-    size_t used = 0;
-    n_rows = 0;
-    RowCursor cur(rec, j0);
+    out.used = 0;
+    RowCursor cur = start;
     int32_t cseg = -1;                  // (the closing rows of consecutive records ascend: the segment is carried along)
     int64_t j = j0;
     for (; j < j1; ++j) {
@@ -261,12 +317,8 @@ int64_t format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int
         if (cseg >= t->n_seg) { chrom = a->tail_chrom; chrom_len = J.tail_len; }     // R8: the closing row's contig
         else { const int32_t cc = t->seg_contig[cseg]; chrom = a->contig_names[cc]; chrom_len = J.contig_len_txt[(size_t)cc]; }
         const size_t need = chrom_len + J.name_len[(size_t)rid] + J.qual_len[(size_t)rid] + (size_t)k * 32 + 160;
-        if (used + need > buf.size()) {
-            out.append(buf.data(), used);
-            used = 0;
-            if (need > buf.size()) buf.resize(need * 2);
-        }
-        char *o = buf.data() + used;
+        out.need(need);
+        char *o = out.p + out.used;
         o = put_str(o, chrom, chrom_len); *o++ = '\t';
         o = put_str(o, a->read_names[rid], J.name_len[(size_t)rid]); *o++ = '\t';
         o = put_int(o, rec->site_pos[j]); *o++ = '\t';
@@ -297,10 +349,9 @@ int64_t format_range(const Job &J, int64_t j0, int64_t j1, std::string &out, int
             else { *o++ = '0'; *o++ = '.'; *o++ = (char)('0' + hi / 10); if (hi % 10) *o++ = (char)('0' + hi % 10); }
         } else o = put_repr(o, h / 100.0);
         *o++ = '\n';
-        used = (size_t)(o - buf.data());
+        out.used = (size_t)(o - out.p);
         ++n_rows;
     }
-    out.append(buf.data(), used);
     return j;
 }
 
@@ -317,8 +368,10 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
         return -12;
     }
     const int64_t n = a->n_records;
-    int nt = n_threads > 0 ? n_threads : mc_host_cores();                 // the cores this process may use
-    nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (n - first) / 4096));
+    const int threads = n_threads > 0 ? n_threads : mc_host_cores();     // the cores this process may use
+    // four pieces per thread, handed out as the threads get to them: on a host that is shared, some of the cores the workers are
+    // bound to run at half the others' pace, and with one piece each the slowest one is the call's time
+    const int nt = (int)std::min<int64_t>(threads > 1 ? 4 * (int64_t)threads : 1, std::max<int64_t>(1, (n - first) / 2048));
 
     // every thread formats its piece of [first, n) and stops at the first record the host must handle itself; the rows before
     // the first such record of all count, what later pieces formatted is dropped (a handful of records per file end a run)
@@ -336,15 +389,50 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     J.tail_len = a->tail_chrom ? strlen(a->tail_chrom) : 0;
     J.lab_pos_len = strlen(a->label_meth);
     J.lab_neg_len = strlen(a->label_unmeth);
-    std::vector<std::string> parts((size_t)nt);
+    std::lock_guard<std::mutex> own_the_pieces(g_fmt_mu);
+    if (g_parts.size() < (size_t)nt) g_parts.resize((size_t)nt);
+    std::vector<PartBuf> &parts = g_parts;
     std::vector<int64_t> rows((size_t)nt, 0), stops((size_t)nt, n);
+    std::vector<int> failed((size_t)nt, 0);
+    static const bool fmt_timing = getenv("MCALLER_FMT_TIMING") != nullptr;      // (per-piece milliseconds on stderr)
+    std::vector<double> t_piece((size_t)nt, 0.0);
     auto piece_lo = [&](int w) { return first + (n - first) * w / nt; };
+    // where every piece begins in the compacted rows (records without MC_I_TOO_MANY before it, wide slots before its first row)
+    const mc_calls_view *rec0 = a->rec;
+    const bool counted = rec0->compacted && !rec0->call_row;
+    std::vector<int64_t> kept0((size_t)nt + 1, 0), wide0((size_t)nt + 1, 0);
+    if (counted) {
+        kept0[0] = kept_in(rec0, 0, first);
+        mc_parallel_for(nt, [&](int w) { kept0[(size_t)w + 1] = kept_in(rec0, piece_lo(w), piece_lo(w + 1)); });
+        for (int w = 0; w < nt; ++w) kept0[(size_t)w + 1] += kept0[(size_t)w];
+        if (!rec0->feats && rec0->feats_wide) {
+            wide0[0] = wide_before(rec0, kept0[0]);
+            mc_parallel_for(nt, [&](int w) {
+                int64_t c = 0;
+                for (int64_t r = kept0[(size_t)w], e = kept0[(size_t)w + 1]; r < e; ++r) c += __builtin_popcount(rec0->feats_wide[r]);
+                wide0[(size_t)w + 1] = c;
+            });
+            for (int w = 0; w < nt; ++w) wide0[(size_t)w + 1] += wide0[(size_t)w];
+        }
+    }
     auto work = [&](int w) {
         const int64_t lo = piece_lo(w), hi = piece_lo(w + 1);
-        parts[(size_t)w].reserve((size_t)(hi - lo) * 96 + 4096);
-        stops[(size_t)w] = format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w]);
+        const RowCursor start = counted ? RowCursor(rec0, kept0[(size_t)w], wide0[(size_t)w]) : RowCursor(rec0, lo);
+        const auto t_a = std::chrono::steady_clock::now();
+        try {
+            stops[(size_t)w] = format_range(J, lo, hi, parts[(size_t)w], rows[(size_t)w], start);
+        } catch (const std::bad_alloc &) { failed[(size_t)w] = 1; }
+        if (fmt_timing) t_piece[(size_t)w] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
     };
+    const auto t_0 = std::chrono::steady_clock::now();
     mc_parallel_for(nt, work);
+    if (fmt_timing) {
+        fprintf(stderr, "[mc_format_diffs] %d pieces in %.2f ms:", nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_0).count() * 1e3);
+        for (int w = 0; w < nt; ++w) fprintf(stderr, " %.2f", t_piece[(size_t)w] * 1e3);
+        fprintf(stderr, "\n");
+    }
+    for (int w = 0; w < nt; ++w)
+        if (failed[(size_t)w]) { mc_set_error("mc_format_diffs: out of memory"); return -10; }
     int64_t stop = n;
     int last = nt;                        // pieces [0, last) count
     for (int w = 0; w < nt; ++w)
@@ -352,13 +440,13 @@ extern "C" int mc_format_diffs(const mc_format_args *a, int64_t first, int32_t n
     *stop_at = stop;
     size_t total = 0;
     std::vector<size_t> at((size_t)last + 1, 0);
-    for (int w = 0; w < last; ++w) { at[(size_t)w] = total; total += parts[(size_t)w].size(); }
-    char *outp = (char *)malloc(std::max<size_t>(total, 1));
+    for (int w = 0; w < last; ++w) { at[(size_t)w] = total; total += parts[(size_t)w].used; }
+    char *outp = out_alloc(std::max<size_t>(total, 1));
     if (!outp) {
         mc_set_error("mc_format_diffs: out of memory (%zu bytes)", total);
         return -10;
     }
-    mc_parallel_for(last, [&](int w) { memcpy(outp + at[(size_t)w], parts[(size_t)w].data(), parts[(size_t)w].size()); });
+    mc_parallel_for(last, [&](int w) { memcpy(outp + at[(size_t)w], parts[(size_t)w].p, parts[(size_t)w].used); });
     for (int w = 0; w < last; ++w) *n_rows += rows[(size_t)w];
     *text = outp;
     *n_bytes = (int64_t)total;
@@ -427,7 +515,9 @@ extern "C" int mc_calls_expand(const mc_calls_view *rec, int64_t n, int32_t k, i
     return 0;
 }
 
-extern "C" void mc_free(void *p) { free(p); }
+extern "C" void mc_free(void *p) {
+    if (p && !out_release(p)) free(p);          // (a block of rows goes back to the formatter's cache)
+}
 
 // repr(d / 1e4) from the integer alone (tests pin it against Python's)
 extern "C" int mc_repr_fixed4(int32_t d, char *out32) {

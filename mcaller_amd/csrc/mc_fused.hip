@@ -56,6 +56,13 @@ static_assert(TILE % FT == 0, "whole pieces per tile");
 static_assert(FR % 64 == 0 && F_THREADS == 256 && (F_CHUNKS + 3) / 4 <= F_CPW, "the chunks are split over 4 waves, at most F_CPW each");
 static_assert(FR < (1 << F_ROW_BITS), "s_rrow keeps the run's flags above its row");
 
+#ifdef MC_FD_TRACE      // (variant build: 100 MHz time stamps of the phases of 1024 workgroups in the middle of the grid)
+__device__ unsigned long long g_fd_trace[1024 * 10];
+#define FD_STAMP(i) do { if (tid == 0 && blockIdx.x >= 40000 && blockIdx.x < 41024) g_fd_trace[(blockIdx.x - 40000) * 10 + (i)] = wall_clock64(); } while (0)
+#else
+#define FD_STAMP(i) do { } while (0)
+#endif
+
 struct FBlock {                     // a name block that overlaps the staged rows (staged indices), and what its windows need of it
     int16_t end, lb;                // lb: first row that is in a run (-1: before the staged rows; >= the staged rows: none)
     int16_t begin;                  // the block's first row (-1: before the staged rows)
@@ -183,6 +190,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ FBlock s_blk[F_MAXB];
     __shared__ int16_t s_bfirst[F_MAXB + 1];    // first run of the block (the runs of later blocks behind it); -1 until known
     __shared__ FSpec s_spec[F_MAXSPEC];
+    __shared__ uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
     const DevTable &T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,6 +207,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     }
     const int64_t h0 = max(s0 - (int64_t)FH, (int64_t)0);
     const int nst = (int)(s1 - h0), i_piece = (int)(s0 - h0);
+    FD_STAMP(0);
     // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
     // chunk in front of its first one.  Their addresses need nothing but the block index, so they set out FIRST and all at once
     // (a lane beyond the staged rows reads the last staged row and drops it: a load behind a test is a round trip of its own) ----
@@ -261,6 +270,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         const bool more_behind = (__ballot(ends_early) >> 63) & 1ull;
         if (over && at < F_MAXB) s_blk[at] = fb;
         if (lane <= F_MAXB) s_bfirst[lane] = -1;
+        if (lane < (FR + 63) / 64 + 2) s_cnt[lane] = 0;
         if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; }
     }
     asm volatile("" : "+v"(re[0].x), "+v"(re[0].y), "+v"(rp[0]), "+v"(rfl[0]), "+v"(rx[0]), "+v"(re[1].x), "+v"(re[1].y), "+v"(rp[1]), "+v"(rfl[1]), "+v"(rx[1]),
@@ -277,6 +287,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     }
     if (!(c_lo > 0 && (c_lo - 1) * 64 + lane < nst)) { pre_p = 0; pre_f = MC_F_MODEL_N; }
     lds_barrier();
+    FD_STAMP(1);
     const int nblk = s_nblk;
     const bool usable = nblk <= F_MAXB;
     const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
@@ -357,7 +368,8 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             const int lb = s_blk[bj].lb, lbm = max(lb, 0);
             if (VALIDATE) {
                 // the row before: the previous lane's, lane 0: the last row of the chunk before (the wave's, or the one loaded in front)
-                int qp = __shfl_up(rp[c], 1), qx = __shfl_up(rx[c], 1);
+                // (wave_shr:1 -- a DPP move, no trip through the LDS crossbar)
+                int qp = __builtin_amdgcn_update_dpp(0, rp[c], 0x138, 0xF, 0xF, false), qx = __builtin_amdgcn_update_dpp(0, rx[c], 0x138, 0xF, 0xF, false);
                 const int sp = __shfl(c > 0 ? rp[c > 0 ? c - 1 : 0] : pre_p, 63), sx = __shfl(c > 0 ? rx[c > 0 ? c - 1 : 0] : pre_x, 63);
                 if (lane == 0) { qp = sp; qx = sx; }
                 const bool mine = i >= i_piece && i < nst && i < s_blk[bj].end && i >= (int)s_blk[bj].begin;
@@ -383,6 +395,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
         lds_barrier();
+        FD_STAMP(2);
         int hbase = 0, ibase = 0, n_in = 0;
 #pragma unroll
         for (int w = 0; w < F_THREADS / 64; ++w) {
@@ -412,6 +425,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         if (tid == 0) { s_rc0[n_runs] = (uint16_t)n_in; s_rrow[n_runs] = (uint16_t)nst; s_ro[n_runs] = 0; }
         lds_barrier();
+        FD_STAMP(3);
     }
     // ---- the mean of every run (its rows in file order, NumPy's pairwise order: np.mean, :186; values fl(d / 1e4), :286) and its
     // site: the first 'M' of meth_ref[p : p + k] (:176, :270) from two words of the block's strand mask -- the words of all runs
@@ -530,49 +544,70 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
                 code = (uint32_t)(o + 1) | (next << 7);
             }
         }
-        s_ro[R] = (uint8_t)code;
+        // is the run's window closed in this piece?  By the head of the next run, if that is a run of the same block (it has a
+        // run before it), lies in the piece, and beyond the site (:179)
+        bool closed = false;
+        if ((code & 15u) && R + 1 < n_runs) {
+            const uint32_t r1 = s_rrow[R + 1];
+            closed = !((r1 >> F_ROW_BITS) & RF_ALONE) && (int)(r1 & ((1 << F_ROW_BITS) - 1)) >= i_piece && s_rpos[R + 1] - p > (int)(code & 15u) - 1;
+        }
+        s_ro[R] = (uint8_t)(code | (closed ? 0x40u : 0u));
+        // (the closed windows of the wave's 64 consecutive runs: one count per wave and turn of the loop)
+        const unsigned long long cm = __ballot(closed);
+        if (lane == 0) s_cnt[R >> 6] = (uint8_t)__popcll(cm);
         wlo = nlo; whi = nhi;
     }
+    FD_STAMP(4);
     lds_barrier();
-    // ---- the closers of the piece, in row order: run R' closes the window of run R' - 1 of its block iff its head lies beyond that
-    // run's site (:179); in front of a block's first run what the special closers of the block close.  Counted per thread over
-    // consecutive runs, numbered across the workgroup, listed (the events' room is free now) ----
+    FD_STAMP(5);
+    // ---- the closers of the piece, in row order (the order in which the reference flushes): every 64 consecutive runs have
+    // counted their closed windows; a wave numbers its runs' windows with one ballot per turn and lists the closing runs (the
+    // events' room is free now) ----
     uint16_t *s_list = reinterpret_cast<uint16_t *>(s_dc);
-    const int rpt = (n_runs + 1 + F_THREADS - 1) / F_THREADS;   // (n_runs itself: where the specials behind the last run go)
-    const int R_lo = tid * rpt, R_hi = min(R_lo + rpt, n_runs + 1);
-    // a block without a run of its own: its specials go in front of the next block's first run
-    if (tid == 0) {
-        int next = n_runs;
-        s_bfirst[nblk] = (int16_t)n_runs;
-        for (int j = nblk - 1; j >= 0; --j) {
-            if (s_bfirst[j] < 0) s_bfirst[j] = (int16_t)next;
-            next = s_bfirst[j];
+    int n_win = 0;
+    {
+        int before = 0;                             // closed windows of the runs in front of this wave's 64 of the turn
+        const int n64 = (n_runs + 63) >> 6;
+        for (int g = 0; g < n64; ++g) {
+            const int c = s_cnt[g];
+            if ((g & 3) == wave) {
+                const int R = g * 64 + lane;
+                const bool closed = R < n_runs && (s_ro[R] & 0x40u);
+                const unsigned long long cm = __ballot(closed);
+                if (closed) s_list[before + __popcll(cm & lt)] = (uint16_t)(R + 1);
+            }
+            before += c;
         }
+        n_win = before;
     }
-    lds_barrier();
-    const int n_spec = s_anyspec ? 2 * nblk + 1 : 0;       // (one piece in twenty has a special closer)
-    auto closes = [&](int Rc) -> bool {           // run Rc (0 < Rc < n_runs) closes the window of the run before it
-        const uint32_t rr = s_rrow[Rc];
-        if ((rr >> F_ROW_BITS) & RF_ALONE) return false;
-        if ((int)(rr & ((1 << F_ROW_BITS) - 1)) < i_piece) return false;
-        const int o1 = (int)(s_ro[Rc - 1] & 15u);
-        return o1 != 0 && s_rpos[Rc] - s_rpos[Rc - 1] > o1 - 1;
-    };
-    int mine = 0;
-    for (int Rc = R_lo; Rc < R_hi; ++Rc) {
-        for (int e = 0; e < n_spec; ++e)
-            if (s_spec[e].kind && (int)s_bfirst[e >> 1] == Rc) ++mine;
-        if (Rc > 0 && Rc < n_runs && closes(Rc)) ++mine;
+    // What the special closers close goes in front of the window their block's first run would close (a block without a run:
+    // the next block's): merged into the list by one thread, from the back -- one piece in twenty has any
+    if (s_anyspec) {
+        lds_barrier();
+        if (tid == 0) {
+            int next = n_runs;
+            for (int j = nblk - 1; j >= 0; --j) {
+                if (s_bfirst[j] < 0) s_bfirst[j] = (int16_t)next;
+                next = s_bfirst[j];
+            }
+            s_bfirst[nblk] = (int16_t)n_runs;
+            int n_s = 0;
+            for (int e = 0; e < 2 * nblk + 1; ++e) n_s += s_spec[e].kind ? 1 : 0;
+            int i = n_win - 1, out = n_win + n_s - 1;
+            for (int e = 2 * nblk; e >= 0; --e) {
+                if (!s_spec[e].kind) continue;
+                const int at = s_bfirst[e >> 1];
+                while (i >= 0 && (int)s_list[i] >= at) s_list[out--] = s_list[i--];
+                s_list[out--] = (uint16_t)(0x8000u | (unsigned)e);
+            }
+            s_scan[0] = n_win + n_s;
+        }
+        lds_barrier();
+        n_win = s_scan[0];
     }
-    int n_win;
-    int rank = wg_exclusive_scan(mine, lane, wave, s_scan, n_win);
     if (n_win > cap) { if (tid == 0) atomicOr(&A.cnt->overflow, 1u); return; }
-    for (int Rc = R_lo; Rc < R_hi; ++Rc) {
-        for (int e = 0; e < n_spec; ++e)
-            if (s_spec[e].kind && (int)s_bfirst[e >> 1] == Rc) s_list[rank++] = (uint16_t)(0x8000u | (unsigned)e);
-        if (Rc > 0 && Rc < n_runs && closes(Rc)) s_list[rank++] = (uint16_t)Rc;
-    }
     lds_barrier();
+    FD_STAMP(6);
     // ---- a window per thread ----
     const uint32_t kbits = (1u << k) - 1u;
     for (int w = tid; w < n_win; w += F_THREADS) {
@@ -648,7 +683,9 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         A.O.info[q] = info;
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
+    FD_STAMP(7);
     for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+    FD_STAMP(8);
 }
 
 }  // namespace
@@ -672,3 +709,10 @@ void mc_launch_fused(const K1Args &A, Payload *sorted, int cap, bool validate, h
         else hipLaunchKernelGGL(k1_fused<false>, grid, dim3(F_THREADS), 0, st, A, sorted, cap);
     }
 }
+
+#ifdef MC_FD_TRACE
+extern "C" int mc_debug_fd_trace(unsigned long long *out, int64_t n_words) {
+    if (n_words > 1024 * 10) n_words = 1024 * 10;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fd_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
+}
+#endif
