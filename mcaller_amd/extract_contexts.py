@@ -158,7 +158,7 @@ class Finisher(object):
         self.blobs = []         # emitted rows as text (bytes), in order
         self.num_observations = 0
         self.pos_set, self.multi, self.w_skips, self.skipped = set(), set(), set(), set()
-        self._n_pos = self._n_multi = self._n_wskips = self._n_skipped = None    # set by the vectorised counters
+        self._n_pos = self._n_multi = self._n_wskips = self._n_skipped = self._kept_pos = None    # set by the vectorised counters
 
     # ---- output ----
     def write_to(self, sink):
@@ -182,6 +182,8 @@ class Finisher(object):
         return [line.split('\t') for line in self.text().decode('utf-8', 'surrogateescape').splitlines()]
 
     def counters(self):
+        if self._n_pos is None and self._kept_pos is not None:
+            self._n_pos = len(distinct_positions(self._kept_pos))
         n_pos = len(self.pos_set) if self._n_pos is None else self._n_pos
         n_multi = len(self.multi) if self._n_multi is None else self._n_multi
         n_wskips = len(self.w_skips) if self._n_wskips is None else self._n_wskips
@@ -266,7 +268,8 @@ class Finisher(object):
         self._n_skipped = int(size(too))
         self._n_wskips = int(size(kept & ((info & _I.I_EMPTY_MASK) != 0)))
         self._n_multi = int(size((info & _I.I_MULTI) != 0))
-        self._n_pos = len(distinct_positions(self._site_pos[:n][kept]))
+        self._kept_pos = self._site_pos[:n][kept]           # (the distinct positions: counted when somebody asks, counters())
+        self._n_pos = None
 
     def _one(self, j):
         P, k, t = self.P, self.k, self.P.table
@@ -568,7 +571,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                     continue
                 raise _Unstreamable('the streaming machinery declined: %s' % e)
 
-    positions = []
+    positions = [np.zeros(1 << 16, dtype=bool)]        # positions[0][p]: a call at site position p has been seen
     in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
     marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
@@ -601,9 +604,14 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         out.n_bytes += n_out
         n = rec.n
         too = (rec.info[:n] & _I.I_TOO_MANY) != 0
-        positions.append(distinct_positions(rec.site_pos[:n][~too]))
-        if len(positions) > 64:                                # (bounded: the union so far)
-            positions[:] = [distinct_positions(np.concatenate(positions))]
+        pos_kept = rec.site_pos[:n][~too]                      # (the distinct positions of the file: a mark per position, counted at the end)
+        if len(pos_kept):
+            top = int(pos_kept.max()) + 1
+            if top > len(positions[0]):
+                positions[0] = np.concatenate([positions[0], np.zeros(max(top, 2 * len(positions[0])) - len(positions[0]), dtype=bool)])
+            if int(pos_kept.min()) < 0:
+                raise _Unstreamable('a negative site position')
+            positions[0][pos_kept] = True
         if train:                                              # (train mode goes record by record: its sets count)
             out.n_obs += fin.num_observations
             out.n_multi += len(fin.multi)
@@ -736,7 +744,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
     out.n_rows = rows_seen
-    out.positions = distinct_positions(np.concatenate(positions)) if positions else np.zeros(0, dtype=np.int32)
+    out.positions = np.flatnonzero(positions[0]).astype(np.int32)
     out.counters = ['thread finished processing...:', '%d observations' % out.n_obs, '%d positions' % len(out.positions),
                     '%d regions with multiple methylated bases' % out.n_multi,
                     '%d observations with skips included' % out.n_wskips,

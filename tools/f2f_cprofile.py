@@ -1,4 +1,5 @@
-"""Where the host time of a file-to-file run goes: cProfile of the CLI on a synthetic file (after two warm-up runs)."""
+"""Where the host time of a file-to-file run goes: cProfile of the CLI on a synthetic file (after two warm-up runs).
+  python tools/f2f_cprofile.py [rows] [motif]"""
 import os, sys, tempfile, contextlib, io, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcaller_amd import synth, mCaller
@@ -8,7 +9,8 @@ codes = synth.genome()
 table, qual = synth.make_table(n, seed=5, codes=codes)
 paths = synth.write_inputs(table, qual, codes, d)
 model = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mcaller_amd', 'models', 'r95_twobase_model_NN_6_m6A.npz')
-argv = ['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model]
+motif = sys.argv[2] if len(sys.argv) > 2 else 'GATC'
+argv = ['-m', motif, '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model]
 out = paths['tsv'][:-4] + '.diffs.6'
 for rep in range(3):
     if os.path.exists(out):
