@@ -122,6 +122,26 @@ __device__ __forceinline__ double logistic(double z, const ExpConsts &C) {
     return z >= 0.0 ? 1.0 - q : q;
 }
 
+// ---- the fast forward: fp32 where the answer does not depend on it ----
+// The reference prints np.round(p, 2) and the label p >= 0.5 (:200-207): 101 thresholds.  A probability computed in fp32 is
+// within a bound of the fp64 one that the weights and the record's inputs give (DevMlp.margin, mc_ctx_set_mlp); a record whose
+// fast probability lies farther than that from every threshold prints the same characters either way, and the others -- one in
+// a few hundred -- are evaluated again in fp64 (phase D of k2_mlp).  The hidden layer in fp32 issues at twice the rate and the
+// tanh is ten instructions instead of thirty: what SURVEY.md section 7 names as the alternative to fp64 throughout.
+// tanh(a) = (1 - e) / (1 + e), e = exp(-2|a|): one v_exp_f32, one v_rcp_f32.  Absolute error <= K2_TANH32_MAX_ERR.
+__device__ __forceinline__ float tanh32(float a) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf((1.0f - e) * r, a);
+}
+
+// distance of p from the nearest threshold the reference's row depends on: the ties of np.round(p, 2) (p x 100 = j + 0.5) and 0.5
+__device__ __forceinline__ double threshold_distance(double p) {
+    const double t = p * 100.0;
+    const double d = fabs((t - floor(t)) - 0.5) * 0.01;
+    return fmin(d, fabs(p - 0.5));
+}
+
 // One lane per record, one hidden unit after the other inside the lane, the weights as SCALAR operands: the records a wave
 // takes belong to one sub-model, so W1[:, j], b1[j], W2[j] are the same for its 64 lanes -- they come through the scalar
 // cache into SGPRs (nine s_load'ed doubles per hidden unit) and the vector pipe issues nothing but the arithmetic:
@@ -163,7 +183,7 @@ __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 // NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
 // unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
 // are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
-template <int NI_T>
+template <int NI_T, bool FAST>
 __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
@@ -178,6 +198,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     __shared__ double s_q[K2B];                 // read quality of the stretch's records
     __shared__ double s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
     __shared__ int s_cnt[K2_SUB][K2_MAXM], s_before[K2_SUB][K2_MAXM], s_tot[K2_MAXM], s_gmodel[K2_SLOTS / 64];
+    __shared__ float s_marg[FAST ? K2_SLOTS : 1];   // the fast forward: how far from the fp64 probability the entry's may lie
+    __shared__ uint16_t s_fix[FAST ? K2_SLOTS : 1]; // ... the entries evaluated again in fp64
+    __shared__ int s_nfix;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -227,6 +250,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
         if (!placed && lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
         K2_STAMP(2);
         __syncthreads();
+        if (FAST && tid == 0) s_nfix = 0;           // (every thread has left the stretch before: phase D read it last)
         if (!placed) {
             uint32_t per_simd = 0;                  // a byte per SIMD: its waves
             int slot = 0;                           // waves of this wave's SIMD with a smaller number
@@ -299,32 +323,73 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
             }
-            const MC_SCALAR_MEM double *wu = (const MC_SCALAR_MEM double *)M.wu + ((size_t)mdl * H + u0) * S;
             double z = 0.0;
-            int u = u0;
-            for (; u + 4 <= u1; u += 4, wu += 4 * S) {          // four independent chains: the fp64 tanh is a long dependent sequence
-                double a0 = x[0] * wu[0], a1 = x[0] * wu[S], a2 = x[0] * wu[2 * S], a3 = x[0] * wu[3 * S];
+            if constexpr (FAST) {
+                float xf[NX];
 #pragma unroll
-                for (int i = 1; i < NX; ++i)
-                    if (i < NI) {
-                        a0 = fma(x[i], wu[i], a0);
-                        a1 = fma(x[i], wu[S + i], a1);
-                        a2 = fma(x[i], wu[2 * S + i], a2);
-                        a3 = fma(x[i], wu[3 * S + i], a3);
-                    }
-                a0 += wu[NI]; a1 += wu[S + NI]; a2 += wu[2 * S + NI]; a3 += wu[3 * S + NI];     // (a second scalar operand in the first fma would cost two moves)
-                tanh_4(a0, a1, a2, a3, C);
-                z = fma(a0, wu[NI + 1], z);
-                z = fma(a1, wu[S + NI + 1], z);
-                z = fma(a2, wu[2 * S + NI + 1], z);
-                z = fma(a3, wu[3 * S + NI + 1], z);
-            }
-            for (; u < u1; ++u, wu += S) {
-                double a0 = x[0] * wu[0];
+                for (int i = 0; i < NX; ++i) xf[i] = (float)x[i];
+                const MC_SCALAR_MEM float *wf = (const MC_SCALAR_MEM float *)M.wu32 + ((size_t)mdl * H + u0) * S;
+                float zf = 0.0f;
+                int u = u0;
+                for (; u + 4 <= u1; u += 4, wf += 4 * S) {          // four independent chains
+                    float a0 = xf[0] * wf[0], a1 = xf[0] * wf[S], a2 = xf[0] * wf[2 * S], a3 = xf[0] * wf[3 * S];
 #pragma unroll
-                for (int i = 1; i < NX; ++i)
-                    if (i < NI) a0 = fma(x[i], wu[i], a0);
-                z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
+                    for (int i = 1; i < NX; ++i)
+                        if (i < NI) {
+                            a0 = __builtin_fmaf(xf[i], wf[i], a0);
+                            a1 = __builtin_fmaf(xf[i], wf[S + i], a1);
+                            a2 = __builtin_fmaf(xf[i], wf[2 * S + i], a2);
+                            a3 = __builtin_fmaf(xf[i], wf[3 * S + i], a3);
+                        }
+                    a0 += wf[NI]; a1 += wf[S + NI]; a2 += wf[2 * S + NI]; a3 += wf[3 * S + NI];
+                    zf = __builtin_fmaf(tanh32(a0), wf[NI + 1], zf);
+                    zf = __builtin_fmaf(tanh32(a1), wf[S + NI + 1], zf);
+                    zf = __builtin_fmaf(tanh32(a2), wf[2 * S + NI + 1], zf);
+                    zf = __builtin_fmaf(tanh32(a3), wf[3 * S + NI + 1], zf);
+                }
+                for (; u < u1; ++u, wf += S) {
+                    float a0 = xf[0] * wf[0];
+#pragma unroll
+                    for (int i = 1; i < NX; ++i)
+                        if (i < NI) a0 = __builtin_fmaf(xf[i], wf[i], a0);
+                    zf = __builtin_fmaf(tanh32(a0 + wf[NI]), wf[NI + 1], zf);
+                }
+                z = (double)zf;
+                if (quarter == 0) {                                  // how far the entry's probability may lie from the fp64 one
+                    const MC_SCALAR_MEM float *mg = (const MC_SCALAR_MEM float *)M.margin + (size_t)mdl * (MC_MAX_K + 2);
+                    float m = mg[0];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+                        if (i < NI) m = __builtin_fmaf(fabsf(xf[i]) * 1.0000002f, mg[1 + i], m);
+                    s_marg[g * 64 + lane] = m * 1.000001f;
+                }
+            } else {
+                const MC_SCALAR_MEM double *wu = (const MC_SCALAR_MEM double *)M.wu + ((size_t)mdl * H + u0) * S;
+                int u = u0;
+                for (; u + 4 <= u1; u += 4, wu += 4 * S) {          // four independent chains: the fp64 tanh is a long dependent sequence
+                    double a0 = x[0] * wu[0], a1 = x[0] * wu[S], a2 = x[0] * wu[2 * S], a3 = x[0] * wu[3 * S];
+    #pragma unroll
+                    for (int i = 1; i < NX; ++i)
+                        if (i < NI) {
+                            a0 = fma(x[i], wu[i], a0);
+                            a1 = fma(x[i], wu[S + i], a1);
+                            a2 = fma(x[i], wu[2 * S + i], a2);
+                            a3 = fma(x[i], wu[3 * S + i], a3);
+                        }
+                    a0 += wu[NI]; a1 += wu[S + NI]; a2 += wu[2 * S + NI]; a3 += wu[3 * S + NI];     // (a second scalar operand in the first fma would cost two moves)
+                    tanh_4(a0, a1, a2, a3, C);
+                    z = fma(a0, wu[NI + 1], z);
+                    z = fma(a1, wu[S + NI + 1], z);
+                    z = fma(a2, wu[2 * S + NI + 1], z);
+                    z = fma(a3, wu[3 * S + NI + 1], z);
+                }
+                for (; u < u1; ++u, wu += S) {
+                    double a0 = x[0] * wu[0];
+    #pragma unroll
+                    for (int i = 1; i < NX; ++i)
+                        if (i < NI) a0 = fma(x[i], wu[i], a0);
+                    z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
+                }
             }
             s_part[quarter][g * 64 + lane] = z;
         }
@@ -336,7 +401,36 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             const int e = s_list[t];
             if (e == 0xFFFF) continue;
             const double z = ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t];
-            prob[base + e] = logistic(z + M.b2[s_gmodel[t >> 6]], C);
+            const double pr = logistic(z + M.b2[s_gmodel[t >> 6]], C);
+            prob[base + e] = pr;
+            if (FAST && !(threshold_distance(pr) > (double)s_marg[t])) s_fix[atomicAdd(&s_nfix, 1)] = (uint16_t)t;     // (NaN too)
+        }
+        if constexpr (FAST) {
+            // ---- D: the entries whose printed digits (or label) could depend on the precision: again in fp64, a wave per entry,
+            // the hidden units across its lanes
+            __syncthreads();
+            const int n_fix = s_nfix;
+            for (int f = wave; f < n_fix; f += K2_WAVES) {
+                const int t = s_fix[f];
+                const int e = s_list[t], mdl = s_gmodel[t >> 6];
+                const int64_t r = base + e;
+                double x[NX];
+                const double q = s_q[e];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+                double part = 0.0;
+                for (int u = lane; u < H; u += 64) {
+                    const double *wu = M.wu + ((size_t)mdl * H + u) * S;
+                    double a0 = x[0] * wu[0];
+#pragma unroll
+                    for (int i = 1; i < NX; ++i)
+                        if (i < NI) a0 = fma(x[i], wu[i], a0);
+                    part = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], part);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                if (lane == 0) prob[r] = logistic(part + M.b2[mdl], C);
+            }
         }
         // (no barrier here: what the next stretch writes before its first barrier -- s_q, s_cnt -- was last read before the
         // barrier above)
@@ -707,11 +801,20 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
                            submodel_in, n, prob, n_dev, overflow);
     else {
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * MC_K2_WG_PER_CU));
-        if (M.n_in == 7)
-            hipLaunchKernelGGL(k2_mlp<7>, dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+        // (flush records: the fast forward unless the context was told otherwise; a plain batched call -- the estimator protocol,
+        // mc_mlp_forward -- is fp64 throughout: its caller gets raw probabilities)
+        const bool fast = M.fast && M.wu32 && !submodel_in;
+        if (M.n_in == 7 && fast)
+            hipLaunchKernelGGL((k2_mlp<7, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+                               prob, n_dev, overflow);
+        else if (M.n_in == 7)
+            hipLaunchKernelGGL((k2_mlp<7, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+                               prob, n_dev, overflow);
+        else if (fast)
+            hipLaunchKernelGGL((k2_mlp<0, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
                                prob, n_dev, overflow);
         else
-            hipLaunchKernelGGL(k2_mlp<0>, dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
+            hipLaunchKernelGGL((k2_mlp<0, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
                                prob, n_dev, overflow);
     }
 }
@@ -724,6 +827,33 @@ void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned lon
                     Counters *host_status, int holes, hipStream_t st, hipEvent_t stop) {
     if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
     else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
+}
+
+// tanh32 against the fp64 tanh over EVERY float: the largest absolute difference (what K2_TANH32_MAX_ERR has to cover)
+namespace {
+__global__ void k_tanh32_err(unsigned long long *out) {
+    unsigned long long worst = 0ull;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)i);
+        if (!(fabsf(x) <= 3.4e38f)) continue;                // (NaN, inf)
+        const double err = fabs((double)tanh32(x) - tanh((double)x));
+        const unsigned long long b = (unsigned long long)__double_as_longlong(err);     // (non-negative doubles order like their bits)
+        worst = b > worst ? b : worst;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(worst, o); worst = v > worst ? v : worst; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, worst);
+}
+}  // namespace
+extern "C" int mc_debug_tanh32_max_err(double *out) {
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    HIP_TRY(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(k_tanh32_err, dim3(4096), dim3(256), 0, 0, d);
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    memcpy(out, &h, 8);
+    return 0;
 }
 
 #ifdef MC_K2_TRACE

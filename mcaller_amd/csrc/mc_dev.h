@@ -125,8 +125,15 @@ struct DevMlp {
     int32_t n_models = 0, n_in = 0, n_hidden = 0;
     double *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
     double *wu = nullptr;      // per sub-model and hidden unit: W1[0..n_in)[j], b1[j], W2[j] -- what k2_mlp reads with scalar loads
+    float *wu32 = nullptr;     // ... the same, rounded to float: the fast forward (k2_mlp<.., true>)
+    float *margin = nullptr;   // per sub-model, MC_MAX_K + 2 floats: K0, K_0 .. K_{n_in-1} -- the fast forward's probability is within
+                               // K0 + sum K_i |x_i| of the fp64 one (mc_ctx_set_mlp works it out from the weights)
+    int fast = 0;              // flush records are scored by the fast forward (fp32 + fp64 where a printed digit could depend on it)
     uint8_t *sub_of_char = nullptr;
 };
+// largest |tanh32(x) - tanh(x)| over all floats x (mc_classify.hip: one v_exp_f32, one v_rcp_f32): measured by exhaustion on the
+// GPU, tests/test_gpu_mlp_fast.py holds the kernel to it
+constexpr double K2_TANH32_MAX_ERR = 3.0e-7;
 
 struct DevForest {
     int32_t n_models = 0, n_in = 0;

@@ -33,27 +33,21 @@
 
 namespace {
 
-#ifndef MC_FT
-#define MC_FT 1024
-#endif
 #ifndef MC_FH
-#define MC_FH 128
+#define MC_FH 64
 #endif
 #ifndef MC_FD_WAVES
 #define MC_FD_WAVES 6
 #endif
-constexpr int FT = MC_FT;           // rows per piece
-constexpr int FH = MC_FH;           // rows in front of the piece that are staged with it
-constexpr int FR = FT + FH;
 constexpr int F_THREADS = 256;
+constexpr int FR = 4 * F_THREADS;   // rows staged per piece: four consecutive ones per thread
+constexpr int FH = MC_FH;           // ... of which in front of the piece (what the piece's first windows reach back into)
+constexpr int FT = FR - FH;         // rows per piece
 constexpr int F_MAXB = 16;          // name blocks per staged range
-constexpr int F_CHUNKS = FR / 64;   // the staged rows in chunks of 64: a wave owns 5 or 4 consecutive ones
-constexpr int F_CPW = 5;
 constexpr int F_ROW_BITS = 11;
 constexpr uint32_t RF_WIDE = 1, RF_UNUSABLE = 2, RF_ALONE = 4;      // flags of a run, above its first row in s_rrow
 constexpr int F_MAXSPEC = 2 * F_MAXB + 1;
-static_assert(TILE % FT == 0, "whole pieces per tile");
-static_assert(FR % 64 == 0 && F_THREADS == 256 && (F_CHUNKS + 3) / 4 <= F_CPW, "the chunks are split over 4 waves, at most F_CPW each");
+static_assert(FH % 4 == 0 && FH >= 16 && FH < FR / 2, "whole groups of four rows in front of a piece");
 static_assert(FR < (1 << F_ROW_BITS), "s_rrow keeps the run's flags above its row");
 
 #ifdef MC_FD_TRACE      // (variant build: 100 MHz time stamps of the phases of 1024 workgroups in the middle of the grid)
@@ -192,11 +186,11 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ FSpec s_spec[F_MAXSPEC];
     __shared__ uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
+    __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
+    __shared__ int4 s_wfirst[F_THREADS / 64];   // ... its first one: (row, position, first row of its block that is in a run); row -1: none
     const DevTable &T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int PIECES = TILE / FT;
     const int64_t piece_no = blockIdx.x;
-    const int64_t tile = piece_no / PIECES;
     const int64_t s0 = piece_no * (int64_t)FT, s1 = min(s0 + (int64_t)FT, T.n_rows);
     if (piece_no == 0 && tid == 0) A.cnt->n_records = (unsigned long long)gridDim.x * (unsigned long long)cap;      // every slot of every piece: holes are records that are not calls
     const int k = A.k;
@@ -208,28 +202,29 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     const int64_t h0 = max(s0 - (int64_t)FH, (int64_t)0);
     const int nst = (int)(s1 - h0), i_piece = (int)(s0 - h0);
     FD_STAMP(0);
-    // ---- the rows: a wave owns consecutive chunks of 64 (lane = row in the chunk) and keeps them in registers; with them the
-    // chunk in front of its first one.  Their addresses need nothing but the block index, so they set out FIRST and all at once
-    // (a lane beyond the staged rows reads the last staged row and drops it: a load behind a test is a round trip of its own) ----
-    const int c_lo = (wave * F_CHUNKS + 3) >> 2, c_hi = ((wave + 1) * F_CHUNKS + 3) >> 2;
-    int32_t rp[F_CPW], rd[F_CPW], rx[F_CPW];
-    uint32_t rfl[F_CPW];
-    int2 re[F_CPW];
-#pragma unroll
-    for (int c = 0; c < F_CPW; ++c) {
-        const int64_t j = h0 + min((c_lo + c) * 64 + lane, nst - 1);
-        re[c] = T.evmu[j];
-        rp[c] = T.pos[j];
-        rfl[c] = T.flags[j];
-        rx[c] = VALIDATE ? T.idx[j] : 0;
+    // ---- the rows: a thread owns FOUR CONSECUTIVE rows of the 1024 staged ones and keeps them in registers -- one 16-byte load
+    // of the positions, two of the (event, model) pairs, the four flag bytes as a word (the event indices on a first pass): the
+    // row before a row is the thread's own three times out of four, so "does this row begin a run" costs a comparison, not a
+    // ballot, a count of leading zeros and a shuffle (with a lane per row the heads and the numbering were a third of the kernel).
+    // The addresses need nothing but the block index: they set out FIRST (a thread beyond the staged rows reads the last staged
+    // group and drops it: a load behind a test is a round trip of its own) ----
+    const int i0 = 4 * tid;
+    const int64_t jg = h0 + min(i0, (nst - 1) & ~3);            // (whole groups stay inside the columns' padding)
+    int4 p4 = *reinterpret_cast<const int4 *>(T.pos + jg);
+    int4 ea = *reinterpret_cast<const int4 *>(T.evmu + jg), eb = *reinterpret_cast<const int4 *>(T.evmu + jg + 2);
+    uint32_t f4 = *reinterpret_cast<const uint32_t *>(T.flags + jg);
+    int4 x4 = make_int4(0, 0, 0, 0);
+    int qp0 = 0, qx0 = 0;                        // (a first pass: the row before the thread's first one, for the wave's first lane)
+    if (VALIDATE) {
+        x4 = *reinterpret_cast<const int4 *>(T.idx + jg);
+        const int64_t jq = h0 + min(max(i0 - 1, 0), nst - 1);
+        qp0 = T.pos[jq];
+        qx0 = T.idx[jq];
     }
-    const int64_t jpre = h0 + min(max((c_lo - 1) * 64 + lane, 0), nst - 1);
-    int32_t pre_p = T.pos[jpre], pre_x = VALIDATE ? T.idx[jpre] : 0;
-    uint32_t pre_f = T.flags[jpre];
     const unsigned overflow = A.cnt->overflow;   // (a piece ran out of room: the pass is repeated, nobody reads what the others write)
-    const int bfrom = T.tile_nb[(h0 >= tile * TILE || tile == 0) ? tile : tile - 1];
-    // the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the tile before began in,
-    // all at once; the whole descriptor, 64 bytes in four loads, and the block's segment
+    const int bfrom = T.tile_nb[h0 / TILE];
+    // the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the staged rows' tile
+    // began in, all at once; the whole descriptor, 64 bytes in four loads, and the block's segment
     const int b = bfrom + lane;
     if (wave == 0) {
         const int bc = min(b, T.n_nb - 1);
@@ -273,24 +268,23 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (lane < (FR + 63) / 64 + 2) s_cnt[lane] = 0;
         if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; }
     }
-    asm volatile("" : "+v"(re[0].x), "+v"(re[0].y), "+v"(rp[0]), "+v"(rfl[0]), "+v"(rx[0]), "+v"(re[1].x), "+v"(re[1].y), "+v"(rp[1]), "+v"(rfl[1]), "+v"(rx[1]),
-                      "+v"(re[2].x), "+v"(re[2].y), "+v"(rp[2]), "+v"(rfl[2]), "+v"(rx[2]), "+v"(re[3].x), "+v"(re[3].y), "+v"(rp[3]), "+v"(rfl[3]), "+v"(rx[3]),
-                      "+v"(re[4].x), "+v"(re[4].y), "+v"(rp[4]), "+v"(rfl[4]), "+v"(rx[4]), "+v"(pre_p), "+v"(pre_f), "+v"(pre_x));
-    static_assert(F_CPW == 5, "the line above lists the rows of five chunks");
+    asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w), "+v"(ea.x), "+v"(ea.y), "+v"(ea.z), "+v"(ea.w), "+v"(eb.x), "+v"(eb.y), "+v"(eb.z), "+v"(eb.w),
+                      "+v"(f4), "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(qp0), "+v"(qx0));
     if (overflow) return;
+    int rp[4] = {p4.x, p4.y, p4.z, p4.w}, rd[4] = {ea.x - ea.y, ea.z - ea.w, eb.x - eb.y, eb.z - eb.w};
+    [[maybe_unused]] const int rx[4] = {x4.x, x4.y, x4.z, x4.w};
+    uint32_t nbits = 0;                          // bit e: the thread's row e is filtered ('N' model k-mer) or not staged
 #pragma unroll
-    for (int c = 0; c < F_CPW; ++c) {
-        const bool staged = c_lo + c < c_hi && (c_lo + c) * 64 + lane < nst;
-        rd[c] = staged ? re[c].x - re[c].y : 0;
-        rp[c] = staged ? rp[c] : 0;
-        rfl[c] = staged ? rfl[c] : (uint32_t)MC_F_MODEL_N;
+    for (int e = 0; e < 4; ++e) {
+        const bool staged = i0 + e < nst;
+        if (!staged || ((f4 >> (8 * e)) & MC_F_MODEL_N)) nbits |= 1u << e;
+        if (!staged) { rp[e] = 0; rd[e] = 0; }
     }
-    if (!(c_lo > 0 && (c_lo - 1) * 64 + lane < nst)) { pre_p = 0; pre_f = MC_F_MODEL_N; }
     lds_barrier();
     FD_STAMP(1);
     const int nblk = s_nblk;
     const bool usable = nblk <= F_MAXB;
-    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const bool at_eof = s1 == T.n_rows && A.tail_contig >= 0;      // the first row of the next shard closes this shard's last window (R6, R8)
 
     if (!usable) {
@@ -336,92 +330,133 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
 
     int n_runs = 0;
     {
-        // ---- which row in a run came last before the wave's rows (none: row -1) ----
-        int carry_row = -1, carry_pos = 0;
-        for (int cc = c_lo - 1; cc >= 0; --cc) {
-            const int i = cc * 64 + lane;
-            int32_t p = pre_p;
-            uint32_t f = pre_f;
-            if (cc != c_lo - 1 && i < nst) { p = T.pos[h0 + i]; f = T.flags[h0 + i]; }
-            int bj = 0;
-            while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
-            const bool in = i >= max((int)s_blk[bj].lb, 0) && i < s_blk[bj].end && !(f & MC_F_MODEL_N);
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                const int top = 63 - __clzll(m);
-                carry_row = cc * 64 + top;
-                carry_pos = __shfl(p, top);
-                break;
-            }
-        }
-        // ---- the wave's rows: which are in runs, which begin one (the row before it in its block that is in a run lies at
+        // ---- the thread's rows: which are in runs, which begin one (the row before it in its block that is in a run lies at
         // another position, or there is none); a first pass: every row of the piece against the row before it ----
-        unsigned long long inm[F_CPW], headm[F_CPW];
-        uint32_t cutm = 0, alonem = 0;  // bit c: the lane's row of chunk c begins its block's first staged run / one whose first rows may lie in front of the staged ones
-        int nh = 0, ni = 0, bj = 0;
+        int bj = 0;
+        while (bj + 1 < nblk && i0 >= s_blk[bj].end) ++bj;
+        const int bj0 = bj;
+        uint32_t inb = 0, lbneg = 0;             // bit e: row e is in a run / its block's tested rows begin in front of the staged ones
+        int lbm[4];
+        int lrow = -1, lpos = 0;                 // the thread's last row in a run
+        [[maybe_unused]] int qp = 0, qx = 0;
+        if (VALIDATE) {
+            // the row before the thread's first: the previous lane's last (wave_shr:1 -- a DPP move), the wave's first lane: loaded
+            qp = __builtin_amdgcn_update_dpp(0, rp[3], 0x138, 0xF, 0xF, false);
+            qx = __builtin_amdgcn_update_dpp(0, rx[3], 0x138, 0xF, 0xF, false);
+            if (lane == 0) { qp = qp0; qx = qx0; }
+        }
 #pragma unroll
-        for (int c = 0; c < F_CPW; ++c) {
-            inm[c] = 0; headm[c] = 0;
-            if (c_lo + c >= c_hi) continue;
-            const int base = (c_lo + c) * 64, i = base + lane;
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
             while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
-            const int lb = s_blk[bj].lb, lbm = max(lb, 0);
+            const int lb = s_blk[bj].lb, bend = s_blk[bj].end;
+            lbm[e] = max(lb, 0);
+            if (lb < 0) lbneg |= 1u << e;
             if (VALIDATE) {
-                // the row before: the previous lane's, lane 0: the last row of the chunk before (the wave's, or the one loaded in front)
-                // (wave_shr:1 -- a DPP move, no trip through the LDS crossbar)
-                int qp = __builtin_amdgcn_update_dpp(0, rp[c], 0x138, 0xF, 0xF, false), qx = __builtin_amdgcn_update_dpp(0, rx[c], 0x138, 0xF, 0xF, false);
-                const int sp = __shfl(c > 0 ? rp[c > 0 ? c - 1 : 0] : pre_p, 63), sx = __shfl(c > 0 ? rx[c > 0 ? c - 1 : 0] : pre_x, 63);
-                if (lane == 0) { qp = sp; qx = sx; }
-                const bool mine = i >= i_piece && i < nst && i < s_blk[bj].end && i >= (int)s_blk[bj].begin;
-                const bool has_pred = i > (int)s_blk[bj].begin;
-                const uint32_t f = mine ? f_row_vflags(rp[c], rx[c], qp, qx, has_pred) : 0u;
+                const int bbeg = s_blk[bj].begin;
+                const bool mine = i >= i_piece && i < nst && i < bend && i >= bbeg;
+                const uint32_t f = mine ? f_row_vflags(rp[e], rx[e], e ? rp[e ? e - 1 : 0] : qp, e ? rx[e ? e - 1 : 0] : qx, i > bbeg) : 0u;
                 if (f & ~s_blk[bj].vf) f_note_validation(A, s_blk[bj].id, f);
             }
-            const bool in = i < nst && i >= lbm && i < s_blk[bj].end && !(rfl[c] & MC_F_MODEL_N);
-            const unsigned long long m = __ballot(in), below = m & lt;
-            const int pl = 63 - __clzll(below | 1ull);
-            int prow = base + pl, ppos = __shfl(rp[c], pl);
-            if (!below) { prow = carry_row; ppos = carry_pos; }
-            const bool alone = prow < lbm, head = in && (alone || ppos != rp[c]);
-            if (head && alone) { alonem |= 1u << c; if (lb < 0) cutm |= 1u << c; }
-            const unsigned long long hm = __ballot(head);
-            inm[c] = m; headm[c] = hm;
-            nh += __popcll(hm); ni += __popcll(m);
-            if (m) {
-                const int top = 63 - __clzll(m);
-                carry_row = base + top;
-                carry_pos = __shfl(rp[c], top);
+            const bool in = !((nbits >> e) & 1u) && i >= lbm[e] && i < bend;
+            if (in) { inb |= 1u << e; lrow = i; lpos = rp[e]; }
+        }
+        // the row in a run before the thread's first one: the last one of the nearest lane below that has any; the wave's lowest
+        // lane with a row in a run finds it in the waves before (s_wlast, after the barrier)
+        const unsigned long long hasm = __ballot(lrow >= 0), below = hasm & lt;
+        const int src = 63 - __clzll(below | 1ull);
+        int prow = __shfl(lrow, src), ppos = __shfl(lpos, src);
+        const bool wave_first = !below && inb != 0u;    // (this thread holds the wave's first row in a run)
+        if (!below) { prow = -1; ppos = 0; }
+        // heads, alone (the block's first run of the staged rows), cut (... whose first rows may lie in front of the staged ones)
+        uint32_t headb = 0, aloneb = 0;
+        int efirst = -1;                         // the thread's first row in a run
+        {
+            int pr = prow, pp = ppos;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!((inb >> e) & 1u)) continue;
+                if (efirst < 0) efirst = e;
+                const bool alone = pr < lbm[e];
+                if (alone || pp != rp[e]) headb |= 1u << e;
+                if (alone) aloneb |= 1u << e;
+                pr = i0 + e; pp = rp[e];
             }
         }
-        if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
+        // (the wave's first row in a run: decided below, from what the waves before publish -- not counted yet)
+        if (wave_first) { headb &= ~(1u << efirst); aloneb &= ~(1u << efirst); }
+        // what a wave publishes: its heads and rows in runs, its last row in a run, its first one with its block's first tested row
+        {
+            int nh = __popc(headb), ni = __popc(inb);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { nh += __shfl_xor(nh, o); ni += __shfl_xor(ni, o); }
+            if (hasm) {
+                const int top = 63 - __clzll(hasm), bot = __ffsll((unsigned long long)hasm) - 1;
+                const int lr = __shfl(lrow, top), lp = __shfl(lpos, top);
+                const int fe = __shfl(efirst, bot);
+                const int fr = 4 * bot + fe + 64 * 4 * wave, fpv = __shfl(efirst == 0 ? rp[0] : efirst == 1 ? rp[1] : efirst == 2 ? rp[2] : rp[3], bot);
+                const int fl = __shfl(efirst == 0 ? lbm[0] : efirst == 1 ? lbm[1] : efirst == 2 ? lbm[2] : lbm[3], bot);
+                if (lane == 0) { s_wlast[wave] = make_int2(lr, lp); s_wfirst[wave] = make_int4(fr, fpv, fl, 0); }
+            } else if (lane == 0) { s_wlast[wave] = make_int2(-1, 0); s_wfirst[wave] = make_int4(-1, 0, 0, 0); }
+            if (lane == 0) { s_wheads[wave] = nh; s_wins[wave] = ni; }
+        }
         lds_barrier();
         FD_STAMP(2);
+        // every wave decides the first row in a run of the waves up to itself (is it a head?  alone?) and adds up what lies before it
         int hbase = 0, ibase = 0, n_in = 0;
+        {
+            int pr = -1, pp = 0;
 #pragma unroll
-        for (int w = 0; w < F_THREADS / 64; ++w) {
-            const int a = s_wheads[w], b2 = s_wins[w];
-            if (w < wave) { hbase += a; ibase += b2; }
-            n_runs += a; n_in += b2;
-        }
-        // ---- runs numbered in row order; the rows in runs packed run after run ----
-        bj = 0;
-#pragma unroll
-        for (int c = 0; c < F_CPW; ++c) {
-            if (c_lo + c >= c_hi) continue;
-            const int i = (c_lo + c) * 64 + lane;
-            const int rid = hbase + __popcll(headm[c] & le) - 1, at = ibase + __popcll(inm[c] & lt);
-            if ((inm[c] >> lane) & 1ull) s_dc[at] = rd[c];
-            if ((headm[c] >> lane) & 1ull) {
-                const uint32_t fl = (((cutm >> c) & 1u) ? RF_UNUSABLE : 0u) | (((alonem >> c) & 1u) ? RF_ALONE : 0u);
-                s_rrow[rid] = (uint16_t)(i | (fl << F_ROW_BITS));
-                s_rpos[rid] = rp[c];
-                s_rc0[rid] = (uint16_t)at;
-                if ((alonem >> c) & 1u) {           // (the block's first run)
-                    while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
-                    s_bfirst[bj] = (int16_t)rid;
+            for (int w = 0; w < F_THREADS / 64; ++w) {
+                const int4 wf = s_wfirst[w];
+                const int2 wl = s_wlast[w];
+                int first_is_head = 0;
+                if (wf.x >= 0) {
+                    const bool alone = pr < wf.z;
+                    first_is_head = (alone || pp != wf.y) ? 1 : 0;
+                    if (w == wave && wave_first) {
+                        if (first_is_head) headb |= 1u << efirst;
+                        if (alone) aloneb |= 1u << efirst;
+                    }
+                    pr = wl.x; pp = wl.y;
                 }
+                const int a = s_wheads[w] + first_is_head, b2 = s_wins[w];
+                if (w < wave) { hbase += a; ibase += b2; }
+                n_runs += a; n_in += b2;
             }
-            hbase += __popcll(headm[c]); ibase += __popcll(inm[c]);
+        }
+        // ---- runs numbered in row order; the rows in runs packed run after run: what the lanes below hold, then the thread's own ----
+        {
+            const int mine = __popc(headb) | (__popc(inb) << 16);
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int excl = incl - mine;
+            hbase += excl & 0xFFFF;
+            ibase += excl >> 16;
+        }
+        bj = bj0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!((inb >> e) & 1u)) continue;
+            const int i = i0 + e;
+            s_dc[ibase] = rd[e];
+            if ((headb >> e) & 1u) {
+                const bool alone = (aloneb >> e) & 1u;
+                const uint32_t fl = ((alone && ((lbneg >> e) & 1u)) ? RF_UNUSABLE : 0u) | (alone ? RF_ALONE : 0u);
+                s_rrow[hbase] = (uint16_t)(i | (fl << F_ROW_BITS));
+                s_rpos[hbase] = rp[e];
+                s_rc0[hbase] = (uint16_t)ibase;
+                if (alone) {                    // (the block's first run)
+                    while (bj + 1 < nblk && i >= s_blk[bj].end) ++bj;
+                    s_bfirst[bj] = (int16_t)hbase;
+                }
+                ++hbase;
+            }
+            ++ibase;
         }
         if (tid == 0) { s_rc0[n_runs] = (uint16_t)n_in; s_rrow[n_runs] = (uint16_t)nst; s_ro[n_runs] = 0; }
         lds_barrier();
@@ -697,7 +732,7 @@ int mc_fused_room(double density) {
     return std::min(FT + 2 * F_MAXB + 2, (want + 15) & ~15);
 }
 int mc_fused_room_max(void) { return FT + 2 * F_MAXB + 2; }
-int64_t mc_fused_pieces(const DevTable &T) { return T.n_tiles * (TILE / FT); }
+int64_t mc_fused_pieces(const DevTable &T) { return (T.n_rows + FT - 1) / FT; }
 
 void mc_launch_fused(const K1Args &A, Payload *sorted, int cap, bool validate, hipStream_t st, hipEvent_t stop) {
     const dim3 grid((unsigned)mc_fused_pieces(A.T));
