@@ -159,6 +159,14 @@ __device__ __forceinline__ double threshold_distance(double p) {
 //      function gives the probability.
 // The earlier version (eight lanes per record, pairs of records per lane group, weights in LDS: 126 LDS reads and ~1200
 // VALU instructions per step of 16 records, 3.1 uneven waves per SIMD) took 53 us for the headline pass.
+// The records of a fused dense pass (k1_fused) lie in fixed room per piece of the table, the slots a piece did not fill are holes --
+// two slots in three.  A stretch of 1024 SLOTS would spend its three barriers and its lists on 300 records: the stretches are made
+// of whole pieces instead, as many as hold at most 1024 records together (eleven, typically), from the pieces' counts.
+struct K2Pieces {
+    const int32_t *cnt;     // [n] records of every piece (k1_fused), nullptr: the records are dense
+    int room;               // slots per piece
+    int64_t n;              // pieces
+};
 constexpr int K2B = 1024;                       // records per workgroup iteration
 #ifndef MC_K2_THREADS
 #define MC_K2_THREADS 1024
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
                                                      double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
-                                                     const unsigned int *__restrict__ overflow) {
+                                                     const unsigned int *__restrict__ overflow, K2Pieces P) {
     if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
@@ -201,6 +209,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     __shared__ float s_marg[FAST ? K2_SLOTS : 1];   // the fast forward: how far from the fp64 probability the entry's may lie
     __shared__ uint16_t s_fix[FAST ? K2_SLOTS : 1]; // ... the entries evaluated again in fp64
     __shared__ int s_nfix;
+    __shared__ int s_pfx[18], s_np, s_ptot;     // a stretch made of pieces: records before every piece of it, pieces, records
+    __shared__ int32_t s_slot[K2B];             // ... the slot of every record of the stretch, from the stretch's first piece's first slot
+    static_assert(K2B == K2_THREADS, "a record per thread and stretch");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -214,10 +225,45 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     const int simd = (int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3;      // HW_ID[5:4]
     int quarter = 0, g_first = 0, g_step = 1;
     bool placed = false;
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    const bool pieces = P.cnt != nullptr;
+    const int64_t n_units = pieces ? P.n : n;                    // what the workgroups share out: pieces, or records
+    const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = min(n_units, blockIdx.x * per), hi = min(n_units, lo + per);
     K2_STAMP(1);
-    for (int64_t base = lo; base < hi; base += K2B) {
+    int64_t base = lo;                          // first record of the stretch (pieces: first piece)
+    for (;;) {
+        if (base >= hi) break;
+        int n_here = (int)min((int64_t)K2B, hi - base), np_here = 0;
+        int64_t slot0 = base;                   // record of the stretch's entry `off`: slot0 + (pieces ? s_slot[off] : off)
+        if (pieces) {
+            // the next pieces that hold at most K2B records together (a piece holds at most its room, and that is below K2B)
+            if (wave == 0) {
+                const bool have = lane < 16 && base + lane < hi;
+                const int c = have ? min(max(P.cnt[base + lane], 0), P.room) : 0;
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const unsigned long long fit = __ballot(have && incl <= K2B);
+                const int np = max(1, __popcll(fit));
+                if (lane < 16) s_pfx[lane] = incl - c;
+                if (lane == np - 1) { s_np = np; s_ptot = min(incl, K2B); }
+            }
+            __syncthreads();
+            np_here = s_np;
+            n_here = s_ptot;
+            slot0 = base * (int64_t)P.room;
+            int sl = 0;
+            if (tid < n_here) {
+                int j = 0;
+                while (j + 1 < np_here && s_pfx[j + 1] <= tid) ++j;
+                sl = j * P.room + (tid - s_pfx[j]);
+            }
+            s_slot[tid] = sl;
+        }
+        auto rec_at = [&](int off) -> int64_t { return slot0 + (pieces ? s_slot[off] : off); };
         // ---- A: the lists
         // (the read quality is a chain of three dependent loads -- segment, read, quality: it starts with the first load of
         // the stretch and is only waited for when the lists are done)
@@ -226,10 +272,10 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
 #pragma unroll
         for (int i = 0; i < K2B / K2_THREADS; ++i) {
             const int off = i * K2_THREADS + tid;
-            const int64_t r = base + off;
+            const int64_t r = slot0 + (pieces ? s_slot[off] : off);     // (a thread's own entry of s_slot: no barrier needed)
             mi[i] = 255;                            // sub-model of record r (255: not scored here)
             qv[i] = 0.0;
-            if (r < hi) {
+            if (off < n_here) {
                 if (submodel_in) mi[i] = submodel_in[r];
                 else {
                     const uint32_t inf = info[r];
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             const int mdl = __builtin_amdgcn_readfirstlane(s_gmodel[g]);
             const int e = s_list[g * 64 + lane];
             const int off = e == 0xFFFF ? s_list[g * 64] : e;       // (padding lanes compute the group's first record again)
-            const int64_t r = base + off;
+            const int64_t r = rec_at(off);
             double x[NX];
             if (submodel_in) {                       // plain batched call: X rows of n_in values
 #pragma unroll
@@ -402,7 +448,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             if (e == 0xFFFF) continue;
             const double z = ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t];
             const double pr = logistic(z + M.b2[s_gmodel[t >> 6]], C);
-            prob[base + e] = pr;
+            prob[rec_at(e)] = pr;
             if (FAST && !(threshold_distance(pr) > (double)s_marg[t])) s_fix[atomicAdd(&s_nfix, 1)] = (uint16_t)t;     // (NaN too)
         }
         if constexpr (FAST) {
@@ -413,7 +459,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             for (int f = wave; f < n_fix; f += K2_WAVES) {
                 const int t = s_fix[f];
                 const int e = s_list[t], mdl = s_gmodel[t >> 6];
-                const int64_t r = base + e;
+                const int64_t r = rec_at(e);
                 double x[NX];
                 const double q = s_q[e];
 #pragma unroll
@@ -433,7 +479,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
             }
         }
         // (no barrier here: what the next stretch writes before its first barrier -- s_q, s_cnt -- was last read before the
-        // barrier above)
+        // barrier above; a stretch made of pieces rewrites s_slot at once, which phases C and D read: one there)
+        if (pieces) __syncthreads();
+        base += pieces ? np_here : K2B;
         K2_STAMP(6);
 #ifdef MC_K2_TRACE
         if (lane == 0 && blockIdx.x < 1024)
@@ -791,8 +839,10 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
 // (k3_forest) or one of the closed forms (k3_simple) -- over n records (n_dev: the count is on the device, n is the capacity)
 void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &S, int n_cu, hipStream_t st, const double *feats, int k,
                           const int32_t *site_seg, const int32_t *seg_read, const double *qual, const uint32_t *info,
-                          const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow) {
+                          const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow,
+                          const int32_t *piece_cnt, int piece_room, int64_t n_pieces) {
     if (n <= 0) return;
+    const K2Pieces P{(piece_room > 0 && piece_room < K2B) ? piece_cnt : nullptr, piece_room, n_pieces};
     if (F.left)                // (a wave per record or a lane per record: the kernel looks at the count, which may be on the device only)
         hipLaunchKernelGGL(k3_forest, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)n_cu * 8))), dim3(K3_THREADS), 0, st,
                            F, feats, k, site_seg, seg_read, qual, info, submodel_in, n, prob, n_dev, overflow);
@@ -806,16 +856,16 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
         const bool fast = M.fast && M.wu32 && !submodel_in;
         if (M.n_in == 7 && fast)
             hipLaunchKernelGGL((k2_mlp<7, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow);
+                               prob, n_dev, overflow, P);
         else if (M.n_in == 7)
             hipLaunchKernelGGL((k2_mlp<7, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow);
+                               prob, n_dev, overflow, P);
         else if (fast)
             hipLaunchKernelGGL((k2_mlp<0, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow);
+                               prob, n_dev, overflow, P);
         else
             hipLaunchKernelGGL((k2_mlp<0, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow);
+                               prob, n_dev, overflow, P);
     }
 }
 

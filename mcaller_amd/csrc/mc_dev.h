@@ -373,6 +373,7 @@ struct K1Args {
     int k, skip_thresh, tail_contig;
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
+    int32_t *piece_cnt;           // the fused dense pass (k1_fused): [pieces] records of every piece
     unsigned long long *chunk_cnt;  // pipelined passes: [PACK_PAD * PACK_WGS] kept records / their wide slots per chunk of the copy-out's packing
                                   // (k_pack), counted by the emit itself as it writes the records; nullptr: nobody packs (or k_pack_count counts)
 };
@@ -506,7 +507,8 @@ void mc_launch_literal(const LitArgs &LA, unsigned grid, hipStream_t st);
 void mc_launch_merge(const DevRecords &O, int64_t n_o, const DevRecords &L, int64_t n_l, const DevRecords &M, int k, hipStream_t st);
 void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &S, int n_cu, hipStream_t st, const double *feats, int k,
                           const int32_t *site_seg, const int32_t *seg_read, const double *qual, const uint32_t *info,
-                          const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow);
+                          const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow,
+                          const int32_t *piece_cnt = nullptr, int piece_room = 0, int64_t n_pieces = 0);
 void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, int holes, hipStream_t st);
 void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
                     Counters *host_status, int holes, hipStream_t st, hipEvent_t stop);

@@ -197,6 +197,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     const int64_t q0 = piece_no * (int64_t)cap;
     if (s0 >= T.n_rows) {                        // (a piece behind the table: all holes)
         for (int w = tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+        if (tid == 0) A.piece_cnt[piece_no] = 0;
         return;
     }
     const int64_t h0 = max(s0 - (int64_t)FH, (int64_t)0);
@@ -325,6 +326,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             else leave_to_rare(A, sorted, q, cl[e].r, cl[e].m, cl[e].nb, c);
         }
         for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+        if (tid == 0) A.piece_cnt[piece_no] = n_win;
         return;
     }
 
@@ -719,6 +721,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         A.O.prob[q] = __longlong_as_double(0x7ff8000000000000LL);
     }
     FD_STAMP(7);
+    if (tid == 0) A.piece_cnt[piece_no] = n_win;                 // (what the classifier makes its stretches of)
     for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
     FD_STAMP(8);
 }

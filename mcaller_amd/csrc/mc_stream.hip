@@ -209,6 +209,8 @@ struct mc_ctx {
         unsigned long long *chunk_cnt = nullptr;               // k_pack_count -> k_pack
         Payload *sorted = nullptr;                             // the pass's payloads in record order (k1_list -> k1_emit, k1_rare_dev)
         int64_t *rare = nullptr;                               // records k1_emit leaves to k1_rare_dev
+        int32_t *piece_cnt = nullptr;                          // the fused dense pass: records of every piece (k1_fused -> k2_mlp)
+        int64_t piece_cap = 0;
         int32_t *h_lo32 = nullptr;                             // in pack_host: the slot means' 32-bit parts, the wide ones' high halves,
         uint32_t *h_hi32 = nullptr;                            // the mask byte of every call (mc_calls_view)
         unsigned char *h_wmask = nullptr;
@@ -1334,8 +1336,10 @@ static int classifier_inputs(const mc_ctx *c) {
 // the classifier of the context over n records (mc_classify.hip)
 static void launch_classifier(mc_ctx *c, hipStream_t st, const double *feats, int k, const int32_t *site_seg, const int32_t *seg_read,
                               const double *qual, const uint32_t *info, const uint8_t *submodel_in, int64_t n, double *prob,
-                              const unsigned long long *n_dev, const unsigned int *overflow) {
-    mc_launch_classifier(c->M, c->F, c->Sc, c->n_cu, st, feats, k, site_seg, seg_read, qual, info, submodel_in, n, prob, n_dev, overflow);
+                              const unsigned long long *n_dev, const unsigned int *overflow, const int32_t *piece_cnt = nullptr,
+                              int piece_room = 0, int64_t n_pieces = 0) {
+    mc_launch_classifier(c->M, c->F, c->Sc, c->n_cu, st, feats, k, site_seg, seg_read, qual, info, submodel_in, n, prob, n_dev, overflow,
+                         piece_cnt, piece_room, n_pieces);
 }
 
 // marked positions are dense (a one-base motif): the scan instance that lists every unit of a tile, bigger payload chunks
@@ -1469,7 +1473,8 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 // K1 (scan, order, emit) of one pass into the record set O on stream st; ev_scan_end is recorded after the scan.
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
                       hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
-                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr, int fused_room = 0) {
+                      const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr, int fused_room = 0,
+                      int32_t *piece_cnt = nullptr) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
@@ -1477,6 +1482,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.tile_local = c->tile_local; A.group_sum = c->group_sum; A.tile_first = c->tile_first; A.O = O; A.cnt = cnt; A.k = prm->k;
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
+    A.piece_cnt = piece_cnt;
     const bool dense = dense_reference(c);
     static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
     const bool runs = dense && !no_runs;
@@ -1724,6 +1730,8 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8 + 1) + 128;       // (every slot mean 64 bits wide at worst, a mask byte per call)
     if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_PAD * PACK_WGS)) return -10;
     if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
+    b.piece_cap = cap / 16 + 64;                               // (a piece has at least 48 slots: mc_fused_room)
+    if (dev_alloc(b.dev_allocs, &b.piece_cnt, (size_t)b.piece_cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
     b.H.capacity = cap;
@@ -1748,7 +1756,8 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
     if (b.prm.score)
         launch_classifier(c, st, b.O.feats, b.k, b.O.site_seg, T.seg_read, c->qual, b.O.info, (const uint8_t *)nullptr, b.cap, b.O.prob,
-                          (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow);
+                          (const unsigned long long *)&b.cnt->n_records, (const unsigned int *)&b.cnt->overflow,
+                          b.fused_room > 0 ? b.piece_cnt : nullptr, b.fused_room, b.fused_room > 0 ? b.slots / b.fused_room : 0);
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_end, st));
     return 0;
 }
@@ -1803,6 +1812,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
     if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
+    if (fused_room > 0 && mc_fused_pieces(T) > b.piece_cap) { b.fused_room = 0; b.slots = 0; }     // (room forced very small: more pieces than counts)
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
         if (!other.used && (other.cap < cap || other.n_nb < T.n_nb)) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
     // K0 (strand resolve) and K1 (scan, ordering, emit) of a pass on the ctx stream, back to back with the next pass: nothing
@@ -1832,7 +1842,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room)) return rc;
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt)) return rc;
     if (int rc = enqueue_k2(c, b, A)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     if (int rc = enqueue_pack(c, b, A.chunk_cnt == nullptr)) return rc;
