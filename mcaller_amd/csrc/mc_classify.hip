@@ -21,12 +21,16 @@ namespace {
 //
 // The constants live in VGPRs on purpose (VgprConst): k2_mlp keeps the weights of four hidden units in SGPRs (72 of the
 // ~100 there are), and constants the compiler put there as well were spilled to VGPR lanes and read back inside the loop.
-struct VgprConst {
+// (PIN = false -- the fast forward, whose hidden layer needs none of them: ordinary constants, alive only where they are used)
+template <bool PIN>
+struct VgprConstT {
     double v;
-    __device__ __forceinline__ explicit VgprConst(double x) : v(x) { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ explicit VgprConstT(double x) : v(x) { if (PIN) asm volatile("" : "+v"(v)); }
     __device__ __forceinline__ operator double() const { return v; }
 };
-struct ExpConsts {
+template <bool PIN>
+struct ExpConstsT {
+    using VgprConst = VgprConstT<PIN>;
     VgprConst two_log2e{2.8853900817779268}, magic{6755399441055744.0}, half_ln2_hi{-0.3465735901845619},
         half_ln2_lo{-9.541074646352939e-11};
     VgprConst t_max4{87.5};        // e^{2t} <= e^175: the product of four such (e^{2t} + 1) stays finite; tanh(87.5) = 1 in double
@@ -34,8 +38,10 @@ struct ExpConsts {
         g5{0.02539682542470863}, g4{0.08888888907016779}, g3{0.26666666666656197}, g2{0.6666666666659861},
         g1{1.3333333333333335}, g0{2.0000000000000004};
 };
+using ExpConsts = ExpConstsT<true>;
 
-__device__ __forceinline__ double exp2t_plus1(double t, const ExpConsts &C) {      // (0 <= t <= 350)
+template <class EC>
+__device__ __forceinline__ double exp2t_plus1(double t, const EC &C) {      // (0 <= t <= 350)
     const double tt = fma(t, C.two_log2e, C.magic);
     const double n = tt - C.magic;
     double r = fma(n, C.half_ln2_hi, t);                    // ln2/2 in two pieces
@@ -65,14 +71,16 @@ __device__ __forceinline__ double recip_ge1(double d) {
     return r;
 }
 
-__device__ __forceinline__ double tanh_1exp(double x, const ExpConsts &C) {
+template <class EC>
+__device__ __forceinline__ double tanh_1exp(double x, const EC &C) {
     const double q = recip_ge1(exp2t_plus1(fmin(fabs(x), C.t_max4), C));
     return copysign(fma(-2.0, q, 1.0), x);
 }
 
 // four at a time, step by step side by side (four independent chains in flight: the Horner scheme alone is a dependent
 // sequence of twelve), and one reciprocal, of the product of the four denominators (each <= e^175 + 1)
-__device__ __forceinline__ void tanh_4(double &x0, double &x1, double &x2, double &x3, const ExpConsts &C) {
+template <class EC>
+__device__ __forceinline__ void tanh_4(double &x0, double &x1, double &x2, double &x3, const EC &C) {
     double t[4] = {fmin(fabs(x0), C.t_max4), fmin(fabs(x1), C.t_max4), fmin(fabs(x2), C.t_max4), fmin(fabs(x3), C.t_max4)};
     double tt[4], r[4], p[4], d[4];
 #define MC_EACH for (int c = 0; c < 4; ++c)
@@ -117,7 +125,8 @@ __device__ __forceinline__ void tanh_4(double &x0, double &x1, double &x2, doubl
 }
 
 // 1 / (1 + e^{-z}) = (1 + tanh(z / 2)) / 2
-__device__ __forceinline__ double logistic(double z, const ExpConsts &C) {
+template <class EC>
+__device__ __forceinline__ double logistic(double z, const EC &C) {
     const double q = recip_ge1(exp2t_plus1(fmin(0.5 * fabs(z), 350.0), C));   // 1 / (e^{|z|} + 1)
     return z >= 0.0 ? 1.0 - q : q;
 }
@@ -191,8 +200,11 @@ __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 // NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
 // unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
 // are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
+// (the fast forward: TWO workgroups per CU -- its hidden layer is a third of the fp64 one's time, and what is left of a stretch is
+// the loads of phase A, three dependent ones, the lists and five barriers: one workgroup's phase A hides behind the other's phase B.
+// 64 registers a lane for that, partial sums as floats: 43 KB of LDS a workgroup)
 template <int NI_T, bool FAST>
-__global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST ? 8 : 4, FAST ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
@@ -204,7 +216,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
     __shared__ uint16_t s_list[K2_SLOTS];       // record (offset in the stretch) of every list entry; 0xFFFF: padding
     __shared__ double s_q[K2B];                 // read quality of the stretch's records
-    __shared__ double s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
+    using part_t = std::conditional_t<FAST, float, double>;
+    __shared__ part_t s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
     __shared__ int s_cnt[K2_SUB][K2_MAXM], s_before[K2_SUB][K2_MAXM], s_tot[K2_MAXM], s_gmodel[K2_SLOTS / 64];
     __shared__ float s_marg[FAST ? K2_SLOTS : 1];   // the fast forward: how far from the fp64 probability the entry's may lie
     __shared__ uint16_t s_fix[FAST ? K2_SLOTS : 1]; // ... the entries evaluated again in fp64
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
-    const ExpConsts C;
+    const ExpConstsT<!FAST> C;
     K2_STAMP(0);
     // Which quarter of the hidden units a wave takes: the one of the SIMD it runs on, so that the four SIMDs of the CU carry
     // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  The waves
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
     int64_t base = lo;                          // first record of the stretch (pieces: first piece)
     for (;;) {
         if (base >= hi) break;
+        K2_STAMP(7);                            // (the stretch begins: slot 15 keeps its clock64, slot 7 is overwritten below)
         int n_here = (int)min((int64_t)K2B, hi - base), np_here = 0;
         int64_t slot0 = base;                   // record of the stretch's entry `off`: slot0 + (pieces ? s_slot[off] : off)
         if (pieces) {
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                         if (i < NI) a0 = __builtin_fmaf(xf[i], wf[i], a0);
                     zf = __builtin_fmaf(tanh32(a0 + wf[NI]), wf[NI + 1], zf);
                 }
-                z = (double)zf;
+                z = (double)zf;                                      // (stored as the float it is)
                 if (quarter == 0) {                                  // how far the entry's probability may lie from the fp64 one
                     const MC_SCALAR_MEM float *mg = (const MC_SCALAR_MEM float *)M.margin + (size_t)mdl * (MC_MAX_K + 2);
                     float m = mg[0];
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
                     z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
                 }
             }
-            s_part[quarter][g * 64 + lane] = z;
+            s_part[quarter][g * 64 + lane] = (part_t)z;
         }
         K2_STAMP(4);
         __syncthreads();
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_mlp(DevMlp M, const double *__r
         for (int t = tid; t < n_groups * 64; t += K2_THREADS) {
             const int e = s_list[t];
             if (e == 0xFFFF) continue;
-            const double z = ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t];
+            const double z = (((double)s_part[0][t] + (double)s_part[1][t]) + (double)s_part[2][t]) + (double)s_part[3][t];
             const double pr = logistic(z + M.b2[s_gmodel[t >> 6]], C);
             prob[rec_at(e)] = pr;
             if (FAST && !(threshold_distance(pr) > (double)s_marg[t])) s_fix[atomicAdd(&s_nfix, 1)] = (uint16_t)t;     // (NaN too)
@@ -850,10 +864,10 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
         hipLaunchKernelGGL(k3_simple, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S, feats, k, site_seg, seg_read, qual, info,
                            submodel_in, n, prob, n_dev, overflow);
     else {
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * MC_K2_WG_PER_CU));
+        const bool fast = M.fast && M.wu32 && !submodel_in;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * (fast ? 2 : MC_K2_WG_PER_CU)));
         // (flush records: the fast forward unless the context was told otherwise; a plain batched call -- the estimator protocol,
         // mc_mlp_forward -- is fp64 throughout: its caller gets raw probabilities)
-        const bool fast = M.fast && M.wu32 && !submodel_in;
         if (M.n_in == 7 && fast)
             hipLaunchKernelGGL((k2_mlp<7, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
                                prob, n_dev, overflow, P);

@@ -32,6 +32,12 @@ for i, nm in enumerate(names):
     print('%-18s min %7d  mean %7d  p90 %7d  max %7d ns' % (nm, v.min(), v.mean(), np.percentile(v, 90), v.max()))
 info = t[:, :, 7][used]
 simd = info & 15; quarter = (info >> 4) & 15; gfirst = (info >> 8) & 255; gstep = (info >> 16) & 255; ng = info >> 24
+tick = dcy.sum() / dns.sum() if False else None
+a_cy = t[:, :, 10][used].astype(np.int64) - t[:, :, 15][used].astype(np.int64)        # stretch begins -> A: classified (clock64 ticks)
+b_cy = t[:, :, 12][used].astype(np.int64) - t[:, :, 11][used].astype(np.int64)
+l_cy = t[:, :, 11][used].astype(np.int64) - t[:, :, 10][used].astype(np.int64)
+c_cy = t[:, :, 14][used].astype(np.int64) - t[:, :, 12][used].astype(np.int64)
+print('last stretch, clock64 ticks (~2.07 per ns): loads + classify mean %.0f  lists %.0f  B %.0f  barrier + C %.0f' % (a_cy.mean(), l_cy.mean(), b_cy.mean(), c_cy.mean()))
 print('groups per block: min %d mean %.2f max %d' % (ng.min(), ng.mean(), ng.max()))
 print('g_step histogram:', np.bincount(gstep.astype(int)))
 print('quarter == simd for %.3f of the waves' % float((simd == quarter).mean()))
