@@ -46,8 +46,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(REPO, 'profiles', 'r04_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_literal.hip',
+PMC_FILE = os.path.join(REPO, 'profiles', 'r05_pmc.json')
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip',
                   'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip', 'mcaller_amd/csrc/mc_devparse.inc']
 
 
@@ -665,6 +665,18 @@ def main():
         step_sync(full)
         sync_ms.append(dev.times_ms())
     sync_ms = {k: float(np.median([t[k] for t in sync_ms[1:]])) for k in sync_ms[0]}
+    # ... and through the pipelined interface, one pass in flight: what the timed steps launch (a one-base motif: K0 + k1_fused
+    # in place of the scan, the ordering kernels and k1_emit_runs of the synchronous pass)
+    dev.set_pass_timing(1)
+    one_ms = []
+    for _ in range(7):
+        next_table(full)
+        dev.run_async(6, 0, 0.0, tail_contig=-1, score=True)
+        dev.wait()
+        one_ms.append(dev.times_ms())
+    fused_room = dev.last_pass_info()[0]
+    one_ms = {k: float(np.median([t[k] for t in one_ms[1:]])) for k in one_ms[0]}
+    dev.set_pass_timing(time_every)
 
     # ---- device end to end: distinct shards from pinned host memory through the table slots (one GPU: rank 0's) ----
     device_e2e, shards = None, []
@@ -1005,6 +1017,11 @@ def main():
                        'algorithmic_GBps_of_the_step': alg_bytes * world / (elapsed_max / args.steps) / 1e9,
                        'kernel_ms': kernel_ms, 'kernel_ms_from_passes': len(tot_ms), 'timing_events_every_n_passes': time_every,
                        'kernel_ms_one_pass_at_a_time': sync_ms,
+                       'kernel_ms_pipelined_one_in_flight': dict(one_ms, fused_room=fused_room,
+                                                                 what='hipEvents around the stages of pipelined passes, one in flight: strand_resolve = '
+                                                                      'k0_first_site, window_scan = scan + ordering + emit as one span'
+                                                                      + (' = k1_fused (one kernel, %d record slots per 960-row piece)' % fused_room
+                                                                         if fused_room else '')),
                        'per_table_kernel_ms': dict(per_table, total=per_table_ms, classifier=sync_ms['classifier']),
                        'resident_rescan': rescan,
                        'h2d_table_s': t_up, 'generate_s': t_gen, 'site_reduction': reduction, 'numa_node_rank0': numa_node,
@@ -1048,6 +1065,15 @@ def main():
         out['device_e2e_what'] = ('config.device_e2e: parsed columns from pinned host memory, records back in host memory; like-for-like '
                                   'CPU leg: cpu_baseline_all_cores')
         out['strong_scaling'] = strong
+        if fused_room:
+            f_ms = one_ms['strand_resolve'] + one_ms['window_scan'] + one_ms['emit']
+            out['roofline_fused_dense'] = {'bound': 'hbm', 'kernel': 'k0_first_site + k1_fused (validating): every kernel that touches a table once in a '
+                                           'pipelined pass over a dense reference', 'achieved': alg_bytes / (f_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                                           'unit': 'GB/s', 'frac': alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                           'algorithmic_bytes': alg_bytes, 'kernel_ms': f_ms,
+                                           'the_pair_ms': per_table_ms, 'the_pair_frac': achieved / HBM_PEAK_GBS,
+                                           'what': 'the same algorithmic bytes over K0 + k1_fused (hipEvents, pipelined passes one in flight); the_pair_*: '
+                                                   'K0 + k1_scan<130> + ordering + k1_emit_runs of the synchronous pass (roofline.frac)'}
         out['file_to_file_dense'] = file_to_file_dense or None
         out['file_to_file_dense_what'] = ('`mCaller -m A` file to file through the CLI on one GPU at 10^7 rows ("1e7") and at the headline size '
                                           '("big"): seconds, phase split of the main thread, which phase bounds the mode')

@@ -43,7 +43,10 @@ constexpr int F_THREADS = 256;
 constexpr int FR = 4 * F_THREADS;   // rows staged per piece: four consecutive ones per thread
 constexpr int FH = MC_FH;           // ... of which in front of the piece (what the piece's first windows reach back into)
 constexpr int FT = FR - FH;         // rows per piece
-constexpr int F_MAXB = 16;          // name blocks per staged range
+#ifndef MC_F_MAXB
+#define MC_F_MAXB 16
+#endif
+constexpr int F_MAXB = MC_F_MAXB;   // name blocks per staged range
 constexpr int F_ROW_BITS = 11;
 constexpr uint32_t RF_WIDE = 1, RF_UNUSABLE = 2, RF_ALONE = 4;      // flags of a run, above its first row in s_rrow
 constexpr int F_MAXSPEC = 2 * F_MAXB + 1;

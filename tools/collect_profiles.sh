@@ -8,13 +8,13 @@ export TMPDIR=/tmp
 mkdir -p $out
 src=$(python3 -c "import bench; print(bench.kernel_source_hash())")
 echo "commit $head, kernel sources $src" > $out/HEAD.txt
-# the PMC passes first: bench.py quotes roofline.traffic from profiles/r04_pmc.json if that file was collected on the kernel
+# the PMC passes first: bench.py quotes roofline.traffic from profiles/r05_pmc.json if that file was collected on the kernel
 # sources the library was built from -- on the box's copy of the repository it is, from here on
 : > $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 4 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 python3 tools/pmc_summary.py $out/fetch $out/write $out/pmc.json "python3 bench.py --steps 4 --warmup 0 --kernels-only" $head
-cp $out/pmc.json profiles/r04_pmc.json
+cp $out/pmc.json profiles/r05_pmc.json
 timeout 1200 python3 bench.py > $out/bench.json 2>> $out/bench.err
 # the driver's own command line (20 steps: the pipeline's fill and drain inside the timed region; ms_per_step_steady beside it)
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmdline.json 2>> $out/bench.err
@@ -30,8 +30,16 @@ cp $out/stats1/*/*kernel_stats.csv $out/kernel_stats_one_pass_at_a_time.csv; rm 
 timeout 600 python3 bench.py --events 1e9 --steps 10 --warmup 3 --kernels-only > $out/bench_1e9.json 2>> $out/bench.err
 # dense (-m A): bench line, kernel averages one pass at a time, PMC passes
 timeout 600 python3 bench.py --motif A --events 1e8 --steps 5 --warmup 2 --kernels-only > $out/bench_dense_1e8.json 2>> $out/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/statsd -- python3 bench.py --motif A --events 1e8 --steps 5 --warmup 2 --kernels-only --no-pipeline > /dev/null 2>> $out/bench.err
+# (pipelined passes, one in flight: K0 + k1_fused; the synchronous passes at the end of the same run: the scan + emit pair)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/statsd -- python3 bench.py --motif A --events 1e8 --steps 20 --warmup 3 --kernels-only --depth 1 > /dev/null 2>> $out/bench.err
 cp $out/statsd/*/*kernel_stats.csv $out/kernel_stats_dense_one_pass_at_a_time.csv; rm -rf $out/statsd
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/statsd -- python3 bench.py --motif A --events 1e8 --steps 20 --warmup 2 --kernels-only --no-pipeline > /dev/null 2>> $out/bench.err
+cp $out/statsd/*/*kernel_stats.csv $out/kernel_stats_dense_synchronous_pair.csv; rm -rf $out/statsd
+# dense file to file and config 5, with their kernel averages
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python3 tools/file_to_file.py 1e7 --motif A > $out/file_to_file_dense.log 2>&1
+cp $out/stats3/*/*kernel_stats.csv $out/kernel_stats_file_to_file_dense.csv; rm -rf $out/stats3
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -- python3 tools/config5.py 1e7 --runs 3 > $out/config5.log 2>&1
+cp $out/stats4/*/*kernel_stats.csv $out/kernel_stats_config5.csv; rm -rf $out/stats4
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetchd -- python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/writed -- python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only > /dev/null 2>> $out/bench.err
 python3 tools/pmc_summary.py $out/fetchd $out/writed $out/pmc_dense.json "python3 bench.py --motif A --events 1e8 --steps 3 --warmup 0 --kernels-only" $head

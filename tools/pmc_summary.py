@@ -28,6 +28,7 @@ def short(name):
 
 PER_TABLE_KERNELS = ['k0_first_site', 'k1_scan<64,0>', 'k1_group_scan', 'k1_list', 'k1_emit']     # every kernel that touches a table once
 DENSE_PER_TABLE_KERNELS = ['k0_first_site', 'k1_scan<130,0>', 'k1_group_scan', 'k1_list', 'k1_emit_runs']
+FUSED_PER_TABLE_KERNELS = ['k0_first_site', 'k1_fused']       # a pipelined pass over a dense reference
 
 
 def kernel_source_hash():
@@ -35,7 +36,7 @@ def kernel_source_hash():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
     for rel in ('mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip',
-                'mcaller_amd/csrc/mc_literal.hip', 'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip',
+                'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip', 'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip',
                 'mcaller_amd/csrc/mc_devparse.inc'):     # (bench.KERNEL_SOURCES, in its order)
         with open(os.path.join(repo, rel), 'rb') as fh:
             h.update(fh.read())
@@ -65,6 +66,9 @@ def main():
         wb = write.get(kname, {'mean': 0.0})['mean'] * 1024.0
         per[kname] = {'fetch_bytes_corrected': fb, 'write_bytes': wb, 'hbm_bytes': fb + wb}
     names = PER_TABLE_KERNELS if 'k1_scan<64,0>' in per else DENSE_PER_TABLE_KERNELS
+    pair_bytes = sum(per[kname]['hbm_bytes'] for kname in DENSE_PER_TABLE_KERNELS if kname in per) if 'k1_fused' in per else None
+    if 'k1_fused' in per:
+        names = FUSED_PER_TABLE_KERNELS
     fe = sum(per[kname]['hbm_bytes'] for kname in names if kname in per)
     cal = None
     if 'k1_scan<64,0>' in per:
@@ -73,7 +77,8 @@ def main():
                'note': 'expected value holds for the 10^8-row workload: 9 B/row streamed; the mask words and the descriptors come on top'}
     json.dump({'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write, 'per_launch_bytes_corrected': per, 'workload': workload,
                'head': head, 'kernel_source_sha16': kernel_source_hash(), 'per_table_kernels': [n for n in names if n in per],
-               'calibration': cal, 'per_table_hbm_bytes': fe}, open(out, 'w'), indent=1)
+               'calibration': cal, 'per_table_hbm_bytes': fe,
+               'per_table_hbm_bytes_of_the_scan_and_emit_pair': pair_bytes}, open(out, 'w'), indent=1)
     print('every kernel that touches a table once: %.1f MB of HBM traffic per table' % (fe / 1e6))
 
 
