@@ -353,6 +353,23 @@ def distinct_positions(pos):
     return (np.flatnonzero(seen) + lo).astype(pos.dtype, copy=False)
 
 
+def cut_names(table, rec):
+    """What a cut of the file at a read start can change is `last_read` (extract_contexts.py:161-174): a read whose name equals
+    the name of the LAST READ THAT HAD A SITE ROW is tested on `event_idx > first_read_ind` instead of on its k-mers.  A table
+    knows that for its own reads (name blocks that repeat: the literal path); across a cut it can only matter for the reads of
+    the piece behind the cut up to and including its first read with a site row, against the reads of the piece in front of it
+    from its last read with a site row on.  A read with a flush record has a site row, so the reads up to the first one with
+    a record (`head`) and the reads from the last one with a record on (`tail`) cover both -- a name that comes back anywhere
+    else, gigabytes later, changes nothing.  -> (head names, tail names, the table has records)"""
+    names, seg_read = table.read_names, table.seg_read
+    n = int(rec.n)
+    if n == 0:
+        every = set(names[int(r)] for r in seg_read)
+        return every, every, False
+    first_seg, last_seg = int(rec.site_seg[0]), int(rec.site_seg[n - 1])
+    return (set(names[int(r)] for r in seg_read[:first_seg + 1]), set(names[int(r)] for r in seg_read[last_seg:]), True)
+
+
 STREAM_SHARD_BYTES = 128 << 20      # eventalign text per shard of a streamed file (~10^6 rows)
 STREAM_SHARD_MAX_BYTES = 2 << 30    # a shard beyond this (the cuts are at read starts: one giant read) sends the file to the one-table path
 
@@ -382,6 +399,9 @@ class StreamResult(object):
         self.n_rows = self.n_bytes = self.n_obs = self.n_multi = self.n_wskips = self.n_skipped = 0
         self.positions = np.zeros(0, dtype=np.int32)
         self.signals = self.contexts = None
+        # what crosses a cut of the file in front of / behind this stream (see cut_names): names up to the first read with a
+        # flush record, names from the last such read on, whether any read had one
+        self.head_names, self.tail_names, self.had_records = set(), set(), False
 
 
 def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thresh, modelset, endline, base, motif,
@@ -403,8 +423,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     on_shard(P, rec, fin, tail name, rows of the shards before): every shard's records when they have been handed out (the
     per-site reduction of a --bed run); mark_all: every contig is marked before the first pass (one site numbering for all the
     GPUs of a run); train: features only, the reference's train dicts are collected (pos_label) and returned.
-    -> StreamResult, or raises _Unstreamable (an exit path of the reference, a read name in two shards: whoever called decides
-    what becomes of the rows the sink has seen)."""
+    -> StreamResult, or raises _Unstreamable (an exit path of the reference, a read name on both sides of a cut -- cut_names():
+    whoever called decides what becomes of the rows the sink has seen).  sink() is handed bytes-like objects that are valid
+    during the call only."""
     import os
     import time
     dev = device if device is not None else get_device()
@@ -595,6 +616,14 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             stop = fin.run(rec)
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
+        # `last_read` across the cut in front of this shard (cut_names): a name on both sides of it sends the file to the one-table path
+        head_n, tail_n, has_rec = cut_names(P.table, rec)
+        if head_n & out.tail_names:
+            raise _Unstreamable('a read name on both sides of a cut between two shards')
+        if not out.had_records:
+            out.head_names |= head_n
+        out.tail_names = tail_n if has_rec else (out.tail_names | tail_n)
+        out.had_records = out.had_records or has_rec
         t_s = time.perf_counter()
         clock['format'] += t_s - t_f
         n_out = fin.write_to(sink)
@@ -684,9 +713,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             if P is not None:
                 if P.fatal is not None:
                     raise _Unstreamable('an exit path of the reference')
-                if out.names.intersection(P.table.read_names):
-                    raise _Unstreamable('a read name in two shards')       # `last_read` would cross the cut (:161)
-                out.names.update(P.table.read_names)
+                out.names.update(P.table.read_names)                       # (what crosses a cut is looked at when the shard's records are here)
                 out.messages.extend(P.messages)
                 rows_before = rows_seen
                 rows_seen += P.table.n_rows

@@ -7,8 +7,10 @@ two passes in flight, every shard's rows appended to the worker's part file as t
 parts in file order, which is the reference's `-t 1` order (extract_contexts.py:179,242: a window never spans two reads).
 Two things cross a cut: the first unfiltered row after a piece closes that piece's last window (R6) and supplies its `chrom`
 column (R8) -> `tail`, which a worker reports as soon as its first shard has been parsed and needs only when it enqueues its
-last; and `last_read`, which only matters when a read name occurs in two pieces -> the parent compares the pieces' names when
-the workers are done, and such a file is not cut at all (the caller falls back to one GPU).  No collective is needed for the
+last; and `last_read` (:161-174), which can only matter for the reads behind a cut up to the first one with a site row against
+the reads in front of it from the last one with a site row on (extract_contexts.cut_names) -> the parent compares those names
+when the workers are done; a name on both sides of a cut, and the file is not cut at all (the caller falls back to one GPU).  A
+read name that comes back anywhere else in the file changes nothing: the pieces stand.  No collective is needed for the
 `.diffs` file; the per-site reduction feeding make_bed is the one exchange step (mc_site_allreduce, RCCL).
 
 The protocol between the parent and its workers: every step that all workers take together is decided by the parent for ALL
@@ -17,7 +19,7 @@ of them at once -- a worker never enters a collective (ncclCommInitRank, ncclAll
   1. worker -> parent: the contig of its first unfiltered row ("head"), as soon as it is known
      parent -> worker: go(tail) -- the head of the next piece that has one -- or abort
   2. worker -> parent: done (counters, read names, rows) or the reference's exit path (`unstreamable`)
-     parent: a read name in two pieces, an exit path -> abort (the caller runs the one-GPU path)
+     parent: a read name on both sides of a cut (cut_names), an exit path -> abort (the caller runs the one-GPU path)
   with --bed, everything rank-local (the device-side counts, shard after shard) has happened inside step 2; then
   3. parent -> worker: probe            worker -> parent: can RCCL be loaded here?  (rank 0: the unique id)
   4. parent -> worker: init(uid) | host worker -> parent: communicator up / not
@@ -178,7 +180,8 @@ def _job(conn, device, job, cache):
         return False
     t_done = time.perf_counter()
     clock = getattr(ec.stream_features, 'last_clock', None) or {}
-    conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, names=list(res.names), n_rows=res.n_rows,
+    conn.send(dict(stop=None, stdout=buf.getvalue(), messages=res.messages, head_names=list(res.head_names), tail_names=list(res.tail_names),
+                   had_records=bool(res.had_records), n_rows=res.n_rows,
                    n_obs=res.n_obs, positions=res.positions, n_multi=res.n_multi, n_wskips=res.n_wskips,
                    n_skipped=res.n_skipped, n_bytes_out=res.n_bytes, signals=res.signals, contexts=res.contexts,
                    seconds=dict(total=t_done - t_job, setup=t_ready - t_job, stream=t_done - t_ready,
@@ -419,11 +422,14 @@ def extract_features_sharded(tsv_input, fasta_input, read2qual, k, skip_thresh, 
         results = W.gather()
         if results is None or any(x.get('stop') for x in results):
             return W.stop()
-        seen = set()
+        # `last_read` across the cuts between the pieces (extract_contexts.cut_names): a name on both sides of one -- among the
+        # reads behind it up to the first with a flush record and the reads in front of it from the last with one -- and the
+        # file is not cut.  A name that comes back anywhere else changes nothing: the pieces stand.
+        tail = set()
         for x in results:
-            if seen.intersection(x['names']):
-                return W.stop()                                  # a read name in two pieces: `last_read` crosses the cut
-            seen.update(x['names'])
+            if tail.intersection(x['head_names']):
+                return W.stop()
+            tail = set(x['tail_names']) if x['had_records'] else tail | set(x['tail_names'])
         t_streamed = time.perf_counter()
         beds, reduction_failed = None, None
         if bed:

@@ -453,3 +453,42 @@ def test_train_mode_over_two_and_three_workers_equals_one_gpu(tmp_path):
         assert open(tmp, 'rb').read() == want_rows
         assert multi_gpu.train_dicts[0] == sig and multi_gpu.train_dicts[1] == ctx
         assert [l for l in buf.getvalue().splitlines() if 'observations' in l or 'regions' in l] == want_lines
+
+
+def test_sharded_run_survives_a_read_name_that_comes_back(tmp_path):
+    """`--gpus 3` over a file in which a read name occurs twice, far apart: the pieces stand (the name is on neither side of a
+    cut in the sense of extract_contexts.cut_names), no fall-back to one GPU, bytes and counter lines equal the one-GPU run."""
+    from mcaller_amd import synth, mCaller, multi_gpu, _lib
+    codes = synth.genome(length=300000, seed=23)
+    table, qual = synth.make_table(400000, seed=6, codes=codes, read_len=(1500, 6000))
+    seg_read = table.seg_read.copy()
+    seg_read[table.n_seg - 4] = seg_read[3]
+    seg_read[table.n_seg // 2] = seg_read[8]
+    table = _lib.Table(table.pos, None, None, table.event_idx, table.flags, table.seg_row_begin, seg_read, table.seg_contig, table.n_reads,
+                       read_names=table.read_names, evmu=table.evmu)
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    model = os.path.join(H.MODELS, 'r95_twobase_model_NN_6_m6A.npz')
+    common = ['-m', 'GATC', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', model]
+    real, took, outs = multi_gpu.extract_features_sharded, [], []
+
+    def spy(*a, **kw):
+        took.append(real(*a, **kw))
+        return took[-1]
+    multi_gpu.extract_features_sharded = spy
+    try:
+        for extra in ([], ['--gpus', '3']):
+            out_path = paths['tsv'][:-4] + '.diffs.6'
+            if os.path.exists(out_path):
+                os.remove(out_path)
+            os.environ['MCALLER_SHARD_DEVICES'] = ','.join(['0'] * (int(extra[1]) if extra else 1))
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    mCaller.main(common + extra)
+            finally:
+                del os.environ['MCALLER_SHARD_DEVICES']
+            outs.append((open(out_path, 'rb').read(), [l for l in buf.getvalue().split('\n') if 'observations' in l or 'positions' in l or 'regions' in l]))
+    finally:
+        multi_gpu.extract_features_sharded = real
+    assert took == [True]                                        # the sharded run stood: no second pass on one GPU
+    assert outs[0] == outs[1] and outs[0][0].count(b'\n') > 200

@@ -342,3 +342,69 @@ def test_streamed_file_with_a_shard_the_device_parser_declines(tmp_path, monkeyp
     want = _run_extract(paths, args, monkeypatch, shards=0)
     assert got[0] == want[0] == 'ok' and got[2] == want[2]
     assert got[1] == want[1] and len(got[1]) > 1000
+
+
+def _rename(table, seg_to, seg_from):
+    """The read of segment seg_to gets the name (and the quality) of the read of segment seg_from: a read name that comes back."""
+    from mcaller_amd import _lib
+    seg_read = table.seg_read.copy()
+    seg_read[seg_to] = seg_read[seg_from]
+    return _lib.Table(table.pos, None, None, table.event_idx, table.flags, table.seg_row_begin, seg_read, table.seg_contig, table.n_reads,
+                      read_names=table.read_names, evmu=table.evmu)
+
+
+def test_a_read_name_that_comes_back_far_away_does_not_stop_the_stream(tmp_path, monkeypatch):
+    """A read name that occurs twice in a file, dozens of reads apart: `last_read` (extract_contexts.py:161-174) never equals it when
+    its second read begins, so the cuts between the shards stand (extract_contexts.cut_names) -- the file is streamed, rows and
+    counter lines equal the one-table path's.  (Up to round 4 any repeated name sent the whole file to the one-table path.)"""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=500000, seed=33)
+    table, qual = synth.make_table(300000, seed=17, codes=codes, read_len=(700, 5000))
+    assert table.n_seg > 40
+    table = _rename(_rename(table, 30, 4), table.n_seg - 3, 11)
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    paths['positions'] = None
+    args = dict(k=6, skip_thresh=0, qual_thresh=0.0, base='A', motif='GATC', model='r95')
+    streamed = []
+    real = ec.stream_features
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        streamed.append(out.n_bytes)
+        return out
+    monkeypatch.setattr(ec, 'stream_features', spy)
+    got = _run_extract(paths, args, monkeypatch, shards=9)
+    assert streamed and streamed[0] > 0                         # streamed to the end: no fall-back
+    want = _run_extract(paths, args, monkeypatch, shards=0)
+    assert got == want and got[0] == 'ok' and len(got[1]) > 1000
+
+
+def test_a_read_name_on_both_sides_of_a_cut_takes_the_one_table_path(tmp_path, monkeypatch):
+    """... and the case that does matter: a read, a read the quality filter drops, and the first read's name again -- `last_read`
+    still holds the name when it comes back.  With a cut between them the stream gives up (the rows appended so far are taken
+    back) and the one-table path, whose literal machine handles the repeat, writes the file: the same bytes either way."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=400000, seed=34)
+    table, qual = synth.make_table(200000, seed=18, codes=codes, read_len=(900, 3000))
+    qual = np.array(qual, dtype=np.float64)
+    assert table.n_seg > 40
+    for s in range(5, table.n_seg - 3, 6):                       # every sixth read: X, (filtered), X again
+        table = _rename(table, s + 2, s)
+        qual[table.seg_read[s + 1]] = 1.0
+    paths = synth.write_inputs(table, qual, codes, str(tmp_path))
+    paths['positions'] = None
+    args = dict(k=6, skip_thresh=0, qual_thresh=5.0, base='A', motif='GATC', model='r95')
+    streamed = []
+    real = ec.stream_features
+
+    def spy(*a, **kw):
+        out = real(*a, **kw)
+        streamed.append(out.n_bytes)
+        return out
+    monkeypatch.setattr(ec, 'stream_features', spy)
+    got = _run_extract(paths, args, monkeypatch, shards=table.n_seg)          # a cut at (nearly) every read start
+    assert not streamed                                          # the stream gave up
+    want = _run_extract(paths, args, monkeypatch, shards=0)
+    assert got == want and got[0] == 'ok' and len(got[1]) > 500
