@@ -383,6 +383,11 @@ typedef struct mc_devparse_result {
     const uint8_t *flags;             /* [n_rows] host copy of the flag column (pinned, owned by ctx)   */
 } mc_devparse_result;
 int mc_read_file_range(const char *path, int64_t byte_begin, int64_t byte_end, char *dst, int32_t n_threads);
+/* ... or WITHOUT the copy: the range mapped from the page cache and registered for the DMA engines (a streamed shard's text goes
+ * to the GPU from where the kernel keeps it).  *ptr points at byte `lo`; valid until mc_unmap_file_range(*handle).  Returns
+ * non-zero where the runtime cannot register the mapping (no GPU ...): read the range with mc_read_file_range then. */
+int mc_map_file_range(const char *path, int64_t lo, int64_t hi, void **handle, const char **ptr);
+void mc_unmap_file_range(void *handle);
 int mc_ctx_parse_begin(mc_ctx *ctx, const char *text, int64_t n_bytes, const char *const *contig_names, int32_t n_contigs,
                        int64_t max_rows, int32_t *slot);
 int mc_ctx_parse_end(mc_ctx *ctx, int32_t slot, mc_devparse_result *out);

@@ -125,6 +125,9 @@ def lib():
         L.mc_ctx_fetch_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_void_p, C.POINTER(C.c_int64)]
         L.mc_read_file_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]
+        L.mc_map_file_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.mc_unmap_file_range.argtypes = [C.c_void_p]
+        L.mc_unmap_file_range.restype = None
         L.mc_ctx_parse_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int64,
                                          C.POINTER(C.c_int32)]
         L.mc_ctx_parse_end.argtypes = [C.c_void_p, C.c_int32, C.POINTER(DevParseResult)]
@@ -292,18 +295,42 @@ class Table(object):
 
 
 class TextBlock(object):
-    """A byte range of a file in the pinned host pool (what the device parser is given)."""
+    """A byte range of a file where the DMA engines can read it (what the device parser is given): mapped from the page cache
+    and registered (mc_map_file_range: no copy by the CPU), or -- MCALLER_READER=pread, or where the mapping cannot be
+    registered -- read into a block of the pinned host pool."""
 
     def __init__(self, path, lo, hi, n_threads=0):
         self.n_bytes = int(hi - lo)
+        self._map = None
+        self._mem = None
+        if self.n_bytes and os.environ.get('MCALLER_READER', 'mmap') != 'pread':
+            handle, ptr = C.c_void_p(), C.c_void_p()
+            if lib().mc_map_file_range(path.encode('utf-8'), int(lo), int(hi), C.byref(handle), C.byref(ptr)) == 0:
+                self._map = handle
+                self.ptr = ptr.value
+                self.array = np.frombuffer((C.c_char * self.n_bytes).from_address(self.ptr), dtype=np.uint8)
+                return
         self._mem = PinnedArray((max(self.n_bytes, 1),), np.uint8)
         self.array = self._mem.array
         self.ptr = self._mem.ptr
         if self.n_bytes:
             check(lib().mc_read_file_range(path.encode('utf-8'), int(lo), int(hi), self.ptr, int(n_threads)))
 
+    @property
+    def mapped(self):
+        return self._map is not None
+
     def token(self, off, n):
         return bytes(self.array[off:off + n]).decode('utf-8', 'surrogateescape')
+
+    def __del__(self):
+        try:
+            if self._map is not None:
+                self.array = None
+                lib().mc_unmap_file_range(self._map)
+                self._map = None
+        except Exception:       # noqa (interpreter shutdown)
+            pass
 
 
 def device_table(res, text):

@@ -5,6 +5,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -175,6 +176,58 @@ extern "C" int mc_host_is_pinned(const void *p) {
     for (const Block &b : g_pool)
         if ((const char *)p >= (const char *)b.p && (const char *)p < (const char *)b.p + b.bytes) return b.pinned ? 1 : 0;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A byte range of a file where the DMA engines can read it WITHOUT a copy by the CPU: the range mapped (MAP_SHARED: the page
+// cache's own pages) and registered with the runtime.  What the streamed reader did until round 5 -- pread into pinned memory, a
+// CPU copy per byte -- reaches 30 GB/s on the two host threads a worker of an eight-GPU run has (38 on sixteen); the mapped range
+// travels at the link's 57 GB/s, and mapping + registering + releasing 128 MB costs 0.7 ms (tools/micro/mmap_register.hip,
+// NOTES.md section 14: "ruled out on paper" in round 4 at a microsecond per page, measured at 0.011).
+// ---------------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+namespace {
+struct MapRec { void *base; size_t len; };
+}
+extern "C" int mc_map_file_range(const char *path, int64_t lo, int64_t hi, void **handle, const char **ptr) {
+    if (!path || !handle || !ptr || lo < 0 || hi <= lo) {
+        mc_set_error("mc_map_file_range: bad arguments");
+        return -12;
+    }
+    *handle = nullptr;
+    *ptr = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        mc_set_error("cannot open %s: %s", path, strerror(errno));
+        return -1;
+    }
+    const int64_t page = sysconf(_SC_PAGESIZE), a0 = lo & ~(page - 1);
+    const size_t len = (size_t)(hi - a0);
+    void *base = mmap(nullptr, len, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, (off_t)a0);
+    close(fd);
+    if (base == MAP_FAILED) {
+        mc_set_error("mmap of %s failed: %s", path, strerror(errno));
+        return -1;
+    }
+    if (hipHostRegister(base, len, hipHostRegisterPortable) != hipSuccess) {        // (no GPU, or the runtime refuses file pages: the caller reads)
+        (void)hipGetLastError();
+        munmap(base, len);
+        mc_set_error("hipHostRegister of %zu mapped bytes of %s failed", len, path);
+        return -10;
+    }
+    *handle = new MapRec{base, len};
+    *ptr = (const char *)base + (lo - a0);
+    return 0;
+}
+
+extern "C" void mc_unmap_file_range(void *handle) {
+    MapRec *m = (MapRec *)handle;
+    if (!m) return;
+    (void)hipHostUnregister(m->base);
+    munmap(m->base, m->len);
+    delete m;
 }
 
 extern "C" int mc_host_pool_config(int32_t parser_uses_pool, int64_t keep_bytes) {
