@@ -296,14 +296,14 @@ class Table(object):
 
 class TextBlock(object):
     """A byte range of a file where the DMA engines can read it (what the device parser is given): mapped from the page cache
-    and registered (mc_map_file_range: no copy by the CPU), or -- MCALLER_READER=pread, or where the mapping cannot be
-    registered -- read into a block of the pinned host pool."""
+    and registered (mc_map_file_range: no copy by the CPU; MCALLER_READER=mmap), or -- the default, and where the mapping cannot
+    be registered -- read into a block of the pinned host pool."""
 
     def __init__(self, path, lo, hi, n_threads=0):
         self.n_bytes = int(hi - lo)
         self._map = None
         self._mem = None
-        if self.n_bytes and os.environ.get('MCALLER_READER', 'mmap') != 'pread':
+        if self.n_bytes and os.environ.get('MCALLER_READER', 'pread').startswith('mmap'):
             handle, ptr = C.c_void_p(), C.c_void_p()
             if lib().mc_map_file_range(path.encode('utf-8'), int(lo), int(hi), C.byref(handle), C.byref(ptr)) == 0:
                 self._map = handle
@@ -327,7 +327,8 @@ class TextBlock(object):
         try:
             if self._map is not None:
                 self.array = None
-                lib().mc_unmap_file_range(self._map)
+                if os.environ.get('MCALLER_READER') != 'mmap_keep':      # (experiment: the mappings stay until the process ends)
+                    lib().mc_unmap_file_range(self._map)
                 self._map = None
         except Exception:       # noqa (interpreter shutdown)
             pass

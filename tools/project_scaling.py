@@ -1,7 +1,7 @@
 """What ONE worker of an N-GPU run costs, measured on one GPU: a PROJECTION of the strong-scaling curve before a node exists.
 
   python tools/project_scaling.py --inputs DIR [--parts 2,4,8] [--runs 3] [--json]
-  python tools/project_scaling.py --inputs DIR --one N [--reader pread|mmap] [--runs 3] [--json]     (what --parts runs per N)
+  python tools/project_scaling.py --inputs DIR --one N [--reader pread|mmap|mmap_keep] [--runs 3] [--json]     (what --parts runs per N)
 
 `mCaller --gpus N` (mcaller_amd/multi_gpu.py; the reference's fan-out: mCaller.py:62-70) cuts the file's consumed byte range
 at read starts into N pieces and starts one worker per GPU; a worker streams its piece with stream_features under
@@ -24,8 +24,8 @@ def one_worker(inputs, n_parts, runs, reader):
     cores_all = int(L.mc_host_cores())
     share = max(2, cores_all // n_parts) if n_parts > 1 else cores_all
     os.environ['MCALLER_HOST_CORES'] = str(share)
-    if reader == 'mmap':
-        os.environ['MCALLER_READER'] = 'mmap'
+    if reader != 'pread':
+        os.environ['MCALLER_READER'] = reader           # mmap | mmap_keep (mcaller_amd._lib.TextBlock)
     from mcaller_amd import extract_contexts as ec
     from mcaller_amd.model_io import load_model_file, shipped_model
     from mcaller_amd.read_qual import extract_read_quality
