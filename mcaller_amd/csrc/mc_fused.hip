@@ -50,9 +50,15 @@ constexpr int F_MAXB = MC_F_MAXB;   // name blocks per staged range
 constexpr int F_ROW_BITS = 11;
 constexpr uint32_t RF_WIDE = 1, RF_UNUSABLE = 2, RF_ALONE = 4;      // flags of a run, above its first row in s_rrow
 constexpr int F_MAXSPEC = 2 * F_MAXB + 1;
+constexpr int F_HEAVY = FR / 4;     // runs of several events a wave can list: a wave takes every fourth 64 of the (at most FR) runs
 static_assert(FH % 4 == 0 && FH >= 16 && FH < FR / 2, "whole groups of four rows in front of a piece");
 static_assert(FR < (1 << F_ROW_BITS), "s_rrow keeps the run's flags above its row");
 
+#ifndef MC_FD_STOP
+#define MC_FD_STOP 0    // (variant builds, tools/fused_probe.py: n > 0 ends the kernel behind its n-th phase -- what the phases cost)
+#endif
+// (what the phases so far left in LDS is read back and stored: a store nobody reads is not a store the compiler has to keep)
+#define FD_STOP_AFTER(n) do { if (MC_FD_STOP == (n)) { A.O.feats[q0 * k + tid] = s_mean[tid] + (double)(s_ro[tid] + s_rrow[tid] + s_rpos[tid] + s_rc0[tid] + s_dc[tid] + s_cnt[tid & 15] + s_bfirst[tid & 15]); return; } } while (0)
 #ifdef MC_FD_TRACE      // (variant build: 100 MHz time stamps of the phases of 1024 workgroups in the middle of the grid)
 __device__ unsigned long long g_fd_trace[1024 * 10];
 #define FD_STAMP(i) do { if (tid == 0 && blockIdx.x >= 40000 && blockIdx.x < 41024) g_fd_trace[(blockIdx.x - 40000) * 10 + (i)] = wall_clock64(); } while (0)
@@ -188,6 +194,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ int16_t s_bfirst[F_MAXB + 1];    // first run of the block (the runs of later blocks behind it); -1 until known
     __shared__ FSpec s_spec[F_MAXSPEC];
     __shared__ uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
+    __shared__ uint16_t s_heavy[4 * F_HEAVY];        // per wave: its runs of more than one event
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
     __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
     __shared__ int4 s_wfirst[F_THREADS / 64];   // ... its first one: (row, position, first row of its block that is in a run); row -1: none
@@ -286,6 +293,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     }
     lds_barrier();
     FD_STAMP(1);
+    FD_STOP_AFTER(1);
     const int nblk = s_nblk;
     const bool usable = nblk <= F_MAXB;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -407,6 +415,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         lds_barrier();
         FD_STAMP(2);
+        FD_STOP_AFTER(2);
         // every wave decides the first row in a run of the waves up to itself (is it a head?  alone?) and adds up what lies before it
         int hbase = 0, ibase = 0, n_in = 0;
         {
@@ -466,6 +475,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (tid == 0) { s_rc0[n_runs] = (uint16_t)n_in; s_rrow[n_runs] = (uint16_t)nst; s_ro[n_runs] = 0; }
         lds_barrier();
         FD_STAMP(3);
+        FD_STOP_AFTER(3);
     }
     // ---- the mean of every run (its rows in file order, NumPy's pairwise order: np.mean, :186; values fl(d / 1e4), :286) and its
     // site: the first 'M' of meth_ref[p : p + k] (:176, :270) from two words of the block's strand mask -- the words of all runs
@@ -483,11 +493,16 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             const int p = s_rpos[R];
             const int pw = ((p >= 0 && p < B.contig_len) ? max(p - 1, 0) : 0) >> 5;     // (two zero words lie behind every contig's mask)
             const uint32_t *g = (B.rev ? A.R.mr : A.R.mf) + B.mask_off + pw;
+#ifdef MC_FD_FAKE_WORDS          // (variant build, timing only: what the two words' trip costs the phase)
+            lo = (uint32_t)pw * 2654435761u; hi = ~lo; (void)g;
+#else
             lo = g[0];
             hi = g[1];
+#endif
         }
     };
     site_words(tid, wlo, whi);
+    int n_heavy = 0;                            // the wave's runs of several events so far (the same in all lanes)
     // the special closers of the piece: what the first unfiltered row of a name block, the head of its first run, and the end
     // of the shard close -- one thread per block, beside the means of the others
     if (tid <= nblk) {
@@ -533,39 +548,16 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     for (int R = tid; R < n_runs; R += F_THREADS) {
         uint32_t nlo, nhi;
         site_words(R + F_THREADS, nlo, nhi);
-        double mean = 0.0;
-        uint32_t rf = 0;
+        // (every second run is ONE event: its mean is fl(d / 1e4), narrow by construction -- done here; the runs of several events are
+        // listed per wave and taken densely below: their sums, the division and the narrow test are most of what a run costs, and
+        // a wave would go through them for the half of its lanes that have none)
         const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
-        const int d0 = s_dc[c0], d1 = s_dc[c0 + 1], d2 = s_dc[c0 + 2], d3 = s_dc[c0 + 3];     // (there is room behind the last row)
-        if (n > 128) { rf = RF_UNUSABLE; mean = 0.0; }          // NumPy's pairwise recursion proper: the row-by-row kernel
-        else if (n >= 8) {
-            const int n8 = n - (n % 8);
-            double r[8];
-#pragma unroll
-            for (int v = 0; v < 8; ++v) r[v] = 0.0;
-            for (int j = 0; j < n8; j += 8) {
-#pragma unroll
-                for (int v = 0; v < 8; ++v) r[v] += div1e4(s_dc[c0 + j + v]);
-            }
-            double acc = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            for (int j = n8; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
-            mean = (0.0 + acc) / (double)n;
-        } else {
-            // (every second run is one event: fl(d / 1e4) over 1 -- no division, and narrow by construction)
-            double acc = -0.0 + div1e4(d0);
-            if (n > 1) acc += div1e4(d1);
-            if (n > 2) acc += div1e4(d2);
-            if (n > 3) acc += div1e4(d3);
-            for (int j = 4; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
-            mean = 0.0 + acc;
-            if (n > 1) mean = mean / (double)n;
+        if (n == 1) s_mean[R] = div1e4(s_dc[c0]);
+        {
+            const unsigned long long hm = __ballot(n > 1);
+            if (n > 1) s_heavy[wave * F_HEAVY + n_heavy + __popcll(hm & lt)] = (uint16_t)R;
+            n_heavy += __popcll(hm);
         }
-        if (n > 1 && n <= 128) {
-            int32_t as_int;
-            if (!slot_is_narrow(mean, &as_int)) rf |= RF_WIDE;
-        }
-        s_mean[R] = mean;
-        if (rf) s_rrow[R] |= (uint16_t)(rf << F_ROW_BITS);
         // the site
         const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
         int bj = 0;
@@ -597,9 +589,48 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (lane == 0) s_cnt[R >> 6] = (uint8_t)__popcll(cm);
         wlo = nlo; whi = nhi;
     }
+    n_heavy = __shfl(n_heavy, 0);               // (the wave's first lane took every turn of the loop)
+    // ---- the runs of several events, the wave's own, densely: the mean in NumPy's pairwise order (np.mean, :186; values fl(d / 1e4),
+    // :286), and whether it travels as an integer ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // (a wave's LDS operations execute in order: its own list)
+#pragma unroll 1
+    for (int i = lane; i < n_heavy; i += 64) {
+        const int R = s_heavy[wave * F_HEAVY + i];
+        double mean = 0.0;
+        uint32_t rf = 0;
+        const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
+        if (n > 128) { rf = RF_UNUSABLE; mean = 0.0; }          // NumPy's pairwise recursion proper: the row-by-row kernel
+        else if (n >= 8) {
+            const int n8 = n - (n % 8);
+            double r[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) r[v] = 0.0;
+            for (int j = 0; j < n8; j += 8) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) r[v] += div1e4(s_dc[c0 + j + v]);
+            }
+            double acc = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (int j = n8; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
+            mean = (0.0 + acc) / (double)n;
+        } else {
+            const int d0 = s_dc[c0], d1 = s_dc[c0 + 1], d2 = s_dc[c0 + 2], d3 = s_dc[c0 + 3];     // (there is room behind the last row)
+            double acc = (-0.0 + div1e4(d0)) + div1e4(d1);
+            if (n > 2) acc += div1e4(d2);
+            if (n > 3) acc += div1e4(d3);
+            for (int j = 4; j < n; ++j) acc += div1e4(s_dc[c0 + j]);
+            mean = (0.0 + acc) / (double)n;
+        }
+        if (n <= 128) {
+            int32_t as_int;
+            if (!slot_is_narrow(mean, &as_int)) rf |= RF_WIDE;
+        }
+        s_mean[R] = mean;
+        if (rf) s_rrow[R] |= (uint16_t)(rf << F_ROW_BITS);
+    }
     FD_STAMP(4);
     lds_barrier();
     FD_STAMP(5);
+    FD_STOP_AFTER(4);
     // ---- the closers of the piece, in row order (the order in which the reference flushes): every 64 consecutive runs have
     // counted their closed windows; a wave numbers its runs' windows with one ballot per turn and lists the closing runs (the
     // events' room is free now) ----
@@ -648,6 +679,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     if (n_win > cap) { if (tid == 0) atomicOr(&A.cnt->overflow, 1u); return; }
     lds_barrier();
     FD_STAMP(6);
+    FD_STOP_AFTER(5);
     // ---- a window per thread ----
     const uint32_t kbits = (1u << k) - 1u;
     for (int w = tid; w < n_win; w += F_THREADS) {
