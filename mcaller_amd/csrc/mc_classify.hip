@@ -865,7 +865,11 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
                            submodel_in, n, prob, n_dev, overflow);
     else {
         const bool fast = M.fast && M.wu32 && !submodel_in;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * (fast ? 2 : MC_K2_WG_PER_CU)));
+        // (two workgroups per CU where there are millions of records -- a one-base motif; the passes of a sparse motif score a few
+        // hundred thousand beside the next pass's scan, and a second workgroup per CU there takes the scan's wave slots: k2_mlp
+        // 33 -> 93 us, the scan 164 -> 184)
+        const bool many = P.cnt != nullptr || n >= ((int64_t)4 << 20);
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * ((fast && many) ? 2 : MC_K2_WG_PER_CU)));
         // (flush records: the fast forward unless the context was told otherwise; a plain batched call -- the estimator protocol,
         // mc_mlp_forward -- is fp64 throughout: its caller gets raw probabilities)
         if (M.n_in == 7 && fast)
