@@ -15,8 +15,21 @@ def default_device_index():
     return 0
 
 
+def _serialized(fn):
+    """A method that calls the library on the context: one at a time (the C ABI's contract)."""
+    import functools
+
+    @functools.wraps(fn)
+    def call(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return call
+
+
 class Device(object):
     def __init__(self, index=None):
+        import threading
+        self._lock = threading.RLock()      # calls on a context are serialized (include/mcaller_hip.h): the stream's formatter thread scores a stray record while the main thread waits
         self.index = default_device_index() if index is None else int(index)
         self._ctx = C.c_void_p()
         check(lib().mc_ctx_create(self.index, C.byref(self._ctx)))
@@ -39,10 +52,12 @@ class Device(object):
             pass
 
     # ---- resident inputs ----
+    @_serialized
     def set_reference(self, arrays):
         v = make_ref_view(arrays)
         check(lib().mc_ctx_set_reference(self._ctx, C.byref(v)))
 
+    @_serialized
     def set_reference_motif(self, arrays, motif_fwd, repl_fwd, motif_rev, repl_rev):
         """The reference from its raw bases, site masks made on the GPU (arrays: MarkedReference.raw_arrays(); motifs:
         MarkedReference.motif_for_the_device())."""
@@ -51,6 +66,7 @@ class Device(object):
         check(lib().mc_ctx_set_reference_motif(self._ctx, C.byref(v), motif_fwd, repl_fwd, len(motif_fwd), motif_rev, repl_rev,
                                                len(motif_rev)))
 
+    @_serialized
     def fetch_reference(self, n_seq_bytes, n_words, n_contigs):
         """(seq, mbits_fwd, mbits_rev, rank_fwd, rank_rev, site_base, n_sites) as the device holds them (tests)."""
         seq = np.empty(n_seq_bytes, dtype=np.uint8)
@@ -61,24 +77,29 @@ class Device(object):
                                            _ptr(base), C.byref(n_sites)))
         return seq, mf, mr, rf, rr, base, n_sites.value
 
+    @_serialized
     def upload_table(self, table):
         v = table.view()
         check(lib().mc_ctx_upload_table(self._ctx, C.byref(v)))
         self.n_rows = table.n_rows
         return self.current_slot()
 
+    @_serialized
     def current_slot(self):
         return int(lib().mc_ctx_current_slot(self._ctx))
 
+    @_serialized
     def select_table(self, slot, as_new=False):
         """Make the table resident in `slot` the current one again; as_new: the next pass does everything the first pass over a
         table does (every row validated), whatever earlier passes learned about it."""
         check(lib().mc_ctx_select_table(self._ctx, int(slot), 1 if as_new else 0))
 
+    @_serialized
     def reserve_tables(self, max_rows, max_segs, max_reads):
         """Size the table slots, the per-pass scratch and the record sets once for a stream of tables up to these sizes."""
         check(lib().mc_ctx_reserve_tables(self._ctx, int(max_rows), int(max_segs), int(max_reads)))
 
+    @_serialized
     def upload_table_async(self, table, qual=None):
         """Enqueue the upload of `table` (+ its read qualities) into a free slot and make it the current table; returns the
         slot.  The table's arrays must stay alive and untouched until wait_upload(slot) (or until the records of a pass over
@@ -98,6 +119,7 @@ class Device(object):
         return slot.value
 
     # ---- the eventalign text parsed on the device (mc_ctx_parse_*) ----
+    @_serialized
     def parse_begin(self, text, contig_names, max_rows):
         """Send a TextBlock and enqueue the parse into a free table slot -> slot."""
         arr = (C.c_char_p * max(1, len(contig_names)))()
@@ -107,6 +129,7 @@ class Device(object):
         check(lib().mc_ctx_parse_begin(self._ctx, text.ptr, int(text.n_bytes), arr, len(contig_names), int(max_rows), C.byref(slot)))
         return slot.value
 
+    @_serialized
     def parse_end(self, slot, text):
         """-> the Table (columns on the device, in `slot`; upload_table_async finishes it), or None: the shard needs the host
         parser (the slot has been given back)."""
@@ -120,9 +143,11 @@ class Device(object):
         t.device_slot = int(slot)
         return t
 
+    @_serialized
     def parse_abandon(self, slot):
         check(lib().mc_ctx_parse_abandon(self._ctx, int(slot)))
 
+    @_serialized
     def fetch_columns(self, slot, n_rows):
         """(pos, evmu [n, 2], event_idx, flags) of the table in `slot`, copied back (tests)."""
         pos, evmu = np.empty(n_rows, dtype=np.int32), np.empty((n_rows, 2), dtype=np.int32)
@@ -130,25 +155,30 @@ class Device(object):
         check(lib().mc_ctx_fetch_columns(self._ctx, int(slot), int(n_rows), _ptr(pos), _ptr(evmu), _ptr(idx), _ptr(fl)))
         return pos, evmu, idx, fl
 
+    @_serialized
     def wait_upload(self, slot):
         check(lib().mc_ctx_wait_upload(self._ctx, int(slot)))
 
+    @_serialized
     def upload_times_ms(self, slot):
         """(H2D ms, 0.0) of the last upload into `slot`; waits for it.  (Nothing runs at upload: the first pass validates.)"""
         a, b = C.c_float(0), C.c_float(0)
         check(lib().mc_ctx_upload_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    @_serialized
     def parse_times_ms(self, slot):
         """(text H2D ms, device parser ms) of the parse begun into `slot` (between parse_begin and parse_end / parse_abandon)."""
         a, b = C.c_float(0), C.c_float(0)
         check(lib().mc_ctx_parse_times_ms(self._ctx, int(slot), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    @_serialized
     def set_read_quality(self, qual):
         q = np.ascontiguousarray(qual, dtype=np.float64)
         check(lib().mc_ctx_set_read_quality(self._ctx, _ptr(q), len(q)))
 
+    @_serialized
     def set_mlp(self, weights, submodel_of_char):
         """weights: list of MLPWeights (same shapes); submodel_of_char: uint8[256]."""
         n_in, n_hidden = weights[0].n_in, weights[0].n_hidden
@@ -164,6 +194,7 @@ class Device(object):
         check(lib().mc_ctx_set_mlp(self._ctx, len(weights), n_in, n_hidden, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
                                    _ptr(soc)))
 
+    @_serialized
     def set_forest(self, forests, submodel_of_char):
         """forests: list of ForestWeights (one per sub-model)."""
         arr = forest_arrays(forests)
@@ -173,6 +204,7 @@ class Device(object):
                                       _ptr(arr['feature']), _ptr(arr['threshold']), _ptr(arr['value']), _ptr(soc)))
         self._clf = 'forest'
 
+    @_serialized
     def set_simple(self, models, submodel_of_char):
         """models: list of LogisticWeights or of GaussianNBWeights (one per sub-model) -- `-c LR` / `-c NBC`."""
         kind = {'logistic': 1, 'gnb': 2}[models[0].kind]
@@ -194,6 +226,7 @@ class Device(object):
             self.set_mlp(weights, submodel_of_char)
             self._clf = 'mlp'
 
+    @_serialized
     def classifier_forward(self, X, submodel):
         X = np.ascontiguousarray(X, dtype=np.float64)
         sm = np.ascontiguousarray(submodel, dtype=np.uint8)
@@ -203,6 +236,7 @@ class Device(object):
         return p
 
     # ---- the hot path ----
+    @_serialized
     def run(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
         """K0+K1+K2 on the resident table; records stay on the device.  Returns their number."""
         p = Params(int(k), int(skip_thresh), float(qual_thresh), int(tail_contig), 1 if score else 0,
@@ -212,6 +246,7 @@ class Device(object):
         self._last = (n.value, int(k))
         return n.value
 
+    @_serialized
     def run_async(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
         """Enqueue one pass (K0 + K1 on the ctx stream, K2 + packing on a side stream); at most four in flight."""
         p = Params(int(k), int(skip_thresh), float(qual_thresh), int(tail_contig), 1 if score else 0,
@@ -219,10 +254,12 @@ class Device(object):
         check(lib().mc_extract_features_async(self._ctx, C.byref(p)))
         self._async_k = getattr(self, '_async_k', []) + [int(k)]
 
+    @_serialized
     def wait_begin(self):
         """Start the copy-out of the oldest pass whose copy-out has not been started, without waiting for it."""
         check(lib().mc_wait_records_begin(self._ctx))
 
+    @_serialized
     def wait(self):
         """Records of the oldest pass in flight: views of pinned buffers (slot means / probabilities of the calls only, see
         Records.call_row), valid until four more passes have been enqueued."""
@@ -232,6 +269,7 @@ class Device(object):
         self._last = (n.value, k)
         return Records.from_view(v, n.value, k, self)
 
+    @_serialized
     def fetch(self, copy=True):
         """Records of the last run.  copy=False: views of the context's pinned buffers (overwritten by the next run)."""
         n, k = self._last
@@ -249,17 +287,21 @@ class Device(object):
         self.run(k, skip_thresh, qual_thresh, **kw)
         return self.fetch()
 
+    @_serialized
     def sync(self):
         """hipDeviceSynchronize on this context's device (all of its streams)."""
         check(lib().mc_ctx_sync(self._ctx))
 
+    @_serialized
     def set_pass_timing(self, every_n):
         """Pipelined passes: record the timing events with every n-th pass only (each costs the queue ~9 us); 0 = never."""
         check(lib().mc_ctx_set_pass_timing(self._ctx, int(every_n)))
 
+    @_serialized
     def last_pass_timed(self):
         return bool(lib().mc_last_pass_timed(self._ctx))
 
+    @_serialized
     def last_pass_info(self):
         """(record slots per piece if the pass handed out last ran as the fused dense kernel, else 0; whether it was repeated
         synchronously inside wait())."""
@@ -267,6 +309,7 @@ class Device(object):
         check(lib().mc_last_pass_info(self._ctx, C.byref(a), C.byref(b)))
         return a.value, bool(b.value)
 
+    @_serialized
     def times_ms(self):
         t = np.zeros(5, dtype=np.float32)
         check(lib().mc_last_times_ms(self._ctx, _ptr(t)))
@@ -286,6 +329,7 @@ class Device(object):
         """Can librccl.so be loaded in this process?  Raises if not (nothing else is touched)."""
         check(lib().mc_comm_available())
 
+    @_serialized
     def site_counts_fetch(self):
         """This rank's own per-site counts as they stand (no collective) -> (n_meth, n_total, first)."""
         n = lib().mc_site_count(self._ctx)
@@ -294,15 +338,18 @@ class Device(object):
         check(lib().mc_site_counts_fetch(self._ctx, _ptr(n_meth), _ptr(n_total), _ptr(first)))
         return n_meth, n_total, first
 
+    @_serialized
     def comm_init(self, world, rank, unique_id):
         """ncclCommInitRank on this GPU (RCCL over xGMI); collective over all ranks."""
         uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
         assert len(uid) == 128
         check(lib().mc_comm_init(self._ctx, int(world), int(rank), _ptr(uid)))
 
+    @_serialized
     def comm_destroy(self):
         lib().mc_comm_destroy(self._ctx)
 
+    @_serialized
     def site_counts(self, row_offset=0, tail_contig=-1):
         """Per-site counts of the last run's records, on the device.  Returns how many records the host scored itself
         (NaN probability on the device): add those with site_counts_add.  Records closed by a row of another contig than
@@ -312,10 +359,12 @@ class Device(object):
         self.n_cross_contig = cross.value
         return pending.value
 
+    @_serialized
     def site_counts_reset(self):
         """Zero the device-side per-site counts (before the first shard of a streamed file)."""
         check(lib().mc_site_counts_reset(self._ctx))
 
+    @_serialized
     def site_counts_accumulate(self, row_offset=0, tail_contig=-1):
         """Add the records of the pass handed out last to the per-site counts (a streamed file: shard after shard); returns
         like site_counts."""
@@ -324,12 +373,14 @@ class Device(object):
         self.n_cross_contig = cross.value
         return pending.value
 
+    @_serialized
     def site_counts_add(self, site, is_meth, first_row):
         site = np.ascontiguousarray(site, dtype=np.int64)
         meth = np.ascontiguousarray(is_meth, dtype=np.uint8)
         first = np.ascontiguousarray(first_row, dtype=np.int64)
         check(lib().mc_site_counts_add(self._ctx, _ptr(site), _ptr(meth), _ptr(first), len(site)))
 
+    @_serialized
     def site_allreduce(self):
         """Sum / min over the ranks of the communicator (none: this rank alone) -> (n_meth, n_total, first, ms)."""
         n = lib().mc_site_count(self._ctx)
@@ -340,6 +391,7 @@ class Device(object):
         return n_meth, n_total, first, ms.value
 
     # ---- the classifier fit behind --train ----
+    @_serialized
     def mlp_fit(self, X, y, jobs, hidden=100, alpha=0.001, lr_init=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8,
                 batch_size=200, max_iter=200, tol=1e-4, n_iter_no_change=10, shuffle=True, seed=1, seeds=None, init=None):
         """Fit one 7-H-1 tanh/logistic perceptron per job on the GPU (mc_mlp_fit; all jobs side by side).
@@ -371,6 +423,7 @@ class Device(object):
         return [dict(W1=W1[j], b1=b1[j], W2=W2[j], b2=float(b2[j]), loss_curve=curve[j, :n_iter[j]].copy(),
                      n_iter=int(n_iter[j]), val_correct=int(correct[j]), n_val=len(va[j])) for j in range(nj)]
 
+    @_serialized
     def mlp_forward(self, X, submodel):
         if getattr(self, '_clf', 'mlp') != 'mlp':
             return self.classifier_forward(X, submodel)

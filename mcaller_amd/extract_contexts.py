@@ -154,6 +154,7 @@ class Finisher(object):
             self.model_keys = None
         self.signals = {bm: {} for bm in self.table.values()} if train else None
         self.contexts = {bm: {} for bm in self.table.values()} if train else None
+        self.stdout = None      # where the exit paths' lines go (None: sys.stdout; a stream that will be replayed by the one-table path: a sink)
         self.host_scored = {}   # record -> probability, for the records the host had to score itself (edge contexts)
         self.blobs = []         # emitted rows as text (bytes), in order
         self.num_observations = 0
@@ -325,12 +326,12 @@ class Finisher(object):
                     row = [chrom, read, str(mpos), context, diffs_txt, strand(rev), label]
                     self.blobs.append(('\t'.join(row) + '\n').encode('utf-8', 'surrogateescape'))
                 except (IndexError, KeyError) as e:                           # :218-223
-                    print(line, '- Index or Key Error')
-                    print(list(self.model_keys or []), list(self.table.keys()), context[centre:centre + 2])
-                    print(e)
+                    print(line, '- Index or Key Error', file=self.stdout)
+                    print(list(self.model_keys or []), list(self.table.keys()), context[centre:centre + 2], file=self.stdout)
+                    print(e, file=self.stdout)
                     return SystemExit(0)
             else:                                                             # :224-228
-                print(line)
+                print(line, file=self.stdout)
                 return SystemExit(0)
             self.num_observations += 1
             self.pos_set.add(mpos)
@@ -596,6 +597,20 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
     marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
+    # The rows of a shard are formatted and written by ONE helper thread while the main thread goes on to the next shard (its
+    # table, its passes, the wait for its records): a one-base motif writes 1.3 GB of rows per 10^8 events, and formatter + write were
+    # two thirds of what the main thread did.  Not in train mode (the per-record transcription holds the interpreter lock) and not
+    # when every shard's records are reduced on the device (on_shard needs what the formatter found).  The helper is at most one
+    # shard behind: the records it reads stay where they are until four more passes have been enqueued.
+    overlap = not train and on_shard is None and not os.environ.get('MCALLER_NO_OVERLAP')
+    fmt_pool = ThreadPoolExecutor(max_workers=1) if overlap else None
+    pending = []                    # the helper's job in flight (a future), if any
+    clock['overlapped'] = bool(overlap)
+
+    def finish_pending():
+        while pending:
+            pending.pop(0).result()                            # (its exception, if it met an exit path, is raised here)
+
     def hand_out():
         t_h = time.perf_counter()
         try:
@@ -611,9 +626,18 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         t_f = time.perf_counter()
         clock['wait_records'] += t_f - t_w
         mark('records here')
+        if overlap:
+            finish_pending()                                   # (the shard before: done, or its exit path raised)
+            clock['wait_formatter'] = clock.get('wait_formatter', 0.0) + time.perf_counter() - t_f
+            pending.append(fmt_pool.submit(_finish, P, tail, rows_before, rec))
+        else:
+            _finish(P, tail, rows_before, rec)
+
+    def _finish(P, tail, rows_before, rec):
+        t_f = time.perf_counter()
         fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label, device=dev, tail_chrom=tail)
-        with contextlib.redirect_stdout(io.StringIO()):        # (its exit paths print; the one-table path will)
-            stop = fin.run(rec)
+        fin.stdout = io.StringIO()                             # (its exit paths print; the one-table path will)
+        stop = fin.run(rec)
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
         # `last_read` across the cut in front of this shard (cut_names): a name on both sides of it sends the file to the one-table path
@@ -749,11 +773,18 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             on_head(None)
         while in_flight:
             hand_out()
+        finish_pending()
     except BaseException:
         next_piece[0] = len(pieces)
         for f, _ in ahead:
             f.cancel()
         try:
+            for fut in pending:                                # (the helper must be done with the records before anything is torn down)
+                try:
+                    fut.result()
+                except BaseException:                          # noqa
+                    pass
+            del pending[:]
             dev.sync()
             for slot, _, _ in parsing:                         # tables the device parser was filling: their slots go back
                 dev.parse_abandon(slot)
@@ -769,6 +800,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         raise
     finally:
         pool.shutdown(wait=True)
+        if fmt_pool is not None:
+            fmt_pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
     out.n_rows = rows_seen
     out.positions = np.flatnonzero(positions[0]).astype(np.int32)
