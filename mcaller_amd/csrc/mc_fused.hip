@@ -193,7 +193,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ FBlock s_blk[F_MAXB];
     __shared__ int16_t s_bfirst[F_MAXB + 1];    // first run of the block (the runs of later blocks behind it); -1 until known
     __shared__ FSpec s_spec[F_MAXSPEC];
-    __shared__ uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
+    __shared__ __attribute__((aligned(16))) uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ uint16_t s_heavy[4 * F_HEAVY];        // per wave: its runs of more than one event
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
     __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
@@ -483,16 +483,27 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     // (a thread's runs are R = tid, tid + 256, ...: the words of the run after the current one are on their way while its mean
     // is added up -- a loop, not five copies of it: the instruction cache holds the kernel)
     uint32_t wlo = 0u, whi = 0u;
+    // (nineteen pieces in twenty lie inside ONE name block: what a run needs of its block is then the same for every run -- taken
+    // once, not looked up per run: the row of the run, the search for its block and four fields of it, twice per run)
+    const bool one_block = nblk == 1;
+    const int b0_len = s_blk[0].contig_len, b0_rev = s_blk[0].rev;
+    const uint32_t *const b0_bits = (b0_rev ? A.R.mr : A.R.mf) + s_blk[0].mask_off;
     auto site_words = [&](int R, uint32_t &lo, uint32_t &hi) {
         lo = hi = 0u;
         if (R < n_runs) {
-            const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
-            int bj = 0;
-            while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
-            const FBlock &B = s_blk[bj];
+            int clen = b0_len;
+            const uint32_t *bits = b0_bits;
+            if (!one_block) {
+                const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
+                int bj = 0;
+                while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
+                const FBlock &B = s_blk[bj];
+                clen = B.contig_len;
+                bits = (B.rev ? A.R.mr : A.R.mf) + B.mask_off;
+            }
             const int p = s_rpos[R];
-            const int pw = ((p >= 0 && p < B.contig_len) ? max(p - 1, 0) : 0) >> 5;     // (two zero words lie behind every contig's mask)
-            const uint32_t *g = (B.rev ? A.R.mr : A.R.mf) + B.mask_off + pw;
+            const int pw = ((p >= 0 && p < clen) ? max(p - 1, 0) : 0) >> 5;     // (two zero words lie behind every contig's mask)
+            const uint32_t *g = bits + pw;
 #ifdef MC_FD_FAKE_WORDS          // (variant build, timing only: what the two words' trip costs the phase)
             lo = (uint32_t)pw * 2654435761u; hi = ~lo; (void)g;
 #else
@@ -551,27 +562,40 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         // (every second run is ONE event: its mean is fl(d / 1e4), narrow by construction -- done here; the runs of several events are
         // listed per wave and taken densely below: their sums, the division and the narrow test are most of what a run costs, and
         // a wave would go through them for the half of its lanes that have none)
+#ifdef MC_FD_NO_MEAN          // (variant build, timing only)
+        const int c0 = 0, n = 1;
+#else
         const int c0 = s_rc0[R], n = (int)s_rc0[R + 1] - c0;
         if (n == 1) s_mean[R] = div1e4(s_dc[c0]);
+#endif
         {
             const unsigned long long hm = __ballot(n > 1);
             if (n > 1) s_heavy[wave * F_HEAVY + n_heavy + __popcll(hm & lt)] = (uint16_t)R;
             n_heavy += __popcll(hm);
         }
         // the site
-        const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
-        int bj = 0;
-        while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
-        const int p = s_rpos[R], L = s_blk[bj].contig_len;
+        int L = b0_len, brev = b0_rev;
+        if (!one_block) {
+            const int row = s_rrow[R] & ((1 << F_ROW_BITS) - 1);
+            int bj = 0;
+            while (bj + 1 < nblk && row >= s_blk[bj].end) ++bj;
+            L = s_blk[bj].contig_len; brev = s_blk[bj].rev;
+        }
+        const int p = s_rpos[R];
         uint32_t code = 0;
+#ifdef MC_FD_NO_SITE          // (variant build, timing only)
+        code = (uint32_t)(p & 7); (void)L; (void)brev;
+        if (false) {
+#else
         if (p >= 0 && p < L) {
+#endif
             const int sh = p - ((max(p - 1, 0) >> 5) << 5);                 // bit of position p in whi:wlo (0 .. 32)
             const uint64_t W = (((uint64_t)whi << 32) | wlo) >> sh;
             const uint32_t bits = (uint32_t)W & ((1u << k) - 1u);
             if (bits) {
                 const int o = __ffs(bits) - 1;
                 // the position behind the site in the read's direction: m + 1, on the reverse strand m - 1 (context[k], :197)
-                const int at_bit = s_blk[bj].rev ? sh + o - 1 : sh + o + 1;
+                const int at_bit = brev ? sh + o - 1 : sh + o + 1;
                 const uint32_t next = at_bit >= 0 ? (uint32_t)(((((uint64_t)whi << 32) | wlo) >> at_bit) & 1ull) : 0u;
                 code = (uint32_t)(o + 1) | (next << 7);
             }
@@ -639,8 +663,12 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     {
         int before = 0;                             // closed windows of the runs in front of this wave's 64 of the turn
         const int n64 = (n_runs + 63) >> 6;
+        // (the counts of all groups in one trip: a read per turn of the loop is an LDS round trip per turn)
+        static_assert((FR + 63) / 64 <= 16, "sixteen counts: four words");
+        const uint4 cw = *reinterpret_cast<const uint4 *>(s_cnt);
         for (int g = 0; g < n64; ++g) {
-            const int c = s_cnt[g];
+            const uint32_t w4 = g < 4 ? cw.x : g < 8 ? cw.y : g < 12 ? cw.z : cw.w;
+            const int c = (int)((w4 >> (8 * (g & 3))) & 0xFFu);
             if ((g & 3) == wave) {
                 const int R = g * 64 + lane;
                 const bool closed = R < n_runs && (s_ro[R] & 0x40u);
@@ -682,6 +710,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     FD_STOP_AFTER(5);
     // ---- a window per thread ----
     const uint32_t kbits = (1u << k) - 1u;
+    const FBlock B0w = s_blk[0];
     for (int w = tid; w < n_win; w += F_THREADS) {
         const int64_t q = q0 + w;
         const unsigned ent = s_list[w];
@@ -693,9 +722,12 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         const int Rc = (int)ent, R = Rc - 1;
         const int hrow = s_rrow[Rc] & ((1 << F_ROW_BITS) - 1);
-        int bj = 0;
-        while (bj + 1 < nblk && hrow >= s_blk[bj].end) ++bj;
-        const FBlock &B = s_blk[bj];
+        FBlock B = B0w;                             // (one name block in the piece: its fields were taken once)
+        if (!one_block) {
+            int bj = 0;
+            while (bj + 1 < nblk && hrow >= s_blk[bj].end) ++bj;
+            B = s_blk[bj];
+        }
         const uint32_t code = s_ro[R];
         const int o = (int)(code & 15u) - 1, m = s_rpos[R] + o;
         const bool rev = B.rev;
