@@ -597,19 +597,22 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
     marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
-    # The rows of a shard are formatted and written by ONE helper thread while the main thread goes on to the next shard (its
+    # The rows of a shard are formatted by one helper thread and appended by another while the main thread goes on to the next shard (its
     # table, its passes, the wait for its records): a one-base motif writes 1.3 GB of rows per 10^8 events, and formatter + write were
     # two thirds of what the main thread did.  Not in train mode (the per-record transcription holds the interpreter lock) and not
     # when every shard's records are reduced on the device (on_shard needs what the formatter found).  The helper is at most one
     # shard behind: the records it reads stay where they are until four more passes have been enqueued.
     overlap = not train and on_shard is None and not os.environ.get('MCALLER_NO_OVERLAP')
     fmt_pool = ThreadPoolExecutor(max_workers=1) if overlap else None
-    pending = []                    # the helper's job in flight (a future), if any
+    write_pool = ThreadPoolExecutor(max_workers=1) if overlap else None     # (... and a second one appends them: in order, one shard behind)
+    pending, writes = [], []        # the helpers' jobs in flight (futures), if any
     clock['overlapped'] = bool(overlap)
 
     def finish_pending():
         while pending:
             pending.pop(0).result()                            # (its exception, if it met an exit path, is raised here)
+        while writes:
+            writes.pop(0).result()
 
     def hand_out():
         t_h = time.perf_counter()
@@ -650,11 +653,20 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         out.had_records = out.had_records or has_rec
         t_s = time.perf_counter()
         clock['format'] += t_s - t_f
-        n_out = fin.write_to(sink)
-        clock['write'] += time.perf_counter() - t_s
-        clock['out_bytes'] += n_out
+
+        def write_rows():
+            t_w = time.perf_counter()
+            n_out = fin.write_to(sink)
+            clock['write'] += time.perf_counter() - t_w
+            clock['out_bytes'] += n_out
+            out.n_bytes += n_out
+        if overlap:
+            while len(writes) > 1:                             # (at most two shards' rows wait to be written)
+                writes.pop(0).result()
+            writes.append(write_pool.submit(write_rows))
+        else:
+            write_rows()
         clock['records'] += int(rec.n)
-        out.n_bytes += n_out
         n = rec.n
         too = (rec.info[:n] & _I.I_TOO_MANY) != 0
         pos_kept = rec.site_pos[:n][~too]                      # (the distinct positions of the file: a mark per position, counted at the end)
@@ -779,12 +791,12 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         for f, _ in ahead:
             f.cancel()
         try:
-            for fut in pending:                                # (the helper must be done with the records before anything is torn down)
+            for fut in pending + writes:                       # (the helpers must be done with the records before anything is torn down)
                 try:
                     fut.result()
                 except BaseException:                          # noqa
                     pass
-            del pending[:]
+            del pending[:], writes[:]
             dev.sync()
             for slot, _, _ in parsing:                         # tables the device parser was filling: their slots go back
                 dev.parse_abandon(slot)
@@ -802,6 +814,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         pool.shutdown(wait=True)
         if fmt_pool is not None:
             fmt_pool.shutdown(wait=True)
+            write_pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
     out.n_rows = rows_seen
     out.positions = np.flatnonzero(positions[0]).astype(np.int32)
