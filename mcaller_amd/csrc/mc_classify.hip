@@ -137,11 +137,17 @@ __device__ __forceinline__ double logistic(double z, const EC &C) {
 // fast probability lies farther than that from every threshold prints the same characters either way, and the others -- one in
 // a few hundred -- are evaluated again in fp64 (phase D of k2_mlp).  The hidden layer in fp32 issues at twice the rate and the
 // tanh is ten instructions instead of thirty: what SURVEY.md section 7 names as the alternative to fp64 throughout.
-// tanh(a) = (1 - e) / (1 + e), e = exp(-2|a|): one v_exp_f32, one v_rcp_f32.  Absolute error <= K2_TANH32_MAX_ERR.
-__device__ __forceinline__ float tanh32(float a) {
-    const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf((1.0f - e) * r, a);
+// tanh(a) = 1 - 2 / (1 + 2^s), s = 2 log2(e) a (the factor is in the weights, DevMlp.wp32): one v_exp_f32, one v_rcp_f32, one fma.
+// 2^s = inf gives 1, 2^s = 0 gives -1, s = 0 gives 0 exactly (the padding unit of an odd layer).  Absolute error against
+// tanh(s ln2 / 2) <= K2_TANH32_MAX_ERR over all floats s (k_tanh32_err).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tanh32s(float s) {
+    return __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s)), -2.0f, 1.0f);
+}
+__device__ __forceinline__ f2 tanh32s_2(f2 s) {
+    const f2 d = (f2){__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)} + 1.0f;
+    const f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return __builtin_elementwise_fma(r, (f2){-2.0f, -2.0f}, (f2){1.0f, 1.0f});
 }
 
 // distance of p from the nearest threshold the reference's row depends on: the ties of np.round(p, 2) (p x 100 = j + 0.5) and 0.5
@@ -153,45 +159,55 @@ __device__ __forceinline__ double threshold_distance(double p) {
 
 // One lane per record, one hidden unit after the other inside the lane, the weights as SCALAR operands: the records a wave
 // takes belong to one sub-model, so W1[:, j], b1[j], W2[j] are the same for its 64 lanes -- they come through the scalar
-// cache into SGPRs (nine s_load'ed doubles per hidden unit) and the vector pipe issues nothing but the arithmetic:
-// 7 + ~30 + 1 fp64 instructions per hidden unit and record, no LDS reads, no address arithmetic, no butterfly.
+// cache into SGPRs (nine s_load'ed doubles per hidden unit; the fast forward: nine float PAIRS per pair of units) and the vector
+// pipe issues nothing but the arithmetic, no LDS reads, no address arithmetic, no butterfly.
 //
 // A workgroup takes a contiguous stretch of the records (the pass's records divided evenly over the workgroups, K2B at a
-// time) and
-//   A. finds the records that are scored at all (skipped records and records whose context leaves the contig are not) and
-//      lists them sub-model by sub-model in LDS, every sub-model's list padded to whole groups of 64; the read quality
-//      (a chain of three dependent loads per record) is fetched here, for all records at once;
-//   B. wave w computes quarter (w & 3) of the hidden units for groups (w >> 2), (w >> 2) + n_waves / 4, ...: the four
-//      SIMDs of the CU carry the same load whatever the number of groups, and a workgroup of 1024 records (~11 groups of
-//      the headline workload) keeps all of them busy.  Partial sums go to LDS;
-//   C. the quarters are added in a fixed order (the result does not depend on which wave ran when) and the logistic
-//      function gives the probability.
+// time), a record per thread, and
+//   A. finds the records that are scored at all (skipped records and records whose context leaves the contig are not), fetches
+//      their read quality (a chain of three dependent loads per record) and lists them sub-model by sub-model in LDS: a wave
+//      counts its records of every sub-model with a ballot and claims room in the sub-models' lists with ONE LDS atomic (a lane
+//      per sub-model) -- the order of a list is whatever the waves' atomics made it, and nothing depends on it: a record's sums are its own;
+//   B. wave w computes a quarter of the hidden units for some of the groups of 64 list entries: the quarter of the SIMD it runs
+//      on, so that the four SIMDs of the CU carry the same load whatever the number of groups.  Partial sums go to LDS, under
+//      the record's place in the stretch;
+//   C. the thread that fetched a record adds its quarters in a fixed order (the result does not depend on which wave ran when)
+//      and the logistic function gives the probability.
+// Two barriers per stretch (after A, after B) and nothing else that all waves wait for: what A of the next stretch writes (the
+// lists, the qualities, the slots, the other of two sets of list lengths) was last read in B of this one, what B writes in C.
+// (Until round 5: per-wave counts, a barrier, prefix sums by 64 threads over 16 counts each, a barrier, the lists padded to whole
+// groups, a barrier; C over the list entries; the fp64 evaluations of the fast forward behind a fifth barrier in every stretch --
+// 10 us of a stretch's 24 with the hidden layer at 10.)
 // The earlier version (eight lanes per record, pairs of records per lane group, weights in LDS: 126 LDS reads and ~1200
 // VALU instructions per step of 16 records, 3.1 uneven waves per SIMD) took 53 us for the headline pass.
 // The records of a fused dense pass (k1_fused) lie in fixed room per piece of the table, the slots a piece did not fill are holes --
-// two slots in three.  A stretch of 1024 SLOTS would spend its three barriers and its lists on 300 records: the stretches are made
-// of whole pieces instead, as many as hold at most 1024 records together (eleven, typically), from the pieces' counts.
+// two slots in three.  A stretch of 1024 SLOTS would spend its barriers and its lists on 300 records: the stretches are made
+// of whole pieces instead, as many as hold at most 1024 records together (eleven, typically), from the pieces' counts -- every wave
+// adds up the same sixteen counts, nothing is shared.
 struct K2Pieces {
     const int32_t *cnt;     // [n] records of every piece (k1_fused), nullptr: the records are dense
     int room;               // slots per piece
     int64_t n;              // pieces
 };
-constexpr int K2B = 1024;                       // records per workgroup iteration
 #ifndef MC_K2_THREADS
 #define MC_K2_THREADS 1024
 #endif
 constexpr int K2_THREADS = MC_K2_THREADS;
+constexpr int K2B = K2_THREADS;                 // records per workgroup iteration: one per thread
 constexpr int K2_WAVES = K2_THREADS / 64;
-constexpr int K2_SLOTS = K2B + K2_MAXM * 64;    // list entries: every sub-model's part is padded to a multiple of 64
-constexpr int K2_SUB = K2B / 64;                // 64-record pieces of a stretch: the unit of the list's prefix sums
-static_assert(K2_WAVES >= 4 && K2_WAVES % 4 == 0 && K2B % K2_THREADS == 0, "four unit quarters; whole records per thread");
-static_assert(K2_SUB * K2_MAXM <= K2_THREADS && K2_MAXM * 64 <= K2_THREADS, "one thread per (piece, sub-model) / per pad entry");
+constexpr int K2_FIX = K2B + 256;               // the fast forward: room for the records to evaluate again (a stretch adds at most K2B)
+static_assert(K2_WAVES >= 4 && K2_WAVES % 4 == 0, "four unit quarters");
+static_assert(K2_MAXM <= 16, "a wave's list claims are one atomic of K2_MAXM lanes; the loops over the sub-models are written out");
 
 #ifdef MC_K2_TRACE      // (variant build for tools/k2_trace.py: 100 MHz time stamps of every wave's phases)
 __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 #define K2_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024) g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + (i)] = wall_clock64(); g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 8 + (i)] = clock64(); } while (0)
+// ... and of wave 0 in every stretch of the first 256 workgroups: [workgroup][stretch < 24][8]
+__device__ unsigned long long g_k2_timeline[256 * 24 * 8];
+#define K2_TL(i) do { if (tid == 0 && blockIdx.x < 256 && stretch_no < 24) g_k2_timeline[((size_t)blockIdx.x * 24 + stretch_no) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define K2_STAMP(i) do { } while (0)
+#define K2_TL(i) do { } while (0)
 #endif
 
 
@@ -200,9 +216,8 @@ __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 // NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
 // unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
 // are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
-// (the fast forward: TWO workgroups per CU -- its hidden layer is a third of the fp64 one's time, and what is left of a stretch is
-// the loads of phase A, three dependent ones, the lists and five barriers: one workgroup's phase A hides behind the other's phase B.
-// 64 registers a lane for that, partial sums as floats: 43 KB of LDS a workgroup)
+// (the fast forward: TWO workgroups per CU where there are millions of records -- one workgroup's phases A and C hide behind the
+// other's phase B.  64 registers a lane for that, partial sums as floats: 50 KB of LDS a workgroup)
 template <int NI_T, bool FAST>
 __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST ? 8 : 4, FAST ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
@@ -214,214 +229,222 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
     const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
-    __shared__ uint16_t s_list[K2_SLOTS];       // record (offset in the stretch) of every list entry; 0xFFFF: padding
-    __shared__ double s_q[K2B];                 // read quality of the stretch's records
     using part_t = std::conditional_t<FAST, float, double>;
-    __shared__ part_t s_part[4][K2_SLOTS];      // partial output sums of the four unit quarters
-    __shared__ int s_cnt[K2_SUB][K2_MAXM], s_before[K2_SUB][K2_MAXM], s_tot[K2_MAXM], s_gmodel[K2_SLOTS / 64];
-    __shared__ float s_marg[FAST ? K2_SLOTS : 1];   // the fast forward: how far from the fp64 probability the entry's may lie
-    __shared__ uint16_t s_fix[FAST ? K2_SLOTS : 1]; // ... the entries evaluated again in fp64
+    __shared__ uint16_t s_list[K2_MAXM][K2B];   // per sub-model: its records (their places in the stretch), in the order of the waves' claims
+    __shared__ int s_tot[2][K2_MAXM];           // ... their number: one set per stretch, the other is cleared meanwhile
+    __shared__ double s_q[K2B];                 // read quality of the stretch's records
+    __shared__ part_t s_part[4][K2B];           // partial output sums of the four unit quarters, by the record's place
+    __shared__ float s_marg[FAST ? K2B : 1];    // the fast forward: how far from the fp64 probability the record's may lie
+    __shared__ unsigned long long s_fixlist[FAST ? K2_FIX : 1];    // ... the records to evaluate again in fp64: record | sub-model << 56
     __shared__ int s_nfix;
-    __shared__ int s_pfx[18], s_np, s_ptot;     // a stretch made of pieces: records before every piece of it, pieces, records
-    __shared__ int32_t s_slot[K2B];             // ... the slot of every record of the stretch, from the stretch's first piece's first slot
-    static_assert(K2B == K2_THREADS, "a record per thread and stretch");
+    __shared__ int32_t s_slot[K2B];             // a stretch made of pieces: the slot of every record, from the stretch's first piece's first slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
     const ExpConstsT<!FAST> C;
     K2_STAMP(0);
     // Which quarter of the hidden units a wave takes: the one of the SIMD it runs on, so that the four SIMDs of the CU carry
-    // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  The waves
-    // register before the first barrier of the first stretch.  (If the workgroup's waves did not land on all four SIMDs:
-    // by wave number.)
+    // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  (If the
+    // workgroup's waves did not land on all four SIMDs: by wave number.)
     __shared__ uint32_t s_simd_of_wave[K2_WAVES / 4];       // a byte per wave
     const int simd = (int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3;      // HW_ID[5:4]
-    int quarter = 0, g_first = 0, g_step = 1;
-    bool placed = false;
+    if (lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
+    if (tid < 2 * K2_MAXM) (&s_tot[0][0])[tid] = 0;
+    if (tid == 0) s_nfix = 0;
+    __syncthreads();
+    int quarter, g_first, g_step;
+    {
+        uint32_t per_simd = 0;                  // a byte per SIMD: its waves
+        int slot = 0;                           // waves of this wave's SIMD with a smaller number
+        for (int w4 = 0; w4 < K2_WAVES / 4; ++w4) {
+            const uint32_t four = __builtin_amdgcn_readfirstlane(s_simd_of_wave[w4]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int sd = (four >> (8 * b)) & 3;
+                per_simd += 1u << (8 * sd);
+                slot += (w4 * 4 + b < wave && sd == simd) ? 1 : 0;
+            }
+        }
+        const bool by_simd = (per_simd & 0xFFu) && (per_simd & 0xFF00u) && (per_simd & 0xFF0000u) && (per_simd & 0xFF000000u);
+        quarter = by_simd ? simd : wave & 3;
+        g_first = by_simd ? slot : wave >> 2;
+        g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : K2_WAVES / 4;
+    }
     const bool pieces = P.cnt != nullptr;
     const int64_t n_units = pieces ? P.n : n;                    // what the workgroups share out: pieces, or records
     const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
     const int64_t lo = min(n_units, blockIdx.x * per), hi = min(n_units, lo + per);
     K2_STAMP(1);
+    // the records whose printed digits (or label) could depend on the precision: again in fp64, a wave per record, the hidden
+    // units across its lanes (the quality is fetched again: a handful of records per stretch)
+    auto again_in_fp64 = [&](int n_fix) {
+        for (int f = wave; f < n_fix; f += K2_WAVES) {
+            const unsigned long long ent = s_fixlist[FAST ? f : 0];
+            const int64_t r = (int64_t)(ent & ((1ull << 56) - 1ull));
+            const int mdl = (int)(ent >> 56);
+            double x[NX];
+            const double q = qual[seg_read[site_seg[r]]];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+            double part = 0.0;
+            for (int u = lane; u < H; u += 64) {
+                const double *wu = M.wu + ((size_t)mdl * H + u) * S;
+                double a0 = x[0] * wu[0];
+#pragma unroll
+                for (int i = 1; i < NX; ++i)
+                    if (i < NI) a0 = fma(x[i], wu[i], a0);
+                part = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], part);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            if (lane == 0) prob[r] = logistic(part + M.b2[mdl], C);
+        }
+    };
+    int buf = 0, stretch_no = 0;
+    (void)stretch_no;
     int64_t base = lo;                          // first record of the stretch (pieces: first piece)
-    for (;;) {
-        if (base >= hi) break;
+    while (base < hi) {
         K2_STAMP(7);                            // (the stretch begins: slot 15 keeps its clock64, slot 7 is overwritten below)
-        int n_here = (int)min((int64_t)K2B, hi - base), np_here = 0;
-        int64_t slot0 = base;                   // record of the stretch's entry `off`: slot0 + (pieces ? s_slot[off] : off)
+        K2_TL(0);
+        int n_here, np_here = 1, my_slot = tid;
+        int64_t slot0 = base;                   // record of the stretch's place `off`: slot0 + (pieces ? s_slot[off] : off)
         if (pieces) {
             // the next pieces that hold at most K2B records together (a piece holds at most its room, and that is below K2B)
-            if (wave == 0) {
-                const bool have = lane < 16 && base + lane < hi;
-                const int c = have ? min(max(P.cnt[base + lane], 0), P.room) : 0;
-                int incl = c;
+            const bool have = lane < 16 && base + lane < hi;
+            const int c = have ? min(max(P.cnt[base + lane], 0), P.room) : 0;
+            int incl = c;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const int v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
-                const unsigned long long fit = __ballot(have && incl <= K2B);
-                const int np = max(1, __popcll(fit));
-                if (lane < 16) s_pfx[lane] = incl - c;
-                if (lane == np - 1) { s_np = np; s_ptot = min(incl, K2B); }
+            for (int o = 1; o < 16; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
             }
-            __syncthreads();
-            np_here = s_np;
-            n_here = s_ptot;
+            np_here = max(1, __popcll(__ballot(have && incl <= K2B)));
+            n_here = min(__builtin_amdgcn_readlane(incl, np_here - 1), K2B);
+            int before = 0, j = 0;              // the thread's piece: the last one with at most tid records in front of it
+#pragma unroll
+            for (int t = 0; t < 15; ++t) {
+                const int inc_t = __builtin_amdgcn_readlane(incl, t);
+                if (t + 1 < np_here && inc_t <= tid) { j = t + 1; before = inc_t; }
+            }
+            my_slot = j * P.room + (tid - before);
             slot0 = base * (int64_t)P.room;
-            int sl = 0;
-            if (tid < n_here) {
-                int j = 0;
-                while (j + 1 < np_here && s_pfx[j + 1] <= tid) ++j;
-                sl = j * P.room + (tid - s_pfx[j]);
-            }
-            s_slot[tid] = sl;
-        }
-        auto rec_at = [&](int off) -> int64_t { return slot0 + (pieces ? s_slot[off] : off); };
-        // ---- A: the lists
-        // (the read quality is a chain of three dependent loads -- segment, read, quality: it starts with the first load of
-        // the stretch and is only waited for when the lists are done)
-        int mi[K2B / K2_THREADS], rank[K2B / K2_THREADS];
-        double qv[K2B / K2_THREADS];
-#pragma unroll
-        for (int i = 0; i < K2B / K2_THREADS; ++i) {
-            const int off = i * K2_THREADS + tid;
-            const int64_t r = slot0 + (pieces ? s_slot[off] : off);     // (a thread's own entry of s_slot: no barrier needed)
-            mi[i] = 255;                            // sub-model of record r (255: not scored here)
-            qv[i] = 0.0;
-            if (off < n_here) {
-                if (submodel_in) mi[i] = submodel_in[r];
-                else {
-                    const uint32_t inf = info[r];
-                    const int32_t seg = site_seg[r];
-                    if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) {
-                        mi[i] = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
-                        qv[i] = qual[seg_read[seg]];
-                    }
+            s_slot[tid] = my_slot;
+        } else n_here = (int)min((int64_t)K2B, hi - base);
+        // ---- A: the thread's record, and the lists
+        // (the read quality is a chain of three dependent loads -- segment, read, quality)
+        const int64_t r = slot0 + my_slot;
+        int mi = 255;                               // sub-model of record r (255: not scored here)
+        double qv = 0.0;
+        if (tid < n_here) {
+            if (submodel_in) mi = submodel_in[r];
+            else {
+                const uint32_t inf = info[r];
+                const int32_t seg = site_seg[r];
+                if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) {
+                    mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+                    qv = qual[seg_read[seg]];
                 }
             }
-            rank[i] = 0;
-            for (int m = 0; m < NM; ++m) {          // (a key outside the models is the KeyError path, :218: the host decides)
-                const unsigned long long bal = __ballot(mi[i] == m);
-                if (mi[i] == m) rank[i] = __popcll(bal & below);
-                if (lane == 0) s_cnt[off >> 6][m] = __popcll(bal);
-            }
         }
-        if (!placed && lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
+        int rank = 0, cnt_lane = 0;                 // (lane m: the wave's records of sub-model m)
+#pragma unroll
+        for (int m = 0; m < K2_MAXM; ++m) {         // (a key outside the models is the KeyError path, :218: the host decides)
+            const unsigned long long bal = __ballot(mi == m && m < NM);
+            if (mi == m) rank = __popcll(bal & below);
+            if (lane == m) cnt_lane = __popcll(bal);
+        }
+        int wbase = 0;
+        if (lane < K2_MAXM && cnt_lane) wbase = atomicAdd(&s_tot[buf][lane], cnt_lane);
+        int mybase = 0;
+#pragma unroll
+        for (int m = 0; m < K2_MAXM; ++m) {
+            const int b = __builtin_amdgcn_readlane(wbase, m);
+            mybase = mi == m ? b : mybase;
+        }
+        if (mi < NM) s_list[mi][mybase + rank] = (uint16_t)tid;
+        s_q[tid] = qv;
         K2_STAMP(2);
+        K2_TL(1);
         __syncthreads();
-        if (FAST && tid == 0) s_nfix = 0;           // (every thread has left the stretch before: phase D read it last)
-        if (!placed) {
-            uint32_t per_simd = 0;                  // a byte per SIMD: its waves
-            int slot = 0;                           // waves of this wave's SIMD with a smaller number
-            for (int w4 = 0; w4 < K2_WAVES / 4; ++w4) {
-                const uint32_t four = __builtin_amdgcn_readfirstlane(s_simd_of_wave[w4]);
+        K2_TL(2);
+        int tot[K2_MAXM], gs[K2_MAXM], n_groups = 0;    // records and first group of every sub-model
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int sd = (four >> (8 * b)) & 3;
-                    per_simd += 1u << (8 * sd);
-                    slot += (w4 * 4 + b < wave && sd == simd) ? 1 : 0;
-                }
-            }
-            const bool by_simd = (per_simd & 0xFFu) && (per_simd & 0xFF00u) && (per_simd & 0xFF0000u) && (per_simd & 0xFF000000u);
-            quarter = by_simd ? simd : wave & 3;
-            g_first = by_simd ? slot : wave >> 2;
-            g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : K2_WAVES / 4;
-            placed = true;
+        for (int m = 0; m < K2_MAXM; ++m) {
+            tot[m] = __builtin_amdgcn_readfirstlane(s_tot[buf][m]);
+            gs[m] = n_groups;
+            n_groups += (tot[m] + 63) >> 6;
         }
-        if (tid < K2_SUB * K2_MAXM) {               // thread (piece c, sub-model m): the sub-model's records in pieces before c
-            const int c = tid / K2_MAXM, m = tid % K2_MAXM;
-            int all = 0, before = 0;
-            if (m < NM)
-                for (int c2 = 0; c2 < K2_SUB; ++c2) { const int v = s_cnt[c2][m]; all += v; before += c2 < c ? v : 0; }
-            s_before[c][m] = before;
-            if (c == 0) s_tot[m] = all;
-        }
-        __syncthreads();
-        int n_groups = 0;
-        {
-            int start[K2_MAXM];                     // first list entry of every sub-model
-#pragma unroll
-            for (int m = 0; m < K2_MAXM; ++m) { start[m] = n_groups * 64; n_groups += (s_tot[m] + 63) >> 6; }
-#pragma unroll
-            for (int i = 0; i < K2B / K2_THREADS; ++i) {
-                const int off = i * K2_THREADS + tid;
-                if (mi[i] < NM) {
-                    int st = 0;
-#pragma unroll
-                    for (int m = 0; m < K2_MAXM; ++m) st = mi[i] == m ? start[m] : st;
-                    s_list[st + s_before[off >> 6][mi[i]] + rank[i]] = (uint16_t)off;
-                }
-            }
-            if (tid < K2_MAXM * 64) {               // padding of sub-model tid / 64, and the sub-model of its groups
-                const int m = tid >> 6;
-                int st = 0;
-#pragma unroll
-                for (int m2 = 0; m2 < K2_MAXM; ++m2) st = m == m2 ? start[m2] : st;
-                const int tot = s_tot[m], g = (tot + 63) >> 6;
-                if (tot + lane < g * 64) s_list[st + tot + lane] = 0xFFFF;
-                if (lane < g) s_gmodel[(st >> 6) + lane] = m;
+        if (tid < K2_MAXM) s_tot[buf ^ 1][tid] = 0;     // (the next stretch's: last read a stretch ago)
+        if constexpr (FAST) {
+            // the list of records to evaluate again has room for everything this stretch may add?  (It is only added to in C.)
+            const int n_fix = __builtin_amdgcn_readfirstlane(s_nfix);
+            if (n_fix > K2_FIX - K2B) {
+                again_in_fp64(n_fix);
+                __syncthreads();
+                if (tid == 0) s_nfix = 0;
             }
         }
-#pragma unroll
-        for (int i = 0; i < K2B / K2_THREADS; ++i) s_q[i * K2_THREADS + tid] = qv[i];
-        __syncthreads();
         K2_STAMP(3);
         // ---- B: a quarter of the hidden units for every fourth (eighth ...) group
         const int u0 = quarter * H / 4, u1 = (quarter + 1) * H / 4;
         for (int g = g_first; g < n_groups; g += g_step) {
-            const int mdl = __builtin_amdgcn_readfirstlane(s_gmodel[g]);
-            const int e = s_list[g * 64 + lane];
-            const int off = e == 0xFFFF ? s_list[g * 64] : e;       // (padding lanes compute the group's first record again)
-            const int64_t r = rec_at(off);
+            int mdl = 0, tot_m = tot[0], lg = g;    // the group's sub-model, its records, the group's number among its groups
+#pragma unroll
+            for (int m = 1; m < K2_MAXM; ++m)
+                if (g >= gs[m] && tot[m] > 0) { mdl = m; tot_m = tot[m]; lg = g - gs[m]; }
+            const int idx = lg * 64 + lane;
+            const bool valid = idx < tot_m;         // (the lanes behind the list's end compute the group's first record again)
+            const int off = s_list[mdl][valid ? idx : lg * 64];
+            const int64_t rr = slot0 + (pieces ? s_slot[off] : off);
             double x[NX];
             if (submodel_in) {                       // plain batched call: X rows of n_in values
 #pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[r * NI + i] : 0.0;
+                for (int i = 0; i < NX; ++i) x[i] = i < NI ? feats[rr * NI + i] : 0.0;
             } else {                                 // flush records: k slot means + read quality (:189-193)
                 const double q = s_q[off];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
+                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[rr * k + i] : (i == k ? q : 0.0);
             }
             double z = 0.0;
             if constexpr (FAST) {
-                float xf[NX];
+                // (two hidden units per instruction: v_pk_fma_f32 with the units' weights side by side in an SGPR pair, the record's
+                // input in both halves of a register pair.  The weights and the bias carry the factor 2 log2(e) -- DevMlp.wp32 -- so that
+                // the sum IS the exponent: tanh(a) = 1 - 2 / (1 + 2^s), one v_exp_f32, one v_rcp_f32, one packed fma per pair)
+                f2 xx[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xf[i] = (float)x[i];
-                const MC_SCALAR_MEM float *wf = (const MC_SCALAR_MEM float *)M.wu32 + ((size_t)mdl * H + u0) * S;
-                float zf = 0.0f;
-                int u = u0;
-                for (; u + 4 <= u1; u += 4, wf += 4 * S) {          // four independent chains
-                    float a0 = xf[0] * wf[0], a1 = xf[0] * wf[S], a2 = xf[0] * wf[2 * S], a3 = xf[0] * wf[3 * S];
+                for (int i = 0; i < NX; ++i) xx[i] = (f2){(float)x[i], (float)x[i]};
+                const int H2 = (H + 1) >> 1;
+                const int p0 = quarter * H2 / 4, p1 = (quarter + 1) * H2 / 4;
+                const MC_SCALAR_MEM f2 *wp = (const MC_SCALAR_MEM f2 *)M.wp32 + ((size_t)mdl * H2 + p0) * S;
+                f2 zz = {0.0f, 0.0f};
+                int p = p0;
+                for (; p + 2 <= p1; p += 2, wp += 2 * S) {          // two independent chains of pairs
+                    f2 a = xx[0] * wp[0], b = xx[0] * wp[S];
 #pragma unroll
                     for (int i = 1; i < NX; ++i)
                         if (i < NI) {
-                            a0 = __builtin_fmaf(xf[i], wf[i], a0);
-                            a1 = __builtin_fmaf(xf[i], wf[S + i], a1);
-                            a2 = __builtin_fmaf(xf[i], wf[2 * S + i], a2);
-                            a3 = __builtin_fmaf(xf[i], wf[3 * S + i], a3);
+                            a = __builtin_elementwise_fma(xx[i], wp[i], a);
+                            b = __builtin_elementwise_fma(xx[i], wp[S + i], b);
                         }
-                    a0 += wf[NI]; a1 += wf[S + NI]; a2 += wf[2 * S + NI]; a3 += wf[3 * S + NI];
-                    zf = __builtin_fmaf(tanh32(a0), wf[NI + 1], zf);
-                    zf = __builtin_fmaf(tanh32(a1), wf[S + NI + 1], zf);
-                    zf = __builtin_fmaf(tanh32(a2), wf[2 * S + NI + 1], zf);
-                    zf = __builtin_fmaf(tanh32(a3), wf[3 * S + NI + 1], zf);
+                    a += wp[NI]; b += wp[S + NI];
+                    zz = __builtin_elementwise_fma(tanh32s_2(a), wp[NI + 1], zz);
+                    zz = __builtin_elementwise_fma(tanh32s_2(b), wp[S + NI + 1], zz);
                 }
-                for (; u < u1; ++u, wf += S) {
-                    float a0 = xf[0] * wf[0];
+                for (; p < p1; ++p, wp += S) {
+                    f2 a = xx[0] * wp[0];
 #pragma unroll
                     for (int i = 1; i < NX; ++i)
-                        if (i < NI) a0 = __builtin_fmaf(xf[i], wf[i], a0);
-                    zf = __builtin_fmaf(tanh32(a0 + wf[NI]), wf[NI + 1], zf);
+                        if (i < NI) a = __builtin_elementwise_fma(xx[i], wp[i], a);
+                    zz = __builtin_elementwise_fma(tanh32s_2(a + wp[NI]), wp[NI + 1], zz);
                 }
-                z = (double)zf;                                      // (stored as the float it is)
-                if (quarter == 0) {                                  // how far the entry's probability may lie from the fp64 one
+                z = (double)(zz.x + zz.y);                           // (stored as the float it is)
+                if (quarter == 0 && valid) {                         // how far the record's probability may lie from the fp64 one
                     const MC_SCALAR_MEM float *mg = (const MC_SCALAR_MEM float *)M.margin + (size_t)mdl * (MC_MAX_K + 2);
                     float m = mg[0];
 #pragma unroll
                     for (int i = 0; i < NX; ++i)
-                        if (i < NI) m = __builtin_fmaf(fabsf(xf[i]) * 1.0000002f, mg[1 + i], m);
-                    s_marg[g * 64 + lane] = m * 1.000001f;
+                        if (i < NI) m = __builtin_fmaf(fabsf(xx[i].x) * 1.0000002f, mg[1 + i], m);
+                    s_marg[FAST ? off : 0] = m * 1.000001f;
                 }
             } else {
                 const MC_SCALAR_MEM double *wu = (const MC_SCALAR_MEM double *)M.wu + ((size_t)mdl * H + u0) * S;
@@ -451,56 +474,34 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
                     z = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], z);
                 }
             }
-            s_part[quarter][g * 64 + lane] = (part_t)z;
+            if (valid) s_part[quarter][off] = (part_t)z;
         }
         K2_STAMP(4);
+        K2_TL(3);
         __syncthreads();
         K2_STAMP(5);
-        // ---- C: the output unit
-        for (int t = tid; t < n_groups * 64; t += K2_THREADS) {
-            const int e = s_list[t];
-            if (e == 0xFFFF) continue;
-            const double z = (((double)s_part[0][t] + (double)s_part[1][t]) + (double)s_part[2][t]) + (double)s_part[3][t];
-            const double pr = logistic(z + M.b2[s_gmodel[t >> 6]], C);
-            prob[rec_at(e)] = pr;
-            if (FAST && !(threshold_distance(pr) > (double)s_marg[t])) s_fix[atomicAdd(&s_nfix, 1)] = (uint16_t)t;     // (NaN too)
+        K2_TL(4);
+        // ---- C: the output unit of the thread's record
+        if (mi < NM) {
+            const double z = (((double)s_part[0][tid] + (double)s_part[1][tid]) + (double)s_part[2][tid]) + (double)s_part[3][tid];
+            const double pr = logistic(z + M.b2[mi], C);
+            prob[r] = pr;
+            if (FAST && !(threshold_distance(pr) > (double)s_marg[FAST ? tid : 0]))       // (NaN too)
+                s_fixlist[FAST ? atomicAdd(&s_nfix, 1) : 0] = (unsigned long long)r | (unsigned long long)mi << 56;
         }
-        if constexpr (FAST) {
-            // ---- D: the entries whose printed digits (or label) could depend on the precision: again in fp64, a wave per entry,
-            // the hidden units across its lanes
-            __syncthreads();
-            const int n_fix = s_nfix;
-            for (int f = wave; f < n_fix; f += K2_WAVES) {
-                const int t = s_fix[f];
-                const int e = s_list[t], mdl = s_gmodel[t >> 6];
-                const int64_t r = rec_at(e);
-                double x[NX];
-                const double q = s_q[e];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = i < k ? feats[r * k + i] : (i == k ? q : 0.0);
-                double part = 0.0;
-                for (int u = lane; u < H; u += 64) {
-                    const double *wu = M.wu + ((size_t)mdl * H + u) * S;
-                    double a0 = x[0] * wu[0];
-#pragma unroll
-                    for (int i = 1; i < NX; ++i)
-                        if (i < NI) a0 = fma(x[i], wu[i], a0);
-                    part = fma(tanh_1exp(a0 + wu[NI], C), wu[NI + 1], part);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-                if (lane == 0) prob[r] = logistic(part + M.b2[mdl], C);
-            }
-        }
-        // (no barrier here: what the next stretch writes before its first barrier -- s_q, s_cnt -- was last read before the
-        // barrier above; a stretch made of pieces rewrites s_slot at once, which phases C and D read: one there)
-        if (pieces) __syncthreads();
         base += pieces ? np_here : K2B;
+        buf ^= 1;
         K2_STAMP(6);
+        K2_TL(5);
+        ++stretch_no;
 #ifdef MC_K2_TRACE
         if (lane == 0 && blockIdx.x < 1024)
             g_k2_trace[((size_t)blockIdx.x * K2_WAVES + wave) * 16 + 7] = (unsigned)simd | (unsigned)quarter << 4 | (unsigned)g_first << 8 | (unsigned)g_step << 16 | (unsigned long long)n_groups << 24;
 #endif
+    }
+    if constexpr (FAST) {
+        __syncthreads();
+        again_in_fp64(s_nfix);
     }
 }
 
@@ -848,6 +849,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
 #ifndef MC_K2_WG_PER_CU
 #define MC_K2_WG_PER_CU 1
 #endif
+#ifndef MC_K2_WG_MANY          // ... where there are millions of records (the fast forward)
+#define MC_K2_WG_MANY 2
+#endif
 
 // the classifier of a context -- MLP (k2_mlp: the 7-input instance for k = 6, the reference's models, or the general one), forest
 // (k3_forest) or one of the closed forms (k3_simple) -- over n records (n_dev: the count is on the device, n is the capacity)
@@ -864,12 +868,12 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
         hipLaunchKernelGGL(k3_simple, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, S, feats, k, site_seg, seg_read, qual, info,
                            submodel_in, n, prob, n_dev, overflow);
     else {
-        const bool fast = M.fast && M.wu32 && !submodel_in;
+        const bool fast = M.fast && M.wp32 && !submodel_in;
         // (two workgroups per CU where there are millions of records -- a one-base motif; the passes of a sparse motif score a few
         // hundred thousand beside the next pass's scan, and a second workgroup per CU there takes the scan's wave slots: k2_mlp
         // 33 -> 93 us, the scan 164 -> 184)
         const bool many = P.cnt != nullptr || n >= ((int64_t)4 << 20);
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * ((fast && many) ? 2 : MC_K2_WG_PER_CU)));
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)n_cu * ((fast && many) ? MC_K2_WG_MANY : MC_K2_WG_PER_CU)));
         // (flush records: the fast forward unless the context was told otherwise; a plain batched call -- the estimator protocol,
         // mc_mlp_forward -- is fp64 throughout: its caller gets raw probabilities)
         if (M.n_in == 7 && fast)
@@ -897,14 +901,14 @@ void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned lon
     else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
 }
 
-// tanh32 against the fp64 tanh over EVERY float: the largest absolute difference (what K2_TANH32_MAX_ERR has to cover)
+// tanh32s(s) against the fp64 tanh(s ln2 / 2) over EVERY float s: the largest absolute difference (what K2_TANH32_MAX_ERR has to cover)
 namespace {
 __global__ void k_tanh32_err(unsigned long long *out) {
     unsigned long long worst = 0ull;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
         const float x = __uint_as_float((unsigned)i);
         if (!(fabsf(x) <= 3.4e38f)) continue;                // (NaN, inf)
-        const double err = fabs((double)tanh32(x) - tanh((double)x));
+        const double err = fabs((double)tanh32s(x) - tanh((double)x * 0.34657359027997264));
         const unsigned long long b = (unsigned long long)__double_as_longlong(err);     // (non-negative doubles order like their bits)
         worst = b > worst ? b : worst;
     }
@@ -925,6 +929,10 @@ extern "C" int mc_debug_tanh32_max_err(double *out) {
 }
 
 #ifdef MC_K2_TRACE
+extern "C" int mc_debug_k2_timeline(unsigned long long *out, int64_t n_words) {
+    if (n_words > 256 * 24 * 8) n_words = 256 * 24 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_timeline), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
+}
 extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
     if (n_words > 1024 * 16 * 16) n_words = 1024 * 16 * 16;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -10;

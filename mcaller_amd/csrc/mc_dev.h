@@ -125,15 +125,17 @@ struct DevMlp {
     int32_t n_models = 0, n_in = 0, n_hidden = 0;
     double *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
     double *wu = nullptr;      // per sub-model and hidden unit: W1[0..n_in)[j], b1[j], W2[j] -- what k2_mlp reads with scalar loads
-    float *wu32 = nullptr;     // ... the same, rounded to float: the fast forward (k2_mlp<.., true>)
+    float *wp32 = nullptr;     // the fast forward (k2_mlp<.., true>): floats, the units in PAIRS -- [model][pair][n_in + 2][2]: the two
+                               // units' weights side by side (one SGPR pair per packed fma); W1 and b1 times 2 log2(e) (tanh32s), W2
+                               // plain; a layer with an odd number of units is padded with a unit of zeros
     float *margin = nullptr;   // per sub-model, MC_MAX_K + 2 floats: K0, K_0 .. K_{n_in-1} -- the fast forward's probability is within
                                // K0 + sum K_i |x_i| of the fp64 one (mc_ctx_set_mlp works it out from the weights)
     int fast = 0;              // flush records are scored by the fast forward (fp32 + fp64 where a printed digit could depend on it)
     uint8_t *sub_of_char = nullptr;
 };
-// largest |tanh32(x) - tanh(x)| over all floats x (mc_classify.hip: one v_exp_f32, one v_rcp_f32): measured by exhaustion on the
-// GPU, tests/test_gpu_mlp_fast.py holds the kernel to it
-constexpr double K2_TANH32_MAX_ERR = 1.5e-7;      // (measured: 1.312e-7)
+// largest |tanh32s(s) - tanh(s ln2 / 2)| over all floats s (mc_classify.hip: one v_exp_f32, one v_rcp_f32, one fma): measured by
+// exhaustion on the GPU, tests/test_gpu_mlp_fast.py holds the kernel to it
+constexpr double K2_TANH32_MAX_ERR = 2.5e-7;      // (measured: 2.180e-7)
 
 struct DevForest {
     int32_t n_models = 0, n_in = 0;

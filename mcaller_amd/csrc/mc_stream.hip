@@ -1231,14 +1231,23 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
     UP(M.wu, wu.data(), wu.size(), c->mlp_allocs);
     // The fast forward (k2_mlp<.., true>): the same weights as floats, and per sub-model how far its probability can lie from
     // the fp64 one, as K0 + sum_i K_i |x_i|.  With u = 2^-24: a hidden unit's input a_j is off by at most g_dot sum_i |x_i W1_ij|
-    // (+ the bias), g_dot = 12 u (seven products and sums, the inputs and weights rounded to float); tanh is 1-Lipschitz and
-    // tanh32 is within K2_TANH32_MAX_ERR of it; the output sum picks up g_acc sum_j |W2_j| (a quarter of the units per partial
-    // sum: 25 terms, their products, the weights' rounding: g_acc = 29 u); the logistic function's slope is at most 1/4.  Five per
-    // cent on top for the float arithmetic the bound itself is evaluated in.
-    std::vector<float> wu32(wu.size()), margin((size_t)n_models * (MC_MAX_K + 2), 0.0f);    // (alive until the copies have been waited for)
+    // (+ the bias), g_dot = (n_in + 5) u (n_in products and sums, the inputs and weights rounded to float -- the weights after the factor
+    // 2 log2(e) that makes the sum the exponent of tanh32s: a relative error either way); tanh is 1-Lipschitz and tanh32s is within
+    // K2_TANH32_MAX_ERR of it; the output sum picks up g_acc sum_j |W2_j| (a quarter of the units per partial sum, two chains of
+    // at most 13 terms and their sum, the products, the weights' rounding: g_acc = 29 u covers 25 in one chain); the logistic
+    // function's slope is at most 1/4.  Five per cent on top for the float arithmetic the bound itself is evaluated in.
+    const int h2 = (n_hidden + 1) / 2;
+    std::vector<float> wp32((size_t)n_models * h2 * S * 2, 0.0f), margin((size_t)n_models * (MC_MAX_K + 2), 0.0f);    // (alive until the copies have been waited for)
     {
-        for (size_t i = 0; i < wu.size(); ++i) wu32[i] = (float)wu[i];
-        const double u = 5.9604644775390625e-08, g_dot = 12.0 * u, g_acc = 29.0 * u;
+        const double c2 = 2.8853900817779268;         // 2 log2(e): the hidden unit's sum is the exponent of tanh32s
+        for (int m = 0; m < n_models; ++m)
+            for (int j = 0; j < n_hidden; ++j) {
+                const double *uj = &wu[((size_t)m * n_hidden + j) * S];
+                float *pj = &wp32[(((size_t)m * h2 + j / 2) * S) * 2 + (j & 1)];
+                for (int i = 0; i <= n_in; ++i) pj[2 * i] = (float)(c2 * uj[i]);
+                pj[2 * (n_in + 1)] = (float)uj[n_in + 1];
+            }
+        const double u = 5.9604644775390625e-08, g_dot = (n_in + 5.0) * u, g_acc = 29.0 * u;
         for (int m = 0; m < n_models; ++m) {
             double sw2 = 0.0, cb = 0.0, ci[MC_MAX_K + 1] = {0};
             for (int j = 0; j < n_hidden; ++j) {
@@ -1252,7 +1261,7 @@ extern "C" int mc_ctx_set_mlp(mc_ctx *c, int32_t n_models, int32_t n_in, int32_t
             mg[0] = (float)(1.05 * 0.25 * (sw2 * K2_TANH32_MAX_ERR + g_dot * cb + g_acc * sw2) + 1e-12);
             for (int i = 0; i < n_in; ++i) mg[1 + i] = (float)(1.05 * 0.25 * g_dot * ci[i]);
         }
-        UP(M.wu32, wu32.data(), wu32.size(), c->mlp_allocs);
+        UP(M.wp32, wp32.data(), wp32.size(), c->mlp_allocs);
         UP(M.margin, margin.data(), margin.size(), c->mlp_allocs);
     }
     // (MCALLER_MLP_FP64=1: every record in fp64, as rounds 1-4 scored them)

@@ -267,6 +267,17 @@ class Device(object):
         check(lib().mc_wait_records(self._ctx, C.byref(n), C.byref(v)))
         k = self._async_k.pop(0)
         self._last = (n.value, k)
+        rerun = C.c_int32(0)
+        check(lib().mc_last_pass_info(self._ctx, None, C.byref(rerun)))
+        if rerun.value:
+            # a pass the library repeated synchronously (irregular reads, record buffers too small) hands out the context's ONE set
+            # of buffers for synchronous runs, which the next such pass overwrites -- and the stream's formatter thread reads a
+            # shard's records while the main thread waits for the next pass: such records are copied (they are rare)
+            rec = Records(n.value, k)
+            vc = rec.view()
+            check(lib().mc_fetch_records(self._ctx, C.byref(vc)))
+            rec.n = n.value
+            return rec
         return Records.from_view(v, n.value, k, self)
 
     @_serialized

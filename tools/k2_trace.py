@@ -49,3 +49,25 @@ print('block 0: wave simd quarter g_first  B-time(ns)')
 for w in range(W):
     i = int(b[w, 7])
     print('   %2d  %d  %d  %d   %6d' % (w, i & 15, (i >> 4) & 15, (i >> 8) & 255, (int(b[w, 4]) - int(b[w, 3])) * 10))
+
+# every stretch of wave 0 of the first 256 workgroups: begin, A done, behind the first barrier, B done (wave 0's groups), behind the
+# second barrier, C done
+tl = np.zeros(256 * 24 * 8, dtype=np.uint64)
+L.mc_debug_k2_timeline.argtypes = [C.c_void_p, C.c_int64]
+if L.mc_debug_k2_timeline(tl.ctypes.data, tl.size) == 0:
+    tl = tl.reshape(256, 24, 8).astype(np.int64) * 10
+    ok = (tl[:, :, 0] > 0) & (tl[:, :, 5] > 0)
+    names = ['A (loads, lists)', 'wait at barrier 1', 'B (own groups)', 'wait at barrier 2', 'C']
+    full = ok.copy(); full[:, 1:] &= ok[:, 1:]          # (every stretch that has stamps)
+    print('stretches with stamps: %d; mean ns per phase of a stretch:' % int(ok.sum()))
+    for i, nm in enumerate(names):
+        d = (tl[:, :, i + 1] - tl[:, :, i])[ok]
+        print('   %-20s mean %7.0f  p50 %7.0f  p90 %7.0f' % (nm, d.mean(), np.percentile(d, 50), np.percentile(d, 90)))
+    d = (tl[:, :, 5] - tl[:, :, 0])[ok]
+    print('   %-20s mean %7.0f' % ('stretch', d.mean()))
+    gap = (tl[:, 1:, 0] - tl[:, :-1, 5])[ok[:, 1:] & ok[:, :-1]]
+    print('   %-20s mean %7.0f' % ('between stretches', gap.mean()))
+    print('workgroup 0, stretch by stretch (ns since its first): begin, A, b1, B, b2, C')
+    for j in range(24):
+        if ok[0, j]:
+            print('   %2d  ' % j + ' '.join('%7d' % (tl[0, j, i] - tl[0, 0, 0]) for i in range(6)))

@@ -11,8 +11,13 @@ __global__ __launch_bounds__(256) void k_rate(unsigned *out, unsigned seed) {
     unsigned a[CH];
     double d[CH];
     unsigned long long q[CH];
+    float f[CH];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f2 g[CH];
+    f4 acc4[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { a[c] = seed + threadIdx.x * (c + 1); d[c] = (double)a[c]; q[c] = a[c]; }
+    for (int c = 0; c < CH; ++c) { a[c] = seed + threadIdx.x * (c + 1); d[c] = (double)a[c]; q[c] = a[c]; f[c] = (float)(a[c] & 1023u) * 1e-3f; g[c] = (f2){f[c], f[c] + 1.0f}; acc4[c] = (f4){f[c], 0.f, 0.f, 0.f}; }
     unsigned s = seed;
     for (int i = 0; i < ITER; ++i) {
 #pragma unroll
@@ -27,11 +32,27 @@ __global__ __launch_bounds__(256) void k_rate(unsigned *out, unsigned seed) {
             if (KIND == 7) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[c]) : "v"(d[(c + 1) % CH]));
             if (KIND == 8) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[c]), "v"(seed) : "vcc");
             if (KIND == 9) asm volatile("v_readlane_b32 %0, %1, 3" : "+s"(s) : "v"(a[c]));
+            if (KIND == 10) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[c]) : "v"(f[(c + 1) % CH]));
+            if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(g[c]) : "v"(g[(c + 1) % CH]));
+            if (KIND == 12) asm volatile("v_exp_f32 %0, %0" : "+v"(f[c]));
+            if (KIND == 13) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[c]));
+            if (KIND == 14) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(g[c]) : "v"(g[(c + 1) % CH]));
+            if (KIND == 15) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[c]) : "v"(seed));
+            if (KIND == 16) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[c]) : "v"(f[c]), "v"(f[(c + 1) % CH]));
+            if (KIND == 17) {           // the mix of the fast forward's hidden layer: 8 packed + 2 exp + 2 rcp per pair of units
+                if (c < 2) asm volatile("v_exp_f32 %0, %0" : "+v"(f[c]));
+                else if (c < 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[c]));
+                else asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n\tv_pk_fma_f32 %0, %0, %1, %1" : "+v"(g[c]) : "v"(g[(c + 1) % CH]));
+            }
+            if (KIND == 18) {           // MFMA from the odd waves, packed fma from the even ones: do the two pipes overlap?
+                if ((threadIdx.x >> 6) & 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[c]) : "v"(f[c]), "v"(f[(c + 1) % CH]));
+                else asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(g[c]) : "v"(g[(c + 1) % CH]));
+            }
         }
     }
     unsigned acc = s;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc ^= a[c] ^ (unsigned)d[c] ^ (unsigned)q[c];
+    for (int c = 0; c < CH; ++c) acc ^= a[c] ^ (unsigned)d[c] ^ (unsigned)q[c] ^ __float_as_uint(f[c]) ^ __float_as_uint(g[c].x + g[c].y) ^ __float_as_uint(acc4[c].x + acc4[c].y + acc4[c].z + acc4[c].w);
     if (acc == 0x12345678u) out[0] = acc;
 }
 template <int KIND>
@@ -55,5 +76,7 @@ int main() {
     unsigned *out; CK(hipMalloc((void **)&out, 4));
     run<0>("v_add_u32", out); run<1>("v_xor_b32", out); run<5>("v_cndmask_b32", out); run<8>("v_cmp_lt_u32", out); run<6>("v_mul_lo_u32", out);
     run<3>("v_lshl_add_u64", out); run<2>("v_add_f64", out); run<7>("v_fma_f64", out); run<9>("v_readlane_b32", out); run<4>("s_add_u32", out);
+    run<10>("v_fma_f32", out); run<11>("v_pk_fma_f32", out); run<14>("v_pk_mul_f32", out); run<12>("v_exp_f32", out); run<13>("v_rcp_f32", out);
+    run<15>("v_bfi_b32", out); run<16>("v_mfma_f32_16x16x4_f32", out); run<17>("mix: 2 exp 2 rcp 8 pk_fma (12 counted as 8)", out); run<18>("half mfma, half pk_fma", out);
     return 0;
 }
