@@ -269,13 +269,14 @@ def dense_file_to_file_leg(inputs_dir, rows, runs):
     warm = secs[1:] if len(secs) > 1 else secs
     med = float(np.median(warm))
     ph = [p for p in res.get('phases_all', [])[1:] if p] or [p for p in res.get('phases_all', []) if p]
-    phases = {k: float(np.median([p[k] for p in ph])) for k in ('parse', 'wait_parser', 'enqueue', 'hand_out', 'wait_records', 'format', 'write')
+    phases = {k: float(np.median([p[k] for p in ph])) for k in ('parse', 'wait_parser', 'enqueue', 'hand_out', 'wait_records', 'wait_formatter', 'format', 'write')
               if ph and all(k in p for p in ph)}
+    fmt_threads = max(1, int(ph[-1].get('format_threads', 1) or 1)) if ph else 1
     bound = None
     if phases:
-        main = {'formatter (mc_format_diffs: shortest round-trip doubles, rows of text)': phases.get('format', 0.0),
+        main = {'formatter (mc_format_diffs: shortest round-trip doubles, rows of text; per helper thread)': phases.get('format', 0.0) / fmt_threads,
                 'write (the rows appended to the output file)': phases.get('write', 0.0),
-                'GPU + copy-out (records waited for)': phases.get('wait_records', 0.0),
+                'GPU + copy-out behind the link (records waited for)': phases.get('wait_records', 0.0),
                 'reader + link + device parser (next table waited for)': phases.get('wait_parser', 0.0)}
         bound = max(main, key=main.get)
     return {'rows': rows, 'motif': 'A', 'tsv_bytes': res['tsv_bytes'], 'diffs_bytes': res['diffs_bytes'], 'calls': res['calls'],
@@ -283,10 +284,12 @@ def dense_file_to_file_leg(inputs_dir, rows, runs):
             'events_per_s': rows / med, 'calls_per_s': res['calls'] / med, 'text_in_GBps': res['tsv_bytes'] / med / 1e9,
             'text_out_GBps': res['diffs_bytes'] / med / 1e9, 'peak_rss_mb': res['peak_rss_mb'],
             'phases_s': phases, 'bound': bound,
-            'phases_what': 'seconds of the MAIN thread per run, median of the warm runs (they add up to the run; the reader threads and '
+            'format_threads': fmt_threads,
+            'phases_what': 'seconds per run, median of the warm runs.  Of the MAIN thread (they add up to the run; the reader threads and '
                            'the GPU work beside it): wait_parser = the next shard\'s table waited for (read, H2D, device parser), enqueue '
-                           '= upload + passes enqueued, hand_out = wait_records (kernels + copy-out of the oldest pass) + format (native '
-                           'row formatter on all host cores) + write (rows appended to the file)',
+                           '= upload + passes enqueued, hand_out = wait_records (kernels + copy-out of the oldest pass) + wait_formatter '
+                           '(the helper two shards back).  Of the helper threads: format = the shards\' rows made (native row formatter '
+                           'on all host cores + the counters; the sum over format_threads helpers), write = rows appended to the file',
             'what': 'python tools/file_to_file.py --inputs ... --motif A --runs %d --json: the CLI in a process of its own, page cache warm' % runs}
 
 

@@ -451,6 +451,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         raise _Unstreamable('one shard')
     import contextlib
     import io
+    import threading
     ref = MarkedReference(fasta_input, base, motif, positions_list)
     ref.quiet = True                   # (an exit path sends the file to the one-table path, which prints)
     if not train:
@@ -597,22 +598,30 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     in_flight = []                  # (P, tail name, rows of the shards before it) of the passes enqueued, oldest first
     marked = [-1]                                          # (>= 0: the reference masks are on the device)
 
-    # The rows of a shard are formatted by one helper thread and appended by another while the main thread goes on to the next shard (its
+    # The rows of a shard are formatted by helper threads and appended by another while the main thread goes on to the next shard (its
     # table, its passes, the wait for its records): a one-base motif writes 1.3 GB of rows per 10^8 events, and formatter + write were
-    # two thirds of what the main thread did.  Not in train mode (the per-record transcription holds the interpreter lock) and not
-    # when every shard's records are reduced on the device (on_shard needs what the formatter found).  The helper is at most one
-    # shard behind: the records it reads stay where they are until four more passes have been enqueued.
+    # two thirds of what the main thread did.  TWO formatting helpers take the shards in turn: what a shard costs there is the native
+    # formatter on all host cores (2.5 ms per 10^6 rows of a one-base motif, one call at a time) and 1.5 ms of interpreter around it
+    # (the counters, the names at the cuts, the marks) -- the one's interpreter part runs beside the other's native part.  What depends
+    # on the order of the shards (names across the cuts, the rows handed to the writer, the totals) is done by every shard in its turn.
+    # Not in train mode (the per-record transcription holds the interpreter lock) and not when every shard's records are reduced on
+    # the device (on_shard needs what the formatter found).  The helpers are at most two shards behind: the records they read stay
+    # where they are until four more passes have been enqueued.
     overlap = not train and on_shard is None and not os.environ.get('MCALLER_NO_OVERLAP')
-    fmt_pool = ThreadPoolExecutor(max_workers=1) if overlap else None
-    write_pool = ThreadPoolExecutor(max_workers=1) if overlap else None     # (... and a second one appends them: in order, one shard behind)
+    fmt_pool = ThreadPoolExecutor(max_workers=2) if overlap else None
+    write_pool = ThreadPoolExecutor(max_workers=1) if overlap else None     # (... and one more appends them: in order, one shard behind)
     pending, writes = [], []        # the helpers' jobs in flight (futures), if any
+    turn = [None]                   # the event the shard handed out last sets when its part in order is done
+    failed = [False]                # a shard met an exit path or a name on both sides of a cut: the shards behind it write nothing
     clock['overlapped'] = bool(overlap)
+    clock['format_threads'] = 2 if overlap else 0           # (0: the main thread formats)
 
-    def finish_pending():
-        while pending:
+    def finish_pending(leave=0):
+        while len(pending) > leave:
             pending.pop(0).result()                            # (its exception, if it met an exit path, is raised here)
-        while writes:
-            writes.pop(0).result()
+        if not leave:
+            while writes:
+                writes.pop(0).result()
 
     def hand_out():
         t_h = time.perf_counter()
@@ -630,17 +639,34 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         clock['wait_records'] += t_f - t_w
         mark('records here')
         if overlap:
-            finish_pending()                                   # (the shard before: done, or its exit path raised)
+            finish_pending(leave=1)                            # (the shard before the last: done, or its exit path raised)
             clock['wait_formatter'] = clock.get('wait_formatter', 0.0) + time.perf_counter() - t_f
-            pending.append(fmt_pool.submit(_finish, P, tail, rows_before, rec))
+            before, mine = turn[0], threading.Event()
+            turn[0] = mine
+            pending.append(fmt_pool.submit(_finish_in_turn, P, tail, rows_before, rec, before, mine))
         else:
-            _finish(P, tail, rows_before, rec)
+            _finish(P, tail, rows_before, rec, None)
 
-    def _finish(P, tail, rows_before, rec):
+    def _finish_in_turn(P, tail, rows_before, rec, before, mine):
+        try:
+            _finish(P, tail, rows_before, rec, before)
+        except BaseException:
+            failed[0] = True
+            raise
+        finally:
+            mine.set()
+
+    def _finish(P, tail, rows_before, rec, before):
         t_f = time.perf_counter()
         fin = Finisher(P, k, base, train, modelset=modelset, pos_label=pos_label, device=dev, tail_chrom=tail)
         fin.stdout = io.StringIO()                             # (its exit paths print; the one-table path will)
         stop = fin.run(rec)
+        t_r = time.perf_counter()
+        if before is not None:
+            before.wait()                                      # ---- from here on: in the order of the shards ----
+            if failed[0]:
+                return
+        t_f += time.perf_counter() - t_r                       # (the wait for the turn is not formatting)
         if stop is not None:
             raise _Unstreamable('an exit path of the reference')
         # `last_read` across the cut in front of this shard (cut_names): a name on both sides of it sends the file to the one-table path
