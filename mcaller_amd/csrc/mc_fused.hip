@@ -736,7 +736,11 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         const bool edge = m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L;
         const int at = edge ? 0 : (rev ? m - 1 : m + 1);
         const int64_t seq_base = B.seq_delta != NO_SEQ_DELTA ? 32 * B.mask_off + B.seq_delta : A.R.seq_off[B.contig];
+#ifdef MC_FD_FAKE_CHAR            // (variant build, timing only: what the base's trip costs the phase)
+        uint32_t base_ch = (uint32_t)(seq_base + at) & 0x5Fu;
+#else
         uint32_t base_ch = A.R.seq[seq_base + at];
+#endif
         bool rare = (B.stray_q != NO_STRAY) && m - B.stray_q >= 0 && m - B.stray_q < k;        // (the stray event of R5 is first in its slot)
         uint32_t have = 0, wide = 0;
         const int lb = B.lb;
@@ -750,7 +754,11 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             const uint32_t rf = rr >> F_ROW_BITS;
             if (rf & RF_UNUSABLE) { rare = true; break; }
             if (slot < 0) continue;
+#ifdef MC_FD_NO_FEATS             // (variant build, timing only: the slot means' stores)
+            if (s_mean[Rt] == 12345.678) A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];
+#else
             A.O.feats[q * k + (rev ? slot : k - 1 - slot)] = s_mean[Rt];            // :187-188 (a window that turns out rare is written again)
+#endif
             have |= 1u << slot;
             if (rf & RF_WIDE) wide |= 1u << slot;
         }

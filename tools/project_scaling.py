@@ -1,6 +1,7 @@
 """What ONE worker of an N-GPU run costs, measured on one GPU: a PROJECTION of the strong-scaling curve before a node exists.
 
   python tools/project_scaling.py --inputs DIR [--parts 2,4,8] [--runs 3] [--json]
+  python tools/project_scaling.py --rows N ...                                          (writes its own synthetic inputs first)
   python tools/project_scaling.py --inputs DIR --one N [--reader pread|mmap|mmap_keep] [--runs 3] [--json]     (what --parts runs per N)
 
 `mCaller --gpus N` (mcaller_amd/multi_gpu.py; the reference's fan-out: mCaller.py:62-70) cuts the file's consumed byte range
@@ -58,7 +59,16 @@ def one_worker(inputs, n_parts, runs, reader):
 def main():
     args = sys.argv[1:]
     as_json = '--json' in args
-    inputs = args[args.index('--inputs') + 1]
+    if '--rows' in args:
+        import tempfile
+        from mcaller_amd import synth
+        inputs = tempfile.mkdtemp(prefix='mc_proj_')
+        codes = synth.genome()
+        table, qual = synth.make_table(int(float(args[args.index('--rows') + 1])), seed=5, codes=codes)
+        synth.write_inputs(table, qual, codes, inputs)
+        del table
+    else:
+        inputs = args[args.index('--inputs') + 1]
     runs = int(args[args.index('--runs') + 1]) if '--runs' in args else 3
     reader = args[args.index('--reader') + 1] if '--reader' in args else 'pread'
     real_stdout = sys.stdout
