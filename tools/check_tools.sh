@@ -34,6 +34,7 @@ run file_to_file_dense  python3 tools/file_to_file.py 2e6 --runs 2 --motif A
 run config5             python3 tools/config5.py 2000000 --runs 2
 run project_scaling     python3 tools/project_scaling.py --rows 2e6 --parts 2 --runs 2
 run pack_probe          tools/pack_probe.sh --events 2e7 --steps 20
+run side_probe          python3 tools/side_probe.py 2e7
 run fused_phase_counters tools/fused_phase_counters.sh 2e7
 run fuzz_gpu            python3 tests/tools/fuzz_gpu.py 5 71000000
 run fuzz_tables_dense   python3 tests/tools/fuzz_tables.py 20 72000000 dense
