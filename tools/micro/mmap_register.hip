@@ -20,10 +20,20 @@
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { printf("usage: mmap_register FILE [window MB] [threads] [max GB]\n"); return 2; }
+    // usage: mmap_register [FILE [window MB] [threads] [max GB]]; without a file: 1 GB of zeros written to /tmp first
+    char own[64] = "";
+    if (argc < 2) {
+        snprintf(own, sizeof own, "/tmp/mc_mmap_register_%d.bin", (int)getpid());
+        FILE *f = fopen(own, "wb");
+        if (!f) { printf("cannot write %s\n", own); return 1; }
+        std::vector<char> block(16 << 20, 1);
+        for (int i = 0; i < 64; ++i) fwrite(block.data(), 1, block.size(), f);
+        fclose(f);
+    }
+    const char *path = argc < 2 ? own : argv[1];
     const size_t window = (size_t)(argc > 2 ? atoi(argv[2]) : 128) << 20;
     const int T = argc > 3 ? atoi(argv[3]) : 2;
-    const int fd = open(argv[1], O_RDONLY);
+    const int fd = open(path, O_RDONLY);
     if (fd < 0) { perror("open"); return 1; }
     struct stat sb;
     fstat(fd, &sb);
@@ -140,5 +150,6 @@ int main(int argc, char **argv) {
         const double dt = now() - t0;
         printf(" \"pread_one_window_ahead\": {\"seconds\": %.4f, \"GBps\": %.2f}}\n", dt, gb / dt);
     }
+    if (own[0]) unlink(own);
     return 0;
 }
