@@ -17,8 +17,11 @@
 //     weights: Glorot-uniform from a counter-based generator -- both defined in oracle/mlp_fit_oracle.py, which restates
 //     the same optimiser on the CPU and is pinned against scikit-learn's own runs.
 //
-// The kernel is latency-bound by construction (one workgroup per fit; the fits of a training job run side by side on
-// different CUs); fp64 throughout, like scikit-learn.
+// The kernel is bound by what ONE wave per SIMD can issue in fp64 (one workgroup per fit; the fits of a training job run side by
+// side on different CUs): per row and wave ~300 instructions -- the two units' dot products and tanh (written out: 27 instructions
+// against the library's ~100), the wave sum, exp and log of the output, the backward sums.  Two rows at a time (their chains side by
+// side) and the written-out tanh took config 5's six fits from 0.71 to 0.49 s; eight waves per fit halve a lane's registers and
+// spill (0.75 s), three / four rows at a time: 0.49 / 0.53.  fp64 throughout, like scikit-learn.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,12 +46,22 @@ hipStream_t mc_internal_stream(const mc_ctx *c);
 
 namespace {
 
-constexpr int FW = 4;                  // waves per fit
+#ifndef MC_FIT_WAVES
+#define MC_FIT_WAVES 4
+#endif
+constexpr int FW = MC_FIT_WAVES;       // waves per fit: one per SIMD -- a lane holds 100 doubles of state (parameters, both moments, gradients): eight
+                                       // waves halve the registers a lane may have and spill (measured: 747 ms for config 5's six fits against 509)
 constexpr int FT = FW * 64;
+#ifndef MC_FIT_ROWS
+#define MC_FIT_ROWS 2
+#endif
+constexpr int FROWS = MC_FIT_ROWS;     // rows a wave takes at a time (their fp64 chains side by side)
 constexpr int DMAX = MC_MAX_K + 1;     // inputs: k slot means + read quality
 constexpr int HMAX = 128;              // two hidden units per lane
 constexpr int NC = 2 * (DMAX + 2);     // gradient components per lane: W1[DMAX][2], b1[2], W2[2]
 constexpr int NP = NC + 2;             // + the wave's loss sum and output-bias gradient
+constexpr int NPH = NP / 2;            // ... exchanged through LDS in two halves (FW x NPH x 64 doubles: 48 KB)
+static_assert(NP % 2 == 0, "two halves");
 
 struct FitJob {
     long long tr_off, n_tr, va_off, n_va;
@@ -107,6 +120,34 @@ __device__ __forceinline__ uint32_t feistel_perm(uint32_t i, uint32_t n, uint32_
     }
 }
 
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)) written out (the scheme of mc_classify.hip's fp64 forward, where it is derived: magic-number
+// rounding, a degree-11 polynomial fitted at Chebyshev nodes, 2^n from one integer instruction, the hardware's reciprocal estimate and
+// two Newton steps): 25 instructions against the library's ~100 with their branches; absolute error < 1e-15.
+__device__ __forceinline__ double fit_tanh(double x) {
+    const double t = fmin(fabs(x), 87.5);
+    const double tt = fma(t, 2.8853900817779268, 6755399441055744.0);
+    const double n = tt - 6755399441055744.0;
+    double r = fma(n, -0.3465735901845619, t);
+    r = fma(n, -9.541074646352939e-11, r);
+    double p = 5.1405589494805136e-05;
+    p = fma(p, r, 0.0002828297056809958);
+    p = fma(p, r, 0.0014109321451518497);
+    p = fma(p, r, 0.00634918945176432);
+    p = fma(p, r, 0.02539682542470863);
+    p = fma(p, r, 0.08888888907016779);
+    p = fma(p, r, 0.26666666666656197);
+    p = fma(p, r, 0.6666666666659861);
+    p = fma(p, r, 1.3333333333333335);
+    p = fma(p, r, 2.0000000000000004);
+    p = fma(p, r, 2.0);
+    p = fma(p, r, 1.0);
+    const double d = fma(p, __hiloint2double((__double2loint(tt) + 1023) << 20, 0), 1.0);      // e^{2t} + 1 >= 2
+    double q = __builtin_amdgcn_rcp(d);
+    q = fma(fma(-d, q, 1.0), q, q);
+    q = fma(fma(-d, q, 1.0), q, q);
+    return copysign(fma(-2.0, q, 1.0), x);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -115,8 +156,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    double(*s_part)[NP][64] = reinterpret_cast<double(*)[NP][64]>(s_raw);                   // [FW][NP][64]
-    double *s_x = reinterpret_cast<double *>(s_raw + sizeof(double) * FW * NP * 64);        // [batch * d]
+    double(*s_part)[NPH][64] = reinterpret_cast<double(*)[NPH][64]>(s_raw);                 // [FW][NPH][64]
+    double *s_x = reinterpret_cast<double *>(s_raw + sizeof(double) * FW * NPH * 64);       // [batch * d]
     uint8_t *s_y = reinterpret_cast<uint8_t *>(s_x + (size_t)A.batch * A.d);                // [batch]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,61 +246,93 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
             double g_w1[DMAX][2], g_b1[2] = {0.0, 0.0}, g_w2[2] = {0.0, 0.0}, g_b2 = 0.0, loss = 0.0;
 #pragma unroll
             for (int i = 0; i < DMAX; ++i) g_w1[i][0] = g_w1[i][1] = 0.0;
-            for (int s = wave; s < nb; s += FW) {
-                double x[DMAX];
+            // (FROWS rows at a time: a wave is alone on its SIMD, and one row is a handful of dependent fp64 chains -- tanh, the wave
+            // sum, exp, log -- that leave it idle; the second row's chains run beside the first's.  The sums take the rows in the
+            // order they always had: w, w + FW, w + 2 FW, ...)
+            for (int s = wave; s < nb; s += FROWS * FW) {
+                int sr[FROWS];
 #pragma unroll
-                for (int i = 0; i < DMAX; ++i) x[i] = i < d ? s_x[s * d + i] : 0.0;
-                const double yy = (double)s_y[s];
-                double a[2];
+                for (int r = 0; r < FROWS; ++r) sr[r] = s + r * FW < nb ? s + r * FW : s;
+                double x[FROWS][DMAX], yy[FROWS], a[FROWS][2], part[FROWS];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    double z = bb1[j];
+                for (int r = 0; r < FROWS; ++r) {
 #pragma unroll
-                    for (int i = 0; i < DMAX; ++i) z += x[i] * w1[i][j];
-                    a[j] = valid[j] ? tanh(z) : 0.0;
+                    for (int i = 0; i < DMAX; ++i) x[r][i] = i < d ? s_x[sr[r] * d + i] : 0.0;
+                    yy[r] = (double)s_y[sr[r]];
                 }
-                const double out = b2 + wave_sum(a[0] * w2[0] + a[1] * w2[1]);
-                const double p = 1.0 / (1.0 + exp(-out));
-                const double pc = fmin(fmax(p, feps), 1.0 - feps);
-                loss -= yy > 0.0 ? log(pc) : log(1.0 - pc);
-                const double delta = p - yy;
-                g_b2 += delta;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    g_w2[j] += a[j] * delta;
-                    const double dh = delta * w2[j] * (1.0 - a[j] * a[j]);
-                    g_b1[j] += dh;
+                for (int r = 0; r < FROWS; ++r) {
 #pragma unroll
-                    for (int i = 0; i < DMAX; ++i) g_w1[i][j] += x[i] * dh;
+                    for (int j = 0; j < 2; ++j) {
+                        double z = bb1[j];
+#pragma unroll
+                        for (int i = 0; i < DMAX; ++i) z += x[r][i] * w1[i][j];
+                        a[r][j] = valid[j] ? fit_tanh(z) : 0.0;
+                    }
+                    part[r] = a[r][0] * w2[0] + a[r][1] * w2[1];
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+                    for (int r = 0; r < FROWS; ++r) part[r] += __shfl_xor(part[r], o);
+                }
+                double p[FROWS], term[FROWS];
+#pragma unroll
+                for (int r = 0; r < FROWS; ++r) {
+                    p[r] = 1.0 / (1.0 + exp(-(b2 + part[r])));
+                    const double pc = fmin(fmax(p[r], feps), 1.0 - feps);
+                    term[r] = yy[r] > 0.0 ? log(pc) : log(1.0 - pc);
+                }
+#pragma unroll
+                for (int r = 0; r < FROWS; ++r) {
+                    if (s + r * FW >= nb) break;
+                    loss -= term[r];
+                    const double delta = p[r] - yy[r];
+                    g_b2 += delta;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        g_w2[j] += a[r][j] * delta;
+                        const double dh = delta * w2[j] * (1.0 - a[r][j] * a[r][j]);
+                        g_b1[j] += dh;
+#pragma unroll
+                        for (int i = 0; i < DMAX; ++i) g_w1[i][j] += x[r][i] * dh;
+                    }
                 }
             }
-            // ---- the four waves' partial sums -> LDS -> every wave adds them in the same order ----
+            // ---- the waves' partial sums -> LDS -> every wave adds them in the same order; in two halves (the room) ----
+            double comp[NP];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int i = 0; i < DMAX; ++i) s_part[wave][(i * 2 + j)][lane] = g_w1[i][j];
-                s_part[wave][2 * DMAX + j][lane] = g_b1[j];
-                s_part[wave][2 * DMAX + 2 + j][lane] = g_w2[j];
+                for (int i = 0; i < DMAX; ++i) comp[i * 2 + j] = g_w1[i][j];
+                comp[2 * DMAX + j] = g_b1[j];
+                comp[2 * DMAX + 2 + j] = g_w2[j];
             }
-            s_part[wave][NC][lane] = loss;
-            s_part[wave][NC + 1][lane] = g_b2;
-            __syncthreads();
-            auto total = [&](int c) -> double {
-                double t = s_part[0][c][lane];
+            comp[NC] = loss;
+            comp[NC + 1] = g_b2;
 #pragma unroll
-                for (int w = 1; w < FW; ++w) t += s_part[w][c][lane];
-                return t;
-            };
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int c = 0; c < NPH; ++c) s_part[wave][c][lane] = comp[hf * NPH + c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NPH; ++c) {
+                    double t = s_part[0][c][lane];
+#pragma unroll
+                    for (int w = 1; w < FW; ++w) t += s_part[w][c][lane];
+                    comp[hf * NPH + c] = t;
+                }
+                __syncthreads();                  // LDS is rewritten by the other half / the next batch
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int i = 0; i < DMAX; ++i) g_w1[i][j] = total(i * 2 + j);
-                g_b1[j] = total(2 * DMAX + j);
-                g_w2[j] = total(2 * DMAX + 2 + j);
+                for (int i = 0; i < DMAX; ++i) g_w1[i][j] = comp[i * 2 + j];
+                g_b1[j] = comp[2 * DMAX + j];
+                g_w2[j] = comp[2 * DMAX + 2 + j];
             }
-            loss = total(NC);
-            g_b2 = total(NC + 1);
-            __syncthreads();                      // LDS is rewritten by the next batch
+            loss = comp[NC];
+            g_b2 = comp[NC + 1];
 
             double sq = w2[0] * w2[0] + w2[1] * w2[1];
 #pragma unroll
@@ -326,7 +399,7 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
             double z = bb1[j];
 #pragma unroll
             for (int i = 0; i < DMAX; ++i) z += (i < d ? A.X[sid * d + i] : 0.0) * w1[i][j];
-            a[j] = valid[j] ? tanh(z) : 0.0;
+            a[j] = valid[j] ? fit_tanh(z) : 0.0;
         }
         const double out = b2 + wave_sum(a[0] * w2[0] + a[1] * w2[1]);
         const double p = 1.0 / (1.0 + exp(-out));
@@ -368,7 +441,7 @@ extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, co
         mc_set_error("mc_mlp_fit: unsupported shape (inputs 1..%d, hidden 1..%d)", DMAX, HMAX);
         return -12;
     }
-    const size_t lds = sizeof(double) * FW * NP * 64 + (size_t)P->batch_size * P->n_in * 8 + (size_t)P->batch_size;
+    const size_t lds = sizeof(double) * FW * NPH * 64 + (size_t)P->batch_size * P->n_in * 8 + (size_t)P->batch_size;
     if (P->batch_size > FT || lds > 64 * 1024) {
         mc_set_error("mc_mlp_fit: batch size %d does not fit (max %d rows)", P->batch_size, FT);
         return -12;
