@@ -20,7 +20,8 @@
 // The kernel is bound by what ONE wave per SIMD can issue in fp64 (one workgroup per fit; the fits of a training job run side by
 // side on different CUs): per row and wave ~300 instructions -- the two units' dot products and tanh (written out: 27 instructions
 // against the library's ~100), the wave sum, exp and log of the output, the backward sums.  Two rows at a time (their chains side by
-// side) and the written-out tanh took config 5's six fits from 0.71 to 0.49 s; eight waves per fit halve a lane's registers and
+// side), exp and log once for the two rows (lane r takes row r's output) and the written-out tanh took config 5's six fits from
+// 0.71 to 0.45 s; eight waves per fit halve a lane's registers and
 // spill (0.75 s), three / four rows at a time: 0.49 / 0.53.  fp64 throughout, like scikit-learn.
 #include <hip/hip_runtime.h>
 
@@ -276,12 +277,21 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
 #pragma unroll
                     for (int r = 0; r < FROWS; ++r) part[r] += __shfl_xor(part[r], o);
                 }
+                // (after the wave sum every lane holds every row's output: lane r takes row r's, so that exp, the division and log --
+                // a third of a row's instructions -- are issued once for the FROWS rows, not once per row; then back to all lanes)
                 double p[FROWS], term[FROWS];
+                {
+                    double my_part = part[0], my_y = yy[0];
 #pragma unroll
-                for (int r = 0; r < FROWS; ++r) {
-                    p[r] = 1.0 / (1.0 + exp(-(b2 + part[r])));
-                    const double pc = fmin(fmax(p[r], feps), 1.0 - feps);
-                    term[r] = yy[r] > 0.0 ? log(pc) : log(1.0 - pc);
+                    for (int r = 1; r < FROWS; ++r) { my_part = lane == r ? part[r] : my_part; my_y = lane == r ? yy[r] : my_y; }
+                    const double my_p = 1.0 / (1.0 + exp(-(b2 + my_part)));
+                    const double pc = fmin(fmax(my_p, feps), 1.0 - feps);
+                    const double my_term = my_y > 0.0 ? log(pc) : log(1.0 - pc);
+#pragma unroll
+                    for (int r = 0; r < FROWS; ++r) {
+                        p[r] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_p), r), __builtin_amdgcn_readlane(__double2loint(my_p), r));
+                        term[r] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_term), r), __builtin_amdgcn_readlane(__double2loint(my_term), r));
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < FROWS; ++r) {
