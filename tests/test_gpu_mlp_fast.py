@@ -99,3 +99,38 @@ def test_fast_forward_on_inputs_far_from_the_training_range():
         H.assert_records_equal(d.wait(), orc, 6, prob_tol=1e-6)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize('k,hidden,n_models', [(4, 37, 3), (8, 100, 4), (5, 1, 2), (7, 64, 1), (6, 51, 4)])
+def test_fast_forward_other_shapes(k, hidden, n_models):
+    """The general instance (k2_mlp<0, true>: the number of inputs at run time) and the shapes the pairs of units have to get right:
+    an odd hidden layer (a padding unit of zeros), a layer of one unit, quarters of uneven size, one to four sub-models -- random
+    weights of the size a trained model has, a dense table, labels and printed probabilities as the fp64 oracle's."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.model_io import MLPWeights
+    rng = np.random.default_rng(1000 * k + hidden)
+    codes = synth.genome(length=300000, seed=k)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(400000, seed=500 + k, codes=codes)
+    arrays = ref.device_arrays()
+    weights = [MLPWeights(rng.normal(0, 0.6, (k + 1, hidden)), rng.normal(0, 0.5, hidden), rng.normal(0, 0.8, hidden), rng.normal(0, 0.3, 1))
+               for _ in range(n_models)]
+    soc = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate('ACGTM'):
+        soc[ord(c)] = i % n_models
+    orc = H.oracle_records(table, arrays, qual, k, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, k)
+    assert int(np.isfinite(orc.prob[:orc.n]).sum()) > 20000
+    d = Device(0)
+    try:
+        d.set_reference(arrays)
+        d.set_mlp(weights, soc)
+        d.upload_table_async(table, qual)
+        d.run_async(k, 0, 0.0, score=True)
+        H.assert_records_equal(d.wait(), orc, k, prob_tol=1e-6)
+        assert d.last_pass_info()[0] > 0                         # (the fused dense pass: the stretches made of pieces)
+        rec = d.extract(k, 0, 0.0, score=True)                   # (the synchronous path: the scan + emit pair, stretches of records)
+        H.assert_records_equal(rec, orc, k, prob_tol=1e-6)
+    finally:
+        d.close()
