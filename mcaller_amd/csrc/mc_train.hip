@@ -2,8 +2,10 @@
 //
 // The reference fits scikit-learn's MLPClassifier(hidden_layer_sizes=(100), alpha=0.001, activation='tanh') on the
 // labelled feature rows the hot path produced (train_model.py:47,:81-100) and scores it with 5-fold GroupKFold
-// (train_model.py:62-65,:92): six independent fits per sub-model.  Here every fit is ONE workgroup that runs the whole
-// Adam optimisation on chip:
+// (train_model.py:62-65,:92): six independent fits per sub-model.  Here every fit is four workgroups that run the whole Adam
+// optimisation on chip and meet once per batch (a counter in global memory, release / acquire fences around it, the waves' partial
+// sums in global memory in two sets taken in turn; a workgroup that waits for seconds fails the call instead of hanging); what ONE
+// workgroup does:
 //
 //   * four waves; lane l of every wave owns hidden units l and l+64 (H <= 128): their input weights, bias, output weight,
 //     both Adam moments and the gradient accumulators live in that lane's registers -- nothing is re-read per step;
@@ -17,12 +19,12 @@
 //     weights: Glorot-uniform from a counter-based generator -- both defined in oracle/mlp_fit_oracle.py, which restates
 //     the same optimiser on the CPU and is pinned against scikit-learn's own runs.
 //
-// The kernel is bound by what ONE wave per SIMD can issue in fp64 (one workgroup per fit; the fits of a training job run side by
-// side on different CUs): per row and wave ~300 instructions -- the two units' dot products and tanh (written out: 27 instructions
-// against the library's ~100), the wave sum, exp and log of the output, the backward sums.  Two rows at a time (their chains side by
-// side), exp and log once for the two rows (lane r takes row r's output) and the written-out tanh took config 5's six fits from
-// 0.71 to 0.45 s, fused multiply-adds to 0.41; eight waves per fit halve a lane's registers and
-// spill (0.75 s), three / four rows at a time: 0.49 / 0.53.  fp64 throughout, like scikit-learn.
+// A workgroup is bound by what ONE wave per SIMD can issue in fp64: per row and wave ~300 instructions -- the two units' dot products
+// and tanh (written out: 27 instructions against the library's ~100), the wave sum, exp and log of the output, the backward sums.
+// Config 5's six fits (9 244 rows, 200 epochs, 9 400 Adam steps each), one workgroup per fit: 0.71 s; the written-out tanh, two
+// rows at a time per wave (their chains side by side), exp and log once for the two rows (lane r takes row r's output): 0.45; fused
+// multiply-adds: 0.41; FOUR workgroups per fit, on one XCD, meeting once per batch: **0.25 s**.  (Eight waves per workgroup halve a
+// lane's registers and spill: 0.75 s; three / four rows at a time: 0.49 / 0.53.)  fp64 throughout, like scikit-learn.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -61,6 +63,10 @@ constexpr int FT = FW * 64;
 #define MC_FIT_ROWS 2
 #endif
 constexpr int FROWS = MC_FIT_ROWS;     // rows a wave takes at a time (their fp64 chains side by side)
+#ifndef MC_FIT_GROUPS
+#define MC_FIT_GROUPS 4                // workgroups per fit (config 5's six fits: 1 / 2 / 4 / 8 / 16 workgroups: 0.42 / 0.29 / 0.25 / 0.31-0.34 / 0.95 s --
+                                       // the meeting costs ~10 us per batch and grows with the workgroups that have to arrive)
+#endif
 constexpr int DMAX = MC_MAX_K + 1;     // inputs: k slot means + read quality
 constexpr int HMAX = 128;              // two hidden units per lane
 constexpr int NC = 2 * (DMAX + 2);     // gradient components per lane: W1[DMAX][2], b1[2], W2[2]
@@ -85,6 +91,11 @@ struct FitArgs {
     double *loss_curve;      // [n_jobs * max_iter]
     int32_t *n_iter;         // [n_jobs]
     long long *val_correct;  // [n_jobs]
+    int G;                   // workgroups per fit
+    int n_jobs, by_xcd;      // fits; fit j = workgroups j, j + 8, ... (n_jobs <= 8) instead of j G .. j G + G - 1
+    double *xpart;           // [n_jobs][2][G * FW][NP][64]: the waves' partial sums of a batch (two sets, taken in turn)
+    unsigned *bar;           // [n_jobs]: workgroups that have written their partial sums, over all batches so far
+    int *failed;             // a workgroup waited for the others for seconds: the call fails
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -166,7 +177,15 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
     uint8_t *s_y = reinterpret_cast<uint8_t *>(s_x + (size_t)A.batch * A.d);                // [batch]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int job = blockIdx.x;
+    // G workgroups per fit: the rows of a batch are dealt to their G x FW waves, every workgroup holds the parameters and takes the
+    // same Adam step from the same totals (added in the same order everywhere: the results do not depend on which wave ran when)
+    // (the workgroups of a fit sit on ONE XCD when there are at most eight fits: consecutive workgroup numbers go to the XCDs in turn,
+    // so fit j takes the numbers j, j + 8, j + 16, ... -- what they exchange stays in that XCD's L2)
+    const int G = A.G;
+    const int job = A.by_xcd ? (int)(blockIdx.x % 8) : (int)(blockIdx.x / G), part = A.by_xcd ? (int)(blockIdx.x / 8) : (int)(blockIdx.x % G);
+    if (job >= A.n_jobs) return;
+    const int gw = part * FW + wave, GW = G * FW;
+    unsigned step = 0;                          // batches so far (what the fit's workgroups count at their meeting point)
     const FitJob J = A.jobs[job];
     const int d = A.d, H = A.H;
     const uint32_t n = (uint32_t)J.n_tr;
@@ -254,10 +273,10 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
             // (FROWS rows at a time: a wave is alone on its SIMD, and one row is a handful of dependent fp64 chains -- tanh, the wave
             // sum, exp, log -- that leave it idle; the second row's chains run beside the first's.  The sums take the rows in the
             // order they always had: w, w + FW, w + 2 FW, ...)
-            for (int s = wave; s < nb; s += FROWS * FW) {
+            for (int s = gw; s < nb; s += FROWS * GW) {
                 int sr[FROWS];
 #pragma unroll
-                for (int r = 0; r < FROWS; ++r) sr[r] = s + r * FW < nb ? s + r * FW : s;
+                for (int r = 0; r < FROWS; ++r) sr[r] = s + r * GW < nb ? s + r * GW : s;
                 double x[FROWS][DMAX], yy[FROWS], a[FROWS][2], part[FROWS];
 #pragma unroll
                 for (int r = 0; r < FROWS; ++r) {
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
                 }
 #pragma unroll
                 for (int r = 0; r < FROWS; ++r) {
-                    if (s + r * FW >= nb) break;
+                    if (s + r * GW >= nb) break;
                     loss -= term[r];
                     const double delta = p[r] - yy[r];
                     g_b2 += delta;
@@ -324,19 +343,59 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
             }
             comp[NC] = loss;
             comp[NC + 1] = g_b2;
+            if (G == 1) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+                for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-                for (int c = 0; c < NPH; ++c) s_part[wave][c][lane] = comp[hf * NPH + c];
+                    for (int c = 0; c < NPH; ++c) s_part[wave][c][lane] = comp[hf * NPH + c];
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < NPH; ++c) {
+                        double t = s_part[0][c][lane];
+#pragma unroll
+                        for (int w = 1; w < FW; ++w) t += s_part[w][c][lane];
+                        comp[hf * NPH + c] = t;
+                    }
+                    __syncthreads();                  // LDS is rewritten by the other half / the next batch
+                }
+            } else {
+                // ---- the workgroups of the fit: every WAVE writes its sums, the workgroups meet, wave w of every workgroup adds up a
+                // quarter of the components over all G x FW waves in their order, the quarters go round through LDS ----
+                static_assert(NP % FW == 0 && NP <= FW * NPH, "a share of the components per wave; the totals fit the LDS block");
+                constexpr int NPW = NP / FW;
+                double *mine = A.xpart + ((((size_t)job * 2 + (step & 1u)) * GW + gw) * NP) * 64;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) mine[c * 64 + lane] = comp[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __syncthreads();
+                if (tid == 0) {
+                    atomicAdd(&A.bar[job], 1u);
+                    const unsigned want = (step + 1u) * (unsigned)G;
+                    for (long spin = 0; ; ++spin) {
+                        if ((int)(__atomic_load_n(&A.bar[job], __ATOMIC_RELAXED) - want) >= 0) break;
+                        if (spin > (1l << 24) || __atomic_load_n(A.failed, __ATOMIC_RELAXED)) { atomicExch(A.failed, 1); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (__atomic_load_n(A.failed, __ATOMIC_RELAXED)) return;
+                const double *all = A.xpart + (((size_t)job * 2 + (step & 1u)) * GW) * NP * 64;
+                double t[NPW];
+#pragma unroll
+                for (int c = 0; c < NPW; ++c) t[c] = all[(wave * NPW + c) * 64 + lane];
+                for (int w2 = 1; w2 < GW; ++w2) {
+#pragma unroll
+                    for (int c = 0; c < NPW; ++c) t[c] += all[((size_t)w2 * NP + wave * NPW + c) * 64 + lane];
+                }
+                double(*s_tot)[64] = reinterpret_cast<double(*)[64]>(s_raw);            // [NP][64], over the waves' block
+#pragma unroll
+                for (int c = 0; c < NPW; ++c) s_tot[wave * NPW + c][lane] = t[c];
                 __syncthreads();
 #pragma unroll
-                for (int c = 0; c < NPH; ++c) {
-                    double t = s_part[0][c][lane];
-#pragma unroll
-                    for (int w = 1; w < FW; ++w) t += s_part[w][c][lane];
-                    comp[hf * NPH + c] = t;
-                }
-                __syncthreads();                  // LDS is rewritten by the other half / the next batch
+                for (int c = 0; c < NP; ++c) comp[c] = s_tot[c][lane];
+                __syncthreads();                      // (the next batch's totals go to the same place)
+                ++step;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -377,7 +436,7 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
             adam(b2, m_b2, v_b2, g_b2 * inv_nb);
         }
         const double epoch_loss = acc / (double)n;
-        if (tid == 0) A.loss_curve[(size_t)job * A.max_iter + epoch] = epoch_loss;
+        if (tid == 0 && part == 0) A.loss_curve[(size_t)job * A.max_iter + epoch] = epoch_loss;
         n_epochs = epoch + 1;
         key = (uint32_t)(splitmix64((J.seed ^ 0xA5A5A5A55A5A5A5Aull) + (unsigned long long)(epoch + 1)) & 0xFFFFFFFFull);
         if (epoch_loss > best - A.tol) ++no_improve;
@@ -387,7 +446,7 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
     }
 
     // ---- results ----
-    if (wave == 0) {
+    if (wave == 0 && part == 0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (valid[j]) {
@@ -405,7 +464,7 @@ __global__ __launch_bounds__(FT) void k4_mlp_fit(FitArgs A) {
     }
     // held-out rows: accuracy as scikit-learn scores it (predict: p > 0.5)
     long long correct = 0;
-    for (long long s = wave; s < J.n_va; s += FW) {
+    for (long long s = gw; s < J.n_va; s += GW) {
         const long long sid = A.va_idx[J.va_off + s];
         double a[2];
 #pragma unroll
@@ -487,6 +546,12 @@ extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, co
     FitJob *djobs;
     int32_t *dtr, *dva, *dnit;
     long long *dcorrect;
+    double *dxpart;
+    unsigned *dbar;
+    int *dfailed;
+    // workgroups per fit: four (the rows of a batch of 200 over 16 waves), one for small batches or on request
+    static const int groups_env = getenv("MCALLER_FIT_WGS") ? atoi(getenv("MCALLER_FIT_WGS")) : 0;
+    const int G = std::max(1, std::min(16, groups_env > 0 ? groups_env : (P->batch_size >= 64 ? MC_FIT_GROUPS : 1)));
     const size_t per_job = (size_t)d * H + 2 * (size_t)H + 1;
     int rc = 0;
     rc |= to_device(pool, &dX, X, (size_t)n_samples * d, st);
@@ -502,13 +567,17 @@ extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, co
     rc |= to_device<double>(pool, &dcurve, nullptr, (size_t)n_jobs * P->max_iter, st);
     rc |= to_device<int32_t>(pool, &dnit, nullptr, (size_t)n_jobs, st);
     rc |= to_device<long long>(pool, &dcorrect, nullptr, (size_t)n_jobs, st);
+    rc |= to_device<double>(pool, &dxpart, nullptr, (size_t)n_jobs * 2 * G * FW * NP * 64, st);
+    rc |= to_device<unsigned>(pool, &dbar, nullptr, (size_t)n_jobs, st);
+    rc |= to_device<int>(pool, &dfailed, nullptr, 1, st);
     if (rc) { cleanup(); return -10; }
     A.X = dX; A.y = dy; A.jobs = djobs; A.tr_idx = dtr; A.va_idx = dva;
     A.d = d; A.H = H; A.batch = P->batch_size; A.max_iter = P->max_iter; A.n_iter_no_change = P->n_iter_no_change;
     A.shuffle = P->shuffle;
     A.alpha = P->alpha; A.lr = P->lr_init; A.beta1 = P->beta1; A.beta2 = P->beta2; A.eps = P->epsilon; A.tol = P->tol;
+    A.G = G; A.n_jobs = n_jobs; A.by_xcd = (G > 1 && n_jobs <= 8) ? 1 : 0; A.xpart = dxpart; A.bar = dbar; A.failed = dfailed;
     A.init = dinit; A.W1 = dW1; A.b1 = db1; A.W2 = dW2; A.b2 = db2; A.loss_curve = dcurve; A.n_iter = dnit; A.val_correct = dcorrect;
-    hipLaunchKernelGGL(k4_mlp_fit, dim3((unsigned)n_jobs), dim3(FT), lds, st, A);
+    hipLaunchKernelGGL(k4_mlp_fit, dim3((unsigned)(A.by_xcd ? 8 * G : n_jobs * G)), dim3(FT), lds, st, A);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(W1, dW1, (size_t)n_jobs * d * H * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(b1, db1, (size_t)n_jobs * H * 8, hipMemcpyDeviceToHost, st);
@@ -517,10 +586,16 @@ extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, co
     if (e == hipSuccess) e = hipMemcpyAsync(loss_curve, dcurve, (size_t)n_jobs * P->max_iter * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(n_iter, dnit, (size_t)n_jobs * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(val_correct, dcorrect, (size_t)n_jobs * 8, hipMemcpyDeviceToHost, st);
+    int fit_failed = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&fit_failed, dfailed, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess) {
         mc_set_error("mc_mlp_fit failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    if (fit_failed) {
+        mc_set_error("mc_mlp_fit: the %d workgroups of a fit did not meet (MCALLER_FIT_WGS=1 runs a fit in one workgroup)", G);
         return -10;
     }
     return 0;
