@@ -2,7 +2,7 @@
 
 `NN` (the default, train_model.py:47) is fitted on the GPU: class balancing (:81-86), 5-fold GroupKFold by context
 (:62-65, :92) and the final fit (:100) are six independent runs of the same optimiser, launched together as one
-`mc_mlp_fit` call (one workgroup per fit, mcaller_amd/csrc/mc_train.hip).  The optimiser is scikit-learn's
+`mc_mlp_fit` call (four workgroups per fit, mcaller_amd/csrc/mc_train.hip).  The optimiser is scikit-learn's
 MLPClassifier recipe (Adam, tanh, alpha=0.001, batches of min(200, n), tol/n_iter_no_change stopping); like the
 reference's `random_state=None` fit, two runs differ unless MCALLER_SEED is set.
 

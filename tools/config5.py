@@ -146,7 +146,7 @@ def main():
                                        train_classifier_s=med_of(train_runs, 'train_classifier_s'),
                                        mlp_fit_ms=med_of(train_runs, 'mlp_fit_s') * 1e3,
                                        mlp_fit_what='six fits (5 GroupKFold folds + the final one) of %s balanced rows in ONE mc_mlp_fit call '
-                                                    '(k4_mlp_fit, a workgroup per fit); Adam iterations per fit: %s' % (
+                                                    '(k4_mlp_fit, four workgroups per fit); Adam iterations per fit: %s' % (
                                                         train_runs[-1]['fit_rows'], train_runs[-1]['fit_iters']),
                                        training_rows=train_runs[-1]['rows_written'], events_per_s=n_rows / med_of(train_runs, 'feature_matrix_s'),
                                        stream_last_run=train_runs[-1]['stream'], seconds_all=[r['seconds'] for r in train_runs]),
