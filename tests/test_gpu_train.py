@@ -70,3 +70,24 @@ def test_small_shapes(dev):
         want = mo.fit(X, y, hidden=h, max_iter=8, seed=5)
         np.testing.assert_allclose(got['loss_curve'], want['loss_curve'], rtol=1e-8)
         np.testing.assert_allclose(got['W2'], want['W2'], rtol=1e-6, atol=1e-9)
+
+
+def test_more_fits_than_xcds_and_repeatability(dev):
+    """Eleven fits in one call (more than the eight a launch spreads over the XCDs one per XCD: the plain numbering of a fit's
+    workgroups) against the oracle, and the same call again: the workgroups of a fit add their sums in a fixed order, so a repeated
+    call gives the same bytes whichever workgroup arrived first."""
+    z = np.load(os.path.join(TRAIN, 'n1000_h100.npz'))
+    X, y = z['X'], z['y']
+    n = len(y)
+    jobs = [(np.nonzero(np.arange(n) % 11 != f)[0], np.nonzero(np.arange(n) % 11 == f)[0]) for f in range(11)]
+    seeds = list(range(21, 32))
+    got = dev.mlp_fit(X, y, jobs, hidden=100, max_iter=12, seeds=seeds)
+    again = dev.mlp_fit(X, y, jobs, hidden=100, max_iter=12, seeds=seeds)
+    for j in (0, 5, 10):
+        want = mo.fit(X[jobs[j][0]], y[jobs[j][0]], hidden=100, max_iter=12, seed=seeds[j])
+        np.testing.assert_allclose(got[j]['loss_curve'], want['loss_curve'], rtol=1e-7)
+        np.testing.assert_allclose(got[j]['W1'], want['W1'], rtol=1e-5, atol=1e-7)
+    for j in range(11):
+        assert np.array_equal(got[j]['W1'], again[j]['W1']) and np.array_equal(got[j]['loss_curve'], again[j]['loss_curve'])
+    # (the library reads MCALLER_FIT_WGS once per process: other group sizes are exercised by tools/config5.py runs under that
+    # variable -- profiles/README.md -- and by the build macro MC_FIT_GROUPS)
