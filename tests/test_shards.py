@@ -128,12 +128,12 @@ def test_bench_starts_its_own_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'bench.py itself'
     # both legs' schema: the weak leg is the contract's keys, the strong leg (BASELINE.json configs[3]: ONE file through
-    # `mCaller --gpus N --bed`) a top-level object of its own
-    assert line['scaling'] == 'weak' and {'value', 'ms_per_step', 'ms_per_step_steady', 'metric', 'unit'} <= set(line)
+    # `mCaller --gpus N --bed`) a top-level object of its own -- summarised; its phases and workers are in the details file
+    assert line['scaling'] == 'weak' and {'value', 'ms_per_step', 'ms_per_step_steady', 'ms_per_step_fp64_mlp', 'metric', 'unit', 'dtype',
+                                          'roofline', 'cpu_baseline', 'vs_baseline', 'config'} <= set(line)
+    assert 'f32' in line['dtype'] and 'f64' in line['dtype']          # (the classifier's hidden layer is fp32: the line says so)
     strong = line['strong_scaling']
     assert strong['scaling'] == 'strong' and strong['n_gpus'] == 2
-    assert {'calls_per_s', 'events_per_s', 'seconds_median', 'seconds_first_run', 'site_reduction', 'workers', 'rows', 'phases_s',
-            'diffs_equal_the_one_gpu_run', 'bed_rows'} <= set(strong)
     r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--gpus', '1', '--dry-ranks'], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])['n_gpus'] == 1
@@ -167,3 +167,42 @@ def test_site_counts_of_the_workers_are_combined_on_the_host_when_the_collective
     host = [dict(own=o, reduced=None, collective_done=False, err=None) for o in own]
     got = combine_site_counts(host)
     assert all(np.array_equal(g, w) for g, w in zip(got[:3], summed))
+
+
+def test_bench_line_is_small_strict_json():
+    """The driver keeps the tail of stdout: round 5's 20.8 KB line went unparsed.  The contract line is strict JSON (no NaN /
+    Infinity), under 6000 characters, and carries the contract's keys + roofline + cpu_baseline -- checked on the dry-run line
+    and on the compaction of the largest full results on record (round 5's lines, 20 KB each, and this round's details)."""
+    import glob
+    import json
+    import bench
+
+    def strict(text):
+        return json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError('not strict JSON: ' + c)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(H.REPO, 'bench.py'), '--dry-ranks'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_lines = r.stdout.splitlines()
+    assert len(out_lines) == 1 and len(out_lines[0]) < bench.LINE_LIMIT
+    strict(out_lines[0])
+    fulls = sorted(glob.glob(os.path.join(H.REPO, 'profiles', 'r05_bench*.json')) + glob.glob(os.path.join(H.REPO, 'profiles', 'r06_bench*details*.json')))
+    assert len(fulls) >= 4
+    for path in fulls:
+        full = json.load(open(path))
+        full['poison'] = float('nan')
+        full['roofline']['traffic_per_kernel'] = {'k%d' % i: 'x' * 100 for i in range(100)}          # (whatever a leg grows)
+        text = json.dumps(bench.contract_line(full))
+        line = strict(text)
+        assert len(text) < bench.LINE_LIMIT, (path, len(text))
+        assert {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'} <= set(line), path
+        assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(line['roofline']), path
+        assert 'workload' in line['config'] and isinstance(line['value'], float)
+        if line['cpu_baseline']:
+            assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline']), path
+    # a leg that balloons is shed before the contract's keys are
+    full = json.load(open(fulls[0]))
+    full['config']['workload'] = 'w' * 3000
+    full['cpu_baseline_reference_like']['cpu_model'] = 'c' * 3500
+    text = json.dumps(bench.contract_line(full))
+    assert len(text) < bench.LINE_LIMIT and 'roofline' in json.loads(text) and 'cpu_baseline' in json.loads(text)
