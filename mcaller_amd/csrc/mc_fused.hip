@@ -196,6 +196,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ uint16_t s_heavy[4 * F_HEAVY];        // per wave: its runs of more than one event
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
+    __shared__ unsigned s_over;                 // Counters.overflow as the workgroup's first wave saw it: ONE answer for all waves
     __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
     __shared__ int4 s_wfirst[F_THREADS / 64];   // ... its first one: (row, position, first row of its block that is in a run); row -1: none
     const DevTable &T = A.T;
@@ -232,7 +233,10 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         qp0 = T.pos[jq];
         qx0 = T.idx[jq];
     }
-    const unsigned overflow = A.cnt->overflow;   // (a piece ran out of room: the pass is repeated, nobody reads what the others write)
+    // (a piece ran out of room: the pass is repeated, nobody reads what the others write.  Read by the first wave only and
+    // handed to the others through LDS: other workgroups set it while this one runs, and waves that saw different values would
+    // part ways in front of the barriers)
+    const unsigned overflow = wave == 0 ? *reinterpret_cast<volatile unsigned int *>(&A.cnt->overflow) : 0u;
     const int bfrom = T.tile_nb[h0 / TILE];
     // the name blocks that overlap the staged rows: the first wave looks at the 64 blocks from the one the staged rows' tile
     // began in, all at once; the whole descriptor, 64 bytes in four loads, and the block's segment
@@ -277,11 +281,10 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (over && at < F_MAXB) s_blk[at] = fb;
         if (lane <= F_MAXB) s_bfirst[lane] = -1;
         if (lane < (FR + 63) / 64 + 2) s_cnt[lane] = 0;
-        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; }
+        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; s_over = overflow; }
     }
     asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w), "+v"(ea.x), "+v"(ea.y), "+v"(ea.z), "+v"(ea.w), "+v"(eb.x), "+v"(eb.y), "+v"(eb.z), "+v"(eb.w),
                       "+v"(f4), "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(qp0), "+v"(qx0));
-    if (overflow) return;
     int rp[4] = {p4.x, p4.y, p4.z, p4.w}, rd[4] = {ea.x - ea.y, ea.z - ea.w, eb.x - eb.y, eb.z - eb.w};
     [[maybe_unused]] const int rx[4] = {x4.x, x4.y, x4.z, x4.w};
     uint32_t nbits = 0;                          // bit e: the thread's row e is filtered ('N' model k-mer) or not staged
@@ -292,6 +295,9 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (!staged) { rp[e] = 0; rd[e] = 0; }
     }
     lds_barrier();
+    // A first pass goes on even so: its rows have to be VALIDATED by this pass -- the repeat is planned as a later pass over a
+    // validated table (TableSlot.passes) and classifies on the flags this pass leaves complete
+    if (!VALIDATE && s_over) return;
     FD_STAMP(1);
     FD_STOP_AFTER(1);
     const int nblk = s_nblk;
@@ -535,6 +541,14 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
                     if (c >= s0 && c < cend && c < s1) {
                         const Closed cl = closed_by(A, c, B.id, 0);
                         if (cl.kind) { e1.kind = (uint8_t)cl.kind; e1.r = cl.r; e1.cr = c; e1.m = cl.m; e1.nb = cl.nb; e1.ns = 1; }
+                    } else if (c < s0 && B.lb < 0 && fr >= 0) {
+                        // The block's tested rows begin in front of the staged rows and nothing but 'N' rows of it is staged in front
+                        // of its first run (a read across a gap of the model: FH and more filtered rows in a row): that run's head
+                        // closes the window of the unfiltered row before the gap (:179 skips the 'N' rows), which the run table
+                        // does not hold.  (The '+' window of R5 in that place is e2's, below)
+                        const int64_t ch = h0 + frow;
+                        const Closed cl = closed_by(A, ch, B.id, s_rpos[fr]);
+                        if (cl.kind == 1) { e1.kind = 1; e1.r = cl.r; e1.cr = ch; e1.m = cl.m; e1.nb = cl.nb; e1.ns = 0; }
                     }
                 }
                 // the head of its first run closes the '+' window of a palindromic first site row (R5; that row is first - 1):

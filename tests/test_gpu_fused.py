@@ -164,3 +164,81 @@ def test_fused_pass_at_full_size_dense():
         wait_fused(d, orc, 6, prob_tol=1e-6)
     finally:
         d.close()
+
+
+def with_model_gaps(table, n_gaps, seed, lengths=(64, 400)):
+    """Stretches of 64 and more consecutive 'N' rows (model k-mer NNNNNN: a read across a gap of the model) inside reads, away
+    from the reads' first rows."""
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(seed)
+    fl = table.flags
+    sb = table.seg_row_begin
+    made = 0
+    for _ in range(n_gaps * 4):
+        s = int(rng.integers(0, table.n_seg))
+        lo, hi = int(sb[s]) + 120, int(sb[s + 1]) - 20
+        L = int(rng.integers(lengths[0], lengths[1] + 1))
+        if hi - lo <= L:
+            continue
+        a = int(rng.integers(lo, hi - L))
+        fl[a:a + L] |= _lib.F_MODEL_N
+        fl[a:a + L] &= np.uint8(0xFF ^ _lib.F_KMER_EQ)
+        made += 1
+        if made == n_gaps:
+            break
+    assert made >= n_gaps // 2
+    return table
+
+
+@pytest.mark.parametrize('read_len,n_rows,skip', [((3000, 20000), 400000, 0), ((600, 2500), 200000, 1), ((3000, 12000), 300000, 3)])
+def test_fused_pass_across_gaps_of_filtered_rows(dev, read_len, n_rows, skip):
+    """A read with 64 .. 400 consecutive 'N' rows: the first unfiltered row behind the gap closes the window of the last unfiltered
+    row in front of it (:179 skips filtered rows), which lies in front of the rows a piece stages -- a special closer
+    (mc_fused.hip: the first run of a block whose tested rows begin in front of the staged rows)."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=150000, seed=67)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(n_rows, seed=6700 + skip, codes=codes, read_len=read_len)
+    table = with_model_gaps(table, 150, seed=5 + skip)
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, 6, skip, 0.0)
+    dev.set_reference(arrays)
+    slot = dev.upload_table_async(table, qual)
+    dev.run_async(6, skip, 0.0, score=False)
+    wait_fused(dev, orc, 6)
+    dev.run_async(6, skip, 0.0, score=False)
+    wait_fused(dev, orc, 6)
+    dev.select_table(slot, as_new=True)
+    dev.run_async(6, skip, 0.0, score=False)
+    dev.run_async(6, skip, 0.0, score=False)
+    wait_fused(dev, orc, 6)
+    wait_fused(dev, orc, 6)
+
+
+def test_out_of_room_on_a_first_pass_still_validates(dev, monkeypatch):
+    """A table's FIRST pass runs out of room AND the table holds reads that contradict what they were classified on (positions
+    going backwards in the middle of a read): the repeat inside wait() is planned as a later pass and classifies on the
+    validation flags the first pass left -- which therefore have to be complete, whatever the pieces saw of the overflow."""
+    from mcaller_amd import synth
+    codes = synth.genome(length=60000, seed=9)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(80000, seed=93, codes=codes, read_len=(1000, 4000))
+    rng = np.random.default_rng(17)
+    sb = table.seg_row_begin
+    for s in rng.choice(table.n_seg, size=min(12, table.n_seg), replace=False):
+        lo, hi = int(sb[s]), int(sb[s + 1])
+        if hi - lo < 400:
+            continue
+        a = int(rng.integers(lo + 200, hi - 100))
+        table.pos[a:a + 40] -= 30                                 # (the read steps back: irregular, found only where it happens)
+    arrays = ref.device_arrays()
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    dev.set_reference(arrays)
+    monkeypatch.setenv('MCALLER_FUSED_ROOM', '16')
+    for _ in range(2):
+        slot = dev.upload_table_async(table, qual)
+        dev.run_async(6, 0, 0.0, score=False)
+        wait_fused(dev, orc, 6, expect_fused=False)
+        assert dev.last_pass_info() == (16, True)
+        dev.run_async(6, 0, 0.0, score=False)                     # a later pass over the same table (room still forced small)
+        wait_fused(dev, orc, 6, expect_fused=False)
