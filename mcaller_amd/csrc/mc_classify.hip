@@ -1,6 +1,7 @@
 // mc_classify.hip: predict_proba (k2_mlp, k3_forest, k3_simple) and the packing of a pass's records for the copy-out (k_pack) -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers: mc_dev.h; the map of the
 // kernels: mc_stream.hip.
 #include "mc_dev.h"
+#include "mc_rows.h"
 
 namespace {
 
@@ -205,28 +206,56 @@ __device__ unsigned long long g_k2_trace[1024 * 16 * 16];
 // ... and of wave 0 in every stretch of the first 256 workgroups: [workgroup][stretch < 24][8]
 __device__ unsigned long long g_k2_timeline[256 * 24 * 8];
 #define K2_TL(i) do { if (tid == 0 && blockIdx.x < 256 && stretch_no < 24) g_k2_timeline[((size_t)blockIdx.x * 24 + stretch_no) * 8 + (i)] = wall_clock64(); } while (0)
+// (wall clock of the side kernel's own phases, an array of their own)
+__device__ unsigned long long g_side_trace[1024 * 16 * 16];
+#define K2_WALL(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_side_trace[((size_t)blockIdx.x * K2_WAVES + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define K2_STAMP(i) do { } while (0)
 #define K2_TL(i) do { } while (0)
+#define K2_WALL(i) do { } while (0)
 #endif
 
 
 #define MC_SCALAR_MEM __attribute__((address_space(4)))    // constant address space: uniform loads from it are s_load
 
-// NI_T: the number of inputs when it is known at compile time (7 for the reference's models: the loops over the inputs
-// unroll exactly), 0: any.  The dot products use fma: nothing here has to reproduce a CPU sum bit for bit (the probabilities
-// are held to 1e-9 against the oracle, 1e-12 against scikit-learn's known answers).
-// (the fast forward: TWO workgroups per CU where there are millions of records -- one workgroup's phases A and C hide behind the
-// other's phase B.  64 registers a lane for that, partial sums as floats: 50 KB of LDS a workgroup)
-template <int NI_T, bool FAST>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST ? 8 : 4, FAST ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+// k2_mlp<.., PACK = true>: the side stream of a pipelined pass as ONE kernel -- the workgroup that scores a stretch of records first
+// finishes the windows of ITS records that the emit left to the row-by-row walk (what k1_rare_dev did in a launch of its own) and
+// packs the stretch for the copy-out as it goes (what k_pack_count + k_pack did in two more launches, reading every record -- and,
+// behind k1_fused, every HOLE -- again): the narrow columns of all records, the slot means (32-bit integers where they are
+// fl(d / 1e4)) and the probability of the calls, compacted -- the layout of pack_layout() / pack_tail() exactly as k_pack writes it.
+// Nothing is shared between workgroups: where a record's rows go follows from counts that are complete when the kernel starts --
+// the emit counts calls and wide slot means as it writes the records (k1_emit per packing chunk, Counters-side chunk_cnt; k1_fused
+// per piece, piece_kw), a window left to the walk is counted there by the walk's own rule (window_too_many, mc_rows.h).
+// score == 0: no classifier (the pass was asked for features only): rare windows and packing alone.
+struct SidePack {
+    K1Args A;                     // the pass: table, reference, descriptors, records, counters, rare_list, chunk_cnt / piece_kw
+    const Payload *sorted;        // its payloads in record order (the walk's input)
+    unsigned char *out;           // the block the copy-out moves
+    Counters *host_status;        // the pass's counters as the host reads them (pinned)
+    int close32, score;
+};
+struct NoPack {};
+// (ROOMY: 128 registers a lane and one workgroup per CU -- the side kernel of a sparse motif, where a CU gets one workgroup anyway and
+// a stretch: the packing's and the walk's registers fit beside the hidden layer's without a spill)
+template <int NI_T, bool FAST, bool PACK = false, bool ROOMY = false>
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAST && !ROOMY) ? 8 : 4, (FAST && !ROOMY) ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
                                                      double *__restrict__ prob, const unsigned long long *__restrict__ n_dev,
-                                                     const unsigned int *__restrict__ overflow, K2Pieces P) {
-    if (overflow && *overflow) return;          // (pipelined pass with record buffers too small: it is repeated)
+                                                     const unsigned int *__restrict__ overflow, K2Pieces P,
+                                                     std::conditional_t<PACK, SidePack, NoPack> SP) {
+    if constexpr (PACK) {
+        // (the host reads the pass's counters from pinned memory, whatever became of the pass)
+        if (*overflow) {
+            constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;
+            if (blockIdx.x == 0 && threadIdx.x < head_words)
+                reinterpret_cast<volatile unsigned int *>(SP.host_status)[threadIdx.x] = reinterpret_cast<const unsigned int *>(SP.A.cnt)[threadIdx.x];
+            return;
+        }
+    } else if (overflow && *overflow) return;   // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
+    K2_WALL(0);
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
     const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
     using part_t = std::conditional_t<FAST, float, double>;
@@ -238,6 +267,12 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
     __shared__ unsigned long long s_fixlist[FAST ? K2_FIX : 1];    // ... the records to evaluate again in fp64: record | sub-model << 56
     __shared__ int s_nfix;
     __shared__ int32_t s_slot[K2B];             // a stretch made of pieces: the slot of every record, from the stretch's first piece's first slot
+    __shared__ uint32_t s_fixrow[(FAST && PACK) ? K2_FIX : 1];   // PACK: ... and their rows in the packed block
+    __shared__ int2 s_pk[PACK ? 2 : 1][PACK ? K2_WAVES : 1];    // PACK: a wave's calls and their wide slot means in the stretch (two sets, like s_tot)
+    __shared__ unsigned long long s_base[PACK ? 2 : 1][4];      // PACK: calls, wide slot means, records in front of the stretch (two sets)
+    __shared__ unsigned long long s_red[PACK ? 6 : 1][PACK ? K2_WAVES : 1];
+    __shared__ unsigned long long s_lay[PACK ? 8 : 1];     // PACK: where the packed block's columns begin (byte offsets): looked up where a stretch is packed,
+                                                           // not carried through the hidden layer in registers the weights need
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the compiler has to know that this is uniform: scalar loads)
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -273,7 +308,80 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
     const bool pieces = P.cnt != nullptr;
     const int64_t n_units = pieces ? P.n : n;                    // what the workgroups share out: pieces, or records
     const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = min(n_units, blockIdx.x * per), hi = min(n_units, lo + per);
+    int64_t lo = min(n_units, blockIdx.x * per), hi = min(n_units, lo + per);
+    // ---- PACK: where this workgroup's records go in the packed block -- calls, wide slot means and records in front of its range, and
+    // in all (the emit's counts: nothing here waits for another workgroup); the pass's counters for the host; then the windows of its
+    // own records that were left to the row-by-row walk ----
+    K2_WALL(1);
+    if constexpr (PACK) {
+        unsigned long long v[6] = {0, 0, 0, 0, 0, 0};           // calls, wide, records: in all; in front of the range
+        if (pieces) {
+            for (int64_t j = tid; j < P.n; j += K2_THREADS) {
+                const unsigned long long c = (unsigned long long)min(max(P.cnt[j], 0), P.room);
+                const uint32_t kw = (uint32_t)SP.A.piece_kw[j];
+                v[0] += kw & 0xFFFFu; v[1] += kw >> 16; v[2] += c;
+                if (j < lo) { v[3] += kw & 0xFFFFu; v[4] += kw >> 16; v[5] += c; }
+            }
+        } else {
+            // (the emit counted per packing chunk: the ranges are whole chunks)
+            const int64_t per_c = (n + PACK_WGS - 1) / PACK_WGS;
+            const int c0 = (int)((int64_t)blockIdx.x * PACK_WGS / gridDim.x), c1 = (int)((int64_t)(blockIdx.x + 1) * PACK_WGS / gridDim.x);
+            lo = min(n, c0 * per_c); hi = min(n, c1 * per_c);
+            for (int j = tid; j < PACK_WGS; j += K2_THREADS) {
+                const unsigned long long kk = SP.A.chunk_cnt[PACK_PAD * j], ww = SP.A.chunk_cnt[PACK_PAD * j + 1];
+                v[0] += kk; v[1] += ww;
+                if (j < c0) { v[3] += kk; v[4] += ww; }
+            }
+            if (tid == 0) { v[2] = (unsigned long long)n; v[5] = (unsigned long long)lo; }
+        }
+        K2_WALL(2);
+        // (a thread's sums fit 32 bits -- a few hundred pieces, one chunk; a wave's too: added up across the wave as such, then one
+        // 64-bit LDS atomic per wave and sum.  Not sixteen partial sums per value read back by everybody: the compiler fetches all
+        // ninety-six at once and spills them)
+        if (tid < 6) s_red[PACK ? tid : 0][0] = 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            unsigned int x = (unsigned int)v[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += (unsigned int)__shfl_xor((int)x, o);
+            if (lane == 0 && x) atomicAdd(&s_red[PACK ? i : 0][0], (unsigned long long)x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = s_red[PACK ? i : 0][0];
+        __syncthreads();            // (s_red has been read)
+        if (tid == 0) {
+            const PackLayout PL = pack_layout((int64_t)v[2], SP.close32);
+            const PackTail PTl = pack_tail(PL.feats, (size_t)v[0], k, (size_t)v[1]);
+            s_lay[0] = PL.pos; s_lay[1] = PL.seg; s_lay[2] = PL.info; s_lay[3] = PTl.lo32; s_lay[4] = PTl.wmask; s_lay[5] = PTl.hi32;
+            s_lay[6] = PTl.prob;
+            s_base[0][0] = v[3]; s_base[0][1] = v[4]; s_base[0][2] = v[5];
+            s_red[0][1] = v[2]; s_red[1][1] = v[0]; s_red[2][1] = v[1];         // (records, calls, wide slot means in all: for the host, at the end)
+        }
+        __syncthreads();
+        K2_WALL(3);
+        const int64_t n_rare = (int64_t)SP.A.cnt->n_rare;
+        if (n_rare > 0) {
+            const int64_t rlo = pieces ? lo * P.room : lo, rhi = pieces ? hi * P.room : hi;
+            for (int64_t i = tid; i < n_rare; i += K2_THREADS) {
+                const int64_t q = SP.A.rare_list[i];
+                // (a slot of more than 128 events -- NumPy's recursion proper, 1.4 KB of stack per lane: not in this kernel; the pass
+                // is marked like one with irregular reads and repeated by the synchronous path)
+#ifndef MC_SIDE_NO_RARE      // (variant build, timing only: what the walk's registers cost the kernel)
+                if (q >= rlo && q < rhi && finish_rare_record<false>(SP.A, SP.sorted, q, true)) {
+                    // (an atomic at device scope, waited for: performed where the workgroup that is through last will read it)
+                    const unsigned long long was = atomicExch(&SP.A.cnt->irregular_pass, SP.A.pass_no);
+                    asm volatile("" :: "v"(was));
+                }
+#endif
+            }
+            // (this workgroup's own threads read what the walks wrote: same CU, same L1 -- no device-scope fence, which on this chip
+            // writes a whole L2 back: 80 us a kernel when every thread executed one)
+            __syncthreads();
+        }
+    }
+    K2_WALL(4);
     K2_STAMP(1);
     // the records whose printed digits (or label) could depend on the precision: again in fp64, a wave per record, the hidden
     // units across its lanes (the quality is fetched again: a handful of records per stretch)
@@ -297,7 +405,11 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-            if (lane == 0) prob[r] = logistic(part + M.b2[mdl], C);
+            if (lane == 0) {
+                const double pr = logistic(part + M.b2[mdl], C);
+                prob[r] = pr;
+                if constexpr (PACK) reinterpret_cast<double *>(SP.out + s_lay[PACK ? 6 : 0])[s_fixrow[(FAST && PACK) ? f : 0]] = pr;
+            }
         }
     };
     int buf = 0, stretch_no = 0;
@@ -335,16 +447,28 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
         const int64_t r = slot0 + my_slot;
         int mi = 255;                               // sub-model of record r (255: not scored here)
         double qv = 0.0;
+        [[maybe_unused]] int p_nw = -1;                // PACK: wide slot means of the thread's record if it is a call, else -1
         if (tid < n_here) {
             if (submodel_in) mi = submodel_in[r];
             else {
                 const uint32_t inf = info[r];
                 const int32_t seg = site_seg[r];
-                if (!(inf & (MC_I_TOO_MANY | MC_I_EDGE))) {
+                if constexpr (PACK) { if (!(inf & MC_I_TOO_MANY)) p_nw = __popc((uint32_t)SP.A.O.wmask[r] & ((1u << k) - 1u)); }
+                bool scored = !(inf & (MC_I_TOO_MANY | MC_I_EDGE));
+                if constexpr (PACK) scored = scored && SP.score != 0;
+                if (scored) {
                     mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
                     qv = qual[seg_read[seg]];
                 }
             }
+        }
+        if constexpr (PACK) {
+            // the wave's calls and their wide slot means in this stretch: the packing (behind C) finds its rows from the waves' counts
+            const int nk = __popcll(__ballot(p_nw >= 0));
+            int nw = max(p_nw, 0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nw += __shfl_xor(nw, o);
+            if (lane == 0) s_pk[PACK ? buf : 0][PACK ? wave : 0] = make_int2(nk, nw);
         }
         int rank = 0, cnt_lane = 0;                 // (lane m: the wave's records of sub-model m)
 #pragma unroll
@@ -364,8 +488,10 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
         if (mi < NM) s_list[mi][mybase + rank] = (uint16_t)tid;
         s_q[tid] = qv;
         K2_STAMP(2);
+        K2_WALL(5);
         K2_TL(1);
         __syncthreads();
+        K2_WALL(6);
         K2_TL(2);
         int tot[K2_MAXM], gs[K2_MAXM], n_groups = 0;    // records and first group of every sub-model
 #pragma unroll
@@ -375,16 +501,8 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
             n_groups += (tot[m] + 63) >> 6;
         }
         if (tid < K2_MAXM) s_tot[buf ^ 1][tid] = 0;     // (the next stretch's: last read a stretch ago)
-        if constexpr (FAST) {
-            // the list of records to evaluate again has room for everything this stretch may add?  (It is only added to in C.)
-            const int n_fix = __builtin_amdgcn_readfirstlane(s_nfix);
-            if (n_fix > K2_FIX - K2B) {
-                again_in_fp64(n_fix);
-                __syncthreads();
-                if (tid == 0) s_nfix = 0;
-            }
-        }
         K2_STAMP(3);
+        K2_WALL(7);
         // ---- B: a quarter of the hidden units for every fourth (eighth ...) group
         const int u0 = quarter * H / 4, u1 = (quarter + 1) * H / 4;
         for (int g = g_first; g < n_groups; g += g_step) {
@@ -477,21 +595,95 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
             if (valid) s_part[quarter][off] = (part_t)z;
         }
         K2_STAMP(4);
+        K2_WALL(8);
         K2_TL(3);
         __syncthreads();
+        K2_WALL(9);
         K2_STAMP(5);
         K2_TL(4);
         // ---- C: the output unit of the thread's record
+        [[maybe_unused]] double p_pr = __longlong_as_double(0x7ff8000000000000LL);     // (a call that is not scored here: NaN, as the records say)
+        [[maybe_unused]] bool p_fix = false;
         if (mi < NM) {
             const double z = (((double)s_part[0][tid] + (double)s_part[1][tid]) + (double)s_part[2][tid]) + (double)s_part[3][tid];
             const double pr = logistic(z + M.b2[mi], C);
             prob[r] = pr;
-            if (FAST && !(threshold_distance(pr) > (double)s_marg[FAST ? tid : 0]))       // (NaN too)
-                s_fixlist[FAST ? atomicAdd(&s_nfix, 1) : 0] = (unsigned long long)r | (unsigned long long)mi << 56;
+            const bool fix = FAST && !(threshold_distance(pr) > (double)s_marg[FAST ? tid : 0]);     // (NaN too)
+            if constexpr (PACK) { p_pr = pr; p_fix = fix; }
+            else if (fix) s_fixlist[FAST ? atomicAdd(&s_nfix, 1) : 0] = (unsigned long long)r | (unsigned long long)mi << 56;
+        }
+        if constexpr (PACK) {
+            // ---- the stretch's records into the packed block: the narrow columns of every record, slot means, mask byte and probability
+            // of the calls.  Everything a record needs is fetched HERE (the hidden layer's registers are free again; the record's
+            // lines are in the caches from A): nothing of it lives through B ----
+            K2_WALL(11);
+            if (tid < n_here) {
+                const uint32_t inf = info[r];
+                const int32_t seg = site_seg[r], pos = SP.A.O.site_pos[r];
+                const int64_t close = SP.A.O.close_row[r];
+                const bool keep = !(inf & MC_I_TOO_MANY);
+                const uint32_t wm = keep ? ((uint32_t)SP.A.O.wmask[r] & ((1u << k) - 1u)) : 0u;
+                double fx[MC_MAX_K];
+#pragma unroll
+                for (int f = 0; f < MC_MAX_K; ++f) fx[f] = (keep && f < k) ? feats[r * k + f] : 0.0;
+                // calls and wide slot means in front of the record: the lanes below, the waves before (their counts: A), the stretches before
+                const unsigned long long kb = __ballot(keep);
+                const int nw = __popc(wm);
+                int w_incl = nw;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int y = __shfl_up(w_incl, o);
+                    if (lane >= o) w_incl += y;
+                }
+                unsigned long long row = s_base[PACK ? buf : 0][0] + (unsigned)__popcll(kb & below), wpos = s_base[PACK ? buf : 0][1] + (unsigned)(w_incl - nw);
+                unsigned kept_all = 0, wide_all = 0;
+#pragma unroll
+                for (int w = 0; w < K2_WAVES; ++w) {
+                    const int2 c = s_pk[PACK ? buf : 0][PACK ? w : 0];
+                    if (w < wave) { row += (unsigned)c.x; wpos += (unsigned)c.y; }
+                    kept_all += (unsigned)c.x; wide_all += (unsigned)c.y;
+                }
+                const unsigned long long real0 = s_base[PACK ? buf : 0][2];
+                if (tid == 0) {         // (the next stretch's: read behind its two barriers)
+                    s_base[PACK ? buf ^ 1 : 0][0] = s_base[PACK ? buf : 0][0] + kept_all;
+                    s_base[PACK ? buf ^ 1 : 0][1] = s_base[PACK ? buf : 0][1] + wide_all;
+                    s_base[PACK ? buf ^ 1 : 0][2] = real0 + (unsigned long long)n_here;
+                }
+                const int64_t io = pieces ? (int64_t)real0 + tid : r;               // (holes are never looked at: the host never sees one)
+                unsigned char *const out = SP.out;
+                if (SP.close32) reinterpret_cast<int32_t *>(out)[io] = (int32_t)close;
+                else reinterpret_cast<int64_t *>(out)[io] = close;
+                reinterpret_cast<int32_t *>(out + s_lay[0])[io] = pos;
+                reinterpret_cast<int32_t *>(out + s_lay[PACK ? 1 : 0])[io] = seg;
+                reinterpret_cast<uint32_t *>(out + s_lay[PACK ? 2 : 0])[io] = inf;
+                if (keep) {
+                    int32_t *o_lo = reinterpret_cast<int32_t *>(out + s_lay[PACK ? 3 : 0]) + row * k;
+                    uint32_t *o_hi = reinterpret_cast<uint32_t *>(out + s_lay[PACK ? 5 : 0]);
+                    (out + s_lay[PACK ? 4 : 0])[row] = (uint8_t)wm;
+                    reinterpret_cast<double *>(out + s_lay[PACK ? 6 : 0])[row] = p_pr;
+#pragma unroll
+                    for (int f = 0; f < MC_MAX_K; ++f)
+                        if (f < k) {
+                            // a slot mean that is fl(d / 1e4) travels as d (the emit noted which are not: DevRecords.wmask)
+                            if (!((wm >> f) & 1u)) o_lo[f] = (int32_t)rint(fx[f] * 1e4);
+                            else {
+                                const unsigned long long bits = (unsigned long long)__double_as_longlong(fx[f]);
+                                o_lo[f] = (int32_t)(uint32_t)bits;
+                                o_hi[wpos++] = (uint32_t)(bits >> 32);
+                            }
+                        }
+                    if (p_fix) {
+                        const int at = atomicAdd(&s_nfix, 1);
+                        s_fixlist[FAST ? at : 0] = (unsigned long long)r | (unsigned long long)mi << 56;
+                        s_fixrow[(FAST && PACK) ? at : 0] = (uint32_t)row;
+                    }
+                }
+            }
         }
         base += pieces ? np_here : K2B;
         buf ^= 1;
         K2_STAMP(6);
+        K2_WALL(10);
         K2_TL(5);
         ++stretch_no;
 #ifdef MC_K2_TRACE
@@ -503,6 +695,32 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(FAST
         __syncthreads();
         again_in_fp64(s_nfix);
     }
+    K2_WALL(13);
+    if constexpr (PACK) {
+        // ---- the pass's counters for the host (pinned memory; read behind ev_done), by the workgroup that is through LAST: what the
+        // row-by-row walks of the others changed (a pass marked for repetition) is in them.  As k_pack sent them: the head as it is,
+        // calls and wide slot means in all, the records without the holes ----
+        // (nothing but that mark crosses workgroups, and it is an atomic at device scope: no fence -- a device-scope release writes
+        // a whole L2 back on this chip)
+        __shared__ int s_last;
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&SP.A.cnt->side_done, 1ull) == (unsigned long long)gridDim.x - 1ull;
+        __syncthreads();
+        if (s_last) {
+            constexpr unsigned head_words = offsetof(Counters, end_of_head) / 4;
+            constexpr int kept_word = (int)(offsetof(Counters, n_kept) / 4);
+            static_assert(offsetof(Counters, n_wide) == offsetof(Counters, n_kept) + 8 && offsetof(Counters, n_records) == 0, "Counters layout");
+            if (tid < (int)head_words && (tid < kept_word || tid >= kept_word + 4) && tid >= 2)
+                reinterpret_cast<volatile unsigned int *>(SP.host_status)[tid] =
+                    __hip_atomic_load(reinterpret_cast<unsigned int *>(SP.A.cnt) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                *reinterpret_cast<volatile unsigned long long *>(&SP.host_status->n_records) = s_red[0][PACK ? 1 : 0];
+                *reinterpret_cast<volatile unsigned long long *>(&SP.host_status->n_kept) = s_red[PACK ? 1 : 0][PACK ? 1 : 0];
+                *reinterpret_cast<volatile unsigned long long *>(&SP.host_status->n_wide) = s_red[PACK ? 2 : 0][PACK ? 1 : 0];
+            }
+        }
+    }
+    K2_WALL(14);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -718,7 +936,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ chunk_cnt,
                                                        unsigned char *__restrict__ out, int k, int close32,
-                                                       Counters *__restrict__ host_status, int holes) {
+                                                       Counters *__restrict__ host_status, int holes, int look) {
+    // look != 0: the chunk counts come from k_pack_count, which looked at the slot means of the records whose mask byte says 0xFF (the
+    // row-by-row paths) -- so does this kernel; look == 0: the emit counted as it wrote the records, every mask byte is what it says
     static_assert(PACK_WGS <= PACK_THREADS && PACK_THREADS % 64 == 0, "one chunk count per thread");
     __shared__ unsigned long long s_sum[6][PACK_THREADS / 64];
     __shared__ unsigned int s_wave[3][PACK_THREADS / 64];
@@ -787,11 +1007,12 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
         unsigned int wmask = 0, n_w = 0;
         if (keep) {
             const unsigned noted = O.wmask[i];
+            const bool literal = noted != 0xFFu || !look;
             for (int f = 0; f < k; ++f) {
                 const double x = s_feats[tid * k + f];
                 int32_t d = 0;
-                const bool narrow = noted != 0xFFu ? !((noted >> f) & 1u) : slot_is_narrow(x, &d);
-                if (narrow) lo32[f] = noted != 0xFFu ? (int32_t)rint(x * 1e4) : d;
+                const bool narrow = literal ? !((noted >> f) & 1u) : slot_is_narrow(x, &d);
+                if (narrow) lo32[f] = literal ? (int32_t)rint(x * 1e4) : d;
                 else {
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
                     lo32[f] = (int32_t)(uint32_t)bits;
@@ -849,6 +1070,9 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
 #ifndef MC_K2_WG_PER_CU
 #define MC_K2_WG_PER_CU 1
 #endif
+#ifndef MC_SIDE_WGS_SPARSE
+#define MC_SIDE_WGS_SPARSE 64
+#endif
 #ifndef MC_K2_WG_MANY          // ... where there are millions of records (the fast forward)
 #define MC_K2_WG_MANY 2
 #endif
@@ -878,16 +1102,16 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
         // mc_mlp_forward -- is fp64 throughout: its caller gets raw probabilities)
         if (M.n_in == 7 && fast)
             hipLaunchKernelGGL((k2_mlp<7, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow, P);
+                               prob, n_dev, overflow, P, NoPack{});
         else if (M.n_in == 7)
             hipLaunchKernelGGL((k2_mlp<7, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow, P);
+                               prob, n_dev, overflow, P, NoPack{});
         else if (fast)
             hipLaunchKernelGGL((k2_mlp<0, true>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow, P);
+                               prob, n_dev, overflow, P, NoPack{});
         else
             hipLaunchKernelGGL((k2_mlp<0, false>), dim3(grid), dim3(K2_THREADS), 0, st, M, feats, k, site_seg, seg_read, qual, info, submodel_in, n,
-                               prob, n_dev, overflow, P);
+                               prob, n_dev, overflow, P, NoPack{});
     }
 }
 
@@ -896,9 +1120,48 @@ void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsig
 }
 
 void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, int holes, hipStream_t st, hipEvent_t stop) {
-    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
-    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes);
+                    Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop) {
+    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status, holes, look);
+    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes, look);
+}
+
+// The side stream of a pipelined pass as ONE kernel (k2_mlp<.., PACK>): rare windows, MLP (score != 0), packing.  -> false: not for this
+// pass (another classifier, a piece's room beyond a stretch): the caller launches k1_rare_dev, the classifier and the packing kernels.
+bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_t st, const K1Args &A, const Payload *sorted, const int32_t *seg_read,
+                    const double *qual, int64_t cap, int score, unsigned char *out, int close32, Counters *host_status, int piece_room,
+                    int64_t n_pieces, hipEvent_t stop) {
+    static const bool off = getenv("MCALLER_SIDE_FUSED") && atoi(getenv("MCALLER_SIDE_FUSED")) == 0;       // (tests, profiles: the three kernels)
+    if (off || cap <= 0) return false;
+    if (score && (other_classifier || !M.W1)) return false;
+    const bool by_piece = piece_room > 0;
+    if (by_piece ? (piece_room >= K2B || !A.piece_kw || !A.piece_cnt) : !A.chunk_cnt) return false;
+    SidePack SP;
+    SP.A = A; SP.sorted = sorted; SP.out = out; SP.host_status = host_status; SP.close32 = close32; SP.score = score;
+    const K2Pieces P{by_piece ? A.piece_cnt : nullptr, piece_room, n_pieces};
+    const bool fast = score && M.fast && M.wp32;
+    // (a dense reference: two workgroups per CU, as the classifier alone; a sparse motif: a power of two of them -- the ranges are whole
+    // packing chunks -- and FEW: the kernel runs beside the next pass's scan, and what counts is how little of the chip it takes from
+    // it, not when it is through.  10^8 rows, 2 x 10^5 records, pipelined step: 256 workgroups 0.2745 ms, 128 / 64 / 32: 0.2638 /
+    // 0.2637 / 0.2634; the three kernels it replaces: 0.2732)
+    unsigned grid;
+    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * (fast ? MC_K2_WG_MANY : MC_K2_WG_PER_CU)));
+    else { grid = 1; while (grid * 2 <= (unsigned)std::min<int64_t>(MC_SIDE_WGS_SPARSE, (int64_t)n_cu * MC_K2_WG_PER_CU)) grid *= 2; }
+    const unsigned long long *n_dev = (const unsigned long long *)&A.cnt->n_records;
+    const unsigned int *overflow = (const unsigned int *)&A.cnt->overflow;
+#define MC_SIDE_LAUNCH(NI, FA, RO) hipExtLaunchKernelGGL((k2_mlp<NI, FA, true, RO>), dim3(grid), dim3(K2_THREADS), 0, st, nullptr, stop, 0, M, (const double *)A.O.feats, A.k, \
+        (const int32_t *)A.O.site_seg, seg_read, qual, (const uint32_t *)A.O.info, (const uint8_t *)nullptr, cap, A.O.prob, n_dev, overflow, P, SP)
+    // (a dense reference too: at 64 registers a lane the packing spills inside the stretch loop -- 2.2 ms per 10^8 rows against 1.3;
+    // MCALLER_SIDE_ROOMY=0: that instance, two workgroups per CU.  MCALLER_SIDE_GRID: workgroups for a sparse motif, a power of two)
+    static const bool roomy_dense = !(getenv("MCALLER_SIDE_ROOMY") && atoi(getenv("MCALLER_SIDE_ROOMY")) == 0);
+    if (by_piece && roomy_dense) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu));
+    static const int grid_sparse = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;
+    if (!by_piece && grid_sparse > 0) { grid = 1; while (grid * 2 <= (unsigned)std::min(grid_sparse, PACK_WGS)) grid *= 2; }
+    if (score && M.n_in == 7 && fast) { if (by_piece && !roomy_dense) MC_SIDE_LAUNCH(7, true, false); else MC_SIDE_LAUNCH(7, true, true); }
+    else if (score && M.n_in == 7) MC_SIDE_LAUNCH(7, false, false);
+    else if (fast) { if (by_piece) MC_SIDE_LAUNCH(0, true, false); else MC_SIDE_LAUNCH(0, true, true); }
+    else MC_SIDE_LAUNCH(0, false, false);
+#undef MC_SIDE_LAUNCH
+    return true;
 }
 
 // tanh32s(s) against the fp64 tanh(s ln2 / 2) over EVERY float s: the largest absolute difference (what K2_TANH32_MAX_ERR has to cover)
@@ -932,6 +1195,10 @@ extern "C" int mc_debug_tanh32_max_err(double *out) {
 extern "C" int mc_debug_k2_timeline(unsigned long long *out, int64_t n_words) {
     if (n_words > 256 * 24 * 8) n_words = 256 * 24 * 8;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_timeline), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
+}
+extern "C" int mc_debug_side_trace(unsigned long long *out, int64_t n_words) {
+    if (n_words > 1024 * 16 * 16) n_words = 1024 * 16 * 16;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_side_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -10;
 }
 extern "C" int mc_debug_k2_trace(unsigned long long *out, int64_t n_words) {
     if (n_words > 1024 * 16 * 16) n_words = 1024 * 16 * 16;

@@ -169,6 +169,7 @@ struct Counters {          // device-side status block
     unsigned int n_rare;       // windows left to k1_rare
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
     unsigned long long n_wide; // slot means of those records that travel as 64 bits (k_pack: the others as 32-bit integers)
+    unsigned long long side_done;  // workgroups of the side stream's kernel (k2_mlp<.., PACK>) that are through: the last one sends the counters to the host
     // the pass in which a name block was last classified irregular (mc_params-independent pass number, never 0).  Written,
     // never zeroed: k0_first_site classifies while it zeroes the other counters, so a count could lose updates -- a pass is
     // special iff this equals its own number
@@ -376,6 +377,9 @@ struct K1Args {
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
     int32_t *piece_cnt;           // the fused dense pass (k1_fused): [pieces] records of every piece
+    int32_t *piece_kw;            // ... [pieces] of them calls (no MC_I_TOO_MANY) | their wide slot means << 16 -- the packing's counts,
+                                  // made where the records are written (windows left to the row-by-row walk: predicted, mc_rows.h);
+                                  // nullptr: nobody packs by piece
     unsigned long long *chunk_cnt;  // pipelined passes: [PACK_PAD * PACK_WGS] kept records / their wide slots per chunk of the copy-out's packing
                                   // (k_pack), counted by the emit itself as it writes the records; nullptr: nobody packs (or k_pack_count counts)
 };
@@ -513,6 +517,9 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
                           const int32_t *piece_cnt = nullptr, int piece_room = 0, int64_t n_pieces = 0);
 void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, int holes, hipStream_t st);
 void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, int holes, hipStream_t st, hipEvent_t stop);
+                    Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop);
+bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_t st, const K1Args &A, const Payload *sorted, const int32_t *seg_read,
+                    const double *qual, int64_t cap, int score, unsigned char *out, int close32, Counters *host_status, int piece_room,
+                    int64_t n_pieces, hipEvent_t stop);
 
 #endif  // MC_DEV_H

@@ -1,89 +1,9 @@
 // mc_emit.hip: the window emit (k1_emit; dense references: k1_emit_runs) and the row-by-row kernels behind it (k1_rare, k1_bigfix) -- part of libmcaller_hip.so's device side (gfx950 / MI355X); shared structures and helpers: mc_dev.h; the map of the
 // kernels: mc_stream.hip.
 #include "mc_dev.h"
+#include "mc_rows.h"
 
 namespace {
-
-// Record for the window of site m whose last row is r, in name block nb_abs (descriptor d).
-__device__ __forceinline__ void emit_record(const K1Args &A, RowSrc &S, const NbDesc &d, int nb_abs, int64_t r, int m,
-                                            int64_t slot) {
-    const DevTable &T = A.T;
-    const int k = A.k;
-    const int64_t L = d.contig_len;
-    const uint32_t *bits = (d.rev ? A.R.mr : A.R.mf) + d.mask_off;
-    int close_pos;
-    bool close_ns;
-    const int64_t close_row = find_close(T, A.desc, A.tail_contig, nb_abs, d.row_end, r, close_pos, close_ns);
-    uint32_t info = d.rev ? MC_I_REV : 0u;
-
-    // ---- window rows: back to the first row at position >= m-k+1 (never before d.first() / the block start) ----
-    // per-slot event counts packed 8 bits each (a slot with > 128 events goes to k1_bigfix)
-    const int64_t lb = max(d.row_begin, d.first());
-    unsigned long long cnt8 = 0;
-    bool big = false;
-    int64_t ws = r;
-    for (int64_t rr = r; rr >= lb; --rr) {
-        if (T.flags[rr] & MC_F_MODEL_N) continue;
-        const int p = T.pos[rr];
-        if (p < m - k + 1) break;
-        if (p > m) continue;        // (cannot happen in a regular block; a block taken for regular on its first rows may not be)
-        const int sh = 8 * (m - p);
-        if (((cnt8 >> sh) & 0xFFull) >= 128ull) big = true;
-        else cnt8 += 1ull << sh;
-        ws = rr;
-    }
-    // the stray event of a palindromic first site row: first in the slot of its pseudo-position
-    int stray_slot = -1;
-    if (d.stray_q != NO_STRAY) {
-        const int sq = m - d.stray_q;
-        if (sq >= 0 && sq < k) {
-            stray_slot = sq;
-            if (((cnt8 >> (8 * sq)) & 0xFFull) >= 128ull) big = true;
-            else cnt8 += 1ull << (8 * sq);
-        }
-    }
-    int nskip = 0;
-    for (int s = 0; s < k; ++s) nskip += (((cnt8 >> (8 * s)) & 0xFFull) == 0ull);
-
-    if (nskip > A.skip_thresh) {
-        info |= MC_I_TOO_MANY;
-        for (int s = 0; s < k; ++s) A.O.feats[slot * k + s] = 0.0;
-    } else {
-        int64_t cur = ws;
-        for (int s = k - 1; s >= 0; --s) {             // positions ascend => slots descend
-            const int dst = d.rev ? s : k - 1 - s;      // :187-188
-            const int n = (int)((cnt8 >> (8 * s)) & 0xFFull);
-            double f = 0.0;
-            if (n == 0) info |= 1u << dst;
-            else if (!big) {
-                if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
-                f = (0.0 + leaf_sum(S, cur, n)) / (double)n;
-            }
-            A.O.feats[slot * k + dst] = f;
-        }
-        if (big) { info |= MC_I_BIG; atomicAdd(&A.cnt->n_big, 1u); }   // k1_bigfix recomputes the record
-        // context[k], the character after the 'M', picks the sub-model (:197)
-        if (m - k + 1 < 0 || (int64_t)m + k > L || m < 1 || m + 1 >= L) {
-            info |= MC_I_EDGE;                   // the 2k-1 context leaves the contig: Python slicing decides
-        } else {
-            unsigned char ch;
-            const uint8_t *seq = A.R.seq + A.R.seq_off[d.contig];
-            if (!d.rev) ch = bit_at(bits, m + 1) ? 'M' : seq[m + 1];
-            else ch = bit_at(bits, m - 1) ? 'M' : comp_char(seq[m - 1]);
-            info |= ((uint32_t)ch) << MC_I_NEXT_SHIFT;
-        }
-    }
-    // the closing row shifts the window when it continues the chain with kmer[0] != 'M' (:242-248)
-    if (!close_ns && close_pos <= m + A.skip_thresh + 1) {
-        if (first_m(bits, L, close_pos, k) > 0) info |= MC_I_MULTI;
-    }
-    A.O.site_pos[slot] = m;
-    A.O.site_seg[slot] = T.nb_seg_begin[nb_abs];        // regular blocks have one segment
-    A.O.close_row[slot] = close_row;
-    A.O.info[slot] = info;
-    A.O.wmask[slot] = 0xFF;                  // (which slot means need 64 bits: k_pack looks)
-    A.O.prob[slot] = __longlong_as_double(0x7ff8000000000000LL);
-}
 
 // The one-event '+' window a reverse read opens on a palindromic first site row (R5): flushed with k-1 empty slots.
 __device__ __forceinline__ void emit_extra(const K1Args &A, const NbDesc &d, int nb_abs, int64_t slot) {
@@ -117,7 +37,6 @@ static_assert(EG >= MC_MAX_K, "one lane per slot");
 
 // Windows longer than WROWS rows (a handful per 10^8 rows, if any): k1_emit lists them, k1_rare walks them row by row,
 // one thread each, after the host has seen the count.
-__device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j);
 
 __global__ void k1_rare(K1Args A, const Payload *__restrict__ sorted, const int64_t *__restrict__ rare_list, int64_t n_rare) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -308,6 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MC_EMIT_WAV
     const uint32_t empties = (uint32_t)(__ballot(fast && s < k && n == 0) >> gsh) & 0xFFu;    // bit s: slot s is empty
     bool kept_rec = false;                  // (lane 0 of a group: its record is a call; wide_bit: which of its slot means are wide)
     unsigned wide_bit = 0u;
+    // (a window left to the row-by-row walk, in a pass whose copy-out is packed: a call has a row in the packed block and the
+    // rows are counted HERE -- will it be a call?  The walk's own count of the empty slots, made now; its slot means travel wide,
+    // all k of them)
+    if (A.chunk_cnt && window && !covered && s == 0 && !window_too_many(A, P.nb, r, m)) { kept_rec = true; wide_bit = (1u << k) - 1u; }
     if (fast) {
     const bool too_many = __popc(empties) > A.skip_thresh;
     const bool rev = P.flags & PF_REV;
@@ -800,89 +723,6 @@ __global__ __launch_bounds__(E_THREADS) __attribute__((amdgpu_waves_per_eu(MC_ER
     ER_STAMP(5);
 }
 
-// Records with a slot of more than 128 events (NumPy's pairwise recursion proper): recomputed here, one
-// thread per such record, so that k1_emit carries neither the stack nor the registers for it.
-__device__ double big_pairwise(RowSrc &S, int64_t &cur, int64_t n) {
-    // emulate  f(n) = n <= 128 ? leaf(n) : f(n2) + f(n - n2),  n2 = n/2 rounded down to a multiple of 8
-    int64_t fsize[40];
-    int fstage[40];      // 0 = not started, 1 = left half pending, 2 = right half pending
-    double fleft[40];
-    int fp = 1;
-    fsize[0] = n;
-    fstage[0] = 0;
-    double ret = 0.0;
-    while (fp > 0) {
-        const int top = fp - 1;
-        int64_t n2 = fsize[top] / 2;
-        n2 -= n2 % 8;
-        if (fstage[top] == 0) {
-            if (fsize[top] <= 128) {
-                ret = leaf_sum(S, cur, (int)fsize[top]);
-                --fp;
-            } else {
-                fstage[top] = 1;
-                fsize[fp] = n2; fstage[fp] = 0; ++fp;
-            }
-        } else if (fstage[top] == 1) {
-            fleft[top] = ret;
-            fstage[top] = 2;
-            fsize[fp] = fsize[top] - n2; fstage[fp] = 0; ++fp;
-        } else {
-            ret = fleft[top] + ret;
-            --fp;
-        }
-    }
-    return ret;
-}
-
-__device__ __noinline__ void bigfix_record(const K1Args &A, int64_t j) {
-    const DevRecords &O = A.O;
-    const uint32_t info = O.info[j];
-    if (!(info & MC_I_BIG)) return;
-    const DevTable &T = A.T;
-    const int k = A.k;
-    const int m = O.site_pos[j];
-    const bool rev = info & MC_I_REV;
-    // name block of the record = the one its (single) segment starts
-    const int seg = O.site_seg[j];
-    int lo = 0, hi = T.n_nb - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (T.nb_seg_begin[mid] <= seg) lo = mid; else hi = mid - 1;
-    }
-    const NbDesc d = A.desc[lo];
-    RowSrc S{T.pos, T.evmu, T.flags, false, 0.0};
-    // last row of the window: the last unfiltered row of the block before the closing row
-    int64_t r = min(O.close_row[j], d.row_end) - 1;
-    const int64_t lb = max(d.row_begin, d.first());
-    while (r >= lb && (T.flags[r] & MC_F_MODEL_N)) --r;
-    int64_t cnt[MC_MAX_K] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t ws = r;
-    for (int64_t rr = r; rr >= lb; --rr) {
-        if (T.flags[rr] & MC_F_MODEL_N) continue;
-        const int p = T.pos[rr];
-        if (p < m - k + 1) break;
-        if (p > m) continue;        // (see emit_record)
-        cnt[m - p] += 1;
-        ws = rr;
-    }
-    int stray_slot = -1;
-    if (d.stray_q != NO_STRAY && m - d.stray_q >= 0 && m - d.stray_q < k) {
-        stray_slot = m - d.stray_q;
-        cnt[stray_slot] += 1;
-    }
-    int64_t cur = ws;
-    for (int s = k - 1; s >= 0; --s) {
-        const int dst = rev ? s : k - 1 - s;
-        double f = 0.0;
-        if (s == stray_slot) { S.stray_pending = true; S.stray_val = (double)d.stray_d / 10000.0; }
-        if (cnt[s] > 0) f = (0.0 + big_pairwise(S, cur, cnt[s])) / (double)cnt[s];
-        O.feats[j * k + dst] = f;
-    }
-    O.info[j] = info & ~MC_I_BIG;
-    O.wmask[j] = 0xFF;
-}
-
 __global__ void k1_bigfix(K1Args A, int64_t n) {
     const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j < n) bigfix_record(A, j);
@@ -894,20 +734,7 @@ __global__ void k1_rare_dev(K1Args A, const Payload *__restrict__ sorted, const 
     if (A.cnt->overflow) return;
     const int64_t n_rare = (int64_t)A.cnt->n_rare;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rare; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = rare_list[i];
-        const Payload P = sorted[q];
-        const NbDesc d = A.desc[P.nb];
-        RowSrc S{A.T.pos, A.T.evmu, A.T.flags, false, 0.0};
-        emit_record(A, S, d, P.nb, P.r, P.m, q);
-        bigfix_record(A, q);
-        if (A.chunk_cnt && !(A.O.info[q] & MC_I_TOO_MANY)) {       // (the packing's counts: k1_emit left this record out)
-            int n_wide = 0;
-            for (int f = 0; f < A.k; ++f) {
-                int32_t d32;
-                n_wide += slot_is_narrow(A.O.feats[q * A.k + f], &d32) ? 0 : 1;
-            }
-            count_for_packing(A.chunk_cnt, q, min((int64_t)A.cnt->n_records, A.O.capacity), true, n_wide);
-        }
+        finish_rare_record(A, sorted, rare_list[i], A.chunk_cnt != nullptr);
     }
 }
 

@@ -30,6 +30,7 @@
 //   * on a table's first pass the piece's rows are validated as the scan validates them (every row against the row before it
 //     in its name block: note_validation), event indices staged with the rows.
 #include "mc_dev.h"
+#include "mc_rows.h"
 
 namespace {
 
@@ -160,6 +161,23 @@ __device__ __forceinline__ void leave_to_rare(const K1Args &A, Payload *__restri
     A.rare_list[atomicAdd(&A.cnt->n_rare, 1u)] = q;
 }
 
+// A window left to the row-by-row walk: will its record be a call?  (The walk's own count of the empty slots, made now: a call has
+// a row in the packed copy-out and the rows are counted per piece, here.)  -> what it adds to the piece's counts: 1 | k << 16, or 0
+__device__ __forceinline__ int rare_counts(const K1Args &A, int nb, int64_t r, int m) {
+    if (!A.piece_kw) return 0;
+    return window_too_many(A, nb, r, m) ? 0 : (1 | (A.k << 16));
+}
+
+// the piece's calls and their wide slot means (what every thread counted of its windows) -> A.piece_kw[piece]; all threads call
+__device__ __forceinline__ void store_piece_counts(const K1Args &A, int64_t piece_no, int mine, int tid, int *s_kw) {
+    if (!A.piece_kw) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((tid & 63) == 0 && mine) atomicAdd(s_kw, mine);
+    lds_barrier();
+    if (tid == 0) A.piece_kw[piece_no] = *s_kw;
+}
+
 // exclusive prefix of `mine` over the workgroup's threads (and the total); s_w: F_THREADS / 64 words of LDS
 __device__ __forceinline__ int wg_exclusive_scan(int mine, int lane, int wave, int *s_w, int &total) {
     int incl = mine;
@@ -196,6 +214,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ uint16_t s_heavy[4 * F_HEAVY];        // per wave: its runs of more than one event
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
+    __shared__ int s_kw;                        // the piece's calls (records without MC_I_TOO_MANY) | their wide slot means << 16: the packing's counts
     __shared__ unsigned s_over;                 // Counters.overflow as the workgroup's first wave saw it: ONE answer for all waves
     __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
     __shared__ int4 s_wfirst[F_THREADS / 64];   // ... its first one: (row, position, first row of its block that is in a run); row -1: none
@@ -208,7 +227,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     const int64_t q0 = piece_no * (int64_t)cap;
     if (s0 >= T.n_rows) {                        // (a piece behind the table: all holes)
         for (int w = tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
-        if (tid == 0) A.piece_cnt[piece_no] = 0;
+        if (tid == 0) { A.piece_cnt[piece_no] = 0; if (A.piece_kw) A.piece_kw[piece_no] = 0; }
         return;
     }
     const int64_t h0 = max(s0 - (int64_t)FH, (int64_t)0);
@@ -281,7 +300,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (over && at < F_MAXB) s_blk[at] = fb;
         if (lane <= F_MAXB) s_bfirst[lane] = -1;
         if (lane < (FR + 63) / 64 + 2) s_cnt[lane] = 0;
-        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; s_over = overflow; }
+        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; s_over = overflow; s_kw = 0; }
     }
     asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w), "+v"(ea.x), "+v"(ea.y), "+v"(ea.z), "+v"(ea.w), "+v"(eb.x), "+v"(eb.y), "+v"(eb.z), "+v"(eb.w),
                       "+v"(f4), "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(qp0), "+v"(qx0));
@@ -334,16 +353,18 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         int n_win;
         int rank = wg_exclusive_scan(mine, lane, wave, s_scan, n_win);
         if (n_win > cap) { if (tid == 0) atomicOr(&A.cnt->overflow, 1u); return; }
+        int kw = 0;
 #pragma unroll 1
         for (int e = 0; e < 5; ++e) {
             if (!cl[e].kind) continue;
             const int64_t q = q0 + rank++;
             const int64_t c = e == 4 ? T.n_rows : s0 + 4 * tid + e;
             if (cl[e].kind == 2) write_extra(A, q, cl[e].m, T.nb_seg_begin[cl[e].nb], c, !cl[e].ns && A.desc[cl[e].nb].extra_multi());
-            else leave_to_rare(A, sorted, q, cl[e].r, cl[e].m, cl[e].nb, c);
+            else { leave_to_rare(A, sorted, q, cl[e].r, cl[e].m, cl[e].nb, c); kw += rare_counts(A, cl[e].nb, cl[e].r, cl[e].m); }
         }
         for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
         if (tid == 0) A.piece_cnt[piece_no] = n_win;
+        store_piece_counts(A, piece_no, kw, tid, &s_kw);
         return;
     }
 
@@ -725,13 +746,14 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     // ---- a window per thread ----
     const uint32_t kbits = (1u << k) - 1u;
     const FBlock B0w = s_blk[0];
+    int kw = 0;                                     // the thread's calls | their wide slot means << 16
     for (int w = tid; w < n_win; w += F_THREADS) {
         const int64_t q = q0 + w;
         const unsigned ent = s_list[w];
         if (ent & 0x8000u) {
             const FSpec &S = s_spec[ent & 0x7FFFu];
             if (S.kind == 2) write_extra(A, q, S.m, T.nb_seg_begin[S.nb], S.cr, !S.ns && A.desc[S.nb].extra_multi());
-            else leave_to_rare(A, sorted, q, S.r, S.m, S.nb, S.cr);
+            else { leave_to_rare(A, sorted, q, S.r, S.m, S.nb, S.cr); kw += rare_counts(A, S.nb, S.r, S.m); }
             continue;
         }
         const int Rc = (int)ent, R = Rc - 1;
@@ -781,6 +803,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             int64_t r = cr - 1;
             while (r > 0 && (T.flags[r] & MC_F_MODEL_N)) --r;
             leave_to_rare(A, sorted, q, r, m, B.id, cr);
+            kw += rare_counts(A, B.id, r, m);
             continue;
         }
         const uint32_t empties = ~have & kbits;
@@ -792,6 +815,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         if (too_many) info |= MC_I_TOO_MANY;
         else {
+            kw += 1 + (__popc(wide) << 16);
             wmask = rev ? wide : __brev(wide) >> (32 - k);
             info |= rev ? empties : __brev(empties) >> (32 - k);   // feature dst came from an empty slot (:186)
             if (edge) info |= MC_I_EDGE;                           // the 2k-1 context leaves the contig: Python slicing decides
@@ -812,6 +836,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     FD_STAMP(7);
     if (tid == 0) A.piece_cnt[piece_no] = n_win;                 // (what the classifier makes its stretches of)
     for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
+    store_piece_counts(A, piece_no, kw, tid, &s_kw);
     FD_STAMP(8);
 }
 

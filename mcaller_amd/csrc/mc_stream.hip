@@ -210,6 +210,7 @@ struct mc_ctx {
         Payload *sorted = nullptr;                             // the pass's payloads in record order (k1_list -> k1_emit, k1_rare_dev)
         int64_t *rare = nullptr;                               // records k1_emit leaves to k1_rare_dev
         int32_t *piece_cnt = nullptr;                          // the fused dense pass: records of every piece (k1_fused -> k2_mlp)
+        int32_t *piece_kw = nullptr;                           // ... its calls | their wide slot means << 16 (k1_fused -> the side stream's kernel)
         int64_t piece_cap = 0;
         int32_t *h_lo32 = nullptr;                             // in pack_host: the slot means' 32-bit parts, the wide ones' high halves,
         uint32_t *h_hi32 = nullptr;                            // the mask byte of every call (mc_calls_view)
@@ -225,6 +226,7 @@ struct mc_ctx {
         int64_t cap = 0, n_nb = 0;
         int k = 0;
         bool used = false, copying = false, timed = true;
+        bool one_kernel = false;   // the side stream ran as one kernel (k2_mlp<.., PACK>): its end is ev_done
         int fused_room = 0;        // > 0: the pass ran as ONE kernel (k1_fused) with this many record slots per piece -- holes in between
         int64_t slots = 0;         // ... record slots in all
         int slot = -1;             // table slot the pass scans
@@ -1483,7 +1485,7 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
                       hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
                       const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr, int fused_room = 0,
-                      int32_t *piece_cnt = nullptr) {
+                      int32_t *piece_cnt = nullptr, int32_t *piece_kw = nullptr) {
     const DevTable &T = c->T;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
@@ -1492,6 +1494,7 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
     A.piece_cnt = piece_cnt;
+    A.piece_kw = fused_room > 0 ? piece_kw : nullptr;
     const bool dense = dense_reference(c);
     static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
     const bool runs = dense && !no_runs;
@@ -1740,7 +1743,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
     if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_PAD * PACK_WGS)) return -10;
     if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
     b.piece_cap = cap / 16 + 64;                               // (a piece has at least 48 slots: mc_fused_room)
-    if (dev_alloc(b.dev_allocs, &b.piece_cnt, (size_t)b.piece_cap)) return -10;
+    if (dev_alloc(b.dev_allocs, &b.piece_cnt, (size_t)b.piece_cap) || dev_alloc(b.dev_allocs, &b.piece_kw, (size_t)b.piece_cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
     b.H.capacity = cap;
@@ -1771,13 +1774,33 @@ static int enqueue_k2(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A) {
     return 0;
 }
 
+// The side stream of a pass as ONE kernel (k2_mlp<.., PACK>, mc_classify.hip): the windows left to the row-by-row walk, the MLP,
+// the packing -- every workgroup for its own records.  -> 1: enqueued (ev_done rides on it); 0: not for this pass (enqueue_k2 +
+// enqueue_pack: k1_rare_dev, the context's classifier, k_pack_count / k_pack)
+static int enqueue_side(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A, bool *done) {
+    const DevTable &T = c->T;
+    hipStream_t st = c->side_stream;
+    *done = false;
+    const bool other = c->F.left != nullptr || c->Sc.params != nullptr;
+    if (b.prm.score && (other || !c->M.W1)) return 0;
+    HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
+    if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
+    if (!mc_launch_side(c->M, other, c->n_cu, st, A, b.sorted, T.seg_read, c->qual, b.cap, b.prm.score ? 1 : 0, b.pack, b.close32 ? 1 : 0, b.st_dev,
+                        b.fused_room, b.fused_room > 0 ? b.slots / b.fused_room : 0, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr))
+        return 0;           // (the wait and the event stay where they are: harmless in front of the three kernels)
+    if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_done, st));
+    HIP_TRY(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
 // Packing of a pass whose classifier has been enqueued (ev_k2_end recorded): what mc_wait_records_begin copies out.
 // count: the chunk counts are not there yet (the emit counts them as it writes the records, except k1_emit_runs)
 static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b, bool count) {
     hipStream_t s2 = c->side_stream;
     const int holes = b.fused_room > 0 ? 1 : 0;
     if (count) mc_launch_pack_count(b.O, b.cnt, b.k, b.chunk_cnt, holes, s2);
-    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev, holes, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
+    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev, holes, count ? 1 : 0, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
     if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_done, s2));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1851,10 +1874,14 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt)) return rc;
-    if (int rc = enqueue_k2(c, b, A)) return rc;
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt, b.piece_kw)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
-    if (int rc = enqueue_pack(c, b, A.chunk_cnt == nullptr)) return rc;
+    b.one_kernel = false;
+    if (int rc = enqueue_side(c, b, A, &b.one_kernel)) return rc;
+    if (!b.one_kernel) {
+        if (int rc = enqueue_k2(c, b, A)) return rc;
+        if (int rc = enqueue_pack(c, b, A.chunk_cnt == nullptr)) return rc;
+    }
     // (nothing goes on the copy stream here: it is a FIFO, and a wait for THIS pass queued now would hold back the
     // copy-out of the previous pass, which mc_wait_records enqueues later)
     HIP_TRY(hipGetLastError());
@@ -1989,7 +2016,7 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
         HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_scan_start));
         HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_emit_end));     // scan + ordering + emit, one span
         t_emit = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_k2_start, b.ev_k2_end));
+        HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_k2_start, b.one_kernel ? b.ev_done : b.ev_k2_end));
         c->times[0] = t_k0; c->times[1] = t_scan; c->times[2] = t_emit; c->times[3] = t_k2;
         c->times[4] = t_k0 + t_scan + t_emit + t_k2;
     }
