@@ -740,3 +740,69 @@ def test_first_second_and_later_passes_over_one_table(dev, motif, broken):
             H.assert_records_equal(dev.wait(), orc, 6)
             dev.select_table(slot, as_new=True)        # ... and everything again, as if the table had just arrived
     dev.sync()
+
+
+def with_stalls(table, n_stalls, reps, seed):
+    """Rows repeated `reps` times in place (a pore that stalls: dozens of events at one position), event indices renumbered
+    monotone in every read's own direction: windows longer than the emit looks back (64 rows) and, from 129 repeats on, slots of more
+    than 128 events (NumPy's pairwise recursion proper)."""
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(seed)
+    n = table.n_rows
+    count = np.ones(n, dtype=np.int64)
+    ok = np.flatnonzero((table.flags & (_lib.F_MODEL_N | _lib.F_SEG_START)) == 0)
+    picks = rng.choice(ok, size=n_stalls, replace=False)
+    count[picks] = rng.choice(reps, size=n_stalls)
+    sb = table.seg_row_begin
+    new_begin = np.concatenate([[0], np.cumsum(count)])[sb]
+    idx = np.repeat(table.event_idx, count).astype(np.int64)
+    for s in range(table.n_seg):
+        a, b = int(new_begin[s]), int(new_begin[s + 1])
+        if b - a < 2:
+            continue
+        up = table.event_idx[sb[s] + 1] > table.event_idx[sb[s]]
+        idx[a:b] = idx[a] + (np.arange(b - a) if up else -np.arange(b - a))
+        if idx[a:b].min() < 0:
+            idx[a:b] -= idx[a:b].min()
+    fl = np.repeat(table.flags, count)
+    first = np.concatenate([[True], np.diff(np.repeat(np.arange(n), count)) != 0])
+    fl[~first] &= np.uint8(0xFF ^ (_lib.F_SEG_START | _lib.F_NAME_START))
+    return _lib.Table(np.repeat(table.pos, count), np.repeat(table.event_e4, count), np.repeat(table.model_e4, count), idx.astype(np.int32), fl,
+                      new_begin.astype(np.int64), table.seg_read, table.seg_contig, table.n_reads, read_names=table.read_names)
+
+
+@pytest.mark.parametrize('motif,reps,skip,expect_rerun', [('GATC', (40, 70, 100, 110), 0, False), ('GATC', (70, 90), 2, False),
+                                                          ('GATC', (70, 130, 300), 0, True), ('A', (40, 60), 0, False),
+                                                          ('A', (70, 140), 1, True)])
+def test_windows_left_to_the_row_by_row_walk_in_pipelined_passes(dev, motif, reps, skip, expect_rerun):
+    """Pipelined, scored passes over reads with stalls: windows of more than 64 rows are left to the row-by-row walk, which the side
+    stream's one kernel does for its own records -- their rows in the packed block were counted by the emit from the walk's own rule
+    (calls: a row; too many skips: none) -- and a slot of more than 128 events marks the pass, which is repeated by the synchronous
+    path.  Records (slot means bit for bit, probabilities) as the oracle's; sparse motif (k1_emit) and dense (k1_fused)."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    codes = synth.genome(length=200000, seed=23)
+    ref = synth.SynthRef(codes, motif=motif)
+    table, qual = synth.make_table(250000, seed=37, codes=codes, read_len=(1500, 6000))
+    table = with_stalls(table, 3000 if motif == 'GATC' else 400, reps, seed=len(reps) + skip)     # (a sparse motif: a stall in seventy lies in a window)
+    arrays = ref.device_arrays()
+    _, weights, _, soc = ec.submodel_setup(H.load_modelset('r95'), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, skip, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    dev.set_reference(arrays)
+    dev.set_mlp(weights, soc)
+    slot = dev.upload_table_async(table, qual)
+    for as_new in (False, True):
+        if as_new:
+            dev.select_table(slot, as_new=True)
+        dev.run_async(6, skip, 0.0, score=True)
+        dev.run_async(6, skip, 0.0, score=True)
+        for _ in range(2):
+            rec = dev.wait()
+            assert bool(dev.last_pass_info()[1]) == expect_rerun
+            H.assert_records_equal(rec, orc, 6, prob_tol=1e-6)
+    dev.run_async(6, skip, 0.0, score=False)                     # features only: the walk and the packing without a classifier
+    rec = dev.wait()
+    orc.prob[:orc.n] = np.nan
+    rec.prob[:rec.n] = np.nan
+    H.assert_records_equal(rec, orc, 6)
