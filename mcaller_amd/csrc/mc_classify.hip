@@ -237,8 +237,10 @@ struct SidePack {
 struct NoPack {};
 // (ROOMY: 128 registers a lane and one workgroup per CU -- the side kernel of a sparse motif, where a CU gets one workgroup anyway and
 // a stretch: the packing's and the walk's registers fit beside the hidden layer's without a spill)
-template <int NI_T, bool FAST, bool PACK = false, bool ROOMY = false>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAST && !ROOMY) ? 8 : 4, (FAST && !ROOMY) ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+// (TH: threads per workgroup = records per stretch.  512 for the side kernel of a dense reference: two workgroups per CU at 128
+// registers a lane -- one's loads and packing behind the other's hidden layer)
+template <int NI_T, bool FAST, bool PACK = false, bool ROOMY = false, int TH = K2_THREADS>
+__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !ROOMY) ? 8 : 4, (FAST && !ROOMY) ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
@@ -256,21 +258,23 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
     } else if (overflow && *overflow) return;   // (pipelined pass with record buffers too small: it is repeated)
     if (n_dev) n = min(n, (int64_t)*n_dev);     // the count is on the device only (pipelined passes): n is the capacity
     K2_WALL(0);
+    constexpr int KB = TH, KW = TH / 64, KFIX = TH + 256;      // records per stretch, waves, room for the records to evaluate again
+    static_assert(KW >= 4 && KW % 4 == 0, "four unit quarters");
     constexpr int NX = NI_T ? NI_T : MC_MAX_K + 1;
     const int H = M.n_hidden, NI = NI_T ? NI_T : M.n_in, S = NI + 2, NM = min(M.n_models, K2_MAXM);
     using part_t = std::conditional_t<FAST, float, double>;
-    __shared__ uint16_t s_list[K2_MAXM][K2B];   // per sub-model: its records (their places in the stretch), in the order of the waves' claims
+    __shared__ uint16_t s_list[K2_MAXM][KB];   // per sub-model: its records (their places in the stretch), in the order of the waves' claims
     __shared__ int s_tot[2][K2_MAXM];           // ... their number: one set per stretch, the other is cleared meanwhile
-    __shared__ double s_q[K2B];                 // read quality of the stretch's records
-    __shared__ part_t s_part[4][K2B];           // partial output sums of the four unit quarters, by the record's place
-    __shared__ float s_marg[FAST ? K2B : 1];    // the fast forward: how far from the fp64 probability the record's may lie
-    __shared__ unsigned long long s_fixlist[FAST ? K2_FIX : 1];    // ... the records to evaluate again in fp64: record | sub-model << 56
+    __shared__ double s_q[KB];                 // read quality of the stretch's records
+    __shared__ part_t s_part[4][KB];           // partial output sums of the four unit quarters, by the record's place
+    __shared__ float s_marg[FAST ? KB : 1];    // the fast forward: how far from the fp64 probability the record's may lie
+    __shared__ unsigned long long s_fixlist[FAST ? KFIX : 1];    // ... the records to evaluate again in fp64: record | sub-model << 56
     __shared__ int s_nfix;
-    __shared__ int32_t s_slot[K2B];             // a stretch made of pieces: the slot of every record, from the stretch's first piece's first slot
-    __shared__ uint32_t s_fixrow[(FAST && PACK) ? K2_FIX : 1];   // PACK: ... and their rows in the packed block
-    __shared__ int2 s_pk[PACK ? 2 : 1][PACK ? K2_WAVES : 1];    // PACK: a wave's calls and their wide slot means in the stretch (two sets, like s_tot)
+    __shared__ int32_t s_slot[KB];             // a stretch made of pieces: the slot of every record, from the stretch's first piece's first slot
+    __shared__ uint32_t s_fixrow[(FAST && PACK) ? KFIX : 1];   // PACK: ... and their rows in the packed block
+    __shared__ int2 s_pk[PACK ? 2 : 1][PACK ? KW : 1];    // PACK: a wave's calls and their wide slot means in the stretch (two sets, like s_tot)
     __shared__ unsigned long long s_base[PACK ? 2 : 1][4];      // PACK: calls, wide slot means, records in front of the stretch (two sets)
-    __shared__ unsigned long long s_red[PACK ? 6 : 1][PACK ? K2_WAVES : 1];
+    __shared__ unsigned long long s_red[PACK ? 6 : 1][PACK ? KW : 1];
     __shared__ unsigned long long s_lay[PACK ? 8 : 1];     // PACK: where the packed block's columns begin (byte offsets): looked up where a stretch is packed,
                                                            // not carried through the hidden layer in registers the weights need
     const int tid = threadIdx.x, lane = tid & 63;
@@ -281,8 +285,11 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
     // Which quarter of the hidden units a wave takes: the one of the SIMD it runs on, so that the four SIMDs of the CU carry
     // a quarter of the arithmetic each whatever the number of groups (the waves of one SIMD share its groups).  (If the
     // workgroup's waves did not land on all four SIMDs: by wave number.)
-    __shared__ uint32_t s_simd_of_wave[K2_WAVES / 4];       // a byte per wave
+    __shared__ uint32_t s_simd_of_wave[KW / 4];       // a byte per wave
     const int simd = (int)__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3;      // HW_ID[5:4]
+    // (the sub-model of a record's context character: from LDS, not a load behind the record's info word)
+    __shared__ uint8_t s_soc[256];
+    if (tid < 256) s_soc[tid] = M.sub_of_char ? M.sub_of_char[tid] : (uint8_t)255;
     if (lane == 0) reinterpret_cast<uint8_t *>(s_simd_of_wave)[wave] = (uint8_t)simd;
     if (tid < 2 * K2_MAXM) (&s_tot[0][0])[tid] = 0;
     if (tid == 0) s_nfix = 0;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
     {
         uint32_t per_simd = 0;                  // a byte per SIMD: its waves
         int slot = 0;                           // waves of this wave's SIMD with a smaller number
-        for (int w4 = 0; w4 < K2_WAVES / 4; ++w4) {
+        for (int w4 = 0; w4 < KW / 4; ++w4) {
             const uint32_t four = __builtin_amdgcn_readfirstlane(s_simd_of_wave[w4]);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
         const bool by_simd = (per_simd & 0xFFu) && (per_simd & 0xFF00u) && (per_simd & 0xFF0000u) && (per_simd & 0xFF000000u);
         quarter = by_simd ? simd : wave & 3;
         g_first = by_simd ? slot : wave >> 2;
-        g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : K2_WAVES / 4;
+        g_step = by_simd ? (int)((per_simd >> (8 * simd)) & 0xFFu) : KW / 4;
     }
     const bool pieces = P.cnt != nullptr;
     const int64_t n_units = pieces ? P.n : n;                    // what the workgroups share out: pieces, or records
@@ -316,18 +323,30 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
     if constexpr (PACK) {
         unsigned long long v[6] = {0, 0, 0, 0, 0, 0};           // calls, wide, records: in all; in front of the range
         if (pieces) {
-            for (int64_t j = tid; j < P.n; j += K2_THREADS) {
-                const unsigned long long c = (unsigned long long)min(max(P.cnt[j], 0), P.room);
-                const uint32_t kw = (uint32_t)SP.A.piece_kw[j];
-                v[0] += kw & 0xFFFFu; v[1] += kw >> 16; v[2] += c;
-                if (j < lo) { v[3] += kw & 0xFFFFu; v[4] += kw >> 16; v[5] += c; }
+            // (one word per piece: records | calls << 9 | wide slot means << 18; thirty-two pieces per thread and turn, eight 16-byte
+            // loads side by side: a turn is a round trip, and a table of 10^8 rows has 10^5 pieces -- a piece at a time this took a
+            // workgroup 45-85 us.  The array has room behind the last piece)
+            for (int64_t j0 = 32 * (int64_t)tid; j0 < P.n; j0 += 32 * TH) {
+                int4 k4[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) k4[e] = *reinterpret_cast<const int4 *>(SP.A.piece_kw + min(j0 + 4 * e, (P.n - 1) & ~(int64_t)3));
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int64_t j = j0 + e;
+                    if (j >= P.n) continue;
+                    const int4 kk = k4[e >> 2];
+                    const uint32_t kw = (uint32_t)((e & 3) == 0 ? kk.x : (e & 3) == 1 ? kk.y : (e & 3) == 2 ? kk.z : kk.w);
+                    const uint32_t c = kw & 511u, kept = (kw >> 9) & 511u, wide = kw >> 18;
+                    v[0] += kept; v[1] += wide; v[2] += c;
+                    if (j < lo) { v[3] += kept; v[4] += wide; v[5] += c; }
+                }
             }
         } else {
             // (the emit counted per packing chunk: the ranges are whole chunks)
             const int64_t per_c = (n + PACK_WGS - 1) / PACK_WGS;
             const int c0 = (int)((int64_t)blockIdx.x * PACK_WGS / gridDim.x), c1 = (int)((int64_t)(blockIdx.x + 1) * PACK_WGS / gridDim.x);
             lo = min(n, c0 * per_c); hi = min(n, c1 * per_c);
-            for (int j = tid; j < PACK_WGS; j += K2_THREADS) {
+            for (int j = tid; j < PACK_WGS; j += TH) {
                 const unsigned long long kk = SP.A.chunk_cnt[PACK_PAD * j], ww = SP.A.chunk_cnt[PACK_PAD * j + 1];
                 v[0] += kk; v[1] += ww;
                 if (j < c0) { v[3] += kk; v[4] += ww; }
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
         const int64_t n_rare = (int64_t)SP.A.cnt->n_rare;
         if (n_rare > 0) {
             const int64_t rlo = pieces ? lo * P.room : lo, rhi = pieces ? hi * P.room : hi;
-            for (int64_t i = tid; i < n_rare; i += K2_THREADS) {
+            for (int64_t i = tid; i < n_rare; i += TH) {
                 const int64_t q = SP.A.rare_list[i];
                 // (a slot of more than 128 events -- NumPy's recursion proper, 1.4 KB of stack per lane: not in this kernel; the pass
                 // is marked like one with irregular reads and repeated by the synchronous path)
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
     // the records whose printed digits (or label) could depend on the precision: again in fp64, a wave per record, the hidden
     // units across its lanes (the quality is fetched again: a handful of records per stretch)
     auto again_in_fp64 = [&](int n_fix) {
-        for (int f = wave; f < n_fix; f += K2_WAVES) {
+        for (int f = wave; f < n_fix; f += KW) {
             const unsigned long long ent = s_fixlist[FAST ? f : 0];
             const int64_t r = (int64_t)(ent & ((1ull << 56) - 1ull));
             const int mdl = (int)(ent >> 56);
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
         int n_here, np_here = 1, my_slot = tid;
         int64_t slot0 = base;                   // record of the stretch's place `off`: slot0 + (pieces ? s_slot[off] : off)
         if (pieces) {
-            // the next pieces that hold at most K2B records together (a piece holds at most its room, and that is below K2B)
+            // the next pieces that hold at most KB records together (a piece holds at most its room, and that is below KB)
             const bool have = lane < 16 && base + lane < hi;
             const int c = have ? min(max(P.cnt[base + lane], 0), P.room) : 0;
             int incl = c;
@@ -430,8 +449,8 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
                 const int v = __shfl_up(incl, o);
                 if (lane >= o) incl += v;
             }
-            np_here = max(1, __popcll(__ballot(have && incl <= K2B)));
-            n_here = min(__builtin_amdgcn_readlane(incl, np_here - 1), K2B);
+            np_here = max(1, __popcll(__ballot(have && incl <= KB)));
+            n_here = min(__builtin_amdgcn_readlane(incl, np_here - 1), KB);
             int before = 0, j = 0;              // the thread's piece: the last one with at most tid records in front of it
 #pragma unroll
             for (int t = 0; t < 15; ++t) {
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
             my_slot = j * P.room + (tid - before);
             slot0 = base * (int64_t)P.room;
             s_slot[tid] = my_slot;
-        } else n_here = (int)min((int64_t)K2B, hi - base);
+        } else n_here = (int)min((int64_t)KB, hi - base);
         // ---- A: the thread's record, and the lists
         // (the read quality is a chain of three dependent loads -- segment, read, quality)
         const int64_t r = slot0 + my_slot;
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
                 bool scored = !(inf & (MC_I_TOO_MANY | MC_I_EDGE));
                 if constexpr (PACK) scored = scored && SP.score != 0;
                 if (scored) {
-                    mi = M.sub_of_char[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
+                    mi = s_soc[(inf >> MC_I_NEXT_SHIFT) & 0xFFu];
                     qv = qual[seg_read[seg]];
                 }
             }
@@ -638,7 +657,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
                 unsigned long long row = s_base[PACK ? buf : 0][0] + (unsigned)__popcll(kb & below), wpos = s_base[PACK ? buf : 0][1] + (unsigned)(w_incl - nw);
                 unsigned kept_all = 0, wide_all = 0;
 #pragma unroll
-                for (int w = 0; w < K2_WAVES; ++w) {
+                for (int w = 0; w < KW; ++w) {
                     const int2 c = s_pk[PACK ? buf : 0][PACK ? w : 0];
                     if (w < wave) { row += (unsigned)c.x; wpos += (unsigned)c.y; }
                     kept_all += (unsigned)c.x; wide_all += (unsigned)c.y;
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu((FAS
                 }
             }
         }
-        base += pieces ? np_here : K2B;
+        base += pieces ? np_here : KB;
         buf ^= 1;
         K2_STAMP(6);
         K2_WALL(10);
@@ -1071,7 +1090,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
 #define MC_K2_WG_PER_CU 1
 #endif
 #ifndef MC_SIDE_WGS_SPARSE
-#define MC_SIDE_WGS_SPARSE 64
+#define MC_SIDE_WGS_SPARSE 128
 #endif
 #ifndef MC_K2_WG_MANY          // ... where there are millions of records (the fast forward)
 #define MC_K2_WG_MANY 2
@@ -1134,32 +1153,35 @@ bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_
     if (off || cap <= 0) return false;
     if (score && (other_classifier || !M.W1)) return false;
     const bool by_piece = piece_room > 0;
-    if (by_piece ? (piece_room >= K2B || !A.piece_kw || !A.piece_cnt) : !A.chunk_cnt) return false;
+    constexpr int TH_SIDE = MC_SIDE_MAX_ROOM;
+    if (by_piece ? (piece_room >= TH_SIDE || !A.piece_kw || !A.piece_cnt) : !A.chunk_cnt) return false;
     SidePack SP;
     SP.A = A; SP.sorted = sorted; SP.out = out; SP.host_status = host_status; SP.close32 = close32; SP.score = score;
     const K2Pieces P{by_piece ? A.piece_cnt : nullptr, piece_room, n_pieces};
     const bool fast = score && M.fast && M.wp32;
-    // (a dense reference: two workgroups per CU, as the classifier alone; a sparse motif: a power of two of them -- the ranges are whole
-    // packing chunks -- and FEW: the kernel runs beside the next pass's scan, and what counts is how little of the chip it takes from
-    // it, not when it is through.  10^8 rows, 2 x 10^5 records, pipelined step: 256 workgroups 0.2745 ms, 128 / 64 / 32: 0.2638 /
-    // 0.2637 / 0.2634; the three kernels it replaces: 0.2732)
+    // Workgroups of 512 threads (a stretch: 512 records) at 128 registers a lane, two to a CU -- with 1024 threads and 64 registers
+    // the packing spills inside the stretch loop (dense: 2.2 ms per 10^8 rows against 1.2), and one workgroup of 1024 per CU is no
+    // faster than two of 512.  A dense reference: two per CU, the pieces shared out evenly.  A sparse motif: a power of two of them --
+    // the ranges are whole packing chunks -- and FEW: the kernel runs beside the next pass's scan, and what counts is how little of
+    // the chip it takes from it, not when it is through.  (10^8 rows, 2 x 10^5 records, pipelined step: 256 workgroups of 1024
+    // threads 0.2745 ms, 128 / 64 / 32 of them 0.2638 / 0.2637 / 0.2634; of 512 threads: 256 / 128 / 64 / 32 0.2602 / 0.2570 /
+    // 0.2633 / 0.2778; the three kernels this one replaces: 0.2732.  MCALLER_SIDE_GRID: another number)
     unsigned grid;
-    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * (fast ? MC_K2_WG_MANY : MC_K2_WG_PER_CU)));
-    else { grid = 1; while (grid * 2 <= (unsigned)std::min<int64_t>(MC_SIDE_WGS_SPARSE, (int64_t)n_cu * MC_K2_WG_PER_CU)) grid *= 2; }
+    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * 2));
+    else {
+        static const int grid_env = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;
+        const int want = grid_env > 0 ? grid_env : MC_SIDE_WGS_SPARSE;
+        grid = 1;
+        while (grid * 2 <= (unsigned)std::min<int64_t>(std::min(want, PACK_WGS), (int64_t)n_cu * 2)) grid *= 2;
+    }
     const unsigned long long *n_dev = (const unsigned long long *)&A.cnt->n_records;
     const unsigned int *overflow = (const unsigned int *)&A.cnt->overflow;
-#define MC_SIDE_LAUNCH(NI, FA, RO) hipExtLaunchKernelGGL((k2_mlp<NI, FA, true, RO>), dim3(grid), dim3(K2_THREADS), 0, st, nullptr, stop, 0, M, (const double *)A.O.feats, A.k, \
+#define MC_SIDE_LAUNCH(NI, FA) hipExtLaunchKernelGGL((k2_mlp<NI, FA, true, true, TH_SIDE>), dim3(grid), dim3(TH_SIDE), 0, st, nullptr, stop, 0, M, (const double *)A.O.feats, A.k, \
         (const int32_t *)A.O.site_seg, seg_read, qual, (const uint32_t *)A.O.info, (const uint8_t *)nullptr, cap, A.O.prob, n_dev, overflow, P, SP)
-    // (a dense reference too: at 64 registers a lane the packing spills inside the stretch loop -- 2.2 ms per 10^8 rows against 1.3;
-    // MCALLER_SIDE_ROOMY=0: that instance, two workgroups per CU.  MCALLER_SIDE_GRID: workgroups for a sparse motif, a power of two)
-    static const bool roomy_dense = !(getenv("MCALLER_SIDE_ROOMY") && atoi(getenv("MCALLER_SIDE_ROOMY")) == 0);
-    if (by_piece && roomy_dense) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu));
-    static const int grid_sparse = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;
-    if (!by_piece && grid_sparse > 0) { grid = 1; while (grid * 2 <= (unsigned)std::min(grid_sparse, PACK_WGS)) grid *= 2; }
-    if (score && M.n_in == 7 && fast) { if (by_piece && !roomy_dense) MC_SIDE_LAUNCH(7, true, false); else MC_SIDE_LAUNCH(7, true, true); }
-    else if (score && M.n_in == 7) MC_SIDE_LAUNCH(7, false, false);
-    else if (fast) { if (by_piece) MC_SIDE_LAUNCH(0, true, false); else MC_SIDE_LAUNCH(0, true, true); }
-    else MC_SIDE_LAUNCH(0, false, false);
+    if (score && M.n_in == 7 && fast) MC_SIDE_LAUNCH(7, true);
+    else if (score && M.n_in == 7) MC_SIDE_LAUNCH(7, false);
+    else if (fast) MC_SIDE_LAUNCH(0, true);
+    else MC_SIDE_LAUNCH(0, false);
 #undef MC_SIDE_LAUNCH
     return true;
 }

@@ -356,6 +356,8 @@ struct __attribute__((aligned(16))) Payload {
 };
 static_assert(sizeof(Payload) == 32, "Payload layout");
 
+constexpr int MC_SIDE_MAX_ROOM = 512;   // the side stream's one kernel takes the pieces of a fused dense pass if their room is below this (a stretch of its records)
+
 struct K1Args {
     DevTable T;
     DevRef R;
@@ -377,9 +379,9 @@ struct K1Args {
     int64_t *rare_list;           // [capacity] records k1_emit leaves to k1_rare
     unsigned long long pass_no;   // what Counters.irregular_pass is set to when the pass cannot be finished by the fast path
     int32_t *piece_cnt;           // the fused dense pass (k1_fused): [pieces] records of every piece
-    int32_t *piece_kw;            // ... [pieces] of them calls (no MC_I_TOO_MANY) | their wide slot means << 16 -- the packing's counts,
-                                  // made where the records are written (windows left to the row-by-row walk: predicted, mc_rows.h);
-                                  // nullptr: nobody packs by piece
+    int32_t *piece_kw;            // ... [pieces] records | of them calls (no MC_I_TOO_MANY) << 9 | their wide slot means << 18 -- the packing's
+                                  // counts, made where the records are written (windows left to the row-by-row walk: predicted,
+                                  // mc_rows.h); rooms below MC_SIDE_MAX_ROOM slots only (the fields fit); nullptr: nobody packs by piece
     unsigned long long *chunk_cnt;  // pipelined passes: [PACK_PAD * PACK_WGS] kept records / their wide slots per chunk of the copy-out's packing
                                   // (k_pack), counted by the emit itself as it writes the records; nullptr: nobody packs (or k_pack_count counts)
 };

@@ -169,13 +169,14 @@ __device__ __forceinline__ int rare_counts(const K1Args &A, int nb, int64_t r, i
 }
 
 // the piece's calls and their wide slot means (what every thread counted of its windows) -> A.piece_kw[piece]; all threads call
-__device__ __forceinline__ void store_piece_counts(const K1Args &A, int64_t piece_no, int mine, int tid, int *s_kw) {
+__device__ __forceinline__ void store_piece_counts(const K1Args &A, int64_t piece_no, int n_win, int mine, int tid, int *s_kw) {
     if (!A.piece_kw) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if ((tid & 63) == 0 && mine) atomicAdd(s_kw, mine);
     lds_barrier();
-    if (tid == 0) A.piece_kw[piece_no] = *s_kw;
+    // (one word per piece: records | calls << 9 | wide slot means << 18 -- the side kernel is for rooms below 512 slots, so they fit)
+    if (tid == 0) A.piece_kw[piece_no] = n_win | ((*s_kw & 0xFFFF) << 9) | ((*s_kw >> 16) << 18);
 }
 
 // exclusive prefix of `mine` over the workgroup's threads (and the total); s_w: F_THREADS / 64 words of LDS
@@ -364,7 +365,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
         if (tid == 0) A.piece_cnt[piece_no] = n_win;
-        store_piece_counts(A, piece_no, kw, tid, &s_kw);
+        store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw);
         return;
     }
 
@@ -836,7 +837,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     FD_STAMP(7);
     if (tid == 0) A.piece_cnt[piece_no] = n_win;                 // (what the classifier makes its stretches of)
     for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
-    store_piece_counts(A, piece_no, kw, tid, &s_kw);
+    store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw);
     FD_STAMP(8);
 }
 

@@ -774,11 +774,22 @@ def with_stalls(table, n_stalls, reps, seed):
 @pytest.mark.parametrize('motif,reps,skip,expect_rerun', [('GATC', (40, 70, 100, 110), 0, False), ('GATC', (70, 90), 2, False),
                                                           ('GATC', (70, 130, 300), 0, True), ('A', (40, 60), 0, False),
                                                           ('A', (70, 140), 1, True)])
-def test_windows_left_to_the_row_by_row_walk_in_pipelined_passes(dev, motif, reps, skip, expect_rerun):
+def test_windows_left_to_the_row_by_row_walk_in_pipelined_passes(motif, reps, skip, expect_rerun):
     """Pipelined, scored passes over reads with stalls: windows of more than 64 rows are left to the row-by-row walk, which the side
     stream's one kernel does for its own records -- their rows in the packed block were counted by the emit from the walk's own rule
     (calls: a row; too many skips: none) -- and a slot of more than 128 events marks the pass, which is repeated by the synchronous
     path.  Records (slot means bit for bit, probabilities) as the oracle's; sparse motif (k1_emit) and dense (k1_fused)."""
+    from mcaller_amd import synth
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.device import Device
+    dev = Device(0)             # (a context of its own: what an earlier test's pass ran out of -- room per piece, doubled since -- decides which kernels run)
+    try:
+        _windows_left_to_the_walk(dev, motif, reps, skip, expect_rerun)
+    finally:
+        dev.close()
+
+
+def _windows_left_to_the_walk(dev, motif, reps, skip, expect_rerun):
     from mcaller_amd import synth
     from mcaller_amd import extract_contexts as ec
     codes = synth.genome(length=200000, seed=23)

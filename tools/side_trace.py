@@ -38,3 +38,21 @@ for i, nm in enumerate(names):
         continue
     v = (col[ok] - t0) * 10
     print('%-32s min %7d  mean %7d  p90 %7d  max %7d ns' % (nm, v.min(), v.mean(), np.percentile(v, 90), v.max()))
+
+# every stretch of wave 0 of the first 256 workgroups (K2_TL): begin, A done, behind the first barrier, B done (wave 0's groups), behind
+# the second barrier, C + packing done
+tl = np.zeros(256 * 24 * 8, dtype=np.uint64)
+L.mc_debug_k2_timeline.argtypes = [C.c_void_p, C.c_int64]
+if L.mc_debug_k2_timeline(tl.ctypes.data, tl.size) == 0:
+    tl = tl.reshape(256, 24, 8).astype(np.int64) * 10
+    ok = (tl[:, :, 0] > 0) & (tl[:, :, 5] > 0)
+    names = ['A (loads, lists)', 'wait at barrier 1', 'B (own groups)', 'wait at barrier 2', 'C + packing']
+    print('stretches with stamps: %d; mean ns per phase of a stretch:' % int(ok.sum()))
+    for i, nm in enumerate(names):
+        d = (tl[:, :, i + 1] - tl[:, :, i])[ok]
+        print('   %-20s mean %7.0f  p50 %7.0f  p90 %7.0f' % (nm, d.mean(), np.percentile(d, 50), np.percentile(d, 90)))
+    d = (tl[:, :, 5] - tl[:, :, 0])[ok]
+    print('   %-20s mean %7.0f' % ('stretch', d.mean()))
+    gap = (tl[:, 1:, 0] - tl[:, :-1, 5])[ok[:, 1:] & ok[:, :-1]]
+    if gap.size:
+        print('   %-20s mean %7.0f' % ('between stretches', gap.mean()))
