@@ -81,6 +81,7 @@ struct FSpec {                      // a special closer's window: finished by k1
     int64_t r, cr;                  // last row of the window, closing row
     int32_t m, nb;
     uint8_t kind, ns;               // (the record goes in front of the window its block's first run closes: s_bfirst)
+    uint8_t counts;                 // kind 1: what the window adds to the piece's calls (the walk's prediction, made beside the means: 0 or 1)
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -168,15 +169,23 @@ __device__ __forceinline__ int rare_counts(const K1Args &A, int nb, int64_t r, i
     return window_too_many(A, nb, r, m) ? 0 : (1 | (A.k << 16));
 }
 
-// the piece's calls and their wide slot means (what every thread counted of its windows) -> A.piece_kw[piece]; all threads call
-__device__ __forceinline__ void store_piece_counts(const K1Args &A, int64_t piece_no, int n_win, int mine, int tid, int *s_kw) {
+// the piece's calls and their wide slot means (what every thread counted of its windows) -> A.piece_kw[piece]; all threads call.
+// No barrier: a wave adds what it counted to the sum in LDS, then marks its arrival; the wave that arrives last finds every sum in
+// (a wave's LDS operations execute in order) and stores the word.
+__device__ __forceinline__ void store_piece_counts(const K1Args &A, int64_t piece_no, int n_win, int mine, int tid, int *s_kw, int *s_arrived) {
     if (!A.piece_kw) return;
+    if (__ballot(mine != 0)) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((tid & 63) == 0 && mine) atomicAdd(s_kw, mine);
-    lds_barrier();
-    // (one word per piece: records | calls << 9 | wide slot means << 18 -- the side kernel is for rooms below 512 slots, so they fit)
-    if (tid == 0) A.piece_kw[piece_no] = n_win | ((*s_kw & 0xFFFF) << 9) | ((*s_kw >> 16) << 18);
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    }
+    if ((tid & 63) == 0) {
+        if (mine) atomicAdd(s_kw, mine);
+        if (atomicAdd(s_arrived, 1) == F_THREADS / 64 - 1) {
+            const int kw = atomicAdd(s_kw, 0);
+            // (one word per piece: records | calls << 9 | wide slot means << 18 -- the side kernel is for rooms below 512 slots, so they fit)
+            A.piece_kw[piece_no] = n_win | ((kw & 0xFFFF) << 9) | ((kw >> 16) << 18);
+        }
+    }
 }
 
 // exclusive prefix of `mine` over the workgroup's threads (and the total); s_w: F_THREADS / 64 words of LDS
@@ -215,6 +224,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[(FR + 63) / 64 + 2];    // closed windows of every 64 consecutive runs
     __shared__ uint16_t s_heavy[4 * F_HEAVY];        // per wave: its runs of more than one event
     __shared__ int s_nblk, s_anyspec, s_wheads[F_THREADS / 64], s_wins[F_THREADS / 64], s_scan[F_THREADS / 64];
+    __shared__ int s_arrived;                   // waves that have added their counts to s_kw
     __shared__ int s_kw;                        // the piece's calls (records without MC_I_TOO_MANY) | their wide slot means << 16: the packing's counts
     __shared__ unsigned s_over;                 // Counters.overflow as the workgroup's first wave saw it: ONE answer for all waves
     __shared__ int2 s_wlast[F_THREADS / 64];    // a wave's last row in a run: (row, position), row -1: none
@@ -301,7 +311,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (over && at < F_MAXB) s_blk[at] = fb;
         if (lane <= F_MAXB) s_bfirst[lane] = -1;
         if (lane < (FR + 63) / 64 + 2) s_cnt[lane] = 0;
-        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; s_over = overflow; s_kw = 0; }
+        if (lane == 0) { s_nblk = more_behind ? F_MAXB + 1 : n; s_anyspec = 0; s_over = overflow; s_kw = 0; s_arrived = 0; }
     }
     asm volatile("" : "+v"(p4.x), "+v"(p4.y), "+v"(p4.z), "+v"(p4.w), "+v"(ea.x), "+v"(ea.y), "+v"(ea.z), "+v"(ea.w), "+v"(eb.x), "+v"(eb.y), "+v"(eb.z), "+v"(eb.w),
                       "+v"(f4), "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(qp0), "+v"(qx0));
@@ -365,7 +375,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         }
         for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
         if (tid == 0) A.piece_cnt[piece_no] = n_win;
-        store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw);
+        store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw, &s_arrived);
         return;
     }
 
@@ -548,7 +558,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         const int j = tid;
         FSpec e1, e2;
         e1.kind = e2.kind = 0;
-        e1.ns = e2.ns = 0; e1.r = e2.r = e1.cr = e2.cr = 0; e1.m = e2.m = e1.nb = e2.nb = 0;
+        e1.ns = e2.ns = 0; e1.r = e2.r = e1.cr = e2.cr = 0; e1.m = e2.m = e1.nb = e2.nb = 0; e1.counts = e2.counts = 0;
         if (j < nblk) {
             const FBlock &B = s_blk[j];
             if (!(B.xflags & 0x80u) && B.end > i_piece) {            // (not filtered; overlaps the piece)
@@ -587,6 +597,9 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
             const Closed cl = closed_by(A, T.n_rows, T.n_nb, 0);
             if (cl.kind) { e1.kind = (uint8_t)cl.kind; e1.r = cl.r; e1.cr = T.n_rows; e1.m = cl.m; e1.nb = cl.nb; e1.ns = 1; }
         }
+        // (will the window the walk finishes be a call?  Asked HERE, beside the others' means: in the windows phase the walk's round
+        // trips would be the workgroup's)
+        if (e1.kind == 1) e1.counts = rare_counts(A, e1.nb, e1.r, e1.m) ? 1 : 0;
         s_spec[2 * j] = e1;
         if (j < nblk) s_spec[2 * j + 1] = e2;
         if (e1.kind | e2.kind) s_anyspec = 1;
@@ -754,7 +767,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
         if (ent & 0x8000u) {
             const FSpec &S = s_spec[ent & 0x7FFFu];
             if (S.kind == 2) write_extra(A, q, S.m, T.nb_seg_begin[S.nb], S.cr, !S.ns && A.desc[S.nb].extra_multi());
-            else { leave_to_rare(A, sorted, q, S.r, S.m, S.nb, S.cr); kw += rare_counts(A, S.nb, S.r, S.m); }
+            else { leave_to_rare(A, sorted, q, S.r, S.m, S.nb, S.cr); kw += S.counts ? (1 | (k << 16)) : 0; }
             continue;
         }
         const int Rc = (int)ent, R = Rc - 1;
@@ -837,7 +850,7 @@ void k1_fused(K1Args A, Payload *__restrict__ sorted, int cap) {
     FD_STAMP(7);
     if (tid == 0) A.piece_cnt[piece_no] = n_win;                 // (what the classifier makes its stretches of)
     for (int w = n_win + tid; w < cap; w += F_THREADS) A.O.info[q0 + w] = MC_I_HOLE | MC_I_TOO_MANY;
-    store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw);
+    store_piece_counts(A, piece_no, n_win, kw, tid, &s_kw, &s_arrived);
     FD_STAMP(8);
 }
 

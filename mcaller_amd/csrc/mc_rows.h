@@ -16,17 +16,33 @@ struct WindowRows { unsigned long long cnt8; int64_t ws; int stray_slot; bool bi
 __device__ __forceinline__ WindowRows window_rows(const DevTable &T, const NbDesc &d, int64_t r, int m, int k) {
     WindowRows W;
     W.cnt8 = 0; W.big = false; W.ws = r; W.stray_slot = -1;
-    // back to the first row at position >= m-k+1 (never before d.first() / the block start)
+    // back to the first row at position >= m-k+1 (never before d.first() / the block start).  Eight rows at a time, their sixteen
+    // loads side by side: a row at a time is a round trip per row, and the thread's workgroup (k1_fused: the piece; the side kernel:
+    // the stretch) waits for this walk
     const int64_t lb = max(d.row_begin, d.first());
-    for (int64_t rr = r; rr >= lb; --rr) {
-        if (T.flags[rr] & MC_F_MODEL_N) continue;
-        const int p = T.pos[rr];
-        if (p < m - k + 1) break;
-        if (p > m) continue;        // (cannot happen in a regular block; a block taken for regular on its first rows may not be)
-        const int sh = 8 * (m - p);
-        if (((W.cnt8 >> sh) & 0xFFull) >= 128ull) W.big = true;
-        else W.cnt8 += 1ull << sh;
-        W.ws = rr;
+    bool done = false;
+    for (int64_t top = r; top >= lb && !done; top -= 8) {
+        int p8[8];
+        uint32_t f8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t rr = max(top - e, lb);
+            p8[e] = T.pos[rr];
+            f8[e] = T.flags[rr];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t rr = top - e;
+            if (done || rr < lb) continue;
+            if (f8[e] & MC_F_MODEL_N) continue;
+            const int p = p8[e];
+            if (p < m - k + 1) { done = true; continue; }
+            if (p > m) continue;        // (cannot happen in a regular block; a block taken for regular on its first rows may not be)
+            const int sh = 8 * (m - p);
+            if (((W.cnt8 >> sh) & 0xFFull) >= 128ull) W.big = true;
+            else W.cnt8 += 1ull << sh;
+            W.ws = rr;
+        }
     }
     // the stray event of a palindromic first site row: first in the slot of its pseudo-position
     if (d.stray_q != NO_STRAY) {

@@ -1494,7 +1494,8 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     A.skip_thresh = prm->skip_thresh; A.tail_contig = prm->tail_contig; A.rare_list = rare_list;
     A.pass_no = pass_no;
     A.piece_cnt = piece_cnt;
-    A.piece_kw = (fused_room > 0 && fused_room < MC_SIDE_MAX_ROOM) ? piece_kw : nullptr;
+    static const bool no_kw = getenv("MCALLER_NO_PIECE_KW") != nullptr;                 // (probe: what the per-piece counts cost k1_fused; the three kernels pack)
+    A.piece_kw = (fused_room > 0 && fused_room < MC_SIDE_MAX_ROOM && !no_kw) ? piece_kw : nullptr;
     const bool dense = dense_reference(c);
     static const bool no_runs = getenv("MCALLER_NO_EMIT_RUNS") != nullptr;         // (tests: the eight-lane emit on a dense reference)
     const bool runs = dense && !no_runs;
