@@ -417,6 +417,14 @@ typedef struct mc_format_args {
  * contig, NaN probability, unknown sub-model key or complement, centre not 'M': the reference's exit/crash paths). */
 int mc_format_diffs(const mc_format_args *args, int64_t first, int32_t n_threads, char **text, int64_t *n_bytes,
                     int64_t *n_rows, int64_t *stop_at);
+/* What records [0, n) add to the reference's counters, in one pass: counts3 = records with MC_I_TOO_MANY (:239), calls with an empty
+ * slot (:234-238), records with MC_I_MULTI (:247-248) -- the SIZES of the reference's sets of (read, site) pairs if *ascending comes
+ * back 1 (every pair new: a table whose read names do not repeat; seg_read[n_seg]: the read of every segment), otherwise the caller
+ * counts distinct pairs itself -- and the positions of the calls (:235): pos_marks[p] = 1 for every call at site position p < n_marks,
+ * *pos_min / *pos_top = smallest position / largest + 1 (a caller whose marks are too short grows them and calls again).  counts3 and
+ * pos_marks may be NULL. */
+int mc_count_records(const mc_calls_view *rec, int64_t n, const int32_t *seg_read, int64_t n_seg, int64_t *counts3, int32_t *ascending,
+                     uint8_t *pos_marks, int64_t n_marks, int64_t *pos_min, int64_t *pos_top);
 /* The columns mc_wait_records does not send, rebuilt on the host (all cores): call_row_out[n] (see mc_calls_view.call_row),
  * close_row_out[n] (64-bit closing rows), feats_out[n_call_rows * k] (the slot means as doubles); any may be NULL. */
 int mc_calls_expand(const mc_calls_view *rec, int64_t n_records, int32_t k, int32_t *call_row_out, int64_t *close_row_out,

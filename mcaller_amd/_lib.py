@@ -179,6 +179,8 @@ def lib():
         L.mc_site_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.mc_mlp_fit.argtypes = [C.c_void_p, C.POINTER(FitParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 13
         L.mc_calls_expand.argtypes = [C.POINTER(CallsView), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mc_count_records.argtypes = [C.POINTER(CallsView), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p,
+                                       C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_format_diffs.argtypes = [C.POINTER(FormatArgs), C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_free.argtypes = [C.c_void_p]
@@ -633,6 +635,20 @@ class Records(object):
     def call_row(self, a):
         self._call_row = a
         self._compacted = a is not None
+
+    def count(self, n, seg_read=None, pos_marks=None):
+        """mc_count_records over records [0, n): -> ((too many skips, skips included, multiple M) or None, ascending, smallest site
+        position of a call, largest + 1); pos_marks: uint8 array, the calls' positions below its length are marked."""
+        v = self.view()
+        counts = np.zeros(3, dtype=np.int64)
+        asc, lo, top = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        if seg_read is not None:
+            seg_read = np.ascontiguousarray(seg_read, dtype=np.int32)
+        check(lib().mc_count_records(C.byref(v), int(n), _ptr(seg_read) if seg_read is not None else None,
+                                     len(seg_read) if seg_read is not None else 0, _ptr(counts) if seg_read is not None else None,
+                                     C.byref(asc), _ptr(pos_marks) if pos_marks is not None else None,
+                                     len(pos_marks) if pos_marks is not None else 0, C.byref(lo), C.byref(top)))
+        return (tuple(int(c) for c in counts) if seg_read is not None else None), bool(asc.value), int(lo.value), int(top.value)
 
     @property
     def n_calls(self):

@@ -95,6 +95,7 @@ static int copy_by_kernel(void *dst, const void *src, size_t bytes, hipStream_t 
     return 0;
 }
 constexpr size_t COPY_BY_KERNEL_MAX = (size_t)4 << 20;      // larger transfers go to the DMA engines
+constexpr size_t COPY_BY_KERNEL_MAX_STREAMING = (size_t)64 << 20;     // ... a pass's records while text is being streamed in: see mc_wait_records_begin
 
 struct TableSlot {
     DevTable T;                        // the table in the slot (pointers into the slot's allocations)
@@ -1942,7 +1943,14 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         // and on the side stream, right behind the packing: the runtime folds the streams of a process onto four hardware
         // queues, and a copy stream that shares one with the parse stream would wait behind the kernels of the shards ahead,
         // which wait for their text)
-        if (out_bytes <= COPY_BY_KERNEL_MAX && c->side_stream) {
+        // (... and while shards of TEXT are on their way -- a slot is being parsed -- also a big one: the 7 MB of a dense shard's
+        // records queued behind six shards of text, 2.5 ms each, and the host waited 0.24 s per 10^8 rows for records that were
+        // long computed.  Resident tables, nothing on the link: the DMA engines, which do not go through the shader caches)
+        static const size_t by_kernel_env = getenv("MCALLER_RECORDS_BY_KERNEL_MAX") ? (size_t)atoll(getenv("MCALLER_RECORDS_BY_KERNEL_MAX")) : 0;
+        bool text_on_the_link = false;
+        for (const TableSlot &S : c->slots) text_on_the_link = text_on_the_link || S.kp_state == 1;
+        const size_t by_kernel_max = by_kernel_env ? by_kernel_env : (text_on_the_link ? COPY_BY_KERNEL_MAX_STREAMING : COPY_BY_KERNEL_MAX);
+        if (out_bytes <= by_kernel_max && c->side_stream) {
             cs = c->side_stream;
             if (int rc = copy_by_kernel(b.pack_host, b.pack, out_bytes, cs)) return rc;
         } else HIP_TRY(hipMemcpyAsync(b.pack_host, b.pack, out_bytes, hipMemcpyDeviceToHost, cs));

@@ -183,6 +183,9 @@ class Finisher(object):
         return [line.split('\t') for line in self.text().decode('utf-8', 'surrogateescape').splitlines()]
 
     def counters(self):
+        if self._n_pos is None and self._kept_pos is None and getattr(self, '_counted_natively', False):
+            n = self._rec.n
+            self._kept_pos = self._site_pos[:n][(self._info[:n] & _I.I_TOO_MANY) == 0]
         if self._n_pos is None and self._kept_pos is not None:
             self._n_pos = len(distinct_positions(self._kept_pos))
         n_pos = len(self.pos_set) if self._n_pos is None else self._n_pos
@@ -231,7 +234,7 @@ class Finisher(object):
                                   label_meth, self.base, self.soc, tail_chrom=self.tail_chrom)
         first, done_to, stop_exc = 0, n, None
         while first < n:
-            blob, n_rows, stop = fmt.rows(first)
+            blob, n_rows, stop = fmt.rows(first, n_threads=FORMAT_THREADS[0])
             self.blobs.append(blob)
             self.num_observations += n_rows
             if stop >= n:
@@ -257,6 +260,15 @@ class Finisher(object):
         site) pairs, and records come in file order: a table whose read names do not repeat has them in strictly ascending
         order of (read id, site) -- every pair is then a new one and a set's size is a count, no sort (a one-base motif: 150 000
         records per shard, four sorts of them were most of what a shard's rows cost)."""
+        if n == self._rec.n and n > 0:
+            # (one pass in the library, without the interpreter lock -- mc_count_records; the pairs ascend unless read names repeat)
+            counts, ascending, _, _ = self._rec.count(n, seg_read=self.P.table.seg_read)
+            if ascending:
+                self._n_skipped, self._n_wskips, self._n_multi = counts
+                self._kept_pos = None
+                self._n_pos = None
+                self._counted_natively = True
+                return
         info = self._info[:n]
         rid = self.P.table.seg_read[self._seg_of[:n]].astype(np.int64)
         key = (rid << 32) | (self._site_pos[:n].astype(np.int64) & 0xFFFFFFFF)
@@ -371,6 +383,7 @@ def cut_names(table, rec):
     return (set(names[int(r)] for r in seg_read[:first_seg + 1]), set(names[int(r)] for r in seg_read[last_seg:]), True)
 
 
+FORMAT_THREADS = [int(__import__('os').environ.get('MCALLER_FORMAT_THREADS', '0'))]     # threads of the native row formatter (0: every core this process may use)
 STREAM_SHARD_BYTES = 128 << 20      # eventalign text per shard of a streamed file (~10^6 rows)
 STREAM_SHARD_MAX_BYTES = 2 << 30    # a shard beyond this (the cuts are at read starts: one giant read) sends the file to the one-table path
 
@@ -694,15 +707,14 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             write_rows()
         clock['records'] += int(rec.n)
         n = rec.n
-        too = (rec.info[:n] & _I.I_TOO_MANY) != 0
-        pos_kept = rec.site_pos[:n][~too]                      # (the distinct positions of the file: a mark per position, counted at the end)
-        if len(pos_kept):
-            top = int(pos_kept.max()) + 1
+        if n:
+            # the distinct positions of the file: a mark per position, counted at the end (mc_count_records: one pass in the library)
+            _, _, lo_pos, top = rec.count(n, pos_marks=positions[0])
+            if lo_pos < 0:
+                raise _Unstreamable('a negative site position')
             if top > len(positions[0]):
                 positions[0] = np.concatenate([positions[0], np.zeros(max(top, 2 * len(positions[0])) - len(positions[0]), dtype=bool)])
-            if int(pos_kept.min()) < 0:
-                raise _Unstreamable('a negative site position')
-            positions[0][pos_kept] = True
+                rec.count(n, pos_marks=positions[0])
         if train:                                              # (train mode goes record by record: its sets count)
             out.n_obs += fin.num_observations
             out.n_multi += len(fin.multi)

@@ -268,3 +268,39 @@ def test_native_motif_marking_equals_str_replace(tmp_path):
         a, b = native.device_arrays(), plain.device_arrays()
         assert all(np.array_equal(a[k], b[k]) for k in a), (motif, base)
         assert native.mark(0) == refmark.methylate_references(seq.upper(), base, motif=motif)
+
+
+def test_count_records_equals_the_numpy_counters():
+    """mc_count_records (what a streamed shard adds to the reference's counters, :184-185, :234-239, :247-248, in one native pass)
+    against the numpy expressions it replaces: counts, the ascending test (repeated read names make it fail: the caller counts
+    distinct pairs), the marks of the calls' positions with marks that are too short, empty input."""
+    from mcaller_amd import _lib
+    rng = np.random.default_rng(3)
+    for n, repeat in ((0, False), (1, False), (5000, False), (5000, True)):
+        rec = _lib.Records(max(n, 1), 6)
+        rec.n = n
+        n_seg = 40
+        seg_read = (np.arange(n_seg, dtype=np.int32) if not repeat else rng.integers(0, 5, n_seg).astype(np.int32))
+        rec.site_seg[:n] = np.sort(rng.integers(0, n_seg, n)).astype(np.int32)
+        pos = np.zeros(n, dtype=np.int64)
+        for s in range(n_seg):                                  # (ascending sites inside a segment, as records in file order have them)
+            m = rec.site_seg[:n] == s
+            pos[m] = np.cumsum(rng.integers(1, 9, int(m.sum())))
+        rec.site_pos[:n] = pos.astype(np.int32)
+        info = rng.integers(0, 64, n).astype(np.uint32) * (rng.random(n) < 0.3)
+        info |= np.where(rng.random(n) < 0.3, _lib.I_TOO_MANY, 0).astype(np.uint32)
+        info |= np.where(rng.random(n) < 0.2, _lib.I_MULTI, 0).astype(np.uint32)
+        rec.info[:n] = info
+        counts, ascending, lo, top = rec.count(n, seg_read=seg_read)
+        too = (info & _lib.I_TOO_MANY) != 0
+        key = (seg_read[rec.site_seg[:n]].astype(np.int64) << 32) | pos
+        assert ascending == (n < 2 or bool((key[1:] > key[:-1]).all())) and (ascending or repeat)
+        assert counts == (int(too.sum()), int((~too & ((info & _lib.I_EMPTY_MASK) != 0)).sum()), int(((info & _lib.I_MULTI) != 0).sum()))
+        kept = pos[~too]
+        assert (lo, top) == ((int(kept.min()), int(kept.max()) + 1) if len(kept) else (0, 0))
+        marks = np.zeros(max(1, top // 2), dtype=bool)          # too short: the positions below its length only
+        _, _, _, top2 = rec.count(n, pos_marks=marks)
+        assert top2 == top and np.array_equal(np.flatnonzero(marks), np.unique(kept[kept < len(marks)]))
+        marks = np.zeros(top + 3, dtype=bool)
+        rec.count(n, pos_marks=marks)
+        assert np.array_equal(np.flatnonzero(marks), np.unique(kept))

@@ -56,6 +56,10 @@ def test_native_repr_matches_python():
     vals += [round(rng.uniform(-30, 30), 4) for _ in range(20000)]                    # what slot means look like
     vals += [rng.randrange(-400000, 400000) / 10000.0 / rng.randrange(1, 9) for _ in range(20000)]
     vals += [struct.unpack('<d', struct.pack('<Q', rng.getrandbits(64)))[0] for _ in range(20000)]   # any bit pattern
+    # the formatter's decimal fast path (a mean that is fl(D / 10^8)): its edges, and the neighbours of such doubles (one ulp off: not D / 10^8)
+    dec = [rng.randrange(1, 10 ** rng.randrange(1, 16)) / 1e8 for _ in range(20000)] + [1e-4, 0.00010001, 9999999.99999999, 1e7, 10000000.00000001,
+                                                                                         99999.99999999, 0.5, 0.25, 0.125, 1 / 3, 2 / 3, 1e7 - 2 ** -29]
+    vals += dec + [-x for x in dec[:2000]] + [float(np.nextafter(x, 0.0)) for x in dec[:5000]] + [float(np.nextafter(x, 1e9)) for x in dec[:5000]]
     for v in vals:
         if v != v:
             assert repr_double(v) == 'nan'
