@@ -148,6 +148,9 @@ int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_t *cuts);
  * the byte range the reference's batch loop consumes for (startline, endline) -- what mc_parse_eventalign parses (:141-148:
  * the last < 500 bytes of a file can stay unread) -- for callers that cut that range into shards. */
 int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64_t hi, int32_t n_parts, int64_t *cuts);
+/* ... at offsets of the caller's choosing (ascending, inside [lo, hi)): cuts[0] = lo, cuts[i + 1] = the first line of a read at or
+ * behind want[i], cuts[n_want + 1] = min(hi, file size) -- a stream whose first shards are small (its pipeline fills sooner). */
+int mc_eventalign_read_cuts_at(const char *path, int64_t lo, int64_t hi, const int64_t *want, int32_t n_want, int64_t *cuts);
 int mc_eventalign_consumed_range(const char *path, int64_t startline, int64_t endline, int64_t *lo, int64_t *hi);
 int mc_parsed_view(const mc_parsed *p, mc_table_view *out);
 const char *mc_parsed_read_name(const mc_parsed *p, int32_t read_id);

@@ -94,6 +94,7 @@ def lib():
         L.mc_parse_eventalign_range.argtypes = L.mc_parse_eventalign.argtypes
         L.mc_eventalign_read_cuts.argtypes = [C.c_char_p, C.c_int32, C.c_void_p]
         L.mc_eventalign_read_cuts_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+        L.mc_eventalign_read_cuts_at.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.mc_eventalign_consumed_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mc_fastq_read_quality.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
         L.mc_fastq_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -395,6 +396,14 @@ def eventalign_read_cuts(path, n_parts, lo=None, hi=None):
     else:
         check(lib().mc_eventalign_read_cuts_range(path.encode('utf-8'), int(lo or 0), int((1 << 62) if hi is None else hi),
                                                   int(n_parts), _ptr(cuts)))
+    return [int(c) for c in cuts]
+
+
+def eventalign_read_cuts_at(path, want, lo, hi):
+    """Byte offsets cutting [lo, hi) at the first lines of the reads at or behind the offsets `want` (ascending): [lo, ..., end]."""
+    want = np.ascontiguousarray(want, dtype=np.int64)
+    cuts = np.zeros(len(want) + 2, dtype=np.int64)
+    check(lib().mc_eventalign_read_cuts_at(path.encode('utf-8'), int(lo), int(hi), _ptr(want), len(want), _ptr(cuts)))
     return [int(c) for c in cuts]
 
 

@@ -394,7 +394,9 @@ extern "C" int mc_eventalign_read_cuts(const char *path, int32_t n_parts, int64_
 
 // The same for the byte range [lo, hi) of the file (lo at a line start; hi is clamped to the file size): cuts[0] = lo,
 // cuts[n_parts] = hi.
-extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64_t hi, int32_t n_parts, int64_t *cuts) {
+// cuts[0] = lo, cuts[i] = the first line of a read at or behind want[i - 1] (i = 1 .. n_parts - 1; want == nullptr: pieces of equal
+// size), cuts[n_parts] = min(hi, file size); in order (a cut that would lie before the one in front of it collapses onto it)
+static int read_cuts(const char *path, int64_t lo, int64_t hi, int32_t n_parts, const int64_t *want, int64_t *cuts) {
     if (n_parts < 1) {
         mc_set_error("mc_eventalign_read_cuts: n_parts %d", n_parts);
         return -12;
@@ -440,8 +442,9 @@ extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64
     std::vector<int64_t> found((size_t)n_parts, lo);
     mc_parallel_for(n_parts - 1, [&](int task) {
         const int32_t i = task + 1;
-        int64_t c = lo + (fsize - lo) * i / n_parts;
+        int64_t c = want ? std::min(want[i - 1], fsize) : lo + (fsize - lo) * i / n_parts;
         if (c <= lo) { found[(size_t)i] = lo; return; }
+        if (c >= fsize) { found[(size_t)i] = fsize; return; }
         // the line that contains byte c-1 ends at `line`: start there, remember the name of the line before it
         int64_t line = c;
         {
@@ -452,6 +455,35 @@ extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64
         while (prev_begin > lo && base[prev_begin - 1] != '\n') --prev_begin;
         Tok prev;
         bool have_prev = name_of(prev_begin, line, &prev);
+        // A read is ~10^4 lines: before the lines are walked one by one, leaps -- the line behind a probe twice as far each time,
+        // as long as it still carries prev's name (lines of one name are taken for one run here: if the name comes back behind
+        // another read, the walk below still stops at a first line of a read, which is all a cut has to be)
+        if (have_prev) {
+            int64_t safe = line;                              // a line start: everything in [line, safe) carries prev's name ... as far as probed
+            for (int64_t step = 1 << 16; safe + step < fsize; step *= 2) {
+                const void *nl = memchr(base + safe + step, '\n', (size_t)(fsize - (safe + step)));
+                if (!nl) break;
+                const int64_t probe = (int64_t)((const char *)nl - base) + 1;
+                if (probe >= fsize) break;
+                Tok cur;
+                if (!name_of(probe, line_end_of(probe), &cur) || cur.n != prev.n || memcmp(cur.p, prev.p, cur.n) != 0) {
+                    // the name changes in (safe, probe]: halve the distance
+                    int64_t a = safe, b = probe;              // a: a line start with prev's name (or `line`), b: a line start without it
+                    while (b - a > 4096) {
+                        const int64_t mid = a + (b - a) / 2;
+                        const void *nm = memchr(base + mid, '\n', (size_t)(b - mid));
+                        const int64_t ml = nm ? (int64_t)((const char *)nm - base) + 1 : b;
+                        if (ml >= b) break;
+                        Tok t2;
+                        if (name_of(ml, line_end_of(ml), &t2) && t2.n == prev.n && memcmp(t2.p, prev.p, t2.n) == 0) a = ml; else b = ml;
+                    }
+                    safe = a;
+                    break;
+                }
+                safe = probe;
+            }
+            line = std::max(line, safe);
+        }
         int64_t cut = fsize;
         while (line < fsize) {
             const int64_t le = line_end_of(line);
@@ -469,6 +501,18 @@ extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64
     cuts[n_parts] = fsize;
     if (base) munmap((void *)base, (size_t)file_size);
     return 0;
+}
+
+extern "C" int mc_eventalign_read_cuts_range(const char *path, int64_t lo, int64_t hi, int32_t n_parts, int64_t *cuts) {
+    return read_cuts(path, lo, hi, n_parts, nullptr, cuts);
+}
+
+extern "C" int mc_eventalign_read_cuts_at(const char *path, int64_t lo, int64_t hi, const int64_t *want, int32_t n_want, int64_t *cuts) {
+    if (n_want < 0 || (n_want > 0 && !want)) {
+        mc_set_error("mc_eventalign_read_cuts_at: bad arguments");
+        return -12;
+    }
+    return read_cuts(path, lo, hi, n_want + 1, want, cuts);
 }
 
 // The byte range [*lo, *hi) the reference's batch loop consumes for (startline, endline) (:141-148): seek to

@@ -385,7 +385,32 @@ def cut_names(table, rec):
 
 FORMAT_THREADS = [int(__import__('os').environ.get('MCALLER_FORMAT_THREADS', '0'))]     # threads of the native row formatter (0: every core this process may use)
 STREAM_SHARD_BYTES = 128 << 20      # eventalign text per shard of a streamed file (~10^6 rows)
+STREAM_SHARD_MIN_BYTES = 8 << 20    # ... of a short range, at least (a shard costs the main thread half a millisecond whatever its size)
+STREAM_MIN_SHARDS = 24              # ... which is cut into at least this many (shard_schedule)
 STREAM_SHARD_MAX_BYTES = 2 << 30    # a shard beyond this (the cuts are at read starts: one giant read) sends the file to the one-table path
+
+
+def shard_schedule(lo, hi):
+    """Where a streamed byte range is cut into shards (offsets, to be moved to read starts): shards of STREAM_SHARD_BYTES, but a
+    short range -- the piece of one GPU of a sharded run -- in at least STREAM_MIN_SHARDS of them (ten shards fill and drain a
+    six-deep pipeline for a third of their time), and the first three shards an eighth, a quarter, half of that: nothing happens on
+    the GPU before the first shard's text has been read and sent, and the last two half and a quarter: what is left to do when
+    the last text has arrived is one shard's parse, pass, copy-out and rows."""
+    total = hi - lo
+    full = int(min(STREAM_SHARD_BYTES, max(STREAM_SHARD_MIN_BYTES, total // STREAM_MIN_SHARDS)))
+    if total < 2 * full:
+        return [lo + total // 2] if total >= 2 * STREAM_SHARD_MIN_BYTES else []
+    head, tail = [full // 8, full // 4, full // 2], [full // 2, full // 4]
+    if total < 4 * full:
+        head, tail = [], []
+    body = total - sum(head) - sum(tail)
+    n_body = max(1, int(round(body / float(full))))
+    sizes = head + [body // n_body] * n_body + tail
+    offs, at = [], lo
+    for sz in sizes[:-1]:
+        at += sz
+        offs.append(at)
+    return offs
 
 
 def head_contig(P, qual_thresh):
@@ -442,17 +467,24 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     during the call only."""
     import os
     import time
+    t_enter = time.perf_counter()
     dev = device if device is not None else get_device()
     if byte_range is None:
         lo, hi = _lib.eventalign_consumed_range(tsv_input, 0, endline)
     else:
         lo, hi = byte_range
     if n_shards is None:
-        n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or max(1, min(1 << 16, (hi - lo) // STREAM_SHARD_BYTES))
-    if n_shards < min_shards:
-        raise _Unstreamable('one shard')
-    cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
-    pieces = [(cuts[i], cuts[i + 1]) for i in range(n_shards) if cuts[i + 1] > cuts[i]]
+        n_shards = int(os.environ.get('MCALLER_STREAM_SHARDS', '0')) or None
+    if n_shards is None:
+        want = shard_schedule(lo, hi)
+        if len(want) + 1 < min_shards:
+            raise _Unstreamable('one shard')
+        cuts = _lib.eventalign_read_cuts_at(tsv_input, want, lo, hi)
+    else:
+        if n_shards < min_shards:
+            raise _Unstreamable('one shard')
+        cuts = _lib.eventalign_read_cuts(tsv_input, n_shards, lo, hi)
+    pieces = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
     if byte_range is not None and not pieces:
         # the range of a GPU of a sharded run that holds no read (fewer reads than GPUs): a finished piece, not a reason to
         # send the whole file to one GPU
@@ -780,6 +812,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 ref.mark(cid)
         head_told = False
         rows_seen, prev_rows_before = 0, 0
+        clock['setup'] = time.perf_counter() - t_enter        # (cuts, FASTA, classifier, table slots, masks: before the first shard is asked for)
+        t_loop = time.perf_counter()
         while True:
             t_q = time.perf_counter()
             P = next_shard()
@@ -854,6 +888,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             fmt_pool.shutdown(wait=True)
             write_pool.shutdown(wait=True)
         L.mc_host_pool_config(0, -1)
+    clock['loop'] = time.perf_counter() - t_loop
     out.n_rows = rows_seen
     out.positions = np.flatnonzero(positions[0]).astype(np.int32)
     out.counters = ['thread finished processing...:', '%d observations' % out.n_obs, '%d positions' % len(out.positions),

@@ -37,3 +37,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(root, f)).read()
                 assert 'oracle' not in re.sub(r'#.*', '', src).replace('"""', ''), f
+
+
+def test_every_library_call_from_python_has_argtypes():
+    """A ctypes call without argtypes passes a Python int as a C int: a byte offset beyond 2^31 arrives cut (mc_eventalign_read_cuts_at
+    did, for a day).  Every mc_* function the package calls has its argument types declared, but for those that take none or small ints."""
+    import glob
+    import re
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mcaller_amd')
+    src = ''.join(open(f).read() for f in glob.glob(os.path.join(here, '*.py')))
+    called = set(re.findall(r'\b(?:lib\(\)|L|_lib\.lib\(\))\.(mc_[a-z0-9_]+)\(', src))
+    typed = set(re.findall(r'L\.(mc_[a-z0-9_]+)\.argtypes', open(os.path.join(here, '_lib.py')).read()))
+    assert called - typed <= {'mc_host_cores', 'mc_last_error', 'mc_repr_fixed4'}, sorted(called - typed)

@@ -108,6 +108,33 @@ def test_read_cuts_and_exact_ranges(tmp_path):
         if n_parts in (2, 3, 7):
             rows = [p.n_rows for p in parts]
             assert min(rows) > 0.5 * whole.n_rows / n_parts    # balanced
+    # ... at offsets of the caller's choosing (a stream's small first shards, extract_contexts.shard_schedule): every cut is the first
+    # read start at or behind its offset, the pieces concatenate to the whole
+    from mcaller_amd import extract_contexts as ec
+    text = open(tsv, 'rb').read()
+    starts = [0]
+    prev = None
+    at = 0
+    for line in text.splitlines(True):
+        name = line.split(b'\t')[3]
+        if prev is not None and name != prev:
+            starts.append(at)
+        prev = name
+        at += len(line)
+    starts = np.array(starts + [size])
+    lo, hi = int(starts[3]), int(starts[-4])
+    for want in ([lo + 1], [lo + 5000, lo + 5001, lo + 300000, hi - 10], ec.shard_schedule(lo, hi), [hi + 7], []):
+        cuts = _lib.eventalign_read_cuts_at(tsv, want, lo, hi)
+        assert len(cuts) == len(want) + 2 and cuts[0] == lo and cuts[-1] == hi and cuts == sorted(cuts)
+        for w, c in zip(want, cuts[1:-1]):
+            first_start = int(starts[np.searchsorted(starts, min(w, hi), side='left')])
+            assert c == min(first_start, hi), (w, c)
+        parts = [_lib.parse_eventalign(tsv, cuts[i], cuts[i + 1], ['ecoli_syn'], exact_range=True) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+        ref_rows = _lib.parse_eventalign(tsv, lo, hi, ['ecoli_syn'], exact_range=True)
+        assert (np.concatenate([p.pos for p in parts]) == ref_rows.pos).all()
+    sched = ec.shard_schedule(0, 3 << 30)
+    sizes = np.diff([0] + sched + [3 << 30])
+    assert len(sizes) >= ec.STREAM_MIN_SHARDS and sizes[0] * 7 < sizes[5] and sizes[-1] * 3 < sizes[5] and sizes.max() <= 1.1 * ec.STREAM_SHARD_BYTES
 
 
 def test_thread_counts_follow_the_affinity_mask(tmp_path):
