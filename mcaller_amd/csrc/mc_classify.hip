@@ -231,6 +231,7 @@ struct SidePack {
     K1Args A;                     // the pass: table, reference, descriptors, records, counters, rare_list, chunk_cnt / piece_kw
     const Payload *sorted;        // its payloads in record order (the walk's input)
     unsigned char *out;           // the block the copy-out moves
+    size_t out_bytes;             // ... its size: a pass that needs more is marked (Counters.overflow, pack_need) and repeated
     Counters *host_status;        // the pass's counters as the host reads them (pinned)
     int close32, score;
 };
@@ -370,6 +371,18 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !RO
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = s_red[PACK ? i : 0][0];
         __syncthreads();            // (s_red has been read)
+        // (the block is sized for the records a table of this size is expected to leave, not for every slot of a fused pass: a pass that
+        // needs more says how much and is repeated -- every workgroup comes to the same conclusion from the same sums)
+        const size_t need_bytes = pack_tail(pack_layout((int64_t)v[2], SP.close32).feats, (size_t)v[0], k, (size_t)v[1]).end;
+        const bool too_big = need_bytes > SP.out_bytes;
+        if (too_big) {
+            if (blockIdx.x == 0 && tid == 0) {
+                atomicExch(&SP.A.cnt->pack_need, (unsigned long long)need_bytes);
+                const unsigned was = atomicOr(&SP.A.cnt->overflow, 1u);
+                asm volatile("" :: "v"(was));
+            }
+            lo = hi;                                   // (no stretch; the counters still go to the host, below)
+        }
         if (tid == 0) {
             const PackLayout PL = pack_layout((int64_t)v[2], SP.close32);
             const PackTail PTl = pack_tail(PL.feats, (size_t)v[0], k, (size_t)v[1]);
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !RO
         }
         __syncthreads();
         K2_WALL(3);
-        const int64_t n_rare = (int64_t)SP.A.cnt->n_rare;
+        const int64_t n_rare = too_big ? 0 : (int64_t)SP.A.cnt->n_rare;
         if (n_rare > 0) {
             const int64_t rlo = pieces ? lo * P.room : lo, rhi = pieces ? hi * P.room : hi;
             for (int64_t i = tid; i < n_rare; i += TH) {
@@ -954,7 +967,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_count(DevRecords O, const
 
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Counters *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ chunk_cnt,
-                                                       unsigned char *__restrict__ out, int k, int close32,
+                                                       unsigned char *__restrict__ out, size_t out_bytes, int k, int close32,
                                                        Counters *__restrict__ host_status, int holes, int look) {
     // look != 0: the chunk counts come from k_pack_count, which looked at the slot means of the records whose mask byte says 0xFF (the
     // row-by-row paths) -- so does this kernel; look == 0: the emit counted as it wrote the records, every mask byte is what it says
@@ -992,6 +1005,18 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack(DevRecords O, const Count
         }
     }
     if (cnt->overflow) return;                                           // (the host runs such a pass again, synchronously)
+    {
+        // (the block is sized for the records expected, not for every slot: a pass that needs more says so and is repeated)
+        const int64_t n_all = min((int64_t)cnt->n_records, O.capacity);
+        const size_t need = pack_tail(pack_layout(holes ? (int64_t)total_real : n_all, close32).feats, (size_t)total, k, (size_t)total_wide).end;
+        if (need > out_bytes) {
+            if (blockIdx.x == 0 && tid == 0) {
+                *reinterpret_cast<volatile unsigned long long *>(&host_status->pack_need) = (unsigned long long)need;
+                *reinterpret_cast<volatile unsigned int *>(&host_status->overflow) = 1u;
+            }
+            return;
+        }
+    }
     const int64_t n = min((int64_t)cnt->n_records, O.capacity);
     const int64_t per = (n + PACK_WGS - 1) / PACK_WGS;
     const int64_t lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
@@ -1138,17 +1163,17 @@ void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsig
     hipLaunchKernelGGL(k_pack_count, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, k, chunk_cnt, holes);
 }
 
-void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop) {
-    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, k, close32, host_status, holes, look);
-    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, k, close32, host_status, holes, look);
+void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, size_t out_bytes, int k,
+                    int close32, Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop) {
+    if (stop) hipExtLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, nullptr, stop, 0, O, cnt, chunk_cnt, out, out_bytes, k, close32, host_status, holes, look);
+    else hipLaunchKernelGGL(k_pack, dim3(PACK_WGS), dim3(PACK_THREADS), 0, st, O, cnt, chunk_cnt, out, out_bytes, k, close32, host_status, holes, look);
 }
 
 // The side stream of a pipelined pass as ONE kernel (k2_mlp<.., PACK>): rare windows, MLP (score != 0), packing.  -> false: not for this
 // pass (another classifier, a piece's room beyond a stretch): the caller launches k1_rare_dev, the classifier and the packing kernels.
 bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_t st, const K1Args &A, const Payload *sorted, const int32_t *seg_read,
-                    const double *qual, int64_t cap, int score, unsigned char *out, int close32, Counters *host_status, int piece_room,
-                    int64_t n_pieces, hipEvent_t stop) {
+                    const double *qual, int64_t cap, int score, unsigned char *out, size_t out_bytes, int close32, Counters *host_status,
+                    int piece_room, int64_t n_pieces, hipEvent_t stop) {
     static const bool off = getenv("MCALLER_SIDE_FUSED") && atoi(getenv("MCALLER_SIDE_FUSED")) == 0;       // (tests, profiles: the three kernels)
     if (off || cap <= 0) return false;
     if (score && (other_classifier || !M.W1)) return false;
@@ -1156,7 +1181,7 @@ bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_
     constexpr int TH_SIDE = MC_SIDE_MAX_ROOM;
     if (by_piece ? (piece_room >= TH_SIDE || !A.piece_kw || !A.piece_cnt) : !A.chunk_cnt) return false;
     SidePack SP;
-    SP.A = A; SP.sorted = sorted; SP.out = out; SP.host_status = host_status; SP.close32 = close32; SP.score = score;
+    SP.A = A; SP.sorted = sorted; SP.out = out; SP.out_bytes = out_bytes; SP.host_status = host_status; SP.close32 = close32; SP.score = score;
     const K2Pieces P{by_piece ? A.piece_cnt : nullptr, piece_room, n_pieces};
     const bool fast = score && M.fast && M.wp32;
     // Workgroups of 512 threads (a stretch: 512 records) at 128 registers a lane, two to a CU -- with 1024 threads and 64 registers

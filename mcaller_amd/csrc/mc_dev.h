@@ -170,6 +170,8 @@ struct Counters {          // device-side status block
     unsigned long long n_kept; // records without MC_I_TOO_MANY (k_pack: rows of the compacted slot means / probabilities)
     unsigned long long n_wide; // slot means of those records that travel as 64 bits (k_pack: the others as 32-bit integers)
     unsigned long long side_done;  // workgroups of the side stream's kernel (k2_mlp<.., PACK>) that are through: the last one sends the counters to the host
+    unsigned long long pack_need;  // bytes the packed block of the pass would take if it is more than the block has (set with `overflow`: the pass is
+                                   // repeated, the next one gets a bigger block); 0: it fitted
     // the pass in which a name block was last classified irregular (mc_params-independent pass number, never 0).  Written,
     // never zeroed: k0_first_site classifies while it zeroes the other counters, so a count could lose updates -- a pass is
     // special iff this equals its own number
@@ -518,10 +520,10 @@ void mc_launch_classifier(const DevMlp &M, const DevForest &F, const DevSimple &
                           const uint8_t *submodel_in, int64_t n, double *prob, const unsigned long long *n_dev, const unsigned int *overflow,
                           const int32_t *piece_cnt = nullptr, int piece_room = 0, int64_t n_pieces = 0);
 void mc_launch_pack_count(const DevRecords &O, const Counters *cnt, int k, unsigned long long *chunk_cnt, int holes, hipStream_t st);
-void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, int k, int close32,
-                    Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop);
+void mc_launch_pack(const DevRecords &O, const Counters *cnt, const unsigned long long *chunk_cnt, unsigned char *out, size_t out_bytes, int k,
+                    int close32, Counters *host_status, int holes, int look, hipStream_t st, hipEvent_t stop);
 bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_t st, const K1Args &A, const Payload *sorted, const int32_t *seg_read,
-                    const double *qual, int64_t cap, int score, unsigned char *out, int close32, Counters *host_status, int piece_room,
-                    int64_t n_pieces, hipEvent_t stop);
+                    const double *qual, int64_t cap, int score, unsigned char *out, size_t out_bytes, int close32, Counters *host_status,
+                    int piece_room, int64_t n_pieces, hipEvent_t stop);
 
 #endif  // MC_DEV_H

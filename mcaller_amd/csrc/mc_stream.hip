@@ -192,6 +192,7 @@ struct mc_ctx {
     int64_t last_n = 0;
     int64_t last_slots = 0;        // record slots the records handed out last occupy on the device (a fused dense pass: with holes in between)
     int last_fused_room = 0, last_rerun = 0;   // how the pass handed out last ran (mc_last_pass_info)
+    size_t pack_min_bytes = 0;     // a pass's packed block: at least this (what a pass that did not fit said it needed, and a quarter)
     int fused_scale = 1;           // the fused dense pass (k1_fused): room per piece x this (doubled when a piece ran out of room)
     int64_t ref_total_len = 0;    // bases of the marked reference (record capacity guess)
     float times[5] = {0, 0, 0, 0, 0};
@@ -213,6 +214,7 @@ struct mc_ctx {
         int32_t *piece_cnt = nullptr;                          // the fused dense pass: records of every piece (k1_fused -> k2_mlp)
         int32_t *piece_kw = nullptr;                           // ... its calls | their wide slot means << 16 (k1_fused -> the side stream's kernel)
         int64_t piece_cap = 0;
+        size_t pack_bytes = 0;                                 // bytes of pack / pack_host
         int32_t *h_lo32 = nullptr;                             // in pack_host: the slot means' 32-bit parts, the wide ones' high halves,
         uint32_t *h_hi32 = nullptr;                            // the mask byte of every call (mc_calls_view)
         unsigned char *h_wmask = nullptr;
@@ -1696,7 +1698,7 @@ static void free_async(mc_ctx *c) {
         b.O = DevRecords();
         b.K = K0Set();
         free_pool(b.k0_allocs);
-        b.cap = b.n_nb = 0; b.k = 0; b.used = false; b.copying = false;
+        b.cap = b.n_nb = 0; b.k = 0; b.pack_bytes = 0; b.used = false; b.copying = false;
     }
     c->ab_head = c->ab_tail = c->ab_count = 0;
 }
@@ -1706,7 +1708,9 @@ static int pinned(void **host, size_t bytes) {
     return 0;
 }
 
-static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) {
+// cap: record slots; pack_rec: records the packed block is sized for (a fused pass: the records expected, not every slot -- ten
+// gigabytes of pinned memory less at 10^8 rows; a pass that needs more is repeated and the next block is bigger)
+static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k, int64_t pack_rec = 0) {
     const DevTable &T = c->T;
     if (!b.ev_done) {
         // events between kernels of this GPU (timing, the side stream's wait for the emit) need no system-scope fence -- without
@@ -1728,7 +1732,9 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
         if (dev_alloc(b.k0_allocs, &b.K.desc, (size_t)nb + 1) || dev_alloc(b.k0_allocs, &b.K.nb_f0, (size_t)nb + 1)) return -10;
         b.n_nb = nb;
     }
-    if (b.cap >= cap && b.k == k) return 0;
+    if (pack_rec <= 0 || pack_rec > cap) pack_rec = cap;
+    const size_t pack_bytes = std::max((size_t)pack_rec * (20 + ((size_t)k + 1) * 8 + 1) + 128, c->pack_min_bytes);       // (every slot mean 64 bits wide at worst, a mask byte per call)
+    if (b.cap >= cap && b.k == k && b.pack_bytes >= pack_bytes) return 0;
     if (b.used) HIP_TRY(hipEventSynchronize(b.ev_done));
     free_pool(b.dev_allocs);
     b.H = DevRecords();
@@ -1741,13 +1747,13 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k) 
                      (long long)cap);
         return -12;
     }
-    const size_t pack_bytes = (size_t)cap * (20 + ((size_t)k + 1) * 8 + 1) + 128;       // (every slot mean 64 bits wide at worst, a mask byte per call)
     if (dev_alloc(b.dev_allocs, &b.pack, pack_bytes) || dev_alloc(b.dev_allocs, &b.chunk_cnt, (size_t)PACK_PAD * PACK_WGS)) return -10;
     if (dev_alloc(b.dev_allocs, &b.sorted, (size_t)cap) || dev_alloc(b.dev_allocs, &b.rare, (size_t)cap)) return -10;
     b.piece_cap = cap / 16 + 64;                               // (a piece has at least 48 slots: mc_fused_room)
     if (dev_alloc(b.dev_allocs, &b.piece_cnt, (size_t)b.piece_cap) || dev_alloc(b.dev_allocs, &b.piece_kw, (size_t)b.piece_cap)) return -10;
     if (b.pack_host) { (void)hipHostFree(b.pack_host); b.pack_host = nullptr; }
     if (pinned((void **)&b.pack_host, pack_bytes)) return -10;
+    b.pack_bytes = pack_bytes;
     b.H.capacity = cap;
     if (!b.st_host) {
         if (pinned((void **)&b.st_host, sizeof(Counters))) return -10;
@@ -1787,7 +1793,7 @@ static int enqueue_side(mc_ctx *c, mc_ctx::AsyncBuf &b, const K1Args &A, bool *d
     if (b.prm.score && (other || !c->M.W1)) return 0;
     HIP_TRY(hipStreamWaitEvent(st, b.ev_emit_end, 0));
     if (b.timed || !MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_k2_start, st));
-    if (!mc_launch_side(c->M, other, c->n_cu, st, A, b.sorted, T.seg_read, c->qual, b.cap, b.prm.score ? 1 : 0, b.pack, b.close32 ? 1 : 0, b.st_dev,
+    if (!mc_launch_side(c->M, other, c->n_cu, st, A, b.sorted, T.seg_read, c->qual, b.cap, b.prm.score ? 1 : 0, b.pack, b.pack_bytes, b.close32 ? 1 : 0, b.st_dev,
                         b.fused_room, b.fused_room > 0 ? b.slots / b.fused_room : 0, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr))
         return 0;           // (the wait and the event stay where they are: harmless in front of the three kernels)
     if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_done, st));
@@ -1802,7 +1808,7 @@ static int enqueue_pack(mc_ctx *c, mc_ctx::AsyncBuf &b, bool count) {
     hipStream_t s2 = c->side_stream;
     const int holes = b.fused_room > 0 ? 1 : 0;
     if (count) mc_launch_pack_count(b.O, b.cnt, b.k, b.chunk_cnt, holes, s2);
-    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.k, b.close32 ? 1 : 0, b.st_dev, holes, count ? 1 : 0, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
+    mc_launch_pack(b.O, b.cnt, b.chunk_cnt, b.pack, b.pack_bytes, b.k, b.close32 ? 1 : 0, b.st_dev, holes, count ? 1 : 0, s2, MC_EVENTS_ON_KERNELS ? b.ev_done : nullptr);
     if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(b.ev_done, s2));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1845,10 +1851,12 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     b.slots = fused_room > 0 ? mc_fused_pieces(T) * fused_room : 0;
     if (int rc = ensure_scratch(c, T.n_nb, T.n_tiles)) return rc;
     if (int rc = ensure_records(c, cap, k)) return rc;          // the scratch all passes share (payloads, lists)
-    if (int rc = ensure_async_buf(c, b, cap, k)) return rc;
+    int64_t pack_rec = fused_room > 0 ? std::min<int64_t>(cap, std::max<int64_t>(guess_capacity(c), c->Omain.capacity)) : cap;
+    if (const char *e = getenv("MCALLER_PACK_RECORDS")) { if (atoll(e) > 0) pack_rec = std::min<int64_t>(cap, atoll(e)); }      // (tests: a packed block that is too small)
+    if (int rc = ensure_async_buf(c, b, cap, k, pack_rec)) return rc;
     if (fused_room > 0 && mc_fused_pieces(T) > b.piece_cap) { b.fused_room = 0; b.slots = 0; }     // (room forced very small: more pieces than counts)
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
-        if (!other.used && (other.cap < cap || other.n_nb < T.n_nb)) { if (int rc = ensure_async_buf(c, other, cap, k)) return rc; }
+        if (!other.used && (other.cap < cap || other.n_nb < T.n_nb || other.pack_bytes < b.pack_bytes)) { if (int rc = ensure_async_buf(c, other, cap, k, pack_rec)) return rc; }
     // K0 (strand resolve) and K1 (scan, ordering, emit) of a pass on the ctx stream, back to back with the next pass: nothing
     // on the scan's path waits for another queue.  K2 (classifier) and the packing on the side stream, behind the pass's
     // emit: they run beside K0 of the next pass (small latency-bound kernels) and the first microseconds of its scan.
@@ -1998,7 +2006,9 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
                 st.overflow, (unsigned)(st.irregular_pass == b.pass_no), st.n_big, st.n_rare, st.n_records);
     c->last_fused_room = b.used ? b.fused_room : 0;
     c->last_rerun = special ? 1 : 0;
-    if (special && st.overflow && b.fused_room > 0 && b.fused_room < mc_fused_room_max())
+    if (special && st.overflow && st.pack_need > 0)           // (the packed block was too small: the next one holds that and a quarter)
+        c->pack_min_bytes = std::max(c->pack_min_bytes, (size_t)st.pack_need + (size_t)st.pack_need / 4);
+    else if (special && st.overflow && b.fused_room > 0 && b.fused_room < mc_fused_room_max())
         c->fused_scale = std::min(c->fused_scale * 2, 64);       // (a piece ran out of room: twice the room from the next pass on)
     if (special) {
         // a pass the fast path alone cannot finish (record buffers too small, irregular reads):

@@ -551,7 +551,18 @@ extern "C" int mc_mlp_fit(mc_ctx *c, const mc_fit_params *P, const double *X, co
     int *dfailed;
     // workgroups per fit: four (the rows of a batch of 200 over 16 waves), one for small batches or on request
     static const int groups_env = getenv("MCALLER_FIT_WGS") ? atoi(getenv("MCALLER_FIT_WGS")) : 0;
-    const int G = std::max(1, std::min(16, groups_env > 0 ? groups_env : (P->batch_size >= 64 ? MC_FIT_GROUPS : 1)));
+    int G = std::max(1, std::min(16, groups_env > 0 ? groups_env : (P->batch_size >= 64 ? MC_FIT_GROUPS : 1)));
+    // The workgroups of a fit meet once per batch by spinning on a counter: every one of them has to be resident for the others to
+    // get past the meeting.  More workgroups than the device holds at once (many jobs in one call) -> one workgroup per fit, which
+    // waits for nobody.
+    if (G > 1) {
+        int per_cu = 0, n_cu = 0, dev_id = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k4_mlp_fit, FT, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        const int64_t wgs = (n_jobs <= 8 ? 8 : (int64_t)n_jobs) * G;            // (by_xcd launches 8 x G)
+        if (per_cu <= 0 || n_cu <= 0 || wgs > (int64_t)per_cu * n_cu) G = 1;
+    }
     const size_t per_job = (size_t)d * H + 2 * (size_t)H + 1;
     int rc = 0;
     rc |= to_device(pool, &dX, X, (size_t)n_samples * d, st);

@@ -242,3 +242,40 @@ def test_out_of_room_on_a_first_pass_still_validates(dev, monkeypatch):
         assert dev.last_pass_info() == (16, True)
         dev.run_async(6, 0, 0.0, score=False)                     # a later pass over the same table (room still forced small)
         wait_fused(dev, orc, 6, expect_fused=False)
+
+
+@pytest.mark.parametrize('motif', ['A', 'GATC'])
+def test_a_packed_block_that_is_too_small_repeats_the_pass(motif, monkeypatch):
+    """The block a pass's records are packed into for the copy-out is sized for the records a table is expected to leave (a fused
+    pass: not for every slot of every piece).  Forced too small: the pass says how much it needed (Counters.pack_need), is repeated by
+    the synchronous path, and the next pass's block holds it."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    from mcaller_amd.model_io import load_model_file, shipped_model
+    codes = synth.genome(length=90000, seed=12)
+    ref = synth.SynthRef(codes, motif=motif)
+    table, qual = synth.make_table(200000, seed=94, codes=codes, read_len=(1000, 4000))
+    arrays = ref.device_arrays()
+    _, weights, _, soc = submodel_setup(load_model_file(shipped_model('r95_twobase_model_NN_6_m6A')), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 0.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    assert orc.n > 300
+    monkeypatch.setenv('MCALLER_PACK_RECORDS', '100')
+    d = Device(0)
+    try:
+        d.set_reference(arrays)
+        d.set_mlp(weights, soc)
+        d.upload_table_async(table, qual)
+        d.run_async(6, 0, 0.0, score=True)
+        rec = d.wait()
+        assert d.last_pass_info()[1]                              # repeated
+        H.assert_records_equal(rec, orc, 6, prob_tol=1e-6)
+        d.run_async(6, 0, 0.0, score=True)
+        d.run_async(6, 0, 0.0, score=True)
+        for _ in range(2):
+            rec = d.wait()
+            assert not d.last_pass_info()[1]                      # the block has grown
+            H.assert_records_equal(rec, orc, 6, prob_tol=1e-6)
+    finally:
+        d.close()
