@@ -83,6 +83,10 @@ def test_config5_train_dicts_and_forest_probabilities_at_1e7_rows(tmp_path, monk
     assert np.isfinite(orc.prob[:orc.n]).sum() == n_obs
 
     # ---- predict mode with the RF model file: the streamed file equals the oracle's rows ----
+    # (the expected TEXT is made from the oracle's records by the product's own row formatter, Finisher / mc_format_diffs: what is
+    # compared with the oracle here are the records -- above, bit for bit -- and that the streamed CLI path writes the rows of exactly
+    # those records; the formatter itself is pinned to the reference's bytes on the CPU side, tests/test_host_pipeline.py and
+    # test_extract_features_dropin_text)
     fin = ec.Finisher(P, 6, 'A', False, modelset=ms, device=dev)
     with contextlib.redirect_stdout(io.StringIO()):
         assert fin.run(orc) is None
