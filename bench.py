@@ -46,8 +46,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(REPO, 'profiles', 'r05_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip',
+PMC_FILE = os.path.join(REPO, 'profiles', 'r06_pmc.json')
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip',
                   'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip', 'mcaller_amd/csrc/mc_devparse.inc']
 
 

@@ -236,12 +236,15 @@ struct SidePack {
     int close32, score;
 };
 struct NoPack {};
+#ifndef MC_SIDE_WAVES
+#define MC_SIDE_WAVES 4
+#endif
 // (ROOMY: 128 registers a lane and one workgroup per CU -- the side kernel of a sparse motif, where a CU gets one workgroup anyway and
 // a stretch: the packing's and the walk's registers fit beside the hidden layer's without a spill)
 // (TH: threads per workgroup = records per stretch.  512 for the side kernel of a dense reference: two workgroups per CU at 128
 // registers a lane -- one's loads and packing behind the other's hidden layer)
 template <int NI_T, bool FAST, bool PACK = false, bool ROOMY = false, int TH = K2_THREADS>
-__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !ROOMY) ? 8 : 4, (FAST && !ROOMY) ? 8 : 4))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
+__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !ROOMY) ? 8 : (ROOMY && FAST ? MC_SIDE_WAVES : 4), (FAST && !ROOMY) ? 8 : (ROOMY && FAST ? MC_SIDE_WAVES : 4)))) void k2_mlp(DevMlp M, const double *__restrict__ feats, int k,
                                                      const int32_t *__restrict__ site_seg, const int32_t *__restrict__ seg_read,
                                                      const double *__restrict__ qual, const uint32_t *__restrict__ info,
                                                      const uint8_t *__restrict__ submodel_in, int64_t n,
@@ -1192,7 +1195,7 @@ bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_
     // threads 0.2745 ms, 128 / 64 / 32 of them 0.2638 / 0.2637 / 0.2634; of 512 threads: 256 / 128 / 64 / 32 0.2602 / 0.2570 /
     // 0.2633 / 0.2778; the three kernels this one replaces: 0.2732.  MCALLER_SIDE_GRID: another number)
     unsigned grid;
-    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * 2));
+    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * (MC_SIDE_WAVES / 2)));
     else {
         static const int grid_env = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;
         const int want = grid_env > 0 ? grid_env : MC_SIDE_WGS_SPARSE;

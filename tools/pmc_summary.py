@@ -21,7 +21,7 @@ def short(name):
     """Kernel name without namespace and arguments; the scan keeps its template arguments (k1_scan<64,0>: the validating
     first pass; <64,1> / <64,2>: repeated passes over a validated table)."""
     name = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-    if name.startswith('k1_scan'):
+    if name.startswith('k1_scan') or name.startswith('k2_mlp'):    # (k2_mlp<NI, FAST, PACK, ROOMY, TH>: PACK = the side stream's one kernel)
         return name.replace(' ', '')
     return name.split('<')[0]
 
@@ -35,7 +35,7 @@ def kernel_source_hash():
     import hashlib
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for rel in ('mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip',
+    for rel in ('mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip',
                 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip', 'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip',
                 'mcaller_amd/csrc/mc_devparse.inc'):     # (bench.KERNEL_SOURCES, in its order)
         with open(os.path.join(repo, rel), 'rb') as fh:
