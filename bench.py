@@ -162,7 +162,7 @@ def python_twin_baseline(paths, model_npz, n_rows_file, motif='GATC', fraction=1
     size = os.path.getsize(paths['tsv'])
     hc = host_cores_info()
     cores = hc['effective']                               # one process per core this container may USE (256 in the affinity mask, a quota of 16)
-    sample = min(size, cores * (24 << 20))                # ~1 s per process at the reference-like ~2e5 rows/s: 10-30 s of CPU work
+    sample = min(size, cores * (64 << 20))                # ~1.3 s per process at the twin's ~4e5 rows/s: 10-30 s of CPU work in all
     sample = max(1 << 20, int(sample * fraction))       # (a one-base motif: a call every eleven rows, one MLP forward each -- a bounded sample)
     n_jobs = cores
     step = sample // n_jobs
