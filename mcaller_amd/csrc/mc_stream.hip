@@ -1,6 +1,7 @@
 // mc_stream.hip -- libmcaller_hip.so, the host side of the device code (gfx950 / MI355X): contexts, table slots, passes, the
 // device parser (mc_devparse.inc), the per-site reduction and RCCL.  C ABI: include/mcaller_hip.h.  The kernels of the passes live
-// in mc_k0.hip, mc_scan.hip, mc_emit.hip, mc_literal.hip, mc_classify.hip (shared structures: mc_dev.h); their map:
+// in mc_k0.hip, mc_scan.hip, mc_emit.hip, mc_fused.hip, mc_literal.hip, mc_classify.hip (shared structures: mc_dev.h; the row-by-row
+// walk of one window: mc_rows.h); their map:
 //
 // The reference's hot path (extract_contexts.py:147-291 + :199) as HIP kernels over a columnar event
 // table resident in HBM:
@@ -29,11 +30,16 @@
 //                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
 //                k1_emit         eight lanes per window: which of the rows before its last row belong to which slot, slot
 //                                means in NumPy pairwise order (fp64) from the rows' (event, model) pairs -> one flush record
-//                k1_rare_dev     windows longer than 64 rows, row by row
-//                k2_mlp          batched 7-H-1 tanh/logistic forward in fp64: one lane per record, weights as scalar operands,
-//                                a quarter of the hidden units per SIMD
-//                k3_forest       random-forest predict_proba;  k_literal / k_merge  irregular reads, row by row
-//                k_site_counts   per-site reduction (+ ncclAllReduce);  k_pack  record columns packed for the copy-out
+//                k1_fused        a dense reference (a one-base motif), pipelined passes: scan, ordering and emit as one kernel,
+//                                fixed room per 960-row piece (mc_fused.hip)
+//                k2_mlp          batched 7-H-1 tanh/logistic forward: one lane per record, weights as scalar operands, a quarter
+//                                of the hidden units per SIMD (flush records: hidden layer in fp32, fp64 where a printed digit
+//                                could depend on it)
+//                k2_mlp<.., PACK>   the side stream of a pipelined pass as ONE kernel: the windows the emit left to the
+//                                row-by-row walk (its own records'), the MLP, the records packed for the copy-out
+//                k1_rare_dev, k_pack_count / k_pack   the same in kernels of their own (other classifiers than the MLP)
+//                k3_forest, k3_simple   random forest / LR / NBC predict_proba;  k_literal / k_merge  irregular reads, row by row
+//                k_site_counts   per-site reduction (+ ncclAllReduce)
 //                k_copy_bytes    small transfers by the compute units (the DMA engines serialise behind queued text)
 //
 // Equivalence with the sequential machine on regular blocks (one contig, positions non-decreasing, event
