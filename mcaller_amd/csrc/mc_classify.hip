@@ -358,17 +358,16 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !RO
             if (tid == 0) { v[2] = (unsigned long long)n; v[5] = (unsigned long long)lo; }
         }
         K2_WALL(2);
-        // (a thread's sums fit 32 bits -- a few hundred pieces, one chunk; a wave's too: added up across the wave as such, then one
-        // 64-bit LDS atomic per wave and sum.  Not sixteen partial sums per value read back by everybody: the compiler fetches all
-        // ninety-six at once and spills them)
+        // (added up across the wave, then one 64-bit LDS atomic per wave and sum.  Not sixteen partial sums per value read back by
+        // everybody: the compiler fetches all ninety-six at once and spills them)
         if (tid < 6) s_red[PACK ? tid : 0][0] = 0ull;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            unsigned int x = (unsigned int)v[i];
+            unsigned long long x = v[i];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += (unsigned int)__shfl_xor((int)x, o);
-            if (lane == 0 && x) atomicAdd(&s_red[PACK ? i : 0][0], (unsigned long long)x);
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0 && x) atomicAdd(&s_red[PACK ? i : 0][0], x);
         }
         __syncthreads();
 #pragma unroll
@@ -652,6 +651,15 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !RO
             // of the calls.  Everything a record needs is fetched HERE (the hidden layer's registers are free again; the record's
             // lines are in the caches from A): nothing of it lives through B ----
             K2_WALL(11);
+            // (the next stretch's bases: written whatever this stretch holds -- sixteen pieces without a record, a long read under
+            // the quality threshold, are a stretch of nothing, and the stretch behind it reads what is written here)
+            if (tid == 0) {
+                unsigned kept_s = 0, wide_s = 0;
+                for (int w = 0; w < KW; ++w) { const int2 c = s_pk[PACK ? buf : 0][PACK ? w : 0]; kept_s += (unsigned)c.x; wide_s += (unsigned)c.y; }
+                s_base[PACK ? buf ^ 1 : 0][0] = s_base[PACK ? buf : 0][0] + kept_s;
+                s_base[PACK ? buf ^ 1 : 0][1] = s_base[PACK ? buf : 0][1] + wide_s;
+                s_base[PACK ? buf ^ 1 : 0][2] = s_base[PACK ? buf : 0][2] + (unsigned long long)n_here;
+            }
             if (tid < n_here) {
                 const uint32_t inf = info[r];
                 const int32_t seg = site_seg[r], pos = SP.A.O.site_pos[r];
@@ -671,19 +679,12 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu((FAST && !RO
                     if (lane >= o) w_incl += y;
                 }
                 unsigned long long row = s_base[PACK ? buf : 0][0] + (unsigned)__popcll(kb & below), wpos = s_base[PACK ? buf : 0][1] + (unsigned)(w_incl - nw);
-                unsigned kept_all = 0, wide_all = 0;
 #pragma unroll
                 for (int w = 0; w < KW; ++w) {
                     const int2 c = s_pk[PACK ? buf : 0][PACK ? w : 0];
                     if (w < wave) { row += (unsigned)c.x; wpos += (unsigned)c.y; }
-                    kept_all += (unsigned)c.x; wide_all += (unsigned)c.y;
                 }
                 const unsigned long long real0 = s_base[PACK ? buf : 0][2];
-                if (tid == 0) {         // (the next stretch's: read behind its two barriers)
-                    s_base[PACK ? buf ^ 1 : 0][0] = s_base[PACK ? buf : 0][0] + kept_all;
-                    s_base[PACK ? buf ^ 1 : 0][1] = s_base[PACK ? buf : 0][1] + wide_all;
-                    s_base[PACK ? buf ^ 1 : 0][2] = real0 + (unsigned long long)n_here;
-                }
                 const int64_t io = pieces ? (int64_t)real0 + tid : r;               // (holes are never looked at: the host never sees one)
                 unsigned char *const out = SP.out;
                 if (SP.close32) reinterpret_cast<int32_t *>(out)[io] = (int32_t)close;
@@ -1195,9 +1196,9 @@ bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_
     // threads 0.2745 ms, 128 / 64 / 32 of them 0.2638 / 0.2637 / 0.2634; of 512 threads: 256 / 128 / 64 / 32 0.2602 / 0.2570 /
     // 0.2633 / 0.2778; the three kernels this one replaces: 0.2732.  MCALLER_SIDE_GRID: another number)
     unsigned grid;
-    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, (int64_t)n_cu * (MC_SIDE_WAVES / 2)));
+    const int grid_env = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;      // (read per launch: tests change it)
+    if (by_piece) grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_pieces, grid_env > 0 ? (int64_t)grid_env : (int64_t)n_cu * (MC_SIDE_WAVES / 2)));
     else {
-        static const int grid_env = getenv("MCALLER_SIDE_GRID") ? atoi(getenv("MCALLER_SIDE_GRID")) : 0;
         const int want = grid_env > 0 ? grid_env : MC_SIDE_WGS_SPARSE;
         grid = 1;
         while (grid * 2 <= (unsigned)std::min<int64_t>(std::min(want, PACK_WGS), (int64_t)n_cu * 2)) grid *= 2;

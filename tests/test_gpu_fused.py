@@ -279,3 +279,36 @@ def test_a_packed_block_that_is_too_small_repeats_the_pass(motif, monkeypatch):
             H.assert_records_equal(rec, orc, 6, prob_tol=1e-6)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize('grid', [3, 16])
+def test_a_stretch_of_nothing_between_stretches_of_records(grid, monkeypatch):
+    """Long reads under the quality threshold: sixteen and more consecutive pieces without a record are a stretch of nothing for the
+    side stream's kernel, and the stretch behind it has to find its rows in the packed block where the stretch in FRONT of the empty
+    one left off (few workgroups, forced: every one of them walks dozens of stretches)."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    from mcaller_amd.model_io import load_model_file, shipped_model
+    codes = synth.genome(length=200000, seed=31)
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(700000, seed=311, codes=codes, read_len=(18000, 45000))
+    qual = qual.copy()
+    qual[1::2] = 7.0                                             # every second read is filtered (:167-168), the others are not
+    qual[0::2] = 11.0
+    arrays = ref.device_arrays()
+    _, weights, _, soc = submodel_setup(load_model_file(shipped_model('r95_twobase_model_NN_6_m6A')), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 9.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    assert orc.n > 20000
+    monkeypatch.setenv('MCALLER_SIDE_GRID', str(grid))
+    d = Device(0)
+    try:
+        d.set_reference(arrays)
+        d.set_mlp(weights, soc)
+        d.upload_table_async(table, qual)
+        for _ in range(2):
+            d.run_async(6, 0, 9.0, score=True)
+            wait_fused(d, orc, 6, prob_tol=1e-6)
+    finally:
+        d.close()
