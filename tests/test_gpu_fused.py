@@ -312,3 +312,31 @@ def test_a_stretch_of_nothing_between_stretches_of_records(grid, monkeypatch):
             wait_fused(d, orc, 6, prob_tol=1e-6)
     finally:
         d.close()
+
+
+def test_fused_pass_at_the_headline_size_with_a_quality_filter():
+    """10^8 rows, -m A, a quality threshold that drops a third of the reads (5-20 k rows each: whole stretches of pieces without a
+    record in the side stream's kernel, 49 stretches a workgroup), scored, two passes in flight: equal to the oracle."""
+    from mcaller_amd import synth
+    from mcaller_amd.device import Device
+    from mcaller_amd.extract_contexts import submodel_setup
+    from mcaller_amd.model_io import load_model_file, shipped_model
+    codes = synth.genome()
+    ref = synth.SynthRef(codes, motif='A')
+    table, qual = synth.make_table(100000000, seed=4242, codes=codes)
+    arrays = ref.device_arrays()
+    _, weights, _, soc = submodel_setup(load_model_file(shipped_model('r95_twobase_model_NN_6_m6A')), 'A')
+    orc = H.oracle_records(table, arrays, qual, 6, 0, 8.0)
+    H.oracle_score(orc, table, qual, weights, soc, 6)
+    assert 8000000 < orc.n < 9500000
+    d = Device(0)
+    try:
+        d.set_reference(arrays)
+        d.set_mlp(weights, soc)
+        d.upload_table_async(table.pinned(), qual)
+        d.run_async(6, 0, 8.0, score=True)
+        d.run_async(6, 0, 8.0, score=True)
+        wait_fused(d, orc, 6, prob_tol=1e-6)
+        wait_fused(d, orc, 6, prob_tol=1e-6)
+    finally:
+        d.close()

@@ -59,6 +59,19 @@ for i in range(n_tables):
             H.oracle_score(orc, table, qual, weights, soc, k)
             dev.set_reference(arrays)
             dev.set_mlp(weights, soc)
+            # (few workgroups, forced, in two tables out of three: every one of them walks many stretches -- stretches of nothing among them
+            # where long reads lie under the quality threshold)
+            g = int(rng.choice([0, 1, 2, 3, 5, 16]))
+            if g:
+                os.environ['MCALLER_SIDE_GRID'] = str(g)
+            else:
+                os.environ.pop('MCALLER_SIDE_GRID', None)
+            if rng.random() < 0.5:
+                qual = qual.copy()
+                qual[rng.random(len(qual)) < 0.5] = 5.0
+                qthr = 8.0
+                orc = H.oracle_records(table, arrays, qual, k, skip, qthr)
+                H.oracle_score(orc, table, qual, weights, soc, k)
             slot = dev.upload_table_async(table, qual)
             for again in range(3):                                   # first pass pipelined and validating, a later one, two in flight declared new
                 if again == 2:
