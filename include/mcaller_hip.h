@@ -268,6 +268,18 @@ typedef struct mc_params {
  * *rerun != 0 -- the pipelined pass could not be finished as enqueued (record room too small, an irregular read, a row that
  * contradicts what a block was classified on) and was repeated synchronously inside mc_wait_records. */
 int mc_last_pass_info(mc_ctx *ctx, int32_t *fused_room, int32_t *rerun);
+/* The rows of a pipelined pass as TEXT, made on the device (mc_rowtext.hip; replaces mc_format_diffs on the host, the row writer of
+ * extract_contexts.py:207-216).  mc_ctx_row_text(on = 1, the two labels of :200-206): the passes enqueued from now on also print their
+ * records where they are -- the packed records, the read names in the shard's text (tables the device parser made:
+ * mc_ctx_parse_begin .. _finish), the contig names, the marked reference, shortest round-trip digits in integer arithmetic
+ * (mc_rowtext.h) -- and send the text to pinned host memory behind the records.  After mc_wait_records, mc_last_row_text says
+ * where: *text / *n_bytes / *n_rows, and *block >= 0, which the caller gives back with mc_row_text_release (any thread) once it
+ * has written the rows; *block < 0: this pass has none (not asked for, another kind of table, no free block, or a record the
+ * device does not print -- a context that leaves the contig, an unknown sub-model key, an unscored record, a number outside
+ * [1e-9, 1e9): the reference's exit paths and the host formatter's general cases) and mc_format_diffs makes the rows as before. */
+int mc_ctx_row_text(mc_ctx *ctx, int32_t on, const char *label_meth, const char *label_unmeth);
+int mc_last_row_text(mc_ctx *ctx, const char **text, int64_t *n_bytes, int64_t *n_rows, int32_t *block);
+int mc_row_text_release(mc_ctx *ctx, int32_t block);
 /* The hot path on the GPU: strand resolve + window scan + classifier.  Leaves the flush records on the
  * device, in file order; *n_records = how many. */
 int mc_extract_features(mc_ctx *ctx, const mc_params *prm, int64_t *n_records);
@@ -438,6 +450,9 @@ int mc_repr_double(double v, char *out32);
 /* ... of d / 1e4 for a 32-bit integer d, from the integer alone (how the formatter prints the slot means that travel as
  * integers, mc_calls_view.feats_lo32): the same characters as mc_repr_double((double)d / 1e4). */
 int mc_repr_fixed4(int32_t d, char *out32);
+/* repr(v) by the device row writer's digit generation (mc_rowtext.h), built for the host: the same characters as mc_repr_double for
+ * 1e-9 <= |v| < 1e9 and for zero; -> length, -1: a double it does not print. */
+int mc_repr_double_rowtext(double v, char *out32);
 
 /* ===== measurement plumbing: a table as nanopolish-eventalign text (13 columns), written by all host cores =====
  * For file-to-file timing on synthetic workloads (bench.py); seq = the contig's bases (k-mers of columns 3 and 10). */

@@ -187,6 +187,10 @@ def lib():
         L.mc_free.argtypes = [C.c_void_p]
         L.mc_free.restype = None
         L.mc_repr_double.argtypes = [C.c_double, C.c_char_p]
+        L.mc_repr_double_rowtext.argtypes = [C.c_double, C.c_char_p]
+        L.mc_ctx_row_text.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_char_p]
+        L.mc_last_row_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.mc_row_text_release.argtypes = [C.c_void_p, C.c_int32]
         _lib = L
     return _lib
 
@@ -525,10 +529,47 @@ class LibBuffer(object):
         self._ptr = None
 
 
+class RowText(object):
+    """The rows of a pass as the device wrote them (mc_last_row_text): `view` is a memoryview over the pinned block, `n_rows` the
+    rows in it; release() (or the end of this object) gives the block back to the context -- the text must have been written by then."""
+
+    def __init__(self, ctx, ptr, n_bytes, n_rows, block):
+        self._ctx, self._block = ctx, int(block)
+        self.n, self.n_rows = int(n_bytes), int(n_rows)
+        self.view = memoryview((C.c_char * self.n).from_address(ptr)).cast('B') if self.n else memoryview(b'')
+
+    def __len__(self):
+        return self.n
+
+    def __bytes__(self):
+        return self.view.tobytes()
+
+    def release(self):
+        if self._block >= 0:
+            block, self._block = self._block, -1
+            self.view.release()
+            self.view = memoryview(b'')
+            self.n = 0
+            lib().mc_row_text_release(self._ctx, block)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # noqa (interpreter shutdown)
+            pass
+
+
 def repr_double(x):
     buf = C.create_string_buffer(40)
     lib().mc_repr_double(float(x), buf)
     return buf.value.decode()
+
+
+def repr_double_rowtext(x):
+    """repr(x) by the device row writer's digit generation, built for the host (None: a double it does not print)."""
+    buf = C.create_string_buffer(40)
+    n = lib().mc_repr_double_rowtext(float(x), buf)
+    return buf.value.decode() if n >= 0 else None
 
 
 def repr_fixed4(d):

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['csrc/mc_stream.hip', 'csrc/mc_k0.hip', 'csrc/mc_scan.hip', 'csrc/mc_emit.hip', 'csrc/mc_fused.hip', 'csrc/mc_literal.hip', 'csrc/mc_classify.hip',
+SOURCES = ['csrc/mc_stream.hip', 'csrc/mc_k0.hip', 'csrc/mc_scan.hip', 'csrc/mc_emit.hip', 'csrc/mc_fused.hip', 'csrc/mc_literal.hip', 'csrc/mc_classify.hip', 'csrc/mc_rowtext.hip',
            'csrc/mc_train.hip', 'csrc/mc_parse.cpp', 'csrc/mc_format.cpp', 'csrc/mc_fastq.cpp', 'csrc/mc_common.cpp', 'csrc/mc_synth.cpp']
 OUT = os.path.join(HERE, 'libmcaller_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-pthread']

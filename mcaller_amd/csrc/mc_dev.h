@@ -526,4 +526,47 @@ bool mc_launch_side(const DevMlp &M, bool other_classifier, int n_cu, hipStream_
                     const double *qual, int64_t cap, int score, unsigned char *out, size_t out_bytes, int close32, Counters *host_status,
                     int piece_room, int64_t n_pieces, hipEvent_t stop);
 
+// ---- rows of text on the device (mc_rowtext.hip) ----
+// a segment as the device parser leaves it (mc_devparse.inc): first row, where its read name stands in the shard's text, contig
+struct KpSeg { long long row; long long name_off; int name_len; int contig; int name_start; int pad; };
+
+struct RowTextStatus {          // what the row writer leaves for the host (a pinned copy travels with the text)
+    unsigned long long n_bytes; // the rows' text (too_small: what it would have taken)
+    unsigned long long n_rows;
+    unsigned int host_needed;   // a record the device does not print: the shard's rows come from the host formatter
+    unsigned int too_small;     // the text did not fit the room it was given
+};
+
+struct RowTextIn {
+    const unsigned char *pack;  // the pass's packed records on the device (pack_layout / pack_tail)
+    int64_t n, m, n_wide;       // records, call rows, wide slot means
+    int k, close32;
+    const int64_t *seg_begin;   // the pass's table: [n_seg + 1]
+    const int32_t *seg_read, *seg_contig;
+    int32_t n_seg;
+    const KpSeg *segs;          // [n_seg] (the device parser's)
+    const char *text;           // the shard's text
+    const double *qual;         // read qualities the pass ran with
+    int32_t n_qual;
+    DevRef R;
+    const uint32_t *cn_off, *cn_len;    // contig names (KpContigs)
+    const char *cn_chars;
+    const uint8_t *sub_of_char;
+    int32_t tail_contig;
+    char lab_meth[8], lab_unmeth[8];
+    int lab_meth_len, lab_unmeth_len;
+};
+
+struct RowTextScratch {
+    uint32_t *kept_blk, *wide_blk;      // [record blocks + 1], [call-row blocks + 1]
+    uint32_t *wide_pref;                // [call rows]
+    uint32_t *rec_len, *rec_row;        // [records]
+    unsigned long long *len_blk;        // [record blocks + 1]
+    RowTextStatus *st;
+};
+
+void mc_row_text_scratch_sizes(int64_t n, int64_t m, int64_t *rec_blocks, int64_t *row_blocks);
+void mc_launch_row_text(const RowTextIn &I, const RowTextScratch &S, char *out, size_t out_cap, char *out_host, RowTextStatus *st_host,
+                        hipStream_t st);
+
 #endif  // MC_DEV_H

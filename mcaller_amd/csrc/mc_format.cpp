@@ -7,6 +7,7 @@
 // in host memory.  Records the host must look at itself (a context that leaves the contig, an unscored record, a
 // sub-model key that does not exist, a base without a complement: the reference's exit/crash paths) stop the run:
 // *stop_at names the first such record and the rows before it are returned.
+#include "mc_rowtext.h"
 #include "../../include/mcaller_hip.h"
 
 #include <algorithm>
@@ -584,6 +585,14 @@ extern "C" int mc_repr_fixed4(int32_t d, char *out32) {
     char *e = put_fixed4(out32, d);
     *e = 0;
     return (int)(e - out32);
+}
+
+// repr(float) as the device row writer makes it (mc_rowtext.h, host build; tests pin it against Python's and against mc_repr_double)
+extern "C" int mc_repr_double_rowtext(double v, char *out32) {
+    RtStore w{out32};
+    if (!rt_put_repr(w, v)) { out32[0] = 0; return -1; }
+    *w.p = 0;
+    return (int)(w.p - out32);
 }
 
 // repr(float) alone (tests pin it against Python's)

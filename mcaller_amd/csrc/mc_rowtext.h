@@ -1,0 +1,163 @@
+// Rows of text on the device (mc_rowtext.hip): the pieces of a .diffs row that are numbers, for a host and a device compiler alike
+// (tests/test_numerics.py runs the host build of these against repr() -- mc_repr_double_rowtext).
+//
+// repr(float) is the shortest decimal that reads back as the same double, of several shortest ones the closest (half-way: the even digit)
+// (CPython: David Gay's dtoa, mode 0; the reference writes its slot means with it, extract_contexts.py:207-216 via str()).
+// The host formatter gets those digits from std::to_chars (mc_format.cpp); here they come from the free-format digit generation
+// of Steele & White / Burger & Dybvig in exact integer arithmetic: v = f * 2^e, the gaps to its neighbours m+ and m-, all
+// scaled to integers r / s; digits are peeled off r while the rest is still further from v than the gap.  For the doubles a row
+// holds (slot means, read qualities: RT_REPR_MIN <= |v| < RT_REPR_MAX -- a slot mean that should be zero is 1e-17 or 1e-20 when its
+// sum left a rounding residue) every quantity stays below 2^116: two 64-bit words, no tables.  Anything outside that range is refused (-> the row, and with it the shard, goes to the host formatter).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIP__)
+#define RT_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
+#else
+#define RT_HD inline
+#endif
+
+typedef unsigned __int128 rt_u128;
+
+#define RT_REPR_MIN 1e-29
+#define RT_REPR_MAX 1e9
+
+// Digits (ASCII, no trailing zeros) of the shortest decimal 0.d1d2...dn * 10^decpt that reads back as v;
+// RT_REPR_MIN <= v < RT_REPR_MAX.  -> n (at most 17)
+RT_HD int rt_shortest_digits(double v, char *dig, int *decpt) {
+    uint64_t bits;
+    __builtin_memcpy(&bits, &v, 8);
+    const uint64_t f = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+    const int e = (int)((bits >> 52) & 0x7FF) - 1075;                 // v = f * 2^e, -149 <= e <= -23 in the range above
+    const bool even = (f & 1ull) == 0;                                // (the interval's ends read back as v iff f is even)
+    // (a power of two: the neighbour below is half as far)
+    const bool pow2 = f == (1ull << 52);
+    rt_u128 r = (rt_u128)f << (pow2 ? 2 : 1), s, mp = pow2 ? 2 : 1, mm = 1;
+    int sh = (pow2 ? 2 : 1) - e;                                      // s = 2^sh
+    // k with 10^(k-1) <= high < 10^k, high = (r + m+) / s the upper end of the interval: a guess from the binary exponent
+    // (floor(log2 v) * log10(2), one too small at most) ...
+    int k = (((e + 52) * 78913) >> 18) + 1;
+    if (k >= 0) {
+        const uint64_t ipow[11] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull,
+                                   10000000000ull};
+        s = ((rt_u128)1 << sh) * ipow[k];
+    } else {
+        // v / 10^k = v * 5^-k * 2^-k: the powers of five into r and the gaps, the powers of two out of s -- the numbers stay
+        // below 2^116 down to 1e-29
+        int j = -k;
+        const uint64_t p5[14] = {1ull, 5ull, 25ull, 125ull, 625ull, 3125ull, 15625ull, 78125ull, 390625ull, 1953125ull, 9765625ull, 48828125ull,
+                                 244140625ull, 1220703125ull};
+        s = (rt_u128)1 << (sh - j);
+        while (j > 0) { const int t = j > 13 ? 13 : j; r *= p5[t]; mp *= p5[t]; mm *= p5[t]; j -= t; }
+    }
+    // ... put right
+    if (even ? (r + mp >= s) : (r + mp > s)) { s *= 10u; ++k; }
+    else if (even ? ((r + mp) * 10u < s) : ((r + mp) * 10u <= s)) { r *= 5u; mp *= 5u; mm *= 5u; s >>= 1; --k; }
+    *decpt = k;
+    int n = 0;
+    for (;;) {
+        r *= 10u; mp *= 10u; mm *= 10u;
+        int d = 0;
+        while (r >= s && d < 10) { r -= s; ++d; }                     // d = floor(r / s) <= 9
+        const bool tc1 = even ? (r <= mm) : (r < mm);                 // the digits so far, as they are, read back as v
+        const bool tc2 = even ? (r + mp >= s) : (r + mp > s);         // ... and so they do with the last one raised by one
+        if (!tc1 && !tc2 && n < 16) { dig[n++] = (char)('0' + d); continue; }
+        if (tc2 && (!tc1 || (r << 1) > s || ((r << 1) == s && (d & 1)))) ++d;      // (both: the closer one, half-way to the even digit -- dtoa.c)
+        if (d < 10) dig[n++] = (char)('0' + d);
+        else {                                                        // (a raised 9: the generation is known not to need this)
+            while (n > 0 && dig[n - 1] == '9') --n;
+            if (n == 0) { dig[n++] = '1'; *decpt = k + 1; }
+            else dig[n - 1] = (char)(dig[n - 1] + 1);
+        }
+        break;
+    }
+    while (n > 1 && dig[n - 1] == '0') --n;
+    return n;
+}
+
+// Where the characters go: counted (the pass that sizes the rows) or stored
+struct RtCount {
+    int n = 0;
+    RT_HD void put(char) { ++n; }
+};
+struct RtStore {
+    char *p;
+    RT_HD void put(char c) { *p++ = c; }
+};
+
+// repr(v), Python's layout (float_repr_style 'short': exponent form iff decpt > 16 or decpt < -3, at least two exponent
+// digits, ".0" behind an integer) -> false: not a double this code prints (nan, inf, outside the range above)
+template <class Sink>
+RT_HD bool rt_put_repr(Sink &o, double v) {
+    if (!(v == v)) return false;
+    uint64_t bits;
+    __builtin_memcpy(&bits, &v, 8);
+    if (bits >> 63) { o.put('-'); bits &= ~(1ull << 63); __builtin_memcpy(&v, &bits, 8); }
+    if (v == 0.0) { o.put('0'); o.put('.'); o.put('0'); return true; }
+    if (!(v >= RT_REPR_MIN && v < RT_REPR_MAX)) return false;
+    char dig[20];
+    int decpt;
+    const int nd = rt_shortest_digits(v, dig, &decpt);
+    if (decpt < -3) {                                                 // d[.ddd]e-XX
+        o.put(dig[0]);
+        if (nd > 1) { o.put('.'); for (int i = 1; i < nd; ++i) o.put(dig[i]); }
+        o.put('e'); o.put('-');
+        const int ex = 1 - decpt;                                     // 5 .. 29 here
+        o.put((char)('0' + ex / 10)); o.put((char)('0' + ex % 10));
+        return true;
+    }
+    if (decpt <= 0) {
+        o.put('0'); o.put('.');
+        for (int i = 0; i < -decpt; ++i) o.put('0');
+        for (int i = 0; i < nd; ++i) o.put(dig[i]);
+        return true;
+    }
+    if (decpt >= nd) {
+        for (int i = 0; i < nd; ++i) o.put(dig[i]);
+        for (int i = nd; i < decpt; ++i) o.put('0');
+        o.put('.'); o.put('0');
+        return true;
+    }
+    for (int i = 0; i < decpt; ++i) o.put(dig[i]);
+    o.put('.');
+    for (int i = decpt; i < nd; ++i) o.put(dig[i]);
+    return true;
+}
+
+// a non-negative integer, decimal
+template <class Sink>
+RT_HD void rt_put_uint(Sink &o, uint64_t a) {
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + (int)(a % 10u)); a /= 10u; } while (a);
+    while (n) o.put(tmp[--n]);
+}
+
+// repr(d / 1e4) from the integer d (mc_format.cpp put_fixed4: at most ten significant digits ARE the shortest digits)
+template <class Sink>
+RT_HD void rt_put_fixed4(Sink &o, int32_t d) {
+    uint32_t a = d < 0 ? (uint32_t)(-(int64_t)d) : (uint32_t)d;
+    if (d < 0) o.put('-');
+    const uint32_t ip = a / 10000u;
+    uint32_t fp = a % 10000u;
+    rt_put_uint(o, ip);
+    o.put('.');
+    if (fp == 0) { o.put('0'); return; }
+    const char f4[4] = {(char)('0' + fp / 1000u), (char)('0' + fp / 100u % 10u), (char)('0' + fp / 10u % 10u), (char)('0' + fp % 10u)};
+    int nf = 4;
+    while (f4[nf - 1] == '0') --nf;
+    for (int i = 0; i < nf; ++i) o.put(f4[i]);
+}
+
+// str(np.round(p, 2)) of a probability (extract_contexts.py:207): hundredths -> false: not in [0, 1] (the host's general path)
+template <class Sink>
+RT_HD bool rt_put_prob2(Sink &o, double p1, double hundredths /* nearbyint(p1 * 100) */) {
+    (void)p1;
+    if (!(hundredths >= 0.0 && hundredths <= 100.0)) return false;
+    const int hi = (int)hundredths;
+    if (hi == 100) { o.put('1'); o.put('.'); o.put('0'); return true; }
+    o.put('0'); o.put('.'); o.put((char)('0' + hi / 10));
+    if (hi % 10) o.put((char)('0' + hi % 10));
+    return true;
+}

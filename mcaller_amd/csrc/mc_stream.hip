@@ -47,11 +47,13 @@
 // seen before) is argued in DESIGN.md; every other block is classified irregular and handled by the
 // literal per-run kernel (k_literal) so results never depend on a CPU path.
 #include "mc_dev.h"
+#include <atomic>
 
 // ===================================================================================================
 // host side
 // ===================================================================================================
 constexpr int MC_PASSES_IN_FLIGHT = 4;   // one being copied out, one computing, two queued (the host enqueues while it copies)
+constexpr int MC_ROW_TEXT_BLOCKS = 6;    // pinned blocks the rows of text leave in (mc_rowtext.hip): a pass's stays taken until the host has written it
 
 // What K0 writes and K1 reads, per pass in flight
 struct K0Set {
@@ -137,6 +139,7 @@ struct TableSlot {
     int kp_cap_segs = 0;
     hipEvent_t ev_parsed = nullptr, ev_text_up = nullptr;
     int kp_state = 0;                  // 0: idle, 1: parse enqueued, 2: results handed out (mc_ctx_parse_end)
+    bool from_parser = false;          // the slot's table was made by the device parser: its text and segments (kp_segs_h, sorted) are the table's
     int64_t kp_bytes = 0, kp_flags_sent = 0;
     std::vector<int64_t> kp_seg_row, kp_seg_off, kp_unk_off;
     std::vector<int32_t> kp_seg_contig, kp_seg_len, kp_unk_len;
@@ -236,6 +239,9 @@ struct mc_ctx {
         int k = 0;
         bool used = false, copying = false, timed = true;
         bool one_kernel = false;   // the side stream ran as one kernel (k2_mlp<.., PACK>): its end is ev_done
+        int want_text = 0;         // the rows as text, made on the device (mc_ctx_row_text was on when the pass was enqueued)
+        int text_block = -1;       // ... the pinned block they are on their way to (mc_wait_records_begin), -1: none
+        hipEvent_t ev_text = nullptr;
         int fused_room = 0;        // > 0: the pass ran as ONE kernel (k1_fused) with this many record slots per piece -- holes in between
         int64_t slots = 0;         // ... record slots in all
         int slot = -1;             // table slot the pass scans
@@ -245,6 +251,29 @@ struct mc_ctx {
         std::vector<void *> dev_allocs, k0_allocs;
     } ab[MC_PASSES_IN_FLIGHT];
     hipStream_t side_stream = nullptr;   // classifier and packing of the pipelined passes
+    // rows of text made on the device (mc_rowtext.hip; mc_ctx_row_text): scratch and one text buffer on the device -- the passes'
+    // row writers run one after the other on the side stream --, pinned blocks on the host
+    struct RowTextCtx {
+        int on = 0;
+        char lab_meth[8] = {}, lab_unmeth[8] = {};
+        int lab_meth_len = 0, lab_unmeth_len = 0;
+        RowTextScratch S = {};
+        int64_t cap_rec = 0, cap_rows = 0;
+        std::vector<void *> allocs, out_allocs;
+        char *out = nullptr;
+        size_t out_cap = 0;
+        double bytes_per_row = 0.0;        // room per call row (raised when a pass's rows did not fit)
+        struct Block {
+            char *p = nullptr, *p_dev = nullptr;
+            size_t cap = 0;
+            RowTextStatus *st = nullptr, *st_dev = nullptr;
+            std::atomic<int> busy{0};
+        } blocks[MC_ROW_TEXT_BLOCKS];
+        long long n_text = 0, n_no_block = 0, n_host_needed = 0, n_too_small = 0, n_other = 0;     // passes, by what became of their rows (MCALLER_VERBOSE)
+        // the pass handed out last
+        int last_block = -1;
+        int64_t last_bytes = 0, last_rows = 0;
+    } rt;
     int ab_head = 0, ab_tail = 0, ab_count = 0;
     unsigned long long pass_counter = 0, sync_pass_no = 0;   // pass numbers (never 0)
     int timing_every = 1;          // pipelined passes: the two timing events go with every n-th pass (mc_ctx_set_pass_timing)
@@ -426,9 +455,15 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     if (c->site_stream) { (void)hipStreamSynchronize(c->site_stream); (void)hipStreamDestroy(c->site_stream); }
     (void)sync_pass_streams(c);
     free_async(c);
+    free_pool(c->rt.allocs);
+    free_pool(c->rt.out_allocs);
+    for (auto &blk : c->rt.blocks) {
+        if (blk.p) (void)hipHostFree(blk.p);
+        if (blk.st) (void)hipHostFree(blk.st);
+    }
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (auto &b : c->ab)
-        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied})
+        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied, b.ev_text})
             if (e) (void)hipEventDestroy(e);
     mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
@@ -715,6 +750,7 @@ static int fill_slot(mc_ctx *c, int at, int64_t n, int32_t n_seg, const int64_t 
                      const int32_t *seg_contig_in, const uint8_t *seg_name_start, int32_t n_reads, const double *read_qual,
                      const mc_table_view *cols) {
     TableSlot &S = c->slots[at];
+    S.from_parser = cols == nullptr;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const SmallLayout L = small_layout(n_seg, n_tiles, read_qual ? n_reads : 0);
     unsigned char *st = S.stage;
@@ -1002,6 +1038,7 @@ extern "C" int mc_ctx_parse_begin(mc_ctx *c, const char *text, int64_t n_bytes, 
     HIP_TRY(hipGetLastError());
     S.refs += 1;                                            // the slot is taken until mc_ctx_parse_finish / _abandon
     S.holds_table = false;                                  // (the columns are being overwritten: S.T describes them no more)
+    S.from_parser = false;
     S.kp_state = 1;
     S.kp_bytes = n_bytes;
     if (slot_out) *slot_out = at;
@@ -1725,7 +1762,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k, 
         const unsigned dev_flags = hipEventDisableSystemFence;
         for (hipEvent_t *e : {&b.ev_k0_start, &b.ev_k0_end, &b.ev_scan_start, &b.ev_scan_end, &b.ev_emit_end, &b.ev_k2_start, &b.ev_k2_end})
             HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
-        for (hipEvent_t *e : {&b.ev_done, &b.ev_copied})
+        for (hipEvent_t *e : {&b.ev_done, &b.ev_copied, &b.ev_text})
             HIP_TRY(hipEventCreate(e));
     }
     // the strand-resolve output (64 B per name block) and the record set are sized apart: tables that come in turn differ by a few
@@ -1836,6 +1873,7 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
         memset(b.st_host, 0, sizeof(Counters));
         b.pass_no = ++c->pass_counter;
         b.used = false;
+        b.want_text = 0; b.text_block = -1;
         b.fused_room = 0; b.slots = 0;
         b.slot = -1;
         c->ab_head = (c->ab_head + 1) % MC_PASSES_IN_FLIGHT;
@@ -1892,6 +1930,8 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
     if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt, b.piece_kw)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
+    b.want_text = c->rt.on;
+    b.text_block = -1;
     b.one_kernel = false;
     if (int rc = enqueue_side(c, b, A, &b.one_kernel)) return rc;
     if (!b.one_kernel) {
@@ -1918,6 +1958,85 @@ static int sync_pass_streams(mc_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream2));
+    return 0;
+}
+
+// The rows of a pass as text, made on the device behind its packed block (mc_rowtext.hip) and sent to a pinned block: for passes
+// over a table the device parser made (the read names are in the shard's text), scored, with the context's classifier's key
+// table.  Whatever is missing -- no free block, another kind of table -- leaves the pass without text: the host formats.
+static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m, int64_t n_wide) {
+    auto &R = c->rt;
+    if (b.slot < 0 || m <= 0 || n <= 0 || !c->side_stream) { R.n_other += 1; return 0; }
+    TableSlot &S = c->slots[b.slot];
+    if (!S.from_parser || !S.text || !S.kp_segs || !S.kp_segs_h || !c->kc.chars || S.T.n_seg <= 0) { R.n_other += 1; return 0; }
+    const uint8_t *soc = c->F.left ? c->F.sub_of_char : (c->Sc.params ? c->Sc.sub_of_char : c->M.sub_of_char);
+    if (!soc || !b.prm.score || !b.qual || !c->R.seq) { R.n_other += 1; return 0; }
+    hipStream_t st = c->side_stream;
+    if (R.bytes_per_row <= 0.0) {
+        size_t longest = 0;
+        for (const std::string &nm : c->kc.names) longest = std::max(longest, nm.size());
+        R.bytes_per_row = 64.0 + 2.0 * b.k + 20.0 * b.k + 64.0 + (double)longest;
+    }
+    const size_t need = (size_t)((double)m * R.bytes_per_row) + 4096;
+    int at = -1;
+    for (int i = 0; i < MC_ROW_TEXT_BLOCKS; ++i)
+        if (!R.blocks[i].busy.load() && (at < 0 || (R.blocks[at].cap < need && R.blocks[i].cap >= need))) at = i;
+    if (at < 0) { R.n_no_block += 1; return 0; }
+    auto &blk = R.blocks[at];
+    if (blk.cap < need) {
+        if (blk.p) { (void)hipHostFree(blk.p); blk.p = nullptr; blk.cap = 0; }
+        const size_t cap = need + need / 4;
+        if (pinned((void **)&blk.p, cap)) return -10;
+        HIP_TRY(hipHostGetDevicePointer((void **)&blk.p_dev, blk.p, 0));
+        blk.cap = cap;
+    }
+    if (!blk.st) {
+        if (pinned((void **)&blk.st, sizeof(RowTextStatus))) return -10;
+        HIP_TRY(hipHostGetDevicePointer((void **)&blk.st_dev, blk.st, 0));
+    }
+    if (R.out_cap < need) {
+        HIP_TRY(hipStreamSynchronize(st));                  // (the row writer of the pass before may be at work in it)
+        free_pool(R.out_allocs);
+        R.out = nullptr; R.out_cap = 0;
+        const size_t cap = need + need / 4;
+        if (dev_alloc(R.out_allocs, &R.out, cap)) return -10;
+        R.out_cap = cap;
+    }
+    int64_t nbr, nbw;
+    mc_row_text_scratch_sizes(n, m, &nbr, &nbw);
+    if (R.cap_rec < n || R.cap_rows < m) {
+        HIP_TRY(hipStreamSynchronize(st));
+        free_pool(R.allocs);
+        R.cap_rec = n + n / 4 + 1024; R.cap_rows = m + m / 4 + 1024;
+        int64_t cbr, cbw;
+        mc_row_text_scratch_sizes(R.cap_rec, R.cap_rows, &cbr, &cbw);
+        if (dev_alloc(R.allocs, &R.S.kept_blk, (size_t)cbr + 2) || dev_alloc(R.allocs, &R.S.wide_blk, (size_t)cbw + 2) ||
+            dev_alloc(R.allocs, &R.S.wide_pref, (size_t)R.cap_rows) || dev_alloc(R.allocs, &R.S.rec_len, (size_t)R.cap_rec) ||
+            dev_alloc(R.allocs, &R.S.rec_row, (size_t)R.cap_rec) || dev_alloc(R.allocs, &R.S.len_blk, (size_t)cbr + 2) ||
+            dev_alloc(R.allocs, &R.S.st, 1)) {
+            R.cap_rec = R.cap_rows = 0;
+            return -10;
+        }
+    }
+    const DevTable &T = S.T;
+    RowTextIn I;
+    I.pack = b.pack; I.n = n; I.m = m; I.n_wide = n_wide; I.k = b.k; I.close32 = b.close32 ? 1 : 0;
+    I.seg_begin = T.seg_begin; I.seg_read = T.seg_read; I.seg_contig = T.seg_contig; I.n_seg = T.n_seg;
+    I.segs = S.kp_segs; I.text = S.text;
+    I.qual = b.qual; I.n_qual = b.n_qual;
+    I.R = c->R;
+    I.cn_off = c->kc.name_off; I.cn_len = c->kc.name_len; I.cn_chars = c->kc.chars;
+    I.sub_of_char = soc;
+    I.tail_contig = b.prm.tail_contig;
+    memcpy(I.lab_meth, R.lab_meth, 8); memcpy(I.lab_unmeth, R.lab_unmeth, 8);
+    I.lab_meth_len = R.lab_meth_len; I.lab_unmeth_len = R.lab_unmeth_len;
+    // (the parser listed the segments as its lanes got there; the host's copy is in file order since mc_ctx_parse_end)
+    if (int rc = copy_by_kernel(S.kp_segs, S.kp_segs_h, (size_t)T.n_seg * sizeof(KpSeg), st)) return rc;
+    mc_launch_row_text(I, R.S, R.out, std::min(R.out_cap, blk.cap), blk.p_dev, blk.st_dev, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b.ev_text, st));
+    blk.busy.store(1);
+    b.text_block = at;
     return 0;
 }
 
@@ -1981,6 +2100,8 @@ extern "C" int mc_wait_records_begin(mc_ctx *c) {
         b.h_n_wide = (int64_t)n_wide;
         b.h_n_calls = (int64_t)m;
         HIP_TRY(hipEventRecord(b.ev_copied, cs));
+        b.text_block = -1;
+        if (b.want_text) { if (int rc = enqueue_row_text(c, b, (int64_t)n, (int64_t)m, (int64_t)n_wide)) return rc; }
     }
     b.copying = true;
     return 0;
@@ -2007,6 +2128,20 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     const Counters st = *b.st_host;
     const bool special = st.overflow || st.irregular_pass == b.pass_no;
     if (b.used && !special && st.n_records > 0) HIP_TRY(hipEventSynchronize(b.ev_copied));
+    c->rt.last_block = -1; c->rt.last_bytes = c->rt.last_rows = 0;
+    if (b.text_block >= 0) {                                  // the rows as text (enqueue_row_text)
+        auto &blk = c->rt.blocks[b.text_block];
+        HIP_TRY(hipEventSynchronize(b.ev_text));
+        const RowTextStatus ts = *blk.st;
+        if (ts.too_small && st.n_kept > 0)
+            c->rt.bytes_per_row = std::max(c->rt.bytes_per_row, 1.25 * (double)ts.n_bytes / (double)st.n_kept + 8.0);
+        c->rt.n_host_needed += ts.host_needed ? 1 : 0;
+        if (ts.host_needed && getenv("MCALLER_VERBOSE")) fprintf(stderr, "mcaller_hip: a pass's rows left to the host formatter (reasons 0x%x)\n", ts.host_needed);
+        c->rt.n_too_small += ts.too_small ? 1 : 0;
+        if (special || ts.host_needed || ts.too_small || ts.n_bytes > blk.cap) blk.busy.store(0);
+        else { c->rt.n_text += 1; c->rt.last_block = b.text_block; c->rt.last_bytes = (int64_t)ts.n_bytes; c->rt.last_rows = (int64_t)ts.n_rows; }
+        b.text_block = -1;
+    }
     if (special && getenv("MCALLER_VERBOSE"))
         fprintf(stderr, "mcaller_hip: pass re-run synchronously (overflow %u, irregular %u, big %u, rare %u, records %llu)\n",
                 st.overflow, (unsigned)(st.irregular_pass == b.pass_no), st.n_big, st.n_rare, st.n_records);
@@ -2062,6 +2197,48 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     out->feats_wide = packed ? b.h_wmask : nullptr;
     out->n_wide = packed ? b.h_n_wide : 0;
     out->n_call_rows = n > 0 && b.used ? b.h_n_calls : 0;
+    return 0;
+}
+
+// ---- rows of text made on the device ----
+extern "C" int mc_ctx_row_text(mc_ctx *c, int32_t on, const char *label_meth, const char *label_unmeth) {
+    auto &R = c->rt;
+    if (on) {
+        const size_t lm = label_meth ? strlen(label_meth) : 0, lu = label_unmeth ? strlen(label_unmeth) : 0;
+        if (lm == 0 || lu == 0 || lm > 8 || lu > 8) {
+            mc_set_error("mc_ctx_row_text: labels of 1..8 characters");
+            return -12;
+        }
+        memset(R.lab_meth, 0, 8); memset(R.lab_unmeth, 0, 8);
+        memcpy(R.lab_meth, label_meth, lm); memcpy(R.lab_unmeth, label_unmeth, lu);
+        R.lab_meth_len = (int)lm; R.lab_unmeth_len = (int)lu;
+        // (no pass in flight: whatever held a block is gone -- a stream that ended on an exception never gave its blocks back)
+        if (c->ab_count == 0)
+            for (auto &blk : R.blocks) blk.busy.store(0);
+    }
+    if (!on && R.on && getenv("MCALLER_VERBOSE"))
+        fprintf(stderr, "mcaller_hip: rows written on the device for %lld passes; not for %lld (no free block), %lld (a record for the host), %lld (room too small), %lld (other)\n",
+                R.n_text, R.n_no_block, R.n_host_needed, R.n_too_small, R.n_other);
+    R.on = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int mc_last_row_text(mc_ctx *c, const char **text, int64_t *n_bytes, int64_t *n_rows, int32_t *block) {
+    const auto &R = c->rt;
+    *block = R.last_block;
+    *text = R.last_block >= 0 ? R.blocks[R.last_block].p : nullptr;
+    *n_bytes = R.last_block >= 0 ? R.last_bytes : 0;
+    *n_rows = R.last_block >= 0 ? R.last_rows : 0;
+    return 0;
+}
+
+// (any thread: the host's writer gives a block back when the rows are in the file)
+extern "C" int mc_row_text_release(mc_ctx *c, int32_t block) {
+    if (block < 0 || block >= MC_ROW_TEXT_BLOCKS) {
+        mc_set_error("mc_row_text_release: no such block (%d)", block);
+        return -12;
+    }
+    c->rt.blocks[block].busy.store(0);
     return 0;
 }
 

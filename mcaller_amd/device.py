@@ -278,7 +278,19 @@ class Device(object):
             check(lib().mc_fetch_records(self._ctx, C.byref(vc)))
             rec.n = n.value
             return rec
-        return Records.from_view(v, n.value, k, self)
+        rec = Records.from_view(v, n.value, k, self)
+        text, nb, nr, block = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int32(-1)
+        check(lib().mc_last_row_text(self._ctx, C.byref(text), C.byref(nb), C.byref(nr), C.byref(block)))
+        if block.value >= 0:                 # the rows as text, made on the device (row_text): the host formatter has nothing to do
+            rec.row_text = _lib.RowText(self._ctx, text.value, nb.value, nr.value, block.value)
+        return rec
+
+    @_serialized
+    def row_text(self, on, label_meth=None, label_unmeth=None):
+        """The passes enqueued from now on also write their rows as text on the device (mc_ctx_row_text): wait() hands them out as
+        Records.row_text when the pass had them."""
+        check(lib().mc_ctx_row_text(self._ctx, 1 if on else 0, label_meth.encode() if label_meth else None,
+                                    label_unmeth.encode() if label_unmeth else None))
 
     @_serialized
     def fetch(self, copy=True):

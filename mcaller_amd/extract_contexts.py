@@ -136,7 +136,8 @@ def compute(P, k, skip_thresh, qual_thresh, modelset, base, train, device=None, 
 class Finisher(object):
     """Flush records -> the reference's rows, counters and train dicts, in record (= file) order.
 
-    Predict mode: the rows are written by the native formatter (mc_format_diffs, all host cores); a record it hands
+    Predict mode: the rows come with the records when the device wrote them (streamed shards: mc_rowtext.hip), else they are
+    written by the native formatter (mc_format_diffs, all host cores); a record it hands
     back (context leaving the contig, unscored, unknown sub-model key: the reference's exit/crash paths) goes through
     `_one`, the literal per-record transcription of extract_contexts.py:179-239, which train mode uses throughout
     (it has to build the Python lists the caller trains on)."""
@@ -167,13 +168,15 @@ class Finisher(object):
         n = 0
         for b in self.blobs:
             if len(b):
-                sink(b.view if isinstance(b, _lib.LibBuffer) else b)
                 n += len(b)
+                sink(b.view if isinstance(b, (_lib.LibBuffer, _lib.RowText)) else b)
+            if isinstance(b, _lib.RowText):
+                b.release()                                    # (the pinned block goes back to the context)
         return n
 
     def text(self, max_rows=None):
         """The rows as bytes; max_rows: only the first that many (the reference's 5000-row batches on an exit)."""
-        blob = b''.join(b.view if isinstance(b, _lib.LibBuffer) else b for b in self.blobs)
+        blob = b''.join(b.view if isinstance(b, (_lib.LibBuffer, _lib.RowText)) else b for b in self.blobs)
         if max_rows is None:
             return blob
         return b''.join(blob.splitlines(True)[:max_rows])
@@ -229,6 +232,14 @@ class Finisher(object):
                     return stop
             return None
         P, t = self.P, self.P.table
+        text = getattr(rec, 'row_text', None)
+        if text is not None:
+            # the rows came with the records, written on the device (mc_rowtext.hip: every record was one the native formatter
+            # would have printed -- anything else and the pass comes without text): the counters are all that is left to do
+            self.blobs.append(text)
+            self.num_observations += text.n_rows
+            self._count(n)
+            return None
         label_meth = 'm6A' if self.base == 'A' else 'm' + self.base                # :200-204
         fmt = _lib.DiffsFormatter(rec, t, P.ref.device_arrays(), P.ref.names, [str(q) for q in P.qual_obj], self.k,
                                   label_meth, self.base, self.soc, tail_chrom=self.tail_chrom)
@@ -653,6 +664,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     # the device (on_shard needs what the formatter found).  The helpers are at most two shards behind: the records they read stay
     # where they are until four more passes have been enqueued.
     overlap = not train and on_shard is None and not os.environ.get('MCALLER_NO_OVERLAP')
+    # ... and the rows themselves are written on the GPU, behind the records they are made from (mc_rowtext.hip), when the shard's
+    # table is one the device parser made: what is left for the helpers is the counters and the write.  MCALLER_DEVICE_ROWS=0: the
+    # host formatter throughout.
+    device_rows = on_device and not train and os.environ.get('MCALLER_DEVICE_ROWS', '1') != '0'
+    clock['device_rows'] = 0
     fmt_pool = ThreadPoolExecutor(max_workers=2) if overlap else None
     write_pool = ThreadPoolExecutor(max_workers=1) if overlap else None     # (... and one more appends them: in order, one shard behind)
     pending, writes = [], []        # the helpers' jobs in flight (futures), if any
@@ -738,6 +754,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
         else:
             write_rows()
         clock['records'] += int(rec.n)
+        clock['device_rows'] += 1 if getattr(rec, 'row_text', None) is not None else 0
         n = rec.n
         if n:
             # the distinct positions of the file: a mark per position, counted at the end (mc_count_records: one pass in the library)
@@ -791,6 +808,9 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             dev.set_reference(ref.device_arrays())
             marked[0] = n_marked
         needs_a_slot(dev.upload_table_async, P.table, P.qual)
+        if device_rows:
+            # (str(quality) on the device is repr of the double: for what read_qual / the FASTQ reader return, floats)
+            dev.row_text(all(isinstance(q, float) for q in P.qual_obj), 'm6A' if base == 'A' else 'm' + base, base)     # :200-204
         dev.run_async(k, skip_thresh, qual_thresh, tail_contig=tail_id, score=not train)
 
     while next_piece[0] < len(pieces) and len(ahead) < 3:      # (the first shards are read while the masks are made)
@@ -849,6 +869,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
                 mark('enqueued')
                 clock['enqueue'] += time.perf_counter() - t_e
                 in_flight.append((prev, ref.names[tail_id] if tail_id >= 0 else None, prev_rows_before))
+                if device_rows and len(in_flight) >= 2:
+                    dev.wait_begin()                           # (the oldest pass's copy-out and row writer start now, not when it is waited for)
             prev = P
             if P is None:
                 break
@@ -883,6 +905,11 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
             pass
         raise
     finally:
+        if device_rows:
+            try:
+                dev.row_text(False)
+            except Exception:                                  # noqa
+                pass
         pool.shutdown(wait=True)
         if fmt_pool is not None:
             fmt_pool.shutdown(wait=True)
