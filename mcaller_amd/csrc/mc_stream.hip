@@ -263,6 +263,7 @@ struct mc_ctx {
         char *out = nullptr;
         size_t out_cap = 0;
         double bytes_per_row = 0.0;        // room per call row (raised when a pass's rows did not fit)
+        bool room_forced = false;          // (tests, MCALLER_ROW_TEXT_ROOM: a pass gets the room the estimate says, not what the buffers hold)
         struct Block {
             char *p = nullptr, *p_dev = nullptr;
             size_t cap = 0;
@@ -1979,7 +1980,8 @@ static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m
     }
     const size_t need = (size_t)((double)m * R.bytes_per_row) + 4096;
     int at = -1;
-    for (int i = 0; i < MC_ROW_TEXT_BLOCKS; ++i)
+    static const int n_blocks = getenv("MCALLER_ROW_TEXT_BLOCKS") ? std::max(0, std::min(MC_ROW_TEXT_BLOCKS, atoi(getenv("MCALLER_ROW_TEXT_BLOCKS")))) : MC_ROW_TEXT_BLOCKS;   // (tests: none free)
+    for (int i = 0; i < n_blocks; ++i)
         if (!R.blocks[i].busy.load() && (at < 0 || (R.blocks[at].cap < need && R.blocks[i].cap >= need))) at = i;
     if (at < 0) { R.n_no_block += 1; return 0; }
     auto &blk = R.blocks[at];
@@ -2032,7 +2034,7 @@ static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m
     I.lab_meth_len = R.lab_meth_len; I.lab_unmeth_len = R.lab_unmeth_len;
     // (the parser listed the segments as its lanes got there; the host's copy is in file order since mc_ctx_parse_end)
     if (int rc = copy_by_kernel(S.kp_segs, S.kp_segs_h, (size_t)T.n_seg * sizeof(KpSeg), st)) return rc;
-    mc_launch_row_text(I, R.S, R.out, std::min(R.out_cap, blk.cap), blk.p_dev, blk.st_dev, st);
+    mc_launch_row_text(I, R.S, R.out, R.room_forced ? std::min(need, std::min(R.out_cap, blk.cap)) : std::min(R.out_cap, blk.cap), blk.p_dev, blk.st_dev, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b.ev_text, st));
     blk.busy.store(1);
@@ -2215,6 +2217,8 @@ extern "C" int mc_ctx_row_text(mc_ctx *c, int32_t on, const char *label_meth, co
         // (no pass in flight: whatever held a block is gone -- a stream that ended on an exception never gave its blocks back)
         if (c->ab_count == 0)
             for (auto &blk : R.blocks) blk.busy.store(0);
+        R.room_forced = getenv("MCALLER_ROW_TEXT_ROOM") != nullptr;                                           // (tests: rows that do not fit)
+        if (R.room_forced && !R.on) R.bytes_per_row = std::max(1.0, atof(getenv("MCALLER_ROW_TEXT_ROOM")));
     }
     if (!on && R.on && getenv("MCALLER_VERBOSE"))
         fprintf(stderr, "mcaller_hip: rows written on the device for %lld passes; not for %lld (no free block), %lld (a record for the host), %lld (room too small), %lld (other)\n",

@@ -70,6 +70,50 @@ def test_native_repr_matches_python():
         assert repr_double(float(np.round(np.float64(p), 2))) == str(np.round(np.float64(p), 2))
 
 
+def test_the_device_row_writers_digits_match_python():
+    """mc_repr_double_rowtext -- mc_rowtext.h's shortest round-trip digits (free-format generation in 128-bit integer arithmetic,
+    what the GPU's row writer prints slot means and read qualities with), built for the host -- == repr(float) over its whole range
+    [1e-29, 1e9) and zero; everything else it refuses (the host formatter's case).  Half-way cases go to the even digit like dtoa.c."""
+    import math
+    import struct
+    from mcaller_amd._lib import repr_double_rowtext as rt
+    rng = random.Random(17)
+    assert [rt(v) for v in (0.0, -0.0, 1.0, -2.5, 0.1 + 0.2, 1e-4, 9.999999999999999e-05, 5e-5, 1e-29, 999999999.9999999)] == \
+        ['0.0', '-0.0', '1.0', '-2.5', '0.30000000000000004', '0.0001', '9.999999999999999e-05', '5e-05', '1e-29', '999999999.9999999']
+    for v in (float('nan'), float('inf'), float('-inf'), 1e9, -1e9, 9.9e-30, 5e-324, 1e300):
+        assert rt(v) is None
+    vals = [-647985485.19140625, 2.9802322387695312e-08, 0.5, 0.25, 0.125, 1 / 3, 2 / 3, 7.055265349382997, 123456789.125, 5.551115123125783e-17,
+            9.25185853854297e-18, 1.3552527156068805e-20]
+    vals += [math.ldexp(1.0 + rng.random(), rng.randrange(-96, 29)) * rng.choice((-1, 1)) for _ in range(60000)]        # any mantissa, any exponent of the range
+    vals += [rng.randrange(-2000000, 2000000) / (rng.randrange(1, 13) * 1e4) for _ in range(40000)]                      # slot means
+    vals += [(rng.randrange(-2000000, 2000000) / 1e4) / rng.randrange(1, 13) for _ in range(40000)]
+    vals += [round(rng.uniform(3, 40), rng.randrange(0, 16)) for _ in range(10000)]                                      # read qualities
+    for _ in range(20000):                                                                                               # sums with a rounding residue
+        n = rng.randrange(2, 10)
+        xs = [rng.randrange(-100000, 100000) / 1e4 for _ in range(n)]
+        vals.append((sum(xs) - sum(reversed(xs))) / n)
+        vals.append(sum(xs) / n)
+    for e in range(-96, 30):                                                                                            # powers of two (the lower gap is half the upper) ...
+        p2 = math.ldexp(1.0, e)
+        vals += [p2, float(np.nextafter(p2, 0.0)), float(np.nextafter(p2, 1e300))]
+    for e in range(-29, 9):                                                                                             # ... and of ten, with their neighbours
+        p10 = float('1e%d' % e)
+        v = w = p10
+        for _ in range(40):
+            vals += [v, w]
+            v, w = float(np.nextafter(v, 0.0)), float(np.nextafter(w, 1e300))
+    vals += [(rng.getrandbits(rng.randrange(30, 54)) | 1) / math.ldexp(1.0, rng.randrange(1, 31)) for _ in range(40000)]    # short binary fractions: the half-way cases
+    vals += [struct.unpack('<d', struct.pack('<Q', rng.getrandbits(64)))[0] for _ in range(20000)]                       # any bit pattern (mostly refused)
+    refused = 0
+    for v in vals:
+        got = rt(v)
+        if v == v and (v == 0.0 or 1e-29 <= abs(v) < 1e9):
+            assert got == repr(v), v
+        else:
+            assert got is None, v
+            refused += 1
+    assert refused < len(vals) // 4
+
 def test_division_by_1e4_without_dividing(tmp_path):
     """k1_emit's div1e4() (reciprocal, two fma) is the IEEE quotient for every int32: proof by exhaustion, in C."""
     import shutil
