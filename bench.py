@@ -47,7 +47,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(REPO, 'profiles', 'r06_pmc.json')
-KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip',
+KERNEL_SOURCES = ['mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_rowtext.h', 'mcaller_amd/csrc/mc_rowtext.hip', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip', 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip',
                   'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip', 'mcaller_amd/csrc/mc_devparse.inc']
 
 
@@ -405,9 +405,11 @@ def dense_file_to_file_leg(inputs_dir, rows, runs):
     phases = {k: float(np.median([p[k] for p in ph])) for k in ('parse', 'wait_parser', 'enqueue', 'hand_out', 'wait_records', 'wait_formatter', 'format', 'write')
               if ph and all(k in p for p in ph)}
     fmt_threads = max(1, int(ph[-1].get('format_threads', 1) or 1)) if ph else 1
+    dev_rows = int(ph[-1].get('device_rows', 0) or 0) if ph else 0         # shards whose rows the GPU wrote (mc_rowtext.hip)
+    n_shards = int(ph[-1].get('shards', 0) or 0) if ph else 0
     bound = None
     if phases:
-        main = {'formatter (mc_format_diffs: shortest round-trip doubles, rows of text; per helper thread)': phases.get('format', 0.0) / fmt_threads,
+        main = {'helper threads (rows the host formatted -- mc_format_diffs -- and the counters; per helper thread)': phases.get('format', 0.0) / fmt_threads,
                 'write (the rows appended to the output file)': phases.get('write', 0.0),
                 'GPU + copy-out behind the link (records waited for)': phases.get('wait_records', 0.0),
                 'reader + link + device parser (next table waited for)': phases.get('wait_parser', 0.0)}
@@ -417,12 +419,13 @@ def dense_file_to_file_leg(inputs_dir, rows, runs):
             'events_per_s': rows / med, 'calls_per_s': res['calls'] / med, 'text_in_GBps': res['tsv_bytes'] / med / 1e9,
             'text_out_GBps': res['diffs_bytes'] / med / 1e9, 'peak_rss_mb': res['peak_rss_mb'],
             'phases_s': phases, 'bound': bound,
-            'format_threads': fmt_threads,
+            'format_threads': fmt_threads, 'shards': n_shards, 'shards_with_rows_written_on_the_gpu': dev_rows,
             'phases_what': 'seconds per run, median of the warm runs.  Of the MAIN thread (they add up to the run; the reader threads and '
                            'the GPU work beside it): wait_parser = the next shard\'s table waited for (read, H2D, device parser), enqueue '
                            '= upload + passes enqueued, hand_out = wait_records (kernels + copy-out of the oldest pass) + wait_formatter '
-                           '(the helper two shards back).  Of the helper threads: format = the shards\' rows made (native row formatter '
-                           'on all host cores + the counters; the sum over format_threads helpers), write = rows appended to the file',
+                           '(the helper two shards back).  Of the helper threads: format = what is left of a shard for the host -- the '
+                           'counters, and the rows of the shards the GPU did not write (native row formatter on all host cores); the sum '
+                           'over format_threads helpers --, write = rows appended to the file',
             'what': 'python tools/file_to_file.py --inputs ... --motif A --runs %d --json: the CLI in a process of its own, page cache warm' % runs}
 
 

@@ -23,9 +23,60 @@ typedef unsigned __int128 rt_u128;
 #define RT_REPR_MIN 1e-29
 #define RT_REPR_MAX 1e9
 
-// Digits (ASCII, no trailing zeros) of the shortest decimal 0.d1d2...dn * 10^decpt that reads back as v;
-// RT_REPR_MIN <= v < RT_REPR_MAX.  -> n (at most 17)
-RT_HD int rt_shortest_digits(double v, char *dig, int *decpt) {
+// Up to 17 decimal digits, four bits each, first digit in the highest place: no array (on the device an array indexed by a running
+// count lives in registers and every access is a chain of selects)
+struct RtDigits {
+    uint64_t lo = 0;            // the last 16 digits pushed
+    unsigned hi = 0;            // what was pushed out of lo (the first digit of 17)
+    int n = 0;
+    RT_HD void push(int d) { hi = (unsigned)(lo >> 60); lo = (lo << 4) | (uint64_t)(unsigned)d; ++n; }
+    RT_HD int at(int i) const {                                       // digit i, 0 = the first
+        const int back = n - 1 - i;                                   // places from the last
+        return back >= 16 ? (int)hi : (int)((lo >> (4 * back)) & 15u);
+    }
+    RT_HD int last() const { return (int)(lo & 15u); }
+    RT_HD void pop() { lo = (lo >> 4) | ((uint64_t)hi << 60); hi = 0; --n; }
+    RT_HD void raise_last() { lo += 1; }
+};
+
+// floor(r / s) for r < 10 s: an estimate from the leading bits, put right (64-bit integers: the quotient of two floats is off by
+// less than one either way)
+RT_HD int rt_small_quotient(uint64_t r, uint64_t s) {
+    int d = (int)((float)r / (float)s);
+    d = d > 9 ? 9 : d;
+    uint64_t p = (uint64_t)(unsigned)d * s;
+    if (p > r) { --d; p -= s; }
+    if (r - p >= s) ++d;
+    return d;
+}
+
+// The digit generation proper: r / s = v / 10^k in [0.1, 1), mp / s and mm / s the gaps to the neighbours' mid-points above and below,
+// in integers of type U (128 bits wide, or 64 when s < 2^60: r * 10, r + mp * 10 and 2 r all stay below 11 s).
+template <class U>
+RT_HD void rt_generate(U r, U s, U mp, U mm, bool even, RtDigits &dig, int *decpt) {
+    for (;;) {
+        r *= 10u; mp *= 10u; mm *= 10u;
+        int d = 0;
+        if (sizeof(U) == 8) { d = rt_small_quotient((uint64_t)r, (uint64_t)s); r -= (U)((uint64_t)(unsigned)d * (uint64_t)s); }
+        else { while (r >= s && d < 10) { r -= s; ++d; } }            // d = floor(r / s) <= 9
+        const bool tc1 = even ? (r <= mm) : (r < mm);                 // the digits so far, as they are, read back as v
+        const bool tc2 = even ? (r + mp >= s) : (r + mp > s);         // ... and so they do with the last one raised by one
+        if (!tc1 && !tc2 && dig.n < 16) { dig.push(d); continue; }
+        if (tc2 && (!tc1 || (r << 1) > s || ((r << 1) == s && (d & 1)))) ++d;      // (both: the closer one, half-way to the even digit -- dtoa.c)
+        if (d < 10) dig.push(d);
+        else {                                                        // (a raised 9: the generation is known not to need this)
+            while (dig.n > 0 && dig.last() == 9) dig.pop();
+            if (dig.n == 0) { dig.push(1); *decpt += 1; }
+            else dig.raise_last();
+        }
+        break;
+    }
+    while (dig.n > 1 && dig.last() == 0) dig.pop();
+}
+
+// Digits (no trailing zeros) of the shortest decimal 0.d1d2...dn * 10^decpt that reads back as v;
+// RT_REPR_MIN <= v < RT_REPR_MAX.  n is at most 17
+RT_HD void rt_shortest_digits(double v, RtDigits &dig, int *decpt) {
     uint64_t bits;
     __builtin_memcpy(&bits, &v, 8);
     const uint64_t f = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
@@ -55,25 +106,9 @@ RT_HD int rt_shortest_digits(double v, char *dig, int *decpt) {
     if (even ? (r + mp >= s) : (r + mp > s)) { s *= 10u; ++k; }
     else if (even ? ((r + mp) * 10u < s) : ((r + mp) * 10u <= s)) { r *= 5u; mp *= 5u; mm *= 5u; s >>= 1; --k; }
     *decpt = k;
-    int n = 0;
-    for (;;) {
-        r *= 10u; mp *= 10u; mm *= 10u;
-        int d = 0;
-        while (r >= s && d < 10) { r -= s; ++d; }                     // d = floor(r / s) <= 9
-        const bool tc1 = even ? (r <= mm) : (r < mm);                 // the digits so far, as they are, read back as v
-        const bool tc2 = even ? (r + mp >= s) : (r + mp > s);         // ... and so they do with the last one raised by one
-        if (!tc1 && !tc2 && n < 16) { dig[n++] = (char)('0' + d); continue; }
-        if (tc2 && (!tc1 || (r << 1) > s || ((r << 1) == s && (d & 1)))) ++d;      // (both: the closer one, half-way to the even digit -- dtoa.c)
-        if (d < 10) dig[n++] = (char)('0' + d);
-        else {                                                        // (a raised 9: the generation is known not to need this)
-            while (n > 0 && dig[n - 1] == '9') --n;
-            if (n == 0) { dig[n++] = '1'; *decpt = k + 1; }
-            else dig[n - 1] = (char)(dig[n - 1] + 1);
-        }
-        break;
-    }
-    while (n > 1 && dig[n - 1] == '0') --n;
-    return n;
+    // every slot mean from a thousandth up: 64-bit integers do
+    if (s < ((rt_u128)1 << 60)) rt_generate<uint64_t>((uint64_t)r, (uint64_t)s, (uint64_t)mp, (uint64_t)mm, even, dig, decpt);
+    else rt_generate<rt_u128>(r, s, mp, mm, even, dig, decpt);
 }
 
 // Where the characters go: counted (the pass that sizes the rows) or stored
@@ -96,12 +131,13 @@ RT_HD bool rt_put_repr(Sink &o, double v) {
     if (bits >> 63) { o.put('-'); bits &= ~(1ull << 63); __builtin_memcpy(&v, &bits, 8); }
     if (v == 0.0) { o.put('0'); o.put('.'); o.put('0'); return true; }
     if (!(v >= RT_REPR_MIN && v < RT_REPR_MAX)) return false;
-    char dig[20];
+    RtDigits dig;
     int decpt;
-    const int nd = rt_shortest_digits(v, dig, &decpt);
+    rt_shortest_digits(v, dig, &decpt);
+    const int nd = dig.n;
     if (decpt < -3) {                                                 // d[.ddd]e-XX
-        o.put(dig[0]);
-        if (nd > 1) { o.put('.'); for (int i = 1; i < nd; ++i) o.put(dig[i]); }
+        o.put((char)('0' + dig.at(0)));
+        if (nd > 1) { o.put('.'); for (int i = 1; i < nd; ++i) o.put((char)('0' + dig.at(i))); }
         o.put('e'); o.put('-');
         const int ex = 1 - decpt;                                     // 5 .. 29 here
         o.put((char)('0' + ex / 10)); o.put((char)('0' + ex % 10));
@@ -110,28 +146,33 @@ RT_HD bool rt_put_repr(Sink &o, double v) {
     if (decpt <= 0) {
         o.put('0'); o.put('.');
         for (int i = 0; i < -decpt; ++i) o.put('0');
-        for (int i = 0; i < nd; ++i) o.put(dig[i]);
+        for (int i = 0; i < nd; ++i) o.put((char)('0' + dig.at(i)));
         return true;
     }
     if (decpt >= nd) {
-        for (int i = 0; i < nd; ++i) o.put(dig[i]);
+        for (int i = 0; i < nd; ++i) o.put((char)('0' + dig.at(i)));
         for (int i = nd; i < decpt; ++i) o.put('0');
         o.put('.'); o.put('0');
         return true;
     }
-    for (int i = 0; i < decpt; ++i) o.put(dig[i]);
+    for (int i = 0; i < decpt; ++i) o.put((char)('0' + dig.at(i)));
     o.put('.');
-    for (int i = decpt; i < nd; ++i) o.put(dig[i]);
+    for (int i = decpt; i < nd; ++i) o.put((char)('0' + dig.at(i)));
     return true;
 }
 
-// a non-negative integer, decimal
+// a non-negative integer below 2^32, decimal (divisions by constants: multiplications)
 template <class Sink>
-RT_HD void rt_put_uint(Sink &o, uint64_t a) {
-    char tmp[20];
-    int n = 0;
-    do { tmp[n++] = (char)('0' + (int)(a % 10u)); a /= 10u; } while (a);
-    while (n) o.put(tmp[--n]);
+RT_HD void rt_put_uint(Sink &o, uint32_t a) {
+    uint32_t p = 1000000000u;
+    bool seen = false;
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t d = a / p;
+        a -= d * p;
+        seen = seen || d != 0 || i == 9;
+        if (seen) o.put((char)('0' + d));
+        p /= 10u;
+    }
 }
 
 // repr(d / 1e4) from the integer d (mc_format.cpp put_fixed4: at most ten significant digits ARE the shortest digits)

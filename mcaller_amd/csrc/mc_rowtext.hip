@@ -136,6 +136,30 @@ __device__ __forceinline__ int rt_comp_of(int c) {          // base_comps, extra
     }
 }
 
+// Where a row's characters go in the writing pass: eight at a time once the address is a multiple of eight (a lane's row is its own
+// stretch of the text: whole words inside it are its alone; the bytes in front of the first such word and behind the last go one by
+// one) -- a store per character was one L2 request per character, 64 lines per instruction.
+struct RtStoreWords {
+    char *p;                    // next character's place
+    uint64_t acc = 0;
+    int fill = -1;              // characters gathered in acc; -1: the address has not reached a multiple of eight yet
+    __device__ __forceinline__ explicit RtStoreWords(char *at) : p(at) { if ((reinterpret_cast<uintptr_t>(at) & 7u) == 0) fill = 0; }
+    __device__ __forceinline__ void put(char c) {
+        if (fill < 0) {
+            *p++ = c;
+            if ((reinterpret_cast<uintptr_t>(p) & 7u) == 0) fill = 0;
+            return;
+        }
+        acc |= (uint64_t)(unsigned char)c << (8 * fill);
+        ++p;
+        if (++fill == 8) { *reinterpret_cast<uint64_t *>(p - 8) = acc; acc = 0; fill = 0; }
+    }
+    __device__ __forceinline__ void flush() {
+        for (int i = 0; i < fill; ++i) p[i - fill] = (char)(acc >> (8 * i));
+        fill = fill < 0 ? fill : 0;
+    }
+};
+
 // The row of record j (call row `row`) into the sink, as mc_format.cpp format_range writes it; false: the host decides
 template <class Sink>
 __device__ unsigned rt_row(const RowTextIn &I, const PackView &V, const uint32_t *wide_pref, int64_t j, uint32_t row, uint32_t info, Sink &o) {
@@ -173,8 +197,8 @@ __device__ unsigned rt_row(const RowTextIn &I, const PackView &V, const uint32_t
         o.put('\t');
     }
     const int32_t mpos = V.site_pos[j];
-    if (mpos < 0) { o.put('-'); rt_put_uint(o, (uint64_t)(-(int64_t)mpos)); }
-    else rt_put_uint(o, (uint64_t)mpos);
+    if (mpos < 0) { o.put('-'); rt_put_uint(o, (uint32_t)(-(int64_t)mpos)); }
+    else rt_put_uint(o, (uint32_t)mpos);
     o.put('\t');
     // the marked context, last_ref[mpos-k+1 : mpos+k]  (:194; mc_format.cpp build_context)
     const int k = I.k;
@@ -265,8 +289,9 @@ __global__ __launch_bounds__(RT_B) void k_rt_rows(RowTextIn I, RowTextScratch S,
         if (j < I.n) len = S.rec_len[j];
         const unsigned long long at = S.len_blk[blockIdx.x] + rt_block_excl(len, s_w, &total);
         if (len) {
-            RtStore w{out + at};
+            RtStoreWords w(out + at);
             (void)rt_row(I, V, S.wide_pref, j, S.rec_row[j], V.info[j], w);
+            w.flush();
         }
     }
 }

@@ -26,6 +26,12 @@ rm -rf $out/fetch $out/write $out/stats
 # ... the same with the side stream as the three kernels it was (k1_rare_dev, k2_mlp, k_pack): what the one kernel replaced, on this box
 MCALLER_SIDE_FUSED=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --kernels-only > $out/stats_bench_three_side_kernels.json 2>> $out/bench.err
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats_three_side_kernels.csv; rm -rf $out/stats
+# the rows of text written on the GPU (mc_rowtext.hip): its kernels alone (one shard, pass after pass, nothing else on the GPU), and the
+# campaign of small files through the CLI as one table (the host formatter) and streamed with the device's row writer
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/statsrt -- python3 tools/rowtext_probe.py 1e6 20 A > $out/rowtext_probe.log 2>&1
+cp $out/statsrt/*/*kernel_stats.csv $out/kernel_stats_rowtext_probe.csv; rm -rf $out/statsrt
+( echo "commit $head, kernel sources $src"; timeout 900 python3 tests/tools/fuzz_rowtext.py ${FUZZ_ROWTEXT_CASES:-300} ${FUZZ_SEED:-31000000} ) > $out/fuzz_rowtext.log 2>&1
+( echo "commit $head, kernel sources $src"; timeout 600 python3 tools/stream_soak.py 3e6 ${SOAK_RUNS_QUICK:-12} A; timeout 600 python3 tools/stream_soak.py 3e6 ${SOAK_RUNS_QUICK:-12} GATC ) > $out/stream_soak_rows_on_the_gpu.log 2>&1
 if [ "$3" != "quick" ]; then
 MCALLER_BENCH_DETAILS=$out/bench_sync_details.json timeout 600 python3 bench.py --no-pipeline --kernels-only > $out/bench_sync.json 2>> $out/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 bench.py --kernels-only --no-pipeline --steps 50 > /dev/null 2>> $out/bench.err
@@ -69,3 +75,5 @@ for f in ("bench","bench_driver_cmdline","bench_sync","bench_1e9","bench_dense_1
 P
 tail -n 3 $out/bench.err
 tail -n 2 $out/fuzz.log $out/fuzz_tables.log $out/pipeline_soak.log $out/stream_soak.log 2>/dev/null
+grep -v "^[EW]2026" $out/rowtext_probe.log | tail -n 2; grep "k_rt_" $out/kernel_stats_rowtext_probe.csv | cut -c1-140
+tail -n 1 $out/fuzz_rowtext.log; tail -n 2 $out/stream_soak_rows_on_the_gpu.log

@@ -35,7 +35,7 @@ def kernel_source_hash():
     import hashlib
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for rel in ('mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip',
+    for rel in ('mcaller_amd/csrc/mc_dev.h', 'mcaller_amd/csrc/mc_rows.h', 'mcaller_amd/csrc/mc_rowtext.h', 'mcaller_amd/csrc/mc_rowtext.hip', 'mcaller_amd/csrc/mc_k0.hip', 'mcaller_amd/csrc/mc_scan.hip', 'mcaller_amd/csrc/mc_emit.hip',
                 'mcaller_amd/csrc/mc_fused.hip', 'mcaller_amd/csrc/mc_literal.hip', 'mcaller_amd/csrc/mc_classify.hip', 'mcaller_amd/csrc/mc_stream.hip',
                 'mcaller_amd/csrc/mc_devparse.inc'):     # (bench.KERNEL_SOURCES, in its order)
         with open(os.path.join(repo, rel), 'rb') as fh:
