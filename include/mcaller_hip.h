@@ -276,7 +276,7 @@ int mc_last_pass_info(mc_ctx *ctx, int32_t *fused_room, int32_t *rerun);
  * where: *text / *n_bytes / *n_rows, and *block >= 0, which the caller gives back with mc_row_text_release (any thread) once it
  * has written the rows; *block < 0: this pass has none (not asked for, another kind of table, no free block, or a record the
  * device does not print -- a context that leaves the contig, an unknown sub-model key, an unscored record, a number outside
- * [1e-9, 1e9): the reference's exit paths and the host formatter's general cases) and mc_format_diffs makes the rows as before. */
+ * [1e-29, 1e9): the reference's exit paths and the host formatter's general cases) and mc_format_diffs makes the rows as before. */
 int mc_ctx_row_text(mc_ctx *ctx, int32_t on, const char *label_meth, const char *label_unmeth);
 int mc_last_row_text(mc_ctx *ctx, const char **text, int64_t *n_bytes, int64_t *n_rows, int32_t *block);
 int mc_row_text_release(mc_ctx *ctx, int32_t block);
@@ -451,7 +451,7 @@ int mc_repr_double(double v, char *out32);
  * integers, mc_calls_view.feats_lo32): the same characters as mc_repr_double((double)d / 1e4). */
 int mc_repr_fixed4(int32_t d, char *out32);
 /* repr(v) by the device row writer's digit generation (mc_rowtext.h), built for the host: the same characters as mc_repr_double for
- * 1e-9 <= |v| < 1e9 and for zero; -> length, -1: a double it does not print. */
+ * 1e-29 <= |v| < 1e9 and for zero; -> length, -1: a double it does not print. */
 int mc_repr_double_rowtext(double v, char *out32);
 
 /* ===== measurement plumbing: a table as nanopolish-eventalign text (13 columns), written by all host cores =====
