@@ -1,7 +1,7 @@
 // mc_stream.hip -- libmcaller_hip.so, the host side of the device code (gfx950 / MI355X): contexts, table slots, passes, the
 // device parser (mc_devparse.inc), the per-site reduction and RCCL.  C ABI: include/mcaller_hip.h.  The kernels of the passes live
-// in mc_k0.hip, mc_scan.hip, mc_emit.hip, mc_fused.hip, mc_literal.hip, mc_classify.hip (shared structures: mc_dev.h; the row-by-row
-// walk of one window: mc_rows.h); their map:
+// in mc_k0.hip, mc_scan.hip, mc_emit.hip, mc_fused.hip, mc_literal.hip, mc_classify.hip, mc_rowtext.hip (shared structures: mc_dev.h; the
+// row-by-row walk of one window: mc_rows.h; the digits of a printed double: mc_rowtext.h); their map:
 //
 // The reference's hot path (extract_contexts.py:147-291 + :199) as HIP kernels over a columnar event
 // table resident in HBM:
@@ -39,6 +39,9 @@
 //                                row-by-row walk (its own records'), the MLP, the records packed for the copy-out
 //                k1_rare_dev, k_pack_count / k_pack   the same in kernels of their own (other classifiers than the MLP)
 //                k3_forest, k3_simple   random forest / LR / NBC predict_proba;  k_literal / k_merge  irregular reads, row by row
+//                k_rt_count / k_rt_scan / k_rt_wide / k_rt_rows<false> / k_rt_scan_len / k_rt_rows<true> / k_rt_copy   the rows of a
+//                                streamed shard as TEXT, written behind its packed records (mc_rowtext.hip; mc_ctx_row_text): one lane
+//                                per record, the rows counted, placed by a scan, written, sent to a pinned block
 //                k_site_counts   per-site reduction (+ ncclAllReduce)
 //                k_copy_bytes    small transfers by the compute units (the DMA engines serialise behind queued text)
 //
