@@ -28,6 +28,8 @@ run k2_trace            env MCALLER_LIB=mcaller_amd/variants/k2_trace.so python3
 run side_trace          env MCALLER_LIB=mcaller_amd/variants/k2_trace.so python3 tools/side_trace.py 2e7
 run side_trace_dense    env MCALLER_LIB=mcaller_amd/variants/k2_trace.so python3 tools/side_trace.py 2e7 A
 run kres                python3 tools/kres.py mc_fused
+run rowtext_probe       python3 tools/rowtext_probe.py 3e5 3
+run fuzz_rowtext        python3 tests/tools/fuzz_rowtext.py 6
 run er_trace            env MCALLER_LIB=mcaller_amd/variants/er_trace.so python3 tools/er_trace.py 1e8     # (its trace window is workgroups 40000-41023: 10^8 rows)
 run em_trace            env MCALLER_LIB=mcaller_amd/variants/em_trace.so python3 tools/em_trace.py 2e7
 run emit_grid_probe     tools/emit_grid_probe.sh 2e7
