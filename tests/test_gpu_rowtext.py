@@ -125,3 +125,46 @@ def test_rows_that_do_not_fit_their_room_come_from_the_host_and_the_room_grows(t
     dev, n_dev, n = run_cli(paths, 'A', {'MCALLER_STREAM_SHARDS': '6', 'MCALLER_ROW_TEXT_ROOM': '8'})
     assert dev == want
     assert 0 < n_dev < n                # (the first shard's rows did not fit eight bytes a row: the host's; the room the next ones got was enough)
+
+
+def test_qualities_that_are_not_floats_are_left_to_the_host(tmp_path):
+    """str(quality) on the device is repr of a double: what the FASTQ reader returns.  A caller's dict of ints (str -> '9', not
+    '9.0') or of numpy doubles (str the same as repr) must come out as the reference writes them: the first from the host
+    formatter, the second from the device."""
+    import numpy as np
+    from mcaller_amd import extract_contexts as ec
+    from mcaller_amd.read_qual import extract_read_quality
+    d = str(tmp_path)
+    paths, rows = write_case(d, 9, edge_reads=False, decimals=(2,))
+    r2q = extract_read_quality(paths['fastq'])
+    size = os.path.getsize(paths['tsv'])
+    tmp = paths['tsv'][:-4] + '.diffs.6.tmp0'
+
+    def run(qual, env):
+        saved = {k: os.environ.pop(k, None) for k in ('MCALLER_NO_STREAM', 'MCALLER_STREAM_SHARDS', 'MCALLER_DEVICE_ROWS')}
+        os.environ.update(env)
+        ec.stream_features.last_clock = None
+        try:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ec.extract_features(paths['tsv'], paths['fasta'], qual, 6, 0, 0.0, MODEL, 'NN', 0, endline=size, train=False, base='A', motif='A')
+        finally:
+            for k in saved:
+                os.environ.pop(k, None)
+                if saved[k] is not None:
+                    os.environ[k] = saved[k]
+        clock = ec.stream_features.last_clock or {}
+        return open(tmp, 'rb').read(), clock.get('device_rows', 0), clock.get('shards', 0)
+
+    ints = {name: int(q) + 3 for name, q in r2q.items()}
+    want, _, _ = run(ints, {'MCALLER_NO_STREAM': '1'})
+    got, n_dev, n = run(ints, {'MCALLER_STREAM_SHARDS': '5'})
+    assert got == want and n >= 2 and n_dev == 0
+    assert b',12\t' in want or b',11\t' in want or b',10\t' in want or any(b',%d\t' % v in want for v in set(ints.values()))
+    npq = {name: np.float64(q) for name, q in r2q.items()}
+    want, _, _ = run(npq, {'MCALLER_NO_STREAM': '1'})
+    got, n_dev, n = run(npq, {'MCALLER_STREAM_SHARDS': '5'})
+    assert got == want and n_dev == n
+    floats, _, _ = run(r2q, {'MCALLER_STREAM_SHARDS': '5'})
+    assert floats == want
