@@ -168,3 +168,20 @@ def test_qualities_that_are_not_floats_are_left_to_the_host(tmp_path):
     assert got == want and n_dev == n
     floats, _, _ = run(r2q, {'MCALLER_STREAM_SHARDS': '5'})
     assert floats == want
+
+
+def test_two_times_ten_to_the_seven_rows_of_a_one_base_motif(tmp_path):
+    """The streamed dense mode at size (2 x 10^7 rows, 2.3 GB of text, 1.8 x 10^6 rows out in the default shard schedule): every
+    shard's rows from the GPU, the file the host formatter's byte for byte."""
+    import hashlib
+    from mcaller_amd import synth
+    d = str(tmp_path)
+    codes = synth.genome()
+    table, qual = synth.make_table(20000000, seed=23, codes=codes)
+    paths = synth.write_inputs(table, qual, codes, d)
+    del table
+    host, n_dev0, n0 = run_cli(paths, 'A', {'MCALLER_DEVICE_ROWS': '0'})
+    dev, n_dev, n = run_cli(paths, 'A', {})
+    assert n0 == n and n >= 10 and n_dev0 == 0 and n_dev == n
+    assert len(dev) == len(host) and dev.count(b'\n') > 1500000
+    assert hashlib.sha256(dev).digest() == hashlib.sha256(host).digest()
