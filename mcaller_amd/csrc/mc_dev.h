@@ -562,6 +562,9 @@ struct RowTextScratch {
     uint32_t *wide_pref;                // [call rows]
     uint32_t *rec_len, *rec_row;        // [records]
     unsigned long long *len_blk;        // [record blocks + 1]
+    double *wval;                       // [wide slot means] the 64-bit slot means, in the order the rows hold them
+    unsigned long long *num_lo;         // [wide slot means + reads] their printed digits, and the read qualities' (mc_rowtext.h RtNum, packed)
+    uint32_t *num_meta;
     RowTextStatus *st;
 };
 

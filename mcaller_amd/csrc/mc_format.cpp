@@ -589,9 +589,16 @@ extern "C" int mc_repr_fixed4(int32_t d, char *out32) {
 
 // repr(float) as the device row writer makes it (mc_rowtext.h, host build; tests pin it against Python's and against mc_repr_double)
 extern "C" int mc_repr_double_rowtext(double v, char *out32) {
+    // (as the kernels do it: the digits made, packed into their 16 bytes, unpacked, laid out -- and the length the counting pass would say)
     RtStore w{out32};
-    if (!rt_put_repr(w, v)) { out32[0] = 0; return -1; }
+    uint64_t lo;
+    uint32_t meta;
+    rt_num_pack(rt_num_of(v), &lo, &meta);
+    const RtNum n = rt_num_unpack(lo, meta);
+    if (!n.ok) { out32[0] = 0; return -1; }
+    rt_put_num(w, n);
     *w.p = 0;
+    if ((int)(w.p - out32) != rt_num_length(n)) { out32[0] = 0; return -2; }
     return (int)(w.p - out32);
 }
 

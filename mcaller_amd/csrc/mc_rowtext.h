@@ -121,43 +121,91 @@ struct RtStore {
     RT_HD void put(char c) { *p++ = c; }
 };
 
-// repr(v), Python's layout (float_repr_style 'short': exponent form iff decpt > 16 or decpt < -3, at least two exponent
-// digits, ".0" behind an integer) -> false: not a double this code prints (nan, inf, outside the range above)
-template <class Sink>
-RT_HD bool rt_put_repr(Sink &o, double v) {
-    if (!(v == v)) return false;
+// A double as its printed digits: what the digit generation leaves and the layout needs -- 16 bytes when it waits in memory between
+// the kernel that makes the digits (a lane per NUMBER: every lane in the generation) and the kernels that lay out rows (a lane per row)
+struct RtNum {
+    RtDigits dig;
+    int decpt = 0;
+    bool neg = false, zero = false, ok = false;     // ok: a double this code prints
+};
+
+RT_HD RtNum rt_num_of(double v) {
+    RtNum n;
+    if (!(v == v)) return n;
     uint64_t bits;
     __builtin_memcpy(&bits, &v, 8);
-    if (bits >> 63) { o.put('-'); bits &= ~(1ull << 63); __builtin_memcpy(&v, &bits, 8); }
-    if (v == 0.0) { o.put('0'); o.put('.'); o.put('0'); return true; }
-    if (!(v >= RT_REPR_MIN && v < RT_REPR_MAX)) return false;
-    RtDigits dig;
-    int decpt;
-    rt_shortest_digits(v, dig, &decpt);
-    const int nd = dig.n;
+    if (bits >> 63) { n.neg = true; bits &= ~(1ull << 63); __builtin_memcpy(&v, &bits, 8); }
+    if (v == 0.0) { n.zero = n.ok = true; return n; }
+    if (!(v >= RT_REPR_MIN && v < RT_REPR_MAX)) return n;
+    rt_shortest_digits(v, n.dig, &n.decpt);
+    n.ok = true;
+    return n;
+}
+
+// meta: bits 0-3 the first of 17 digits, 4-8 the number of digits, 9-16 decpt + 64, 17 negative, 18 zero, 19 ok
+RT_HD void rt_num_pack(const RtNum &n, uint64_t *lo, uint32_t *meta) {
+    *lo = n.dig.lo;
+    *meta = (n.dig.hi & 15u) | ((uint32_t)n.dig.n << 4) | ((uint32_t)(n.decpt + 64) << 9) | (n.neg ? 1u << 17 : 0u) | (n.zero ? 1u << 18 : 0u) |
+            (n.ok ? 1u << 19 : 0u);
+}
+RT_HD RtNum rt_num_unpack(uint64_t lo, uint32_t meta) {
+    RtNum n;
+    n.dig.lo = lo; n.dig.hi = meta & 15u; n.dig.n = (int)((meta >> 4) & 31u);
+    n.decpt = (int)((meta >> 9) & 255u) - 64;
+    n.neg = (meta >> 17) & 1u; n.zero = (meta >> 18) & 1u; n.ok = (meta >> 19) & 1u;
+    return n;
+}
+
+// the characters of an RtNum (ok), Python's layout (float_repr_style 'short': exponent form iff decpt > 16 or decpt < -3, at least two
+// exponent digits, ".0" behind an integer)
+template <class Sink>
+RT_HD void rt_put_num(Sink &o, const RtNum &n) {
+    if (n.neg) o.put('-');
+    if (n.zero) { o.put('0'); o.put('.'); o.put('0'); return; }
+    const RtDigits &dig = n.dig;
+    const int nd = dig.n, decpt = n.decpt;
     if (decpt < -3) {                                                 // d[.ddd]e-XX
         o.put((char)('0' + dig.at(0)));
         if (nd > 1) { o.put('.'); for (int i = 1; i < nd; ++i) o.put((char)('0' + dig.at(i))); }
         o.put('e'); o.put('-');
         const int ex = 1 - decpt;                                     // 5 .. 29 here
         o.put((char)('0' + ex / 10)); o.put((char)('0' + ex % 10));
-        return true;
+        return;
     }
     if (decpt <= 0) {
         o.put('0'); o.put('.');
         for (int i = 0; i < -decpt; ++i) o.put('0');
         for (int i = 0; i < nd; ++i) o.put((char)('0' + dig.at(i)));
-        return true;
+        return;
     }
     if (decpt >= nd) {
         for (int i = 0; i < nd; ++i) o.put((char)('0' + dig.at(i)));
         for (int i = nd; i < decpt; ++i) o.put('0');
         o.put('.'); o.put('0');
-        return true;
+        return;
     }
     for (int i = 0; i < decpt; ++i) o.put((char)('0' + dig.at(i)));
     o.put('.');
     for (int i = decpt; i < nd; ++i) o.put((char)('0' + dig.at(i)));
+}
+
+// how many characters rt_put_num writes
+RT_HD int rt_num_length(const RtNum &n) {
+    int len = n.neg ? 1 : 0;
+    if (n.zero) return len + 3;
+    const int nd = n.dig.n, decpt = n.decpt;
+    if (decpt < -3) return len + nd + (nd > 1 ? 1 : 0) + 4;
+    if (decpt <= 0) return len + 2 - decpt + nd;
+    if (decpt >= nd) return len + decpt + 2;
+    return len + nd + 1;
+}
+
+// repr(v) -> false: not a double this code prints (nan, inf, outside the range above)
+template <class Sink>
+RT_HD bool rt_put_repr(Sink &o, double v) {
+    const RtNum n = rt_num_of(v);
+    if (!n.ok) return false;
+    rt_put_num(o, n);
     return true;
 }
 

@@ -9,8 +9,11 @@
 //
 //   k_rt_count     records without MC_I_TOO_MANY per block of 256 records | wide slot means per block of 256 call rows
 //   k_rt_scan      the two lists of block sums -> offsets (one workgroup)
-//   k_rt_wide      wide slot means before every call row
-//   k_rt_rows<false>   every record's row, counted: its length (the digits are made, not stored), block sums of the lengths
+//   k_rt_wide      wide slot means before every call row; the 64-bit slot means gathered into one list, in the rows' order
+//   k_rt_digits    a lane per NUMBER of that list (and per read quality): its shortest round-trip digits, 16 bytes each -- every lane
+//                  of a wave in the digit generation (a lane per row would run it for the rows' 64-bit slots while the rows whose slot
+//                  travels as an integer wait, then the other way round, six slots in turn: three times the instructions)
+//   k_rt_rows<false>   every record's row, counted from the digits' counts: its length, block sums of the lengths
 //   k_rt_scan_len  offsets of the blocks' rows; the total against the room there is
 //   k_rt_rows<true>    the rows, written at their offsets
 //   k_rt_copy      the text into pinned host memory (by the compute units: the DMA engines are busy with the next shards' text),
@@ -121,7 +124,31 @@ __global__ __launch_bounds__(RT_B) void k_rt_wide(RowTextIn I, RowTextScratch S)
     uint32_t total;
     const uint32_t v = r < I.m ? (uint32_t)__popc((unsigned)V.wmask[r]) : 0u;
     const uint32_t ex = rt_block_excl(v, s_w, &total);
-    if (r < I.m) S.wide_pref[r] = S.wide_blk[blockIdx.x] + ex;
+    if (r < I.m) {
+        uint32_t w = S.wide_blk[blockIdx.x] + ex;
+        S.wide_pref[r] = w;
+        const unsigned mask = V.wmask[r];
+        const int32_t *lo = V.lo32 + (size_t)r * I.k;
+        for (int s2 = 0; s2 < I.k; ++s2)
+            if ((mask >> s2) & 1u) {
+                const uint64_t bits = ((uint64_t)V.hi32[w] << 32) | (uint32_t)lo[s2];
+                double f;
+                __builtin_memcpy(&f, &bits, 8);
+                S.wval[w++] = f;
+            }
+    }
+}
+
+// the printed digits of every 64-bit slot mean and of every read's quality: a lane per number
+__global__ __launch_bounds__(RT_B) void k_rt_digits(RowTextIn I, RowTextScratch S) {
+    const int64_t i = (int64_t)blockIdx.x * RT_B + threadIdx.x;
+    if (i >= I.n_wide + I.n_qual) return;
+    const double v = i < I.n_wide ? S.wval[i] : I.qual[i - I.n_wide];
+    uint64_t lo;
+    uint32_t meta;
+    rt_num_pack(rt_num_of(v), &lo, &meta);         // (a number this code does not print -- nan, out of range -- says so in its meta word: whether
+    S.num_lo[i] = lo;                              //  a row needs it is the row's business, an empty slot's garbage is never looked at)
+    S.num_meta[i] = meta;
 }
 
 __device__ __forceinline__ int rt_comp_of(int c) {          // base_comps, extract_contexts.py:11; -1: KeyError there
@@ -154,15 +181,24 @@ struct RtStoreWords {
         ++p;
         if (++fill == 8) { *reinterpret_cast<uint64_t *>(p - 8) = acc; acc = 0; fill = 0; }
     }
+    __device__ __forceinline__ void put_num(const RtNum &n) { rt_put_num(*this, n); }
     __device__ __forceinline__ void flush() {
         for (int i = 0; i < fill; ++i) p[i - fill] = (char)(acc >> (8 * i));
         fill = fill < 0 ? fill : 0;
     }
 };
 
+// ... and in the counting pass: a number's length comes from its digits' count
+struct RtCountRows {
+    int n = 0;
+    __device__ __forceinline__ void put(char) { ++n; }
+    __device__ __forceinline__ void put_num(const RtNum &num) { n += rt_num_length(num); }
+};
+
 // The row of record j (call row `row`) into the sink, as mc_format.cpp format_range writes it; false: the host decides
 template <class Sink>
-__device__ unsigned rt_row(const RowTextIn &I, const PackView &V, const uint32_t *wide_pref, int64_t j, uint32_t row, uint32_t info, Sink &o) {
+__device__ unsigned rt_row(const RowTextIn &I, const PackView &V, const RowTextScratch &S, int64_t j, uint32_t row, uint32_t info, Sink &o) {
+    const uint32_t *wide_pref = S.wide_pref;
     const double p1 = V.prob[row];
     if (!(p1 == p1)) return 1u << 1;                                               // (scored by the host)
     const int32_t seg = V.site_seg[j];
@@ -237,20 +273,23 @@ __device__ unsigned rt_row(const RowTextIn &I, const PackView &V, const uint32_t
         const int32_t *lo = V.lo32 + (size_t)row * k;
         for (int s = 0; s < k; ++s) {
             const bool is_wide = (mask >> s) & 1u;
-            uint32_t hi32 = 0;
-            if (is_wide) hi32 = V.hi32[wide++];
+            const uint32_t w = wide;
+            wide += is_wide ? 1u : 0u;
             if ((empty >> s) & 1u) o.put('0');                                    // literal int 0  (:186)
             else if (!is_wide) rt_put_fixed4(o, lo[s]);
             else {
-                const uint64_t bits = ((uint64_t)hi32 << 32) | (uint32_t)lo[s];
-                double f;
-                __builtin_memcpy(&f, &bits, 8);
-                if (!rt_put_repr(o, f)) return 1u << 14;
+                const RtNum num = rt_num_unpack(S.num_lo[w], S.num_meta[w]);       // (k_rt_digits)
+                if (!num.ok) return 1u << 14;
+                o.put_num(num);
             }
             o.put(',');
         }
     }
-    if (!rt_put_repr(o, I.qual[rid])) return 1u << 15;                              // str(read quality)
+    {
+        const RtNum num = rt_num_unpack(S.num_lo[(size_t)I.n_wide + rid], S.num_meta[(size_t)I.n_wide + rid]);     // str(read quality)
+        if (!num.ok) return 1u << 15;
+        o.put_num(num);
+    }
     o.put('\t');
     o.put((info & MC_I_REV) ? '-' : '+');
     o.put('\t');
@@ -275,8 +314,8 @@ __global__ __launch_bounds__(RT_B) void k_rt_rows(RowTextIn I, RowTextScratch S,
         const uint32_t row = S.kept_blk[blockIdx.x] + rt_block_excl(kept, s_w, &total);
         uint32_t len = 0;
         if (kept) {
-            RtCount c;
-            const unsigned why = rt_row(I, V, S.wide_pref, j, row, info, c);
+            RtCountRows c;
+            const unsigned why = rt_row(I, V, S, j, row, info, c);
             if (!why) len = (uint32_t)c.n;
             else atomicOr(&S.st->host_needed, why);
         }
@@ -290,7 +329,7 @@ __global__ __launch_bounds__(RT_B) void k_rt_rows(RowTextIn I, RowTextScratch S,
         const unsigned long long at = S.len_blk[blockIdx.x] + rt_block_excl(len, s_w, &total);
         if (len) {
             RtStoreWords w(out + at);
-            (void)rt_row(I, V, S.wide_pref, j, S.rec_row[j], V.info[j], w);
+            (void)rt_row(I, V, S, j, S.rec_row[j], V.info[j], w);
             w.flush();
         }
     }
@@ -344,6 +383,8 @@ void mc_launch_row_text(const RowTextIn &I, const RowTextScratch &S, char *out, 
     hipLaunchKernelGGL(k_rt_count, dim3((unsigned)(nbr + nbw)), dim3(RT_B), 0, st, I, S, (unsigned)nbr);
     hipLaunchKernelGGL(k_rt_scan, dim3(1), dim3(RT_B), 0, st, S, nbr, nbw);
     if (nbw > 0) hipLaunchKernelGGL(k_rt_wide, dim3((unsigned)nbw), dim3(RT_B), 0, st, I, S);
+    const int64_t n_num = I.n_wide + I.n_qual;
+    if (n_num > 0) hipLaunchKernelGGL(k_rt_digits, dim3((unsigned)((n_num + RT_B - 1) / RT_B)), dim3(RT_B), 0, st, I, S);
     hipLaunchKernelGGL(k_rt_rows<false>, dim3((unsigned)nbr), dim3(RT_B), 0, st, I, S, out);
     hipLaunchKernelGGL(k_rt_scan_len, dim3(1), dim3(RT_B), 0, st, S, nbr, (unsigned long long)out_cap);
     hipLaunchKernelGGL(k_rt_rows<true>, dim3((unsigned)nbr), dim3(RT_B), 0, st, I, S, out);

@@ -39,9 +39,10 @@
 //                                row-by-row walk (its own records'), the MLP, the records packed for the copy-out
 //                k1_rare_dev, k_pack_count / k_pack   the same in kernels of their own (other classifiers than the MLP)
 //                k3_forest, k3_simple   random forest / LR / NBC predict_proba;  k_literal / k_merge  irregular reads, row by row
-//                k_rt_count / k_rt_scan / k_rt_wide / k_rt_rows<false> / k_rt_scan_len / k_rt_rows<true> / k_rt_copy   the rows of a
-//                                streamed shard as TEXT, written behind its packed records (mc_rowtext.hip; mc_ctx_row_text): one lane
-//                                per record, the rows counted, placed by a scan, written, sent to a pinned block
+//                k_rt_count / k_rt_scan / k_rt_wide / k_rt_digits / k_rt_rows<false> / k_rt_scan_len / k_rt_rows<true> / k_rt_copy   the
+//                                rows of a streamed shard as TEXT, written behind its packed records (mc_rowtext.hip; mc_ctx_row_text):
+//                                the digits of every 64-bit slot mean one lane per number, the rows one lane per record -- counted,
+//                                placed by a scan, written --, the text sent to a pinned block
 //                k_site_counts   per-site reduction (+ ncclAllReduce)
 //                k_copy_bytes    small transfers by the compute units (the DMA engines serialise behind queued text)
 //
@@ -261,7 +262,7 @@ struct mc_ctx {
         char lab_meth[8] = {}, lab_unmeth[8] = {};
         int lab_meth_len = 0, lab_unmeth_len = 0;
         RowTextScratch S = {};
-        int64_t cap_rec = 0, cap_rows = 0;
+        int64_t cap_rec = 0, cap_rows = 0, cap_wide = 0, cap_num = 0;
         std::vector<void *> allocs, out_allocs;
         char *out = nullptr;
         size_t out_cap = 0;
@@ -2009,17 +2010,20 @@ static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m
     }
     int64_t nbr, nbw;
     mc_row_text_scratch_sizes(n, m, &nbr, &nbw);
-    if (R.cap_rec < n || R.cap_rows < m) {
+    if (R.cap_rec < n || R.cap_rows < m || R.cap_wide < n_wide || R.cap_num < n_wide + b.n_qual) {
         HIP_TRY(hipStreamSynchronize(st));
         free_pool(R.allocs);
         R.cap_rec = n + n / 4 + 1024; R.cap_rows = m + m / 4 + 1024;
+        R.cap_wide = std::max<int64_t>(n_wide + n_wide / 4 + 1024, R.cap_wide);
+        R.cap_num = std::max<int64_t>(R.cap_wide + b.n_qual + b.n_qual / 4 + 1024, R.cap_num);
         int64_t cbr, cbw;
         mc_row_text_scratch_sizes(R.cap_rec, R.cap_rows, &cbr, &cbw);
         if (dev_alloc(R.allocs, &R.S.kept_blk, (size_t)cbr + 2) || dev_alloc(R.allocs, &R.S.wide_blk, (size_t)cbw + 2) ||
             dev_alloc(R.allocs, &R.S.wide_pref, (size_t)R.cap_rows) || dev_alloc(R.allocs, &R.S.rec_len, (size_t)R.cap_rec) ||
             dev_alloc(R.allocs, &R.S.rec_row, (size_t)R.cap_rec) || dev_alloc(R.allocs, &R.S.len_blk, (size_t)cbr + 2) ||
-            dev_alloc(R.allocs, &R.S.st, 1)) {
-            R.cap_rec = R.cap_rows = 0;
+            dev_alloc(R.allocs, &R.S.wval, (size_t)R.cap_wide) || dev_alloc(R.allocs, &R.S.num_lo, (size_t)R.cap_num) ||
+            dev_alloc(R.allocs, &R.S.num_meta, (size_t)R.cap_num) || dev_alloc(R.allocs, &R.S.st, 1)) {
+            R.cap_rec = R.cap_rows = R.cap_wide = R.cap_num = 0;
             return -10;
         }
     }
