@@ -269,7 +269,8 @@ typedef struct mc_params {
  * contradicts what a block was classified on) and was repeated synchronously inside mc_wait_records. */
 int mc_last_pass_info(mc_ctx *ctx, int32_t *fused_room, int32_t *rerun);
 /* The rows of a pipelined pass as TEXT, made on the device (mc_rowtext.hip; replaces mc_format_diffs on the host, the row writer of
- * extract_contexts.py:207-216).  mc_ctx_row_text(on = 1, the two labels of :200-206): the passes enqueued from now on also print their
+ * extract_contexts.py:207-216).  mc_ctx_row_text(on = 1, the two labels of :200-206; on = 2 at the start of a stream: also takes back the
+ * blocks an earlier stream never released -- nobody may be reading them any more): the passes enqueued from now on also print their
  * records where they are -- the packed records, the read names in the shard's text (tables the device parser made:
  * mc_ctx_parse_begin .. _finish), the contig names, the marked reference, shortest round-trip digits in integer arithmetic
  * (mc_rowtext.h) -- and send the text to pinned host memory behind the records.  After mc_wait_records, mc_last_row_text says

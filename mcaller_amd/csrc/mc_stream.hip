@@ -2221,8 +2221,9 @@ extern "C" int mc_ctx_row_text(mc_ctx *c, int32_t on, const char *label_meth, co
         memset(R.lab_meth, 0, 8); memset(R.lab_unmeth, 0, 8);
         memcpy(R.lab_meth, label_meth, lm); memcpy(R.lab_unmeth, label_unmeth, lu);
         R.lab_meth_len = (int)lm; R.lab_unmeth_len = (int)lu;
-        // (no pass in flight: whatever held a block is gone -- a stream that ended on an exception never gave its blocks back)
-        if (c->ab_count == 0)
+        // on == 2, the first call of a stream: whatever held a block is gone (a stream that ended on an exception never gave its blocks
+        // back).  Not on the later calls: with no pass in flight the host's writer may still be reading the blocks of the passes handed out
+        if (on == 2 && c->ab_count == 0)
             for (auto &blk : R.blocks) blk.busy.store(0);
         R.room_forced = getenv("MCALLER_ROW_TEXT_ROOM") != nullptr;                                           // (tests: rows that do not fit)
         if (R.room_forced && !R.on) R.bytes_per_row = std::max(1.0, atof(getenv("MCALLER_ROW_TEXT_ROOM")));

@@ -286,10 +286,11 @@ class Device(object):
         return rec
 
     @_serialized
-    def row_text(self, on, label_meth=None, label_unmeth=None):
+    def row_text(self, on, label_meth=None, label_unmeth=None, first=False):
         """The passes enqueued from now on also write their rows as text on the device (mc_ctx_row_text): wait() hands them out as
-        Records.row_text when the pass had them."""
-        check(lib().mc_ctx_row_text(self._ctx, 1 if on else 0, label_meth.encode() if label_meth else None,
+        Records.row_text when the pass had them.  first: the start of a stream -- blocks an earlier stream never gave back are taken
+        back (nobody reads them any more)."""
+        check(lib().mc_ctx_row_text(self._ctx, (2 if first else 1) if on else 0, label_meth.encode() if label_meth else None,
                                     label_unmeth.encode() if label_unmeth else None))
 
     @_serialized

@@ -669,6 +669,8 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     # host formatter throughout.
     device_rows = on_device and not train and os.environ.get('MCALLER_DEVICE_ROWS', '1') != '0'
     clock['device_rows'] = 0
+    if device_rows:
+        dev.row_text(True, 'm6A' if base == 'A' else 'm' + base, base, first=True)     # (:200-204; the blocks of a stream that failed are free again)
     fmt_pool = ThreadPoolExecutor(max_workers=2) if overlap else None
     write_pool = ThreadPoolExecutor(max_workers=1) if overlap else None     # (... and one more appends them: in order, one shard behind)
     pending, writes = [], []        # the helpers' jobs in flight (futures), if any

@@ -87,7 +87,9 @@ def run_cli(paths, motif, env):
     return open(out, 'rb').read(), clock.get('device_rows', 0), clock.get('shards', 0)
 
 
-@pytest.mark.parametrize('motif', ['A', 'GATC'])
+# ('AA' can overlap itself: its masks are made by the host contig by contig as the contigs first appear, and every new contig's upload
+# waits until no pass is in flight -- the moments at which a shard's rows may still be with the host's writer while nothing is in flight)
+@pytest.mark.parametrize('motif', ['A', 'GATC', 'AA'])
 def test_rows_written_on_the_device_are_the_host_formatters(tmp_path, motif):
     with_text = without = 0
     for seed in (11, 12, 13):
@@ -95,7 +97,7 @@ def test_rows_written_on_the_device_are_the_host_formatters(tmp_path, motif):
         os.makedirs(d)
         paths, rows = write_case(d, seed)
         want, _, _ = run_cli(paths, motif, {'MCALLER_NO_STREAM': '1'})
-        assert want.count(b'\n') > (500 if motif == 'A' else 5)
+        assert want.count(b'\n') > (500 if motif == 'A' else 5 if motif == 'GATC' else 50)
         for shards in ('3', '8'):
             host, n_dev0, n0 = run_cli(paths, motif, {'MCALLER_STREAM_SHARDS': shards, 'MCALLER_DEVICE_ROWS': '0'})
             dev, n_dev, n = run_cli(paths, motif, {'MCALLER_STREAM_SHARDS': shards})
