@@ -206,3 +206,44 @@ def test_bench_line_is_small_strict_json():
     full['cpu_baseline_reference_like']['cpu_model'] = 'c' * 3500
     text = json.dumps(bench.contract_line(full))
     assert len(text) < bench.LINE_LIMIT and 'roofline' in json.loads(text) and 'cpu_baseline' in json.loads(text)
+
+
+def test_worker_parts_are_joined_behind_what_the_output_holds(tmp_path):
+    """multi_gpu._join_parts: the parts in order behind whatever the output file holds (the reference appends), a fresh output is
+    the first part renamed, the rest copied in the kernel or -- where copy_file_range is missing or refuses -- block by block."""
+    import random
+    from mcaller_amd.multi_gpu import _join_parts
+    rng = random.Random(3)
+    blobs = [bytes(rng.getrandbits(8) for _ in range(n)) for n in (1000, 0, 70000, 5)]
+
+    def files(tag):
+        paths = []
+        for i, b in enumerate(blobs):
+            p = str(tmp_path / ('%s%d' % (tag, i)))
+            open(p, 'wb').write(b)
+            paths.append(p)
+        return paths
+
+    out = str(tmp_path / 'fresh')
+    parts = files('a')
+    _join_parts(out, parts)
+    assert open(out, 'rb').read() == b''.join(blobs) and not any(os.path.exists(p) for p in parts)
+    out = str(tmp_path / 'appended')
+    open(out, 'wb').write(b'rows of an earlier run\n')
+    _join_parts(out, files('b'))
+    assert open(out, 'rb').read() == b'rows of an earlier run\n' + b''.join(blobs)
+    out = str(tmp_path / 'empty')
+    open(out, 'wb').close()
+    _join_parts(out, files('c')[2:3])
+    assert open(out, 'rb').read() == blobs[2]
+    saved = getattr(os, 'copy_file_range', None)
+    if saved is not None:
+        del os.copy_file_range
+    try:
+        out = str(tmp_path / 'plain')
+        open(out, 'wb').write(b'X')
+        _join_parts(out, files('d'))
+        assert open(out, 'rb').read() == b'X' + b''.join(blobs)
+    finally:
+        if saved is not None:
+            os.copy_file_range = saved
