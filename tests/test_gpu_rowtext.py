@@ -187,3 +187,27 @@ def test_two_times_ten_to_the_seven_rows_of_a_one_base_motif(tmp_path):
     assert n0 == n and n >= 10 and n_dev0 == 0 and n_dev == n
     assert len(dev) == len(host) and dev.count(b'\n') > 1500000
     assert hashlib.sha256(dev).digest() == hashlib.sha256(host).digest()
+
+
+def test_shards_that_find_no_free_block_come_from_the_host(tmp_path):
+    """One pinned block instead of six (MCALLER_ROW_TEXT_BLOCKS, read once per process: a process of its own): a shard whose rows are
+    ready while the block is still with the writer gets none and is formatted by the host -- the file is the same."""
+    import subprocess
+    import sys
+    d = str(tmp_path)
+    paths, rows = write_case(d, 21, n_reads=48, edge_reads=False, decimals=(2,))
+    want, _, _ = run_cli(paths, 'A', {'MCALLER_NO_STREAM': '1'})
+    out = paths['tsv'][:-4] + '.diffs.6'
+    os.remove(out)
+    env = dict(os.environ, MCALLER_ROW_TEXT_BLOCKS='1', MCALLER_STREAM_SHARDS='12', MCALLER_VERBOSE='1')
+    for k in ('MCALLER_NO_STREAM', 'MCALLER_DEVICE_ROWS'):
+        env.pop(k, None)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'mcaller_amd.mCaller', '-m', 'A', '-r', paths['fasta'], '-e', paths['tsv'], '-f', paths['fastq'], '-d', MODEL],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out, 'rb').read() == want
+    said = [l for l in r.stderr.splitlines() if 'rows written on the device for' in l]
+    assert said, r.stderr[-2000:]
+    n_text, n_no_block = int(said[-1].split(' for ')[1].split()[0]), int(said[-1].split('not for ')[1].split()[0])
+    assert n_text >= 1 and n_text + n_no_block == 12
