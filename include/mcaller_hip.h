@@ -294,8 +294,8 @@ int mc_fetch_records_view(mc_ctx *ctx, mc_calls_view *out);
  * pass with its own counters, strand-resolve output and record set -- and copied out (one DMA transfer: the narrow columns
  * of the n records, then slot means and probabilities of the records that are calls, see mc_calls_view.call_row) when it
  * is waited for, beside the kernels of the passes behind it; no host round trip sits inside a pass.  At
- * most four passes are in flight (one being copied out, one computing, two queued).  mc_wait_records hands out the
- * OLDEST pass and returns a view of the context's pinned buffers (valid until four more passes have been enqueued).  A
+ * most six passes are in flight (one being copied out, one in the side stream's kernels, one computing, the others queued).  mc_wait_records hands out the
+ * OLDEST pass and returns a view of the context's pinned buffers (valid until six more passes have been enqueued).  A
  * pass that needs more than the fast path (irregular reads, record buffers too small) is re-run synchronously inside
  * mc_wait_records -- results are the same, only slower.  Either classifier (MLP: k2_mlp, forest: k3_forest) runs on the side
  * stream behind the pass's emit. */

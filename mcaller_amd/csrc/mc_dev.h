@@ -501,9 +501,9 @@ void mc_launch_extend(const DevTable &T, NbDesc *desc, const int64_t *nb_f0, int
 void mc_launch_summarize(const DevTable &T, hipStream_t st);
 void mc_launch_scan(const K1Args &A, bool dense, int scan_mode, hipStream_t st);
 void mc_launch_group_scan(const int32_t *cnt, int64_t n, int32_t *local, int64_t *group_sum, hipStream_t st);
-void mc_launch_list(const K1Args &A, Payload *sorted, int gather, hipStream_t st);
+void mc_launch_list(const K1Args &A, Payload *sorted, int gather, hipStream_t st, hipEvent_t stop = nullptr);
 int mc_emit_occupancy(void);            // resident k1_emit workgroups per CU (occupancy query)
-void mc_launch_emit(const K1Args &A, const Payload *sorted, unsigned grid, hipStream_t st, hipEvent_t stop);
+void mc_launch_emit(const K1Args &A, const Payload *sorted, unsigned grid, hipStream_t st, hipEvent_t stop, hipEvent_t start = nullptr);
 void mc_launch_emit_runs(const K1Args &A, Payload *sorted, hipStream_t st, hipEvent_t stop);
 // the fused pass of a dense reference (mc_fused.hip): room per piece, pieces of a table, the launch
 int mc_fused_room(double density);

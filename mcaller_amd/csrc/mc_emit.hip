@@ -749,8 +749,8 @@ int mc_emit_occupancy(void) {
 
 // (`stop` rides on the emit's own dispatch packet: a hipEventRecord behind it is a barrier packet of its own and costs the
 // queue 5-9 us)
-void mc_launch_emit(const K1Args &A, const Payload *sorted, unsigned grid, hipStream_t st, hipEvent_t stop) {
-    if (stop) hipExtLaunchKernelGGL(k1_emit, dim3(grid), dim3(256), 0, st, nullptr, stop, 0, A, sorted);
+void mc_launch_emit(const K1Args &A, const Payload *sorted, unsigned grid, hipStream_t st, hipEvent_t stop, hipEvent_t start) {
+    if (stop) hipExtLaunchKernelGGL(k1_emit, dim3(grid), dim3(256), 0, st, start, stop, 0, A, sorted);
     else hipLaunchKernelGGL(k1_emit, dim3(grid), dim3(256), 0, st, A, sorted);
 }
 

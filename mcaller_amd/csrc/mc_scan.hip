@@ -943,6 +943,8 @@ void mc_launch_group_scan(const int32_t *cnt, int64_t n, int32_t *local, int64_t
     hipLaunchKernelGGL(k1_group_scan, dim3((unsigned)((n + GROUP - 1) / GROUP)), dim3(GROUP), 0, st, cnt, n, local, group_sum);
 }
 
-void mc_launch_list(const K1Args &A, Payload *sorted, int gather, hipStream_t st) {
-    hipLaunchKernelGGL(k1_list, dim3((unsigned)((A.T.n_tiles * 8 + 255) / 256)), dim3(256), 0, st, A, sorted, gather);
+void mc_launch_list(const K1Args &A, Payload *sorted, int gather, hipStream_t st, hipEvent_t stop) {
+    const dim3 grid((unsigned)((A.T.n_tiles * 8 + 255) / 256));
+    if (stop) hipExtLaunchKernelGGL(k1_list, grid, dim3(256), 0, st, nullptr, stop, 0, A, sorted, gather);
+    else hipLaunchKernelGGL(k1_list, grid, dim3(256), 0, st, A, sorted, gather);
 }

@@ -30,6 +30,7 @@
 //                k1_group_scan / k1_list   file order of the windows; payloads gathered into it
 //                k1_emit         eight lanes per window: which of the rows before its last row belong to which slot, slot
 //                                means in NumPy pairwise order (fp64) from the rows' (event, model) pairs -> one flush record
+//                                (a pipelined pass: on the side stream, in front of the pass's classifier and packing)
 //                k1_fused        a dense reference (a one-base motif), pipelined passes: scan, ordering and emit as one kernel,
 //                                fixed room per 960-row piece (mc_fused.hip)
 //                k2_mlp          batched 7-H-1 tanh/logistic forward: one lane per record, weights as scalar operands, a quarter
@@ -56,7 +57,12 @@
 // ===================================================================================================
 // host side
 // ===================================================================================================
-constexpr int MC_PASSES_IN_FLIGHT = 4;   // one being copied out, one computing, two queued (the host enqueues while it copies)
+#ifndef MC_PASSES_IN_FLIGHT_N
+#define MC_PASSES_IN_FLIGHT_N 6
+#endif
+// one being copied out, one in the side stream's kernels, one computing, two or three queued: a pass is 0.6-0.7 ms from its strand resolve
+// to its records in host memory, and the ctx stream takes a new one every 0.21 ms (four in flight left it waiting for the host)
+constexpr int MC_PASSES_IN_FLIGHT = MC_PASSES_IN_FLIGHT_N;
 constexpr int MC_ROW_TEXT_BLOCKS = 6;    // pinned blocks the rows of text leave in (mc_rowtext.hip): a pass's stays taken until the host has written it
 
 // What K0 writes and K1 reads, per pass in flight
@@ -246,6 +252,9 @@ struct mc_ctx {
         int want_text = 0;         // the rows as text, made on the device (mc_ctx_row_text was on when the pass was enqueued)
         int text_block = -1;       // ... the pinned block they are on their way to (mc_wait_records_begin), -1: none
         hipEvent_t ev_text = nullptr;
+        hipEvent_t ev_list_end = nullptr;   // the pass's payloads are in file order (k1_list): what its emit, on the side stream, waits for
+        hipEvent_t ev_emit_start = nullptr; // ... and when that emit began (a timed pass: its own time, not the wait for the side stream's turn)
+        bool emit_aside = false;
         int fused_room = 0;        // > 0: the pass ran as ONE kernel (k1_fused) with this many record slots per piece -- holes in between
         int64_t slots = 0;         // ... record slots in all
         int slot = -1;             // table slot the pass scans
@@ -468,7 +477,7 @@ extern "C" void mc_ctx_destroy(mc_ctx *c) {
     }
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     for (auto &b : c->ab)
-        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied, b.ev_text})
+        for (hipEvent_t e : {b.ev_k0_start, b.ev_k0_end, b.ev_scan_start, b.ev_scan_end, b.ev_emit_end, b.ev_k2_start, b.ev_k2_end, b.ev_done, b.ev_copied, b.ev_text, b.ev_list_end, b.ev_emit_start})
             if (e) (void)hipEventDestroy(e);
     mc_comm_destroy(c);
     for (auto &ev : c->ev) (void)hipEventDestroy(ev);
@@ -1536,8 +1545,10 @@ static int enqueue_k0(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
 static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters *cnt, const DevRecords &O, hipStream_t st,
                       hipEvent_t ev_scan_end, K1Args *out_args, Payload *sorted, int64_t *rare_list, unsigned long long pass_no,
                       const PassPlan &plan, hipEvent_t ev_emit_end = nullptr, unsigned long long *chunk_cnt = nullptr, int fused_room = 0,
-                      int32_t *piece_cnt = nullptr, int32_t *piece_kw = nullptr) {
+                      int32_t *piece_cnt = nullptr, int32_t *piece_kw = nullptr, hipStream_t emit_st = nullptr, hipEvent_t ev_list_end = nullptr,
+                      hipEvent_t ev_emit_start = nullptr, bool *emit_went_aside = nullptr) {
     const DevTable &T = c->T;
+    if (emit_went_aside) *emit_went_aside = false;
     K1Args A;
     A.T = T; A.R = c->R; A.desc = K.desc; A.tile_chunk = c->tile_chunk; A.payload = c->payload;
     A.payload_cap = c->payload_cap; A.tile_cnt = c->tile_cnt; A.tile_half = c->tile_half;
@@ -1572,14 +1583,25 @@ static int enqueue_k1(mc_ctx *c, const mc_params *prm, const K0Set &K, Counters 
     mc_launch_group_scan(c->tile_cnt, T.n_tiles, c->tile_local, c->group_sum, st);
     // (dense references: a workgroup per piece, the mean of every position once, see k1_emit_runs -- which takes the payloads where
     // the scan left them: no gather)
-    mc_launch_list(A, sorted, runs ? 0 : 1, st);
+    // The eight-lane emit of a pipelined pass goes to the SIDE stream, in front of the pass's classifier and packing: it reads nothing but
+    // the pass's own buffers (its sorted payloads, descriptors, records, counters) and the table, is bound by latency (three dependent
+    // round trips: 39 us with a few thousand waves), and on the ctx stream the next pass's strand resolve and scan waited behind it
+    const bool emit_aside = emit_st != nullptr && ev_list_end != nullptr && !runs;
+    mc_launch_list(A, sorted, runs ? 0 : 1, st, (emit_aside && MC_EVENTS_ON_KERNELS) ? ev_list_end : nullptr);
     // (ev_emit_end rides on the emit's own dispatch packet: a hipEventRecord behind it is a barrier packet of its own and
     // costs the queue 5-9 us)
     const unsigned emit_grid = (unsigned)std::min<int64_t>((O.capacity * EG + 255) / 256, (int64_t)c->n_cu * c->emit_wgs);
     hipEvent_t on_packet = (ev_emit_end && MC_EVENTS_ON_KERNELS) ? ev_emit_end : nullptr;
+    hipStream_t est = st;
+    if (emit_aside) {
+        if (!MC_EVENTS_ON_KERNELS) HIP_TRY(hipEventRecord(ev_list_end, st));
+        HIP_TRY(hipStreamWaitEvent(emit_st, ev_list_end, 0));
+        est = emit_st;
+    }
+    if (emit_went_aside) *emit_went_aside = emit_aside;
     if (runs) mc_launch_emit_runs(A, sorted, st, on_packet);
-    else mc_launch_emit(A, sorted, emit_grid, st, on_packet);
-    if (ev_emit_end && !on_packet) HIP_TRY(hipEventRecord(ev_emit_end, st));
+    else mc_launch_emit(A, sorted, emit_grid, est, on_packet, (emit_aside && on_packet) ? ev_emit_start : nullptr);
+    if (ev_emit_end && !on_packet) HIP_TRY(hipEventRecord(ev_emit_end, est));
     *out_args = A;
     return 0;
 }
@@ -1765,7 +1787,7 @@ static int ensure_async_buf(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t cap, int k, 
         // it a record costs the queue ~5 us instead of ~9; the two the host waits for before it reads pinned memory (ev_done,
         // ev_copied) keep the default
         const unsigned dev_flags = hipEventDisableSystemFence;
-        for (hipEvent_t *e : {&b.ev_k0_start, &b.ev_k0_end, &b.ev_scan_start, &b.ev_scan_end, &b.ev_emit_end, &b.ev_k2_start, &b.ev_k2_end})
+        for (hipEvent_t *e : {&b.ev_k0_start, &b.ev_k0_end, &b.ev_scan_start, &b.ev_scan_end, &b.ev_emit_end, &b.ev_k2_start, &b.ev_k2_end, &b.ev_list_end, &b.ev_emit_start})
             HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
         for (hipEvent_t *e : {&b.ev_done, &b.ev_copied, &b.ev_text})
             HIP_TRY(hipEventCreate(e));
@@ -1906,10 +1928,16 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     if (fused_room > 0 && mc_fused_pieces(T) > b.piece_cap) { b.fused_room = 0; b.slots = 0; }     // (room forced very small: more pieces than counts)
     for (auto &other : c->ab)               // all record sets at once: no (pinned) allocation later, in the middle of a stream
         if (!other.used && (other.cap < cap || other.n_nb < T.n_nb || other.pack_bytes < b.pack_bytes)) { if (int rc = ensure_async_buf(c, other, cap, k, pack_rec)) return rc; }
-    // K0 (strand resolve) and K1 (scan, ordering, emit) of a pass on the ctx stream, back to back with the next pass: nothing
-    // on the scan's path waits for another queue.  K2 (classifier) and the packing on the side stream, behind the pass's
-    // emit: they run beside K0 of the next pass (small latency-bound kernels) and the first microseconds of its scan.
-    // Measured on the 10^8-row table (rocprofv3 timelines), passes per second relative to this layout:
+    // K0 (strand resolve), the scan and the ordering of a pass on the ctx stream, back to back with the next pass: nothing on the
+    // scan's path waits for another queue.  The eight-lane EMIT of a sparse reference, K2 (classifier) and the packing on the side
+    // stream, behind the pass's ordering (an event on k1_list's dispatch packet): three dependent round trips with a few thousand
+    // waves, 39 us during which the next pass's strand resolve and scan stood in the queue behind it -- beside the scan it takes 70-120
+    // us and nobody waits for it.  The ctx stream takes a new pass every 0.21 ms then, and a pass is 0.6-0.7 ms from its strand
+    // resolve to its records in host memory: with four passes in flight at most the ctx stream ran dry every second pass waiting for
+    // the host (the emit on the side stream: 0.264 against 0.262 ms per pass); with six at most, four or five kept in flight: 0.242.
+    // (The fused kernel of a dense reference and the run-table emit stay where they are: the one is the scan, the other reads the
+    // scan's shared scratch.)
+    // Measured earlier on the 10^8-row table (rocprofv3 timelines), passes per second relative to the layout with the emit on the ctx stream:
     // K0 on the side stream beside K2 on the ctx stream -3 % (two cross-queue hand-overs of 15-25 us on the scan's path);
     // K2 + packing deferred so that they run beside the next SCAN: the same (K2 gets one wave per SIMD there and takes 195 us
     // instead of 68); separate streams for K0 and K2: they land on one hardware queue and serialise; low-priority side
@@ -1933,7 +1961,9 @@ extern "C" int mc_extract_features_async(mc_ctx *c, const mc_params *prm) {
     K1Args A;
     // (no event between the scan and the ordering kernels here: a record costs the queue ~5 us; the feature extraction is timed
     // as one span, the split into scan and emit comes from mc_extract_features or from rocprofv3)
-    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt, b.piece_kw)) return rc;
+    static const bool emit_aside = !(getenv("MCALLER_EMIT_ON_SIDE") && atoi(getenv("MCALLER_EMIT_ON_SIDE")) == 0);      // (=0: the emit stays on the ctx stream)
+    if (int rc = enqueue_k1(c, prm, b.K, b.cnt, b.O, st, nullptr, &A, b.sorted, b.rare, b.pass_no, plan, b.ev_emit_end, b.chunk_cnt, b.fused_room, b.piece_cnt, b.piece_kw,
+                            emit_aside ? c->side_stream : nullptr, b.ev_list_end, b.timed ? b.ev_emit_start : nullptr, &b.emit_aside)) return rc;
     b.close32 = T.n_rows < INT32_MAX;           // (a closing row can be n_rows itself: the next shard's first row)
     b.want_text = c->rt.on;
     b.text_block = -1;
@@ -2183,8 +2213,14 @@ extern "C" int mc_wait_records(mc_ctx *c, int64_t *n_records, mc_calls_view *out
     if (b.used && b.timed) {
         float t_k0 = 0, t_scan = 0, t_emit = 0, t_k2 = 0;
         HIP_TRY(hipEventElapsedTime(&t_k0, b.ev_k0_start, b.ev_scan_start));
-        HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_emit_end));     // scan + ordering + emit, one span
-        t_emit = 0.0f;
+        if (b.emit_aside && MC_EVENTS_ON_KERNELS) {
+            // (the emit ran on the side stream: the ctx stream's span ends with the ordering, the emit's own time beside it)
+            HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_list_end));
+            HIP_TRY(hipEventElapsedTime(&t_emit, b.ev_emit_start, b.ev_emit_end));
+        } else {
+            HIP_TRY(hipEventElapsedTime(&t_scan, b.ev_scan_start, b.ev_emit_end));     // scan + ordering + emit, one span
+            t_emit = 0.0f;
+        }
         HIP_TRY(hipEventElapsedTime(&t_k2, b.ev_k2_start, b.one_kernel ? b.ev_done : b.ev_k2_end));
         c->times[0] = t_k0; c->times[1] = t_scan; c->times[2] = t_emit; c->times[3] = t_k2;
         c->times[4] = t_k0 + t_scan + t_emit + t_k2;

@@ -248,7 +248,7 @@ class Device(object):
 
     @_serialized
     def run_async(self, k, skip_thresh, qual_thresh, tail_contig=-1, score=True, entry_read=-1, entry_first_idx=0):
-        """Enqueue one pass (K0 + K1 on the ctx stream, K2 + packing on a side stream); at most four in flight."""
+        """Enqueue one pass (K0 + K1 on the ctx stream, the emit, K2 + packing on a side stream); at most six in flight."""
         p = Params(int(k), int(skip_thresh), float(qual_thresh), int(tail_contig), 1 if score else 0,
                    int(entry_read), int(entry_first_idx))
         check(lib().mc_extract_features_async(self._ctx, C.byref(p)))
@@ -262,7 +262,7 @@ class Device(object):
     @_serialized
     def wait(self):
         """Records of the oldest pass in flight: views of pinned buffers (slot means / probabilities of the calls only, see
-        Records.call_row), valid until four more passes have been enqueued."""
+        Records.call_row), valid until six more passes have been enqueued."""
         n, v = C.c_int64(0), _lib.CallsView()
         check(lib().mc_wait_records(self._ctx, C.byref(n), C.byref(v)))
         k = self._async_k.pop(0)

@@ -662,7 +662,7 @@ def stream_features(tsv_input, fasta_input, read2qual, k, skip_thresh, qual_thre
     # on the order of the shards (names across the cuts, the rows handed to the writer, the totals) is done by every shard in its turn.
     # Not in train mode (the per-record transcription holds the interpreter lock) and not when every shard's records are reduced on
     # the device (on_shard needs what the formatter found).  The helpers are at most two shards behind: the records they read stay
-    # where they are until four more passes have been enqueued.
+    # where they are until six more passes have been enqueued.
     overlap = not train and on_shard is None and not os.environ.get('MCALLER_NO_OVERLAP')
     # ... and the rows themselves are written on the GPU, behind the records they are made from (mc_rowtext.hip), when the shard's
     # table is one the device parser made: what is left for the helpers is the counters and the write.  MCALLER_DEVICE_ROWS=0: the
