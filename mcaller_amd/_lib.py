@@ -533,8 +533,8 @@ class RowText(object):
     """The rows of a pass as the device wrote them (mc_last_row_text): `view` is a memoryview over the pinned block, `n_rows` the
     rows in it; release() (or the end of this object) gives the block back to the context -- the text must have been written by then."""
 
-    def __init__(self, ctx, ptr, n_bytes, n_rows, block):
-        self._ctx, self._block = ctx, int(block)
+    def __init__(self, device, ptr, n_bytes, n_rows, block):
+        self._dev, self._block = device, int(block)        # (the Device, not its context: a block outlives neither)
         self.n, self.n_rows = int(n_bytes), int(n_rows)
         self.view = memoryview((C.c_char * self.n).from_address(ptr)).cast('B') if self.n else memoryview(b'')
 
@@ -550,7 +550,7 @@ class RowText(object):
             self.view.release()
             self.view = memoryview(b'')
             self.n = 0
-            lib().mc_row_text_release(self._ctx, block)
+            self._dev._row_text_release(block)
 
     def __del__(self):
         try:

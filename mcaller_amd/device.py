@@ -41,9 +41,16 @@ class Device(object):
         return int(lib().mc_bind_to_device_numa_node(int(device)))
 
     def close(self):
-        if self._ctx:
-            lib().mc_ctx_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        with self._lock:
+            if self._ctx:
+                lib().mc_ctx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+
+    def _row_text_release(self, block):
+        """A RowText gives its pinned block back (any thread; nothing to do once the context is gone)."""
+        with self._lock:
+            if self._ctx:
+                lib().mc_row_text_release(self._ctx, int(block))
 
     def __del__(self):
         try:
@@ -282,7 +289,7 @@ class Device(object):
         text, nb, nr, block = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int32(-1)
         check(lib().mc_last_row_text(self._ctx, C.byref(text), C.byref(nb), C.byref(nr), C.byref(block)))
         if block.value >= 0:                 # the rows as text, made on the device (row_text): the host formatter has nothing to do
-            rec.row_text = _lib.RowText(self._ctx, text.value, nb.value, nr.value, block.value)
+            rec.row_text = _lib.RowText(self, text.value, nb.value, nr.value, block.value)
         return rec
 
     @_serialized
