@@ -274,7 +274,8 @@ int mc_last_pass_info(mc_ctx *ctx, int32_t *fused_room, int32_t *rerun);
  * records where they are -- the packed records, the read names in the shard's text (tables the device parser made:
  * mc_ctx_parse_begin .. _finish), the contig names, the marked reference, shortest round-trip digits in integer arithmetic
  * (mc_rowtext.h) -- and send the text to pinned host memory behind the records.  After mc_wait_records, mc_last_row_text says
- * where: *text / *n_bytes / *n_rows, and *block >= 0, which the caller gives back with mc_row_text_release (any thread) once it
+ * where: *text / *n_bytes / *n_rows, and *block >= 0 -- a handle (the block and the ticket it was taken with: one that is given back twice, or
+ * after a later stream began, frees nothing) --, which the caller gives back with mc_row_text_release (any thread) once it
  * has written the rows; *block < 0: this pass has none (not asked for, another kind of table, no free block, or a record the
  * device does not print -- a context that leaves the contig, an unknown sub-model key, an unscored record, a number outside
  * [1e-29, 1e9): the reference's exit paths and the host formatter's general cases) and mc_format_diffs makes the rows as before. */

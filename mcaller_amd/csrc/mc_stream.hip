@@ -64,6 +64,7 @@
 // to its records in host memory, and the ctx stream takes a new one every 0.21 ms (four in flight left it waiting for the host)
 constexpr int MC_PASSES_IN_FLIGHT = MC_PASSES_IN_FLIGHT_N;
 constexpr int MC_ROW_TEXT_BLOCKS = 6;    // pinned blocks the rows of text leave in (mc_rowtext.hip): a pass's stays taken until the host has written it
+static_assert(MC_ROW_TEXT_BLOCKS <= 8, "a block's handle is ticket * 8 + index");
 
 // What K0 writes and K1 reads, per pass in flight
 struct K0Set {
@@ -281,8 +282,9 @@ struct mc_ctx {
             char *p = nullptr, *p_dev = nullptr;
             size_t cap = 0;
             RowTextStatus *st = nullptr, *st_dev = nullptr;
-            std::atomic<int> busy{0};
+            std::atomic<int> busy{0};          // 0: free; else the ticket of the pass whose rows it holds (what mc_row_text_release must name)
         } blocks[MC_ROW_TEXT_BLOCKS];
+        int next_ticket = 0;
         long long n_text = 0, n_no_block = 0, n_host_needed = 0, n_too_small = 0, n_other = 0;     // passes, by what became of their rows (MCALLER_VERBOSE)
         // the pass handed out last
         int last_block = -1;
@@ -2016,7 +2018,7 @@ static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m
     int at = -1;
     static const int n_blocks = getenv("MCALLER_ROW_TEXT_BLOCKS") ? std::max(0, std::min(MC_ROW_TEXT_BLOCKS, atoi(getenv("MCALLER_ROW_TEXT_BLOCKS")))) : MC_ROW_TEXT_BLOCKS;   // (tests: none free)
     for (int i = 0; i < n_blocks; ++i)
-        if (!R.blocks[i].busy.load() && (at < 0 || (R.blocks[at].cap < need && R.blocks[i].cap >= need))) at = i;
+        if (R.blocks[i].busy.load() == 0 && (at < 0 || (R.blocks[at].cap < need && R.blocks[i].cap >= need))) at = i;
     if (at < 0) { R.n_no_block += 1; return 0; }
     auto &blk = R.blocks[at];
     if (blk.cap < need) {
@@ -2074,7 +2076,8 @@ static int enqueue_row_text(mc_ctx *c, mc_ctx::AsyncBuf &b, int64_t n, int64_t m
     mc_launch_row_text(I, R.S, R.out, R.room_forced ? std::min(need, std::min(R.out_cap, blk.cap)) : std::min(R.out_cap, blk.cap), blk.p_dev, blk.st_dev, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b.ev_text, st));
-    blk.busy.store(1);
+    R.next_ticket = R.next_ticket >= (1 << 24) ? 1 : R.next_ticket + 1;
+    blk.busy.store(R.next_ticket);
     b.text_block = at;
     return 0;
 }
@@ -2271,9 +2274,11 @@ extern "C" int mc_ctx_row_text(mc_ctx *c, int32_t on, const char *label_meth, co
     return 0;
 }
 
+// (*block: the block's index and the ticket it was taken with -- a handle that has been given back, or that a later stream's first
+// mc_ctx_row_text(2) declared void, frees nothing when it is given back again)
 extern "C" int mc_last_row_text(mc_ctx *c, const char **text, int64_t *n_bytes, int64_t *n_rows, int32_t *block) {
     const auto &R = c->rt;
-    *block = R.last_block;
+    *block = R.last_block >= 0 ? R.blocks[R.last_block].busy.load() * 8 + R.last_block : -1;
     *text = R.last_block >= 0 ? R.blocks[R.last_block].p : nullptr;
     *n_bytes = R.last_block >= 0 ? R.last_bytes : 0;
     *n_rows = R.last_block >= 0 ? R.last_rows : 0;
@@ -2282,11 +2287,12 @@ extern "C" int mc_last_row_text(mc_ctx *c, const char **text, int64_t *n_bytes, 
 
 // (any thread: the host's writer gives a block back when the rows are in the file)
 extern "C" int mc_row_text_release(mc_ctx *c, int32_t block) {
-    if (block < 0 || block >= MC_ROW_TEXT_BLOCKS) {
+    if (block < 0 || (block & 7) >= MC_ROW_TEXT_BLOCKS) {
         mc_set_error("mc_row_text_release: no such block (%d)", block);
         return -12;
     }
-    c->rt.blocks[block].busy.store(0);
+    int ticket = block >> 3;
+    if (ticket > 0) (void)c->rt.blocks[block & 7].busy.compare_exchange_strong(ticket, 0);     // (a stale handle: the block is somebody else's by now)
     return 0;
 }
 
