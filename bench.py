@@ -589,9 +589,10 @@ def main():
     # A step = one FULL pass of the hot path over a resident table -- what a table costs when it is scanned once: the table is
     # declared new (nothing an earlier pass learned is used), the scan streams positions and event indices and validates every
     # row; records (slot means, sites, probabilities) land in pinned host memory.  The two tables are taken in turn.  Passes
-    # are pipelined (the library's streaming interface, mc_extract_features_async / mc_wait_records): K0 + K1 of consecutive
-    # passes back to back on one stream, K2 + packing on a side stream, copy-outs back to back on a third, four passes in
-    # flight at most; every pass's records are complete in host memory before the timed region ends.
+    # are pipelined (the library's streaming interface, mc_extract_features_async / mc_wait_records): strand resolve, scan and
+    # ordering of consecutive passes back to back on one stream; the emit, K2 + packing on a side stream beside the next pass's
+    # scan; copy-outs back to back on a third; --depth passes kept in flight (default four, the library allows six); every
+    # pass's records are complete in host memory before the timed region ends.
     # --no-pipeline times mc_extract_features instead (one pass at a time, host sync inside).
     step_no = [0]
 
